@@ -1,0 +1,171 @@
+"""Pin the oracle: analytic known-answer tests, numpy-vs-torch backend agreement,
+independent torch library cross-checks."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import np_ops as N
+from oracle import torch_ops as T
+
+rng = np.random.default_rng(0)
+
+
+def r(*shape):
+    return rng.standard_normal(shape)
+
+
+def test_same_pad_asymmetric():
+    # even size, stride 2, k=3: out=4, total=1 -> before 0, after 1 (extra bottom/right)
+    assert N.same_pad(8, 3, 2) == (4, 0, 1)
+    assert N.same_pad(7, 3, 2) == (4, 1, 1)
+    assert N.same_pad(5, 3, 1) == (5, 1, 1)
+    assert N.same_pad(16, 9, 2) == (8, 3, 4)
+
+
+def test_conv2d_delta_kernel_identity_and_shift():
+    x = r(2, 6, 7, 3)
+    w = np.zeros((3, 3, 3, 3))
+    for c in range(3):
+        w[1, 1, c, c] = 1.0
+    np.testing.assert_allclose(N.conv2d(x, w), x)
+    w = np.zeros((3, 3, 3, 3))
+    for c in range(3):
+        w[0, 2, c, c] = 1.0        # y[h,w] = x[h-1, w+1]
+    y = N.conv2d(x, w)
+    np.testing.assert_allclose(y[:, 1:, :-1], x[:, :-1, 1:])
+    assert np.all(y[:, 0] == 0) and np.all(y[:, :, -1] == 0)
+
+
+@pytest.mark.parametrize('k,stride,hw', [(3, 1, (9, 8)), (1, 1, (5, 6)), (5, 1, (7, 9)),
+                                         (3, 2, (8, 8)), (3, 2, (7, 9))])
+def test_conv2d_np_vs_torch(k, stride, hw):
+    x = r(2, hw[0], hw[1], 5)
+    w = r(k, k, 5, 4)
+    b = r(4)
+    a = N.conv2d(x, w, b, stride=stride)
+    t = T.to_numpy(T.conv2d(T.asarray(x), T.asarray(w), T.asarray(b), stride=stride))
+    np.testing.assert_allclose(a, t, rtol=1e-10, atol=1e-10)
+    av = N.conv2d(x, w, b, stride=stride, padding='valid')
+    tv = T.to_numpy(T.conv2d(T.asarray(x), T.asarray(w), T.asarray(b), stride=stride, padding='valid'))
+    np.testing.assert_allclose(av, tv, rtol=1e-10, atol=1e-10)
+
+
+def test_conv2d_5d_folds_batch():
+    x = r(2, 3, 5, 6, 4)
+    w = r(3, 3, 4, 2)
+    y = N.conv2d(x, w)
+    for t in range(3):
+        np.testing.assert_allclose(y[:, t], N.conv2d(x[:, t], w))
+
+
+@pytest.mark.parametrize('stride', [2, 4])
+def test_conv_transpose_is_adjoint_of_same_strided_conv(stride):
+    # <conv_s(y), x> == <y, convT_s(x)>  with the SAME weights (HWOI <-> HWIO transpose)
+    k, ci, co = 9, 3, 2
+    x = r(2, 5, 6, ci)                    # lives on the small grid
+    y = r(2, 5 * stride, 6 * stride, co)  # lives on the big grid
+    w_t = r(k, k, co, ci)                 # HWOI for the transposed conv (maps ci -> co)
+    up = N.conv2d_transpose(x, w_t, stride)
+    assert up.shape == y.shape
+    # forward conv big->small uses kernel HWIO with in=co, out=ci: w_t itself is (k,k,co,ci)
+    down = N.conv2d(y, w_t, None, stride=stride)
+    np.testing.assert_allclose((up * y).sum(), (down * x).sum(), rtol=1e-10)
+    tt = T.to_numpy(T.conv2d_transpose(T.asarray(x), T.asarray(w_t), stride))
+    np.testing.assert_allclose(up, tt, rtol=1e-10, atol=1e-10)
+
+
+def test_depth_to_space_formula_and_not_pixel_shuffle():
+    n, h, w, r_, cp = 2, 3, 4, 2, 3
+    x = np.arange(n * h * w * r_ * r_ * cp, dtype=np.float64).reshape(n, h, w, r_ * r_ * cp)
+    y = N.depth_to_space(x, r_)
+    for i in range(r_):
+        for j in range(r_):
+            for c in range(cp):
+                np.testing.assert_array_equal(y[:, i::r_, j::r_, c], x[..., (i * r_ + j) * cp + c])
+    t = T.to_numpy(T.depth_to_space(T.asarray(x), r_))
+    np.testing.assert_array_equal(y, t)
+    # torch pixel_shuffle uses the CRD order -> must differ for cp>1
+    ps = F.pixel_shuffle(torch.from_numpy(x).permute(0, 3, 1, 2), r_).permute(0, 2, 3, 1).numpy()
+    assert not np.array_equal(ps, y)
+
+
+def test_resize_bilinear_ramp_and_library():
+    x = np.tile(np.arange(8, dtype=np.float64)[None, None, :, None], (1, 6, 1, 2))
+    y = N.resize_bilinear(x, 24, 32)
+    # interior of a linear ramp is reproduced exactly: value = (ox+0.5)/4-0.5
+    ox = np.arange(32)
+    expect = np.clip((ox + 0.5) / 4 - 0.5, 0, 7)
+    np.testing.assert_allclose(y[0, 5, :, 0], expect, atol=1e-12)
+    z = r(2, 5, 7, 3)
+    a = N.resize_bilinear(z, 20, 28)
+    t = T.to_numpy(T.resize_bilinear(T.asarray(z), 20, 28))
+    lib = F.interpolate(torch.from_numpy(z).permute(0, 3, 1, 2), size=(20, 28), mode='bilinear',
+                        align_corners=False).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(a, t, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a, lib, rtol=1e-10, atol=1e-10)
+
+
+def test_maxpool_lcb_attention_backends():
+    x = r(2, 7, 6, 4)
+    np.testing.assert_array_equal(N.max_pool2(x), T.to_numpy(T.max_pool2(T.asarray(x))))
+    assert N.max_pool2(x).shape == (2, 3, 3, 4)
+    w, b = r(7, 6, 4, 2), r(7, 6, 2)
+    np.testing.assert_allclose(N.locally_connected_1x1(x, w, b),
+                               T.to_numpy(T.locally_connected_1x1(T.asarray(x), T.asarray(w), T.asarray(b))),
+                               rtol=1e-12)
+    w1, b1, w2, b2 = r(1, 1, 4, 1), r(1), r(1, 1, 1, 4), r(4)
+    a = N.channel_attention(x, w1, b1, w2, b2)
+    t = T.to_numpy(T.channel_attention(*(T.asarray(v) for v in (x, w1, b1, w2, b2))))
+    np.testing.assert_allclose(a, t, rtol=1e-12)
+    # zero weights: scale = sigmoid(b2)
+    a0 = N.channel_attention(x, w1 * 0, b1, w2 * 0, b2 * 0)
+    np.testing.assert_allclose(a0, 0.5 * x)
+
+
+def test_conv_lstm_backends_and_first_step():
+    x = r(2, 3, 5, 6, 2)
+    f = 3
+    K, U, b = r(3, 3, 2, 4 * f) * 0.3, r(3, 3, f, 4 * f) * 0.3, r(4 * f) * 0.1
+    a = N.conv_lstm2d(x, K, U, b)
+    t = T.to_numpy(T.conv_lstm2d(*(T.asarray(v) for v in (x, K, U, b))))
+    np.testing.assert_allclose(a, t, rtol=1e-10, atol=1e-12)
+    # t=0: h0=c0=0 -> c1 = i*tanh(zc), h1 = o*tanh(c1)
+    z = N.conv2d(x[:, 0], K, b)
+    c1 = N.hard_sigmoid(z[..., :f]) * np.tanh(z[..., 2 * f:3 * f])
+    h1 = N.hard_sigmoid(z[..., 3 * f:]) * np.tanh(c1)
+    np.testing.assert_allclose(a[:, 0], h1, rtol=1e-12)
+
+
+def test_losses_known_answers():
+    y = rng.random((2, 16, 17, 1))
+    assert N.dssim(y, y) == pytest.approx(0.0, abs=1e-12)
+    assert N.mae(y, y + 0.25) == pytest.approx(0.25)
+    assert N.mse(y, y - 0.5) == pytest.approx(0.25)
+    assert N.bce(np.ones((3, 1)), np.full((3, 1), 0.5)) == pytest.approx(np.log(2.0))
+    p = rng.random((2, 16, 17, 1)) - 0.3        # negative minimum -> shift branch
+    for fn in ('dssim', 'dssim_mae', 'dssim_mse', 'dssim_mae_mse', 'mae', 'mse'):
+        a = getattr(N, fn)(y, p)
+        t = float(getattr(T, fn)(T.asarray(y), T.asarray(p)))
+        assert a == pytest.approx(t, rel=1e-10), fn
+    g = N._gauss_kernel()
+    assert g.shape == (11, 11) and g.sum() == pytest.approx(1.0)
+    assert g[5, 5] == g.max()
+
+
+def test_adam_first_step_is_lr_sign():
+    w = r(10)
+    g = np.sign(r(10)) * (0.5 + rng.random(10))   # |g| >> eps
+    w1, m, v = N.adam_step(w, g, np.zeros(10), np.zeros(10), 1, 1e-3)
+    np.testing.assert_allclose(w1, w - 1e-3 * np.sign(g), atol=1e-8)
+    wt, mt, vt = T.adam_step(*(T.asarray(a) for a in (w, g, np.zeros(10), np.zeros(10))), 1, 1e-3)
+    np.testing.assert_allclose(w1, T.to_numpy(wt), rtol=1e-12)
+    assert N.piecewise_lr(100000, 1e5, 1e-3, 1e-4) == 1e-3
+    assert N.piecewise_lr(100001, 1e5, 1e-3, 1e-4) == 1e-4
+
+
+def test_activations_backends():
+    x = r(50)
+    for k in (None, 'relu', 'sigmoid', 'tanh', 'elu', 'leaky_relu', 'selu', 'gelu'):
+        np.testing.assert_allclose(N.activation(x, k), T.to_numpy(T.activation(T.asarray(x), k)),
+                                   rtol=1e-7, atol=1e-12, err_msg=str(k))
