@@ -1,0 +1,201 @@
+// ChannelAttention2D (squeeze-excite, r=4) for gfx950 -- dl4ds/models/blocks.py:537-593:
+//     y = x * sigmoid(W2^T relu(W1^T mean_{axes 1,2}(x) + b1) + b2)
+// The tensor is viewed as [G][R][P*C]: the mean runs over R, the tiny MLP over the last C channels of
+// each of the G*P instances.  4-D (B,H,W,C): G=B, R=H*W, P=1.  5-D (B,T,H,W,C) as the reference reaches
+// it through spt_postups.py:153-154 reduces axes [1,2] = (T,H): G=B, R=T*H, P=W.
+// Kernels: wave/LDS column-sum reduction (HBM-bound, one read of x), one-block MLP forward/backward,
+// broadcast-scale.  Backward needs sum_r(dy*x) -- a second column-sum with a fused product.
+#include "ops.h"
+#include <algorithm>
+
+namespace {
+
+// partial[(g*nb + blockIdx.x)*Q + q] = sum over this block's rows of a[g][r][q] (* b[g][r][q])
+template <int TX>
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ partial, int R, int Q) {
+    constexpr int TY = 256 / TX;
+    __shared__ float red[TY][TX + 1];
+    const int tx = threadIdx.x % TX, tyi = threadIdx.x / TX;
+    const int q = blockIdx.y * TX + tx;
+    const int g = blockIdx.z;
+    const float* ap = a + (size_t)g * R * Q;
+    const float* bp = b ? b + (size_t)g * R * Q : nullptr;
+    float sum = 0.f;
+    if (q < Q) {
+        for (int r = blockIdx.x * TY + tyi; r < R; r += gridDim.x * TY) {
+            float v = ap[(size_t)r * Q + q];
+            if (bp) v *= bp[(size_t)r * Q + q];
+            sum += v;
+        }
+    }
+    red[tyi][tx] = sum;
+    __syncthreads();
+    if (tyi == 0 && q < Q) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < TY; ++k) s += red[k][tx];
+        partial[((size_t)g * gridDim.x + blockIdx.x) * Q + q] = s;
+    }
+}
+
+// out[g*Q+q] = scale * sum_k partial[(g*nb+k)*Q+q]
+__global__ void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int nb, int Q,
+                                     int GQ, float scale) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= GQ) return;
+    const int g = e / Q, q = e - g * Q;
+    float s = 0.f;
+    for (int k = 0; k < nb; ++k) s += partial[((size_t)g * nb + k) * Q + q];
+    out[e] = s * scale;
+}
+
+// one thread per (instance, c)
+__global__ void chatt_mlp_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
+                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                     const float* __restrict__ b2, float* __restrict__ hidden,
+                                     float* __restrict__ scale, int ninst, int C, int Cr) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ninst * C) return;
+    const int inst = e / C, c = e - inst * C;
+    const float* m = mean + (size_t)inst * C;
+    float z = b2[c];
+    for (int j = 0; j < Cr; ++j) {
+        float h = b1[j];
+        for (int k = 0; k < C; ++k) h += m[k] * w1[k * Cr + j];
+        h = fmaxf(h, 0.f);
+        if (c == 0) hidden[(size_t)inst * Cr + j] = h;
+        z += h * w2[j * C + c];
+    }
+    scale[e] = 1.f / (1.f + expf(-z));
+}
+
+__global__ void chatt_scale_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                   float* __restrict__ y, int R, int Q, size_t total) {
+    const size_t RQ = (size_t)R * Q;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = e / RQ;
+        const int q = (int)(e % Q);
+        y[e] = x[e] * scale[g * Q + q];
+    }
+}
+
+// single block: phase A per instance, phase B deterministic parameter-gradient sums
+__global__ void __launch_bounds__(256) chatt_mlp_bwd_kernel(
+    const float* __restrict__ ds, const float* __restrict__ mean, const float* __restrict__ hidden,
+    const float* __restrict__ scale, const float* __restrict__ w1, const float* __restrict__ w2,
+    float* __restrict__ dpre1, float* __restrict__ dpre2, float* __restrict__ dmean, float* __restrict__ dw1,
+    float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2, int ninst, int C, int Cr,
+    float inv_r, int accumulate) {
+    for (int inst = threadIdx.x; inst < ninst; inst += blockDim.x) {
+        const float* s = scale + (size_t)inst * C;
+        const float* h = hidden + (size_t)inst * Cr;
+        float* p2 = dpre2 + (size_t)inst * C;
+        float* p1 = dpre1 + (size_t)inst * Cr;
+        for (int c = 0; c < C; ++c) p2[c] = ds[(size_t)inst * C + c] * s[c] * (1.f - s[c]);
+        for (int j = 0; j < Cr; ++j) {
+            float dh = 0.f;
+            for (int c = 0; c < C; ++c) dh += p2[c] * w2[j * C + c];
+            p1[j] = (h[j] > 0.f) ? dh : 0.f;
+        }
+        for (int c = 0; c < C; ++c) {
+            float dm = 0.f;
+            for (int j = 0; j < Cr; ++j) dm += p1[j] * w1[c * Cr + j];
+            dmean[(size_t)inst * C + c] = dm * inv_r;
+        }
+    }
+    __syncthreads();
+    // dW1[c][j] = sum_inst mean[c]*dpre1[j] ; dW2[j][c] = sum_inst h[j]*dpre2[c]
+    for (int e = threadIdx.x; e < C * Cr; e += blockDim.x) {
+        const int c = e / Cr, j = e - c * Cr;
+        float a1 = 0.f, a2 = 0.f;
+        for (int inst = 0; inst < ninst; ++inst) {
+            a1 += mean[(size_t)inst * C + c] * dpre1[(size_t)inst * Cr + j];
+            a2 += hidden[(size_t)inst * Cr + j] * dpre2[(size_t)inst * C + c];
+        }
+        dw1[c * Cr + j] = accumulate ? dw1[c * Cr + j] + a1 : a1;
+        dw2[j * C + c] = accumulate ? dw2[j * C + c] + a2 : a2;
+    }
+    for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
+        float a = 0.f;
+        for (int inst = 0; inst < ninst; ++inst) a += dpre1[(size_t)inst * Cr + j];
+        db1[j] = accumulate ? db1[j] + a : a;
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f;
+        for (int inst = 0; inst < ninst; ++inst) a += dpre2[(size_t)inst * C + c];
+        db2[c] = accumulate ? db2[c] + a : a;
+    }
+}
+
+__global__ void chatt_dx_kernel(const float* __restrict__ dy, const float* __restrict__ scale,
+                                const float* __restrict__ dmean, float* __restrict__ dx, int R, int Q, size_t total,
+                                int accumulate) {
+    const size_t RQ = (size_t)R * Q;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = e / RQ;
+        const int q = (int)(e % Q);
+        const float v = dy[e] * scale[g * Q + q] + dmean[g * Q + q];
+        dx[e] = accumulate ? dx[e] + v : v;
+    }
+}
+
+int pick_tx(int Q) { return Q <= 8 ? 8 : (Q <= 16 ? 16 : (Q <= 32 ? 32 : 64)); }
+int colsum_blocks(int R, int TY) { return std::max(1, std::min(cdiv(R, TY * 8), 256)); }
+
+void colsum(hipStream_t s, const float* a, const float* b, float* partial, float* out, int G, int R, int Q, float scale) {
+    const int TX = pick_tx(Q), TY = 256 / TX;
+    const int nb = colsum_blocks(R, TY);
+    dim3 grid((unsigned)nb, (unsigned)cdiv(Q, TX), (unsigned)G);
+    switch (TX) {
+        case 8: hipLaunchKernelGGL(colsum_kernel<8>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+        case 16: hipLaunchKernelGGL(colsum_kernel<16>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+        case 32: hipLaunchKernelGGL(colsum_kernel<32>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+        default: hipLaunchKernelGGL(colsum_kernel<64>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+    }
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(G * Q, 256)), dim3(256), 0, s, partial, out, nb, Q, G * Q, scale);
+    HIP_CHECK(hipGetLastError());
+}
+inline int ew_blocks(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 8192)); }
+
+}  // namespace
+
+// workspace layout (floats): [partial: G*256*Q][ds: G*Q][dmean: G*Q][dpre1: G*P*Cr][dpre2: G*P*C]
+size_t chatt_workspace_bytes(const AttShape& sh) {
+    const size_t Q = (size_t)sh.P * sh.C;
+    return ((size_t)sh.G * 256 * Q + 2 * (size_t)sh.G * Q + (size_t)sh.G * sh.P * (sh.Cr + sh.C)) * sizeof(float);
+}
+
+void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, const float* w1, const float* b1,
+                   const float* w2, const float* b2, float* mean, float* hidden, float* scale, float* workspace) {
+    const int Q = sh.P * sh.C;
+    const int ninst = sh.G * sh.P;
+    colsum(s, x, nullptr, workspace, mean, sh.G, sh.R, Q, 1.f / (float)sh.R);
+    hipLaunchKernelGGL(chatt_mlp_fwd_kernel, dim3(cdiv(ninst * sh.C, 256)), dim3(256), 0, s, mean, w1, b1, w2, b2,
+                       hidden, scale, ninst, sh.C, sh.Cr);
+    HIP_CHECK(hipGetLastError());
+    const size_t total = (size_t)sh.G * sh.R * Q;
+    hipLaunchKernelGGL(chatt_scale_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, scale, y, sh.R, Q, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, int accumulate_dx, const AttShape& sh,
+                    const float* w1, const float* w2, const float* mean, const float* hidden, const float* scale,
+                    float* dw1, float* db1, float* dw2, float* db2, int accumulate_dw, float* workspace) {
+    const int Q = sh.P * sh.C;
+    const int ninst = sh.G * sh.P;
+    float* partial = workspace;
+    float* ds = partial + (size_t)sh.G * 256 * Q;
+    float* dmean = ds + (size_t)sh.G * Q;
+    float* dpre1 = dmean + (size_t)sh.G * Q;
+    float* dpre2 = dpre1 + (size_t)ninst * sh.Cr;
+    colsum(s, dy, x, partial, ds, sh.G, sh.R, Q, 1.f);
+    hipLaunchKernelGGL(chatt_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, ds, mean, hidden, scale, w1, w2, dpre1, dpre2,
+                       dmean, dw1, db1, dw2, db2, ninst, sh.C, sh.Cr, 1.f / (float)sh.R, accumulate_dw);
+    HIP_CHECK(hipGetLastError());
+    const size_t total = (size_t)sh.G * sh.R * Q;
+    hipLaunchKernelGGL(chatt_dx_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, scale, dmean, dx, sh.R, Q, total,
+                       accumulate_dx);
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,609 @@
+// extern "C" boundary of libdl4ds_hip.so -- see include/dl4ds_hip.h for the contract of every symbol.
+#include "../../include/dl4ds_hip.h"
+#include "graph.h"
+#include "runtime.h"
+#include "dist.h"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+// ---- internal functions defined in other translation units
+Trainer* trainer_create(Graph* g, int loss_kind, const AdamCfg& cfg);
+void graph_load_inputs(Graph& g, const float* const* inputs, int n_inputs, int B, bool is_host);
+void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host);
+void trainer_step(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host, float* loss_host);
+struct CganTrainer;
+CganTrainer* cgan_create(Graph* gen, Graph* disc, int px_loss_kind, float lr, float beta1, float lam);
+void cgan_destroy(CganTrainer* t);
+void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B, bool is_host,
+               const float* dropout_keep_host, bool apply_update, float* losses_host);
+Trainer* cgan_disc_trainer(CganTrainer* t);
+Trainer* cgan_gen_trainer(CganTrainer* t);
+
+namespace {
+thread_local std::string g_last_error;
+Runtime g_rt;
+std::mutex g_rt_mu;
+}  // namespace
+
+Runtime& rt() { return g_rt; }
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+void rt_ensure_init() {
+    std::lock_guard<std::mutex> lk(g_rt_mu);
+    if (g_rt.inited) return;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    g_rt.device = dev;
+    HIP_CHECK(hipStreamCreateWithFlags(&g_rt.stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&g_rt.comm_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreate(&g_rt.ev0));
+    HIP_CHECK(hipEventCreate(&g_rt.ev1));
+    g_rt.inited = true;
+}
+
+#define API_BEGIN try {
+#define API_END                                   \
+    }                                             \
+    catch (const std::exception& e) {             \
+        set_last_error(e.what());                 \
+        return -1;                                \
+    }                                             \
+    catch (...) {                                 \
+        set_last_error("unknown C++ exception");  \
+        return -1;                                \
+    }                                             \
+    return 0;
+
+struct dl4ds_graph { Graph g; };
+struct dl4ds_trainer {
+    Trainer* t = nullptr;          // supervised trainer
+    CganTrainer* c = nullptr;      // or a CGAN trainer
+};
+
+static hipStream_t S() { rt_ensure_init(); return rt().stream; }
+static float* scratch(size_t bytes) {       // grow-only scratch for the single-op entry points
+    static float* p = nullptr;
+    static size_t cap = 0;
+    if (bytes > cap) {
+        HIP_CHECK(hipStreamSynchronize(S()));
+        if (p) HIP_CHECK(hipFree(p));
+        HIP_CHECK(hipMalloc((void**)&p, bytes));
+        cap = bytes;
+    }
+    return p;
+}
+static float* nc(const float* p) { return const_cast<float*>(p); }
+
+extern "C" {
+
+const char* dl4ds_last_error(void) { return g_last_error.c_str(); }
+
+int dl4ds_init(int device) {
+    API_BEGIN
+    {
+        std::lock_guard<std::mutex> lk(g_rt_mu);
+        DL4DS_REQUIRE(!g_rt.inited || g_rt.device == device, "dl4ds_init: already initialised on another device");
+        HIP_CHECK(hipSetDevice(device));
+    }
+    rt_ensure_init();
+    API_END
+}
+int dl4ds_device_count(int* n) {
+    API_BEGIN
+    HIP_CHECK(hipGetDeviceCount(n));
+    API_END
+}
+int dl4ds_device_name(char* buf, int buflen) {
+    API_BEGIN
+    rt_ensure_init();
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, rt().device));
+    std::snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    API_END
+}
+int dl4ds_malloc(void** p, size_t bytes) {
+    API_BEGIN
+    rt_ensure_init();
+    HIP_CHECK(hipMalloc(p, bytes > 0 ? bytes : 4));
+    API_END
+}
+int dl4ds_free(void* p) {
+    API_BEGIN
+    if (p) { HIP_CHECK(hipStreamSynchronize(S())); HIP_CHECK(hipFree(p)); }
+    API_END
+}
+int dl4ds_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    API_BEGIN
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+int dl4ds_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    API_BEGIN
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+int dl4ds_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+    API_BEGIN
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S()));
+    API_END
+}
+int dl4ds_memset(void* p, int value, size_t bytes) {
+    API_BEGIN
+    HIP_CHECK(hipMemsetAsync(p, value, bytes, S()));
+    API_END
+}
+int dl4ds_sync(void) {
+    API_BEGIN
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+int dl4ds_event_timer_start(void) {
+    API_BEGIN
+    HIP_CHECK(hipEventRecord(rt().ev0, S()));
+    API_END
+}
+int dl4ds_event_timer_stop(float* ms) {
+    API_BEGIN
+    HIP_CHECK(hipEventRecord(rt().ev1, S()));
+    HIP_CHECK(hipEventSynchronize(rt().ev1));
+    HIP_CHECK(hipEventElapsedTime(ms, rt().ev0, rt().ev1));
+    API_END
+}
+
+// ------------------------------------------------------------------------------------------------ ops
+int dl4ds_op_conv2d_fwd(const float* x, const float* w, const float* b, const float* add, float* y, int N, int H, int W,
+                        int Cin, int Cout, int KS, int relu, int d2s_r) {
+    API_BEGIN
+    TView in = make_view(nc(x), N, H, W, Cin);
+    TView out = (d2s_r > 1) ? make_view_d2s(y, N, H, W, Cout, d2s_r) : make_view(y, N, H, W, Cout);
+    ConvEpilogue ep;
+    ep.bias = b;
+    if (add) ep.add = make_view(nc(add), N, H, W, Cout);
+    ep.relu = relu;
+    conv2d_forward(S(), in, w, KS, out, ep);
+    API_END
+}
+int dl4ds_op_conv2d_dgrad(const float* dz, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int KS,
+                          int d2s_r, int accumulate) {
+    API_BEGIN
+    const size_t nw = (size_t)KS * KS * Cin * Cout;
+    float* wt = scratch(nw * sizeof(float));
+    conv2d_dgrad_weights(S(), w, wt, KS, Cin, Cout);
+    TView dzv = (d2s_r > 1) ? make_view_d2s(nc(dz), N, H, W, Cout, d2s_r) : make_view(nc(dz), N, H, W, Cout);
+    ConvEpilogue ep;
+    ep.accumulate = accumulate;
+    conv2d_forward(S(), dzv, wt, KS, make_view(dx, N, H, W, Cin), ep);
+    API_END
+}
+int dl4ds_op_conv2d_wgrad(const float* x, const float* dz, float* dw, int N, int H, int W, int Cin, int Cout, int KS,
+                          int d2s_r, int accumulate) {
+    API_BEGIN
+    TView xv = make_view(nc(x), N, H, W, Cin);
+    TView dzv = (d2s_r > 1) ? make_view_d2s(nc(dz), N, H, W, Cout, d2s_r) : make_view(nc(dz), N, H, W, Cout);
+    const size_t ws = conv2d_wgrad_workspace_bytes(xv, dzv, KS);
+    conv2d_wgrad(S(), xv, dzv, KS, dw, accumulate, scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_bias_act_bwd(float* dy, const float* y, float* db, int N, int H, int W, int C) {
+    API_BEGIN
+    TView dyv = make_view(dy, N, H, W, C);
+    TView none{nullptr, 0, 0, 0, 0, 0, 0, 0};
+    const size_t ws = bias_grad_workspace_bytes(dyv);
+    bias_act_backward(S(), dyv, y ? make_view(nc(y), N, H, W, C) : none, y ? dyv : none, db, 0, scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_conv2d_transpose_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout,
+                                  int KS, int stride, int relu) {
+    API_BEGIN
+    TView in = make_view(nc(x), N, H, W, Cin);
+    TView out = make_view(y, N, H * stride, W * stride, Cout);
+    const size_t ws = conv2d_transpose_workspace_bytes(in, out, KS, stride);
+    conv2d_transpose_forward(S(), in, w, KS, stride, out, relu, scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_conv2d_transpose_dgrad(const float* dz, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
+                                    int KS, int stride, int accumulate) {
+    API_BEGIN
+    TView dxv = make_view(dx, N, H, W, Cin);
+    TView dzv = make_view(nc(dz), N, H * stride, W * stride, Cout);
+    const size_t ws = conv2d_transpose_workspace_bytes(dxv, dzv, KS, stride);
+    conv2d_transpose_dgrad(S(), dzv, w, KS, stride, dxv, accumulate, scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, int N, int H, int W, int Cin, int Cout,
+                                    int KS, int stride, int accumulate) {
+    API_BEGIN
+    TView xv = make_view(nc(x), N, H, W, Cin);
+    TView dzv = make_view(nc(dz), N, H * stride, W * stride, Cout);
+    const size_t ws = conv2d_transpose_workspace_bytes(xv, dzv, KS, stride);
+    conv2d_transpose_wgrad(S(), xv, dzv, KS, stride, dw, accumulate, scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r) {
+    API_BEGIN
+    depth_to_space(S(), x, y, N, H, W, C, r);
+    API_END
+}
+int dl4ds_op_space_to_depth(const float* y, float* x, int N, int H, int W, int C, int r) {
+    API_BEGIN
+    space_to_depth(S(), y, x, N, H, W, C, r);
+    API_END
+}
+int dl4ds_op_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C) {
+    API_BEGIN
+    maxpool2_forward(S(), make_view(nc(x), N, H, W, C), make_view(y, N, H / 2, W / 2, C));
+    API_END
+}
+int dl4ds_op_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C) {
+    API_BEGIN
+    int acc = 0;
+    if ((H | W) & 1) { fill(S(), dx, (size_t)N * H * W * C, 0.f); acc = 1; }
+    maxpool2_backward(S(), make_view(nc(x), N, H, W, C), make_view(nc(y), N, H / 2, W / 2, C),
+                      make_view(nc(dy), N, H / 2, W / 2, C), make_view(dx, N, H, W, C), acc);
+    API_END
+}
+int dl4ds_op_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo) {
+    API_BEGIN
+    resize_bilinear_forward(S(), make_view(nc(x), N, H, W, C), make_view(y, N, Ho, Wo, C));
+    API_END
+}
+int dl4ds_op_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo) {
+    API_BEGIN
+    resize_bilinear_backward(S(), make_view(nc(dy), N, Ho, Wo, C), make_view(dx, N, H, W, C), 0);
+    API_END
+}
+int dl4ds_op_localconv_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int C, int F) {
+    API_BEGIN
+    localconv_forward(S(), make_view(nc(x), N, H, W, C), w, b, make_view(y, N, H, W, F));
+    API_END
+}
+int dl4ds_op_localconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N,
+                           int H, int W, int C, int F) {
+    API_BEGIN
+    TView dxv{nullptr, 0, 0, 0, 0, 0, 0, 0};
+    if (dx) dxv = make_view(dx, N, H, W, C);
+    localconv_backward(S(), make_view(nc(x), N, H, W, C), w, make_view(nc(dy), N, H, W, F), dxv, 0, dw, db, 0);
+    API_END
+}
+int dl4ds_op_chatt_fwd(const float* x, float* y, int G, int R, int P, int C, int Cr, const float* w1, const float* b1,
+                       const float* w2, const float* b2, float* saved) {
+    API_BEGIN
+    AttShape sh{G, R, P, C, Cr};
+    const size_t inst = (size_t)G * P;
+    float* mean = saved;
+    float* scale = mean + inst * C;
+    float* hidden = scale + inst * C;
+    chatt_forward(S(), x, y, sh, w1, b1, w2, b2, mean, hidden, scale, scratch(chatt_workspace_bytes(sh)));
+    API_END
+}
+int dl4ds_op_chatt_bwd(const float* x, const float* dy, float* dx, int G, int R, int P, int C, int Cr, const float* w1,
+                       const float* w2, const float* saved, float* dw1, float* db1, float* dw2, float* db2) {
+    API_BEGIN
+    AttShape sh{G, R, P, C, Cr};
+    const size_t inst = (size_t)G * P;
+    const float* mean = saved;
+    const float* scale = mean + inst * C;
+    const float* hidden = scale + inst * C;
+    chatt_backward(S(), x, dy, dx, 0, sh, w1, w2, mean, hidden, scale, dw1, db1, dw2, db2, 0,
+                   scratch(chatt_workspace_bytes(sh)));
+    API_END
+}
+int dl4ds_op_loss(int kind, const float* yt, const float* yp, float* dpred, int N, int H, int W, int C, float* loss_dev) {
+    API_BEGIN
+    const size_t ws = loss_workspace_bytes(kind, N, H, W, C);
+    loss_forward_backward(S(), kind, yt, yp, dpred, N, H, W, C, 1.f, loss_dev, 0, scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_bce(const float* p, float label, int n, float* loss_dev, float* dp) {
+    API_BEGIN
+    bce_forward_backward(S(), p, label, n, 1.f, loss_dev, dp, 0);
+    API_END
+}
+int dl4ds_op_adam(float* w, const float* g, float* m, float* v, size_t n, int t, float lr, float beta1, float beta2,
+                  float eps, float grad_scale) {
+    API_BEGIN
+    const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) /
+                               (1.0 - std::pow((double)beta1, (double)t)));
+    adam_update(S(), w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    API_END
+}
+
+// ------------------------------------------------------------------------------------------------ graph
+int dl4ds_graph_create(dl4ds_graph** g) {
+    API_BEGIN
+    *g = new dl4ds_graph();
+    (*g)->g.stream = S();
+    API_END
+}
+int dl4ds_graph_destroy(dl4ds_graph* g) {
+    API_BEGIN
+    if (g) { HIP_CHECK(hipStreamSynchronize(S())); delete g; }
+    API_END
+}
+int dl4ds_graph_input(dl4ds_graph* g, int H, int W, int C, int nmul, int* tid) {
+    API_BEGIN
+    *tid = g->g.add_tensor(H, W, C, nmul, false, true);
+    API_END
+}
+int dl4ds_graph_param(dl4ds_graph* g, size_t n, int* pid) {
+    API_BEGIN
+    *pid = g->g.add_param(n);
+    API_END
+}
+int dl4ds_graph_conv2d(dl4ds_graph* g, int in, int w, int b, int add, int KS, int Cout, int relu, int d2s_r, int* out) {
+    API_BEGIN
+    *out = g_conv2d(g->g, in, w, b, add, KS, Cout, relu, d2s_r);
+    API_END
+}
+int dl4ds_graph_conv2d_transpose(dl4ds_graph* g, int in, int w, int KS, int stride, int Cout, int relu, int* out) {
+    API_BEGIN
+    *out = g_conv2d_transpose(g->g, in, w, KS, stride, Cout, relu);
+    API_END
+}
+int dl4ds_graph_chatt(dl4ds_graph* g, int in, int w1, int b1, int w2, int b2, int Cr, int T5, int* out) {
+    API_BEGIN
+    *out = g_chatt(g->g, in, w1, b1, w2, b2, Cr, T5);
+    API_END
+}
+int dl4ds_graph_concat(dl4ds_graph* g, const int* ins, int n, int* out) {
+    API_BEGIN
+    *out = g_concat(g->g, ins, n);
+    API_END
+}
+int dl4ds_graph_add(dl4ds_graph* g, int a, int b, int relu, int* out) {
+    API_BEGIN
+    *out = g_add(g->g, a, b, relu);
+    API_END
+}
+int dl4ds_graph_act(dl4ds_graph* g, int in, int kind, int* out) {
+    API_BEGIN
+    *out = g_act(g->g, in, kind);
+    API_END
+}
+int dl4ds_graph_maxpool2(dl4ds_graph* g, int in, int* out) {
+    API_BEGIN
+    *out = g_maxpool2(g->g, in);
+    API_END
+}
+int dl4ds_graph_resize(dl4ds_graph* g, int in, int Ho, int Wo, int* out) {
+    API_BEGIN
+    *out = g_resize(g->g, in, Ho, Wo);
+    API_END
+}
+int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out) {
+    API_BEGIN
+    *out = g_localconv(g->g, in, w, b, F);
+    API_END
+}
+int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out) {
+    API_BEGIN
+    *out = g_repeat_time(g->g, in, T);
+    API_END
+}
+int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out) {
+    API_BEGIN
+    *out = g_convlstm(g->g, in, wk, wr, b, KS, F, T, relu);
+    API_END
+}
+int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out) {
+    API_BEGIN
+    *out = g_gap(g->g, in, 0);
+    API_END
+}
+int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out) {
+    API_BEGIN
+    *out = g_dense(g->g, in, w, b, F, act);
+    API_END
+}
+int dl4ds_graph_dropout(dl4ds_graph* g, int in, float rate, int* out) {
+    API_BEGIN
+    *out = g_dropout(g->g, in, rate);
+    API_END
+}
+int dl4ds_graph_output(dl4ds_graph* g, int tid) {
+    API_BEGIN
+    DL4DS_REQUIRE(tid >= 0 && tid < (int)g->g.tensors.size(), "bad tensor id");
+    g->g.outputs.push_back(tid);
+    API_END
+}
+int dl4ds_graph_finalize(dl4ds_graph* g) {
+    API_BEGIN
+    g->g.finalize();
+    API_END
+}
+int dl4ds_graph_tensor_shape(dl4ds_graph* g, int tid, int shape4[4]) {
+    API_BEGIN
+    const GTensor& t = g->g.tensors.at(tid);
+    shape4[0] = t.nmul; shape4[1] = t.H; shape4[2] = t.W; shape4[3] = t.C;
+    API_END
+}
+int dl4ds_graph_param_count(dl4ds_graph* g, size_t* n_arena, int* n_params) {
+    API_BEGIN
+    *n_arena = g->g.n_params;
+    *n_params = (int)g->g.params.size();
+    API_END
+}
+int dl4ds_graph_param_info(dl4ds_graph* g, int pid, size_t* offset, size_t* n) {
+    API_BEGIN
+    *offset = g->g.params.at(pid).offset;
+    *n = g->g.params.at(pid).n;
+    API_END
+}
+int dl4ds_graph_set_param(dl4ds_graph* g, int pid, const float* src) {
+    API_BEGIN
+    DL4DS_REQUIRE(g->g.finalized, "graph not finalized");
+    const GParam& p = g->g.params.at(pid);
+    HIP_CHECK(hipMemcpyAsync(g->g.W + p.offset, src, p.n * sizeof(float), hipMemcpyHostToDevice, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+int dl4ds_graph_get_param(dl4ds_graph* g, int pid, float* dst) {
+    API_BEGIN
+    const GParam& p = g->g.params.at(pid);
+    HIP_CHECK(hipMemcpyAsync(dst, g->g.W + p.offset, p.n * sizeof(float), hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+int dl4ds_graph_get_grad(dl4ds_graph* g, int pid, float* dst) {
+    API_BEGIN
+    const GParam& p = g->g.params.at(pid);
+    HIP_CHECK(hipMemcpyAsync(dst, g->g.G + p.offset, p.n * sizeof(float), hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+int dl4ds_graph_arena_ptrs(dl4ds_graph* g, float** w, float** gr) {
+    API_BEGIN
+    *w = g->g.W;
+    *gr = g->g.G;
+    API_END
+}
+int dl4ds_graph_forward(dl4ds_graph* g, const float* const* inputs, int n_inputs, int B, int training, int is_host,
+                        float* out) {
+    API_BEGIN
+    Graph& G = g->g;
+    DL4DS_REQUIRE(!G.outputs.empty(), "graph has no output");
+    graph_load_inputs(G, inputs, n_inputs, B, is_host != 0);
+    G.forward(B, training != 0);
+    if (out) {
+        const GTensor& o = G.tensors[G.outputs[0]];
+        HIP_CHECK(hipMemcpyAsync(out, o.data, o.per_sample() * B * sizeof(float),
+                                 is_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, S()));
+        if (is_host) HIP_CHECK(hipStreamSynchronize(S()));
+    }
+    API_END
+}
+int dl4ds_graph_tensor_ptr(dl4ds_graph* g, int tid, int grad, float** p) {
+    API_BEGIN
+    const GTensor& t = g->g.tensors.at(tid);
+    *p = grad ? t.grad : t.data;
+    API_END
+}
+
+// ------------------------------------------------------------------------------------------------ training
+int dl4ds_trainer_create(dl4ds_graph* g, int loss_kind, float lr0, float lr1, double lr_boundary, float beta1,
+                         float beta2, float eps, dl4ds_trainer** tr) {
+    API_BEGIN
+    AdamCfg c;
+    c.lr0 = lr0; c.lr1 = lr1; c.boundary = lr_boundary; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
+    dl4ds_trainer* h = new dl4ds_trainer();
+    h->t = trainer_create(&g->g, loss_kind, c);
+    *tr = h;
+    API_END
+}
+int dl4ds_trainer_destroy(dl4ds_trainer* tr) {
+    API_BEGIN
+    if (tr) {
+        HIP_CHECK(hipStreamSynchronize(S()));
+        if (tr->t) delete tr->t;
+        if (tr->c) cgan_destroy(tr->c);
+        delete tr;
+    }
+    API_END
+}
+int dl4ds_trainer_step(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true, int B,
+                       int is_host, float* loss_host) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
+    trainer_step(*tr->t, inputs, n_inputs, y_true, B, is_host != 0, loss_host);
+    API_END
+}
+int dl4ds_trainer_loss_and_grads(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true,
+                                 int B, int is_host, float* loss_host) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
+    trainer_loss_and_grads(*tr->t, inputs, n_inputs, y_true, B, is_host != 0);
+    if (loss_host) {
+        HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
+        HIP_CHECK(hipStreamSynchronize(S()));
+    }
+    API_END
+}
+int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, long* step) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
+    Trainer& t = *tr->t;
+    const size_t bytes = t.g->n_params * sizeof(float);
+    if (m_host) HIP_CHECK(hipMemcpyAsync(m_host, t.m, bytes, hipMemcpyDeviceToHost, S()));
+    if (v_host) HIP_CHECK(hipMemcpyAsync(v_host, t.v, bytes, hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    if (step) *step = t.step;
+    API_END
+}
+int dl4ds_trainer_last_loss(dl4ds_trainer* tr, float* loss_host) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
+    HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+
+int dl4ds_cgan_create(dl4ds_graph* gen, dl4ds_graph* disc, int px_loss_kind, float lr, float beta1, float lam,
+                      dl4ds_trainer** tr) {
+    API_BEGIN
+    dl4ds_trainer* h = new dl4ds_trainer();
+    h->c = cgan_create(&gen->g, &disc->g, px_loss_kind, lr, beta1, lam);
+    *tr = h;
+    API_END
+}
+int dl4ds_cgan_step(dl4ds_trainer* tr, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B,
+                    int is_host, const float* dropout_keep_host, int apply_update, float* losses_host) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->c, "not a CGAN trainer");
+    cgan_step(*tr->c, gen_inputs, n_gen_inputs, hr, B, is_host != 0, dropout_keep_host, apply_update != 0, losses_host);
+    API_END
+}
+int dl4ds_cgan_get_disc_grad(dl4ds_trainer* tr, int pid, float* dst) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->c, "not a CGAN trainer");
+    Graph* g = cgan_disc_trainer(tr->c)->g;
+    const GParam& p = g->params.at(pid);
+    HIP_CHECK(hipMemcpyAsync(dst, g->G + p.offset, p.n * sizeof(float), hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+
+// ------------------------------------------------------------------------------------------------ dist
+int dl4ds_dist_unique_id(char id128[128]) {
+    API_BEGIN
+    dist_unique_id(id128);
+    API_END
+}
+int dl4ds_dist_init(int rank, int world, const char id128[128]) {
+    API_BEGIN
+    dist_init(rank, world, id128);
+    API_END
+}
+int dl4ds_dist_world(int* rank, int* world) {
+    API_BEGIN
+    dist_world(*rank, *world);
+    API_END
+}
+int dl4ds_dist_broadcast_trainer(dl4ds_trainer* tr, int root) {
+    API_BEGIN
+    std::vector<Trainer*> ts;
+    if (tr->t) ts.push_back(tr->t);
+    if (tr->c) { ts.push_back(cgan_gen_trainer(tr->c)); ts.push_back(cgan_disc_trainer(tr->c)); }
+    for (Trainer* t : ts) {
+        dist_broadcast(t->g->W, t->g->n_params, root, S());
+        dist_broadcast(t->m, t->g->n_params, root, S());
+        dist_broadcast(t->v, t->g->n_params, root, S());
+    }
+    HIP_CHECK(hipStreamSynchronize(S()));
+    API_END
+}
+int dl4ds_dist_allreduce_sum(float* buf, size_t n) {
+    API_BEGIN
+    dist_allreduce_grads(buf, n, S());
+    API_END
+}
+int dl4ds_dist_finalize(void) {
+    API_BEGIN
+    dist_finalize();
+    API_END
+}
+
+}  // extern "C"

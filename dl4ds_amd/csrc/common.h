@@ -1,0 +1,109 @@
+// dl4ds_amd -- gfx950 (MI355X / CDNA4) native kernels for the dl4ds conv-SR train step.
+// Common device/host helpers.  fp32 NHWC everywhere (Keras channels_last).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <stdexcept>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// Tensor view: logical NHWC tensor (N,H,W,C) living in HBM.
+//   ld   : floats between consecutive pixels (>= C; > C for channel slices of a wider buffer)
+//   d2s  : 0/1 -> plain.  r>=2 -> the memory holds depth_to_space(r) of the logical tensor, i.e.
+//          logical (n,h,w,c) lives at [n, h*r+i, w*r+j, c % Cp] of an (N, H*r, W*r, Cp=C/r^2)
+//          buffer with (i*r+j) = c / Cp   (tf.nn.depth_to_space "DCR", blocks.py:427).
+//   vec  : float4 access at channel offsets that are multiples of 4 is legal (alignment + no
+//          group straddling)
+struct TView {
+    float* p;
+    int N, H, W, C;
+    int ld;
+    int d2s;
+    int vec;
+};
+
+__host__ __device__ inline TView make_view(float* p, int N, int H, int W, int C) {
+    TView v;
+    v.p = p; v.N = N; v.H = H; v.W = W; v.C = C; v.ld = C; v.d2s = 0;
+    v.vec = ((C & 3) == 0) && ((((uintptr_t)p) & 15) == 0);
+    return v;
+}
+
+// view whose memory is the depth_to_space(r) image of the logical (N,H,W,C) tensor
+__host__ __device__ inline TView make_view_d2s(float* p, int N, int H, int W, int C, int r) {
+    TView v;
+    int cp = C / (r * r);
+    v.p = p; v.N = N; v.H = H; v.W = W; v.C = C; v.ld = cp; v.d2s = r;
+    v.vec = ((cp & 3) == 0) && ((((uintptr_t)p) & 15) == 0);
+    return v;
+}
+
+__device__ __forceinline__ size_t view_off(const TView& v, int n, int y, int x, int c) {
+    if (v.d2s > 1) {
+        const int r = v.d2s;
+        const int cp = v.C / (r * r);
+        const int g = c / cp;
+        const int cc = c - g * cp;
+        const int i = g / r, j = g - i * r;
+        return (((size_t)n * (v.H * r) + (y * r + i)) * (size_t)(v.W * r) + (x * r + j)) * v.ld + cc;
+    }
+    return (((size_t)n * v.H + y) * (size_t)v.W + x) * v.ld + c;
+}
+
+// channels c..c+3 (c % 4 == 0), zero beyond C
+__device__ __forceinline__ float4 view_load4(const TView& v, int n, int y, int x, int c) {
+    if (v.vec && c + 3 < v.C) {
+        return *reinterpret_cast<const float4*>(v.p + view_off(v, n, y, x, c));
+    }
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < v.C) r.x = v.p[view_off(v, n, y, x, c)];
+    if (c + 1 < v.C) r.y = v.p[view_off(v, n, y, x, c + 1)];
+    if (c + 2 < v.C) r.z = v.p[view_off(v, n, y, x, c + 2)];
+    if (c + 3 < v.C) r.w = v.p[view_off(v, n, y, x, c + 3)];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes on CDNA)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side error handling: C++ exceptions inside the library, converted to int status + message
+// at the C ABI (capi.cpp).
+struct Dl4dsError : public std::runtime_error {
+    explicit Dl4dsError(const std::string& m) : std::runtime_error(m) {}
+};
+
+#define HIP_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            throw Dl4dsError(std::string("HIP error: ") + hipGetErrorString(_e) + " at " +     \
+                             __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")");      \
+        }                                                                                      \
+    } while (0)
+
+#define DL4DS_REQUIRE(cond, msg)                                                               \
+    do {                                                                                       \
+        if (!(cond)) throw Dl4dsError(std::string("dl4ds: ") + (msg) + " [" #cond "]");        \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,478 @@
+// NHWC fp32 convolution for gfx950 as implicit GEMM on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32 fma chains at the 157 TFLOP/s vector rate).
+//
+//   forward / dgrad : M = output pixels (16-wide row segments of a 2-D spatial tile so the KSxKS halo
+//                     is reused from LDS), N = Cout, K = KS*KS*Cin.  Input halo tile and the filter
+//                     slice of the current (channel-chunk, tap-group) are staged in LDS; each wave owns
+//                     MT x NT accumulator tiles.  Epilogue fuses bias, residual add, ReLU, ReLU-mask,
+//                     gradient accumulation and the depth_to_space store (through TView).
+//   wgrad           : M = Cin, N = Cout, K = pixels.  Each block walks a strip of spatial tiles with
+//                     all KS*KS taps accumulated in registers, writes one partial slab, and a second
+//                     kernel reduces the slabs deterministically.
+//
+// Replaces (third-party in the reference): tf.keras.layers.Conv2D forward and the Conv2DBackpropInput /
+// Conv2DBackpropFilter TF autodiff would have produced -- call sites dl4ds/models/blocks.py:49-61,208,
+// 249-259,299,414-416,479,582-583; sp_postups.py:134,156; discriminator.py:35-65.
+#include "ops.h"
+#include <algorithm>
+#include <mutex>
+#include <map>
+
+namespace {
+
+constexpr int kLdsBudget = 80 * 1024;   // 2 workgroups per CU (160 KiB LDS)
+
+struct ConvParams {
+    TView in, out, add, mask;
+    const float* w;
+    const float* bias;
+    int Cin, Cout, H, W;
+    int CK, TPS;
+    int tiles_x, tiles_y;
+    int relu, accumulate;
+    int wvec;
+};
+
+template <int KS, int MT, int NT, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvParams a) {
+    constexpr int TW = 16;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int BM = WM * MT * 16;
+    constexpr int TH = BM / TW;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BN4 = BN / 4;
+    constexpr int PAD = KS / 2;
+    constexpr int TWH = TW + KS - 1;
+    constexpr int THH = TH + KS - 1;
+    constexpr int HPIX = TWH * THH;
+    constexpr int NP = (BN % 32 == 0) ? BN + 16 : BN;   // rows k and k+1 land on disjoint bank halves
+    constexpr int KK = KS * KS;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CK = a.CK;
+    const int P = CK + 2;                                // P = 2*odd -> conflict-free A-fragment reads
+    float* in_tile = smem;
+    float* w_tile = smem + ((HPIX * P + 3) & ~3);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int n0 = blockIdx.y * BN;
+
+    int a_base[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_base[i] = ((wm * MT + i) * TWH + l15) * P + lq;
+    const int b_base = lq * NP + wn * NT * 16 + l15;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        const int ck = min(CK, a.Cin - c0);
+        const int ck4 = (ck + 3) >> 2;
+        __syncthreads();
+        // ---- stage the input halo tile, channels [c0, c0+ck) (zero outside the image / beyond Cin)
+        for (int idx = tid; idx < HPIX * ck4; idx += NTHR) {
+            const int pix = idx / ck4;
+            const int q = idx - pix * ck4;
+            const int r = pix / TWH;
+            const int c = pix - r * TWH;
+            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = view_load4(a.in, n, gy, gx, c0 + q * 4);
+            float2* d = reinterpret_cast<float2*>(in_tile + pix * P + q * 4);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+        }
+        for (int tg = 0; tg < KK; tg += a.TPS) {
+            const int ntap = min(a.TPS, KK - tg);
+            if (tg > 0) __syncthreads();
+            // ---- stage the filter slice [ntap][ck4*4][BN] (zero rows/cols beyond Cin/Cout)
+            const int rows = ck4 * 4;
+            for (int idx = tid; idx < ntap * rows * BN4; idx += NTHR) {
+                const int q = idx % BN4;
+                const int row = idx / BN4;
+                const int tl = row / rows;
+                const int r = row - tl * rows;
+                const int co = n0 + q * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < ck && co < a.Cout) {
+                    const float* src = a.w + ((size_t)(tg + tl) * a.Cin + (c0 + r)) * a.Cout + co;
+                    if (a.wvec && co + 3 < a.Cout) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (co + 1 < a.Cout) v.y = src[1];
+                        if (co + 2 < a.Cout) v.z = src[2];
+                        if (co + 3 < a.Cout) v.w = src[3];
+                    }
+                }
+                *reinterpret_cast<float4*>(w_tile + (tl * CK + r) * NP + q * 4) = v;
+            }
+            __syncthreads();
+            // ---- MFMA over the staged taps
+            for (int tl = 0; tl < ntap; ++tl) {
+                const int tap = tg + tl;
+                const int ky = tap / KS, kx = tap - ky * KS;
+                const float* ap = in_tile + (ky * TWH + kx) * P;
+                const float* bp = w_tile + tl * CK * NP + b_base;
+                // software pipeline: fragments of step kk+1 are in flight while step kk's MFMAs issue
+                float av[MT], bv[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = ap[a_base[i]];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = bp[j * 16];
+                for (int kk = 0; kk < ck4; ++kk) {
+                    const int kn = (kk + 1 < ck4) ? kk + 1 : kk;
+                    float an[MT], bn[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) an[i] = ap[a_base[i] + kn * 4];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bn[j] = bp[kn * 4 * NP + j * 16];
+                    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) av[i] = an[i];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[j] = bn[j];
+                }
+            }
+        }
+    }
+
+    // ---- epilogue.  C/D layout of 16x16x4: col = lane&15 (cout), row = (lane>>4)*4 + reg (pixel)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int gy = y0 + wm * MT + i;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + (wn * NT + j) * 16 + l15;
+            const bool ok = (gy < a.H) && (co < a.Cout);
+            const float bv = (ok && a.bias) ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int gx = x0 + lq * 4 + rg;
+                if (ok && gx < a.W) {
+                    float v = acc[i][j][rg] + bv;
+                    if (a.add.p) v += a.add.p[view_off(a.add, n, gy, gx, co)];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.mask.p) v = (a.mask.p[view_off(a.mask, n, gy, gx, co)] > 0.f) ? v : 0.f;
+                    const size_t o = view_off(a.out, n, gy, gx, co);
+                    if (a.accumulate) v += a.out.p[o];
+                    a.out.p[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+struct FwdCfg { int BN, BM; };
+
+template <int KS, int MT, int NT, int WM, int WN>
+void launch_fwd(hipStream_t s, ConvParams& p, int N) {
+    constexpr int BM = WM * MT * 16, TH = BM / 16, BN = WN * NT * 16;
+    constexpr int TWH = 16 + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
+    constexpr int NP = (BN % 32 == 0) ? BN + 16 : BN;
+    constexpr int KK = KS * KS;
+    auto kern = conv_igemm_kernel<KS, MT, NT, WM, WN>;
+    // pick the channel chunk CK (multiple of 4) and taps-per-stage under the LDS budget
+    const int cin4 = (p.Cin + 3) & ~3;
+    int CK = 0, TPS = 1;
+    const int cand[] = {cin4, 64, 48, 32, 16, 8, 4};
+    auto bytes = [&](int ck, int tps) {
+        return (size_t)(((HPIX * (ck + 2) + 3) & ~3) + tps * ck * NP) * sizeof(float);
+    };
+    for (int c : cand) {
+        if (c > cin4) continue;
+        if (bytes(c, 1) <= (size_t)kLdsBudget) { CK = c; break; }
+    }
+    DL4DS_REQUIRE(CK > 0, "conv tile does not fit in LDS");
+    const int tps_cand[] = {KK, KS, 1};
+    for (int tps : tps_cand) {
+        if (bytes(CK, tps) <= (size_t)kLdsBudget) { TPS = tps; break; }
+    }
+    p.CK = CK;
+    p.TPS = TPS;
+    p.tiles_x = cdiv(p.W, 16);
+    p.tiles_y = cdiv(p.H, TH);
+    const size_t lds = bytes(CK, TPS);
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    });
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * N), (unsigned)cdiv(p.Cout, BN));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int KS>
+void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
+    // choose the cout tile minimising padded work (ties -> larger tile)
+    const int bns[] = {192, 128, 96, 48, 32, 16};
+    int best = 16;
+    long bestw = -1;
+    for (int bn : bns) {
+        long wk = (long)cdiv(p.Cout, bn) * bn;
+        if (bestw < 0 || wk < bestw) { bestw = wk; best = bn; }
+    }
+    switch (best) {
+        case 192: launch_fwd<KS, 4, 6, 2, 2>(s, p, N); break;   // 8x16 pixels x 192 couts
+        case 128: launch_fwd<KS, 4, 4, 2, 2>(s, p, N); break;   // 8x16 x 128
+        case 96:  launch_fwd<KS, 4, 3, 2, 2>(s, p, N); break;   // 8x16 x 96
+        case 48:  launch_fwd<KS, 4, 3, 4, 1>(s, p, N); break;   // 16x16 x 48
+        case 32:  launch_fwd<KS, 4, 2, 4, 1>(s, p, N); break;   // 16x16 x 32
+        default:  launch_fwd<KS, 4, 1, 4, 1>(s, p, N); break;   // 16x16 x 16
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+__global__ void dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int KK, int Cin,
+                                     int Cout) {
+    const size_t total = (size_t)KK * Cin * Cout;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        // destination index e = (tap', co, ci)
+        const int ci = (int)(e % Cin);
+        const size_t r = e / Cin;
+        const int co = (int)(r % Cout);
+        const int tp = (int)(r / Cout);
+        wt[e] = w[((size_t)(KK - 1 - tp) * Cin + ci) * Cout + co];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+struct WgradParams {
+    TView x, dz;
+    float* partial;     // [S][KK][Cin][Cout]
+    int Cin, Cout, H, W;
+    int tiles_x, tiles_y, ntiles, S;
+};
+
+// block = 4 waves; wave w owns cout tiles [w*COT,(w+1)*COT) of the block's 64*COT couts and ALL
+// (tap, cin-tile) combinations of the block's 16*CIT cins.
+template <int KS, int CIT, int COT>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a) {
+    constexpr int TW = 16, TH = 8;
+    constexpr int PAD = KS / 2;
+    constexpr int TWH = TW + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
+    constexpr int KK = KS * KS;
+    constexpr int CIB = 16 * CIT;
+    constexpr int COB = 64 * COT;
+    constexpr int PX = (CIB % 32 == 16) ? CIB : CIB + 16;   // pixel k and k+1 on disjoint bank halves
+    constexpr int PZ = (COB % 32 == 16) ? COB : COB + 16;
+    constexpr int NPIX = TW * TH;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* x_tile = smem;                       // [HPIX][PX]
+    float* z_tile = smem + HPIX * PX;           // [NPIX][PZ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ci0 = blockIdx.z * CIB;
+    const int co0 = blockIdx.y * COB;
+
+    f32x4 acc[KK][CIT][COT];
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int n = t / a.tiles_y;
+        const int x0 = tx * TW, y0 = ty * TH;
+        __syncthreads();
+        // stage x halo tile (channels ci0 .. ci0+CIB)
+        for (int idx = tid; idx < HPIX * (CIB / 4); idx += 256) {
+            const int pix = idx / (CIB / 4);
+            const int q = idx - pix * (CIB / 4);
+            const int r = pix / TWH, c = pix - r * TWH;
+            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin)
+                v = view_load4(a.x, n, gy, gx, ci0 + q * 4);
+            *reinterpret_cast<float4*>(x_tile + pix * PX + q * 4) = v;
+        }
+        // stage dz tile (channels co0 .. co0+COB); zero outside the image so padded pixels add nothing
+        for (int idx = tid; idx < NPIX * (COB / 4); idx += 256) {
+            const int pix = idx / (COB / 4);
+            const int q = idx - pix * (COB / 4);
+            const int r = pix / TW, c = pix - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < a.H && gx < a.W && co0 + q * 4 < a.Cout) v = view_load4(a.dz, n, gy, gx, co0 + q * 4);
+            *reinterpret_cast<float4*>(z_tile + pix * PZ + q * 4) = v;
+        }
+        __syncthreads();
+        // K loop over the 128 pixels, 4 per MFMA: pixel pk = kk*4 + lq -> (row kk>>2, col (kk&3)*4+lq)
+#pragma unroll 2
+        for (int kk = 0; kk < NPIX / 4; ++kk) {
+            const int pr = kk >> 2;
+            const int pc = (kk & 3) * 4 + lq;
+            float bv[COT];
+#pragma unroll
+            for (int j = 0; j < COT; ++j) bv[j] = z_tile[(pr * TW + pc) * PZ + (wave * COT + j) * 16 + l15];
+#pragma unroll
+            for (int tp = 0; tp < KK; ++tp) {
+                const int ky = tp / KS, kx = tp % KS;
+                const float* xp = x_tile + ((pr + ky) * TWH + (pc + kx)) * PX + l15;
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) {
+                    const float av = xp[i * 16];
+#pragma unroll
+                    for (int j = 0; j < COT; ++j)
+                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[tp][i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // write the partial slab: D row = ci (lq*4+reg), col = co (l15)
+    float* slab = a.partial + (size_t)blockIdx.x * KK * a.Cin * a.Cout;
+#pragma unroll
+    for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+            for (int j = 0; j < COT; ++j) {
+                const int co = co0 + (wave * COT + j) * 16 + l15;
+                if (co >= a.Cout) continue;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int ci = ci0 + i * 16 + lq * 4 + rg;
+                    if (ci < a.Cin) slab[((size_t)tp * a.Cin + ci) * a.Cout + co] = acc[tp][i][j][rg];
+                }
+            }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n,
+                                    int S, int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += partial[(size_t)k * n + e];
+        out[e] = accumulate ? out[e] + s : s;
+    }
+}
+
+struct WgradPlan { int S, CIB, COB, tiles_x, tiles_y, ntiles; };
+
+WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
+    WgradPlan p;
+    p.tiles_x = cdiv(x.W, 16);
+    p.tiles_y = cdiv(x.H, 8);
+    p.ntiles = p.tiles_x * p.tiles_y * x.N;
+    p.CIB = (x.C > 32) ? 48 : (x.C > 16 ? 32 : 16);
+    if (KS == 5) p.CIB = 16;
+    p.COB = 64;
+    const int cob = cdiv(dz.C, p.COB), cib = cdiv(x.C, p.CIB);
+    int target = std::max(1, 1024 / (cob * cib));
+    const size_t params = (size_t)KS * KS * x.C * dz.C;
+    const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (params * sizeof(float)));
+    p.S = (int)std::min<size_t>(std::min<size_t>(target, p.ntiles), cap);
+    if (p.S < 1) p.S = 1;
+    return p;
+}
+
+template <int KS, int CIT, int COT>
+void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
+    constexpr int TWH = 16 + KS - 1, THH = 8 + KS - 1, HPIX = TWH * THH;
+    constexpr int CIB = 16 * CIT, COB = 64 * COT;
+    constexpr int PX = (CIB % 32 == 16) ? CIB : CIB + 16;
+    constexpr int PZ = (COB % 32 == 16) ? COB : COB + 16;
+    const size_t lds = (size_t)(HPIX * PX + 128 * PZ) * sizeof(float);
+    auto kern = conv_wgrad_kernel<KS, CIT, COT>;
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    });
+    DL4DS_REQUIRE(lds <= (size_t)kLdsBudget, "wgrad tile does not fit in LDS");
+    dim3 grid((unsigned)pl.S, (unsigned)cdiv(p.Cout, COB), (unsigned)cdiv(p.Cin, CIB));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+// =============================================================================================
+void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
+                    const ConvEpilogue& ep) {
+    DL4DS_REQUIRE(in.N == out.N && in.H == out.H && in.W == out.W, "conv2d: stride-1 SAME shapes differ");
+    ConvParams p;
+    p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
+    p.w = w; p.bias = ep.bias;
+    p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
+    p.relu = ep.relu; p.accumulate = ep.accumulate;
+    p.wvec = ((out.C & 3) == 0) && ((((uintptr_t)w) & 15) == 0);
+    p.CK = 0; p.TPS = 1; p.tiles_x = p.tiles_y = 0;
+    switch (KS) {
+        case 1: dispatch_fwd<1>(s, p, in.N); break;
+        case 3: dispatch_fwd<3>(s, p, in.N); break;
+        case 5: dispatch_fwd<5>(s, p, in.N); break;
+        default: throw Dl4dsError("conv2d: kernel size " + std::to_string(KS) + " not supported (1,3,5)");
+    }
+}
+
+void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int Cin, int Cout) {
+    const size_t total = (size_t)KS * KS * Cin * Cout;
+    const int blocks = (int)std::min<size_t>(cdivz(total, 256), 2048);
+    hipLaunchKernelGGL(dgrad_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wt, KS * KS, Cin, Cout);
+    HIP_CHECK(hipGetLastError());
+}
+
+size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS) {
+    WgradPlan pl = plan_wgrad(x, dz, KS);
+    return (size_t)pl.S * KS * KS * x.C * dz.C * sizeof(float);
+}
+
+void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate,
+                  float* workspace, size_t workspace_bytes) {
+    DL4DS_REQUIRE(x.N == dz.N && x.H == dz.H && x.W == dz.W, "wgrad: shapes differ");
+    WgradPlan pl = plan_wgrad(x, dz, KS);
+    const size_t n = (size_t)KS * KS * x.C * dz.C;
+    DL4DS_REQUIRE(workspace_bytes >= (size_t)pl.S * n * sizeof(float), "wgrad: workspace too small");
+    WgradParams p;
+    p.x = x; p.dz = dz; p.partial = workspace;
+    p.Cin = x.C; p.Cout = dz.C; p.H = x.H; p.W = x.W;
+    p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S;
+    if (KS == 1) {
+        if (pl.CIB == 48) launch_wgrad<1, 3, 1>(s, p, pl);
+        else if (pl.CIB == 32) launch_wgrad<1, 2, 1>(s, p, pl);
+        else launch_wgrad<1, 1, 1>(s, p, pl);
+    } else if (KS == 3) {
+        if (pl.CIB == 48) launch_wgrad<3, 3, 1>(s, p, pl);
+        else if (pl.CIB == 32) launch_wgrad<3, 2, 1>(s, p, pl);
+        else launch_wgrad<3, 1, 1>(s, p, pl);
+    } else if (KS == 5) {
+        launch_wgrad<5, 1, 1>(s, p, pl);
+    } else {
+        throw Dl4dsError("wgrad: kernel size not supported (1,3,5)");
+    }
+    const int blocks = (int)std::min<size_t>(cdivz(n, 256), 4096);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, n, pl.S, accumulate);
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,398 @@
+// HBM-bound helper kernels of the dl4ds train step (gfx950): ReLU-mask + bias-gradient reduction,
+// strided/d2s view copies (concat, residual gradients), activations, depth_to_space, 2x2 max-pool,
+// bilinear resize, per-pixel locally-connected 1x1 layer.  All fp32 NHWC.
+//
+// Reference call sites (third-party TF ops there): blocks.py:75 (Activation), :228 (Add), :276/:656
+// (Concatenate), :427 (depth_to_space), :489 (Resizing), :613 (MaxPooling2D), :322-328 (LocallyConnected2D).
+#include "ops.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ void unflatten_pix(const TView& v, size_t pix, int& n, int& y, int& x) {
+    x = (int)(pix % v.W);
+    size_t r = pix / v.W;
+    y = (int)(r % v.H);
+    n = (int)(r / v.H);
+}
+
+// ------------------------------------------------------------------------------------------
+// dz = dy * [y > 0]; partial[blockIdx.x][c] = sum over this block's pixels of dz[..., c]
+template <int TX>
+__global__ void __launch_bounds__(256) bias_act_bwd_kernel(TView dy, TView y, TView dz, float* partial,
+                                                           size_t npix) {
+    constexpr int TY = 256 / TX;
+    __shared__ float red[TY][TX + 1];
+    const int tx = threadIdx.x % TX, tyi = threadIdx.x / TX;
+    const int c = blockIdx.y * TX + tx;
+    float sum = 0.f;
+    if (c < dy.C) {
+        for (size_t pix = (size_t)blockIdx.x * TY + tyi; pix < npix; pix += (size_t)gridDim.x * TY) {
+            int n, yy, xx;
+            unflatten_pix(dy, pix, n, yy, xx);
+            float v = dy.p[view_off(dy, n, yy, xx, c)];
+            if (y.p) v = (y.p[view_off(y, n, yy, xx, c)] > 0.f) ? v : 0.f;
+            if (dz.p) dz.p[view_off(dz, n, yy, xx, c)] = v;
+            sum += v;
+        }
+    }
+    red[tyi][tx] = sum;
+    __syncthreads();
+    if (tyi == 0 && partial) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < TY; ++k) s += red[k][tx];
+        if (c < dy.C) partial[(size_t)blockIdx.x * dy.C + c] = s;
+    }
+}
+
+__global__ void reduce_slabs_kernel2(const float* __restrict__ partial, float* __restrict__ out, size_t n,
+                                     int S, int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += partial[(size_t)k * n + e];
+        out[e] = accumulate ? out[e] + s : s;
+    }
+}
+
+int bias_blocks(size_t npix, int TY) { return (int)std::min<size_t>(cdivz(npix, (size_t)TY * 8), 1024); }
+
+int pick_tx(int C) { return C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64)); }
+
+// ------------------------------------------------------------------------------------------
+__global__ void view_axpy_kernel(TView src, TView dst, float alpha, int accumulate, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % src.C);
+        int n, y, x;
+        unflatten_pix(src, e / src.C, n, y, x);
+        const float v = alpha * src.p[view_off(src, n, y, x, c)];
+        const size_t o = view_off(dst, n, y, x, c);
+        dst.p[o] = accumulate ? dst.p[o] + v : v;
+    }
+}
+
+__global__ void flat_axpy4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, float alpha,
+                                  int accumulate, size_t n4) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        float4 v = src[e];
+        v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        if (accumulate) {
+            float4 d = dst[e];
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+        }
+        dst[e] = v;
+    }
+}
+
+__global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                               size_t n, int relu) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        float v = a[e] + b[e];
+        out[e] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+__device__ __forceinline__ float act_f(float x, int kind) {
+    switch (kind) {
+        case ACT_RELU: return fmaxf(x, 0.f);
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        case ACT_TANH: return tanhf(x);
+        case ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case ACT_LEAKY_RELU: return x > 0.f ? x : 0.2f * x;
+        case ACT_SELU: return 1.0507009873554805f * (x > 0.f ? x : 1.6732632423543772f * expm1f(x));
+        case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_df(float x, int kind) {
+    switch (kind) {
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case ACT_SIGMOID: { float s = 1.f / (1.f + expf(-x)); return s * (1.f - s); }
+        case ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
+        case ACT_ELU: return x > 0.f ? 1.f : expf(x);
+        case ACT_LEAKY_RELU: return x > 0.f ? 1.f : 0.2f;
+        case ACT_SELU: return 1.0507009873554805f * (x > 0.f ? 1.f : 1.6732632423543772f * expf(x));
+        case ACT_GELU: {
+            const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        default: return 1.f;
+    }
+}
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int kind) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        y[e] = act_f(x[e], kind);
+}
+__global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                               size_t n, int kind, int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float g = dy[e] * act_df(x[e], kind);
+        dx[e] = accumulate ? dx[e] + g : g;
+    }
+}
+__global__ void fill_kernel(float* p, size_t n, float v) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void maxpool2_fwd_kernel(TView x, TView y, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % y.C);
+        int n, oy, ox;
+        unflatten_pix(y, e / y.C, n, oy, ox);
+        float m = x.p[view_off(x, n, 2 * oy, 2 * ox, c)];
+        m = fmaxf(m, x.p[view_off(x, n, 2 * oy, 2 * ox + 1, c)]);
+        m = fmaxf(m, x.p[view_off(x, n, 2 * oy + 1, 2 * ox, c)]);
+        m = fmaxf(m, x.p[view_off(x, n, 2 * oy + 1, 2 * ox + 1, c)]);
+        y.p[view_off(y, n, oy, ox, c)] = m;
+    }
+}
+// one thread per OUTPUT element writes its 2x2 input window (windows are disjoint -> no atomics);
+// gradient goes to the first maximum in row-major window order.  Rows/cols dropped by the VALID
+// pooling (odd H or W) must have been zero-filled / left untouched by the caller.
+__global__ void maxpool2_bwd_kernel(TView x, TView y, TView dy, TView dx, int accumulate, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % y.C);
+        int n, oy, ox;
+        unflatten_pix(y, e / y.C, n, oy, ox);
+        const float m = y.p[view_off(y, n, oy, ox, c)];
+        const float g = dy.p[view_off(dy, n, oy, ox, c)];
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+            const float xv = x.p[view_off(x, n, iy, ix, c)];
+            float gv = 0.f;
+            if (!found && xv == m) { gv = g; found = true; }
+            const size_t o = view_off(dx, n, iy, ix, c);
+            dx.p[o] = accumulate ? dx.p[o] + gv : gv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_src(int o, float scale, int in_size, int& lo, int& hi, float& f) {
+    const float src = ((float)o + 0.5f) * scale - 0.5f;
+    const float fl = floorf(src);
+    lo = max((int)fl, 0);
+    hi = min((int)ceilf(src), in_size - 1);
+    f = src - fl;
+}
+__global__ void resize_fwd_kernel(TView x, TView y, float sy, float sx, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % y.C);
+        int n, oy, ox;
+        unflatten_pix(y, e / y.C, n, oy, ox);
+        int y0, y1, x0, x1;
+        float fy, fx;
+        bilinear_src(oy, sy, x.H, y0, y1, fy);
+        bilinear_src(ox, sx, x.W, x0, x1, fx);
+        const float v00 = x.p[view_off(x, n, y0, x0, c)], v01 = x.p[view_off(x, n, y0, x1, c)];
+        const float v10 = x.p[view_off(x, n, y1, x0, c)], v11 = x.p[view_off(x, n, y1, x1, c)];
+        const float top = v00 * (1.f - fx) + v01 * fx;
+        const float bot = v10 * (1.f - fx) + v11 * fx;
+        y.p[view_off(y, n, oy, ox, c)] = top * (1.f - fy) + bot * fy;
+    }
+}
+// gather form (deterministic): one thread per INPUT element sums the output pixels that read it
+__global__ void resize_bwd_kernel(TView dy, TView dx, float sy, float sx, int accumulate, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % dx.C);
+        int n, iy, ix;
+        unflatten_pix(dx, e / dx.C, n, iy, ix);
+        // candidate outputs: src in (iy-1, iy+1)  <=>  o in ((iy-0.5)/s-0.5, (iy+1.5)/s-0.5)
+        const int oy_lo = max(0, (int)floorf(((float)iy - 0.5f) / sy - 0.5f) - 1);
+        const int oy_hi = min(dy.H - 1, (int)ceilf(((float)iy + 1.5f) / sy - 0.5f) + 1);
+        const int ox_lo = max(0, (int)floorf(((float)ix - 0.5f) / sx - 0.5f) - 1);
+        const int ox_hi = min(dy.W - 1, (int)ceilf(((float)ix + 1.5f) / sx - 0.5f) + 1);
+        float g = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float fy;
+            bilinear_src(oy, sy, dx.H, y0, y1, fy);
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - fy;
+            if (y1 == iy) wy += fy;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float fx;
+                bilinear_src(ox, sx, dx.W, x0, x1, fx);
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - fx;
+                if (x1 == ix) wx += fx;
+                if (wx == 0.f) continue;
+                g += wy * wx * dy.p[view_off(dy, n, oy, ox, c)];
+            }
+        }
+        const size_t o = view_off(dx, n, iy, ix, c);
+        dx.p[o] = accumulate ? dx.p[o] + g : g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int kLcMax = 8;
+__global__ void localconv_fwd_kernel(TView x, const float* __restrict__ w, const float* __restrict__ b, TView y,
+                                     size_t npix) {
+    const int C = x.C, F = y.C;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+        int n, yy, xx;
+        unflatten_pix(x, pix, n, yy, xx);
+        const size_t hw = (size_t)yy * x.W + xx;
+        float xv[kLcMax];
+        for (int c = 0; c < C; ++c) xv[c] = x.p[view_off(x, n, yy, xx, c)];
+        for (int f = 0; f < F; ++f) {
+            float s = b ? b[hw * F + f] : 0.f;
+            for (int c = 0; c < C; ++c) s += xv[c] * w[(hw * C + c) * F + f];
+            y.p[view_off(y, n, yy, xx, f)] = s;
+        }
+    }
+}
+// one thread per (h,w): loops the batch, so dW / db need no atomics
+__global__ void localconv_bwd_kernel(TView x, const float* __restrict__ w, TView dy, TView dx, int acc_dx,
+                                     float* __restrict__ dw, float* __restrict__ db, int acc_dw) {
+    const int C = x.C, F = dy.C;
+    const size_t nhw = (size_t)x.H * x.W;
+    for (size_t hw = (size_t)blockIdx.x * blockDim.x + threadIdx.x; hw < nhw; hw += (size_t)gridDim.x * blockDim.x) {
+        const int yy = (int)(hw / x.W), xx = (int)(hw % x.W);
+        float wl[kLcMax * kLcMax], gw[kLcMax * kLcMax], gb[kLcMax];
+        for (int i = 0; i < C * F; ++i) { wl[i] = w[hw * C * F + i]; gw[i] = 0.f; }
+        for (int f = 0; f < F; ++f) gb[f] = 0.f;
+        for (int n = 0; n < x.N; ++n) {
+            float xv[kLcMax], gy[kLcMax];
+            for (int c = 0; c < C; ++c) xv[c] = x.p[view_off(x, n, yy, xx, c)];
+            for (int f = 0; f < F; ++f) { gy[f] = dy.p[view_off(dy, n, yy, xx, f)]; gb[f] += gy[f]; }
+            for (int c = 0; c < C; ++c) {
+                float s = 0.f;
+                for (int f = 0; f < F; ++f) { s += gy[f] * wl[c * F + f]; gw[c * F + f] += xv[c] * gy[f]; }
+                if (dx.p) {
+                    const size_t o = view_off(dx, n, yy, xx, c);
+                    dx.p[o] = acc_dx ? dx.p[o] + s : s;
+                }
+            }
+        }
+        for (int i = 0; i < C * F; ++i) dw[hw * C * F + i] = acc_dw ? dw[hw * C * F + i] + gw[i] : gw[i];
+        if (db) for (int f = 0; f < F; ++f) db[hw * F + f] = acc_dw ? db[hw * F + f] + gb[f] : gb[f];
+    }
+}
+
+inline int ew_blocks(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 8192)); }
+inline bool plain_contig(const TView& v) { return v.d2s <= 1 && v.ld == v.C; }
+
+}  // namespace
+
+// =============================================================================================
+size_t bias_grad_workspace_bytes(const TView& dy) {
+    const size_t npix = (size_t)dy.N * dy.H * dy.W;
+    const int TX = pick_tx(dy.C);
+    return (size_t)bias_blocks(npix, 256 / TX) * dy.C * sizeof(float);
+}
+
+void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TView& dz, float* db,
+                       int accumulate_db, float* workspace, size_t workspace_bytes) {
+    const size_t npix = (size_t)dy.N * dy.H * dy.W;
+    const int TX = pick_tx(dy.C);
+    const int TY = 256 / TX;
+    const int nb = bias_blocks(npix, TY);
+    float* partial = nullptr;
+    if (db) {
+        DL4DS_REQUIRE(workspace_bytes >= (size_t)nb * dy.C * sizeof(float), "bias grad workspace too small");
+        partial = workspace;
+    }
+    dim3 grid((unsigned)nb, (unsigned)cdiv(dy.C, TX));
+    switch (TX) {
+        case 8: hipLaunchKernelGGL(bias_act_bwd_kernel<8>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+        case 16: hipLaunchKernelGGL(bias_act_bwd_kernel<16>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+        case 32: hipLaunchKernelGGL(bias_act_bwd_kernel<32>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+        default: hipLaunchKernelGGL(bias_act_bwd_kernel<64>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+    }
+    HIP_CHECK(hipGetLastError());
+    if (db) {
+        hipLaunchKernelGGL(reduce_slabs_kernel2, dim3(cdiv(dy.C, 256)), dim3(256), 0, s, partial, db,
+                           (size_t)dy.C, nb, accumulate_db);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, int accumulate) {
+    DL4DS_REQUIRE(src.N == dst.N && src.H == dst.H && src.W == dst.W && src.C == dst.C, "view_axpy: shape mismatch");
+    const size_t total = (size_t)src.N * src.H * src.W * src.C;
+    if (total == 0) return;
+    if (plain_contig(src) && plain_contig(dst) && (total & 3) == 0 && ((((uintptr_t)src.p) | ((uintptr_t)dst.p)) & 15) == 0) {
+        hipLaunchKernelGGL(flat_axpy4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(src.p), reinterpret_cast<float4*>(dst.p), alpha, accumulate, total / 4);
+    } else {
+        hipLaunchKernelGGL(view_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, dst, alpha, accumulate, total);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void add_act(hipStream_t s, const float* a, const float* b, float* out, size_t n, int relu) {
+    hipLaunchKernelGGL(add_act_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, out, n, relu);
+    HIP_CHECK(hipGetLastError());
+}
+void act_forward(hipStream_t s, const float* x, float* y, size_t n, int kind) {
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n, kind);
+    HIP_CHECK(hipGetLastError());
+}
+void act_backward(hipStream_t s, const float* x, const float* dy, float* dx, size_t n, int kind, int accumulate) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, dy, dx, n, kind, accumulate);
+    HIP_CHECK(hipGetLastError());
+}
+void fill(hipStream_t s, float* p, size_t n, float v) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, n, v);
+    HIP_CHECK(hipGetLastError());
+}
+
+void depth_to_space(hipStream_t s, const float* x, float* y, int N, int H, int W, int C, int r) {
+    TView src = make_view(const_cast<float*>(x), N, H, W, C);
+    TView dst = make_view_d2s(y, N, H, W, C, r);
+    view_axpy(s, src, dst, 1.f, 0);
+}
+void space_to_depth(hipStream_t s, const float* y, float* x, int N, int H, int W, int C, int r) {
+    TView src = make_view_d2s(const_cast<float*>(y), N, H, W, C, r);
+    TView dst = make_view(x, N, H, W, C);
+    view_axpy(s, src, dst, 1.f, 0);
+}
+
+void maxpool2_forward(hipStream_t s, const TView& x, const TView& y) {
+    DL4DS_REQUIRE(y.H == x.H / 2 && y.W == x.W / 2 && y.C == x.C && y.N == x.N, "maxpool2: shapes");
+    const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, total);
+    HIP_CHECK(hipGetLastError());
+}
+void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TView& dy, const TView& dx, int accumulate) {
+    DL4DS_REQUIRE((x.H % 2 == 0 && x.W % 2 == 0) || accumulate,
+                  "maxpool2 backward with odd sizes needs a pre-zeroed accumulate target");
+    const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, dy, dx, accumulate, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void resize_bilinear_forward(hipStream_t s, const TView& x, const TView& y) {
+    const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
+                       (float)x.W / (float)y.W, total);
+    HIP_CHECK(hipGetLastError());
+}
+void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate) {
+    const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
+                       (float)dx.W / (float)dy.W, accumulate, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void localconv_forward(hipStream_t s, const TView& x, const float* w, const float* b, const TView& y) {
+    DL4DS_REQUIRE(x.C <= kLcMax && y.C <= kLcMax, "localconv: at most 8 channels in/out");
+    const size_t npix = (size_t)x.N * x.H * x.W;
+    hipLaunchKernelGGL(localconv_fwd_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, w, b, y, npix);
+    HIP_CHECK(hipGetLastError());
+}
+void localconv_backward(hipStream_t s, const TView& x, const float* w, const TView& dy, const TView& dx,
+                        int accumulate_dx, float* dw, float* db, int accumulate_dw) {
+    DL4DS_REQUIRE(x.C <= kLcMax && dy.C <= kLcMax, "localconv: at most 8 channels in/out");
+    const size_t nhw = (size_t)x.H * x.W;
+    hipLaunchKernelGGL(localconv_bwd_kernel, dim3(ew_blocks(nhw)), dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db,
+                       accumulate_dw);
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,116 @@
+// Static op-list runtime for the dl4ds conv-SR train step on one MI355X.
+//
+// The Python builders (dl4ds_amd/models/*.py -- same signatures as dl4ds.models.*) lower a model into
+// this graph through the C ABI: tensors (NHWC, batch = B * nmul), parameters (slices of ONE flat fp32
+// arena, so Adam and the RCCL all-reduce each touch a single buffer), and ops with hand-written
+// forward/backward.  No autograd tape, no allocator calls inside a step, one HIP stream.
+#pragma once
+#include "ops.h"
+#include <memory>
+#include <vector>
+
+struct Graph;
+
+struct GTensor {
+    int H = 0, W = 0, C = 0;
+    int nmul = 1;              // batch multiplier: N = B * nmul (time_window for TimeDistributed tensors)
+    bool requires_grad = true;
+    bool is_input = false;
+    float* data = nullptr;
+    float* grad = nullptr;
+    bool grad_written = false;
+    size_t per_sample() const { return (size_t)nmul * H * W * C; }
+};
+
+struct GParam {
+    size_t offset = 0, n = 0;
+    bool grad_written = false;
+};
+
+struct BwdCtx {
+    int B;                 // batch of the forward pass the saved activations belong to
+    int b_off, b_cnt;      // sample range to back-propagate (CGAN: the "fake" half of a 2B batch)
+    bool param_grads;      // compute parameter gradients
+    bool input_grads;      // propagate into tensors flagged is_input (CGAN generator path)
+};
+
+struct GOp {
+    virtual ~GOp() {}
+    virtual void forward(Graph& g, int B, bool training) = 0;
+    virtual void backward(Graph& g, const BwdCtx& c) = 0;
+    virtual size_t workspace_bytes(Graph& g, int B) { return 0; }
+    virtual size_t saved_floats_per_sample(Graph& g) { return 0; }   // op-private saved activations
+    float* saved = nullptr;
+    virtual void on_finalize(Graph& g) {}
+    const char* kind = "op";
+};
+
+struct Graph {
+    std::vector<GTensor> tensors;
+    std::vector<GParam> params;
+    std::vector<std::unique_ptr<GOp>> ops;
+    std::vector<int> inputs, outputs;
+    size_t n_params = 0;
+    float* W = nullptr;        // parameter arena
+    float* G = nullptr;        // gradient arena
+    float* Wt = nullptr;       // scratch arena (flipped/transposed or re-arranged weights for dgrad/deconv)
+    size_t wt_floats = 0;
+    bool own_arena = true;
+    int maxB = 0;
+    bool finalized = false;
+    float* workspace = nullptr;
+    size_t workspace_bytes = 0;
+    hipStream_t stream = nullptr;
+    std::vector<float*> allocations;
+
+    ~Graph();
+    int add_tensor(int H, int W, int C, int nmul, bool requires_grad, bool is_input);
+    int add_param(size_t n);
+    size_t reserve_wt(size_t floats) { size_t o = wt_floats; wt_floats += (floats + 3) & ~(size_t)3; return o; }
+    void finalize();
+    void prepare(int B);                    // (re)allocate activations / workspace for batch B
+    void forward(int B, bool training);
+    void zero_grad_flags();
+    void backward(const BwdCtx& c);
+    TView view(int tid, int B, bool grad, int b_off = 0, int b_cnt = -1) const;
+    float* wp(int pid) const { return W + params[pid].offset; }
+    float* gp(int pid) const { return G + params[pid].offset; }
+};
+
+// ---- op constructors (graph.hip)
+int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu, int d2s);
+int g_conv2d_transpose(Graph& g, int in, int w, int KS, int stride, int Cout, int relu);
+int g_chatt(Graph& g, int in, int w1, int b1, int w2, int b2, int Cr, int mode5d_T);
+int g_concat(Graph& g, const int* ins, int n);
+int g_add(Graph& g, int a, int b, int relu);
+int g_act(Graph& g, int in, int kind);
+int g_maxpool2(Graph& g, int in);
+int g_resize(Graph& g, int in, int Ho, int Wo);
+int g_localconv(Graph& g, int in, int w, int b, int F);
+int g_repeat_time(Graph& g, int in, int T);
+int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, int relu);
+int g_gap(Graph& g, int in, int T);
+int g_dense(Graph& g, int in, int w, int b, int F, int act);
+int g_dropout(Graph& g, int in, float rate);
+
+// ---- trainer (trainer.hip)
+struct AdamCfg {
+    float lr0 = 1e-3f, lr1 = 1e-3f;
+    double boundary = 1e30;        // PiecewiseConstantDecay([boundary],[lr0,lr1]) -- supervised.py:340-346
+    float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f;
+};
+
+struct Trainer {
+    Graph* g = nullptr;
+    AdamCfg cfg;
+    float* m = nullptr;
+    float* v = nullptr;
+    long step = 0;                 // optimizer.iterations
+    int loss_kind = LOSS_MAE;
+    float* d_loss = nullptr;       // device scalars [8]
+    float* loss_ws = nullptr;
+    size_t loss_ws_bytes = 0;
+    float* y_true = nullptr;
+    size_t y_true_floats = 0;
+    ~Trainer();
+};

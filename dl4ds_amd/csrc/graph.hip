@@ -1,0 +1,491 @@
+// Graph runtime + op implementations (forward and hand-written backward) -- see graph.h.
+#include "graph.h"
+#include <algorithm>
+#include <cstring>
+
+// ============================================================================================ Graph
+Graph::~Graph() {
+    for (float* p : allocations) (void)hipFree(p);
+    if (own_arena) {
+        if (W) (void)hipFree(W);
+        if (G) (void)hipFree(G);
+    }
+    if (Wt) (void)hipFree(Wt);
+    if (workspace) (void)hipFree(workspace);
+}
+
+int Graph::add_tensor(int H, int W_, int C, int nmul, bool requires_grad, bool is_input) {
+    DL4DS_REQUIRE(!finalized, "graph already finalized");
+    DL4DS_REQUIRE(H > 0 && W_ > 0 && C > 0 && nmul > 0, "bad tensor shape");
+    GTensor t;
+    t.H = H; t.W = W_; t.C = C; t.nmul = nmul; t.requires_grad = requires_grad; t.is_input = is_input;
+    tensors.push_back(t);
+    if (is_input) inputs.push_back((int)tensors.size() - 1);
+    return (int)tensors.size() - 1;
+}
+
+int Graph::add_param(size_t n) {
+    DL4DS_REQUIRE(!finalized, "graph already finalized");
+    GParam p;
+    p.offset = n_params;
+    p.n = n;
+    n_params += (n + 3) & ~(size_t)3;          // keep every slice 16-byte aligned for float4 access
+    params.push_back(p);
+    return (int)params.size() - 1;
+}
+
+void Graph::finalize() {
+    DL4DS_REQUIRE(!finalized, "graph already finalized");
+    if (own_arena) {
+        const size_t bytes = std::max<size_t>(n_params, 4) * sizeof(float);
+        HIP_CHECK(hipMalloc((void**)&W, bytes));
+        HIP_CHECK(hipMalloc((void**)&G, bytes));
+        HIP_CHECK(hipMemset(W, 0, bytes));
+        HIP_CHECK(hipMemset(G, 0, bytes));
+    }
+    for (auto& op : ops) op->on_finalize(*this);
+    if (wt_floats) HIP_CHECK(hipMalloc((void**)&Wt, wt_floats * sizeof(float)));
+    finalized = true;
+}
+
+void Graph::prepare(int B) {
+    DL4DS_REQUIRE(finalized, "graph not finalized");
+    DL4DS_REQUIRE(B > 0, "batch must be positive");
+    if (B <= maxB) return;
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (float* p : allocations) HIP_CHECK(hipFree(p));
+    allocations.clear();
+    if (workspace) { HIP_CHECK(hipFree(workspace)); workspace = nullptr; }
+    // one slab for all activations + gradients + op-private saved buffers (288 GB HBM: no reuse games)
+    size_t total = 0;
+    auto bump = [&](size_t floats) { size_t o = total; total += (floats + 63) & ~(size_t)63; return o; };
+    std::vector<size_t> doff(tensors.size()), goff(tensors.size()), soff(ops.size());
+    for (size_t i = 0; i < tensors.size(); ++i) {
+        doff[i] = bump(tensors[i].per_sample() * B);
+        goff[i] = (tensors[i].requires_grad) ? bump(tensors[i].per_sample() * B) : (size_t)-1;
+    }
+    for (size_t i = 0; i < ops.size(); ++i) soff[i] = bump(ops[i]->saved_floats_per_sample(*this) * B + 64);
+    float* slab = nullptr;
+    HIP_CHECK(hipMalloc((void**)&slab, total * sizeof(float)));
+    allocations.push_back(slab);
+    for (size_t i = 0; i < tensors.size(); ++i) {
+        tensors[i].data = slab + doff[i];
+        tensors[i].grad = (goff[i] == (size_t)-1) ? nullptr : slab + goff[i];
+    }
+    for (size_t i = 0; i < ops.size(); ++i) ops[i]->saved = slab + soff[i];
+    size_t ws = 1 << 20;
+    for (auto& op : ops) ws = std::max(ws, op->workspace_bytes(*this, B));
+    workspace_bytes = ws;
+    HIP_CHECK(hipMalloc((void**)&workspace, ws));
+    maxB = B;
+}
+
+TView Graph::view(int tid, int B, bool grad, int b_off, int b_cnt) const {
+    const GTensor& t = tensors[tid];
+    float* base = grad ? t.grad : t.data;
+    DL4DS_REQUIRE(base != nullptr, "tensor buffer missing (no grad buffer / graph not prepared)");
+    const int cnt = (b_cnt < 0) ? B : b_cnt;
+    return make_view(base + (size_t)b_off * t.per_sample(), cnt * t.nmul, t.H, t.W, t.C);
+}
+
+void Graph::forward(int B, bool training) {
+    prepare(B);
+    for (auto& op : ops) op->forward(*this, B, training);
+}
+
+void Graph::zero_grad_flags() {
+    for (auto& t : tensors) t.grad_written = false;
+    for (auto& p : params) p.grad_written = false;
+}
+
+void Graph::backward(const BwdCtx& c) {
+    for (auto& t : tensors) t.grad_written = false;
+    for (int o : outputs) tensors[o].grad_written = true;      // seeded by the loss
+    for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i]->backward(*this, c);
+    if (c.param_grads) {
+        // parameters never reached by the backward pass get an explicit zero gradient
+        for (auto& p : params)
+            if (!p.grad_written) { fill(stream, G + p.offset, p.n, 0.f); p.grad_written = true; }
+    }
+}
+
+namespace {
+
+inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
+    const GTensor& t = g.tensors[tid];
+    return t.requires_grad && (!t.is_input || c.input_grads);
+}
+
+// ============================================================================================ Conv2D
+struct ConvOp : GOp {
+    int in, w, b, add, out, KS, Cout, relu, d2s;
+    size_t wt_off = 0;
+    ConvOp() { kind = "conv2d"; }
+    void on_finalize(Graph& g) override { wt_off = g.reserve_wt(g.params[w].n); }
+    TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        float* base = (grad ? to.grad : to.data) + (size_t)bo * to.per_sample();
+        const int N = (bc < 0 ? B : bc) * to.nmul;
+        if (d2s > 1) return make_view_d2s(base, N, ti.H, ti.W, Cout, d2s);
+        return make_view(base, N, ti.H, ti.W, Cout);
+    }
+    void forward(Graph& g, int B, bool) override {
+        ConvEpilogue ep;
+        ep.bias = (b >= 0) ? g.wp(b) : nullptr;
+        if (add >= 0) ep.add = g.view(add, B, false);
+        ep.relu = relu;
+        conv2d_forward(g.stream, g.view(in, B, false), g.wp(w), KS, out_view(g, false, B, 0, -1), ep);
+    }
+    size_t workspace_bytes(Graph& g, int B) override {
+        TView x = g.view(in, B, false);
+        TView dz = make_view(nullptr, x.N, x.H, x.W, Cout);
+        return std::max(conv2d_wgrad_workspace_bytes(x, dz, KS), bias_grad_workspace_bytes(dz));
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;      // nothing flowed into this op
+        TView dY = out_view(g, true, c.B, c.b_off, c.b_cnt);
+        const bool need_db = c.param_grads && b >= 0;
+        if (relu || need_db) {
+            TView none{nullptr, 0, 0, 0, 0, 0, 0, 0};
+            TView Y = out_view(g, false, c.B, c.b_off, c.b_cnt);
+            bias_act_backward(g.stream, dY, relu ? Y : none, relu ? dY : none, need_db ? g.gp(b) : nullptr,
+                              need_db ? (int)g.params[b].grad_written : 0, g.workspace, g.workspace_bytes);
+            if (need_db) g.params[b].grad_written = true;
+        }
+        if (add >= 0 && wants_grad(g, add, c)) {
+            view_axpy(g.stream, dY, g.view(add, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[add].grad_written);
+            g.tensors[add].grad_written = true;
+        }
+        if (c.param_grads) {
+            conv2d_wgrad(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, g.gp(w),
+                         g.params[w].grad_written, g.workspace, g.workspace_bytes);
+            g.params[w].grad_written = true;
+        }
+        if (wants_grad(g, in, c)) {
+            float* wt = g.Wt + wt_off;
+            conv2d_dgrad_weights(g.stream, g.wp(w), wt, KS, g.tensors[in].C, Cout);
+            ConvEpilogue ep;
+            ep.accumulate = g.tensors[in].grad_written;
+            conv2d_forward(g.stream, dY, wt, KS, g.view(in, c.B, true, c.b_off, c.b_cnt), ep);
+            g.tensors[in].grad_written = true;
+        }
+    }
+};
+
+// ============================================================================================ ChannelAttention
+struct ChAttOp : GOp {
+    int in, out, w1, b1, w2, b2, Cr, T5;   // T5 > 0: 5-D mode (B,T,H,W,C), mean over (T,H)
+    ChAttOp() { kind = "chatt"; }
+    AttShape shape(Graph& g, int B) {
+        const GTensor& t = g.tensors[in];
+        AttShape s;
+        if (T5 > 0) { s.G = B; s.R = t.nmul * t.H; s.P = t.W; }
+        else { s.G = B * t.nmul; s.R = t.H * t.W; s.P = 1; }
+        s.C = t.C; s.Cr = Cr;
+        return s;
+    }
+    size_t saved_floats_per_sample(Graph& g) override {
+        const GTensor& t = g.tensors[in];
+        const size_t inst = (T5 > 0) ? (size_t)t.W : (size_t)t.nmul;
+        return inst * (2 * (size_t)t.C + Cr);
+    }
+    size_t workspace_bytes(Graph& g, int B) override { return chatt_workspace_bytes(shape(g, B)); }
+    void ptrs(Graph& g, int B, float*& mean, float*& hidden, float*& scale) {
+        AttShape s = shape(g, B);
+        const size_t inst = (size_t)s.G * s.P;
+        mean = saved; scale = mean + inst * s.C; hidden = scale + inst * s.C;
+    }
+    void forward(Graph& g, int B, bool) override {
+        float *mean, *hidden, *scale;
+        ptrs(g, B, mean, hidden, scale);
+        chatt_forward(g.stream, g.tensors[in].data, g.tensors[out].data, shape(g, B), g.wp(w1), g.wp(b1), g.wp(w2),
+                      g.wp(b2), mean, hidden, scale, g.workspace);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        DL4DS_REQUIRE(c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B), "chatt: partial-batch backward not supported");
+        float *mean, *hidden, *scale;
+        ptrs(g, c.B, mean, hidden, scale);
+        const bool dx = wants_grad(g, in, c);
+        DL4DS_REQUIRE(dx, "chatt: input must require grad");
+        const int accw = g.params[w1].grad_written;
+        chatt_backward(g.stream, g.tensors[in].data, g.tensors[out].grad, g.tensors[in].grad,
+                       g.tensors[in].grad_written, shape(g, c.B), g.wp(w1), g.wp(w2), mean, hidden, scale,
+                       g.gp(w1), g.gp(b1), g.gp(w2), g.gp(b2), accw, g.workspace);
+        g.tensors[in].grad_written = true;
+        g.params[w1].grad_written = g.params[b1].grad_written = true;
+        g.params[w2].grad_written = g.params[b2].grad_written = true;
+    }
+};
+
+// ============================================================================================ Concat
+struct ConcatOp : GOp {
+    std::vector<int> ins;
+    int out;
+    ConcatOp() { kind = "concat"; }
+    TView slice(Graph& g, int B, bool grad, int k, int bo, int bc) {
+        TView v = g.view(out, B, grad, bo, bc);
+        int off = 0;
+        for (int i = 0; i < k; ++i) off += g.tensors[ins[i]].C;
+        v.p += off;
+        v.C = g.tensors[ins[k]].C;
+        v.vec = v.vec && ((off & 3) == 0) && ((v.C & 3) == 0);
+        return v;
+    }
+    void forward(Graph& g, int B, bool) override {
+        for (size_t k = 0; k < ins.size(); ++k)
+            view_axpy(g.stream, g.view(ins[k], B, false), slice(g, B, false, (int)k, 0, -1), 1.f, 0);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        for (size_t k = 0; k < ins.size(); ++k) {
+            if (!wants_grad(g, ins[k], c)) continue;
+            view_axpy(g.stream, slice(g, c.B, true, (int)k, c.b_off, c.b_cnt),
+                      g.view(ins[k], c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[ins[k]].grad_written);
+            g.tensors[ins[k]].grad_written = true;
+        }
+    }
+};
+
+// ============================================================================================ Add (+ReLU)
+struct AddOp : GOp {
+    int a, b, out, relu;
+    AddOp() { kind = "add"; }
+    void forward(Graph& g, int B, bool) override {
+        add_act(g.stream, g.tensors[a].data, g.tensors[b].data, g.tensors[out].data,
+                g.tensors[out].per_sample() * B, relu);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        TView dY = g.view(out, c.B, true, c.b_off, c.b_cnt);
+        if (relu) {
+            TView none{nullptr, 0, 0, 0, 0, 0, 0, 0};
+            bias_act_backward(g.stream, dY, g.view(out, c.B, false, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace,
+                              g.workspace_bytes);
+        }
+        for (int t : {a, b}) {
+            if (!wants_grad(g, t, c)) continue;
+            view_axpy(g.stream, dY, g.view(t, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[t].grad_written);
+            g.tensors[t].grad_written = true;
+        }
+    }
+};
+
+// ============================================================================================ Activation
+struct ActOp : GOp {
+    int in, out, act;
+    ActOp() { kind = "act"; }
+    void forward(Graph& g, int B, bool) override {
+        act_forward(g.stream, g.tensors[in].data, g.tensors[out].data, g.tensors[out].per_sample() * B, act);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        const size_t ps = g.tensors[in].per_sample();
+        const size_t off = (size_t)c.b_off * ps;
+        const size_t n = (size_t)(c.b_cnt < 0 ? c.B : c.b_cnt) * ps;
+        act_backward(g.stream, g.tensors[in].data + off, g.tensors[out].grad + off, g.tensors[in].grad + off, n, act,
+                     g.tensors[in].grad_written);
+        g.tensors[in].grad_written = true;
+    }
+};
+
+// ============================================================================================ MaxPool 2x2
+struct MaxPoolOp : GOp {
+    int in, out;
+    MaxPoolOp() { kind = "maxpool2"; }
+    void forward(Graph& g, int B, bool) override {
+        maxpool2_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        const GTensor& t = g.tensors[in];
+        TView dx = g.view(in, c.B, true, c.b_off, c.b_cnt);
+        int acc = t.grad_written;
+        if (!acc && ((t.H | t.W) & 1)) {    // rows/cols dropped by VALID pooling receive zero gradient
+            fill(g.stream, dx.p, (size_t)dx.N * dx.H * dx.W * dx.C, 0.f);
+            acc = 1;
+        }
+        maxpool2_backward(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), g.view(out, c.B, false, c.b_off, c.b_cnt),
+                          g.view(out, c.B, true, c.b_off, c.b_cnt), dx, acc);
+        g.tensors[in].grad_written = true;
+    }
+};
+
+// ============================================================================================ Bilinear resize
+struct ResizeOp : GOp {
+    int in, out;
+    ResizeOp() { kind = "resize"; }
+    void forward(Graph& g, int B, bool) override {
+        resize_bilinear_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        resize_bilinear_backward(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt),
+                                 g.view(in, c.B, true, c.b_off, c.b_cnt), g.tensors[in].grad_written);
+        g.tensors[in].grad_written = true;
+    }
+};
+
+// ============================================================================================ LocallyConnected 1x1
+struct LocalConvOp : GOp {
+    int in, out, w, b;
+    LocalConvOp() { kind = "localconv"; }
+    void forward(Graph& g, int B, bool) override {
+        localconv_forward(g.stream, g.view(in, B, false), g.wp(w), b >= 0 ? g.wp(b) : nullptr, g.view(out, B, false));
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        DL4DS_REQUIRE(c.param_grads, "localconv: backward without parameter gradients not supported");
+        const bool dx = wants_grad(g, in, c);
+        TView dxv{nullptr, 0, 0, 0, 0, 0, 0, 0};
+        if (dx) dxv = g.view(in, c.B, true, c.b_off, c.b_cnt);
+        localconv_backward(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), g.wp(w),
+                           g.view(out, c.B, true, c.b_off, c.b_cnt), dxv, g.tensors[in].grad_written, g.gp(w),
+                           b >= 0 ? g.gp(b) : nullptr, g.params[w].grad_written);
+        if (dx) g.tensors[in].grad_written = true;
+        g.params[w].grad_written = true;
+        if (b >= 0) g.params[b].grad_written = true;
+    }
+};
+
+// ============================================================================================ expand+repeat over T
+// tf.expand_dims(s,1); tf.repeat(s, T, axis=1)  (spt_postups.py:139-140): (B,H,W,C) -> (B,T,H,W,C)
+struct RepeatTimeOp : GOp {
+    int in, out, T;
+    RepeatTimeOp() { kind = "repeat_time"; }
+    void forward(Graph& g, int B, bool) override {
+        const size_t ps = g.tensors[in].per_sample();
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t)
+                HIP_CHECK(hipMemcpyAsync(g.tensors[out].data + ((size_t)b * T + t) * ps, g.tensors[in].data + (size_t)b * ps,
+                                         ps * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        const GTensor& ti = g.tensors[in];
+        const size_t ps = ti.per_sample();
+        const int b1 = c.b_off + (c.b_cnt < 0 ? c.B : c.b_cnt);
+        for (int b = c.b_off; b < b1; ++b)
+            for (int t = 0; t < T; ++t) {
+                TView src = make_view(g.tensors[out].grad + ((size_t)b * T + t) * ps, 1, ti.H, ti.W, ti.C);
+                TView dst = make_view(ti.grad + (size_t)b * ps, 1, ti.H, ti.W, ti.C);
+                view_axpy(g.stream, src, dst, 1.f, (t > 0) || ti.grad_written);
+            }
+        g.tensors[in].grad_written = true;
+    }
+};
+
+template <class T>
+T* push(Graph& g) {
+    T* p = new T();
+    g.ops.emplace_back(p);
+    return p;
+}
+
+}  // namespace
+
+// ============================================================================================ constructors
+int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu, int d2s) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(KS == 1 || KS == 3 || KS == 5, "conv2d: kernel size must be 1, 3 or 5");
+    DL4DS_REQUIRE(g.params.at(w).n == (size_t)KS * KS * ti.C * Cout, "conv2d: kernel parameter size mismatch");
+    if (b >= 0) DL4DS_REQUIRE(g.params.at(b).n == (size_t)Cout, "conv2d: bias size mismatch");
+    int out;
+    if (d2s > 1) {
+        DL4DS_REQUIRE(Cout % (d2s * d2s) == 0, "conv2d: Cout not divisible by r^2");
+        DL4DS_REQUIRE(add < 0, "conv2d: residual add cannot be combined with depth_to_space");
+        out = g.add_tensor(ti.H * d2s, ti.W * d2s, Cout / (d2s * d2s), ti.nmul, true, false);
+    } else {
+        out = g.add_tensor(ti.H, ti.W, Cout, ti.nmul, true, false);
+    }
+    if (add >= 0) {
+        const GTensor& ta = g.tensors.at(add);
+        DL4DS_REQUIRE(ta.H == ti.H && ta.W == ti.W && ta.C == Cout && ta.nmul == ti.nmul, "conv2d: add shape mismatch");
+    }
+    ConvOp* op = push<ConvOp>(g);
+    op->in = in; op->w = w; op->b = b; op->add = add; op->out = out; op->KS = KS; op->Cout = Cout; op->relu = relu;
+    op->d2s = d2s;
+    return out;
+}
+
+int g_chatt(Graph& g, int in, int w1, int b1, int w2, int b2, int Cr, int mode5d_T) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(g.params.at(w1).n == (size_t)ti.C * Cr && g.params.at(w2).n == (size_t)Cr * ti.C, "chatt: kernel sizes");
+    DL4DS_REQUIRE(g.params.at(b1).n == (size_t)Cr && g.params.at(b2).n == (size_t)ti.C, "chatt: bias sizes");
+    if (mode5d_T > 0) DL4DS_REQUIRE(ti.nmul == mode5d_T, "chatt: 5-D mode needs nmul == time_window");
+    const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
+    ChAttOp* op = push<ChAttOp>(g);
+    op->in = in; op->out = out; op->w1 = w1; op->b1 = b1; op->w2 = w2; op->b2 = b2; op->Cr = Cr; op->T5 = mode5d_T;
+    return out;
+}
+
+int g_concat(Graph& g, const int* ins, int n) {
+    DL4DS_REQUIRE(n >= 2, "concat: need at least two inputs");
+    const GTensor t0 = g.tensors.at(ins[0]);
+    int C = 0;
+    for (int i = 0; i < n; ++i) {
+        const GTensor& t = g.tensors.at(ins[i]);
+        DL4DS_REQUIRE(t.H == t0.H && t.W == t0.W && t.nmul == t0.nmul,
+                      "concat: spatial sizes differ (PadConcat zero-padding is not implemented yet)");
+        C += t.C;
+    }
+    const int out = g.add_tensor(t0.H, t0.W, C, t0.nmul, true, false);
+    ConcatOp* op = push<ConcatOp>(g);
+    op->ins.assign(ins, ins + n);
+    op->out = out;
+    return out;
+}
+
+int g_add(Graph& g, int a, int b, int relu) {
+    const GTensor ta = g.tensors.at(a), tb = g.tensors.at(b);
+    DL4DS_REQUIRE(ta.H == tb.H && ta.W == tb.W && ta.C == tb.C && ta.nmul == tb.nmul, "add: shape mismatch");
+    const int out = g.add_tensor(ta.H, ta.W, ta.C, ta.nmul, true, false);
+    AddOp* op = push<AddOp>(g);
+    op->a = a; op->b = b; op->out = out; op->relu = relu;
+    return out;
+}
+
+int g_act(Graph& g, int in, int kind) {
+    const GTensor ti = g.tensors.at(in);
+    const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
+    ActOp* op = push<ActOp>(g);
+    op->in = in; op->out = out; op->act = kind;
+    return out;
+}
+
+int g_maxpool2(Graph& g, int in) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(ti.H >= 2 && ti.W >= 2, "maxpool2: grid too small");
+    const int out = g.add_tensor(ti.H / 2, ti.W / 2, ti.C, ti.nmul, true, false);
+    MaxPoolOp* op = push<MaxPoolOp>(g);
+    op->in = in; op->out = out;
+    return out;
+}
+
+int g_resize(Graph& g, int in, int Ho, int Wo) {
+    const GTensor ti = g.tensors.at(in);
+    const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
+    ResizeOp* op = push<ResizeOp>(g);
+    op->in = in; op->out = out;
+    return out;
+}
+
+int g_localconv(Graph& g, int in, int w, int b, int F) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(g.params.at(w).n == (size_t)ti.H * ti.W * ti.C * F, "localconv: kernel size mismatch");
+    if (b >= 0) DL4DS_REQUIRE(g.params.at(b).n == (size_t)ti.H * ti.W * F, "localconv: bias size mismatch");
+    const int out = g.add_tensor(ti.H, ti.W, F, ti.nmul, true, false);
+    LocalConvOp* op = push<LocalConvOp>(g);
+    op->in = in; op->out = out; op->w = w; op->b = b;
+    return out;
+}
+
+int g_repeat_time(Graph& g, int in, int T) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(ti.nmul == 1, "repeat_time: input must be a per-sample tensor");
+    const int out = g.add_tensor(ti.H, ti.W, ti.C, T, true, false);
+    RepeatTimeOp* op = push<RepeatTimeOp>(g);
+    op->in = in; op->out = out; op->T = T;
+    return out;
+}

@@ -1,0 +1,89 @@
+// Internal C++ launch API of the gfx950 kernels (one stream argument everywhere; no hidden syncs).
+#pragma once
+#include "common.h"
+
+// ----------------------------------------------------------------------------- conv (conv.hip)
+// y = epilogue(conv_same_stride1(x, w)) ; w is HWIO flattened [KS*KS][Cin][Cout]
+struct ConvEpilogue {
+    const float* bias = nullptr;   // [Cout] or null
+    TView add{nullptr, 0, 0, 0, 0, 0, 0, 0};    // optional residual added before the activation
+    TView mask{nullptr, 0, 0, 0, 0, 0, 0, 0};   // optional: result zeroed where mask <= 0 (ReLU backward)
+    int relu = 0;
+    int accumulate = 0;            // out += result (gradient accumulation)
+};
+void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
+                    const ConvEpilogue& ep);
+// wt[(KS*KS-1-tap)][co][ci] = w[tap][ci][co] : conv2d_forward(dz, wt) == dgrad
+void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int Cin, int Cout);
+// dw[tap][ci][co] (+)= sum_{n,y,x} x[n,y+ky-p,x+kx-p,ci] * dz[n,y,x,co]
+size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS);
+void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate,
+                  float* workspace, size_t workspace_bytes);
+// Conv2DTranspose(k, stride s, 'same', no bias), kernel HWOI [k*k][Cout][Cin] (blocks.py:508-516)
+void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, int KS, int stride,
+                              const TView& out, int relu, float* workspace, size_t workspace_bytes);
+void conv2d_transpose_dgrad(hipStream_t s, const TView& dz, const float* w, int KS, int stride,
+                            const TView& dx, int accumulate, float* workspace, size_t workspace_bytes);
+void conv2d_transpose_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, int stride,
+                            float* dw, int accumulate, float* workspace, size_t workspace_bytes);
+size_t conv2d_transpose_workspace_bytes(const TView& in, const TView& out, int KS, int stride);
+
+// ------------------------------------------------------------------- elementwise (elementwise.hip)
+// dz = dy * (y > 0 ? 1 : 0) (if y.p) written to dz (may alias dy); db[c] (+)= sum dz[...,c] (if db)
+size_t bias_grad_workspace_bytes(const TView& dy);
+void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TView& dz, float* db,
+                       int accumulate_db, float* workspace, size_t workspace_bytes);
+// dst (+)= alpha * src  (same logical shape; either side may be a strided / d2s view)
+void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, int accumulate);
+// out = act(a + b)
+void add_act(hipStream_t s, const float* a, const float* b, float* out, size_t n, int relu);
+// in-place / out-of-place activation forward y = f(x) and backward dx (+)= dy * f'(x)
+enum ActKind { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_ELU = 4,
+               ACT_LEAKY_RELU = 5, ACT_SELU = 6, ACT_GELU = 7 };
+void act_forward(hipStream_t s, const float* x, float* y, size_t n, int kind);
+void act_backward(hipStream_t s, const float* x, const float* dy, float* dx, size_t n, int kind,
+                  int accumulate);
+void fill(hipStream_t s, float* p, size_t n, float v);
+// depth_to_space standalone (used by tests and unfused fallbacks)
+void depth_to_space(hipStream_t s, const float* x, float* y, int N, int H, int W, int C, int r);
+void space_to_depth(hipStream_t s, const float* y, float* x, int N, int H, int W, int C, int r);
+// MaxPooling2D(2,2) valid
+void maxpool2_forward(hipStream_t s, const TView& x, const TView& y);
+void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TView& dy, const TView& dx,
+                       int accumulate);
+// bilinear resize (half-pixel centres)
+void resize_bilinear_forward(hipStream_t s, const TView& x, const TView& y);
+void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate);
+// LocallyConnected2D 1x1: y[n,h,w,f] = b[h,w,f] + sum_c x[n,h,w,c] W[h,w,c,f]
+void localconv_forward(hipStream_t s, const TView& x, const float* w, const float* b, const TView& y);
+void localconv_backward(hipStream_t s, const TView& x, const float* w, const TView& dy, const TView& dx,
+                        int accumulate_dx, float* dw, float* db, int accumulate_dw);
+
+// --------------------------------------------------------- channel attention (attention.hip)
+// x viewed as [G][R][Q]: mean over R, MLP over the last C channels of Q=(P*C), scale.
+struct AttShape { int G, R, P, C, Cr; };
+void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, const float* w1,
+                   const float* b1, const float* w2, const float* b2, float* mean, float* hidden,
+                   float* scale, float* workspace);
+void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, int accumulate_dx,
+                    const AttShape& sh, const float* w1, const float* w2, const float* mean,
+                    const float* hidden, const float* scale, float* dw1, float* db1, float* dw2,
+                    float* db2, int accumulate_dw, float* workspace);
+size_t chatt_workspace_bytes(const AttShape& sh);
+
+// ----------------------------------------------------------------------- losses (losses.hip)
+enum LossKind { LOSS_MAE = 0, LOSS_MSE = 1, LOSS_DSSIM = 2, LOSS_DSSIM_MAE = 3, LOSS_DSSIM_MSE = 4,
+                LOSS_DSSIM_MAE_MSE = 5 };
+// loss_out[0] = scale * loss ; dpred (+)= scale * dloss/dpred.  y_true,y_pred: (N,H,W,C) contiguous.
+size_t loss_workspace_bytes(int kind, int N, int H, int W, int C);
+void loss_forward_backward(hipStream_t s, int kind, const float* y_true, const float* y_pred,
+                           float* dpred, int N, int H, int W, int C, float scale, float* loss_out,
+                           int accumulate, float* workspace, size_t workspace_bytes);
+// BCE on probabilities p[n] vs constant label; loss_out[0] (+)= scale*mean ; dp = scale*dL/dp
+void bce_forward_backward(hipStream_t s, const float* p, float label, int n, float scale,
+                          float* loss_out, float* dp, int accumulate_loss);
+
+// -------------------------------------------------------------------------- optimiser (adam.hip)
+// Keras Adam on a flat arena. lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.
+void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, size_t n, float lr_t,
+                 float beta1, float beta2, float eps, float grad_scale);

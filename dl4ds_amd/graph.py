@@ -1,0 +1,322 @@
+"""Python side of the graph runtime: lowers layer calls to the C-ABI graph (dl4ds_graph_*) and wraps
+the result in a Keras-like ``Model`` (the surface the reference uses: ``model(inputs, training=)``,
+``.predict``, ``.name``, ``.count_params``, ``.get_weights/.set_weights``, ``.summary`` --
+dl4ds/training/supervised.py:320,396-409; cgan.py:597-600; inference.py:172-173,238)."""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+
+ACT_KINDS = {'relu': 1, 'sigmoid': 2, 'tanh': 3, 'elu': 4, 'leaky_relu': 5, 'selu': 6, 'gelu': 7}
+
+
+class Tensor:
+    __slots__ = ('id', 'H', 'W', 'C', 'nmul')
+
+    def __init__(self, id, H, W, C, nmul=1):
+        self.id, self.H, self.W, self.C, self.nmul = id, H, W, C, nmul
+
+    @property
+    def shape(self):
+        return (self.nmul, self.H, self.W, self.C)
+
+
+def _check_activation(act):
+    if act is None or act == 'linear':
+        return None
+    if act not in ACT_KINDS:
+        raise ValueError(f'activation {act!r} not supported; one of {sorted(ACT_KINDS)} or None')
+    return act
+
+
+class GraphBuilder:
+    """Thin object API over dl4ds_graph_*; owns parameter names, shapes and initialisers."""
+
+    def __init__(self):
+        self._l = _lib.lib()
+        h = ctypes.c_void_p()
+        _lib.check(self._l.dl4ds_graph_create(ctypes.byref(h)))
+        self.h = h
+        self.params = OrderedDict()          # name -> dict(pid, shape, init)
+        self.inputs = []
+        self.outputs = []
+        self.layers = []                     # (kind, name, out_shape) for summary()
+        self.finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self._l.dl4ds_graph_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- tensors / params
+    def input(self, H, W, C, nmul=1):
+        tid = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_input(self.h, int(H), int(W), int(C), int(nmul), ctypes.byref(tid)))
+        t = Tensor(tid.value, int(H), int(W), int(C), int(nmul))
+        self.inputs.append(t)
+        return t
+
+    def param(self, name, shape, init='glorot'):
+        shape = tuple(int(s) for s in shape)
+        if name in self.params:                 # shared weights (e.g. spc conv2x applied twice)
+            p = self.params[name]
+            if p['shape'] != shape:
+                raise ValueError(f'parameter {name} re-used with shape {shape} != {p["shape"]}')
+            return p['pid']
+        pid = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_param(self.h, int(np.prod(shape)), ctypes.byref(pid)))
+        self.params[name] = dict(pid=pid.value, shape=shape, init=init)
+        return pid.value
+
+    def _out(self, tid, kind, name):
+        s = (ctypes.c_int * 4)()
+        _lib.check(self._l.dl4ds_graph_tensor_shape(self.h, tid, s))
+        t = Tensor(tid, s[1], s[2], s[3], s[0])
+        self.layers.append((kind, name, t.shape))
+        return t
+
+    # ---------------------------------------------------------------- ops
+    def conv2d(self, x, name, filters, ks, use_bias=True, activation=None, add=None, d2s=0):
+        activation = _check_activation(activation)
+        w = self.param(name + '/kernel', (ks, ks, x.C, filters))
+        b = self.param(name + '/bias', (filters,), 'zeros') if use_bias else -1
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_conv2d(self.h, x.id, w, b, -1 if add is None else add.id, int(ks),
+                                              int(filters), int(activation == 'relu'), int(d2s), ctypes.byref(out)))
+        y = self._out(out.value, 'conv2d', name)
+        if activation not in (None, 'relu'):
+            y = self.act(y, activation, name + '/act')
+        return y
+
+    def conv2d_transpose(self, x, name, filters, ks, stride, activation=None):
+        activation = _check_activation(activation)
+        w = self.param(name + '/kernel', (ks, ks, filters, x.C))
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_conv2d_transpose(self.h, x.id, w, int(ks), int(stride), int(filters),
+                                                        int(activation == 'relu'), ctypes.byref(out)))
+        y = self._out(out.value, 'conv2d_transpose', name)
+        if activation not in (None, 'relu'):
+            y = self.act(y, activation, name + '/act')
+        return y
+
+    def channel_attention(self, x, name, nf, r=4, time_window_5d=0):
+        cr = int(nf / r)
+        if cr < 1:
+            raise ValueError(f'ChannelAttention2D needs nf >= r (got nf={nf}, r={r})')
+        w1 = self.param(name + '/conv1/kernel', (1, 1, x.C, cr))
+        b1 = self.param(name + '/conv1/bias', (cr,), 'zeros')
+        w2 = self.param(name + '/conv2/kernel', (1, 1, cr, nf))
+        b2 = self.param(name + '/conv2/bias', (nf,), 'zeros')
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_chatt(self.h, x.id, w1, b1, w2, b2, cr, int(time_window_5d), ctypes.byref(out)))
+        return self._out(out.value, 'channel_attention', name)
+
+    def concat(self, xs, name='concat'):
+        ids = (ctypes.c_int * len(xs))(*[t.id for t in xs])
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_concat(self.h, ids, len(xs), ctypes.byref(out)))
+        return self._out(out.value, 'concat', name)
+
+    def add(self, a, b, relu=False, name='add'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_add(self.h, a.id, b.id, int(relu), ctypes.byref(out)))
+        return self._out(out.value, 'add', name)
+
+    def act(self, x, kind, name='act'):
+        kind = _check_activation(kind)
+        if kind is None:
+            return x
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_act(self.h, x.id, ACT_KINDS[kind], ctypes.byref(out)))
+        return self._out(out.value, 'activation:' + kind, name)
+
+    def maxpool2(self, x, name='maxpool'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_maxpool2(self.h, x.id, ctypes.byref(out)))
+        return self._out(out.value, 'maxpool2', name)
+
+    def resize(self, x, ho, wo, name='resize'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_resize(self.h, x.id, int(ho), int(wo), ctypes.byref(out)))
+        return self._out(out.value, 'resize_bilinear', name)
+
+    def localconv(self, x, name, filters=2, use_bias=True):
+        w = self.param(name + '/kernel', (x.H, x.W, x.C, filters))
+        b = self.param(name + '/bias', (x.H, x.W, filters), 'zeros') if use_bias else -1
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_localconv(self.h, x.id, w, b, int(filters), ctypes.byref(out)))
+        return self._out(out.value, 'locally_connected', name)
+
+    def repeat_time(self, x, T, name='repeat_time'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_repeat_time(self.h, x.id, int(T), ctypes.byref(out)))
+        return self._out(out.value, 'repeat_time', name)
+
+    def convlstm(self, x, name, filters, ks, T, activation=None):
+        activation = _check_activation(activation)
+        wk = self.param(name + '/kernel', (ks, ks, x.C, 4 * filters))
+        wr = self.param(name + '/recurrent_kernel', (ks, ks, filters, 4 * filters), 'orthogonal')
+        b = self.param(name + '/bias', (4 * filters,), 'lstm_bias')
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_convlstm(self.h, x.id, wk, wr, b, int(ks), int(filters), int(T),
+                                                int(activation == 'relu'), ctypes.byref(out)))
+        y = self._out(out.value, 'convlstm2d', name)
+        if activation not in (None, 'relu'):
+            y = self.act(y, activation, name + '/act')
+        return y
+
+    def gap(self, x, name='gap'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_gap(self.h, x.id, ctypes.byref(out)))
+        return self._out(out.value, 'global_avg_pool', name)
+
+    def dense(self, x, name, units, activation=None):
+        activation = _check_activation(activation)
+        w = self.param(name + '/kernel', (x.C, units))
+        b = self.param(name + '/bias', (units,), 'zeros')
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_dense(self.h, x.id, w, b, int(units), ACT_KINDS.get(activation, 0),
+                                             ctypes.byref(out)))
+        return self._out(out.value, 'dense', name)
+
+    def dropout(self, x, rate, name='dropout'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_dropout(self.h, x.id, float(rate), ctypes.byref(out)))
+        return self._out(out.value, 'dropout', name)
+
+    # ---------------------------------------------------------------- finish
+    def finalize(self, output, seed=None):
+        _lib.check(self._l.dl4ds_graph_output(self.h, output.id))
+        self.outputs.append(output)
+        _lib.check(self._l.dl4ds_graph_finalize(self.h))
+        self.finalized = True
+        self.initialize(seed)
+
+    def initialize(self, seed=None):
+        """Keras default initialisers: glorot_uniform kernels, zero biases, ConvLSTM2D orthogonal
+        recurrent kernel and unit forget bias."""
+        rng = np.random.default_rng(seed)
+        for name, p in self.params.items():
+            shape, init = p['shape'], p['init']
+            if init == 'zeros':
+                val = np.zeros(shape, np.float32)
+            elif init == 'lstm_bias':
+                f = shape[0] // 4
+                val = np.zeros(shape, np.float32)
+                val[f:2 * f] = 1.0
+            elif init == 'orthogonal':
+                rows = int(np.prod(shape[:-1]))
+                a = rng.standard_normal((max(rows, shape[-1]), min(rows, shape[-1])))
+                q, r = np.linalg.qr(a)
+                q *= np.sign(np.diag(r))
+                if rows < shape[-1]:
+                    q = q.T
+                val = q[:rows, :shape[-1]].reshape(shape).astype(np.float32)
+            else:
+                if len(shape) == 4:
+                    rf = shape[0] * shape[1]
+                    fan_in, fan_out = rf * shape[2], rf * shape[3]
+                else:
+                    fan_in, fan_out = shape[0], shape[-1]
+                lim = np.sqrt(6.0 / (fan_in + fan_out))
+                val = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            self.set_param(name, val)
+
+    def set_param(self, name, value):
+        p = self.params[name]
+        value = np.ascontiguousarray(value, np.float32)
+        if value.shape != p['shape']:
+            raise ValueError(f'{name}: expected shape {p["shape"]}, got {value.shape}')
+        _lib.check(self._l.dl4ds_graph_set_param(self.h, p['pid'], value.ctypes.data))
+
+    def get_param(self, name, grad=False):
+        p = self.params[name]
+        out = np.empty(p['shape'], np.float32)
+        fn = self._l.dl4ds_graph_get_grad if grad else self._l.dl4ds_graph_get_param
+        _lib.check(fn(self.h, p['pid'], out.ctypes.data))
+        return out
+
+
+class Model:
+    """What a dl4ds builder returns (stands in for tf.keras.Model on the hot path)."""
+
+    def __init__(self, gb, name, input_shapes):
+        self.graph = gb
+        self.name = name
+        self.input_shapes = input_shapes      # list of per-sample shapes, Keras style (H,W,C) / (T,H,W,C)
+        self.output_shape = self._keras_shape(gb.outputs[0])
+
+    @staticmethod
+    def _keras_shape(t):
+        return (t.H, t.W, t.C) if t.nmul == 1 else (t.nmul, t.H, t.W, t.C)
+
+    # --- weights
+    def count_params(self):
+        return int(sum(np.prod(p['shape']) for p in self.graph.params.values()))
+
+    @property
+    def weight_names(self):
+        return list(self.graph.params.keys())
+
+    def get_weights(self):
+        return OrderedDict((k, self.graph.get_param(k)) for k in self.graph.params)
+
+    def set_weights(self, weights):
+        if isinstance(weights, dict):
+            for k, v in weights.items():
+                self.graph.set_param(k, np.asarray(v))
+        else:
+            for k, v in zip(self.graph.params, weights):
+                self.graph.set_param(k, np.asarray(v))
+
+    def get_gradients(self):
+        return OrderedDict((k, self.graph.get_param(k, grad=True)) for k in self.graph.params)
+
+    @property
+    def trainable_variables(self):
+        return list(self.get_weights().items())
+
+    variables = trainable_variables
+
+    # --- forward
+    def _prep_inputs(self, inputs):
+        if isinstance(inputs, np.ndarray):
+            inputs = [inputs]
+        inputs = [np.ascontiguousarray(a, np.float32) for a in inputs]
+        if len(inputs) != len(self.graph.inputs):
+            raise ValueError(f'model {self.name} expects {len(self.graph.inputs)} inputs, got {len(inputs)}')
+        b = inputs[0].shape[0]
+        for a, t, ks in zip(inputs, self.graph.inputs, self.input_shapes):
+            if tuple(a.shape[1:]) != tuple(ks) or a.shape[0] != b:
+                raise ValueError(f'input shape {a.shape} does not match (batch,)+{tuple(ks)}')
+        return inputs, b
+
+    def __call__(self, inputs, training=False):
+        inputs, b = self._prep_inputs(inputs)
+        out = np.empty((b,) + self.output_shape, np.float32)
+        ptrs = (ctypes.c_void_p * len(inputs))(*[a.ctypes.data for a in inputs])
+        _lib.check(self.graph._l.dl4ds_graph_forward(self.graph.h, ptrs, len(inputs), b, int(training), 1,
+                                                     out.ctypes.data))
+        return out
+
+    def predict(self, inputs, batch_size=32, verbose=0):
+        if isinstance(inputs, np.ndarray):
+            inputs = [inputs]
+        n = inputs[0].shape[0]
+        outs = []
+        for i in range(0, n, batch_size):
+            outs.append(self([a[i:i + batch_size] for a in inputs], training=False))
+        return np.concatenate(outs, axis=0)
+
+    def summary(self, line_length=100, print_fn=print):
+        print_fn(f'Model: "{self.name}"')
+        print_fn('_' * line_length)
+        for kind, name, shape in self.graph.layers:
+            print_fn(f'{name[:50]:52s}{kind:24s}{str(shape)}')
+        print_fn('=' * line_length)
+        print_fn(f'Total params: {self.count_params():,}')

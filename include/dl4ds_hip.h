@@ -1,0 +1,178 @@
+/* dl4ds_hip.h -- C ABI of libdl4ds_hip.so: the MI355X (gfx950) native replacement for the
+ * TensorFlow/Keras + Horovod arithmetic behind dl4ds's conv-SR train step.
+ *
+ * The reference (carlos-gg/dl4ds 1.8.0) has NO plugin / FFI interface: its hot path sits behind plain
+ * Python (`dl4ds.models.*` builders returning tf.keras.Model; `SupervisedTrainer.run`, `CGANTrainer.run`,
+ * `Predictor.run`).  The entry points below are what a ctypes binding for that path needs; each names the
+ * reference code it replaces (paths relative to the reference repo).  The Python mirror that binds them is
+ * dl4ds_amd/ (same builder / trainer signatures as the reference).
+ *
+ * Conventions: every function returns 0 on success, <0 on error (message: dl4ds_last_error()); no C++
+ * exception crosses the boundary; all tensors are fp32 NHWC ("channels_last"), conv kernels HWIO,
+ * transposed-conv kernels HWOI, dense kernels [in][out]; pointers named *_dev are device (HBM) pointers,
+ * *_host are host pointers; sizes are element counts unless called bytes.  One library-wide HIP stream;
+ * calls are asynchronous unless documented otherwise.  Thread-compatible (one thread drives a handle).
+ */
+#ifndef DL4DS_HIP_H
+#define DL4DS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dl4ds_graph dl4ds_graph;
+typedef struct dl4ds_trainer dl4ds_trainer;
+
+/* ---------------------------------------------------------------- runtime / memory (plumbing)
+ * replaces: tf.config device selection, dl4ds/utils.py:174-203; training/base.py:97-122 */
+const char* dl4ds_last_error(void);
+int dl4ds_init(int device);                       /* hipSetDevice + create the library stream */
+int dl4ds_device_count(int* n);
+int dl4ds_device_name(char* buf, int buflen);
+int dl4ds_malloc(void** p_dev, size_t bytes);
+int dl4ds_free(void* p_dev);
+int dl4ds_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);   /* synchronous */
+int dl4ds_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);   /* synchronous */
+int dl4ds_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);    /* async on the stream */
+int dl4ds_memset(void* p_dev, int value, size_t bytes);
+int dl4ds_sync(void);                             /* hipStreamSynchronize(library stream) */
+int dl4ds_event_timer_start(void);                /* hipEventRecord on the library stream */
+int dl4ds_event_timer_stop(float* ms);            /* record + synchronize + elapsed ms */
+
+/* ---------------------------------------------------------------- single-op entry points
+ * (unit-testable against the oracle; contiguous NHWC device tensors) */
+
+/* y = [relu](conv_same_s1(x,w) + b + add), optionally stored through depth_to_space(d2s_r).
+ * replaces tf.keras.layers.Conv2D (blocks.py:49-61,208,249-259,299,414-416,479; sp_postups.py:134,156)
+ * fused with Add (blocks.py:228), Activation (blocks.py:75) and tf.nn.depth_to_space (blocks.py:427). */
+int dl4ds_op_conv2d_fwd(const float* x_dev, const float* w_dev, const float* b_dev, const float* add_dev,
+                        float* y_dev, int N, int H, int W, int Cin, int Cout, int KS, int relu, int d2s_r);
+/* dx (+)= dgrad(dz, w); dz may be given in depth_to_space(d2s_r) layout (gradient of a fused-d2s conv) */
+int dl4ds_op_conv2d_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int N, int H, int W,
+                          int Cin, int Cout, int KS, int d2s_r, int accumulate);
+/* dw (+)= wgrad(x, dz) */
+int dl4ds_op_conv2d_wgrad(const float* x_dev, const float* dz_dev, float* dw_dev, int N, int H, int W,
+                          int Cin, int Cout, int KS, int d2s_r, int accumulate);
+/* dz = dy * [y>0] (if y_dev) in place over dy; db = sum_pixels dz (if db_dev) */
+int dl4ds_op_bias_act_bwd(float* dy_dev, const float* y_dev, float* db_dev, int N, int H, int W, int C);
+/* Conv2DTranspose(k=KS, stride, 'same', use_bias=False) -- blocks.py:508-516; kernel HWOI */
+int dl4ds_op_conv2d_transpose_fwd(const float* x_dev, const float* w_dev, float* y_dev, int N, int H, int W,
+                                  int Cin, int Cout, int KS, int stride, int relu);
+int dl4ds_op_conv2d_transpose_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int N, int H,
+                                    int W, int Cin, int Cout, int KS, int stride, int accumulate);
+int dl4ds_op_conv2d_transpose_wgrad(const float* x_dev, const float* dz_dev, float* dw_dev, int N, int H,
+                                    int W, int Cin, int Cout, int KS, int stride, int accumulate);
+/* tf.nn.depth_to_space / its adjoint -- blocks.py:427 */
+int dl4ds_op_depth_to_space(const float* x_dev, float* y_dev, int N, int H, int W, int C, int r);
+int dl4ds_op_space_to_depth(const float* y_dev, float* x_dev, int N, int H, int W, int C, int r);
+/* MaxPooling2D((2,2)) -- blocks.py:613 */
+int dl4ds_op_maxpool2_fwd(const float* x_dev, float* y_dev, int N, int H, int W, int C);
+int dl4ds_op_maxpool2_bwd(const float* x_dev, const float* y_dev, const float* dy_dev, float* dx_dev, int N,
+                          int H, int W, int C);
+/* Resizing(..., 'bilinear') -- blocks.py:489; discriminator.py:62-63 */
+int dl4ds_op_resize_bilinear_fwd(const float* x_dev, float* y_dev, int N, int H, int W, int C, int Ho, int Wo);
+int dl4ds_op_resize_bilinear_bwd(const float* dy_dev, float* dx_dev, int N, int H, int W, int C, int Ho, int Wo);
+/* LocallyConnected2D(F,(1,1),implementation=3) -- blocks.py:322-328 */
+int dl4ds_op_localconv_fwd(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int N,
+                           int H, int W, int C, int F);
+int dl4ds_op_localconv_bwd(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev,
+                           float* dw_dev, float* db_dev, int N, int H, int W, int C, int F);
+/* ChannelAttention2D -- blocks.py:585-593.  x is [G][R][P*C] (4-D: G=B,R=H*W,P=1; 5-D: G=B,R=T*H,P=W).
+ * saved_dev: G*P*(2C+Cr) floats written by fwd and consumed by bwd. */
+int dl4ds_op_chatt_fwd(const float* x_dev, float* y_dev, int G, int R, int P, int C, int Cr, const float* w1_dev,
+                       const float* b1_dev, const float* w2_dev, const float* b2_dev, float* saved_dev);
+int dl4ds_op_chatt_bwd(const float* x_dev, const float* dy_dev, float* dx_dev, int G, int R, int P, int C, int Cr,
+                       const float* w1_dev, const float* w2_dev, const float* saved_dev, float* dw1_dev,
+                       float* db1_dev, float* dw2_dev, float* db2_dev);
+/* dl4ds/losses.py:5-89.  kind: 0 mae 1 mse 2 dssim 3 dssim_mae 4 dssim_mse 5 dssim_mae_mse.
+ * loss_dev[0] = loss ; dpred_dev = dloss/dpred (may be NULL). */
+int dl4ds_op_loss(int kind, const float* y_true_dev, const float* y_pred_dev, float* dpred_dev, int N, int H,
+                  int W, int C, float* loss_dev);
+/* Keras BinaryCrossentropy(from_logits=False) vs a constant label -- cgan.py:546-549,567-571 */
+int dl4ds_op_bce(const float* p_dev, float label, int n, float* loss_dev, float* dp_dev);
+/* tf.keras.optimizers.Adam step t (1-based) -- supervised.py:353; cgan.py:277-278 */
+int dl4ds_op_adam(float* w_dev, const float* g_dev, float* m_dev, float* v_dev, size_t n, int t, float lr,
+                  float beta1, float beta2, float eps, float grad_scale);
+
+/* ---------------------------------------------------------------- model graph
+ * replaces the tf.keras functional graphs assembled by dl4ds/models/{sp_postups,sp_preups,spt_postups,
+ * spt_preups,discriminator}.py.  The Python builders add tensors / parameters / ops in call order. */
+int dl4ds_graph_create(dl4ds_graph** g);
+int dl4ds_graph_destroy(dl4ds_graph* g);
+/* nmul: batch multiplier of the tensor (1, or time_window for (B,T,H,W,C) tensors) */
+int dl4ds_graph_input(dl4ds_graph* g, int H, int W, int C, int nmul, int* tensor_id);
+int dl4ds_graph_param(dl4ds_graph* g, size_t n, int* param_id);
+int dl4ds_graph_conv2d(dl4ds_graph* g, int in, int w, int b, int add, int KS, int Cout, int relu, int d2s_r, int* out);
+int dl4ds_graph_conv2d_transpose(dl4ds_graph* g, int in, int w, int KS, int stride, int Cout, int relu, int* out);
+int dl4ds_graph_chatt(dl4ds_graph* g, int in, int w1, int b1, int w2, int b2, int Cr, int time_window_5d, int* out);
+int dl4ds_graph_concat(dl4ds_graph* g, const int* ins, int n, int* out);
+int dl4ds_graph_add(dl4ds_graph* g, int a, int b, int relu, int* out);
+int dl4ds_graph_act(dl4ds_graph* g, int in, int kind, int* out);   /* 1 relu 2 sigmoid 3 tanh 4 elu 5 leaky 6 selu 7 gelu */
+int dl4ds_graph_maxpool2(dl4ds_graph* g, int in, int* out);
+int dl4ds_graph_resize(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
+int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out);
+int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out);
+int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out);
+int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out);
+int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out);
+int dl4ds_graph_dropout(dl4ds_graph* g, int in, float rate, int* out);
+int dl4ds_graph_output(dl4ds_graph* g, int tensor_id);
+int dl4ds_graph_finalize(dl4ds_graph* g);
+int dl4ds_graph_tensor_shape(dl4ds_graph* g, int tensor_id, int shape4[4]);   /* nmul,H,W,C */
+/* parameters: flat fp32 arena; param_id -> (offset, n).  model.get_weights()/set_weights() analogue */
+int dl4ds_graph_param_count(dl4ds_graph* g, size_t* n_arena, int* n_params);
+int dl4ds_graph_param_info(dl4ds_graph* g, int param_id, size_t* offset, size_t* n);
+int dl4ds_graph_set_param(dl4ds_graph* g, int param_id, const float* src_host);
+int dl4ds_graph_get_param(dl4ds_graph* g, int param_id, float* dst_host);
+int dl4ds_graph_get_grad(dl4ds_graph* g, int param_id, float* dst_host);
+int dl4ds_graph_arena_ptrs(dl4ds_graph* g, float** w_dev, float** g_dev);
+/* model(inputs, training=...) / model.predict -- inference.py:238; cgan.py:597-600.
+ * inputs: n_inputs pointers in graph-input order; is_host selects host or device pointers.
+ * out: output tensor 0 copied to out (host or device per is_host); synchronous if is_host. */
+int dl4ds_graph_forward(dl4ds_graph* g, const float* const* inputs, int n_inputs, int B, int training, int is_host,
+                        float* out);
+int dl4ds_graph_tensor_ptr(dl4ds_graph* g, int tensor_id, int grad, float** p_dev);
+
+/* ---------------------------------------------------------------- training
+ * replaces the Keras fit inner step configured by SupervisedTrainer.run (supervised.py:336-353,396-406):
+ * forward -> loss -> backward -> [RCCL all-reduce] -> Adam(PiecewiseConstantDecay). */
+int dl4ds_trainer_create(dl4ds_graph* g, int loss_kind, float lr0, float lr1, double lr_boundary, float beta1,
+                         float beta2, float eps, dl4ds_trainer** tr);
+int dl4ds_trainer_destroy(dl4ds_trainer* tr);
+/* one optimisation step.  inputs in graph-input order; y_true (B*nmul,H,W,C) of output 0.
+ * loss_host: NULL -> fully asynchronous step; else the loss value (forces a stream sync). */
+int dl4ds_trainer_step(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true, int B,
+                       int is_host, float* loss_host);
+/* loss/gradients without the optimiser update (tests; model.evaluate analogue) */
+int dl4ds_trainer_loss_and_grads(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true,
+                                 int B, int is_host, float* loss_host);
+int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, long* step);
+int dl4ds_trainer_last_loss(dl4ds_trainer* tr, float* loss_host);   /* synchronises */
+
+/* CGAN step -- cgan.py:575-639 with generator_loss (:525-553, lambda) and discriminator_loss (:556-572).
+ * gen: generator graph (inputs: lr[, static]); disc: discriminator graph (inputs: lr, hr/generated).
+ * losses_host[4] = gen_total, gen_gan, gen_px, disc (NULL -> asynchronous).
+ * dropout_keep_host: optional 2*B*C keep-mask (real rows first) for the discriminator's Dropout(0.4). */
+int dl4ds_cgan_create(dl4ds_graph* gen, dl4ds_graph* disc, int px_loss_kind, float lr, float beta1, float lam,
+                      dl4ds_trainer** tr);
+int dl4ds_cgan_step(dl4ds_trainer* tr, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B,
+                    int is_host, const float* dropout_keep_host, int apply_update, float* losses_host);
+int dl4ds_cgan_get_disc_grad(dl4ds_trainer* tr, int param_id, float* dst_host);
+
+/* ---------------------------------------------------------------- data parallelism (RCCL over xGMI)
+ * replaces Horovod: hvd.init/rank/size (base.py:97-107), DistributedOptimizer / DistributedGradientTape
+ * gradient averaging (supervised.py:365; cgan.py:608-611), broadcast of variables + optimiser slots from
+ * rank 0 (supervised.py:369; cgan.py:633-637). */
+int dl4ds_dist_unique_id(char id128[128]);                       /* rank 0: ncclGetUniqueId */
+int dl4ds_dist_init(int rank, int world, const char id128[128]); /* ncclCommInitRank on the current device */
+int dl4ds_dist_world(int* rank, int* world);
+int dl4ds_dist_broadcast_trainer(dl4ds_trainer* tr, int root);   /* params + Adam m,v + step */
+int dl4ds_dist_allreduce_sum(float* buf_dev, size_t n);          /* on the library stream */
+int dl4ds_dist_finalize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DL4DS_HIP_H */
