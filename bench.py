@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Headline benchmark: HR samples/s of one full train step (forward + MAE + backward + [RCCL gradient
+all-reduce] + Keras-Adam) of dl4ds's 4x residual-backbone sub-pixel SR model at 128->512 grids
+(BASELINE.json configs[1]; configs[2] when launched on N GPUs).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  Inputs are synthetic, resident in HBM before the timed
+region; weights are random-init (glorot) -- there is no dataset / checkpoint access.  fp32 throughout.
+torch is used ONLY for the multi-process rendezvous (gloo, CPU) and, on rank 0 at N=1, by the oracle that
+provides the CPU baseline; every GPU kernel is in libdl4ds_hip.so.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+FWD_GFLOP_PER_SAMPLE = 18.336
+STEP_GFLOP_PER_SAMPLE = 55.0           # fwd + dgrad + wgrad
+BACKBONE_STEP_GFLOP_PER_SAMPLE = 52.5  # convs from stem through spc.conv2x#2 (the 40 % MFMA target subset)
+
+
+def synthetic_batch(seed, batch, hr=512, scale=4):
+    """HR y in U[0,1) box-blurred 5x5; LR x = scale x scale block mean."""
+    rng = np.random.default_rng(seed)
+    raw = rng.random((batch, hr + 4, hr + 4, 1))
+    cs = np.pad(raw.cumsum(axis=1).cumsum(axis=2), ((0, 0), (1, 0), (1, 0), (0, 0)))
+    y = (cs[:, 5:, 5:] - cs[:, :-5, 5:] - cs[:, 5:, :-5] + cs[:, :-5, :-5]) / 25.0
+    x = y.reshape(batch, hr // scale, scale, hr // scale, scale, 1).mean(axis=(2, 4))
+    return x.astype(np.float32), y.astype(np.float32)
+
+
+def cpu_baseline(weights, budget_s=25.0):
+    """The oracle (torch-CPU restatement of the identical graph, fp32, all host cores) timed on a bounded
+    sample of the same workload: B=2 at 128->512, 1 warm-up + up to 3 timed steps."""
+    import torch
+    from oracle import torch_ops as T
+    from oracle import models as M
+    from oracle import train as TR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dict(backbone_block='resnet', upsampling='spc', scale=4)
+    P = M.Params()
+    for k, v in weights.items():
+        P[k] = torch.from_numpy(np.array(v, np.float32)).requires_grad_(True)
+    opt = TR.Adam(P, lr=1e-3)
+    b = 2
+    x, y = synthetic_batch(4242, b)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    TR.supervised_step('net_postupsampling', cfg, P, xt, None, yt, loss='mae', opt=opt)   # warm-up
+    times = []
+    t_all = time.perf_counter()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        TR.supervised_step('net_postupsampling', cfg, P, xt, None, yt, loss='mae', opt=opt)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s:
+            break
+    dt = float(np.median(times))
+    return {'value': b / dt, 'unit': 'HR samples/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle torch-CPU fp32 train step (fwd+MAE+bwd+Adam), B={b} at 128->512, '
+                      f'median of {len(times)} steps after 1 warm-up, {cores} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+        args.gpus = world
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    import dl4ds_amd._lib as L
+    from dl4ds_amd.device import DeviceArray
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import SupervisedEngine
+    from dl4ds_amd import parallel
+
+    lib = L.lib()                       # binds LOCAL_RANK -> device, fails loudly without a GPU
+    if world > 1:
+        parallel.init_from_torch_distributed(dist, rank, world)
+
+    B = args.batch
+    model = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (128, 128), seed=7)
+    eng = SupervisedEngine(model, loss='mae', learning_rate=(1e-3 * world, 1e-4 * world), lr_decay_after=1e5)
+    if world > 1:
+        parallel.broadcast_trainer(eng)
+    x, y = synthetic_batch(1002 + rank, B)
+    dx, dy = DeviceArray.from_numpy(x), DeviceArray.from_numpy(y)
+    w0 = model.get_weights() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+
+    def barrier():
+        L.check(lib.dl4ds_sync())
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.step_device([dx.ptr], dy.ptr, B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step_device([dx.ptr], dy.ptr, B)
+    L.check(lib.dl4ds_sync())
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss = eng.last_loss()
+
+    # ---- per-kernel HIP-event timing of a few extra steps (outside the timed region)
+    roofline = None
+    breakdown = None
+    if rank == 0 and not args.no_profile:
+        nprof = 3
+        L.check(lib.dl4ds_profile_enable(1))
+        for _ in range(nprof):
+            eng.step_device([dx.ptr], dy.ptr, B)
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.check(lib.dl4ds_profile_report(buf, len(buf)))
+        L.check(lib.dl4ds_profile_enable(0))
+        rep = json.loads(buf.value.decode())
+        tot = sum(v['ms'] for v in rep.values())
+        breakdown = {k: {'launches_per_step': v['n'] / nprof, 'ms_per_step': v['ms'] / nprof,
+                         'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else None,
+                         'gbps': v['bytes'] / (v['ms'] * 1e-3) / 1e9}
+                     for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms'])}
+        dom = max((k for k in rep if rep[k]['flops'] > 0), key=lambda k: rep[k]['ms'])
+        d = rep[dom]
+        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                    'launches': d['n'], 'avg_launch_ms': d['ms'] / d['n'],
+                    'algorithmic_gflop_per_launch': d['flops'] / d['n'] / 1e9,
+                    'share_of_step_time': d['ms'] / tot}
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            'metric': 'HR samples/s (train step) at 4x 128->512 residual SR',
+            'value': value, 'unit': 'HR samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: net_postupsampling(resnet, spc, scale=4, lr 128x128 -> hr 512x512, '
+                                   '204405 params), MAE, Adam' if world == 1 else
+                                   'configs[2]: same model, data-parallel over RCCL',
+                       'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'loss_after_run': loss},
+            'step_tflops_per_gpu': value / world * STEP_GFLOP_PER_SAMPLE / 1e3,
+            'backbone_conv_mfma_frac': value / world * BACKBONE_STEP_GFLOP_PER_SAMPLE / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+            'roofline': roofline,
+            'cpu_baseline': None,
+        }
+        if breakdown is not None and os.environ.get('DL4DS_BENCH_BREAKDOWN'):
+            out['breakdown'] = breakdown
+        if w0 is not None:
+            try:
+                out['cpu_baseline'] = cpu_baseline(w0)
+                out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+            except Exception as e:          # the baseline must never kill the GPU number
+                out['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        parallel.finalize()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -4,6 +4,7 @@
 // grad_scale folds the 1/world_size of the data-parallel gradient average.  HBM-bound: 16 B read +
 // 12 B written per parameter, float4 vectorised.
 #include "ops.h"
+#include "prof.h"
 #include <algorithm>
 
 namespace {
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const 
 void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
                  float beta2, float eps, float grad_scale) {
     if (n == 0) return;
+    ProfScope ps(s, "adam", 0.0, 28.0 * (double)n);
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n / 4 + 1, 256), 2048));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
     HIP_CHECK(hipGetLastError());

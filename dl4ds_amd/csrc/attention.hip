@@ -6,6 +6,7 @@
 // Kernels: wave/LDS column-sum reduction (HBM-bound, one read of x), one-block MLP forward/backward,
 // broadcast-scale.  Backward needs sum_r(dy*x) -- a second column-sum with a fused product.
 #include "ops.h"
+#include "prof.h"
 #include <algorithm>
 
 namespace {
@@ -171,6 +172,7 @@ void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, 
                    const float* w2, const float* b2, float* mean, float* hidden, float* scale, float* workspace) {
     const int Q = sh.P * sh.C;
     const int ninst = sh.G * sh.P;
+    ProfScope ps(s, "chatt_fwd", 0.0, 12.0 * (double)sh.G * sh.R * Q);
     colsum(s, x, nullptr, workspace, mean, sh.G, sh.R, Q, 1.f / (float)sh.R);
     hipLaunchKernelGGL(chatt_mlp_fwd_kernel, dim3(cdiv(ninst * sh.C, 256)), dim3(256), 0, s, mean, w1, b1, w2, b2,
                        hidden, scale, ninst, sh.C, sh.Cr);
@@ -190,6 +192,7 @@ void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, i
     float* dmean = ds + (size_t)sh.G * Q;
     float* dpre1 = dmean + (size_t)sh.G * Q;
     float* dpre2 = dpre1 + (size_t)ninst * sh.Cr;
+    ProfScope ps(s, "chatt_bwd", 0.0, 16.0 * (double)sh.G * sh.R * Q);
     colsum(s, dy, x, partial, ds, sh.G, sh.R, Q, 1.f);
     hipLaunchKernelGGL(chatt_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, ds, mean, hidden, scale, w1, w2, dpre1, dpre2,
                        dmean, dw1, db1, dw2, db2, ninst, sh.C, sh.Cr, 1.f / (float)sh.R, accumulate_dw);

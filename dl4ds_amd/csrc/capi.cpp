@@ -3,6 +3,7 @@
 #include "graph.h"
 #include "runtime.h"
 #include "dist.h"
+#include "prof.h"
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -151,6 +152,21 @@ int dl4ds_event_timer_stop(float* ms) {
     HIP_CHECK(hipEventRecord(rt().ev1, S()));
     HIP_CHECK(hipEventSynchronize(rt().ev1));
     HIP_CHECK(hipEventElapsedTime(ms, rt().ev0, rt().ev1));
+    API_END
+}
+
+int dl4ds_profile_enable(int on) {
+    API_BEGIN
+    HIP_CHECK(hipStreamSynchronize(S()));
+    prof().reset();
+    prof().on = (on != 0);
+    API_END
+}
+int dl4ds_profile_report(char* buf, size_t buflen) {
+    API_BEGIN
+    const std::string r = prof().report_json(S());
+    DL4DS_REQUIRE(r.size() + 1 <= buflen, "profile report buffer too small");
+    std::memcpy(buf, r.c_str(), r.size() + 1);
     API_END
 }
 

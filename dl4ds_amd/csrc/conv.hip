@@ -14,6 +14,7 @@
 // Conv2DBackpropFilter TF autodiff would have produced -- call sites dl4ds/models/blocks.py:49-61,208,
 // 249-259,299,414-416,479,582-583; sp_postups.py:134,156; discriminator.py:35-65.
 #include "ops.h"
+#include "prof.h"
 #include <algorithm>
 #include <mutex>
 #include <map>
@@ -220,6 +221,10 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     });
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * N), (unsigned)cdiv(p.Cout, BN));
+    const double px = (double)N * p.H * p.W;
+    ProfScope ps(s, "conv_igemm<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
+                        std::to_string(WM) + "," + std::to_string(WN) + ">",
+                 2.0 * px * KK * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KK * p.Cin * p.Cout));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
@@ -412,6 +417,9 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     });
     DL4DS_REQUIRE(lds <= (size_t)kLdsBudget, "wgrad tile does not fit in LDS");
     dim3 grid((unsigned)pl.S, (unsigned)cdiv(p.Cout, COB), (unsigned)cdiv(p.Cin, CIB));
+    const double px = (double)p.x.N * p.H * p.W;
+    ProfScope ps(s, "conv_wgrad<" + std::to_string(KS) + "," + std::to_string(CIT) + "," + std::to_string(COT) + ">",
+                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
@@ -440,6 +448,7 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
 void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int Cin, int Cout) {
     const size_t total = (size_t)KS * KS * Cin * Cout;
     const int blocks = (int)std::min<size_t>(cdivz(total, 256), 2048);
+    ProfScope ps(s, "dgrad_weights", 0.0, 8.0 * (double)total);
     hipLaunchKernelGGL(dgrad_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wt, KS * KS, Cin, Cout);
     HIP_CHECK(hipGetLastError());
 }
@@ -473,6 +482,7 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
         throw Dl4dsError("wgrad: kernel size not supported (1,3,5)");
     }
     const int blocks = (int)std::min<size_t>(cdivz(n, 256), 4096);
+    ProfScope ps(s, "wgrad_reduce_slabs", 0.0, 4.0 * (double)n * (pl.S + 1));
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, n, pl.S, accumulate);
     HIP_CHECK(hipGetLastError());
 }

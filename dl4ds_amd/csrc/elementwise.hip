@@ -5,6 +5,7 @@
 // Reference call sites (third-party TF ops there): blocks.py:75 (Activation), :228 (Add), :276/:656
 // (Concatenate), :427 (depth_to_space), :489 (Resizing), :613 (MaxPooling2D), :322-328 (LocallyConnected2D).
 #include "ops.h"
+#include "prof.h"
 #include <algorithm>
 
 namespace {
@@ -299,6 +300,7 @@ void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TVi
         partial = workspace;
     }
     dim3 grid((unsigned)nb, (unsigned)cdiv(dy.C, TX));
+    ProfScope ps(s, "bias_act_bwd", 0.0, 4.0 * (double)npix * dy.C * (1 + (y.p ? 1 : 0) + (dz.p ? 1 : 0)));
     switch (TX) {
         case 8: hipLaunchKernelGGL(bias_act_bwd_kernel<8>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
         case 16: hipLaunchKernelGGL(bias_act_bwd_kernel<16>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
@@ -317,6 +319,7 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
     DL4DS_REQUIRE(src.N == dst.N && src.H == dst.H && src.W == dst.W && src.C == dst.C, "view_axpy: shape mismatch");
     const size_t total = (size_t)src.N * src.H * src.W * src.C;
     if (total == 0) return;
+    ProfScope ps(s, "view_axpy", 0.0, 4.0 * (double)total * (2 + (accumulate ? 1 : 0)));
     if (plain_contig(src) && plain_contig(dst) && (total & 3) == 0 && ((((uintptr_t)src.p) | ((uintptr_t)dst.p)) & 15) == 0) {
         hipLaunchKernelGGL(flat_axpy4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
                            reinterpret_cast<const float4*>(src.p), reinterpret_cast<float4*>(dst.p), alpha, accumulate, total / 4);
@@ -327,19 +330,23 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
 }
 
 void add_act(hipStream_t s, const float* a, const float* b, float* out, size_t n, int relu) {
+    ProfScope ps(s, "add_act", 0.0, 12.0 * (double)n);
     hipLaunchKernelGGL(add_act_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, out, n, relu);
     HIP_CHECK(hipGetLastError());
 }
 void act_forward(hipStream_t s, const float* x, float* y, size_t n, int kind) {
+    ProfScope ps(s, "act_fwd", 0.0, 8.0 * (double)n);
     hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n, kind);
     HIP_CHECK(hipGetLastError());
 }
 void act_backward(hipStream_t s, const float* x, const float* dy, float* dx, size_t n, int kind, int accumulate) {
+    ProfScope ps(s, "act_bwd", 0.0, 12.0 * (double)n);
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, dy, dx, n, kind, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 void fill(hipStream_t s, float* p, size_t n, float v) {
     if (n == 0) return;
+    ProfScope ps(s, "fill", 0.0, 4.0 * (double)n);
     hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, n, v);
     HIP_CHECK(hipGetLastError());
 }

@@ -2,6 +2,7 @@
 // mixes :58-89) and Keras BinaryCrossentropy(from_logits=False) (cgan.py:546-549,567-571), each fused
 // with its gradient w.r.t. the prediction.  Wave reductions -> one partial per block -> finish kernel.
 #include "ops.h"
+#include "prof.h"
 #include <algorithm>
 
 namespace {
@@ -111,6 +112,7 @@ void loss_forward_backward(hipStream_t s, int kind, const float* y_true, const f
     DL4DS_REQUIRE(workspace_bytes >= loss_workspace_bytes(kind, N, H, W, C), "loss workspace too small");
     const int nb = loss_blocks(n);
     const float inv_n = 1.f / (float)n;
+    ProfScope ps(s, "pixel_loss", 0.0, 12.0 * (double)n);
     hipLaunchKernelGGL(pixel_loss_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, dpred, n, scale * wa * inv_n,
                        scale * ws * inv_n, accumulate, workspace);
     HIP_CHECK(hipGetLastError());

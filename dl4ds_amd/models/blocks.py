@@ -1,0 +1,114 @@
+"""Blocks of dl4ds/models/blocks.py lowered onto the gfx950 graph runtime.
+
+Each function takes the GraphBuilder ``g``, a layer-name prefix and the input Tensor(s) and returns
+the output Tensor.  Fusions are decided here: Conv2D+bias+ReLU(+residual Add) is one kernel launch,
+SubpixelConvolution's depth_to_space is the conv's store pattern.  Only the configuration space the
+hot path covers is accepted (normalization None, dropout 0): anything else raises.
+"""
+from ..utils import checkarg_dropout_variant
+
+
+def _reject_unsupported(normalization, dropout_rate, dropout_variant=None):
+    checkarg_dropout_variant(dropout_variant)
+    if normalization is not None:
+        if normalization not in ['bn', 'ln']:
+            raise ValueError(f'Normalization not supported, got {normalization}')
+        raise NotImplementedError("normalization='bn'/'ln' is not implemented on the MI355X path yet")
+    if dropout_rate and dropout_rate > 0:
+        raise NotImplementedError('dropout_rate > 0 is not implemented on the MI355X path yet')
+
+
+def conv_block(g, name, x, filters, ks_cl1=3, ks_cl2=3, activation='relu', normalization=None,
+               attention=False, dropout_rate=0, dropout_variant=None, time_window_5d=0):
+    """ConvBlock.call -- blocks.py:87-103."""
+    _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    y = g.conv2d(x, name + '/conv1', filters, ks_cl1, activation=activation)
+    y = g.conv2d(y, name + '/conv2', filters, ks_cl2, activation=activation)
+    if attention:
+        y = g.channel_attention(y, name + '/att', filters, time_window_5d=time_window_5d)
+    return y
+
+
+def residual_block(g, name, x, filters, activation='relu', normalization=None, attention=False,
+                   dropout_rate=0, dropout_variant=None, use_1x1conv=False):
+    """ResidualBlock.call -- blocks.py:210-230: conv1 -> act -> conv2 -> [att] -> (+ conv1x1(X) | X) -> act."""
+    _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    y = g.conv2d(x, name + '/conv1', filters, 3, activation=activation)
+    skip = g.conv2d(x, name + '/conv1x1', filters, 1) if use_1x1conv else x
+    if attention:
+        y = g.conv2d(y, name + '/conv2', filters, 3)
+        y = g.channel_attention(y, name + '/att', filters)
+        if activation in (None, 'relu', 'linear'):
+            return g.add(y, skip, relu=(activation == 'relu'), name=name + '/add')
+        return g.act(g.add(y, skip, name=name + '/add'), activation, name + '/act')
+    # fused: conv2 + bias + skip + activation in one epilogue
+    return g.conv2d(y, name + '/conv2', filters, 3, activation=activation, add=skip)
+
+
+def dense_block(g, name, x, filters, activation='relu', normalization=None, attention=False,
+                dropout_rate=0, dropout_variant=None):
+    """DenseBlock.call -- blocks.py:262-277.  conv1 consumes the RAW X (line 267)."""
+    _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    y = g.conv2d(x, name + '/conv1', 4 * filters, 1, activation=activation)
+    y = g.conv2d(y, name + '/conv2', filters, 3)
+    if attention:
+        y = g.channel_attention(y, name + '/att', filters)
+    return g.concat([y, x], name + '/concat')
+
+
+def transition_block(g, name, x, filters, activation='relu', normalization=None):
+    """TransitionBlock.call without BN: 1x1 conv -> act -- blocks.py:301-309."""
+    if normalization == 'bn':
+        raise NotImplementedError("normalization='bn' is not implemented on the MI355X path yet")
+    return g.conv2d(x, name + '/conv', filters, 1, activation=activation)
+
+
+def localized_conv_block(g, name, x, filters=2):
+    """LocalizedConvBlock -- blocks.py:312-333 (TransitionBlock(2) -> LocallyConnected2D 1x1 + bias)."""
+    y = transition_block(g, name + '/transition', x, filters)
+    return g.localconv(y, name + '/localconv', filters, use_bias=True)
+
+
+def recurrent_conv_block(g, name, x, filters, time_window, activation='relu', normalization=None,
+                         dropout_rate=0, dropout_variant=None):
+    """RecurrentConvBlock.call -- blocks.py:380-398: ConvLSTM2D 5x5 -> act -> ConvLSTM2D 3x3 -> act."""
+    _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    y = g.convlstm(x, name + '/convlstm1', filters, 5, time_window, activation=activation)
+    return g.convlstm(y, name + '/convlstm2', filters, 3, time_window, activation=activation)
+
+
+def subpixel_block(g, name, x, scale, n_filters):
+    """SubpixelConvolutionBlock.call -- blocks.py:433-454.  ``conv2x`` is ONE weight set applied at
+    every x2 stage; depth_to_space is fused into the conv store."""
+    seq = {2: [2], 4: [2, 2], 8: [2, 2, 2], 10: [2, 5], 20: [2, 2, 5]}.get(scale, [scale])
+    for f in seq:
+        sub = {2: 'conv2x', 5: 'conv5x'}.get(f, 'conv')
+        x = g.conv2d(x, f'{name}/{sub}', n_filters * f * f, 3, d2s=f)
+    return x
+
+
+def resize_conv_block(g, name, x, scale, n_filters, interpolation='bilinear'):
+    """ResizeConvolutionBlock.call -- blocks.py:485-491."""
+    if interpolation != 'bilinear':
+        raise NotImplementedError(f"rc_interpolation={interpolation!r}: only 'bilinear' is implemented")
+    y = g.resize(x, int(x.H * scale), int(x.W * scale), name + '/resize')
+    return g.conv2d(y, name + '/conv', n_filters, 3)
+
+
+def deconv_block(g, name, x, scale, n_filters, output_activation=None):
+    """DeconvolutionBlock.call -- blocks.py:522-534 (9x9 Conv2DTranspose, no bias).  The reference
+    falls through for scale == 4 and applies a third (x4) deconvolution, yielding a 16x grid; that
+    defect is reported instead of reproduced."""
+    if scale == 4:
+        raise ValueError("DeconvolutionBlock(scale=4) is broken in the reference (blocks.py:525-533 applies "
+                         "x2, x2 and then x4); use scale 2 or 8, or the 'spc'/'rc' upsamplers")
+    if scale == 8:
+        x = g.conv2d_transpose(x, name + '/deconv_1of2_scale_x2', n_filters, 9, 2)
+        x = g.conv2d_transpose(x, name + '/deconv_2of2_scale_x2', n_filters, 9, 2, activation=output_activation)
+        return g.conv2d_transpose(x, name + '/deconv_2of2_scale_x2', n_filters, 9, 2, activation=output_activation)
+    return g.conv2d_transpose(x, f'{name}/deconv_scale_x{scale}', n_filters, 9, scale, activation=output_activation)
+
+
+def pad_concat(g, name, t1, t2):
+    """PadConcat.call -- blocks.py:629-656 (zero padding only needed for odd grids)."""
+    return g.concat([t1, t2], name)

@@ -1,0 +1,88 @@
+"""net_postupsampling -- same signature as dl4ds/models/sp_postups.py:14-32, graph per :95-217."""
+from ..graph import GraphBuilder, Model
+from ..utils import checkarg_backbone, checkarg_upsampling, checkarg_dropout_variant
+from .blocks import (conv_block, residual_block, dense_block, transition_block, localized_conv_block,
+                     subpixel_block, resize_conv_block, deconv_block, _reject_unsupported)
+
+
+def backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, normalization, attention,
+                     dropout_rate, dropout_variant):
+    """Backbone shared by sp_postups.py:132-168 and sp_preups.py:115-151."""
+    if backbone_block in ('convnext', 'unet'):
+        raise NotImplementedError(f"backbone_block={backbone_block!r} is not implemented for this builder on the "
+                                  "MI355X path")
+    _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    init_n_filters = n_filters
+    x = b = g.conv2d(x_in, 'stem', n_filters, 3)
+    for i in range(n_blocks):
+        n_filters = init_n_filters * (i + 1)
+        if backbone_block == 'convnet':
+            b = conv_block(g, f'ConvBlock{i+1}', b, n_filters, activation=activation, attention=attention)
+        elif backbone_block == 'resnet':
+            b = residual_block(g, f'ResidualBlock{i+1}', b, n_filters, activation=activation,
+                               attention=attention, use_1x1conv=(i != 0))
+        elif backbone_block == 'densenet':
+            b = dense_block(g, f'DenseBlock{i+1}', b, n_filters, activation=activation, attention=attention)
+            b = transition_block(g, f'Transition{i+1}', b, b.C // 2)
+    if backbone_block == 'convnet':
+        x = g.conv2d(b, 'backbone_last', n_filters, 3, activation=activation)
+    elif backbone_block == 'resnet':
+        # x = TransitionBlock(x) ; x = Add()([x, b]) with b = act(conv(b)): the Add is fused into the 1x1 conv's
+        # epilogue only when no activation separates them, so keep it explicit: b first, then skip + b.
+        b = g.conv2d(b, 'backbone_last', n_filters, 3, activation=activation)
+        x = transition_block(g, 'TransitionSkip', x, n_filters, activation)
+        x = g.add(x, b, name='backbone_add')
+    elif backbone_block == 'densenet':
+        b = g.conv2d(b, 'backbone_last', n_filters, 3, activation=activation)
+        x = g.concat([x, b], 'backbone_concat')
+        x = transition_block(g, 'TransitionBackboneLast', x, n_filters, activation)
+    return x, n_filters
+
+
+def tail_section(g, x, s_in, init_n_filters, n_filters_aux, n_channels_out, activation, output_activation,
+                 normalization, dropout_rate, localcon_layer):
+    """sp_postups.py:184-212 / sp_preups.py:155-183 / :289-309."""
+    if localcon_layer:
+        lws = localized_conv_block(g, 'LocalizedConvBlock', x)
+        x = g.concat([x, lws], 'lcb_concat')
+    if s_in is not None:
+        s = conv_block(g, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
+                       normalization=normalization, attention=False)
+        x = g.concat([x, s], 'aux_concat')
+    x = transition_block(g, 'TransitionLast', x, init_n_filters)
+    x = conv_block(g, 'ConvBlock_att', x, init_n_filters, activation=None, normalization=normalization,
+                   attention=True, dropout_rate=dropout_rate)
+    return conv_block(g, 'ConvBlock_out', x, n_channels_out, activation=output_activation,
+                      normalization=normalization, attention=False)
+
+
+def net_postupsampling(backbone_block, upsampling, scale, n_channels, n_aux_channels, lr_size,
+                       n_channels_out=1, n_filters=8, n_blocks=6, normalization=None, dropout_rate=0,
+                       dropout_variant=None, attention=False, activation='relu', output_activation=None,
+                       rc_interpolation='bilinear', localcon_layer=False, seed=None):
+    backbone_block = checkarg_backbone(backbone_block)
+    upsampling = checkarg_upsampling(upsampling)
+    dropout_variant = checkarg_dropout_variant(dropout_variant)
+    h_lr, w_lr = int(lr_size[0]), int(lr_size[1])
+    h_hr, w_hr = int(h_lr * scale), int(w_lr * scale)
+
+    g = GraphBuilder()
+    x_in = g.input(h_lr, w_lr, n_channels)
+    s_in = g.input(h_hr, w_hr, n_aux_channels) if n_aux_channels > 0 else None
+    x, nf = backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, normalization,
+                             attention, dropout_rate, dropout_variant)
+    model_name = backbone_block + '_' + upsampling
+    if upsampling == 'spc':
+        x = subpixel_block(g, 'SubpixelConvolution', x, scale, nf)
+    elif upsampling == 'rc':
+        x = resize_conv_block(g, 'ResizeConvolution', x, scale, nf, rc_interpolation)
+    elif upsampling == 'dc':
+        x = transition_block(g, 'TransitionDC', x, n_filters, activation)
+        x = deconv_block(g, 'Deconvolution', x, scale, nf, activation)
+    else:
+        raise ValueError("net_postupsampling needs a post-upsampling method ('spc', 'rc' or 'dc')")
+    x = tail_section(g, x, s_in, n_filters, nf, n_channels_out, activation, output_activation,
+                     normalization, dropout_rate, localcon_layer)
+    g.finalize(x, seed)
+    shapes = [(h_lr, w_lr, n_channels)] + ([(h_hr, w_hr, n_aux_channels)] if s_in is not None else [])
+    return Model(g, model_name, shapes)

@@ -1,0 +1,98 @@
+"""Thin Python handles over the C-ABI trainers (dl4ds_trainer_* / dl4ds_cgan_*): one call = one
+optimisation step executed entirely by libdl4ds_hip.so (forward, loss, backward, RCCL gradient
+all-reduce, Keras-form Adam)."""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib
+from ..ops import LOSS_KINDS
+
+
+def _lr_schedule(learning_rate, lr_decay_after):
+    """supervised.py:336-352: a (lr0, lr1) pair becomes PiecewiseConstantDecay([lr_decay_after], [lr0, lr1])."""
+    if isinstance(learning_rate, (tuple, list)) and len(learning_rate) > 1:
+        return float(learning_rate[0]), float(learning_rate[1]), float(lr_decay_after)
+    if isinstance(learning_rate, (tuple, list)):
+        learning_rate = learning_rate[0]
+    return float(learning_rate), float(learning_rate), 1e30
+
+
+class SupervisedEngine:
+    """fit() inner step of SupervisedTrainer.run (supervised.py:353,396-406)."""
+
+    def __init__(self, model, loss='mae', learning_rate=1e-3, lr_decay_after=1e5, beta_1=0.9, beta_2=0.999,
+                 epsilon=1e-7):
+        if loss not in LOSS_KINDS:
+            raise ValueError(f'loss {loss!r} not available on the MI355X path; one of {sorted(LOSS_KINDS)}')
+        self.model = model
+        self._l = _lib.lib()
+        lr0, lr1, boundary = _lr_schedule(learning_rate, lr_decay_after)
+        h = ctypes.c_void_p()
+        _lib.check(self._l.dl4ds_trainer_create(model.graph.h, LOSS_KINDS[loss], lr0, lr1, boundary, beta_1, beta_2,
+                                                epsilon, ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self._l.dl4ds_trainer_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _host_args(self, inputs, y_true):
+        inputs, b = self.model._prep_inputs(inputs)
+        y = np.ascontiguousarray(y_true, np.float32)
+        if y.shape != (b,) + self.model.output_shape:
+            raise ValueError(f'y_true shape {y.shape} != {(b,) + self.model.output_shape}')
+        ptrs = (ctypes.c_void_p * len(inputs))(*[a.ctypes.data for a in inputs])
+        return inputs, y, ptrs, b
+
+    def step(self, inputs, y_true):
+        """One optimisation step on host arrays; returns the batch loss (synchronises)."""
+        inputs, y, ptrs, b = self._host_args(inputs, y_true)
+        loss = ctypes.c_float()
+        _lib.check(self._l.dl4ds_trainer_step(self.h, ptrs, len(inputs), y.ctypes.data, b, 1, ctypes.byref(loss)))
+        return float(loss.value)
+
+    def step_device(self, input_ptrs, y_ptr, batch, want_loss=False):
+        """One step on HBM-resident buffers (raw device pointers); asynchronous unless want_loss."""
+        ptrs = (ctypes.c_void_p * len(input_ptrs))(*input_ptrs)
+        loss = ctypes.c_float()
+        _lib.check(self._l.dl4ds_trainer_step(self.h, ptrs, len(input_ptrs), y_ptr, int(batch), 0,
+                                              ctypes.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def loss_and_grads(self, inputs, y_true):
+        """Loss and parameter gradients without the Adam update (model.evaluate / test hook)."""
+        inputs, y, ptrs, b = self._host_args(inputs, y_true)
+        loss = ctypes.c_float()
+        _lib.check(self._l.dl4ds_trainer_loss_and_grads(self.h, ptrs, len(inputs), y.ctypes.data, b, 1,
+                                                        ctypes.byref(loss)))
+        return float(loss.value), self.model.get_gradients()
+
+    def evaluate(self, inputs, y_true):
+        return self.loss_and_grads(inputs, y_true)[0]
+
+    def last_loss(self):
+        loss = ctypes.c_float()
+        _lib.check(self._l.dl4ds_trainer_last_loss(self.h, ctypes.byref(loss)))
+        return float(loss.value)
+
+    def optimizer_state(self):
+        n_arena = ctypes.c_size_t()
+        n_params = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_param_count(self.model.graph.h, ctypes.byref(n_arena), ctypes.byref(n_params)))
+        m = np.empty(n_arena.value, np.float32)
+        v = np.empty(n_arena.value, np.float32)
+        step = ctypes.c_long()
+        _lib.check(self._l.dl4ds_trainer_get_state(self.h, m.ctypes.data, v.ctypes.data, ctypes.byref(step)))
+        out_m, out_v = OrderedDict(), OrderedDict()
+        for name, p in self.model.graph.params.items():
+            off, n = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(self._l.dl4ds_graph_param_info(self.model.graph.h, p['pid'], ctypes.byref(off), ctypes.byref(n)))
+            out_m[name] = m[off.value:off.value + n.value].reshape(p['shape'])
+            out_v[name] = v[off.value:off.value + n.value].reshape(p['shape'])
+        return out_m, out_v, int(step.value)

@@ -40,6 +40,11 @@ int dl4ds_memset(void* p_dev, int value, size_t bytes);
 int dl4ds_sync(void);                             /* hipStreamSynchronize(library stream) */
 int dl4ds_event_timer_start(void);                /* hipEventRecord on the library stream */
 int dl4ds_event_timer_stop(float* ms);            /* record + synchronize + elapsed ms */
+/* per-launch HIP-event timing on the library stream (off by default).  report: JSON
+ * {"<kernel tag>": {"n": launches, "ms": total, "flops": algorithmic, "bytes": algorithmic}, ...};
+ * synchronises and clears the log. */
+int dl4ds_profile_enable(int on);
+int dl4ds_profile_report(char* json_buf, size_t buflen);
 
 /* ---------------------------------------------------------------- single-op entry points
  * (unit-testable against the oracle; contiguous NHWC device tensors) */

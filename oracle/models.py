@@ -326,8 +326,10 @@ def _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation)
     raise ValueError(backbone_block)
 
 
-def _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation):
-    x = transition_block(ops, P, 'TransitionLast', x, x.shape[-1] // 2)
+def _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation, transition_filters=None):
+    """spt_postups.py:150-157 (TransitionLast = C//2) / spt_preups.py:131-138 (TransitionLast = n_filters)."""
+    tf_ = x.shape[-1] // 2 if transition_filters is None else transition_filters
+    x = transition_block(ops, P, 'TransitionLast', x, tf_)
     x = conv_block(ops, P, 'ConvBlock_att', x, n_filters, activation=None, attention=True)
     return conv_block(ops, P, 'ConvBlock_out', x, n_channels_out, activation=output_activation)
 
@@ -366,7 +368,7 @@ def recnet_pin(ops, P, x_in, s_in=None, *, backbone_block, time_window, n_channe
     if localcon_layer:
         lws = localized_conv_block(ops, P, 'LocalizedConvBlock', x)
         x = ops.concat([x, lws])
-    return _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation)
+    return _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation, transition_filters=n_filters)
 
 
 # ----------------------------------------------------------------------------
