@@ -47,29 +47,42 @@ def cpu_baseline(weights, budget_s=25.0):
     from oracle import torch_ops as T
     from oracle import models as M
     from oracle import train as TR
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     cfg = dict(backbone_block='resnet', upsampling='spc', scale=4)
     P = M.Params()
     for k, v in weights.items():
         P[k] = torch.from_numpy(np.array(v, np.float32)).requires_grad_(True)
     opt = TR.Adam(P, lr=1e-3)
-    b = 2
+    b = 4
     x, y = synthetic_batch(4242, b)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
-    TR.supervised_step('net_postupsampling', cfg, P, xt, None, yt, loss='mae', opt=opt)   # warm-up
-    times = []
-    t_all = time.perf_counter()
-    for _ in range(3):
+
+    def step():
         t0 = time.perf_counter()
         TR.supervised_step('net_postupsampling', cfg, P, xt, None, yt, loss='mae', opt=opt)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > budget_s:
-            break
+        return time.perf_counter() - t0
+
+    # oneDNN does not scale to every hardware thread on this graph (2x64-core host: 256 threads are ~100x
+    # slower than 32): probe a few thread counts for a couple of seconds each and keep the fastest.
+    t_all = time.perf_counter()
+    best = None
+    for threads in sorted({min(ncpu, t) for t in (16, 32, 64)}):
+        torch.set_num_threads(threads)
+        first = step()                                     # warm-up for this thread count
+        if first > 8.0 or time.perf_counter() - t_all > budget_s:
+            continue
+        dt = min(step(), step())
+        if best is None or dt < best[1]:
+            best = (threads, dt)
+    if best is None:
+        best = (torch.get_num_threads(), first)
+    threads, _ = best
+    torch.set_num_threads(threads)
+    times = [step() for _ in range(3)]
     dt = float(np.median(times))
-    return {'value': b / dt, 'unit': 'HR samples/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle torch-CPU fp32 train step (fwd+MAE+bwd+Adam), B={b} at 128->512, '
-                      f'median of {len(times)} steps after 1 warm-up, {cores} threads'}
+    return {'value': b / dt, 'unit': 'HR samples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle torch-CPU (oneDNN) fp32 train step (fwd+MAE+bwd+Adam), B={b} at 128->512, median of '
+                      f'3 steps after warm-up; {threads} threads = fastest of 16/32/64 on a {ncpu}-thread host'}
 
 
 def main():

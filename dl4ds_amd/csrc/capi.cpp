@@ -201,7 +201,7 @@ int dl4ds_op_conv2d_wgrad(const float* x, const float* dz, float* dw, int N, int
     TView xv = make_view(nc(x), N, H, W, Cin);
     TView dzv = (d2s_r > 1) ? make_view_d2s(nc(dz), N, H, W, Cout, d2s_r) : make_view(nc(dz), N, H, W, Cout);
     const size_t ws = conv2d_wgrad_workspace_bytes(xv, dzv, KS);
-    conv2d_wgrad(S(), xv, dzv, KS, dw, accumulate, scratch(ws), ws);
+    conv2d_wgrad(S(), xv, dzv, KS, dw, accumulate, nullptr, 0, scratch(ws), ws);
     API_END
 }
 int dl4ds_op_bias_act_bwd(float* dy, const float* y, float* db, int N, int H, int W, int C) {

@@ -7,8 +7,9 @@
 //                     MT x NT accumulator tiles.  Epilogue fuses bias, residual add, ReLU, ReLU-mask,
 //                     gradient accumulation and the depth_to_space store (through TView).
 //   wgrad           : M = Cin, N = Cout, K = pixels.  Each block walks a strip of spatial tiles with
-//                     all KS*KS taps accumulated in registers, writes one partial slab, and a second
-//                     kernel reduces the slabs deterministically.
+//                     all KS*KS taps accumulated in registers and writes partial slabs; the bias gradient
+//                     (column sums of dz) rides along for free; a second kernel reduces the slabs
+//                     deterministically.  Waves split Cout (wide layers) or the pixel/K axis (Cout <= 32).
 //
 // Replaces (third-party in the reference): tf.keras.layers.Conv2D forward and the Conv2DBackpropInput /
 // Conv2DBackpropFilter TF autodiff would have produced -- call sites dl4ds/models/blocks.py:49-61,208,
@@ -17,11 +18,29 @@
 #include "prof.h"
 #include <algorithm>
 #include <mutex>
-#include <map>
 
 namespace {
 
 constexpr int kLdsBudget = 80 * 1024;   // 2 workgroups per CU (160 KiB LDS)
+
+// issue U independent 16-byte loads before the first LDS store so the memory latency is paid once per
+// batch, not once per element
+template <int U, int NTHR, class LoadF, class StoreF>
+__device__ __forceinline__ void staged_copy(int total, int tid, LoadF ld, StoreF st) {
+    for (int base = tid; base < total; base += NTHR * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * NTHR;
+            v[u] = (idx < total) ? ld(idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * NTHR;
+            if (idx < total) st(idx, v[u]);
+        }
+    }
+}
 
 struct ConvParams {
     TView in, out, add, mask;
@@ -32,6 +51,7 @@ struct ConvParams {
     int tiles_x, tiles_y;
     int relu, accumulate;
     int wvec;
+    unsigned m_txy[2];      // magic dividers for tiles_x, tiles_y
 };
 
 template <int KS, int MT, int NT, int WM, int WN>
@@ -83,44 +103,65 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         const int ck = min(CK, a.Cin - c0);
         const int ck4 = (ck + 3) >> 2;
+        const unsigned m4 = div_magic(ck4);
         __syncthreads();
         // ---- stage the input halo tile, channels [c0, c0+ck) (zero outside the image / beyond Cin)
-        for (int idx = tid; idx < HPIX * ck4; idx += NTHR) {
-            const int pix = idx / ck4;
-            const int q = idx - pix * ck4;
-            const int r = pix / TWH;
-            const int c = pix - r * TWH;
-            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = view_load4(a.in, n, gy, gx, c0 + q * 4);
-            float2* d = reinterpret_cast<float2*>(in_tile + pix * P + q * 4);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
-        }
+        staged_copy<4, NTHR>(
+            HPIX * ck4, tid,
+            [&](int idx) {
+                const int pix = fast_div(idx, m4);
+                const int q = idx - pix * ck4;
+                const int r = pix / TWH;
+                const int c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = view_load4(a.in, n, gy, gx, c0 + q * 4);
+                return v;
+            },
+            [&](int idx, float4 v) {
+                const int pix = fast_div(idx, m4);
+                const int q = idx - pix * ck4;
+                float2* d = reinterpret_cast<float2*>(in_tile + pix * P + q * 4);
+                d[0] = make_float2(v.x, v.y);
+                d[1] = make_float2(v.z, v.w);
+            });
         for (int tg = 0; tg < KK; tg += a.TPS) {
             const int ntap = min(a.TPS, KK - tg);
             if (tg > 0) __syncthreads();
             // ---- stage the filter slice [ntap][ck4*4][BN] (zero rows/cols beyond Cin/Cout)
             const int rows = ck4 * 4;
-            for (int idx = tid; idx < ntap * rows * BN4; idx += NTHR) {
-                const int q = idx % BN4;
-                const int row = idx / BN4;
-                const int tl = row / rows;
-                const int r = row - tl * rows;
-                const int co = n0 + q * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < ck && co < a.Cout) {
-                    const float* src = a.w + ((size_t)(tg + tl) * a.Cin + (c0 + r)) * a.Cout + co;
-                    if (a.wvec && co + 3 < a.Cout) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        v.x = src[0];
-                        if (co + 1 < a.Cout) v.y = src[1];
-                        if (co + 2 < a.Cout) v.z = src[2];
-                        if (co + 3 < a.Cout) v.w = src[3];
-                    }
-                }
-                *reinterpret_cast<float4*>(w_tile + (tl * CK + r) * NP + q * 4) = v;
+            const unsigned mrows = div_magic(rows);
+            {
+                const float* wsrc = a.w + ((size_t)tg * a.Cin + c0) * a.Cout;
+                staged_copy<5, NTHR>(
+                    ntap * rows * BN4, tid,
+                    [&](int idx) {
+                        const int row = idx / BN4;
+                        const int q = idx - row * BN4;
+                        const int tl = fast_div(row, mrows);
+                        const int r = row - tl * rows;
+                        const int co = n0 + q * 4;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (r < ck && co < a.Cout) {
+                            const float* src = wsrc + ((size_t)tl * a.Cin + r) * a.Cout + co;
+                            if (a.wvec && co + 3 < a.Cout) {
+                                v = *reinterpret_cast<const float4*>(src);
+                            } else {
+                                v.x = src[0];
+                                if (co + 1 < a.Cout) v.y = src[1];
+                                if (co + 2 < a.Cout) v.z = src[2];
+                                if (co + 3 < a.Cout) v.w = src[3];
+                            }
+                        }
+                        return v;
+                    },
+                    [&](int idx, float4 v) {
+                        const int row = idx / BN4;
+                        const int q = idx - row * BN4;
+                        const int tl = fast_div(row, mrows);
+                        const int r = row - tl * rows;
+                        *reinterpret_cast<float4*>(w_tile + (tl * CK + r) * NP + q * 4) = v;
+                    });
             }
             __syncthreads();
             // ---- MFMA over the staged taps
@@ -158,24 +199,40 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
         }
     }
 
-    // ---- epilogue.  C/D layout of 16x16x4: col = lane&15 (cout), row = (lane>>4)*4 + reg (pixel)
+    // ---- epilogue.  C/D layout of 16x16x4: col = lane&15 (cout), row = (lane>>4)*4 + reg (pixel).
+    // Addresses are separable: offset = pixel_base(i, rg) + channel_offset(j)  (also for d2s views).
+    size_t q_out[NT], q_add[NT], q_mask[NT];
+    float bias_v[NT];
+    bool co_ok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + (wn * NT + j) * 16 + l15;
+        co_ok[j] = co < a.Cout;
+        const int cs = co_ok[j] ? co : 0;
+        q_out[j] = view_chan_off(a.out, cs);
+        q_add[j] = a.add.p ? view_chan_off(a.add, cs) : 0;
+        q_mask[j] = a.mask.p ? view_chan_off(a.mask, cs) : 0;
+        bias_v[j] = (a.bias && co_ok[j]) ? a.bias[cs] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int gy = y0 + wm * MT + i;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int co = n0 + (wn * NT + j) * 16 + l15;
-            const bool ok = (gy < a.H) && (co < a.Cout);
-            const float bv = (ok && a.bias) ? a.bias[co] : 0.f;
+        for (int rg = 0; rg < 4; ++rg) {
+            const int gx = x0 + lq * 4 + rg;
+            const bool pix_ok = (gy < a.H) && (gx < a.W);
+            const int sy = pix_ok ? gy : 0, sx = pix_ok ? gx : 0;
+            const size_t p_out = view_pix_base(a.out, n, sy, sx);
+            const size_t p_add = a.add.p ? view_pix_base(a.add, n, sy, sx) : 0;
+            const size_t p_mask = a.mask.p ? view_pix_base(a.mask, n, sy, sx) : 0;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int gx = x0 + lq * 4 + rg;
-                if (ok && gx < a.W) {
-                    float v = acc[i][j][rg] + bv;
-                    if (a.add.p) v += a.add.p[view_off(a.add, n, gy, gx, co)];
+            for (int j = 0; j < NT; ++j) {
+                if (pix_ok && co_ok[j]) {
+                    float v = acc[i][j][rg] + bias_v[j];
+                    if (a.add.p) v += a.add.p[p_add + q_add[j]];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.mask.p) v = (a.mask.p[view_off(a.mask, n, gy, gx, co)] > 0.f) ? v : 0.f;
-                    const size_t o = view_off(a.out, n, gy, gx, co);
+                    if (a.mask.p) v = (a.mask.p[p_mask + q_mask[j]] > 0.f) ? v : 0.f;
+                    const size_t o = p_out + q_out[j];
                     if (a.accumulate) v += a.out.p[o];
                     a.out.p[o] = v;
                 }
@@ -185,8 +242,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
 }
 
 // --------------------------------------------------------------------------------------------
-struct FwdCfg { int BN, BM; };
-
 template <int KS, int MT, int NT, int WM, int WN>
 void launch_fwd(hipStream_t s, ConvParams& p, int N) {
     constexpr int BM = WM * MT * 16, TH = BM / 16, BN = WN * NT * 16;
@@ -267,21 +322,23 @@ __global__ void dgrad_weights_kernel(const float* __restrict__ w, float* __restr
 // --------------------------------------------------------------------------------------------
 struct WgradParams {
     TView x, dz;
-    float* partial;     // [S][KK][Cin][Cout]
+    float* partial;     // [S*WK][KK*Cin*Cout + Cout]  (weight slab followed by the bias-gradient slab)
     int Cin, Cout, H, W;
     int tiles_x, tiles_y, ntiles, S;
 };
 
-// block = 4 waves; wave w owns cout tiles [w*COT,(w+1)*COT) of the block's 64*COT couts and ALL
-// (tap, cin-tile) combinations of the block's 16*CIT cins.
-template <int KS, int CIT, int COT>
+// block = 4 waves arranged WCO (cout tiles) x WK (pixel/K split).  A wave owns cout tiles
+// [wco*COT,(wco+1)*COT) of the block's 16*COT*WCO couts, ALL (tap, cin-tile) combinations of the block's
+// 16*CIT cins, and every WK-th group of 4 pixels of each spatial tile.
+template <int KS, int CIT, int COT, int WCO>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a) {
     constexpr int TW = 16, TH = 8;
+    constexpr int WK = 4 / WCO;
     constexpr int PAD = KS / 2;
     constexpr int TWH = TW + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
     constexpr int KK = KS * KS;
     constexpr int CIB = 16 * CIT;
-    constexpr int COB = 64 * COT;
+    constexpr int COB = 16 * COT * WCO;
     constexpr int PX = (CIB % 32 == 16) ? CIB : CIB + 16;   // pixel k and k+1 on disjoint bank halves
     constexpr int PZ = (COB % 32 == 16) ? COB : COB + 16;
     constexpr int NPIX = TW * TH;
@@ -292,17 +349,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wco = wave % WCO, wk = wave / WCO;
     const int l15 = lane & 15, lq = lane >> 4;
     const int ci0 = blockIdx.z * CIB;
     const int co0 = blockIdx.y * COB;
 
     f32x4 acc[KK][CIT][COT];
+    float bsum[COT];
 #pragma unroll
     for (int t = 0; t < KK; ++t)
 #pragma unroll
         for (int i = 0; i < CIT; ++i)
 #pragma unroll
             for (int j = 0; j < COT; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < COT; ++j) bsum[j] = 0.f;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
         int t = tile;
@@ -313,35 +374,52 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
         const int x0 = tx * TW, y0 = ty * TH;
         __syncthreads();
         // stage x halo tile (channels ci0 .. ci0+CIB)
-        for (int idx = tid; idx < HPIX * (CIB / 4); idx += 256) {
-            const int pix = idx / (CIB / 4);
-            const int q = idx - pix * (CIB / 4);
-            const int r = pix / TWH, c = pix - r * TWH;
-            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin)
-                v = view_load4(a.x, n, gy, gx, ci0 + q * 4);
-            *reinterpret_cast<float4*>(x_tile + pix * PX + q * 4) = v;
-        }
+        staged_copy<4, 256>(
+            HPIX * (CIB / 4), tid,
+            [&](int idx) {
+                const int pix = idx / (CIB / 4);
+                const int q = idx - pix * (CIB / 4);
+                const int r = pix / TWH, c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin)
+                    v = view_load4(a.x, n, gy, gx, ci0 + q * 4);
+                return v;
+            },
+            [&](int idx, float4 v) {
+                const int pix = idx / (CIB / 4);
+                const int q = idx - pix * (CIB / 4);
+                *reinterpret_cast<float4*>(x_tile + pix * PX + q * 4) = v;
+            });
         // stage dz tile (channels co0 .. co0+COB); zero outside the image so padded pixels add nothing
-        for (int idx = tid; idx < NPIX * (COB / 4); idx += 256) {
-            const int pix = idx / (COB / 4);
-            const int q = idx - pix * (COB / 4);
-            const int r = pix / TW, c = pix - r * TW;
-            const int gy = y0 + r, gx = x0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < a.H && gx < a.W && co0 + q * 4 < a.Cout) v = view_load4(a.dz, n, gy, gx, co0 + q * 4);
-            *reinterpret_cast<float4*>(z_tile + pix * PZ + q * 4) = v;
-        }
+        staged_copy<4, 256>(
+            NPIX * (COB / 4), tid,
+            [&](int idx) {
+                const int pix = idx / (COB / 4);
+                const int q = idx - pix * (COB / 4);
+                const int r = pix / TW, c = pix - r * TW;
+                const int gy = y0 + r, gx = x0 + c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy < a.H && gx < a.W && co0 + q * 4 < a.Cout) v = view_load4(a.dz, n, gy, gx, co0 + q * 4);
+                return v;
+            },
+            [&](int idx, float4 v) {
+                const int pix = idx / (COB / 4);
+                const int q = idx - pix * (COB / 4);
+                *reinterpret_cast<float4*>(z_tile + pix * PZ + q * 4) = v;
+            });
         __syncthreads();
         // K loop over the 128 pixels, 4 per MFMA: pixel pk = kk*4 + lq -> (row kk>>2, col (kk&3)*4+lq)
 #pragma unroll 2
-        for (int kk = 0; kk < NPIX / 4; ++kk) {
+        for (int kk = wk; kk < NPIX / 4; kk += WK) {
             const int pr = kk >> 2;
             const int pc = (kk & 3) * 4 + lq;
             float bv[COT];
 #pragma unroll
-            for (int j = 0; j < COT; ++j) bv[j] = z_tile[(pr * TW + pc) * PZ + (wave * COT + j) * 16 + l15];
+            for (int j = 0; j < COT; ++j) {
+                bv[j] = z_tile[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
+                bsum[j] += bv[j];
+            }
 #pragma unroll
             for (int tp = 0; tp < KK; ++tp) {
                 const int ky = tp / KS, kx = tp % KS;
@@ -356,60 +434,136 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
             }
         }
     }
+    // K-split waves: pairwise tree reduction through LDS so the block emits ONE slab
+    if (WK > 1) {
+        constexpr int SLOTF = (KK * CIT * COT * 4 + COT) * 64;      // floats per wave image
+        for (int half = WK / 2; half >= 1; half >>= 1) {
+            __syncthreads();
+            if (wk >= half && wk < 2 * half) {
+                float* dst = smem + (size_t)((wk - half) * WCO + wco) * SLOTF + lane;
+                int o = 0;
+#pragma unroll
+                for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                        for (int j = 0; j < COT; ++j)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) { dst[o * 64] = acc[tp][i][j][rg]; ++o; }
+#pragma unroll
+                for (int j = 0; j < COT; ++j) { dst[o * 64] = bsum[j]; ++o; }
+            }
+            __syncthreads();
+            if (wk < half) {
+                const float* src = smem + (size_t)(wk * WCO + wco) * SLOTF + lane;
+                int o = 0;
+#pragma unroll
+                for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                        for (int j = 0; j < COT; ++j)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) { acc[tp][i][j][rg] += src[o * 64]; ++o; }
+#pragma unroll
+                for (int j = 0; j < COT; ++j) { bsum[j] += src[o * 64]; ++o; }
+            }
+        }
+        if (wk != 0) return;
+    }
     // write the partial slab: D row = ci (lq*4+reg), col = co (l15)
-    float* slab = a.partial + (size_t)blockIdx.x * KK * a.Cin * a.Cout;
+    const size_t nw = (size_t)KK * a.Cin * a.Cout;
+    float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
 #pragma unroll
     for (int tp = 0; tp < KK; ++tp)
 #pragma unroll
         for (int i = 0; i < CIT; ++i)
 #pragma unroll
             for (int j = 0; j < COT; ++j) {
-                const int co = co0 + (wave * COT + j) * 16 + l15;
-                if (co >= a.Cout) continue;
+                const int co = co0 + (wco * COT + j) * 16 + l15;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int ci = ci0 + i * 16 + lq * 4 + rg;
-                    if (ci < a.Cin) slab[((size_t)tp * a.Cin + ci) * a.Cout + co] = acc[tp][i][j][rg];
+                    if (co < a.Cout && ci < a.Cin) slab[((size_t)tp * a.Cin + ci) * a.Cout + co] = acc[tp][i][j][rg];
                 }
             }
-}
-
-__global__ void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n,
-                                    int S, int accumulate) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += partial[(size_t)k * n + e];
-        out[e] = accumulate ? out[e] + s : s;
+    // bias gradient: sum the 4 pixel sub-lanes of each cout column; only the first cin block writes it
+    if (blockIdx.z == 0) {
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int co = co0 + (wco * COT + j) * 16 + l15;
+            if (lq == 0 && co < a.Cout) slab[nw + co] = v;
+        }
     }
 }
 
-struct WgradPlan { int S, CIB, COB, tiles_x, tiles_y, ntiles; };
+// out0[e] (+)= sum_k partial[k*n + e] for e < n0 ; out1[e-n0] likewise for e >= n0.
+// One block reduces 16 consecutive elements: thread = (slab sub-index 0..15, element 0..15) -> 64-byte row
+// segments per slab, 16 slabs in flight per block, fixed summation order (deterministic).
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out0,
+                                                           float* __restrict__ out1, size_t n0, size_t n, int S,
+                                                           int acc0, int acc1) {
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const size_t ngroups = (n + 15) >> 4;
+    for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const size_t e = grp * 16 + el;
+        float s = 0.f;
+        if (e < n) {
+            int k = sl;
+            for (; k + 48 < S; k += 64) {       // 4 independent loads in flight
+                const float a0 = partial[(size_t)k * n + e], a1 = partial[(size_t)(k + 16) * n + e];
+                const float a2 = partial[(size_t)(k + 32) * n + e], a3 = partial[(size_t)(k + 48) * n + e];
+                s += (a0 + a1) + (a2 + a3);
+            }
+            for (; k < S; k += 16) s += partial[(size_t)k * n + e];
+        }
+        red[sl][el] = s;
+        __syncthreads();
+        if (sl == 0 && e < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][el];
+            if (e < n0) out0[e] = acc0 ? out0[e] + t : t;
+            else if (out1) out1[e - n0] = acc1 ? out1[e - n0] + t : t;
+        }
+        __syncthreads();
+    }
+}
+
+struct WgradPlan { int S, CIT, WCO, WK, tiles_x, tiles_y, ntiles; };
 
 WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     WgradPlan p;
     p.tiles_x = cdiv(x.W, 16);
     p.tiles_y = cdiv(x.H, 8);
     p.ntiles = p.tiles_x * p.tiles_y * x.N;
-    p.CIB = (x.C > 32) ? 48 : (x.C > 16 ? 32 : 16);
-    if (KS == 5) p.CIB = 16;
-    p.COB = 64;
-    const int cob = cdiv(dz.C, p.COB), cib = cdiv(x.C, p.CIB);
-    int target = std::max(1, 1024 / (cob * cib));
-    const size_t params = (size_t)KS * KS * x.C * dz.C;
-    const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (params * sizeof(float)));
+    p.CIT = (x.C > 32) ? 3 : (x.C > 16 ? 2 : 1);
+    if (KS == 5) p.CIT = 1;
+    p.WCO = (dz.C <= 16) ? 1 : (dz.C <= 32 ? 2 : 4);
+    p.WK = 4 / p.WCO;
+    const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
+    int target = std::max(1, 768 / (cob * cib));
+    const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
+    const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (slab * sizeof(float)));
     p.S = (int)std::min<size_t>(std::min<size_t>(target, p.ntiles), cap);
     if (p.S < 1) p.S = 1;
     return p;
 }
 
-template <int KS, int CIT, int COT>
+template <int KS, int CIT, int COT, int WCO>
 void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     constexpr int TWH = 16 + KS - 1, THH = 8 + KS - 1, HPIX = TWH * THH;
-    constexpr int CIB = 16 * CIT, COB = 64 * COT;
+    constexpr int CIB = 16 * CIT, COB = 16 * COT * WCO;
     constexpr int PX = (CIB % 32 == 16) ? CIB : CIB + 16;
     constexpr int PZ = (COB % 32 == 16) ? COB : COB + 16;
-    const size_t lds = (size_t)(HPIX * PX + 128 * PZ) * sizeof(float);
-    auto kern = conv_wgrad_kernel<KS, CIT, COT>;
+    constexpr int WK = 4 / WCO;
+    constexpr size_t red_bytes = (size_t)(WK / 2) * WCO * (KS * KS * CIT * COT * 4 + COT) * 64 * sizeof(float);
+    const size_t lds = std::max((size_t)(HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
+    auto kern = conv_wgrad_kernel<KS, CIT, COT, WCO>;
     static std::once_flag once;
     std::call_once(once, [&]() {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -418,10 +572,29 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     DL4DS_REQUIRE(lds <= (size_t)kLdsBudget, "wgrad tile does not fit in LDS");
     dim3 grid((unsigned)pl.S, (unsigned)cdiv(p.Cout, COB), (unsigned)cdiv(p.Cin, CIB));
     const double px = (double)p.x.N * p.H * p.W;
-    ProfScope ps(s, "conv_wgrad<" + std::to_string(KS) + "," + std::to_string(CIT) + "," + std::to_string(COT) + ">",
+    ProfScope ps(s, "conv_wgrad<" + std::to_string(KS) + "," + std::to_string(CIT) + "," + std::to_string(COT) + "," +
+                        std::to_string(WCO) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     HIP_CHECK(hipGetLastError());
+}
+
+template <int KS, int CIT>
+void dispatch_wgrad_wco(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
+    switch (pl.WCO) {
+        case 1: launch_wgrad<KS, CIT, 1, 1>(s, p, pl); break;
+        case 2: launch_wgrad<KS, CIT, 1, 2>(s, p, pl); break;
+        default: launch_wgrad<KS, CIT, 1, 4>(s, p, pl); break;
+    }
+}
+
+template <int KS>
+void dispatch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
+    switch (pl.CIT) {
+        case 3: dispatch_wgrad_wco<KS, 3>(s, p, pl); break;
+        case 2: dispatch_wgrad_wco<KS, 2>(s, p, pl); break;
+        default: dispatch_wgrad_wco<KS, 1>(s, p, pl); break;
+    }
 }
 
 }  // namespace
@@ -455,34 +628,30 @@ void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int 
 
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS) {
     WgradPlan pl = plan_wgrad(x, dz, KS);
-    return (size_t)pl.S * KS * KS * x.C * dz.C * sizeof(float);
+    return (size_t)pl.S * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
 }
 
-void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate,
-                  float* workspace, size_t workspace_bytes) {
+void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate, float* db,
+                  int accumulate_db, float* workspace, size_t workspace_bytes) {
     DL4DS_REQUIRE(x.N == dz.N && x.H == dz.H && x.W == dz.W, "wgrad: shapes differ");
     WgradPlan pl = plan_wgrad(x, dz, KS);
-    const size_t n = (size_t)KS * KS * x.C * dz.C;
-    DL4DS_REQUIRE(workspace_bytes >= (size_t)pl.S * n * sizeof(float), "wgrad: workspace too small");
+    const size_t nw = (size_t)KS * KS * x.C * dz.C;
+    const size_t n = nw + dz.C;
+    const int nslabs = pl.S;
+    DL4DS_REQUIRE(workspace_bytes >= (size_t)nslabs * n * sizeof(float), "wgrad: workspace too small");
     WgradParams p;
     p.x = x; p.dz = dz; p.partial = workspace;
     p.Cin = x.C; p.Cout = dz.C; p.H = x.H; p.W = x.W;
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S;
-    if (KS == 1) {
-        if (pl.CIB == 48) launch_wgrad<1, 3, 1>(s, p, pl);
-        else if (pl.CIB == 32) launch_wgrad<1, 2, 1>(s, p, pl);
-        else launch_wgrad<1, 1, 1>(s, p, pl);
-    } else if (KS == 3) {
-        if (pl.CIB == 48) launch_wgrad<3, 3, 1>(s, p, pl);
-        else if (pl.CIB == 32) launch_wgrad<3, 2, 1>(s, p, pl);
-        else launch_wgrad<3, 1, 1>(s, p, pl);
-    } else if (KS == 5) {
-        launch_wgrad<5, 1, 1>(s, p, pl);
-    } else {
-        throw Dl4dsError("wgrad: kernel size not supported (1,3,5)");
+    switch (KS) {
+        case 1: dispatch_wgrad<1>(s, p, pl); break;
+        case 3: dispatch_wgrad<3>(s, p, pl); break;
+        case 5: dispatch_wgrad_wco<5, 1>(s, p, pl); break;
+        default: throw Dl4dsError("wgrad: kernel size not supported (1,3,5)");
     }
-    const int blocks = (int)std::min<size_t>(cdivz(n, 256), 4096);
-    ProfScope ps(s, "wgrad_reduce_slabs", 0.0, 4.0 * (double)n * (pl.S + 1));
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, n, pl.S, accumulate);
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 16), 8192));
+    ProfScope ps(s, "wgrad_reduce_slabs", 0.0, 4.0 * (double)n * (nslabs + 1));
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
+                       accumulate_db);
     HIP_CHECK(hipGetLastError());
 }

@@ -56,6 +56,20 @@ __global__ void reduce_slabs_kernel2(const float* __restrict__ partial, float* _
     }
 }
 
+// mask-only fast path on contiguous tensors: dz = dy * [y > 0], 16 bytes per lane
+__global__ void __launch_bounds__(256) relu_mask_flat4_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                              float4* __restrict__ dz, size_t n4) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        float4 g = dy[e];
+        const float4 m = y[e];
+        g.x = m.x > 0.f ? g.x : 0.f;
+        g.y = m.y > 0.f ? g.y : 0.f;
+        g.z = m.z > 0.f ? g.z : 0.f;
+        g.w = m.w > 0.f ? g.w : 0.f;
+        dz[e] = g;
+    }
+}
+
 int bias_blocks(size_t npix, int TY) { return (int)std::min<size_t>(cdivz(npix, (size_t)TY * 8), 1024); }
 
 int pick_tx(int C) { return C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64)); }
@@ -291,6 +305,16 @@ size_t bias_grad_workspace_bytes(const TView& dy) {
 void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TView& dz, float* db,
                        int accumulate_db, float* workspace, size_t workspace_bytes) {
     const size_t npix = (size_t)dy.N * dy.H * dy.W;
+    const size_t total = npix * dy.C;
+    if (!db && y.p && dz.p && plain_contig(dy) && plain_contig(y) && plain_contig(dz) && (total & 3) == 0 &&
+        ((((uintptr_t)dy.p) | ((uintptr_t)y.p) | ((uintptr_t)dz.p)) & 15) == 0) {
+        ProfScope ps(s, "relu_mask_flat", 0.0, 12.0 * (double)total);
+        hipLaunchKernelGGL(relu_mask_flat4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(dy.p), reinterpret_cast<const float4*>(y.p),
+                           reinterpret_cast<float4*>(dz.p), total / 4);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int TX = pick_tx(dy.C);
     const int TY = 256 / TX;
     const int nb = bias_blocks(npix, TY);

@@ -145,22 +145,21 @@ struct ConvOp : GOp {
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;      // nothing flowed into this op
         TView dY = out_view(g, true, c.B, c.b_off, c.b_cnt);
-        const bool need_db = c.param_grads && b >= 0;
-        if (relu || need_db) {
-            TView none{nullptr, 0, 0, 0, 0, 0, 0, 0};
-            TView Y = out_view(g, false, c.B, c.b_off, c.b_cnt);
-            bias_act_backward(g.stream, dY, relu ? Y : none, relu ? dY : none, need_db ? g.gp(b) : nullptr,
-                              need_db ? (int)g.params[b].grad_written : 0, g.workspace, g.workspace_bytes);
-            if (need_db) g.params[b].grad_written = true;
+        if (relu) {      // dZ = dY * [y > 0], in place (every consumer of y has already contributed to dY)
+            bias_act_backward(g.stream, dY, out_view(g, false, c.B, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace,
+                              g.workspace_bytes);
         }
         if (add >= 0 && wants_grad(g, add, c)) {
             view_axpy(g.stream, dY, g.view(add, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[add].grad_written);
             g.tensors[add].grad_written = true;
         }
-        if (c.param_grads) {
+        if (c.param_grads) {     // weight gradient; the bias gradient (column sums of dZ) rides along
+            const bool need_db = b >= 0;
             conv2d_wgrad(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, g.gp(w),
-                         g.params[w].grad_written, g.workspace, g.workspace_bytes);
+                         g.params[w].grad_written, need_db ? g.gp(b) : nullptr,
+                         need_db ? (int)g.params[b].grad_written : 0, g.workspace, g.workspace_bytes);
             g.params[w].grad_written = true;
+            if (need_db) g.params[b].grad_written = true;
         }
         if (wants_grad(g, in, c)) {
             float* wt = g.Wt + wt_off;

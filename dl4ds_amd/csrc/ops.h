@@ -15,10 +15,10 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
                     const ConvEpilogue& ep);
 // wt[(KS*KS-1-tap)][co][ci] = w[tap][ci][co] : conv2d_forward(dz, wt) == dgrad
 void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int Cin, int Cout);
-// dw[tap][ci][co] (+)= sum_{n,y,x} x[n,y+ky-p,x+kx-p,ci] * dz[n,y,x,co]
+// dw[tap][ci][co] (+)= sum_{n,y,x} x[n,y+ky-p,x+kx-p,ci] * dz[n,y,x,co] ; db[co] (+)= sum dz[n,y,x,co] (db may be null)
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS);
-void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate,
-                  float* workspace, size_t workspace_bytes);
+void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate, float* db,
+                  int accumulate_db, float* workspace, size_t workspace_bytes);
 // Conv2DTranspose(k, stride s, 'same', no bias), kernel HWOI [k*k][Cout][Cin] (blocks.py:508-516)
 void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, int KS, int stride,
                               const TView& out, int relu, float* workspace, size_t workspace_bytes);
