@@ -345,6 +345,14 @@ int dl4ds_graph_input(dl4ds_graph* g, int H, int W, int C, int nmul, int* tid) {
     *tid = g->g.add_tensor(H, W, C, nmul, false, true);
     API_END
 }
+int dl4ds_graph_input_requires_grad(dl4ds_graph* g, int tid) {
+    API_BEGIN
+    DL4DS_REQUIRE(!g->g.finalized, "graph already finalized");
+    GTensor& t = g->g.tensors.at(tid);
+    DL4DS_REQUIRE(t.is_input, "not an input tensor");
+    t.requires_grad = true;
+    API_END
+}
 int dl4ds_graph_param(dl4ds_graph* g, size_t n, int* pid) {
     API_BEGIN
     *pid = g->g.add_param(n);

@@ -1,0 +1,146 @@
+// One conditional-GAN optimisation step -- dl4ds/training/cgan.py:575-639 (train_step) with generator_loss
+// (:525-553, total = BCE(1, D(fake)) + lambda * px_loss) and discriminator_loss (:556-572).
+//
+// The reference runs D twice (real, fake) under two gradient tapes.  Here D runs ONCE on a 2B batch
+// [real ; fake] (same weights, per-sample independent), then two backward passes through it:
+//   pass 1: dL_D/dp on all 2B rows  -> D parameter gradients (no input gradients)
+//   pass 2: dL_G,gan/dp on the fake half only -> gradient w.r.t. D's HR input = dL/d(generated), no D parameter grads
+// and the generator back-propagates lambda * dpx/dgen + (pass-2 result).
+#include "graph.h"
+#include "runtime.h"
+#include "dist.h"
+#include <cmath>
+
+Trainer* trainer_create(Graph* g, int loss_kind, const AdamCfg& cfg);
+void graph_load_inputs(Graph& g, const float* const* inputs, int n_inputs, int B, bool is_host);
+void trainer_apply_adam(Trainer& t);
+
+struct CganTrainer {
+    Trainer* G = nullptr;
+    Trainer* D = nullptr;
+    int px_kind = LOSS_MAE;
+    float lam = 100.f;
+    float* d_losses = nullptr;     // [0] gen_gan [1] gen_px [2] d_real [3] d_fake
+    float* hr = nullptr;
+    size_t hr_floats = 0;
+    float* loss_ws = nullptr;
+    size_t loss_ws_bytes = 0;
+};
+
+CganTrainer* cgan_create(Graph* gen, Graph* disc, int px_loss_kind, float lr, float beta1, float lam) {
+    DL4DS_REQUIRE(disc->inputs.size() == 2, "discriminator must have two inputs (lr/conditioning, hr/generated)");
+    DL4DS_REQUIRE(disc->tensors[disc->inputs[1]].requires_grad, "discriminator HR input must be created with requires_grad");
+    const GTensor& go = gen->tensors[gen->outputs.at(0)];
+    const GTensor& dr = disc->tensors[disc->inputs[1]];
+    DL4DS_REQUIRE(go.H == dr.H && go.W == dr.W && go.C == dr.C && go.nmul == dr.nmul,
+                  "generator output and discriminator HR input shapes differ");
+    AdamCfg c;
+    c.lr0 = c.lr1 = lr;
+    c.beta1 = beta1;
+    CganTrainer* t = new CganTrainer();
+    t->G = trainer_create(gen, px_loss_kind, c);
+    t->D = trainer_create(disc, LOSS_MAE, c);
+    t->px_kind = px_loss_kind;
+    t->lam = lam;
+    HIP_CHECK(hipMalloc((void**)&t->d_losses, 8 * sizeof(float)));
+    HIP_CHECK(hipMemset(t->d_losses, 0, 8 * sizeof(float)));
+    return t;
+}
+
+void cgan_destroy(CganTrainer* t) {
+    if (!t) return;
+    delete t->G;
+    delete t->D;
+    if (t->d_losses) (void)hipFree(t->d_losses);
+    if (t->hr) (void)hipFree(t->hr);
+    if (t->loss_ws) (void)hipFree(t->loss_ws);
+    delete t;
+}
+Trainer* cgan_disc_trainer(CganTrainer* t) { return t->D; }
+Trainer* cgan_gen_trainer(CganTrainer* t) { return t->G; }
+
+void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B, bool is_host,
+               const float* dropout_keep_host, bool apply_update, float* losses_host) {
+    Graph& G = *t.G->g;
+    Graph& D = *t.D->g;
+    hipStream_t s = G.stream;
+    const GTensor& go = G.tensors[G.outputs[0]];
+    const size_t hr_n = go.per_sample() * B;
+    // ---- generator forward
+    graph_load_inputs(G, gen_inputs, n_gen_inputs, B, is_host);
+    if (hr_n > t.hr_floats) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (t.hr) HIP_CHECK(hipFree(t.hr));
+        HIP_CHECK(hipMalloc((void**)&t.hr, hr_n * sizeof(float)));
+        t.hr_floats = hr_n;
+    }
+    const size_t lws = loss_workspace_bytes(t.px_kind, B * go.nmul, go.H, go.W, go.C);
+    if (lws > t.loss_ws_bytes) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (t.loss_ws) HIP_CHECK(hipFree(t.loss_ws));
+        HIP_CHECK(hipMalloc((void**)&t.loss_ws, lws));
+        t.loss_ws_bytes = lws;
+    }
+    HIP_CHECK(hipMemcpyAsync(t.hr, hr, hr_n * sizeof(float), is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    G.forward(B, true);
+    // ---- discriminator forward on [real ; fake]
+    D.prepare(2 * B);
+    GTensor& dlr = D.tensors[D.inputs[0]];
+    GTensor& dhr = D.tensors[D.inputs[1]];
+    const GTensor& glr = G.tensors[G.inputs[0]];
+    DL4DS_REQUIRE(glr.per_sample() == dlr.per_sample(), "discriminator conditioning input must match the generator's first input");
+    const size_t lr_n = dlr.per_sample() * B;
+    HIP_CHECK(hipMemcpyAsync(dlr.data, glr.data, lr_n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(dlr.data + lr_n, glr.data, lr_n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(dhr.data, t.hr, hr_n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(dhr.data + hr_n, go.data, hr_n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (dropout_keep_host) {
+        DL4DS_REQUIRE(!D.dropout_ops.empty(), "dropout mask given but the discriminator has no dropout op");
+        GOp* dop = D.dropout_ops[0];
+        size_t n = 0;
+        for (size_t i = 0; i < D.ops.size(); ++i)
+            if (D.ops[i].get() == dop) n = dop->saved_floats_per_sample(D) * 2 * B;
+        dop->set_mask(D, dropout_keep_host, n);
+    }
+    D.forward(2 * B, true);
+    GTensor& dout = D.tensors[D.outputs[0]];
+    DL4DS_REQUIRE(dout.per_sample() == 1, "discriminator must output one probability per sample");
+    float* p_real = dout.data;
+    float* p_fake = dout.data + B;
+    // ---- pass 1: discriminator loss -> D parameter gradients
+    D.zero_grad_flags();
+    bce_forward_backward(s, p_real, 1.f, B, 1.f, t.d_losses + 2, dout.grad, 0);
+    bce_forward_backward(s, p_fake, 0.f, B, 1.f, t.d_losses + 3, dout.grad + B, 0);
+    BwdCtx c1{2 * B, 0, 2 * B, true, false};
+    D.backward(c1);
+    // ---- pass 2: generator's adversarial loss through D (fake half, inputs only)
+    bce_forward_backward(s, p_fake, 1.f, B, 1.f, t.d_losses + 0, dout.grad + B, 0);
+    BwdCtx c2{2 * B, B, B, false, true};
+    D.backward(c2);
+    // ---- generator backward: lambda * dpx/dgen + dgan/dgen
+    G.zero_grad_flags();
+    loss_forward_backward(s, t.px_kind, t.hr, go.data, go.grad, B * go.nmul, go.H, go.W, go.C, t.lam, t.d_losses + 1, 0,
+                          t.loss_ws, t.loss_ws_bytes);
+    TView src = make_view(dhr.grad + hr_n, B * go.nmul, go.H, go.W, go.C);
+    TView dst = make_view(go.grad, B * go.nmul, go.H, go.W, go.C);
+    view_axpy(s, src, dst, 1.f, 1);
+    BwdCtx cg{B, 0, B, true, false};
+    G.backward(cg);
+    // ---- data-parallel average + the two Adam updates (cgan.py:608-617)
+    if (apply_update) {
+        dist_allreduce_grads(G.G, G.n_params, s);
+        dist_allreduce_grads(D.G, D.n_params, s);
+        trainer_apply_adam(*t.G);
+        trainer_apply_adam(*t.D);
+    }
+    if (losses_host) {
+        float h[4];
+        HIP_CHECK(hipMemcpyAsync(h, t.d_losses, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const float px = h[1] / t.lam;               // loss kernel was scaled by lambda
+        losses_host[0] = h[0] + t.lam * px;          // gen_total
+        losses_host[1] = h[0];                       // gen_gan
+        losses_host[2] = px;                         // gen_px
+        losses_host[3] = h[2] + h[3];                // disc
+    }
+}

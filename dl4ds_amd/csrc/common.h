@@ -25,6 +25,8 @@ struct TView {
     int vec;
     int cp;              // d2s: channels per (i,j) group = C / r^2
     unsigned mcp, mr;    // d2s: magic multipliers for exact n/cp and n/r (fast_div)
+    size_t nstride;      // floats between consecutive images n (default: contiguous); lets a view pick
+                         // frame t of every sample of a (B,T,H,W,C) buffer without a copy
 };
 
 // exact n / d for 0 <= n < 2^20, 1 <= d <= 4096 with magic = 2^32/d + 1 (0 encodes d == 1)
@@ -36,6 +38,7 @@ __host__ __device__ inline TView make_view(float* p, int N, int H, int W, int C)
     v.p = p; v.N = N; v.H = H; v.W = W; v.C = C; v.ld = C; v.d2s = 0;
     v.vec = ((C & 3) == 0) && ((((uintptr_t)p) & 15) == 0);
     v.cp = C; v.mcp = 0; v.mr = 0;
+    v.nstride = (size_t)H * W * C;
     return v;
 }
 
@@ -46,6 +49,7 @@ __host__ __device__ inline TView make_view_d2s(float* p, int N, int H, int W, in
     v.p = p; v.N = N; v.H = H; v.W = W; v.C = C; v.ld = cp; v.d2s = r;
     v.vec = ((cp & 3) == 0) && ((((uintptr_t)p) & 15) == 0);
     v.cp = cp; v.mcp = div_magic(cp); v.mr = div_magic(r);
+    v.nstride = (size_t)H * W * C;
     return v;
 }
 
@@ -55,18 +59,18 @@ __device__ __forceinline__ size_t view_off(const TView& v, int n, int y, int x, 
         const int g = fast_div(c, v.mcp);
         const int cc = c - g * v.cp;
         const int i = fast_div(g, v.mr), j = g - i * r;
-        return (((size_t)n * (v.H * r) + (y * r + i)) * (size_t)(v.W * r) + (x * r + j)) * v.ld + cc;
+        return (size_t)n * v.nstride + ((size_t)(y * r + i) * (size_t)(v.W * r) + (x * r + j)) * v.ld + cc;
     }
-    return (((size_t)n * v.H + y) * (size_t)v.W + x) * v.ld + c;
+    return (size_t)n * v.nstride + ((size_t)y * v.W + x) * v.ld + c;
 }
 
 // separable addressing: view_off(v,n,y,x,c) == view_pix_base(v,n,y,x) + view_chan_off(v,c)
 __device__ __forceinline__ size_t view_pix_base(const TView& v, int n, int y, int x) {
     if (v.d2s > 1) {
         const int r = v.d2s;
-        return (((size_t)n * (v.H * r) + (size_t)y * r) * (size_t)(v.W * r) + (size_t)x * r) * v.ld;
+        return (size_t)n * v.nstride + (((size_t)y * r) * (size_t)(v.W * r) + (size_t)x * r) * v.ld;
     }
-    return (((size_t)n * v.H + y) * (size_t)v.W + x) * v.ld;
+    return (size_t)n * v.nstride + ((size_t)y * v.W + x) * v.ld;
 }
 __device__ __forceinline__ size_t view_chan_off(const TView& v, int c) {
     if (v.d2s > 1) {

@@ -291,7 +291,7 @@ __global__ void localconv_bwd_kernel(TView x, const float* __restrict__ w, TView
 }
 
 inline int ew_blocks(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 8192)); }
-inline bool plain_contig(const TView& v) { return v.d2s <= 1 && v.ld == v.C; }
+inline bool plain_contig(const TView& v) { return v.d2s <= 1 && v.ld == v.C && v.nstride == (size_t)v.H * v.W * v.C; }
 
 }  // namespace
 

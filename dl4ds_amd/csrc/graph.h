@@ -42,6 +42,7 @@ struct GOp {
     virtual size_t saved_floats_per_sample(Graph& g) { return 0; }   // op-private saved activations
     float* saved = nullptr;
     virtual void on_finalize(Graph& g) {}
+    virtual bool set_mask(Graph& g, const float* host, size_t n) { return false; }   // dropout keep-mask injection
     const char* kind = "op";
 };
 
@@ -50,6 +51,7 @@ struct Graph {
     std::vector<GParam> params;
     std::vector<std::unique_ptr<GOp>> ops;
     std::vector<int> inputs, outputs;
+    std::vector<GOp*> dropout_ops;
     size_t n_params = 0;
     float* W = nullptr;        // parameter arena
     float* G = nullptr;        // gradient arena

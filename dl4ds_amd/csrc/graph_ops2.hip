@@ -1,0 +1,271 @@
+// Graph ops for the U-Net / CGAN / spatio-temporal configurations: Conv2DTranspose, ConvLSTM2D,
+// GlobalAveragePooling, Dense, Dropout.  See graph.h for the runtime contract.
+#include "graph.h"
+#include "head.h"
+#include <algorithm>
+
+namespace {
+
+inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
+    const GTensor& t = g.tensors[tid];
+    return t.requires_grad && (!t.is_input || c.input_grads);
+}
+template <class T>
+T* push(Graph& g) {
+    T* p = new T();
+    g.ops.emplace_back(p);
+    return p;
+}
+const TView kNone{nullptr, 0, 0, 0, 0, 0, 0, 0};
+
+// ============================================================================================ Conv2DTranspose
+struct ConvTOp : GOp {
+    int in, w, out, KS, stride, Cout, relu;
+    ConvTOp() { kind = "conv2d_transpose"; }
+    size_t workspace_bytes(Graph& g, int B) override {
+        TView x = g.view(in, B, false);
+        TView y = g.view(out, B, false);
+        return conv2d_transpose_workspace_bytes(x, y, KS, stride);
+    }
+    void forward(Graph& g, int B, bool) override {
+        conv2d_transpose_forward(g.stream, g.view(in, B, false), g.wp(w), KS, stride, g.view(out, B, false), relu,
+                                 g.workspace, g.workspace_bytes);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        TView dY = g.view(out, c.B, true, c.b_off, c.b_cnt);
+        if (relu)
+            bias_act_backward(g.stream, dY, g.view(out, c.B, false, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace,
+                              g.workspace_bytes);
+        if (c.param_grads) {
+            conv2d_transpose_wgrad(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, stride, g.gp(w),
+                                   g.params[w].grad_written, g.workspace, g.workspace_bytes);
+            g.params[w].grad_written = true;
+        }
+        if (wants_grad(g, in, c)) {
+            conv2d_transpose_dgrad(g.stream, dY, g.wp(w), KS, stride, g.view(in, c.B, true, c.b_off, c.b_cnt),
+                                   g.tensors[in].grad_written, g.workspace, g.workspace_bytes);
+            g.tensors[in].grad_written = true;
+        }
+    }
+};
+
+// ============================================================================================ ConvLSTM2D
+struct ConvLSTMOp : GOp {
+    int in, out, wk, wr, b, KS, F, T, relu;
+    size_t wt_k = 0, wt_r = 0;
+    ConvLSTMOp() { kind = "convlstm2d"; }
+    void on_finalize(Graph& g) override {
+        wt_k = g.reserve_wt(g.params[wk].n);
+        wt_r = g.reserve_wt(g.params[wr].n);
+    }
+    size_t hw(Graph& g) { return (size_t)g.tensors[in].H * g.tensors[in].W; }
+    size_t saved_floats_per_sample(Graph& g) override {
+        return (size_t)T * hw(g) * (4 * F + F + F + 4 * F) + 2 * hw(g) * F;
+    }
+    size_t workspace_bytes(Graph& g, int B) override {
+        const GTensor& ti = g.tensors[in];
+        TView xa = make_view(nullptr, B * T, ti.H, ti.W, ti.C), za = make_view(nullptr, B * T, ti.H, ti.W, 4 * F);
+        TView hf = make_view(nullptr, B, ti.H, ti.W, F), zf = make_view(nullptr, B, ti.H, ti.W, 4 * F);
+        return std::max(conv2d_wgrad_workspace_bytes(xa, za, KS), conv2d_wgrad_workspace_bytes(hf, zf, KS));
+    }
+    struct Bufs { float *Z, *C, *H, *dZ, *dh, *dc; };
+    Bufs bufs(Graph& g, int B) {
+        const size_t n = (size_t)B * T * hw(g);
+        Bufs r;
+        r.Z = saved; r.C = r.Z + n * 4 * F; r.H = r.C + n * F; r.dZ = r.H + n * F;
+        r.dh = r.dZ + n * 4 * F; r.dc = r.dh + (size_t)B * hw(g) * F;
+        return r;
+    }
+    TView frame(Graph& g, float* base, int B, int t, int ch) {      // frame t of every sample of a (B,T,H,W,ch) buffer
+        const GTensor& ti = g.tensors[in];
+        TView v = make_view(base + (size_t)t * hw(g) * ch, B, ti.H, ti.W, ch);
+        v.nstride = (size_t)T * hw(g) * ch;
+        return v;
+    }
+    void forward(Graph& g, int B, bool) override {
+        const GTensor& ti = g.tensors[in];
+        Bufs bf = bufs(g, B);
+        ConvEpilogue ep;
+        ep.bias = g.wp(b);
+        conv2d_forward(g.stream, g.view(in, B, false), g.wp(wk), KS, make_view(bf.Z, B * T, ti.H, ti.W, 4 * F), ep);
+        for (int t = 0; t < T; ++t) {
+            TView zt = frame(g, bf.Z, B, t, 4 * F);
+            if (t > 0) {
+                ConvEpilogue er;
+                er.accumulate = 1;
+                conv2d_forward(g.stream, frame(g, bf.H, B, t - 1, F), g.wp(wr), KS, zt, er);
+            }
+            convlstm_gates_forward(g.stream, zt, frame(g, bf.C, B, t > 0 ? t - 1 : 0, F), frame(g, bf.C, B, t, F),
+                                   frame(g, bf.H, B, t, F), frame(g, g.tensors[out].data, B, t, F), relu, t == 0);
+        }
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        DL4DS_REQUIRE(c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B), "convlstm: partial-batch backward not supported");
+        const int B = c.B;
+        const GTensor& ti = g.tensors[in];
+        Bufs bf = bufs(g, B);
+        float* Ut = g.Wt + wt_r;
+        conv2d_dgrad_weights(g.stream, g.wp(wr), Ut, KS, F, 4 * F);
+        TView dh = make_view(bf.dh, B, ti.H, ti.W, F), dc = make_view(bf.dc, B, ti.H, ti.W, F);
+        for (int t = T - 1; t >= 0; --t) {
+            TView dzt = frame(g, bf.dZ, B, t, 4 * F);
+            convlstm_gates_backward(g.stream, frame(g, bf.Z, B, t, 4 * F), frame(g, bf.C, B, t > 0 ? t - 1 : 0, F),
+                                    frame(g, bf.C, B, t, F), frame(g, g.tensors[out].data, B, t, F),
+                                    frame(g, g.tensors[out].grad, B, t, F), dh, dc, dzt, relu, t == 0, t == T - 1);
+            if (t > 0) {
+                ConvEpilogue ep;
+                conv2d_forward(g.stream, dzt, Ut, KS, dh, ep);
+            }
+        }
+        TView dZall = make_view(bf.dZ, B * T, ti.H, ti.W, 4 * F);
+        if (c.param_grads) {
+            conv2d_wgrad(g.stream, g.view(in, B, false), dZall, KS, g.gp(wk), g.params[wk].grad_written, g.gp(b),
+                         g.params[b].grad_written, g.workspace, g.workspace_bytes);
+            g.params[wk].grad_written = g.params[b].grad_written = true;
+            for (int t = 1; t < T; ++t) {
+                conv2d_wgrad(g.stream, frame(g, bf.H, B, t - 1, F), frame(g, bf.dZ, B, t, 4 * F), KS, g.gp(wr),
+                             g.params[wr].grad_written, nullptr, 0, g.workspace, g.workspace_bytes);
+                g.params[wr].grad_written = true;
+            }
+        }
+        if (wants_grad(g, in, c)) {
+            float* Kt = g.Wt + wt_k;
+            conv2d_dgrad_weights(g.stream, g.wp(wk), Kt, KS, ti.C, 4 * F);
+            ConvEpilogue ep;
+            ep.accumulate = g.tensors[in].grad_written;
+            conv2d_forward(g.stream, dZall, Kt, KS, g.view(in, B, true), ep);
+            g.tensors[in].grad_written = true;
+        }
+    }
+};
+
+// ============================================================================================ GlobalAveragePooling2D
+struct GapOp : GOp {
+    int in, out;
+    GapOp() { kind = "gap"; }
+    void forward(Graph& g, int B, bool) override {
+        const GTensor& ti = g.tensors[in];
+        gap_forward(g.stream, ti.data, g.tensors[out].data, B * ti.nmul, ti.H * ti.W, ti.C);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        const GTensor& ti = g.tensors[in];
+        const int cnt = (c.b_cnt < 0 ? c.B : c.b_cnt) * ti.nmul;
+        gap_backward(g.stream, g.tensors[out].grad + (size_t)c.b_off * ti.nmul * ti.C,
+                     ti.grad + (size_t)c.b_off * ti.per_sample(), cnt, ti.H * ti.W, ti.C, ti.grad_written);
+        g.tensors[in].grad_written = true;
+    }
+};
+
+// ============================================================================================ Dense (+activation)
+struct DenseOp : GOp {
+    int in, out, w, b, F, act;
+    DenseOp() { kind = "dense"; }
+    void forward(Graph& g, int B, bool) override {
+        const GTensor& ti = g.tensors[in];
+        dense_forward(g.stream, ti.data, g.wp(w), b >= 0 ? g.wp(b) : nullptr, g.tensors[out].data, B * ti.nmul, ti.C, F, act);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        const GTensor& ti = g.tensors[in];
+        const int cnt = (c.b_cnt < 0 ? c.B : c.b_cnt) * ti.nmul;
+        const bool dx = wants_grad(g, in, c);
+        dense_backward(g.stream, ti.data, g.wp(w), g.tensors[out].data, g.tensors[out].grad, dx ? ti.grad : nullptr,
+                       ti.grad_written, g.gp(w), b >= 0 ? g.gp(b) : nullptr, g.params[w].grad_written, c.param_grads,
+                       c.b_off * ti.nmul, cnt, ti.C, F, act);
+        if (dx) g.tensors[in].grad_written = true;
+        if (c.param_grads) {
+            g.params[w].grad_written = true;
+            if (b >= 0) g.params[b].grad_written = true;
+        }
+    }
+};
+
+// ============================================================================================ Dropout
+struct DropoutOp : GOp {
+    int in, out;
+    float rate;
+    bool injected = false;
+    unsigned long long counter = 0;
+    DropoutOp() { kind = "dropout"; }
+    size_t saved_floats_per_sample(Graph& g) override { return g.tensors[in].per_sample(); }
+    bool set_mask(Graph& g, const float* host, size_t n) override {
+        HIP_CHECK(hipMemcpyAsync(saved, host, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        injected = true;
+        return true;
+    }
+    void forward(Graph& g, int B, bool training) override {
+        const size_t n = g.tensors[in].per_sample() * B;
+        if (!training) {
+            HIP_CHECK(hipMemcpyAsync(g.tensors[out].data, g.tensors[in].data, n * sizeof(float), hipMemcpyDeviceToDevice,
+                                     g.stream));
+            return;
+        }
+        if (!injected) dropout_make_mask(g.stream, saved, n, rate, 0x5DEECE66Dull + (++counter) * 0x1000003ull);
+        injected = false;
+        dropout_apply(g.stream, g.tensors[in].data, saved, g.tensors[out].data, n, 1.f / (1.f - rate), 0);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        const size_t ps = g.tensors[in].per_sample();
+        const size_t off = (size_t)c.b_off * ps, n = (size_t)(c.b_cnt < 0 ? c.B : c.b_cnt) * ps;
+        dropout_apply(g.stream, g.tensors[out].grad + off, saved + off, g.tensors[in].grad + off, n, 1.f / (1.f - rate),
+                      g.tensors[in].grad_written);
+        g.tensors[in].grad_written = true;
+    }
+};
+
+}  // namespace
+
+int g_conv2d_transpose(Graph& g, int in, int w, int KS, int stride, int Cout, int relu) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(g.params.at(w).n == (size_t)KS * KS * Cout * ti.C, "conv2d_transpose: kernel parameter size mismatch");
+    const int out = g.add_tensor(ti.H * stride, ti.W * stride, Cout, ti.nmul, true, false);
+    ConvTOp* op = push<ConvTOp>(g);
+    op->in = in; op->w = w; op->out = out; op->KS = KS; op->stride = stride; op->Cout = Cout; op->relu = relu;
+    return out;
+}
+
+int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, int relu) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(ti.nmul == T, "convlstm: input tensor must carry the time window as batch multiplier");
+    DL4DS_REQUIRE(KS == 1 || KS == 3 || KS == 5, "convlstm: kernel size must be 1, 3 or 5");
+    DL4DS_REQUIRE(g.params.at(wk).n == (size_t)KS * KS * ti.C * 4 * F, "convlstm: kernel size mismatch");
+    DL4DS_REQUIRE(g.params.at(wr).n == (size_t)KS * KS * F * 4 * F, "convlstm: recurrent kernel size mismatch");
+    DL4DS_REQUIRE(g.params.at(b).n == (size_t)4 * F, "convlstm: bias size mismatch");
+    const int out = g.add_tensor(ti.H, ti.W, F, T, true, false);
+    ConvLSTMOp* op = push<ConvLSTMOp>(g);
+    op->in = in; op->out = out; op->wk = wk; op->wr = wr; op->b = b; op->KS = KS; op->F = F; op->T = T; op->relu = relu;
+    return out;
+}
+
+int g_gap(Graph& g, int in, int) {
+    const GTensor ti = g.tensors.at(in);
+    const int out = g.add_tensor(1, 1, ti.C, ti.nmul, true, false);
+    GapOp* op = push<GapOp>(g);
+    op->in = in; op->out = out;
+    return out;
+}
+
+int g_dense(Graph& g, int in, int w, int b, int F, int act) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(ti.H == 1 && ti.W == 1, "dense: input must be (B,1,1,C)");
+    DL4DS_REQUIRE(g.params.at(w).n == (size_t)ti.C * F, "dense: kernel size mismatch");
+    DL4DS_REQUIRE(act == ACT_NONE || act == ACT_SIGMOID || act == ACT_RELU || act == ACT_TANH, "dense: activation");
+    const int out = g.add_tensor(1, 1, F, ti.nmul, true, false);
+    DenseOp* op = push<DenseOp>(g);
+    op->in = in; op->out = out; op->w = w; op->b = b; op->F = F; op->act = act;
+    return out;
+}
+
+int g_dropout(Graph& g, int in, float rate) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(rate >= 0.f && rate < 1.f, "dropout: rate must be in [0,1)");
+    const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
+    DropoutOp* op = push<DropoutOp>(g);
+    op->in = in; op->out = out; op->rate = rate;
+    g.dropout_ops.push_back(op);
+    return out;
+}

@@ -1,0 +1,142 @@
+// Discriminator head of dl4ds/models/discriminator.py:72-79: GlobalAveragePooling2D -> Dropout(0.4) ->
+// Dense(32, sigmoid) -> Dense(1, sigmoid).  Tiny tensors ((B, C) with C <= a few hundred): one reduction
+// kernel for the pooling, single-wave-per-row kernels for the dense layers; deterministic sums.
+#include "ops.h"
+#include "prof.h"
+#include "head.h"
+#include <algorithm>
+
+namespace {
+
+// out[n][c] = mean over the HW pixels of x[n, :, :, c]
+__global__ void __launch_bounds__(256) gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C) {
+    __shared__ float red[256];
+    const int n = blockIdx.x, c = blockIdx.y;
+    const float* p = x + (size_t)n * HW * C + c;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += p[(size_t)i * C];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)n * C + c] = red[0] / (float)HW;
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int C, size_t total,
+                               int accumulate) {
+    const float inv = 1.f / (float)HW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const size_t n = e / ((size_t)HW * C);
+        const float v = dy[n * C + c] * inv;
+        dx[e] = accumulate ? dx[e] + v : v;
+    }
+}
+
+// y[b][f] = act(b[f] + sum_c x[b][c] w[c][f]); one thread per output
+__global__ void dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                 float* __restrict__ y, int B, int Cin, int F, int act) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * F) return;
+    const int bi = e / F, f = e - bi * F;
+    float s = b ? b[f] : 0.f;
+    for (int c = 0; c < Cin; ++c) s += x[(size_t)bi * Cin + c] * w[(size_t)c * F + f];
+    if (act == ACT_SIGMOID) s = 1.f / (1.f + expf(-s));
+    else if (act == ACT_RELU) s = fmaxf(s, 0.f);
+    else if (act == ACT_TANH) s = tanhf(s);
+    y[e] = s;
+}
+
+// dz = dy * act'(y) (in place over dy); then dW, db, dx -- single block, deterministic loops over the batch
+__global__ void __launch_bounds__(256) dense_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ y, float* __restrict__ dy,
+                                                        float* __restrict__ dx, int acc_dx, float* __restrict__ dw,
+                                                        float* __restrict__ db, int acc_dw, int want_dw, int b0, int B,
+                                                        int Cin, int F, int act) {
+    for (int e = threadIdx.x; e < B * F; e += blockDim.x) {
+        const size_t i = (size_t)b0 * F + e;
+        float g = dy[i];
+        const float yy = y[i];
+        if (act == ACT_SIGMOID) g *= yy * (1.f - yy);
+        else if (act == ACT_RELU) g = yy > 0.f ? g : 0.f;
+        else if (act == ACT_TANH) g *= 1.f - yy * yy;
+        dy[i] = g;
+    }
+    __syncthreads();
+    if (want_dw) {
+        for (int e = threadIdx.x; e < Cin * F; e += blockDim.x) {
+            const int c = e / F, f = e - c * F;
+            float s = 0.f;
+            for (int bi = 0; bi < B; ++bi) s += x[(size_t)(b0 + bi) * Cin + c] * dy[(size_t)(b0 + bi) * F + f];
+            dw[e] = acc_dw ? dw[e] + s : s;
+        }
+        if (db)
+            for (int f = threadIdx.x; f < F; f += blockDim.x) {
+                float s = 0.f;
+                for (int bi = 0; bi < B; ++bi) s += dy[(size_t)(b0 + bi) * F + f];
+                db[f] = acc_dw ? db[f] + s : s;
+            }
+    }
+    if (dx)
+        for (int e = threadIdx.x; e < B * Cin; e += blockDim.x) {
+            const int bi = e / Cin, c = e - bi * Cin;
+            float s = 0.f;
+            for (int f = 0; f < F; ++f) s += dy[(size_t)(b0 + bi) * F + f] * w[(size_t)c * F + f];
+            const size_t o = (size_t)(b0 + bi) * Cin + c;
+            dx[o] = acc_dx ? dx[o] + s : s;
+        }
+}
+
+// counter-based keep mask (splitmix-style hash of (seed, index)); keep with probability 1-rate
+__global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float rate, unsigned long long seed) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (e + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const float u = (float)(z >> 40) * (1.f / 16777216.f);
+        mask[e] = (u >= rate) ? 1.f : 0.f;
+    }
+}
+__global__ void dropout_apply_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
+                                     size_t n, float scale, int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[e] * mask[e] * scale;
+        y[e] = accumulate ? y[e] + v : v;
+    }
+}
+
+inline int ew_blocks(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 4096)); }
+}  // namespace
+
+void gap_forward(hipStream_t s, const float* x, float* out, int N, int HW, int C) {
+    ProfScope ps(s, "gap_fwd", 0.0, 4.0 * (double)N * HW * C);
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, C), dim3(256), 0, s, x, out, HW, C);
+    HIP_CHECK(hipGetLastError());
+}
+void gap_backward(hipStream_t s, const float* dy, float* dx, int N, int HW, int C, int accumulate) {
+    const size_t total = (size_t)N * HW * C;
+    ProfScope ps(s, "gap_bwd", 0.0, 4.0 * (double)total);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, HW, C, total, accumulate);
+    HIP_CHECK(hipGetLastError());
+}
+void dense_forward(hipStream_t s, const float* x, const float* w, const float* b, float* y, int B, int Cin, int F, int act) {
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3(cdiv(B * F, 256)), dim3(256), 0, s, x, w, b, y, B, Cin, F, act);
+    HIP_CHECK(hipGetLastError());
+}
+void dense_backward(hipStream_t s, const float* x, const float* w, const float* y, float* dy, float* dx, int acc_dx,
+                    float* dw, float* db, int acc_dw, int want_dw, int b0, int B, int Cin, int F, int act) {
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3(1), dim3(256), 0, s, x, w, y, dy, dx, acc_dx, dw, db, acc_dw, want_dw, b0, B,
+                       Cin, F, act);
+    HIP_CHECK(hipGetLastError());
+}
+void dropout_make_mask(hipStream_t s, float* mask, size_t n, float rate, unsigned long long seed) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, mask, n, rate, seed);
+    HIP_CHECK(hipGetLastError());
+}
+void dropout_apply(hipStream_t s, const float* x, const float* mask, float* y, size_t n, float scale, int accumulate) {
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, mask, y, n, scale, accumulate);
+    HIP_CHECK(hipGetLastError());
+}

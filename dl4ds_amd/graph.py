@@ -54,9 +54,11 @@ class GraphBuilder:
             pass
 
     # ---------------------------------------------------------------- tensors / params
-    def input(self, H, W, C, nmul=1):
+    def input(self, H, W, C, nmul=1, requires_grad=False):
         tid = ctypes.c_int()
         _lib.check(self._l.dl4ds_graph_input(self.h, int(H), int(W), int(C), int(nmul), ctypes.byref(tid)))
+        if requires_grad:
+            _lib.check(self._l.dl4ds_graph_input_requires_grad(self.h, tid.value))
         t = Tensor(tid.value, int(H), int(W), int(C), int(nmul))
         self.inputs.append(t)
         return t

@@ -18,7 +18,7 @@ def residual_discriminator(n_channels, upsampling, is_spatiotemporal, scale, lr_
     h, w = int(hr_size[0]), int(hr_size[1])
     g = GraphBuilder()
     x_in = g.input(h, w, n_channels)
-    x_ref = g.input(h, w, 1)
+    x_ref = g.input(h, w, 1, requires_grad=True)     # the generator's adversarial gradient flows through it
     x1 = b = g.conv2d(x_in, 'branch1_in', n_filters, 3)
     for i in range(n_res_blocks):
         b = residual_block(g, f'ResidualBlock{i+1}_branch1', b, n_filters, normalization=normalization,

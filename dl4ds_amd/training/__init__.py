@@ -1,1 +1,1 @@
-from .engine import SupervisedEngine
+from .engine import SupervisedEngine, CGANEngine

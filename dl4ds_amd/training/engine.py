@@ -96,3 +96,51 @@ class SupervisedEngine:
             out_m[name] = m[off.value:off.value + n.value].reshape(p['shape'])
             out_v[name] = v[off.value:off.value + n.value].reshape(p['shape'])
         return out_m, out_v, int(step.value)
+
+
+class CGANEngine:
+    """train_step of the CGAN trainer (cgan.py:575-639): one simultaneous generator + discriminator update."""
+
+    def __init__(self, generator, discriminator, loss='mae', learning_rate=2e-4, beta_1=0.5, lambda_scaling_factor=100.0):
+        if loss not in LOSS_KINDS:
+            raise ValueError(f'loss {loss!r} not available on the MI355X path; one of {sorted(LOSS_KINDS)}')
+        if isinstance(learning_rate, (tuple, list)):
+            learning_rate = learning_rate[0]
+        self.generator, self.discriminator = generator, discriminator
+        self._l = _lib.lib()
+        h = ctypes.c_void_p()
+        _lib.check(self._l.dl4ds_cgan_create(generator.graph.h, discriminator.graph.h, LOSS_KINDS[loss],
+                                             float(learning_rate), float(beta_1), float(lambda_scaling_factor),
+                                             ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self._l.dl4ds_trainer_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def step(self, gen_inputs, hr_array, dropout_keep=None, apply_update=True):
+        """Returns (gen_total_loss, gen_gan_loss, gen_px_loss, disc_loss).  dropout_keep: optional (2B, C) keep-mask
+        (real rows first) for the discriminator's Dropout(0.4); None -> generated on the device."""
+        inputs, b = self.generator._prep_inputs(gen_inputs)
+        hr = np.ascontiguousarray(hr_array, np.float32)
+        if hr.shape != (b,) + self.generator.output_shape:
+            raise ValueError(f'hr_array shape {hr.shape} != {(b,) + self.generator.output_shape}')
+        ptrs = (ctypes.c_void_p * len(inputs))(*[a.ctypes.data for a in inputs])
+        mask = None
+        if dropout_keep is not None:
+            mask = np.ascontiguousarray(dropout_keep, np.float32)
+        out = (ctypes.c_float * 4)()
+        _lib.check(self._l.dl4ds_cgan_step(self.h, ptrs, len(inputs), hr.ctypes.data, b, 1,
+                                           None if mask is None else mask.ctypes.data, int(apply_update), out))
+        return tuple(float(v) for v in out)
+
+    def step_device(self, input_ptrs, hr_ptr, batch, want_losses=False):
+        ptrs = (ctypes.c_void_p * len(input_ptrs))(*input_ptrs)
+        out = (ctypes.c_float * 4)()
+        _lib.check(self._l.dl4ds_cgan_step(self.h, ptrs, len(input_ptrs), hr_ptr, int(batch), 0, None, 1,
+                                           out if want_losses else None))
+        return tuple(float(v) for v in out) if want_losses else None

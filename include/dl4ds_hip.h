@@ -108,6 +108,9 @@ int dl4ds_graph_create(dl4ds_graph** g);
 int dl4ds_graph_destroy(dl4ds_graph* g);
 /* nmul: batch multiplier of the tensor (1, or time_window for (B,T,H,W,C) tensors) */
 int dl4ds_graph_input(dl4ds_graph* g, int H, int W, int C, int nmul, int* tensor_id);
+/* allocate a gradient buffer for an input (the discriminator's HR input: the generator's adversarial
+ * gradient flows through it -- cgan.py:600-613) */
+int dl4ds_graph_input_requires_grad(dl4ds_graph* g, int tensor_id);
 int dl4ds_graph_param(dl4ds_graph* g, size_t n, int* param_id);
 int dl4ds_graph_conv2d(dl4ds_graph* g, int in, int w, int b, int add, int KS, int Cout, int relu, int d2s_r, int* out);
 int dl4ds_graph_conv2d_transpose(dl4ds_graph* g, int in, int w, int KS, int stride, int Cout, int relu, int* out);

@@ -65,6 +65,14 @@ SUP_CASES = [
     ('net_postupsampling', dict(backbone_block='convnet', upsampling='spc', scale=5, n_blocks=1, activation='elu',
                                 output_activation='sigmoid'), (1, 8, 8, 1), None),
     ('net_pin', dict(backbone_block='resnet'), (2, 32, 32, 2), None),
+    ('unet_pin', dict(n_filters=4, n_blocks=3, decoder_upsampling='dc'), (2, 32, 32, 3), (2, 32, 32, 1)),
+    ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='spc', attention=True), (1, 16, 24, 2), None),
+    ('unet_pin', dict(n_filters=8, n_blocks=2, decoder_upsampling='rc'), (1, 16, 16, 5), (1, 16, 16, 1)),
+    ('recnet_postupsampling', dict(backbone_block='densenet', upsampling='rc', scale=2, time_window=3, n_filters=4,
+                                   n_blocks=1, attention=True, localcon_layer=True), (2, 3, 8, 8, 1), (2, 16, 16, 1)),
+    ('recnet_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=2, time_window=2, n_filters=4,
+                                   n_blocks=1), (1, 2, 10, 6, 2), None),
+    ('recnet_pin', dict(backbone_block='convnet', time_window=4, n_filters=4, n_blocks=1), (1, 4, 8, 8, 2), None),
 ]
 
 
@@ -122,3 +130,56 @@ def test_cfg2_parameter_count_and_name():
     assert m.output_shape == (64, 64, 1)
     m = PM.net_pin('resnet', 2, 0, (16, 16))
     assert m.count_params() == 121341 and m.name == 'resnet_pin'
+
+
+def test_cgan_step_matches_oracle():
+    """cfg5-shaped (tiny): U-Net(dc decoder) generator + residual discriminator, one CGAN step with an injected
+    dropout mask: losses, both gradient sets and the two Adam updates against the torch-CPU restatement."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import CGANEngine
+    B, H = 2, 16
+    gcfg = dict(n_filters=4, n_blocks=2, decoder_upsampling='dc')
+    dcfg = dict(upsampling='pin', scale=8, n_filters=4, n_res_blocks=2)
+    gen = PM.unet_pin('unet', 3, 1, hr_size=(H, H), seed=3, **gcfg)
+    disc = PM.residual_discriminator(3, 'pin', False, 8, (H // 8, H // 8), n_filters=4, n_res_blocks=2, hr_size=(H, H),
+                                     seed=4)
+    rng = np.random.default_rng(9)
+    for m in (gen, disc):
+        w = m.get_weights()
+        for k in w:
+            if k.endswith('bias'):
+                w[k] = (rng.standard_normal(w[k].shape) * 0.05).astype(np.float32)
+        m.set_weights(w)
+    PG = M.Params(); PD = M.Params()
+    for k, v in gen.get_weights().items():
+        PG[k] = v.astype(np.float64)
+    for k, v in disc.get_weights().items():
+        PD[k] = v.astype(np.float64)
+    lr = rng.random((B, H, H, 3)).astype(np.float32)
+    st = rng.random((B, H, H, 1)).astype(np.float32)
+    hr = rng.random((B, H, H, 1)).astype(np.float32)
+    mask = (rng.random((2 * B, 8)) > 0.4).astype(np.float32)
+    PGt, PDt = M.convert(PG, T, requires_grad=True), M.convert(PD, T, requires_grad=True)
+    optG, optD = TR.Adam(PGt, lr=2e-4, beta1=0.5), TR.Adam(PDt, lr=2e-4, beta1=0.5)
+    t64 = lambda a: T.asarray(a.astype(np.float64))
+    ref = TR.cgan_step('unet_pin', gcfg, PGt, dcfg, PDt, t64(lr), t64(hr), t64(st),
+                       dropout_masks=(t64(mask[:B]), t64(mask[B:])), optG=optG, optD=optD)
+    eng = CGANEngine(gen, disc, loss='mae', learning_rate=2e-4, beta_1=0.5)
+    g0, d0 = gen.get_weights(), disc.get_weights()
+    out = eng.step([lr, st], hr, dropout_keep=mask)
+    assert out[0] == pytest.approx(ref['gen_total'], rel=1e-4)
+    assert out[1] == pytest.approx(ref['gen_gan'], rel=1e-4)
+    assert out[2] == pytest.approx(ref['gen_px'], rel=1e-4)
+    assert out[3] == pytest.approx(ref['disc'], rel=1e-4)
+    gg, gd = gen.get_gradients(), disc.get_gradients()
+    sg = max(float(v.abs().max()) for v in ref['gradsG'].values())
+    sd = max(float(v.abs().max()) for v in ref['gradsD'].values())
+    for k, v in ref['gradsG'].items():
+        assert np.abs(gg[k] - v.numpy()).max() / sg < 1e-3, k
+    for k, v in ref['gradsD'].items():
+        assert np.abs(gd[k] - v.numpy()).max() / sd < 1e-3, k
+    # first Adam step = -lr * sign(g) (to eps): compare against the oracle's updated weights
+    for m, P0, Pt in ((gen, g0, PGt), (disc, d0, PDt)):
+        w = m.get_weights()
+        for k in w:
+            assert np.abs((w[k] - P0[k]) - (Pt[k].detach().numpy() - P0[k])).max() < 0.2 * 2e-4 + 1e-7, k

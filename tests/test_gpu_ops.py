@@ -219,3 +219,18 @@ def test_adam_matches_keras_form(ops):
         close(aw, rw, 1e-6)
         close(am, rm, 1e-6)
         close(av, rv, 1e-6)
+
+
+@pytest.mark.parametrize('n,h,w,ci,co,s', [(2, 6, 7, 4, 3, 2), (1, 8, 8, 16, 8, 2), (1, 4, 5, 24, 16, 2),
+                                           (1, 5, 4, 6, 4, 4), (1, 3, 3, 5, 2, 5), (1, 4, 4, 8, 8, 8)])
+def test_conv2d_transpose_fwd_dgrad_wgrad(ops, n, h, w, ci, co, s):
+    x, wt = R(n, h, w, ci), R(9, 9, co, ci) * 0.1
+    ref = N.conv2d_transpose(x.astype(np.float64), wt.astype(np.float64), s)
+    close(ops.conv2d_transpose(x, wt, s), ref)
+    close(ops.conv2d_transpose(x, wt, s, relu=True), np.maximum(ref, 0))
+    dz = R(*ref.shape)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wtt = torch.tensor(wt, dtype=torch.float64, requires_grad=True)
+    (T.conv2d_transpose(xt, wtt, s) * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    close(ops.conv2d_transpose_dgrad(dz, wt, s), xt.grad.numpy())
+    close(ops.conv2d_transpose_wgrad(x, dz, 9, s), wtt.grad.numpy())
