@@ -1,0 +1,295 @@
+// DSSIM loss of dl4ds/losses.py:23-55 fused with its gradient w.r.t. the prediction:
+//   drange = max(max y, max p) - min(min y, min p)   (whole batch; differentiated through, like TF does)
+//   x = y - min(y) if min(y) < 0 else y ;  q = p - min(p) if min(p) < 0 else p
+//   ssim   = tf.image.ssim(x, q, max_val=drange, 11x11 gaussian sigma 1.5, VALID, k1=.01, k2=.03)
+//   dssim  = mean_n((1 - ssim_n)/2)
+// Kernels: (1) min/max(+arg) reduction, (2) 16x16-tile SSIM map from an LDS halo tile (121 taps, four
+// filtered moments) emitting the three per-map derivatives, (3) the transposed 11x11 filter of those
+// derivatives per input pixel, (4) scalar fix-ups (drange and shift terms routed to arg-max / arg-min).
+#include "ops.h"
+#include "prof.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int KF = 11, KH = 5, TS = 16, TL = TS + KF - 1;    // filter, half, tile, tile+halo
+
+struct Gauss { float g[KF]; };
+Gauss make_gauss() {
+    Gauss k;
+    double s = 0;
+    for (int i = 0; i < KF; ++i) { double c = i - (KF - 1) / 2.0; k.g[i] = (float)std::exp(-c * c / (2.0 * 1.5 * 1.5)); s += k.g[i]; }
+    for (int i = 0; i < KF; ++i) k.g[i] = (float)(k.g[i] / s);   // outer(g,g)/sum == outer(g/s, g/s)
+    return k;
+}
+
+struct Stats {            // device-resident scalars
+    float minT, maxT, minP, maxP;
+    unsigned long long argminP, argmaxP;
+    float sumS, gc1, gc2, sumdy;
+};
+
+__global__ void __launch_bounds__(256) minmax_kernel(const float* __restrict__ t, const float* __restrict__ p, size_t n,
+                                                     float* __restrict__ pf, unsigned long long* __restrict__ pi) {
+    __shared__ float s[4][256];
+    __shared__ unsigned long long si[2][256];
+    float mnT = 3.4e38f, mxT = -3.4e38f, mnP = 3.4e38f, mxP = -3.4e38f;
+    unsigned long long amn = 0, amx = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float a = t[e], b = p[e];
+        mnT = fminf(mnT, a); mxT = fmaxf(mxT, a);
+        if (b < mnP) { mnP = b; amn = e; }
+        if (b > mxP) { mxP = b; amx = e; }
+    }
+    const int i = threadIdx.x;
+    s[0][i] = mnT; s[1][i] = mxT; s[2][i] = mnP; s[3][i] = mxP; si[0][i] = amn; si[1][i] = amx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (i < o) {
+            s[0][i] = fminf(s[0][i], s[0][i + o]);
+            s[1][i] = fmaxf(s[1][i], s[1][i + o]);
+            if (s[2][i + o] < s[2][i] || (s[2][i + o] == s[2][i] && si[0][i + o] < si[0][i])) { s[2][i] = s[2][i + o]; si[0][i] = si[0][i + o]; }
+            if (s[3][i + o] > s[3][i] || (s[3][i + o] == s[3][i] && si[1][i + o] < si[1][i])) { s[3][i] = s[3][i + o]; si[1][i] = si[1][i + o]; }
+        }
+        __syncthreads();
+    }
+    if (i == 0) {
+        for (int k = 0; k < 4; ++k) pf[blockIdx.x * 4 + k] = s[k][0];
+        pi[blockIdx.x * 2] = si[0][0];
+        pi[blockIdx.x * 2 + 1] = si[1][0];
+    }
+}
+__global__ void minmax_finish_kernel(const float* __restrict__ pf, const unsigned long long* __restrict__ pi, int nb,
+                                     Stats* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    float mnT = pf[0], mxT = pf[1], mnP = pf[2], mxP = pf[3];
+    unsigned long long amn = pi[0], amx = pi[1];
+    for (int k = 1; k < nb; ++k) {
+        mnT = fminf(mnT, pf[4 * k]); mxT = fmaxf(mxT, pf[4 * k + 1]);
+        if (pf[4 * k + 2] < mnP || (pf[4 * k + 2] == mnP && pi[2 * k] < amn)) { mnP = pf[4 * k + 2]; amn = pi[2 * k]; }
+        if (pf[4 * k + 3] > mxP || (pf[4 * k + 3] == mxP && pi[2 * k + 1] < amx)) { mxP = pf[4 * k + 3]; amx = pi[2 * k + 1]; }
+    }
+    st->minT = mnT; st->maxT = mxT; st->minP = mnP; st->maxP = mxP; st->argminP = amn; st->argmaxP = amx;
+    st->sumS = 0.f; st->gc1 = 0.f; st->gc2 = 0.f; st->sumdy = 0.f;
+}
+
+// one block = one 16x16 tile of the (Ho,Wo) SSIM map of plane (n,c)
+__global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__ t, const float* __restrict__ p, int H, int W,
+                                                       int C, int Ho, int Wo, int tiles_x, int tiles_y, Gauss gk,
+                                                       const Stats* __restrict__ st, float* __restrict__ dmu,
+                                                       float* __restrict__ da, float* __restrict__ db,
+                                                       float* __restrict__ partial) {
+    __shared__ float sx[TL][TL + 1], sq[TL][TL + 1];
+    __shared__ float red[3][256];
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const int c = b % C, n = b / C;
+    const float shT = st->minT < 0.f ? st->minT : 0.f, shP = st->minP < 0.f ? st->minP : 0.f;
+    const float drange = fmaxf(st->maxT, st->maxP) - fminf(st->minT, st->minP);
+    const float c1 = (0.01f * drange) * (0.01f * drange), c2 = (0.03f * drange) * (0.03f * drange);
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    for (int i = threadIdx.x; i < TL * TL; i += 256) {
+        const int r = i / TL, cc = i % TL;
+        const int y = oy0 + r, x = ox0 + cc;
+        float a = 0.f, q = 0.f;
+        if (y < H && x < W) {
+            const size_t o = (((size_t)n * H + y) * W + x) * C + c;
+            a = t[o] - shT; q = p[o] - shP;
+        }
+        sx[r][cc] = a; sq[r][cc] = q;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    float S = 0.f, g1 = 0.f, g2 = 0.f;
+    if (oy < Ho && ox < Wo) {
+        float mx = 0.f, my = 0.f, A = 0.f, Bq = 0.f;
+#pragma unroll
+        for (int i = 0; i < KF; ++i) {
+            float rx = 0.f, ry = 0.f, ra = 0.f, rb = 0.f;
+#pragma unroll
+            for (int j = 0; j < KF; ++j) {
+                const float a = sx[ly + i][lx + j], q = sq[ly + i][lx + j], w = gk.g[j];
+                rx += w * a; ry += w * q; ra += w * a * q; rb += w * (a * a + q * q);
+            }
+            mx += gk.g[i] * rx; my += gk.g[i] * ry; A += gk.g[i] * ra; Bq += gk.g[i] * rb;
+        }
+        const float N1 = 2.f * mx * my + c1, D1 = mx * mx + my * my + c1;
+        const float N2 = 2.f * A - 2.f * mx * my + c2, D2 = Bq - mx * mx - my * my + c2;
+        const float lum = N1 / D1, cs = N2 / D2;
+        S = lum * cs;
+        const size_t o = (((size_t)n * C + c) * Ho + oy) * Wo + ox;
+        dmu[o] = cs * (2.f * mx / D1 - N1 * 2.f * my / (D1 * D1)) + lum * (-2.f * mx / D2 + N2 * 2.f * my / (D2 * D2));
+        da[o] = lum * 2.f / D2;
+        db[o] = -lum * N2 / (D2 * D2);
+        g1 = cs * (D1 - N1) / (D1 * D1);
+        g2 = lum * (D2 - N2) / (D2 * D2);
+    }
+    red[0][threadIdx.x] = S; red[1][threadIdx.x] = g1; red[2][threadIdx.x] = g2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 3; ++k) partial[(size_t)blockIdx.x * 3 + k] = red[k][0];
+}
+
+__global__ void sum3_kernel(const float* __restrict__ partial, int nb, Stats* st) {
+    __shared__ double red[3][256];
+    double a[3] = {0, 0, 0};
+    for (int k = threadIdx.x; k < nb; k += 256)
+        for (int j = 0; j < 3; ++j) a[j] += partial[(size_t)k * 3 + j];
+    for (int j = 0; j < 3; ++j) red[j][threadIdx.x] = a[j];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int j = 0; j < 3; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { st->sumS = (float)red[0][0]; st->gc1 = (float)red[1][0]; st->gc2 = (float)red[2][0]; }
+}
+
+// one block = one 16x16 tile of INPUT pixels of plane (n,c): transposed 11x11 filter of the derivative maps
+__global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__ t, const float* __restrict__ p, int H, int W,
+                                                       int C, int Ho, int Wo, int tiles_x, int tiles_y, Gauss gk,
+                                                       const Stats* __restrict__ st, const float* __restrict__ dmu,
+                                                       const float* __restrict__ da, const float* __restrict__ db,
+                                                       float coef, float* __restrict__ dpred, int accumulate,
+                                                       float* __restrict__ partial) {
+    __shared__ float s1[TL][TL + 1], s2[TL][TL + 1], s3[TL][TL + 1];
+    __shared__ float red[256];
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const int c = b % C, n = b / C;
+    const float shT = st->minT < 0.f ? st->minT : 0.f, shP = st->minP < 0.f ? st->minP : 0.f;
+    const int y0 = ty * TS, x0 = tx * TS;
+    // input pixel (y,x) is covered by outputs (y-i, x-j), i,j in [0,10]: halo tile starts at (y0-10, x0-10)
+    for (int i = threadIdx.x; i < TL * TL; i += 256) {
+        const int r = i / TL, cc = i % TL;
+        const int oy = y0 - (KF - 1) + r, ox = x0 - (KF - 1) + cc;
+        float a = 0.f, bb = 0.f, d = 0.f;
+        if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+            const size_t o = (((size_t)n * C + c) * Ho + oy) * Wo + ox;
+            a = dmu[o]; bb = da[o]; d = db[o];
+        }
+        s1[r][cc] = a; s2[r][cc] = bb; s3[r][cc] = d;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+    const int y = y0 + ly, x = x0 + lx;
+    float g = 0.f;
+    if (y < H && x < W) {
+        float T1 = 0.f, T2 = 0.f, T3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KF; ++i) {
+            float r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < KF; ++j) {
+                const float w = gk.g[j];
+                r1 += w * s1[ly + (KF - 1) - i][lx + (KF - 1) - j];
+                r2 += w * s2[ly + (KF - 1) - i][lx + (KF - 1) - j];
+                r3 += w * s3[ly + (KF - 1) - i][lx + (KF - 1) - j];
+            }
+            T1 += gk.g[i] * r1; T2 += gk.g[i] * r2; T3 += gk.g[i] * r3;
+        }
+        const size_t o = (((size_t)n * H + y) * W + x) * C + c;
+        const float xv = t[o] - shT, qv = p[o] - shP;
+        g = coef * (T1 + xv * T2 + 2.f * qv * T3);
+        dpred[o] = accumulate ? dpred[o] + g : g;
+    }
+    red[threadIdx.x] = g;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void dssim_finish_kernel(const float* __restrict__ partial, int nb, Stats* st, float weight, float inv_m,
+                                    float coef, float* __restrict__ dpred, float* __restrict__ loss_out, int accumulate_loss) {
+    __shared__ double red[256];
+    double a = 0;
+    for (int k = threadIdx.x; k < nb; k += 256) a += partial[k];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const float sumdy = (float)red[0];
+    const float v = weight * (0.5f - 0.5f * st->sumS * inv_m);
+    loss_out[0] = accumulate_loss ? loss_out[0] + v : v;
+    if (!dpred) return;
+    const float drange = fmaxf(st->maxT, st->maxP) - fminf(st->minT, st->minP);
+    // dL/ddrange through c1=(k1*L)^2, c2=(k2*L)^2
+    const float ddr = coef * (st->gc1 * 2.f * 0.01f * 0.01f * drange + st->gc2 * 2.f * 0.03f * 0.03f * drange);
+    if (st->maxP > st->maxT) dpred[st->argmaxP] += ddr;      // tf.maximum routes ties to its first argument (y_true)
+    if (st->minP < st->minT) dpred[st->argminP] -= ddr;
+    if (st->minP < 0.f) dpred[st->argminP] -= sumdy;         // q = p - min(p)
+}
+
+struct Layout { size_t stats, pf, pi, maps, part, total; int nb_mm; };
+Layout layout(int N, int H, int W, int C) {
+    Layout l;
+    const int Ho = H - KF + 1, Wo = W - KF + 1;
+    l.nb_mm = 512;
+    size_t o = 0;
+    auto bump = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    l.stats = bump(sizeof(Stats));
+    l.pf = bump((size_t)l.nb_mm * 4 * sizeof(float));
+    l.pi = bump((size_t)l.nb_mm * 2 * sizeof(unsigned long long));
+    l.maps = bump(3 * (size_t)N * C * Ho * Wo * sizeof(float));
+    const size_t tiles = (size_t)N * C * cdiv(H, TS) * cdiv(W, TS);
+    l.part = bump(tiles * 3 * sizeof(float));
+    l.total = o;
+    return l;
+}
+}  // namespace
+
+size_t dssim_workspace_bytes(int N, int H, int W, int C) { return layout(N, H, W, C).total; }
+
+void dssim_forward_backward(hipStream_t s, const float* y_true, const float* y_pred, float* dpred, int N, int H, int W, int C,
+                            float weight, float* loss_out, int accumulate_loss, float* workspace, size_t workspace_bytes) {
+    DL4DS_REQUIRE(H >= KF && W >= KF, "dssim needs grids of at least 11x11");
+    Layout l = layout(N, H, W, C);
+    DL4DS_REQUIRE(workspace_bytes >= l.total, "dssim workspace too small");
+    char* base = reinterpret_cast<char*>(workspace);
+    Stats* st = reinterpret_cast<Stats*>(base + l.stats);
+    float* pf = reinterpret_cast<float*>(base + l.pf);
+    unsigned long long* pi = reinterpret_cast<unsigned long long*>(base + l.pi);
+    const int Ho = H - KF + 1, Wo = W - KF + 1;
+    const size_t msz = (size_t)N * C * Ho * Wo;
+    float* dmu = reinterpret_cast<float*>(base + l.maps);
+    float* da = dmu + msz;
+    float* db = da + msz;
+    float* part = reinterpret_cast<float*>(base + l.part);
+    const size_t n = (size_t)N * H * W * C;
+    static const Gauss gk = make_gauss();
+    ProfScope ps(s, "dssim", 0.0, 4.0 * (double)n * 8);
+    const int nb = (int)std::min<size_t>(l.nb_mm, cdivz(n, 256));
+    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n, pf, pi);
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(64), 0, s, pf, pi, nb, st);
+    const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
+    const int nbf = N * C * txo * tyo;
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(nbf), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txo, tyo, gk, st, dmu, da,
+                       db, part);
+    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(256), 0, s, part, nbf, st);
+    const float inv_m = 1.f / (float)msz;
+    const float coef = -0.5f * weight * inv_m;
+    int nbb = 0;
+    if (dpred) {
+        const int txi = cdiv(W, TS), tyi = cdiv(H, TS);
+        nbb = N * C * txi * tyi;
+        hipLaunchKernelGGL(ssim_bwd_kernel, dim3(nbb), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txi, tyi, gk, st, dmu, da,
+                           db, coef, dpred, 1, part);
+    }
+    hipLaunchKernelGGL(dssim_finish_kernel, dim3(1), dim3(256), 0, s, part, nbb, st, weight, inv_m, coef, dpred, loss_out,
+                       accumulate_loss);
+    HIP_CHECK(hipGetLastError());
+}

@@ -234,3 +234,25 @@ def test_conv2d_transpose_fwd_dgrad_wgrad(ops, n, h, w, ci, co, s):
     (T.conv2d_transpose(xt, wtt, s) * torch.tensor(dz, dtype=torch.float64)).sum().backward()
     close(ops.conv2d_transpose_dgrad(dz, wt, s), xt.grad.numpy())
     close(ops.conv2d_transpose_wgrad(x, dz, 9, s), wtt.grad.numpy())
+
+
+@pytest.mark.parametrize('kind', ['dssim', 'dssim_mae', 'dssim_mse', 'dssim_mae_mse'])
+@pytest.mark.parametrize('case', ['positive', 'negative_min', 'pred_sets_range', 'multichannel'])
+def test_dssim_losses(ops, kind, case):
+    c = 2 if case == 'multichannel' else 1
+    yt = rng.random((2, 29, 37, c)).astype(np.float32)
+    yp = (yt + 0.1 * rng.standard_normal(yt.shape)).astype(np.float32)
+    if case == 'positive':
+        yp = np.abs(yp) + 0.01
+    elif case == 'negative_min':
+        yp = yp - 0.3                       # min(pred) < 0 -> shift branch + argmin routing
+        yt = yt - 0.1
+    elif case == 'pred_sets_range':
+        yp[1, 5, 7, 0] = 3.0                # max(pred) > max(true) -> drange gradient reaches the prediction
+        yp[0, 20, 3, 0] = -1.0
+    t = torch.tensor(yp, dtype=torch.float64, requires_grad=True)
+    lv = getattr(T, kind)(torch.tensor(yt, dtype=torch.float64), t)
+    lv.backward()
+    a, g = ops.loss(kind, yt, yp)
+    assert a == pytest.approx(float(lv.detach()), rel=2e-4, abs=1e-6)
+    close(g, t.grad.numpy(), 1e-3)
