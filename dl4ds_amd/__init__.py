@@ -27,3 +27,15 @@ LOSS_FUNCTIONS = ['mae', 'mse', 'dssim', 'dssim_mae', 'dssim_mse', 'dssim_mae_ms
                   'msdssim', 'msdssim_mae', 'msdssim_mae_mse']
 
 DROPOUT_VARIANTS = ['vanilla', 'gaussian', 'spatial', 'mcdrop', 'mcgaussiandrop', 'mcspatialdrop']
+
+
+def __getattr__(name):
+    # lazy: importing the package must not need the GPU library (tests/test_abi.py runs on CPU)
+    import importlib
+    lazy = {'SupervisedTrainer': '.training', 'CGANTrainer': '.training', 'Predictor': '.inference',
+            'predict': '.inference', 'net_postupsampling': '.models', 'net_pin': '.models', 'unet_pin': '.models',
+            'recnet_postupsampling': '.models', 'recnet_pin': '.models', 'residual_discriminator': '.models',
+            'DataGenerator': '.dataloader', 'create_batch_hr_lr': '.dataloader', 'create_pair_hr_lr': '.dataloader'}
+    if name in lazy:
+        return getattr(importlib.import_module(lazy[name], __name__), name)
+    raise AttributeError(name)

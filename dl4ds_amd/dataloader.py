@@ -1,0 +1,201 @@
+"""Host-side batch preparation (numpy) -- the step just BEFORE the hot path.
+
+Mirrors dl4ds/dataloader.py:11-505 and dl4ds/utils.py:251-401 for the cases the trainers use: random
+square crops, coarsening by `scale` (cv2.INTER_AREA at an integer ratio == block mean), re-expansion for
+'pin' models, predictor / static-variable channel stacking, spatio-temporal windows.  OpenCV is not a
+dependency here: 'inter_area' down-scaling is an exact block mean for integer ratios; every other resize
+goes through scipy.ndimage.zoom (order 0/1/3), which is an approximation of cv2's kernels, documented in
+DESIGN.md ("next" row f1: on-device batch preparation).  Season/time-metadata channels are not implemented.
+"""
+import numpy as np
+
+from . import POSTUPSAMPLING_METHODS, INTERPOLATION_METHODS
+
+
+def checkarray_ndim(array, ndim=3, add_axis_position=-1):
+    """utils.py:46-55."""
+    if array.ndim < ndim:
+        return np.expand_dims(array, axis=add_axis_position)
+    return array
+
+
+def crop_array(array, size, yx=None, position=False, rng=None):
+    """utils.py:251-327: square crop of a [y,x(,c)] or [t,y,x,c] array; random corner when yx is None."""
+    if array.ndim not in [2, 3, 4, 5]:
+        raise TypeError('Input array is not a 2D, 3D, or 4D ndarray')
+    if not isinstance(size, (int, np.integer)):
+        raise TypeError('`Size` must be integer')
+    ax = {2: 0, 3: 0, 4: 1, 5: 2}[array.ndim]
+    sy, sx = array.shape[ax], array.shape[ax + 1]
+    if size > sy or size > sx:
+        raise ValueError('`Size` larger than the input image size')
+    if yx is not None:
+        y, x = yx
+    else:
+        rng = np.random if rng is None else rng
+        y = int(rng.randint(0, sy - size + 1)) if hasattr(rng, 'randint') else int(rng.integers(0, sy - size + 1))
+        x = int(rng.randint(0, sx - size + 1)) if hasattr(rng, 'randint') else int(rng.integers(0, sx - size + 1))
+    sl = [slice(None)] * array.ndim
+    sl[ax], sl[ax + 1] = slice(y, y + size), slice(x, x + size)
+    out = array[tuple(sl)]
+    return (out, y, x) if position else out
+
+
+def _resize2d(a, size_y, size_x, interpolation):
+    """a: [y,x,c] float array."""
+    h, w = a.shape[:2]
+    if (h, w) == (size_y, size_x):
+        return a
+    if interpolation == 'inter_area' and h % size_y == 0 and w % size_x == 0:
+        fy, fx = h // size_y, w // size_x
+        return a.reshape(size_y, fy, size_x, fx, -1).mean(axis=(1, 3))
+    if interpolation == 'inter_area' and size_y % h == 0 and size_x % w == 0:
+        return np.repeat(np.repeat(a, size_y // h, axis=0), size_x // w, axis=1)   # nearest-like up-scaling
+    from scipy import ndimage
+    order = {'nearest': 0, 'bilinear': 1, 'inter_area': 1, 'bicubic': 3, 'lanczos': 3}[interpolation]
+    return ndimage.zoom(a, (size_y / h, size_x / w, 1), order=order, mode='nearest', grid_mode=True)
+
+
+def resize_array(array, newsize, interpolation='inter_area', squeezed=True, keep_dynamic_range=False):
+    """utils.py:330-401 (newsize is (x, y) like cv2)."""
+    if interpolation not in INTERPOLATION_METHODS:
+        raise ValueError(f'`interpolation` must be one of {INTERPOLATION_METHODS}. Received {interpolation}')
+    size_x, size_y = newsize
+    a = np.asarray(array, dtype=np.float64)
+    if a.ndim == 2:
+        out = _resize2d(a[..., None], size_y, size_x, interpolation)[..., 0]
+    elif a.ndim == 3:
+        out = _resize2d(a, size_y, size_x, interpolation)
+    elif a.ndim == 4:
+        out = np.stack([_resize2d(a[i], size_y, size_x, interpolation) for i in range(a.shape[0])])
+    else:
+        raise RuntimeError(f'Wrong dimensions, got {a.ndim}')
+    if squeezed:
+        out = np.squeeze(out)
+    if keep_dynamic_range:
+        out = np.clip(out, a_min=a.min(), a_max=a.max())
+    return out
+
+
+def create_pair_hr_lr(array, array_lr, upsampling, scale, patch_size, static_vars=None, predictors=None,
+                      season=None, debug=False, interpolation='inter_area', rng=None):
+    """dataloader.py:11-294 without the season channels.  Returns (hr, lr[, static_hr])."""
+    if season is not None:
+        raise NotImplementedError('season channels are not implemented')
+    hr = np.asarray(array)
+    spt = hr.ndim == 4
+    hr_y, hr_x = (hr.shape[1], hr.shape[2]) if spt else (hr.shape[0], hr.shape[1])
+    lr_given = array_lr is not None
+    nd = 4 if spt else 3
+    crop = None
+    if upsampling == 'pin':
+        if lr_given:
+            lr_full = resize_array(checkarray_ndim(np.asarray(array_lr), nd), (hr_x, hr_y), interpolation, squeezed=False)
+        else:
+            lr_x, lr_y = int(hr_x / scale), int(hr_y / scale)
+            lr_full = resize_array(hr, (lr_x, lr_y), interpolation, squeezed=False)
+            lr_full = resize_array(lr_full, (hr_x, hr_y), interpolation, squeezed=False)
+        hr = checkarray_ndim(hr, nd)
+        lr = checkarray_ndim(lr_full, nd)
+        if predictors is not None:
+            p = resize_array(predictors, (int(hr_x / scale), int(hr_y / scale)), interpolation, squeezed=False)
+            p = resize_array(p, (hr_x, hr_y), interpolation, squeezed=False)
+            lr = np.concatenate([lr, checkarray_ndim(p, nd)], axis=-1)
+        if patch_size is not None:
+            hr, cy, cx = crop_array(hr, patch_size, position=True, rng=rng)
+            lr = crop_array(lr, patch_size, yx=(cy, cx))
+            crop = (cy, cx)
+    elif upsampling in POSTUPSAMPLING_METHODS:
+        hr = checkarray_ndim(hr, nd)
+        if lr_given:
+            lr = checkarray_ndim(np.asarray(array_lr), nd)
+        else:
+            lr = checkarray_ndim(resize_array(hr, (int(hr_x / scale), int(hr_y / scale)), interpolation, squeezed=False), nd)
+        lr_y, lr_x = (lr.shape[1], lr.shape[2]) if spt else (lr.shape[0], lr.shape[1])
+        if predictors is not None:
+            p = checkarray_ndim(resize_array(predictors, (lr_x, lr_y), interpolation, squeezed=False), nd)
+            lr = np.concatenate([lr, p], axis=-1)
+        if patch_size is not None:
+            ps_lr = int(patch_size / scale)
+            lr, cy, cx = crop_array(lr, ps_lr, position=True, rng=rng)
+            hr = crop_array(hr, patch_size, yx=(int(cy * scale), int(cx * scale)))
+            crop = (int(cy * scale), int(cx * scale))
+    else:
+        raise ValueError(f'unknown upsampling {upsampling}')
+    static_hr = None
+    if static_vars is not None:
+        stat = []
+        for var in static_vars:
+            v = checkarray_ndim(np.squeeze(np.asarray(var)), 3)
+            if crop is not None:
+                v = crop_array(v, patch_size, yx=crop)
+            stat.append(v)
+            if not spt:
+                if upsampling in POSTUPSAMPLING_METHODS:
+                    v_lr = checkarray_ndim(resize_array(v, (lr.shape[1], lr.shape[0]), interpolation, squeezed=False), 3)
+                else:
+                    v_lr = v
+                lr = np.concatenate([lr, v_lr], axis=-1)
+        static_hr = np.concatenate(stat, axis=-1).astype('float32')
+    hr = np.asarray(hr, 'float32')
+    lr = np.asarray(lr, 'float32')
+    if static_hr is not None:
+        return hr, lr, static_hr
+    return hr, lr
+
+
+def create_batch_hr_lr(all_indices, index, array, array_lr, upsampling, scale=4, batch_size=32, patch_size=None,
+                       time_window=None, static_vars=None, predictors=None, interpolation='inter_area',
+                       time_metadata=None, rng=None):
+    """dataloader.py:297-360."""
+    idx = all_indices[index * batch_size:(index + 1) * batch_size]
+    b_hr, b_lr, b_aux = [], [], []
+    for i in idx:
+        if time_window is None:
+            d, dl = array[i], (None if array_lr is None else array_lr[i])
+            p = None if predictors is None else predictors[i]
+        else:
+            d, dl = array[i:i + time_window], (None if array_lr is None else array_lr[i:i + time_window])
+            p = None if predictors is None else predictors[i:i + time_window]
+        res = create_pair_hr_lr(d, dl, upsampling, scale, patch_size, static_vars=static_vars, predictors=p,
+                                interpolation=interpolation, rng=rng)
+        if static_vars is not None:
+            b_aux.append(res[2])
+        b_hr.append(res[0])
+        b_lr.append(res[1])
+    if static_vars is not None:
+        return [np.asarray(b_lr), np.asarray(b_aux)], [np.asarray(b_hr)]
+    return [np.asarray(b_lr)], [np.asarray(b_hr)]
+
+
+class DataGenerator:
+    """dataloader.py:363-505 (a keras.utils.Sequence there; a plain indexable object here)."""
+
+    def __init__(self, array, array_lr, backbone, upsampling, scale, batch_size=32, patch_size=None, time_window=None,
+                 static_vars=None, predictors=None, interpolation='inter_area', repeat=None, seed=None, rank=0,
+                 world=1):
+        self.array = np.asarray(getattr(array, 'values', array))
+        self.array_lr = None if array_lr is None else np.asarray(getattr(array_lr, 'values', array_lr))
+        self.batch_size, self.scale, self.upsampling, self.backbone = batch_size, scale, upsampling, backbone
+        self.patch_size, self.time_window = patch_size, time_window
+        self.static_vars = None if static_vars is None else [np.asarray(getattr(v, 'values', v)) for v in static_vars]
+        self.predictors = None if predictors is None else np.concatenate([np.asarray(p) for p in predictors], axis=-1)
+        self.interpolation, self.repeat = interpolation, repeat
+        self.n = self.array.shape[0] - self.time_window if self.time_window is not None else self.array.shape[0]
+        self.rng = np.random.default_rng(seed)
+        perm = self.rng.permutation(self.n)
+        self.indices = perm[rank::world] if world > 1 else perm      # rank-strided shard of one seeded permutation
+        if self.repeat is not None and isinstance(self.repeat, int):
+            self.indices = np.hstack([self.indices for _ in range(self.repeat)])
+        if patch_size is not None and upsampling in POSTUPSAMPLING_METHODS and patch_size % scale != 0:
+            raise ValueError('`patch_size` must be divisible by `scale`')
+
+    def __len__(self):
+        n_batches = len(self.indices) // self.batch_size
+        return n_batches
+
+    def __getitem__(self, index):
+        return create_batch_hr_lr(self.indices, index, self.array, self.array_lr, upsampling=self.upsampling,
+                                  scale=self.scale, batch_size=self.batch_size, patch_size=self.patch_size,
+                                  time_window=self.time_window, static_vars=self.static_vars,
+                                  predictors=self.predictors, interpolation=self.interpolation, rng=self.rng)

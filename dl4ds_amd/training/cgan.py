@@ -1,0 +1,109 @@
+"""CGANTrainer -- same signature and ``.run()`` as dl4ds/training/cgan.py:30-444; ``train_step``,
+``generator_loss`` and ``discriminator_loss`` (:525-639) execute inside libdl4ds_hip (csrc/cgan.hip)."""
+import time
+
+import numpy as np
+
+from .. import POSTUPSAMPLING_METHODS
+from ..dataloader import create_batch_hr_lr
+from .. import models as M
+from .. import parallel
+from .base import Trainer
+from .engine import CGANEngine
+
+
+class CGANTrainer(Trainer):
+    def __init__(self, backbone, upsampling, data_train, data_test, data_train_lr=None, data_test_lr=None,
+                 predictors_train=None, predictors_test=None, scale=5, patch_size=None, time_window=None, loss='mae',
+                 epochs=60, batch_size=16, learning_rates=(2e-4, 2e-4), device='GPU', gpu_memory_growth=True,
+                 model_list=None, steps_per_epoch=None, interpolation='inter_area', static_vars=None,
+                 checkpoints_frequency=0, save=False, save_path=None, save_logs=False, save_loss_history=True,
+                 generator_params={}, discriminator_params={}, verbose=True):
+        super().__init__(backbone=backbone, upsampling=upsampling, data_train=data_train, data_train_lr=data_train_lr,
+                         time_window=time_window, loss=loss, batch_size=batch_size, patch_size=patch_size, scale=scale,
+                         device=device, gpu_memory_growth=gpu_memory_growth, verbose=verbose, model_list=model_list,
+                         save=save, save_path=save_path)
+        self.data_test, self.data_test_lr = data_test, data_test_lr
+        self.predictors_train, self.predictors_test = predictors_train, predictors_test
+        if self.predictors_train is not None and not isinstance(self.predictors_train, list):
+            raise TypeError('`predictors_train` must be a list of ndarrays')
+        if self.predictors_test is not None and not isinstance(self.predictors_test, list):
+            raise TypeError('`predictors_test` must be a list of ndarrays')
+        self.epochs, self.steps_per_epoch, self.interpolation = epochs, steps_per_epoch, interpolation
+        self.static_vars = None if static_vars is None else [getattr(v, 'values', v) for v in static_vars]
+        if self.static_vars is None:
+            # the reference crashes here (cgan.py:354 `static_array=aux_hr` is unbound without static variables)
+            raise ValueError('CGANTrainer needs at least one static variable (reference behaviour: cgan.py:343-354)')
+        self.checkpoints_frequency, self.save_logs, self.save_loss_history = checkpoints_frequency, save_logs, save_loss_history
+        self.generator_params, self.discriminator_params = generator_params, discriminator_params
+        self.learning_rates = learning_rates
+        if self.time_window is not None and not self.model_is_spatiotemporal:
+            self.time_window = None
+        self.gentotal, self.gengan, self.genpxloss, self.disc = [], [], [], []
+
+    def setup_model(self):
+        """cgan.py:174-262."""
+        n_channels, n_aux = self._channels(self.predictors_train, self.static_vars)
+        lr_size, hr_size = self._grid_sizes()
+        gp = self.generator_params
+        if self.upsampling in POSTUPSAMPLING_METHODS:
+            if self.model_is_spatiotemporal:
+                self.generator = M.recnet_postupsampling(backbone_block=self.backbone, upsampling=self.upsampling,
+                                                         scale=self.scale, n_channels=n_channels, n_aux_channels=n_aux,
+                                                         lr_size=lr_size, time_window=self.time_window, **gp)
+            else:
+                self.generator = M.net_postupsampling(backbone_block=self.backbone, upsampling=self.upsampling,
+                                                      scale=self.scale, n_channels=n_channels, n_aux_channels=n_aux,
+                                                      lr_size=lr_size, **gp)
+        elif self.model_is_spatiotemporal:
+            self.generator = M.recnet_pin(backbone_block=self.backbone, n_channels=n_channels, n_aux_channels=n_aux,
+                                          hr_size=hr_size, time_window=self.time_window, **gp)
+        elif self.backbone == 'unet':
+            self.generator = M.unet_pin(backbone_block=self.backbone, n_channels=n_channels, n_aux_channels=n_aux,
+                                        hr_size=hr_size, **gp)
+        else:
+            self.generator = M.net_pin(backbone_block=self.backbone, n_channels=n_channels, n_aux_channels=n_aux,
+                                       hr_size=hr_size, **gp)
+        self.discriminator = M.residual_discriminator(n_channels=n_channels, upsampling=self.upsampling,
+                                                      is_spatiotemporal=self.model_is_spatiotemporal, scale=self.scale,
+                                                      lr_size=lr_size, hr_size=hr_size, **self.discriminator_params)
+        if self.verbose == 1 and self.running_on_first_worker:
+            self.generator.summary(line_length=150)
+            self.discriminator.summary(line_length=150)
+
+    def run(self):
+        """cgan.py:264-444: epoch/step loop around train_step."""
+        t0 = time.time()
+        self.setup_model()
+        self.engine = CGANEngine(self.generator, self.discriminator, loss=self.lossf,
+                                 learning_rate=self.learning_rates[0], beta_1=0.5)
+        n_samples = self.data_train.shape[0] - (self.time_window or 0)
+        if self.steps_per_epoch is None:
+            self.steps_per_epoch = n_samples // self.batch_size
+        rng = np.random.default_rng(17)
+        preds = None if self.predictors_train is None else np.concatenate(self.predictors_train, axis=-1)
+        first = True
+        for epoch in range(self.epochs):
+            idx = parallel.shard_indices(n_samples, self.rank, self.world, seed=17, epoch=epoch)
+            steps = min(self.steps_per_epoch // self.world, len(idx) // self.batch_size)
+            for i in range(steps):
+                (lr_array, aux_hr), (hr_array,) = create_batch_hr_lr(
+                    idx, i, self.data_train, self.data_train_lr, upsampling=self.upsampling, scale=self.scale,
+                    batch_size=self.batch_size, patch_size=self.patch_size, time_window=self.time_window,
+                    static_vars=self.static_vars, predictors=preds, interpolation=self.interpolation, rng=rng)
+                losses = self.engine.step([lr_array, aux_hr], hr_array)
+                if first and self.world > 1:
+                    parallel.broadcast_trainer(self.engine)       # cgan.py:626-637 (after the first step)
+                first = False
+                for lst, v in zip((self.gentotal, self.gengan, self.genpxloss, self.disc), losses):
+                    lst.append(v)
+            if self.verbose and self.running_on_first_worker and steps:
+                print(f'Epoch {epoch + 1}/{self.epochs} - gen_total {self.gentotal[-1]:.4f} gen_gan {self.gengan[-1]:.4f} '
+                      f'gen_px {self.genpxloss[-1]:.4f} disc {self.disc[-1]:.4f}')
+        self.running_time = time.time() - t0
+        if self.save_loss_history and self.save and self.running_on_first_worker:
+            np.save(self.save_path + 'losses.npy', np.array([self.gentotal, self.gengan, self.genpxloss, self.disc]))
+        self.save_results(self.generator, folder_prefix='cgan_')
+        return self
+
+    fit = run
