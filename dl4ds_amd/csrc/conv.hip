@@ -18,6 +18,7 @@
 #include "prof.h"
 #include <algorithm>
 #include <mutex>
+#include <cstdlib>
 
 namespace {
 
@@ -52,7 +53,85 @@ struct ConvParams {
     int relu, accumulate;
     int wvec;
     unsigned m_txy[2];      // magic dividers for tiles_x, tiles_y
+    int dbg;                // ablation flags (DL4DS_CONV_DBG): 1 skip re-staging weights, 2 skip epilogue, 4 skip MFMA
 };
+
+// Epilogue shared by the forward/dgrad kernels.  The MFMA is issued as D = W^T-fragment x pixel-fragment, so with the
+// 16x16x4 C/D layout (col = lane&15, row = (lane>>4)*4 + reg) every lane owns FOUR CONSECUTIVE output channels
+// (cout = tile*16 + lq*4 + reg) of ONE pixel (column l15 of the m-tile's row): one 16-byte store per accumulator tile
+// instead of four scattered dword stores -- the epilogue is store-issue bound, so this is worth ~1.5x on the whole
+// kernel.  Offsets are separable (pixel base + channel offset), which also covers depth_to_space views.
+template <int MT, int NT>
+struct AccPack { f32x4 v[MT][NT]; };
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& a, const AccPack<MT, NT> accp, int n, int x0, int y0, int n0,
+                                              int wm, int wn, int l15, int lq) {
+    const bool vec_ok = a.out.vec && (!a.add.p || a.add.vec) && (!a.mask.p || a.mask.vec) && ((a.Cout & 3) == 0);
+    const int gx = x0 + l15;
+    // Two separately unrolled nests (vector / scalar) keep each body under clang's pragma-unroll size cap; a rolled
+    // loop would index the accumulators dynamically and push all of them through scratch memory.
+    if (vec_ok) {
+        // Cout % 4 == 0 and co % 4 == 0: a lane's four channels are all valid or all out of range
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + (wn * NT + j) * 16 + lq * 4;
+            const bool co_ok = co < a.Cout;
+            const int cs = co_ok ? co : 0;
+            const size_t q_out = view_chan_off(a.out, cs);
+            const size_t q_add = a.add.p ? view_chan_off(a.add, cs) : 0;
+            const size_t q_mask = a.mask.p ? view_chan_off(a.mask, cs) : 0;
+            float4 bias_v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias && co_ok) bias_v = *reinterpret_cast<const float4*>(a.bias + cs);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int gy = y0 + wm * MT + i;
+                if (co_ok && gy < a.H && gx < a.W) {
+                    float4 v = make_float4(accp.v[i][j][0] + bias_v.x, accp.v[i][j][1] + bias_v.y,
+                                           accp.v[i][j][2] + bias_v.z, accp.v[i][j][3] + bias_v.w);
+                    if (a.add.p) {
+                        const float4 r = *reinterpret_cast<const float4*>(a.add.p + view_pix_base(a.add, n, gy, gx) + q_add);
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (a.mask.p) {
+                        const float4 m = *reinterpret_cast<const float4*>(a.mask.p + view_pix_base(a.mask, n, gy, gx) + q_mask);
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    }
+                    float4* dst = reinterpret_cast<float4*>(a.out.p + view_pix_base(a.out, n, gy, gx) + q_out);
+                    if (a.accumulate) {
+                        const float4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *dst = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + (wn * NT + j) * 16 + lq * 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int gy = y0 + wm * MT + i;
+                const bool pix_ok = gy < a.H && gx < a.W;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    if (pix_ok && co + rg < a.Cout) {
+                        float t = accp.v[i][j][rg] + (a.bias ? a.bias[co + rg] : 0.f);
+                        if (a.add.p) t += a.add.p[view_off(a.add, n, gy, gx, co + rg)];
+                        if (a.relu) t = fmaxf(t, 0.f);
+                        if (a.mask.p) t = (a.mask.p[view_off(a.mask, n, gy, gx, co + rg)] > 0.f) ? t : 0.f;
+                        const size_t o = view_off(a.out, n, gy, gx, co + rg);
+                        if (a.accumulate) t += a.out.p[o];
+                        a.out.p[o] = t;
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int KS, int MT, int NT, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvParams a) {
@@ -188,7 +267,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) av[i] = an[i];
@@ -199,46 +278,207 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
         }
     }
 
-    // ---- epilogue.  C/D layout of 16x16x4: col = lane&15 (cout), row = (lane>>4)*4 + reg (pixel).
-    // Addresses are separable: offset = pixel_base(i, rg) + channel_offset(j)  (also for d2s views).
-    size_t q_out[NT], q_add[NT], q_mask[NT];
-    float bias_v[NT];
-    bool co_ok[NT];
+    {
+        AccPack<MT, NT> accp;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = n0 + (wn * NT + j) * 16 + l15;
-        co_ok[j] = co < a.Cout;
-        const int cs = co_ok[j] ? co : 0;
-        q_out[j] = view_chan_off(a.out, cs);
-        q_add[j] = a.add.p ? view_chan_off(a.add, cs) : 0;
-        q_mask[j] = a.mask.p ? view_chan_off(a.mask, cs) : 0;
-        bias_v[j] = (a.bias && co_ok[j]) ? a.bias[cs] : 0.f;
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) accp.v[i][j] = acc[i][j];
+        conv_epilogue<MT, NT>(a, accp, n, x0, y0, n0, wm, wn, l15, lq);
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// Pipelined variant for the MFMA-bound layers whose whole input-channel range fits one LDS chunk
+// (the 48->192 sub-pixel convolutions): 8 waves share a 16x16-pixel tile (filter traffic per MFMA halves),
+// the filter slice of tap t+1 is fetched into registers while tap t's MFMAs issue and is written to the
+// second LDS buffer afterwards -> global/L2 latency never sits on the MFMA critical path, one barrier per tap.
+template <int KS, int MT, int NT, int WM, int WN, int WREG>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_pipe_kernel(const ConvParams a) {
+    constexpr int TW = 16;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int BM = WM * MT * 16;
+    constexpr int TH = BM / TW;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BN4 = BN / 4;
+    constexpr int PAD = KS / 2;
+    constexpr int TWH = TW + KS - 1;
+    constexpr int THH = TH + KS - 1;
+    constexpr int HPIX = TWH * THH;
+    constexpr int NP = (BN % 32 == 0) ? BN + 16 : BN;
+    constexpr int KK = KS * KS;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CK = a.CK;                 // == Cin rounded up to 4 (single chunk)
+    const int P = CK + 2;
+    float* in_tile = smem;
+    float* w_tile = smem + ((HPIX * P + 3) & ~3);        // two buffers of CK*NP floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int n0 = blockIdx.y * BN;
+
+    int a_base[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int gy = y0 + wm * MT + i;
+    for (int i = 0; i < MT; ++i) a_base[i] = ((wm * MT + i) * TWH + l15) * P + lq;
+    const int b_base = lq * NP + wn * NT * 16 + l15;
+
+    f32x4 acc[MT][NT];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int gx = x0 + lq * 4 + rg;
-            const bool pix_ok = (gy < a.H) && (gx < a.W);
-            const int sy = pix_ok ? gy : 0, sx = pix_ok ? gx : 0;
-            const size_t p_out = view_pix_base(a.out, n, sy, sx);
-            const size_t p_add = a.add.p ? view_pix_base(a.add, n, sy, sx) : 0;
-            const size_t p_mask = a.mask.p ? view_pix_base(a.mask, n, sy, sx) : 0;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (pix_ok && co_ok[j]) {
-                    float v = acc[i][j][rg] + bias_v[j];
-                    if (a.add.p) v += a.add.p[p_add + q_add[j]];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.mask.p) v = (a.mask.p[p_mask + q_mask[j]] > 0.f) ? v : 0.f;
-                    const size_t o = p_out + q_out[j];
-                    if (a.accumulate) v += a.out.p[o];
-                    a.out.p[o] = v;
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ck4 = CK >> 2;
+    const int wtotal = CK * BN4;          // float4 per tap slice (rows padded to CK)
+    float4 wreg[WREG];
+    auto load_w = [&](int tap) {
+        const float* wsrc = a.w + (size_t)tap * a.Cin * a.Cout;
+#pragma unroll
+        for (int u = 0; u < WREG; ++u) {
+            const int idx = tid + u * NTHR;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < wtotal) {
+                const int r = idx / BN4;
+                const int q = idx - r * BN4;
+                const int co = n0 + q * 4;
+                if (r < a.Cin && co < a.Cout) {
+                    const float* src = wsrc + (size_t)r * a.Cout + co;
+                    if (a.wvec && co + 3 < a.Cout) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (co + 1 < a.Cout) v.y = src[1];
+                        if (co + 2 < a.Cout) v.z = src[2];
+                        if (co + 3 < a.Cout) v.w = src[3];
+                    }
                 }
             }
+            wreg[u] = v;
         }
+    };
+    auto store_w = [&](int buf) {
+        float* wdst = w_tile + buf * CK * NP;
+#pragma unroll
+        for (int u = 0; u < WREG; ++u) {
+            const int idx = tid + u * NTHR;
+            if (idx < wtotal) {
+                const int r = idx / BN4;
+                const int q = idx - r * BN4;
+                *reinterpret_cast<float4*>(wdst + r * NP + q * 4) = wreg[u];
+            }
+        }
+    };
+
+    load_w(0);
+    {
+        const unsigned m4 = div_magic(ck4);
+        staged_copy<4, NTHR>(
+            HPIX * ck4, tid,
+            [&](int idx) {
+                const int pix = fast_div(idx, m4);
+                const int q = idx - pix * ck4;
+                const int r = pix / TWH;
+                const int c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = view_load4(a.in, n, gy, gx, q * 4);
+                return v;
+            },
+            [&](int idx, float4 v) {
+                const int pix = fast_div(idx, m4);
+                const int q = idx - pix * ck4;
+                float2* d = reinterpret_cast<float2*>(in_tile + pix * P + q * 4);
+                d[0] = make_float2(v.x, v.y);
+                d[1] = make_float2(v.z, v.w);
+            });
     }
+    store_w(0);
+    __syncthreads();
+
+    for (int tap = 0; tap < KK; ++tap) {
+        if (tap + 1 < KK) load_w(tap + 1);            // in flight during this tap's MFMAs
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const float* ap = in_tile + (ky * TWH + kx) * P;
+        const float* bp = w_tile + (tap & 1) * CK * NP + b_base;
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i] = ap[a_base[i]];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = bp[j * 16];
+        for (int kk = 0; kk < ck4; ++kk) {
+            const int kn = (kk + 1 < ck4) ? kk + 1 : kk;
+            float an[MT], bn[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) an[i] = ap[a_base[i] + kn * 4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bn[j] = bp[kn * 4 * NP + j * 16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = bn[j];
+        }
+        if (tap + 1 < KK) store_w((tap + 1) & 1);     // that buffer was last read during tap-1 (barrier since)
+        __syncthreads();
+    }
+
+    {
+        AccPack<MT, NT> accp;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) accp.v[i][j] = acc[i][j];
+        conv_epilogue<MT, NT>(a, accp, n, x0, y0, n0, wm, wn, l15, lq);
+    }
+}
+
+constexpr int kLdsMax = 160 * 1024;
+
+// returns false when the layer does not fit the single-chunk double-buffered layout
+template <int KS, int MT, int NT, int WM, int WN, int WREG>
+bool try_launch_pipe(hipStream_t s, ConvParams& p, int N) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int BM = WM * MT * 16, TH = BM / 16, BN = WN * NT * 16;
+    constexpr int TWH = 16 + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
+    constexpr int NP = (BN % 32 == 0) ? BN + 16 : BN;
+    const int cin4 = (p.Cin + 3) & ~3;
+    const size_t lds = (size_t)(((HPIX * (cin4 + 2) + 3) & ~3) + 2 * cin4 * NP) * sizeof(float);
+    if (lds > (size_t)kLdsMax || cin4 * (BN / 4) > WREG * NTHR) return false;
+    auto kern = conv_igemm_pipe_kernel<KS, MT, NT, WM, WN, WREG>;
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax));
+    });
+    p.CK = cin4;
+    p.TPS = 1;
+    p.tiles_x = cdiv(p.W, 16);
+    p.tiles_y = cdiv(p.H, TH);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * N), (unsigned)cdiv(p.Cout, BN));
+    const double px = (double)N * p.H * p.W;
+    ProfScope ps(s, "conv_igemm_pipe<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
+                        std::to_string(WM) + "," + std::to_string(WN) + ">",
+                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, s, p);
+    HIP_CHECK(hipGetLastError());
+    return true;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -293,6 +533,14 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
     for (int bn : bns) {
         long wk = (long)cdiv(p.Cout, bn) * bn;
         if (bestw < 0 || wk < bestw) { bestw = wk; best = bn; }
+    }
+    // MFMA-bound wide layers with a single input-channel chunk: double-buffered, 8-wave, 16x16-pixel kernel
+    const bool pipe_ok = KS <= 3 && p.Cin >= 16 && (long)p.H * p.W >= 256;
+    switch (best) {
+        case 192: if (pipe_ok && try_launch_pipe<KS, 4, 6, 4, 2, 6>(s, p, N)) return; break;
+        case 128: if (pipe_ok && try_launch_pipe<KS, 4, 4, 4, 2, 6>(s, p, N)) return; break;
+        case 96:  if (pipe_ok && try_launch_pipe<KS, 4, 3, 4, 2, 6>(s, p, N)) return; break;
+        default: break;
     }
     switch (best) {
         case 192: launch_fwd<KS, 4, 6, 2, 2>(s, p, N); break;   // 8x16 pixels x 192 couts
@@ -410,28 +658,46 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
             });
         __syncthreads();
         // K loop over the 128 pixels, 4 per MFMA: pixel pk = kk*4 + lq -> (row kk>>2, col (kk&3)*4+lq)
-#pragma unroll 2
+        // software pipeline: the KK*CIT + COT fragments of step kk+WK are in flight while step kk's MFMAs issue
+        float av[KK][CIT], bv[COT];
+        {
+            const int pr = wk >> 2, pc = (wk & 3) * 4 + lq;
+#pragma unroll
+            for (int j = 0; j < COT; ++j) bv[j] = z_tile[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
+#pragma unroll
+            for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                for (int i = 0; i < CIT; ++i)
+                    av[tp][i] = x_tile[((pr + tp / KS) * TWH + (pc + tp % KS)) * PX + l15 + i * 16];
+        }
         for (int kk = wk; kk < NPIX / 4; kk += WK) {
-            const int pr = kk >> 2;
-            const int pc = (kk & 3) * 4 + lq;
-            float bv[COT];
+            const int kn = (kk + WK < NPIX / 4) ? kk + WK : kk;
+            const int pr = kn >> 2, pc = (kn & 3) * 4 + lq;
+            float an[KK][CIT], bn[COT];
 #pragma unroll
-            for (int j = 0; j < COT; ++j) {
-                bv[j] = z_tile[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
-                bsum[j] += bv[j];
-            }
+            for (int j = 0; j < COT; ++j) bn[j] = z_tile[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
 #pragma unroll
-            for (int tp = 0; tp < KK; ++tp) {
-                const int ky = tp / KS, kx = tp % KS;
-                const float* xp = x_tile + ((pr + ky) * TWH + (pc + kx)) * PX + l15;
+            for (int tp = 0; tp < KK; ++tp)
 #pragma unroll
-                for (int i = 0; i < CIT; ++i) {
-                    const float av = xp[i * 16];
+                for (int i = 0; i < CIT; ++i)
+                    an[tp][i] = x_tile[((pr + tp / KS) * TWH + (pc + tp % KS)) * PX + l15 + i * 16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < COT; ++j) bsum[j] += bv[j];
+#pragma unroll
+            for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                for (int i = 0; i < CIT; ++i)
 #pragma unroll
                     for (int j = 0; j < COT; ++j)
-                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[tp][i][j], 0, 0, 0);
-                }
-            }
+                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tp][i], bv[j], acc[tp][i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < COT; ++j) bv[j] = bn[j];
+#pragma unroll
+            for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) av[tp][i] = an[tp][i];
         }
     }
     // K-split waves: pairwise tree reduction through LDS so the block emits ONE slab
@@ -609,6 +875,7 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = ((out.C & 3) == 0) && ((((uintptr_t)w) & 15) == 0);
+    p.dbg = getenv("DL4DS_CONV_DBG") ? atoi(getenv("DL4DS_CONV_DBG")) : 0;
     p.CK = 0; p.TPS = 1; p.tiles_x = p.tiles_y = 0;
     switch (KS) {
         case 1: dispatch_fwd<1>(s, p, in.N); break;
