@@ -6,6 +6,7 @@
 #include "prof.h"
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -39,6 +40,7 @@ void rt_ensure_init() {
     g_rt.device = dev;
     HIP_CHECK(hipStreamCreateWithFlags(&g_rt.stream, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&g_rt.comm_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&g_rt.aux_stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreate(&g_rt.ev0));
     HIP_CHECK(hipEventCreate(&g_rt.ev1));
     g_rt.inited = true;
@@ -333,6 +335,7 @@ int dl4ds_graph_create(dl4ds_graph** g) {
     API_BEGIN
     *g = new dl4ds_graph();
     (*g)->g.stream = S();
+    if (!getenv("DL4DS_NO_AUX_STREAM")) (*g)->g.aux_stream = rt().aux_stream;
     API_END
 }
 int dl4ds_graph_destroy(dl4ds_graph* g) {

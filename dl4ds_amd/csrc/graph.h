@@ -62,6 +62,14 @@ struct Graph {
     bool finalized = false;
     float* workspace = nullptr;
     size_t workspace_bytes = 0;
+    // weight-gradient kernels run on a second stream (own workspace) concurrently with the dgrad chain:
+    // the two MFMA streams fill each other's staging / epilogue bubbles on the CUs
+    hipStream_t aux_stream = nullptr;
+    float* aux_workspace = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool aux_used = false;
+    void fork_aux();            // aux_stream waits for everything enqueued on `stream` so far
+    void join_aux();            // `stream` waits for everything enqueued on aux_stream
     hipStream_t stream = nullptr;
     std::vector<float*> allocations;
 

@@ -1,5 +1,6 @@
 // Graph runtime + op implementations (forward and hand-written backward) -- see graph.h.
 #include "graph.h"
+#include "prof.h"
 #include <algorithm>
 #include <cstring>
 
@@ -12,6 +13,30 @@ Graph::~Graph() {
     }
     if (Wt) (void)hipFree(Wt);
     if (workspace) (void)hipFree(workspace);
+    if (aux_workspace) (void)hipFree(aux_workspace);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+}
+
+// per-launch profiling wants stand-alone kernel durations: no concurrency while the profiler is on
+static bool aux_enabled(const Graph& g) { return g.aux_stream != nullptr && !prof().on; }
+
+void Graph::fork_aux() {
+    if (!aux_enabled(*this)) return;
+    if (!ev_fork) {
+        HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventRecord(ev_fork, stream));
+    HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+    aux_used = true;
+}
+
+void Graph::join_aux() {
+    if (!aux_stream || !aux_used) return;
+    HIP_CHECK(hipEventRecord(ev_join, aux_stream));
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
+    aux_used = false;
 }
 
 int Graph::add_tensor(int H, int W_, int C, int nmul, bool requires_grad, bool is_input) {
@@ -56,6 +81,7 @@ void Graph::prepare(int B) {
     for (float* p : allocations) HIP_CHECK(hipFree(p));
     allocations.clear();
     if (workspace) { HIP_CHECK(hipFree(workspace)); workspace = nullptr; }
+    if (aux_workspace) { HIP_CHECK(hipFree(aux_workspace)); aux_workspace = nullptr; }
     // one slab for all activations + gradients + op-private saved buffers (288 GB HBM: no reuse games)
     size_t total = 0;
     auto bump = [&](size_t floats) { size_t o = total; total += (floats + 63) & ~(size_t)63; return o; };
@@ -77,6 +103,7 @@ void Graph::prepare(int B) {
     for (auto& op : ops) ws = std::max(ws, op->workspace_bytes(*this, B));
     workspace_bytes = ws;
     HIP_CHECK(hipMalloc((void**)&workspace, ws));
+    if (aux_stream) HIP_CHECK(hipMalloc((void**)&aux_workspace, ws));
     maxB = B;
 }
 
@@ -102,6 +129,7 @@ void Graph::backward(const BwdCtx& c) {
     for (auto& t : tensors) t.grad_written = false;
     for (int o : outputs) tensors[o].grad_written = true;      // seeded by the loss
     for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i]->backward(*this, c);
+    join_aux();
     if (c.param_grads) {
         // parameters never reached by the backward pass get an explicit zero gradient
         for (auto& p : params)
@@ -155,9 +183,15 @@ struct ConvOp : GOp {
         }
         if (c.param_grads) {     // weight gradient; the bias gradient (column sums of dZ) rides along
             const bool need_db = b >= 0;
-            conv2d_wgrad(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, g.gp(w),
+            // on the aux stream: overlaps with this op's dgrad and everything after it on the main stream (dZ and
+            // the input activation are not written again during this backward pass)
+            g.fork_aux();
+            const bool on_aux = aux_enabled(g);
+            hipStream_t ws_stream = on_aux ? g.aux_stream : g.stream;
+            float* ws_buf = on_aux ? g.aux_workspace : g.workspace;
+            conv2d_wgrad(ws_stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, g.gp(w),
                          g.params[w].grad_written, need_db ? g.gp(b) : nullptr,
-                         need_db ? (int)g.params[b].grad_written : 0, g.workspace, g.workspace_bytes);
+                         need_db ? (int)g.params[b].grad_written : 0, ws_buf, g.workspace_bytes);
             g.params[w].grad_written = true;
             if (need_db) g.params[b].grad_written = true;
         }
