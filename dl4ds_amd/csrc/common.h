@@ -96,6 +96,50 @@ __device__ __forceinline__ float4 view_load4(const TView& v, int n, int y, int x
     return r;
 }
 
+// Branch-free staging loads.  A load inside a divergent `if` ends its basic block with s_waitcnt vmcnt(0), which
+// serialises every staging load into its own L2/HBM round trip (measured: ~40 % of the conv kernels), and a plain
+// `ok ? load : 0` select is turned back into exactly that branch by LLVM.  So the load is split in three:
+//   *_raw   : ALWAYS issues the load, from a clamped (valid) address, returns whatever is there
+//   *_valid : 4-bit mask of the components that are really inside the tensor
+//   mask4   : applied later (when the value is written to LDS), through opaque asm so it stays straight-line code
+__device__ __forceinline__ float4 mask4(float4 r, unsigned bits) {
+    unsigned m0 = (bits & 1u) ? 0xffffffffu : 0u, m1 = (bits & 2u) ? 0xffffffffu : 0u;
+    unsigned m2 = (bits & 4u) ? 0xffffffffu : 0u, m3 = (bits & 8u) ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
+    r.x = __uint_as_float(__float_as_uint(r.x) & m0);
+    r.y = __uint_as_float(__float_as_uint(r.y) & m1);
+    r.z = __uint_as_float(__float_as_uint(r.z) & m2);
+    r.w = __uint_as_float(__float_as_uint(r.w) & m3);
+    return r;
+}
+__device__ __forceinline__ unsigned valid4(int c, int C, bool pred) {
+    const int k = pred ? min(max(C - c, 0), 4) : 0;
+    return (1u << k) - 1u;
+}
+__device__ __forceinline__ float4 view_load4_raw(const TView& v, int n, int y, int x, int c, bool pred) {
+    const int ys = pred ? y : 0, xs = pred ? x : 0;
+    if (v.vec) {                                   // uniform; vec implies C % 4 == 0 (cp % 4 == 0 for d2s)
+        const int cs = (pred && c < v.C) ? c : 0;
+        return *reinterpret_cast<const float4*>(v.p + view_off(v, n, ys, xs, cs));
+    }
+    float4 r;
+    r.x = v.p[view_off(v, n, ys, xs, min(max(c, 0), v.C - 1))];
+    r.y = v.p[view_off(v, n, ys, xs, min(c + 1, v.C - 1))];
+    r.z = v.p[view_off(v, n, ys, xs, min(c + 2, v.C - 1))];
+    r.w = v.p[view_off(v, n, ys, xs, min(c + 3, v.C - 1))];
+    return r;
+}
+// floats [co, co+4) of a row of `Cout` floats
+__device__ __forceinline__ float4 row_load4_raw(const float* row, int co, int Cout, bool vec, bool pred) {
+    if (vec) return *reinterpret_cast<const float4*>(row + ((pred && co < Cout) ? co : 0));
+    float4 r;
+    r.x = row[min(max(co, 0), Cout - 1)];
+    r.y = row[min(co + 1, Cout - 1)];
+    r.z = row[min(co + 2, Cout - 1)];
+    r.w = row[min(co + 3, Cout - 1)];
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes on CDNA)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -26,19 +26,20 @@ constexpr int kLdsBudget = 80 * 1024;   // 2 workgroups per CU (160 KiB LDS)
 
 // issue U independent 16-byte loads before the first LDS store so the memory latency is paid once per
 // batch, not once per element
-template <int U, int NTHR, class LoadF, class StoreF>
-__device__ __forceinline__ void staged_copy(int total, int tid, LoadF ld, StoreF st) {
+template <int U, int NTHR, class LoadF, class ValidF, class StoreF>
+__device__ __forceinline__ void staged_copy(int total, int tid, LoadF ld, ValidF valid, StoreF st) {
     for (int base = tid; base < total; base += NTHR * U) {
         float4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int idx = base + u * NTHR;
-            v[u] = (idx < total) ? ld(idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = idx < total;
+            v[u] = ld(ok ? idx : 0, ok);           // always issued (clamped address); masked at store time
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int idx = base + u * NTHR;
-            if (idx < total) st(idx, v[u]);
+            if (idx < total) st(idx, mask4(v[u], valid(idx)));
         }
     }
 }
@@ -187,15 +188,21 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
         // ---- stage the input halo tile, channels [c0, c0+ck) (zero outside the image / beyond Cin)
         staged_copy<4, NTHR>(
             HPIX * ck4, tid,
+            [&](int idx, bool ok) {
+                const int pix = fast_div(idx, m4);
+                const int q = idx - pix * ck4;
+                const int r = pix / TWH;
+                const int c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                return view_load4_raw(a.in, n, gy, gx, c0 + q * 4, ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);
+            },
             [&](int idx) {
                 const int pix = fast_div(idx, m4);
                 const int q = idx - pix * ck4;
                 const int r = pix / TWH;
                 const int c = pix - r * TWH;
                 const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = view_load4(a.in, n, gy, gx, c0 + q * 4);
-                return v;
+                return valid4(c0 + q * 4, a.Cin, gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);
             },
             [&](int idx, float4 v) {
                 const int pix = fast_div(idx, m4);
@@ -214,25 +221,21 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
                 const float* wsrc = a.w + ((size_t)tg * a.Cin + c0) * a.Cout;
                 staged_copy<5, NTHR>(
                     ntap * rows * BN4, tid,
+                    [&](int idx, bool ok) {
+                        const int row = idx / BN4;
+                        const int q = idx - row * BN4;
+                        const int tl = fast_div(row, mrows);
+                        const int r = row - tl * rows;
+                        const bool rok = ok && r < ck;
+                        const float* src = wsrc + ((size_t)tl * a.Cin + (rok ? r : 0)) * a.Cout;
+                        return row_load4_raw(src, n0 + q * 4, a.Cout, a.wvec != 0, rok);
+                    },
                     [&](int idx) {
                         const int row = idx / BN4;
                         const int q = idx - row * BN4;
                         const int tl = fast_div(row, mrows);
                         const int r = row - tl * rows;
-                        const int co = n0 + q * 4;
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (r < ck && co < a.Cout) {
-                            const float* src = wsrc + ((size_t)tl * a.Cin + r) * a.Cout + co;
-                            if (a.wvec && co + 3 < a.Cout) {
-                                v = *reinterpret_cast<const float4*>(src);
-                            } else {
-                                v.x = src[0];
-                                if (co + 1 < a.Cout) v.y = src[1];
-                                if (co + 2 < a.Cout) v.z = src[2];
-                                if (co + 3 < a.Cout) v.w = src[3];
-                            }
-                        }
-                        return v;
+                        return valid4(n0 + q * 4, a.Cout, r < ck);
                     },
                     [&](int idx, float4 v) {
                         const int row = idx / BN4;
@@ -289,12 +292,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
 }
 
 // --------------------------------------------------------------------------------------------
-// Pipelined variant for the MFMA-bound layers whose whole input-channel range fits one LDS chunk
-// (the 48->192 sub-pixel convolutions): 8 waves share a 16x16-pixel tile (filter traffic per MFMA halves),
-// the filter slice of tap t+1 is fetched into registers while tap t's MFMAs issue and is written to the
-// second LDS buffer afterwards -> global/L2 latency never sits on the MFMA critical path, one barrier per tap.
-template <int KS, int MT, int NT, int WM, int WN, int WREG>
-__global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_pipe_kernel(const ConvParams a) {
+// Double-buffered ("db") variant for the MFMA-bound layers.  The K loop is flattened into stages
+// s = (channel chunk, tap group); while stage s's MFMAs issue, the filter slice of stage s+1 (and, at a chunk
+// boundary, the next chunk's input halo tile) is already in flight from L2/HBM into registers and is written to
+// the alternate LDS buffers after the MFMA block -> one barrier per stage, and the memory system sees a smooth
+// stream instead of every CU staging at the same instant (measured: in-phase staging bursts cost ~40 % of the
+// kernel in the single-buffered version).  Single-chunk layers (e.g. 48->192) keep one input buffer.
+//   IR / WR : float4 registers per thread reserved for the input / filter prefetch.
+//   MC      : multi-chunk capable (keeps the input prefetch registers live across the stage loop).
+template <int KS, int MT, int NT, int WM, int WN, int IR, int WR, bool MC>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_db_kernel(const ConvParams a) {
     constexpr int TW = 16;
     constexpr int NTHR = 64 * WM * WN;
     constexpr int BM = WM * MT * 16;
@@ -309,10 +316,15 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_pipe_kernel(const 
     constexpr int KK = KS * KS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int CK = a.CK;                 // == Cin rounded up to 4 (single chunk)
+    const int CK = a.CK, TPS = a.TPS;
     const int P = CK + 2;
-    float* in_tile = smem;
-    float* w_tile = smem + ((HPIX * P + 3) & ~3);        // two buffers of CK*NP floats
+    const int nchunks = MC ? (a.Cin + CK - 1) / CK : 1;
+    const int ngroups = (KK + TPS - 1) / TPS;
+    const int nstages = nchunks * ngroups;
+    const int in_floats = (HPIX * P + 3) & ~3;
+    const int w_floats = TPS * CK * NP;
+    float* in_buf = smem;                                            // [1 or 2][in_floats]
+    float* w_buf = smem + (nchunks > 1 ? 2 : 1) * in_floats;         // [2][w_floats]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -339,103 +351,146 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_pipe_kernel(const 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ck4 = CK >> 2;
-    const int wtotal = CK * BN4;          // float4 per tap slice (rows padded to CK)
-    float4 wreg[WREG];
-    auto load_w = [&](int tap) {
-        const float* wsrc = a.w + (size_t)tap * a.Cin * a.Cout;
-#pragma unroll
-        for (int u = 0; u < WREG; ++u) {
-            const int idx = tid + u * NTHR;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < wtotal) {
-                const int r = idx / BN4;
-                const int q = idx - r * BN4;
-                const int co = n0 + q * 4;
-                if (r < a.Cin && co < a.Cout) {
-                    const float* src = wsrc + (size_t)r * a.Cout + co;
-                    if (a.wvec && co + 3 < a.Cout) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        v.x = src[0];
-                        if (co + 1 < a.Cout) v.y = src[1];
-                        if (co + 2 < a.Cout) v.z = src[2];
-                        if (co + 3 < a.Cout) v.w = src[3];
-                    }
-                }
-            }
-            wreg[u] = v;
-        }
-    };
-    auto store_w = [&](int buf) {
-        float* wdst = w_tile + buf * CK * NP;
-#pragma unroll
-        for (int u = 0; u < WREG; ++u) {
-            const int idx = tid + u * NTHR;
-            if (idx < wtotal) {
-                const int r = idx / BN4;
-                const int q = idx - r * BN4;
-                *reinterpret_cast<float4*>(wdst + r * NP + q * 4) = wreg[u];
-            }
-        }
-    };
+    float4 ireg[IR], wreg[WR];
+    const int ckq = CK >> 2;                       // float4 groups per pixel of a full chunk
+    const unsigned mckq = div_magic(ckq);
+    const int in_total = HPIX * ckq;
+    const int rows_w = CK;                         // filter rows staged per tap (zero beyond Cin)
+    const unsigned mrows = div_magic(rows_w);
 
-    load_w(0);
-    {
-        const unsigned m4 = div_magic(ck4);
-        staged_copy<4, NTHR>(
-            HPIX * ck4, tid,
-            [&](int idx) {
-                const int pix = fast_div(idx, m4);
-                const int q = idx - pix * ck4;
+    auto load_in = [&](int chunk) {
+        const int c0 = chunk * CK;
+#pragma unroll
+        for (int u = 0; u < IR; ++u) {
+            const int idx0 = tid + u * NTHR;
+            const bool ok = idx0 < in_total;
+            const int idx = ok ? idx0 : 0;
+            const int pix = fast_div(idx, mckq);
+            const int q = idx - pix * ckq;
+            const int r = pix / TWH;
+            const int c = pix - r * TWH;
+            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+            ireg[u] = view_load4_raw(a.in, n, gy, gx, c0 + q * 4,
+                                     ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c0 + q * 4 < a.Cin);
+        }
+    };
+    auto store_in = [&](int chunk) {
+        float* dst = in_buf + (chunk & 1) * in_floats;
+        const int c0 = chunk * CK;
+#pragma unroll
+        for (int u = 0; u < IR; ++u) {
+            const int idx = tid + u * NTHR;
+            if (idx < in_total) {
+                const int pix = fast_div(idx, mckq);
+                const int q = idx - pix * ckq;
                 const int r = pix / TWH;
                 const int c = pix - r * TWH;
                 const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = view_load4(a.in, n, gy, gx, q * 4);
-                return v;
-            },
-            [&](int idx, float4 v) {
-                const int pix = fast_div(idx, m4);
-                const int q = idx - pix * ck4;
-                float2* d = reinterpret_cast<float2*>(in_tile + pix * P + q * 4);
+                const float4 v = mask4(ireg[u], valid4(c0 + q * 4, a.Cin, gy >= 0 && gy < a.H && gx >= 0 && gx < a.W));
+                float2* d = reinterpret_cast<float2*>(dst + pix * P + q * 4);
                 d[0] = make_float2(v.x, v.y);
                 d[1] = make_float2(v.z, v.w);
-            });
-    }
+            }
+        }
+    };
+    auto load_w = [&](int stage) {
+        const int chunk = stage / ngroups;
+        const int tg = (stage - chunk * ngroups) * TPS;
+        const int ntap = min(TPS, KK - tg);
+        const int c0 = chunk * CK;
+        const float* wsrc = a.w + ((size_t)tg * a.Cin + c0) * a.Cout;
+        const int total = ntap * rows_w * BN4;
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+            const int idx0 = tid + u * NTHR;
+            const bool ok = idx0 < total;
+            const int idx = ok ? idx0 : 0;
+            const int row = idx / BN4;
+            const int q = idx - row * BN4;
+            const int tl = fast_div(row, mrows);
+            const int r = row - tl * rows_w;
+            const bool rok = ok && (c0 + r < a.Cin);
+            const float* src = wsrc + ((size_t)tl * a.Cin + (rok ? r : 0)) * a.Cout;
+            wreg[u] = row_load4_raw(src, n0 + q * 4, a.Cout, a.wvec != 0, rok);
+        }
+    };
+    auto store_w = [&](int stage) {
+        const int chunk = stage / ngroups;
+        const int tg = (stage - chunk * ngroups) * TPS;
+        const int ntap = min(TPS, KK - tg);
+        const int total = ntap * rows_w * BN4;
+        float* dst = w_buf + (stage & 1) * w_floats;
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+            const int idx = tid + u * NTHR;
+            if (idx < total) {
+                const int row = idx / BN4;
+                const int q = idx - row * BN4;
+                const int tl = fast_div(row, mrows);
+                const int r = row - tl * rows_w;
+                *reinterpret_cast<float4*>(dst + (tl * CK + r) * NP + q * 4) =
+                    mask4(wreg[u], valid4(n0 + q * 4, a.Cout, chunk * CK + r < a.Cin));
+            }
+        }
+    };
+
+    load_in(0);
+    load_w(0);
+    store_in(0);
     store_w(0);
     __syncthreads();
 
-    for (int tap = 0; tap < KK; ++tap) {
-        if (tap + 1 < KK) load_w(tap + 1);            // in flight during this tap's MFMAs
-        const int ky = tap / KS, kx = tap - ky * KS;
-        const float* ap = in_tile + (ky * TWH + kx) * P;
-        const float* bp = w_tile + (tap & 1) * CK * NP + b_base;
-        float av[MT], bv[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) av[i] = ap[a_base[i]];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = bp[j * 16];
-        for (int kk = 0; kk < ck4; ++kk) {
-            const int kn = (kk + 1 < ck4) ? kk + 1 : kk;
-            float an[MT], bn[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) an[i] = ap[a_base[i] + kn * 4];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bn[j] = bp[kn * 4 * NP + j * 16];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = an[i];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = bn[j];
+    for (int s = 0; s < nstages; ++s) {
+        const int chunk = s / ngroups;
+        const int gi = s - chunk * ngroups;
+        const int nxt = s + 1;
+        const bool new_chunk = MC && (nxt < nstages) && (gi == ngroups - 1);
+        if (nxt < nstages) {
+            if (new_chunk) load_in(chunk + 1);
+            load_w(nxt);
         }
-        if (tap + 1 < KK) store_w((tap + 1) & 1);     // that buffer was last read during tap-1 (barrier since)
+        // ---- MFMA over this stage's taps
+        const int tg = gi * TPS;
+        const int ntap = min(TPS, KK - tg);
+        const int ck_here = min(CK, a.Cin - chunk * CK);
+        const int ck4 = (ck_here + 3) >> 2;
+        const float* inb = in_buf + ((nchunks > 1) ? (chunk & 1) * in_floats : 0);
+        const float* wb = w_buf + (s & 1) * w_floats + b_base;
+        for (int tl = 0; tl < ntap; ++tl) {
+            const int tap = tg + tl;
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const float* ap = inb + (ky * TWH + kx) * P;
+            const float* bp = wb + tl * CK * NP;
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = ap[a_base[i]];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = bp[j * 16];
+            for (int kk = 0; kk < ck4; ++kk) {
+                const int kn = (kk + 1 < ck4) ? kk + 1 : kk;
+                float an[MT], bn[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) an[i] = ap[a_base[i] + kn * 4];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bn[j] = bp[kn * 4 * NP + j * 16];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = bn[j];
+            }
+        }
+        // ---- park the prefetched data in the alternate buffers (last read >= one barrier ago)
+        if (nxt < nstages) {
+            if (new_chunk) store_in(chunk + 1);
+            store_w(nxt);
+        }
         __syncthreads();
     }
 
@@ -451,32 +506,53 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_pipe_kernel(const 
 
 constexpr int kLdsMax = 160 * 1024;
 
-// returns false when the layer does not fit the single-chunk double-buffered layout
-template <int KS, int MT, int NT, int WM, int WN, int WREG>
-bool try_launch_pipe(hipStream_t s, ConvParams& p, int N) {
+// Picks (CK, TPS) for the db kernel: largest stage that fits the prefetch registers and the LDS limit
+// (80 KB -> two workgroups per CU; single-chunk layouts may take the whole 160 KB with 8 waves).
+template <int KS, int MT, int NT, int WM, int WN, int IR, int WR, bool MC>
+bool try_launch_db(hipStream_t s, ConvParams& p, int N, size_t lds_limit) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int BM = WM * MT * 16, TH = BM / 16, BN = WN * NT * 16;
     constexpr int TWH = 16 + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
     constexpr int NP = (BN % 32 == 0) ? BN + 16 : BN;
+    constexpr int KK = KS * KS;
     const int cin4 = (p.Cin + 3) & ~3;
-    const size_t lds = (size_t)(((HPIX * (cin4 + 2) + 3) & ~3) + 2 * cin4 * NP) * sizeof(float);
-    if (lds > (size_t)kLdsMax || cin4 * (BN / 4) > WREG * NTHR) return false;
-    auto kern = conv_igemm_pipe_kernel<KS, MT, NT, WM, WN, WREG>;
+    int bestCK = 0, bestTPS = 0;
+    size_t best_lds = 0;
+    long best_work = -1;
+    const int ck_cand[] = {cin4, 64, 48, 32, 24, 16, 8};
+    const int tps_cand[] = {KK, KS, 1};
+    for (int ck : ck_cand) {
+        if (ck > cin4 || (ck & 3)) continue;
+        if (HPIX * (ck / 4) > IR * NTHR) continue;
+        const int nchunks = (p.Cin + ck - 1) / ck;
+        if (!MC && nchunks > 1) continue;
+        for (int tps : tps_cand) {
+            if (tps * ck * (BN / 4) > WR * NTHR) continue;
+            const size_t lds = (size_t)((nchunks > 1 ? 2 : 1) * ((HPIX * (ck + 2) + 3) & ~3) + 2 * tps * ck * NP) * sizeof(float);
+            if (lds > lds_limit) continue;
+            // padded channel work (ceil(Cin/ck)*ck) first, then the largest stage (fewest barriers)
+            const long waste = (long)nchunks * ck - p.Cin;
+            const long work = (long)tps * ck * 1000 - waste * 100000;
+            if (work > best_work) { best_work = work; bestCK = ck; bestTPS = tps; best_lds = lds; }
+        }
+    }
+    if (bestCK == 0) return false;
+    auto kern = conv_igemm_db_kernel<KS, MT, NT, WM, WN, IR, WR, MC>;
     static std::once_flag once;
     std::call_once(once, [&]() {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax));
     });
-    p.CK = cin4;
-    p.TPS = 1;
+    p.CK = bestCK;
+    p.TPS = bestTPS;
     p.tiles_x = cdiv(p.W, 16);
     p.tiles_y = cdiv(p.H, TH);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * N), (unsigned)cdiv(p.Cout, BN));
     const double px = (double)N * p.H * p.W;
-    ProfScope ps(s, "conv_igemm_pipe<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
+    ProfScope ps(s, "conv_igemm_db<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
                         std::to_string(WM) + "," + std::to_string(WN) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
-    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), best_lds, s, p);
     HIP_CHECK(hipGetLastError());
     return true;
 }
@@ -534,13 +610,17 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
         long wk = (long)cdiv(p.Cout, bn) * bn;
         if (bestw < 0 || wk < bestw) { bestw = wk; best = bn; }
     }
-    // MFMA-bound wide layers with a single input-channel chunk: double-buffered, 8-wave, 16x16-pixel kernel
-    const bool pipe_ok = KS <= 3 && p.Cin >= 16 && (long)p.H * p.W >= 256;
-    switch (best) {
-        case 192: if (pipe_ok && try_launch_pipe<KS, 4, 6, 4, 2, 6>(s, p, N)) return; break;
-        case 128: if (pipe_ok && try_launch_pipe<KS, 4, 4, 4, 2, 6>(s, p, N)) return; break;
-        case 96:  if (pipe_ok && try_launch_pipe<KS, 4, 3, 4, 2, 6>(s, p, N)) return; break;
-        default: break;
+    // MFMA-bound layers: double-buffered kernel (8 waves for wide Cout, 4 waves x two workgroups per CU otherwise)
+    const bool db_ok = p.Cin >= 16 && (long)p.H * p.W >= 256;
+    if (db_ok) {
+        switch (best) {
+            case 192: if (try_launch_db<KS, 4, 6, 4, 2, 8, 6, false>(s, p, N, kLdsMax)) return; break;
+            case 128: if (try_launch_db<KS, 4, 4, 4, 2, 8, 6, false>(s, p, N, kLdsMax)) return; break;
+            case 96:  if (try_launch_db<KS, 4, 3, 4, 2, 8, 6, true>(s, p, N, kLdsBudget)) return; break;
+            case 48:  if (try_launch_db<KS, 4, 3, 4, 1, 6, 3, true>(s, p, N, kLdsBudget)) return; break;
+            case 32:  if (try_launch_db<KS, 4, 2, 4, 1, 6, 3, true>(s, p, N, kLdsBudget)) return; break;
+            default: break;
+        }
     }
     switch (best) {
         case 192: launch_fwd<KS, 4, 6, 2, 2>(s, p, N); break;   // 8x16 pixels x 192 couts
@@ -624,15 +704,20 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
         // stage x halo tile (channels ci0 .. ci0+CIB)
         staged_copy<4, 256>(
             HPIX * (CIB / 4), tid,
+            [&](int idx, bool ok) {
+                const int pix = idx / (CIB / 4);
+                const int q = idx - pix * (CIB / 4);
+                const int r = pix / TWH, c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                return view_load4_raw(a.x, n, gy, gx, ci0 + q * 4,
+                                      ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin);
+            },
             [&](int idx) {
                 const int pix = idx / (CIB / 4);
                 const int q = idx - pix * (CIB / 4);
                 const int r = pix / TWH, c = pix - r * TWH;
                 const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin)
-                    v = view_load4(a.x, n, gy, gx, ci0 + q * 4);
-                return v;
+                return valid4(ci0 + q * 4, a.Cin, gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);
             },
             [&](int idx, float4 v) {
                 const int pix = idx / (CIB / 4);
@@ -642,14 +727,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
         // stage dz tile (channels co0 .. co0+COB); zero outside the image so padded pixels add nothing
         staged_copy<4, 256>(
             NPIX * (COB / 4), tid,
-            [&](int idx) {
+            [&](int idx, bool ok) {
                 const int pix = idx / (COB / 4);
                 const int q = idx - pix * (COB / 4);
                 const int r = pix / TW, c = pix - r * TW;
                 const int gy = y0 + r, gx = x0 + c;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy < a.H && gx < a.W && co0 + q * 4 < a.Cout) v = view_load4(a.dz, n, gy, gx, co0 + q * 4);
-                return v;
+                return view_load4_raw(a.dz, n, gy, gx, co0 + q * 4, ok && gy < a.H && gx < a.W && co0 + q * 4 < a.Cout);
+            },
+            [&](int idx) {
+                const int pix = idx / (COB / 4);
+                const int q = idx - pix * (COB / 4);
+                const int r = pix / TW, c = pix - r * TW;
+                return valid4(co0 + q * 4, a.Cout, y0 + r < a.H && x0 + c < a.W);
             },
             [&](int idx, float4 v) {
                 const int pix = idx / (COB / 4);
