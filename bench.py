@@ -90,7 +90,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--batch', type=int, default=64,
+                    help='per-GPU batch (weak scaling); 64 = the reference default (training/supervised.py:49)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
@@ -104,9 +105,11 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get('DL4DS_FORCE_DIST'))      # exercise the RCCL path even with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('gloo', rank=rank, world_size=world)
 
     import dl4ds_amd._lib as L
@@ -116,13 +119,13 @@ def main():
     from dl4ds_amd import parallel
 
     lib = L.lib()                       # binds LOCAL_RANK -> device, fails loudly without a GPU
-    if world > 1:
+    if dist is not None:
         parallel.init_from_torch_distributed(dist, rank, world)
 
     B = args.batch
     model = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (128, 128), seed=7)
     eng = SupervisedEngine(model, loss='mae', learning_rate=(1e-3 * world, 1e-4 * world), lr_decay_after=1e5)
-    if world > 1:
+    if dist is not None:
         parallel.broadcast_trainer(eng)
     x, y = synthetic_batch(1002 + rank, B)
     dx, dy = DeviceArray.from_numpy(x), DeviceArray.from_numpy(y)

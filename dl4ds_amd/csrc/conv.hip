@@ -658,7 +658,7 @@ struct WgradParams {
 // block = 4 waves arranged WCO (cout tiles) x WK (pixel/K split).  A wave owns cout tiles
 // [wco*COT,(wco+1)*COT) of the block's 16*COT*WCO couts, ALL (tap, cin-tile) combinations of the block's
 // 16*CIT cins, and every WK-th group of 4 pixels of each spatial tile.
-template <int KS, int CIT, int COT, int WCO>
+template <int KS, int CIT, int COT, int WCO, bool PF>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a) {
     constexpr int TW = 16, TH = 8;
     constexpr int WK = 4 / WCO;
@@ -671,9 +671,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
     constexpr int PZ = (COB % 32 == 16) ? COB : COB + 16;
     constexpr int NPIX = TW * TH;
 
+    // PF (small-channel variants): the next tile's x / dz are fetched into registers while this tile's MFMAs issue and
+    // parked in the second LDS buffer afterwards -> one barrier per tile and no exposed HBM latency.
+    constexpr int XR = (HPIX * (CIB / 4) + 255) / 256, ZR = (NPIX * (COB / 4) + 255) / 256;
+    constexpr int TILE_FLOATS = HPIX * PX + NPIX * PZ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* x_tile = smem;                       // [HPIX][PX]
-    float* z_tile = smem + HPIX * PX;           // [NPIX][PZ]
+    float* z_tile = smem + HPIX * PX;           // [NPIX][PZ]   (second copy of both at +TILE_FLOATS when PF)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -693,13 +697,83 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
 #pragma unroll
     for (int j = 0; j < COT; ++j) bsum[j] = 0.f;
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+    float4 xr[PF ? XR : 1], zr[PF ? ZR : 1];
+    auto tile_xyn = [&](int tile, int& n, int& y0, int& x0) {
         int t = tile;
         const int tx = t % a.tiles_x;
         t /= a.tiles_x;
         const int ty = t % a.tiles_y;
-        const int n = t / a.tiles_y;
-        const int x0 = tx * TW, y0 = ty * TH;
+        n = t / a.tiles_y;
+        x0 = tx * TW;
+        y0 = ty * TH;
+    };
+    auto pf_load = [&](int tile) {
+        int n, y0, x0;
+        tile_xyn(tile, n, y0, x0);
+#pragma unroll
+        for (int u = 0; u < (PF ? XR : 0); ++u) {
+            const int idx0 = tid + u * 256;
+            const bool ok = idx0 < HPIX * (CIB / 4);
+            const int idx = ok ? idx0 : 0;
+            const int pix = idx / (CIB / 4), q = idx - pix * (CIB / 4);
+            const int r = pix / TWH, c = pix - r * TWH;
+            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+            xr[u] = view_load4_raw(a.x, n, gy, gx, ci0 + q * 4,
+                                   ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin);
+        }
+#pragma unroll
+        for (int u = 0; u < (PF ? ZR : 0); ++u) {
+            const int idx0 = tid + u * 256;
+            const bool ok = idx0 < NPIX * (COB / 4);
+            const int idx = ok ? idx0 : 0;
+            const int pix = idx / (COB / 4), q = idx - pix * (COB / 4);
+            const int r = pix / TW, c = pix - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            zr[u] = view_load4_raw(a.dz, n, gy, gx, co0 + q * 4, ok && gy < a.H && gx < a.W && co0 + q * 4 < a.Cout);
+        }
+    };
+    auto pf_store = [&](int tile, int buf) {
+        int n, y0, x0;
+        tile_xyn(tile, n, y0, x0);
+        float* xt = x_tile + buf * TILE_FLOATS;
+        float* zt = z_tile + buf * TILE_FLOATS;
+#pragma unroll
+        for (int u = 0; u < (PF ? XR : 0); ++u) {
+            const int idx = tid + u * 256;
+            if (idx < HPIX * (CIB / 4)) {
+                const int pix = idx / (CIB / 4), q = idx - pix * (CIB / 4);
+                const int r = pix / TWH, c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                *reinterpret_cast<float4*>(xt + pix * PX + q * 4) =
+                    mask4(xr[u], valid4(ci0 + q * 4, a.Cin, gy >= 0 && gy < a.H && gx >= 0 && gx < a.W));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < (PF ? ZR : 0); ++u) {
+            const int idx = tid + u * 256;
+            if (idx < NPIX * (COB / 4)) {
+                const int pix = idx / (COB / 4), q = idx - pix * (COB / 4);
+                const int r = pix / TW, c = pix - r * TW;
+                *reinterpret_cast<float4*>(zt + pix * PZ + q * 4) =
+                    mask4(zr[u], valid4(co0 + q * 4, a.Cout, y0 + r < a.H && x0 + c < a.W));
+            }
+        }
+    };
+    if (PF && (int)blockIdx.x < a.ntiles) {
+        pf_load(blockIdx.x);
+        pf_store(blockIdx.x, 0);
+        __syncthreads();
+    }
+    int pbuf = 0;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+        int n, y0, x0;
+        tile_xyn(tile, n, y0, x0);
+        const float* xt = x_tile + (PF ? pbuf * TILE_FLOATS : 0);
+        const float* zt = z_tile + (PF ? pbuf * TILE_FLOATS : 0);
+        if (PF) {
+            if (tile + a.S < a.ntiles) pf_load(tile + a.S);
+        } else {
         __syncthreads();
         // stage x halo tile (channels ci0 .. ci0+CIB)
         staged_copy<4, 256>(
@@ -746,30 +820,31 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
                 *reinterpret_cast<float4*>(z_tile + pix * PZ + q * 4) = v;
             });
         __syncthreads();
+        }
         // K loop over the 128 pixels, 4 per MFMA: pixel pk = kk*4 + lq -> (row kk>>2, col (kk&3)*4+lq)
         // software pipeline: the KK*CIT + COT fragments of step kk+WK are in flight while step kk's MFMAs issue
         float av[KK][CIT], bv[COT];
         {
             const int pr = wk >> 2, pc = (wk & 3) * 4 + lq;
 #pragma unroll
-            for (int j = 0; j < COT; ++j) bv[j] = z_tile[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
+            for (int j = 0; j < COT; ++j) bv[j] = zt[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
 #pragma unroll
             for (int tp = 0; tp < KK; ++tp)
 #pragma unroll
                 for (int i = 0; i < CIT; ++i)
-                    av[tp][i] = x_tile[((pr + tp / KS) * TWH + (pc + tp % KS)) * PX + l15 + i * 16];
+                    av[tp][i] = xt[((pr + tp / KS) * TWH + (pc + tp % KS)) * PX + l15 + i * 16];
         }
         for (int kk = wk; kk < NPIX / 4; kk += WK) {
             const int kn = (kk + WK < NPIX / 4) ? kk + WK : kk;
             const int pr = kn >> 2, pc = (kn & 3) * 4 + lq;
             float an[KK][CIT], bn[COT];
 #pragma unroll
-            for (int j = 0; j < COT; ++j) bn[j] = z_tile[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
+            for (int j = 0; j < COT; ++j) bn[j] = zt[(pr * TW + pc) * PZ + (wco * COT + j) * 16 + l15];
 #pragma unroll
             for (int tp = 0; tp < KK; ++tp)
 #pragma unroll
                 for (int i = 0; i < CIT; ++i)
-                    an[tp][i] = x_tile[((pr + tp / KS) * TWH + (pc + tp % KS)) * PX + l15 + i * 16];
+                    an[tp][i] = xt[((pr + tp / KS) * TWH + (pc + tp % KS)) * PX + l15 + i * 16];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < COT; ++j) bsum[j] += bv[j];
@@ -787,6 +862,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
             for (int tp = 0; tp < KK; ++tp)
 #pragma unroll
                 for (int i = 0; i < CIT; ++i) av[tp][i] = an[tp][i];
+        }
+        if (PF) {
+            if (tile + a.S < a.ntiles) pf_store(tile + a.S, pbuf ^ 1);     // that buffer was last read one barrier ago
+            pbuf ^= 1;
+            __syncthreads();
         }
     }
     // K-split waves: pairwise tree reduction through LDS so the block emits ONE slab
@@ -901,7 +981,9 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     p.WCO = (dz.C <= 16) ? 1 : (dz.C <= 32 ? 2 : 4);
     p.WK = 4 / p.WCO;
     const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
-    int target = std::max(1, 768 / (cob * cib));
+    // every block does the same amount of work, so the grid should be exactly one residency round:
+    // 256 CUs x 2 workgroups (LDS / VGPR limited) = 512 blocks.  768 blocks ran as 1.5 rounds (+33 % time).
+    int target = std::max(1, 512 / (cob * cib));
     const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
     const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (slab * sizeof(float)));
     p.S = (int)std::min<size_t>(std::min<size_t>(target, p.ntiles), cap);
@@ -911,14 +993,15 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
 
 template <int KS, int CIT, int COT, int WCO>
 void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
+    constexpr bool PF = (CIT == 1 && WCO == 1 && KS <= 3);     // prefetch registers fit only for the small-channel variants
     constexpr int TWH = 16 + KS - 1, THH = 8 + KS - 1, HPIX = TWH * THH;
     constexpr int CIB = 16 * CIT, COB = 16 * COT * WCO;
     constexpr int PX = (CIB % 32 == 16) ? CIB : CIB + 16;
     constexpr int PZ = (COB % 32 == 16) ? COB : COB + 16;
     constexpr int WK = 4 / WCO;
     constexpr size_t red_bytes = (size_t)(WK / 2) * WCO * (KS * KS * CIT * COT * 4 + COT) * 64 * sizeof(float);
-    const size_t lds = std::max((size_t)(HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
-    auto kern = conv_wgrad_kernel<KS, CIT, COT, WCO>;
+    const size_t lds = std::max((size_t)(PF ? 2 : 1) * (HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
+    auto kern = conv_wgrad_kernel<KS, CIT, COT, WCO, PF>;
     static std::once_flag once;
     std::call_once(once, [&]() {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

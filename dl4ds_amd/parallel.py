@@ -19,7 +19,19 @@ def rank_world_from_env():
 def init_with_id(rank, world, id_bytes):
     assert len(id_bytes) == 128
     buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
-    _lib.check(_lib.lib().dl4ds_dist_init(int(rank), int(world), buf))
+    lib = _lib.lib()
+    # RCCL prints a banner ("Hostname : ...", "Librccl path : ...") on stdout at communicator creation; keep stdout
+    # clean for callers that print machine-readable results (bench.py's single JSON line): send it to stderr.
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        st = lib.dl4ds_dist_init(int(rank), int(world), buf)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    _lib.check(st)
 
 
 def unique_id():
