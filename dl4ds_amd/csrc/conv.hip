@@ -1041,6 +1041,7 @@ void dispatch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
 void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                     const ConvEpilogue& ep) {
     DL4DS_REQUIRE(in.N == out.N && in.H == out.H && in.W == out.W, "conv2d: stride-1 SAME shapes differ");
+    if (conv2d_direct_forward(s, in, w, KS, out, ep)) return;      // a handful of channels: HBM-bound stencil
     ConvParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
     p.w = w; p.bias = ep.bias;
@@ -1066,6 +1067,7 @@ void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int 
 }
 
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS) {
+    if (const int ds = conv2d_direct_wgrad_slabs(x, dz, KS)) return (size_t)ds * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
     WgradPlan pl = plan_wgrad(x, dz, KS);
     return (size_t)pl.S * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
 }
@@ -1076,17 +1078,22 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     WgradPlan pl = plan_wgrad(x, dz, KS);
     const size_t nw = (size_t)KS * KS * x.C * dz.C;
     const size_t n = nw + dz.C;
-    const int nslabs = pl.S;
+    const int direct_slabs = conv2d_direct_wgrad_slabs(x, dz, KS);
+    const int nslabs = direct_slabs ? direct_slabs : pl.S;
     DL4DS_REQUIRE(workspace_bytes >= (size_t)nslabs * n * sizeof(float), "wgrad: workspace too small");
     WgradParams p;
     p.x = x; p.dz = dz; p.partial = workspace;
     p.Cin = x.C; p.Cout = dz.C; p.H = x.H; p.W = x.W;
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S;
-    switch (KS) {
-        case 1: dispatch_wgrad<1>(s, p, pl); break;
-        case 3: dispatch_wgrad<3>(s, p, pl); break;
-        case 5: dispatch_wgrad_wco<5, 1>(s, p, pl); break;
-        default: throw Dl4dsError("wgrad: kernel size not supported (1,3,5)");
+    if (direct_slabs) {
+        conv2d_direct_wgrad(s, x, dz, KS, workspace, direct_slabs);
+    } else {
+        switch (KS) {
+            case 1: dispatch_wgrad<1>(s, p, pl); break;
+            case 3: dispatch_wgrad<3>(s, p, pl); break;
+            case 5: dispatch_wgrad_wco<5, 1>(s, p, pl); break;
+            default: throw Dl4dsError("wgrad: kernel size not supported (1,3,5)");
+        }
     }
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 16), 8192));
     ProfScope ps(s, "wgrad_reduce_slabs", 0.0, 4.0 * (double)n * (nslabs + 1));

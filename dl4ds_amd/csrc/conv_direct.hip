@@ -1,0 +1,367 @@
+// dl4ds_amd -- direct (VALU) 3x3 convolutions for layers with a handful of channels.
+//
+// The tail of every dl4ds generator is ConvBlock_out (blocks.py:87-103 called from sp_postups.py:209-212): a
+// C -> 1 and a 1 -> 1 3x3 convolution on the FULL-RESOLUTION grid, plus the C_in -> 8 stem on the LR grid.  With
+// Cin*Cout <= 8 there is no GEMM to speak of: a 16x16x4 MFMA tile would be >= 15/16 padding, and the implicit-GEMM
+// kernels spent 0.5-1.6 ms per launch on layers that move 0.13-0.6 GB (cfg2, batch 64).  These layers are pure HBM
+// streaming, so they are written as stencils:
+//   * one output pixel per thread, 8x32-pixel tile per 256-thread block, persistent over tiles;
+//   * the halo'd input tile is staged in LDS as float4 planes ([c/4][row][col][4]) so that consecutive lanes read
+//     consecutive 16-byte words (conflict-free ds_read_b128);
+//   * the <= 72 weights live in SGPRs (staged zero-padded through LDS once per block, v_readfirstlane), so every
+//     FMA takes its weight as a scalar operand;
+//   * the same epilogue semantics as the MFMA kernels (bias, residual add, ReLU, ReLU-mask, accumulate).
+// dgrad is the same kernel run on the flipped/transposed weights (conv2d_dgrad_weights), exactly as for the MFMA path.
+// The weight gradient accumulates the KK*CI*CO (+CO bias) sums per thread over a persistent loop and writes one
+// partial slab per block in the layout conv2d_wgrad's deterministic slab reduction already consumes.
+#include "ops.h"
+#include "prof.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int DTX = 32, DTY = 8;        // output tile (one pixel per thread, 256 threads)
+
+struct DirectParams {
+    TView in, out, add, mask;
+    const float* w;
+    const float* bias;
+    float* partial;                      // wgrad only: [gridDim.x][KK*Cin*Cout + Cout]
+    int Cin, Cout, H, W;
+    int tiles_x, tiles_y, ntiles;
+    unsigned m_tx, m_ty;
+    int relu, accumulate;
+};
+
+// Stage the (DTY+KS-1) x (DTX+KS-1) halo tile of `v` (CI padded channels) around (n, y0, x0) into LDS planes.
+template <int KS, int CI>
+__device__ __forceinline__ void stage_tile(const TView& v, int Cin, int H, int W, int n, int y0, int x0, int tid,
+                                           float* __restrict__ tile) {
+    constexpr int R = KS / 2, HWD = DTX + KS - 1, HHT = DTY + KS - 1, HPIX = HWD * HHT;
+    constexpr int VEC = CI < 4 ? CI : 4, NPL = CI / VEC;
+    constexpr int TOTAL = HPIX * NPL;
+    constexpr int ITERS = (TOTAL + 255) / 256;
+    if (VEC == 4 && v.vec) {
+        float4 r[ITERS];
+        unsigned m[ITERS];
+#pragma unroll
+        for (int u = 0; u < ITERS; ++u) {
+            const int e = tid + u * 256;
+            const int hp = e / NPL, pl = e - hp * NPL;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = y0 - R + hy, gx = x0 - R + hx;
+            const bool ok = e < TOTAL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            r[u] = view_load4_raw(v, n, gy, gx, pl * 4, ok);
+            m[u] = valid4(pl * 4, Cin, ok);
+        }
+#pragma unroll
+        for (int u = 0; u < ITERS; ++u) {
+            const int e = tid + u * 256;
+            if (e < TOTAL) {
+                const int hp = e / NPL, pl = e - hp * NPL;
+                *reinterpret_cast<float4*>(tile + ((size_t)pl * HPIX + hp) * 4) = mask4(r[u], m[u]);
+            }
+        }
+    } else {
+        // scalar path (Cin < 4, or a view without 16-byte alignment): one (pixel, channel) float per element
+        constexpr int TS = HPIX * CI;
+        constexpr int ITS = (TS + 255) / 256;
+        float r[ITS];
+        unsigned m[ITS];
+#pragma unroll
+        for (int u = 0; u < ITS; ++u) {
+            const int e = tid + u * 256;
+            const int hp = e / CI, c = e - hp * CI;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = y0 - R + hy, gx = x0 - R + hx;
+            const bool ok = e < TS && c < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            r[u] = v.p[view_off(v, n, ok ? gy : 0, ok ? gx : 0, ok ? c : 0)];
+            m[u] = ok ? 0xffffffffu : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < ITS; ++u) {
+            const int e = tid + u * 256;
+            if (e < TS) {
+                const int hp = e / CI, c = e - hp * CI;
+                unsigned mm = m[u];
+                asm volatile("" : "+v"(mm));
+                tile[((size_t)(c / VEC) * HPIX + hp) * VEC + (c % VEC)] = __uint_as_float(__float_as_uint(r[u]) & mm);
+            }
+        }
+    }
+}
+
+template <int KS, int CI, int CO>
+__global__ void __launch_bounds__(256) conv_direct_kernel(const DirectParams a) {
+    constexpr int HWD = DTX + KS - 1, HHT = DTY + KS - 1, HPIX = HWD * HHT;
+    constexpr int VEC = CI < 4 ? CI : 4, NPL = CI / VEC;
+    constexpr int KK = KS * KS, NWT = KK * CI * CO;
+    __shared__ __attribute__((aligned(16))) float tile[NPL * HPIX * VEC];
+    __shared__ float wl[NWT];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NWT; e += 256) {
+        const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+        wl[e] = (ci < a.Cin && co < a.Cout) ? a.w[((size_t)tap * a.Cin + ci) * a.Cout + co] : 0.f;
+    }
+    __syncthreads();
+    float ws[NWT];
+#pragma unroll
+    for (int e = 0; e < NWT; ++e) ws[e] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wl[e])));
+    float bs[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) bs[co] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+
+    const int ty = tid / DTX, tx = tid % DTX;
+    const bool vec_out = (CO % 4 == 0) && a.Cout == CO && a.out.vec && (!a.add.p || a.add.vec) && (!a.mask.p || a.mask.vec);
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int q = fast_div(t, a.m_tx);
+        const int bx = t - q * a.tiles_x;
+        const int n = fast_div(q, a.m_ty);
+        const int by = q - n * a.tiles_y;
+        const int x0 = bx * DTX, y0 = by * DTY;
+        stage_tile<KS, CI>(a.in, a.Cin, a.H, a.W, n, y0, x0, tid, tile);
+        __syncthreads();
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    float v[VEC];
+                    const float* src = tile + ((size_t)pl * HPIX + (ty + dy) * HWD + tx + dx) * VEC;
+                    if (VEC == 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(src);
+                        v[0] = t4.x; v[1] = t4.y; v[2 % VEC] = t4.z; v[3 % VEC] = t4.w;
+                    } else if (VEC == 2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(src);
+                        v[0] = t2.x; v[1 % VEC] = t2.y;
+                    } else {
+                        v[0] = src[0];
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+#pragma unroll
+                        for (int co = 0; co < CO; ++co)
+                            acc[co] = fmaf(v[k], ws[((dy * KS + dx) * CI + pl * VEC + k) * CO + co], acc[co]);
+                    }
+                }
+            }
+        }
+        const int gy = y0 + ty, gx = x0 + tx;
+        if (gy < a.H && gx < a.W) {
+            if (vec_out) {
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4) {
+                    float4 v = make_float4(acc[(c4 * 4) % CO] + bs[(c4 * 4) % CO], acc[(c4 * 4 + 1) % CO] + bs[(c4 * 4 + 1) % CO],
+                                           acc[(c4 * 4 + 2) % CO] + bs[(c4 * 4 + 2) % CO], acc[(c4 * 4 + 3) % CO] + bs[(c4 * 4 + 3) % CO]);
+                    if (a.add.p) {
+                        const float4 r = *reinterpret_cast<const float4*>(a.add.p + view_off(a.add, n, gy, gx, c4 * 4));
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (a.mask.p) {
+                        const float4 m = *reinterpret_cast<const float4*>(a.mask.p + view_off(a.mask, n, gy, gx, c4 * 4));
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    }
+                    float4* dst = reinterpret_cast<float4*>(a.out.p + view_off(a.out, n, gy, gx, c4 * 4));
+                    if (a.accumulate) {
+                        const float4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *dst = v;
+                }
+            } else {
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    if (co < a.Cout) {
+                        float tv = acc[co] + bs[co];
+                        if (a.add.p) tv += a.add.p[view_off(a.add, n, gy, gx, co)];
+                        if (a.relu) tv = fmaxf(tv, 0.f);
+                        if (a.mask.p) tv = (a.mask.p[view_off(a.mask, n, gy, gx, co)] > 0.f) ? tv : 0.f;
+                        const size_t o = view_off(a.out, n, gy, gx, co);
+                        if (a.accumulate) tv += a.out.p[o];
+                        a.out.p[o] = tv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dW[tap][ci][co] = sum_p x[p + tap][ci] * dz[p][co], db[co] = sum_p dz[p][co]; a.in = x, a.out = dz.
+template <int KS, int CI, int CO>
+__global__ void __launch_bounds__(256) conv_direct_wgrad_kernel(const DirectParams a) {
+    constexpr int HWD = DTX + KS - 1, HHT = DTY + KS - 1, HPIX = HWD * HHT;
+    constexpr int VEC = CI < 4 ? CI : 4, NPL = CI / VEC;
+    constexpr int KK = KS * KS, NWT = KK * CI * CO, NACC = NWT + CO;
+    __shared__ __attribute__((aligned(16))) float tile[NPL * HPIX * VEC];
+    __shared__ float red[4][NACC];
+    const int tid = threadIdx.x;
+    const int ty = tid / DTX, tx = tid % DTX;
+    float acc[NACC];
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) acc[e] = 0.f;
+    const bool vec_dz = (CO % 4 == 0) && a.Cout == CO && a.out.vec;
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int q = fast_div(t, a.m_tx);
+        const int bx = t - q * a.tiles_x;
+        const int n = fast_div(q, a.m_ty);
+        const int by = q - n * a.tiles_y;
+        const int x0 = bx * DTX, y0 = by * DTY;
+        const int gy = y0 + ty, gx = x0 + tx;
+        const bool pok = gy < a.H && gx < a.W;
+        // dz of this thread's pixel: issued before the staging so that both are in flight together
+        float dz[CO];
+        if (vec_dz) {
+#pragma unroll
+            for (int c4 = 0; c4 < CO / 4; ++c4) {
+                const float4 r4 = mask4(view_load4_raw(a.out, n, gy, gx, c4 * 4, pok), valid4(c4 * 4, a.Cout, pok));
+                dz[(c4 * 4) % CO] = r4.x; dz[(c4 * 4 + 1) % CO] = r4.y; dz[(c4 * 4 + 2) % CO] = r4.z; dz[(c4 * 4 + 3) % CO] = r4.w;
+            }
+        } else {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                const bool ok = pok && co < a.Cout;
+                const float r = a.out.p[view_off(a.out, n, ok ? gy : 0, ok ? gx : 0, ok ? co : 0)];
+                unsigned mm = ok ? 0xffffffffu : 0u;
+                asm volatile("" : "+v"(mm));
+                dz[co] = __uint_as_float(__float_as_uint(r) & mm);
+            }
+        }
+        stage_tile<KS, CI>(a.in, a.Cin, a.H, a.W, n, y0, x0, tid, tile);
+        __syncthreads();
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[NWT + co] += dz[co];
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    float v[VEC];
+                    const float* src = tile + ((size_t)pl * HPIX + (ty + dy) * HWD + tx + dx) * VEC;
+                    if (VEC == 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(src);
+                        v[0] = t4.x; v[1] = t4.y; v[2 % VEC] = t4.z; v[3 % VEC] = t4.w;
+                    } else if (VEC == 2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(src);
+                        v[0] = t2.x; v[1 % VEC] = t2.y;
+                    } else {
+                        v[0] = src[0];
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+#pragma unroll
+                        for (int co = 0; co < CO; ++co) {
+                            const int e = ((dy * KS + dx) * CI + pl * VEC + k) * CO + co;
+                            acc[e] = fmaf(v[k], dz[co], acc[e]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // block reduction in a fixed order: lanes (butterfly) -> waves -> slab
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) {
+        const float s = wave_sum(acc[e]);
+        if (lane == 0) red[wave][e] = s;
+    }
+    __syncthreads();
+    const size_t nw = (size_t)KK * a.Cin * a.Cout;
+    float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
+    for (int e = tid; e < NACC; e += 256) {
+        const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < NWT) {
+            const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+            if (ci < a.Cin && co < a.Cout) slab[((size_t)tap * a.Cin + ci) * a.Cout + co] = s;
+        } else if (e - NWT < a.Cout) {
+            slab[nw + (e - NWT)] = s;
+        }
+    }
+}
+
+inline int pad_pow2(int c) { int p = 1; while (p < c) p <<= 1; return p; }
+
+bool eligible(const TView& in, const TView& out, int KS) {
+    if (KS != 3) return false;
+    if (in.d2s > 1 || out.d2s > 1) return false;
+    if (in.C < 1 || out.C < 1) return false;
+    return pad_pow2(in.C) * pad_pow2(out.C) <= 8;
+}
+
+void fill_tiles(DirectParams& p, int N) {
+    p.tiles_x = cdiv(p.W, DTX);
+    p.tiles_y = cdiv(p.H, DTY);
+    p.ntiles = p.tiles_x * p.tiles_y * N;
+    p.m_tx = div_magic(p.tiles_x);
+    p.m_ty = div_magic(p.tiles_y);
+}
+
+template <int KS, int CI, int CO>
+void launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks) {
+    const double px = (double)p.in.N * p.H * p.W;
+    const std::string tag = std::string(wgrad ? "conv_direct_wgrad<" : "conv_direct<") + std::to_string(KS) + "," +
+                            std::to_string(CI) + "," + std::to_string(CO) + ">";
+    ProfScope ps(s, tag, 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * px * (p.Cin + p.Cout));
+    if (wgrad) hipLaunchKernelGGL((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_direct_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+void dispatch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks) {
+    const int ci = pad_pow2(p.Cin), co = pad_pow2(p.Cout);
+    switch (ci * 16 + co) {
+        case 1 * 16 + 1: launch_direct<3, 1, 1>(s, p, wgrad, blocks); break;
+        case 1 * 16 + 2: launch_direct<3, 1, 2>(s, p, wgrad, blocks); break;
+        case 1 * 16 + 4: launch_direct<3, 1, 4>(s, p, wgrad, blocks); break;
+        case 1 * 16 + 8: launch_direct<3, 1, 8>(s, p, wgrad, blocks); break;
+        case 2 * 16 + 1: launch_direct<3, 2, 1>(s, p, wgrad, blocks); break;
+        case 2 * 16 + 2: launch_direct<3, 2, 2>(s, p, wgrad, blocks); break;
+        case 2 * 16 + 4: launch_direct<3, 2, 4>(s, p, wgrad, blocks); break;
+        case 4 * 16 + 1: launch_direct<3, 4, 1>(s, p, wgrad, blocks); break;
+        case 4 * 16 + 2: launch_direct<3, 4, 2>(s, p, wgrad, blocks); break;
+        case 8 * 16 + 1: launch_direct<3, 8, 1>(s, p, wgrad, blocks); break;
+        default: throw Dl4dsError("conv_direct: unsupported channel combination");
+    }
+}
+
+}  // namespace
+
+bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
+                           const ConvEpilogue& ep) {
+    if (!eligible(in, out, KS)) return false;
+    if ((ep.add.p && ep.add.d2s > 1) || (ep.mask.p && ep.mask.d2s > 1)) return false;
+    DirectParams p;
+    p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
+    p.w = w; p.bias = ep.bias; p.partial = nullptr;
+    p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
+    p.relu = ep.relu; p.accumulate = ep.accumulate;
+    fill_tiles(p, in.N);
+    if (p.ntiles == 0) return true;
+    dispatch_direct(s, p, false, std::min(p.ntiles, 2048));
+    return true;
+}
+
+int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS) {
+    if (!eligible(x, dz, KS)) return 0;
+    const int ntiles = cdiv(x.W, DTX) * cdiv(x.H, DTY) * x.N;
+    return std::max(1, std::min(ntiles, 1024));
+}
+
+void conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs) {
+    DirectParams p;
+    p.in = x; p.out = dz; p.add = TView{nullptr, 0, 0, 0, 0, 0, 0, 0}; p.mask = p.add;
+    p.w = nullptr; p.bias = nullptr; p.partial = partial;
+    p.Cin = x.C; p.Cout = dz.C; p.H = x.H; p.W = x.W;
+    p.relu = 0; p.accumulate = 0;
+    fill_tiles(p, x.N);
+    dispatch_direct(s, p, true, slabs);
+}

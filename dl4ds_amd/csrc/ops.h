@@ -19,6 +19,12 @@ void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int 
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS);
 void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate, float* db,
                   int accumulate_db, float* workspace, size_t workspace_bytes);
+// Stencil (VALU) path for 3x3 layers with pad2(Cin)*pad2(Cout) <= 8 (conv_direct.hip); conv2d_forward / conv2d_wgrad
+// route to it themselves.  forward returns false when the layer is not eligible; wgrad_slabs returns 0.
+bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
+                           const ConvEpilogue& ep);
+int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS);
+void conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs);
 // Conv2DTranspose(k, stride s, 'same', no bias), kernel HWOI [k*k][Cout][Cin] (blocks.py:508-516)
 void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, int KS, int stride,
                               const TView& out, int relu, float* workspace, size_t workspace_bytes);

@@ -39,6 +39,9 @@ CONV_CASES = [
     (1, 8, 16, 48, 192, 3), (1, 24, 24, 50, 40, 3), (2, 16, 32, 40, 48, 3), (1, 12, 12, 192, 48, 3),
     (2, 17, 16, 8, 48, 1), (1, 16, 16, 48, 8, 1), (1, 10, 10, 24, 200, 1), (1, 16, 16, 6, 12, 5),
     (1, 9, 9, 16, 32, 5), (1, 8, 8, 130, 128, 3), (1, 6, 6, 256, 100, 3),
+    # stencil path (conv_direct.hip): pad2(Cin) * pad2(Cout) <= 8, ragged tiles, several tiles per block
+    (2, 21, 70, 1, 1, 3), (1, 9, 33, 3, 1, 3), (2, 8, 32, 1, 3, 3), (1, 17, 40, 2, 4, 3), (1, 5, 5, 4, 2, 3),
+    (3, 40, 100, 7, 1, 3), (1, 11, 65, 2, 2, 3), (1, 16, 31, 1, 7, 3), (1, 3, 2, 5, 1, 3),
 ]
 
 
@@ -56,6 +59,23 @@ def test_conv2d_fused_epilogues(ops):
     close(ops.conv2d(x, wt, b, relu=True), np.maximum(ref, 0))
     close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
     close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+
+
+@pytest.mark.parametrize('ci,co', [(8, 1), (1, 8), (1, 1), (3, 2)])
+def test_conv2d_fused_epilogues_stencil_path(ops, ci, co):
+    n, h, w = 2, 19, 45
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    close(ops.conv2d(x, wt, b, relu=True), np.maximum(ref, 0))
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    dz = R(n, h, w, co)
+    gx, gw = _torch_conv_grads(x, wt, dz)
+    base_x, base_w = R(*gx.shape), R(*gw.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+    close(ops.conv2d_wgrad(x, dz, 3, accumulate_into=base_w), gw + base_w)
+    a = ops.conv2d_wgrad(x, dz, 3)
+    np.testing.assert_array_equal(a, ops.conv2d_wgrad(x, dz, 3))   # bitwise reproducible
 
 
 @pytest.mark.parametrize('ci,co,r', [(8, 32, 2), (48, 192, 2), (4, 50, 5), (6, 36, 3)])

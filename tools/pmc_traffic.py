@@ -19,8 +19,10 @@ out = {}
 for k in fetch:
     m = re.search(r'(conv_\w+)<([^>]*)>', k)
     args = m.group(2).replace(' ', '').split(',') if m else []
-    if m and 'pipe' in m.group(1):
-        args = args[:5]                      # drop the WREG template argument (not part of bench.py's tag)
+    if m and 'igemm_db' in m.group(1):
+        args = args[:5]                      # bench.py's tag carries <KS,MT,NT,WM,WN> only
+    if m and 'wgrad' in m.group(1):
+        args = args[:4]                      # ... and <KS,CIT,COT,WCO> for wgrad (drop the prefetch flag)
     tag = (m.group(1).replace('_kernel', '') + '<' + ','.join(args) + '>') if m else k[:60]
     f = sum(fetch[k]) / len(fetch[k])
     w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
