@@ -16,6 +16,7 @@
 // partial slab per block in the layout conv2d_wgrad's deterministic slab reduction already consumes.
 #include "ops.h"
 #include "prof.h"
+#include "launch.h"
 #include <algorithm>
 
 namespace {
@@ -294,6 +295,7 @@ bool eligible(const TView& in, const TView& out, int KS) {
     if (KS != 3) return false;
     if (in.d2s > 1 || out.d2s > 1) return false;
     if (in.C < 1 || out.C < 1) return false;
+    if ((long)cdiv(in.W, DTX) * cdiv(in.H, DTY) * in.N >= (1l << 20)) return false;      // fast_div range
     return pad_pow2(in.C) * pad_pow2(out.C) <= 8;
 }
 
@@ -306,7 +308,10 @@ void fill_tiles(DirectParams& p, int N) {
 }
 
 template <int KS, int CI, int CO>
-void launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks) {
+int launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int max_blocks) {
+    // persistent kernels: one residency round (blocks do equal work)
+    const int blocks = std::min(max_blocks, wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256)
+                                                  : resident_blocks<conv_direct_kernel<KS, CI, CO>>(256));
     const double px = (double)p.in.N * p.H * p.W;
     const std::string tag = std::string(wgrad ? "conv_direct_wgrad<" : "conv_direct<") + std::to_string(KS) + "," +
                             std::to_string(CI) + "," + std::to_string(CO) + ">";
@@ -314,21 +319,23 @@ void launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks)
     if (wgrad) hipLaunchKernelGGL((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_direct_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
+    return blocks;
 }
 
-void dispatch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks) {
+// returns the number of blocks launched (= partial slabs written, for wgrad)
+int dispatch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks) {
     const int ci = pad_pow2(p.Cin), co = pad_pow2(p.Cout);
     switch (ci * 16 + co) {
-        case 1 * 16 + 1: launch_direct<3, 1, 1>(s, p, wgrad, blocks); break;
-        case 1 * 16 + 2: launch_direct<3, 1, 2>(s, p, wgrad, blocks); break;
-        case 1 * 16 + 4: launch_direct<3, 1, 4>(s, p, wgrad, blocks); break;
-        case 1 * 16 + 8: launch_direct<3, 1, 8>(s, p, wgrad, blocks); break;
-        case 2 * 16 + 1: launch_direct<3, 2, 1>(s, p, wgrad, blocks); break;
-        case 2 * 16 + 2: launch_direct<3, 2, 2>(s, p, wgrad, blocks); break;
-        case 2 * 16 + 4: launch_direct<3, 2, 4>(s, p, wgrad, blocks); break;
-        case 4 * 16 + 1: launch_direct<3, 4, 1>(s, p, wgrad, blocks); break;
-        case 4 * 16 + 2: launch_direct<3, 4, 2>(s, p, wgrad, blocks); break;
-        case 8 * 16 + 1: launch_direct<3, 8, 1>(s, p, wgrad, blocks); break;
+        case 1 * 16 + 1: return launch_direct<3, 1, 1>(s, p, wgrad, blocks);
+        case 1 * 16 + 2: return launch_direct<3, 1, 2>(s, p, wgrad, blocks);
+        case 1 * 16 + 4: return launch_direct<3, 1, 4>(s, p, wgrad, blocks);
+        case 1 * 16 + 8: return launch_direct<3, 1, 8>(s, p, wgrad, blocks);
+        case 2 * 16 + 1: return launch_direct<3, 2, 1>(s, p, wgrad, blocks);
+        case 2 * 16 + 2: return launch_direct<3, 2, 2>(s, p, wgrad, blocks);
+        case 2 * 16 + 4: return launch_direct<3, 2, 4>(s, p, wgrad, blocks);
+        case 4 * 16 + 1: return launch_direct<3, 4, 1>(s, p, wgrad, blocks);
+        case 4 * 16 + 2: return launch_direct<3, 4, 2>(s, p, wgrad, blocks);
+        case 8 * 16 + 1: return launch_direct<3, 8, 1>(s, p, wgrad, blocks);
         default: throw Dl4dsError("conv_direct: unsupported channel combination");
     }
 }
@@ -346,7 +353,7 @@ bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int K
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     fill_tiles(p, in.N);
     if (p.ntiles == 0) return true;
-    dispatch_direct(s, p, false, std::min(p.ntiles, 2048));
+    dispatch_direct(s, p, false, p.ntiles);
     return true;
 }
 
@@ -356,12 +363,12 @@ int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS) {
     return std::max(1, std::min(ntiles, 1024));
 }
 
-void conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs) {
+int conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs) {
     DirectParams p;
     p.in = x; p.out = dz; p.add = TView{nullptr, 0, 0, 0, 0, 0, 0, 0}; p.mask = p.add;
     p.w = nullptr; p.bias = nullptr; p.partial = partial;
     p.Cin = x.C; p.Cout = dz.C; p.H = x.H; p.W = x.W;
     p.relu = 0; p.accumulate = 0;
     fill_tiles(p, x.N);
-    dispatch_direct(s, p, true, slabs);
+    return dispatch_direct(s, p, true, slabs);
 }

@@ -23,8 +23,12 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
 // route to it themselves.  forward returns false when the layer is not eligible; wgrad_slabs returns 0.
 bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep);
+// 3x3, Cin <= 16, Cout <= 16: register-resident filter, persistent MFMA kernel (conv_narrow.hip)
+bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
+                           const ConvEpilogue& ep);
 int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS);
-void conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs);
+// writes at most `slabs` partial slabs (the workspace bound); returns how many it wrote
+int conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs);
 // Conv2DTranspose(k, stride s, 'same', no bias), kernel HWOI [k*k][Cout][Cin] (blocks.py:508-516)
 void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, int KS, int stride,
                               const TView& out, int relu, float* workspace, size_t workspace_bytes);

@@ -42,6 +42,9 @@ CONV_CASES = [
     # stencil path (conv_direct.hip): pad2(Cin) * pad2(Cout) <= 8, ragged tiles, several tiles per block
     (2, 21, 70, 1, 1, 3), (1, 9, 33, 3, 1, 3), (2, 8, 32, 1, 3, 3), (1, 17, 40, 2, 4, 3), (1, 5, 5, 4, 2, 3),
     (3, 40, 100, 7, 1, 3), (1, 11, 65, 2, 2, 3), (1, 16, 31, 1, 7, 3), (1, 3, 2, 5, 1, 3),
+    # register-resident-filter MFMA path (conv_narrow.hip): Cin, Cout <= 16, Cin % 4 == 0
+    (2, 40, 35, 8, 8, 3), (1, 33, 20, 16, 12, 3), (2, 70, 18, 4, 16, 3), (1, 64, 64, 12, 8, 3), (1, 5, 3, 8, 16, 3),
+    (6, 32, 16, 16, 16, 3),
 ]
 
 
