@@ -960,6 +960,7 @@ void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int 
 
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS) {
     if (const int ds = conv2d_direct_wgrad_slabs(x, dz, KS)) return (size_t)ds * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
+    if (const int ns = conv2d_narrow_wgrad_slabs(x, dz, KS)) return (size_t)ns * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
     WgradPlan pl = plan_wgrad(x, dz, KS);
     return (size_t)pl.S * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
 }
@@ -971,7 +972,8 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     const size_t nw = (size_t)KS * KS * x.C * dz.C;
     const size_t n = nw + dz.C;
     const int direct_slabs = conv2d_direct_wgrad_slabs(x, dz, KS);
-    int nslabs = direct_slabs ? direct_slabs : pl.S;
+    const int narrow_slabs = (direct_slabs || getenv("DL4DS_NO_NARROW")) ? 0 : conv2d_narrow_wgrad_slabs(x, dz, KS);
+    int nslabs = direct_slabs ? direct_slabs : (narrow_slabs ? narrow_slabs : pl.S);
     DL4DS_REQUIRE(workspace_bytes >= (size_t)nslabs * n * sizeof(float), "wgrad: workspace too small");
     WgradParams p;
     p.x = x; p.dz = dz; p.partial = workspace;
@@ -979,6 +981,8 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S;
     if (direct_slabs) {
         nslabs = conv2d_direct_wgrad(s, x, dz, KS, workspace, direct_slabs);
+    } else if (narrow_slabs) {
+        nslabs = conv2d_narrow_wgrad(s, x, dz, KS, workspace, narrow_slabs);
     } else {
         switch (KS) {
             case 1: dispatch_wgrad<1>(s, p, pl); break;

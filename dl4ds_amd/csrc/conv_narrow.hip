@@ -141,7 +141,185 @@ void launch_narrow(hipStream_t s, ConvParams& p, int N) {
     HIP_CHECK(hipGetLastError());
 }
 
+// --------------------------------------------------------------------------------------------
+// Weight gradient for Cin <= 8: dW[tap][ci][co] = sum_p x[p + tap][ci] * dz[p][co].
+// GEMM view per MFMA: rows = cout (first operand, dz), columns = (tap-of-a-pair, cin) (second operand, x), K = 4
+// consecutive pixels of a tile row.  With 8 cins two taps share the 16 columns, so the nine taps take five MFMAs per
+// pixel quad -- pairs (0,1) (3,4) (6,7) are horizontally adjacent (one contiguous 16-float LDS segment per k-slot),
+// pair (2,5) is vertically adjacent (second half one tile row further), tap 8 is alone -- instead of the nine the
+// general kernel issues (one 16-cin tile per tap, half of it padding).  All LDS reads use immediate offsets from
+// two per-lane bases; the dz fragment of a quad is read once and reused by the five MFMAs; the bias gradient is the
+// running sum of those dz fragments.  Persistent blocks, one partial slab per block, fixed reduction order.
+struct NarrowWgradParams {
+    TView x, dz;
+    float* partial;
+    int Cin, Cout, H, W;
+    int tiles_x, tiles_y, ntiles;
+    unsigned m_tx, m_ty;
+};
+
+template <int PZ>     // dz channels per pixel in LDS: 8 (Cout <= 8) or 16
+__global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowWgradParams a) {
+    constexpr int TWH = NTW + 2, THH = NTH + 2, HPIX = TWH * THH;
+    constexpr int XQ = HPIX * 2;                        // float4s in the x halo tile (8 channels per pixel)
+    constexpr int ZQ4 = PZ / 4, ZQ = NTW * NTH * ZQ4;   // float4s in the dz tile
+    constexpr int XIT = (XQ + 255) / 256, ZIT = (ZQ + 255) / 256;
+    constexpr int XF = HPIX * 8 + 32;                   // + slack: the unused half of the lone tap reads one pixel on
+    constexpr int NG = 5, NV = NG * 4 + 1;              // accumulator groups; values per lane in the final reduction
+    __shared__ __attribute__((aligned(16))) float smem[XF + NTW * NTH * PZ];
+    static_assert(XF + NTW * NTH * PZ >= NV * 256, "reduction buffer does not fit");
+    float* xt = smem;
+    float* zt = smem + XF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    if (tid < 32) xt[HPIX * 8 + tid] = 0.f;
+
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool zlane = (PZ == 16) || l15 < 8;           // PZ == 8: lanes 8..15 would read the next pixel's channels
+    const float* zrd = zt + ((wave * NROWS) * NTW + lq) * PZ + (zlane ? l15 : 0);
+    const float* xa = xt + ((wave * NROWS) * TWH + lq) * 8 + l15;                        // halves one pixel apart
+    const float* xb = xt + ((wave * NROWS) * TWH + lq) * 8 + (l15 & 7) + (l15 >> 3) * TWH * 8;   // one row apart
+
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int q0 = fast_div(t, a.m_tx);
+        const int bx = t - q0 * a.tiles_x;
+        const int n = fast_div(q0, a.m_ty);
+        const int by = q0 - n * a.tiles_y;
+        const int x0 = bx * NTW, y0 = by * NTH;
+        {
+            float4 xr[XIT], zr[ZIT];
+            unsigned xm[XIT], zm[ZIT];
+#pragma unroll
+            for (int u = 0; u < XIT; ++u) {
+                const int e = tid + u * 256;
+                const int pix = e >> 1, c4 = e & 1;
+                const int hy = pix / TWH, hx = pix - hy * TWH;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool ok = e < XQ && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool cok = ok && c4 * 4 < a.Cin;
+                const size_t off = (size_t)n * a.x.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.x.ld +
+                                   (cok ? c4 * 4 : 0);
+                xr[u] = *reinterpret_cast<const float4*>(a.x.p + off);
+                xm[u] = valid4(c4 * 4, a.Cin, ok);
+            }
+#pragma unroll
+            for (int u = 0; u < ZIT; ++u) {
+                const int e = tid + u * 256;
+                const int pix = e / ZQ4, c4 = e - pix * ZQ4;
+                const int ry = pix / NTW, rx = pix - ry * NTW;
+                const int gy = y0 + ry, gx = x0 + rx;
+                const bool ok = e < ZQ && gy < a.H && gx < a.W;
+                const bool cok = ok && c4 * 4 < a.Cout;
+                const size_t off = (size_t)n * a.dz.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.dz.ld +
+                                   (cok ? c4 * 4 : 0);
+                zr[u] = *reinterpret_cast<const float4*>(a.dz.p + off);
+                zm[u] = valid4(c4 * 4, a.Cout, ok);
+            }
+#pragma unroll
+            for (int u = 0; u < XIT; ++u) {
+                const int e = tid + u * 256;
+                if (e < XQ) *reinterpret_cast<float4*>(xt + (size_t)e * 4) = mask4(xr[u], xm[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < ZIT; ++u) {
+                const int e = tid + u * 256;
+                if (e < ZQ) *reinterpret_cast<float4*>(zt + (size_t)e * 4) = mask4(zr[u], zm[u]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NROWS; ++r) {
+            __builtin_amdgcn_sched_barrier(0);          // one row's fragments in flight at a time (VGPR bound)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dzv = zrd[(r * NTW + q * 4) * PZ];
+                if (PZ == 8) dzv = zlane ? dzv : 0.f;
+                bsum += dzv;
+                const float x0v = xa[((r + 0) * TWH + q * 4 + 0) * 8];     // taps (0,0) | (0,1)
+                const float x1v = xa[((r + 1) * TWH + q * 4 + 0) * 8];     // taps (1,0) | (1,1)
+                const float x2v = xa[((r + 2) * TWH + q * 4 + 0) * 8];     // taps (2,0) | (2,1)
+                const float x3v = xb[((r + 0) * TWH + q * 4 + 2) * 8];     // taps (0,2) | (1,2)
+                const float x4v = xa[((r + 2) * TWH + q * 4 + 2) * 8];     // tap  (2,2) | unused
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x0v, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x1v, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x2v, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x3v, acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x4v, acc[4], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- block reduction (waves in fixed order) and slab write by wave 0
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) smem[(g * 4 + rg) * 256 + tid] = acc[g][rg];
+    smem[(NG * 4) * 256 + tid] = bsum;
+    __syncthreads();
+    if (wave != 0) return;
+    const size_t nw = (size_t)9 * a.Cin * a.Cout;
+    float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
+    const int half = l15 >> 3, ci = l15 & 7;
+    const int tap_a[NG] = {0, 3, 6, 2, 8}, tap_b[NG] = {1, 4, 7, 5, -1};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int tap = half ? tap_b[g] : tap_a[g];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float* src = smem + (g * 4 + rg) * 256 + lane;
+            const float v = (src[0] + src[64]) + (src[128] + src[192]);
+            const int co = lq * 4 + rg;
+            if (tap >= 0 && ci < a.Cin && co < a.Cout) slab[((size_t)tap * a.Cin + ci) * a.Cout + co] = v;
+        }
+    }
+    {
+        const float* src = smem + (NG * 4) * 256 + lane;
+        const float v = (src[0] + src[64]) + (src[128] + src[192]);
+        if (lq == 0 && l15 < a.Cout) slab[nw + l15] = v;
+    }
+}
+
+bool narrow_wgrad_eligible(const TView& x, const TView& dz, int KS) {
+    if (KS != 3 || x.C > 8 || dz.C > 16 || x.d2s > 1 || dz.d2s > 1 || !x.vec || !dz.vec) return false;
+    return (long)cdiv(x.W, NTW) * cdiv(x.H, NTH) * x.N < (1l << 20);                   // fast_div range
+}
+
 }  // namespace
+
+int conv2d_narrow_wgrad_slabs(const TView& x, const TView& dz, int KS) {
+    if (!narrow_wgrad_eligible(x, dz, KS)) return 0;
+    const int ntiles = cdiv(x.W, NTW) * cdiv(x.H, NTH) * x.N;
+    return std::max(1, std::min(ntiles, 1024));
+}
+
+int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int max_slabs) {
+    NarrowWgradParams p;
+    p.x = x; p.dz = dz; p.partial = partial;
+    p.Cin = x.C; p.Cout = dz.C; p.H = x.H; p.W = x.W;
+    p.tiles_x = cdiv(p.W, NTW);
+    p.tiles_y = cdiv(p.H, NTH);
+    p.ntiles = p.tiles_x * p.tiles_y * x.N;
+    p.m_tx = div_magic(p.tiles_x);
+    p.m_ty = div_magic(p.tiles_y);
+    const bool wide = dz.C > 8;
+    const int resident = wide ? resident_blocks<conv_narrow_wgrad_kernel<16>>(256) : resident_blocks<conv_narrow_wgrad_kernel<8>>(256);
+    const int blocks = std::max(1, std::min(std::min(max_slabs, p.ntiles), resident));
+    const double px = (double)x.N * p.H * p.W;
+    ProfScope ps(s, std::string("conv_narrow_wgrad<") + (wide ? "16>" : "8>"), 2.0 * px * 9 * p.Cin * p.Cout,
+                 4.0 * px * (p.Cin + p.Cout));
+    if (wide) hipLaunchKernelGGL((conv_narrow_wgrad_kernel<16>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_narrow_wgrad_kernel<8>), dim3(blocks), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+    return blocks;
+}
 
 bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep) {
