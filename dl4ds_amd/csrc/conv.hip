@@ -934,6 +934,7 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     DL4DS_REQUIRE(in.N == out.N && in.H == out.H && in.W == out.W, "conv2d: stride-1 SAME shapes differ");
     if (conv2d_direct_forward(s, in, w, KS, out, ep)) return;      // a handful of channels: HBM-bound stencil
     if (!getenv("DL4DS_NO_NARROW") && conv2d_narrow_forward(s, in, w, KS, out, ep)) return;
+    if (!getenv("DL4DS_NO_STREAM") && conv2d_stream_forward(s, in, w, KS, out, ep)) return;
     ConvParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
     p.w = w; p.bias = ep.bias;

@@ -1,0 +1,311 @@
+// dl4ds_amd -- implicit-GEMM 3x3 / 1x1 convolution with the filter streamed from L2 straight into MFMA operands.
+//
+// The MFMA-bound layers of the residual backbone and of SubpixelConvolution (blocks.py:210-230, 433-454: 48->48,
+// 48->192 and, as dgrad, 192->48 at 128^2 .. 256^2) spent ~45 % of their time outside the matrix cores in the
+// LDS-staged kernels: every 1.9 us stage waited for its filter slice (global -> registers -> LDS -> barrier) and the
+// eight waves of a CU marched through prologue / stages / epilogue in lock-step.  Here the filter never touches LDS:
+//   * output channels are assigned to MFMA rows as cout = n0 + NT*row + j (j = accumulator tile), so ONE
+//     global_load_dwordx{NT} per lane and k-step yields the first operand of all NT tiles; the rows of one k-step are
+//     contiguous 64*NT-byte segments that stay hot in L2 (the whole filter is 83 KB for 48->48);
+//   * the K axis is ordered (tap, e) with MFMA k-slot q owning cin group [E*q, E*q+E) (E = CK/4), so the second
+//     operand (pixels) comes from the LDS halo tile as ds_read_b128/b64 at IMMEDIATE offsets, each feeding 4 (2) k-steps;
+//   * there is no barrier inside the K loop; waves drift apart and one wave's loads/epilogue overlap other waves' MFMAs;
+//     LDS holds only the input tile (67 KB at CK = 48), two workgroups per CU;
+//   * with that row assignment a lane ends up with 4*NT CONSECUTIVE output channels of one pixel -> NT float4 stores,
+//     also through depth_to_space views;
+//   * workgroups are numbered so that each XCD walks a contiguous range of tiles and the n-blocks of one tile run
+//     back to back on the same XCD (the input tile is fetched from HBM once per L2).
+// Rows beyond Cin (padded K) read real filter rows of the next tap (finite values) against ZEROED pixels, so the
+// inner loop needs no masks; only the very last tap clamps its row index.
+#include "ops.h"
+#include "prof.h"
+#include "conv_kernels.h"
+#include <algorithm>
+#include <mutex>
+
+namespace {
+
+template <int NT> struct WVec;
+template <> struct WVec<1> { typedef float T; };
+template <> struct WVec<2> { typedef float T __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct WVec<3> { typedef float T __attribute__((ext_vector_type(3), aligned(4))); };
+template <> struct WVec<4> { typedef float T __attribute__((ext_vector_type(4), aligned(4))); };
+
+template <int NT>
+__device__ __forceinline__ float wget(const typename WVec<NT>::T& v, int j) {
+    if constexpr (NT == 1) return v;
+    else return v[j];
+}
+
+struct StreamParams {
+    ConvParams c;
+    int nblk;           // n-blocks (16*NT couts each)
+    int ntiles;         // spatial tiles * batch
+    int per_xcd;        // tiles per XCD (contiguous range)
+    unsigned m_nblk;
+};
+
+template <int KS, int E, int NT>
+__global__ void __launch_bounds__(256, 2) conv_stream_kernel(const StreamParams sp) {
+    const ConvParams& a = sp.c;
+    constexpr int G = (E % 4 == 0) ? 4 : 2;          // k-steps fed by one LDS read
+    constexpr int NGRP = E / G;
+    constexpr int CK = 4 * E;                        // input channels per chunk
+    constexpr int P = CK + G;                        // LDS pixel pitch: P/G odd -> conflict-free b128 / b64 reads
+    constexpr int TW = 16, TH = 16, MT = 4, PAD = KS / 2;
+    constexpr int TWH = TW + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
+    constexpr int KK = KS * KS, NGS = KK * NGRP;     // group-steps per chunk
+    constexpr int Q4 = CK / 4;
+    constexpr int TOTAL = HPIX * Q4, ITERS = (TOTAL + 255) / 256;
+    constexpr int WPD = 2;                           // filter prefetch distance in group-steps
+    typedef typename WVec<NT>::T wvec_t;
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // ---- which (tile, n-block): XCD = id % 8 owns tiles [xcd*per_xcd, (xcd+1)*per_xcd), n-blocks innermost
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int tl = fast_div(slot, sp.m_nblk);
+    const int nb = slot - tl * sp.nblk;
+    const int t = xcd * sp.per_xcd + tl;
+    if (tl >= sp.per_xcd || t >= sp.ntiles) return;
+    const int q = fast_div(t, a.m_txy[0]);
+    const int bx = t - q * a.tiles_x;
+    const int n = fast_div(q, a.m_txy[1]);
+    const int by = q - n * a.tiles_y;
+    const int x0 = bx * TW, y0 = by * TH;
+    const int n0 = nb * 16 * NT;
+
+    // ---- filter addressing: lane (row l15, k-slot lq) reads floats [co, co+NT) of row (tap*Cin + c0 + E*lq + e)
+    const int co_lane = min(n0 + NT * l15, a.Cout - NT);          // rows beyond Cout are never stored
+    const int last_row = KK * a.Cin - 1;
+    const float* wlane = a.w + co_lane;
+
+    const float* rd = tile + ((wave * MT) * TWH + l15) * P + E * lq;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (c0 > 0) __syncthreads();
+        // ---- stage the halo tile, channels [c0, c0+CK): all loads in flight, masked when written
+        {
+            float4 r[ITERS];
+            unsigned m[ITERS];
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                const int e = tid + u * 256;
+                const int pix = e / Q4, c4 = e - pix * Q4;
+                const int hy = pix / TWH, hx = pix - hy * TWH;
+                const int gy = y0 - PAD + hy, gx = x0 - PAD + hx;
+                const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                r[u] = view_load4_raw(a.in, n, gy, gx, c0 + c4 * 4, ok && c0 + c4 * 4 < a.Cin);
+                m[u] = valid4(c0 + c4 * 4, a.Cin, ok);
+            }
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                const int e = tid + u * 256;
+                if (e < TOTAL) {
+                    const int pix = e / Q4, c4 = e - pix * Q4;
+                    const float4 v = mask4(r[u], m[u]);
+                    float* d = tile + (size_t)pix * P + c4 * 4;
+                    if (G == 4) {
+                        *reinterpret_cast<float4*>(d) = v;
+                    } else {
+                        reinterpret_cast<float2*>(d)[0] = make_float2(v.x, v.y);
+                        reinterpret_cast<float2*>(d)[1] = make_float2(v.z, v.w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- K loop over group-steps gs = tap*NGRP + g, software-pipelined: pixel fragments one group ahead,
+        //      filter fragments WPD groups ahead (L2 latency)
+        const int row_lane = c0 + E * lq;
+        auto load_w = [&](int gs, wvec_t (&dst)[G]) {
+            const int tap = gs / NGRP, g = gs - tap * NGRP;
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                int row = tap * a.Cin + row_lane + g * G + s;
+                if (tap == KK - 1) row = min(row, last_row);
+                dst[s] = *reinterpret_cast<const wvec_t*>(wlane + (size_t)row * a.Cout);
+            }
+        };
+        auto load_a = [&](int gs, float (&dst)[MT][G]) {
+            const int tap = gs / NGRP, g = gs - tap * NGRP;
+            const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float* src = rd + ((i + ky) * TWH + kx) * P + g * G;
+                if (G == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    dst[i][0] = v.x; dst[i][1] = v.y; dst[i][2 % G] = v.z; dst[i][3 % G] = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(src);
+                    dst[i][0] = v.x; dst[i][1] = v.y;
+                }
+            }
+        };
+        wvec_t wv[WPD + 1][G];
+        float av[2][MT][G];
+#pragma unroll
+        for (int d = 0; d < WPD; ++d)
+            if (d < NGS) load_w(d, wv[d]);
+        load_a(0, av[0]);
+#pragma unroll
+        for (int gs = 0; gs < NGS; ++gs) {
+            if (gs + WPD < NGS) load_w(gs + WPD, wv[(gs + WPD) % (WPD + 1)]);
+            if (gs + 1 < NGS) load_a(gs + 1, av[(gs + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < G; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wget<NT>(wv[gs % (WPD + 1)][s], j), av[gs & 1][i][s],
+                                                                          acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: lane (pixel column l15, k-slot lq) owns couts n0 + 4*NT*lq + [0, 4*NT) of rows wave*4 + i
+    const int gx = x0 + l15;
+    const int cb = n0 + 4 * NT * lq;
+    float4 bias_v[NT];
+    size_t q_out[NT], q_add[NT], q_mask[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int v = 0; v < NT; ++v) {
+        const int co = cb + 4 * v;
+        cok[v] = co < a.Cout;
+        const int cs = cok[v] ? co : 0;
+        q_out[v] = view_chan_off(a.out, cs);
+        q_add[v] = a.add.p ? view_chan_off(a.add, cs) : 0;
+        q_mask[v] = a.mask.p ? view_chan_off(a.mask, cs) : 0;
+        bias_v[v] = (a.bias && cok[v]) ? *reinterpret_cast<const float4*>(a.bias + cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int gy = y0 + wave * MT + i;
+        if (gy < a.H && gx < a.W) {
+            const size_t pb_out = view_pix_base(a.out, n, gy, gx);
+            const size_t pb_add = a.add.p ? view_pix_base(a.add, n, gy, gx) : 0;
+            const size_t pb_mask = a.mask.p ? view_pix_base(a.mask, n, gy, gx) : 0;
+#pragma unroll
+            for (int v = 0; v < NT; ++v) {
+                if (cok[v]) {
+                    // value index 4v+c within the lane's 4*NT couts  <->  accumulator (tile j, reg r): 4v+c = NT*r + j
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = acc[i][(4 * v + c) % NT][(4 * v + c) / NT];
+                    float4 r4 = make_float4(o[0] + bias_v[v].x, o[1] + bias_v[v].y, o[2] + bias_v[v].z, o[3] + bias_v[v].w);
+                    if (a.add.p) {
+                        const float4 ad = *reinterpret_cast<const float4*>(a.add.p + pb_add + q_add[v]);
+                        r4.x += ad.x; r4.y += ad.y; r4.z += ad.z; r4.w += ad.w;
+                    }
+                    if (a.relu) { r4.x = fmaxf(r4.x, 0.f); r4.y = fmaxf(r4.y, 0.f); r4.z = fmaxf(r4.z, 0.f); r4.w = fmaxf(r4.w, 0.f); }
+                    if (a.mask.p) {
+                        const float4 mk = *reinterpret_cast<const float4*>(a.mask.p + pb_mask + q_mask[v]);
+                        r4.x = mk.x > 0.f ? r4.x : 0.f; r4.y = mk.y > 0.f ? r4.y : 0.f;
+                        r4.z = mk.z > 0.f ? r4.z : 0.f; r4.w = mk.w > 0.f ? r4.w : 0.f;
+                    }
+                    float4* dst = reinterpret_cast<float4*>(a.out.p + pb_out + q_out[v]);
+                    if (a.accumulate) {
+                        const float4 old = *dst;
+                        r4.x += old.x; r4.y += old.y; r4.z += old.z; r4.w += old.w;
+                    }
+                    *dst = r4;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int E, int NT>
+void launch_stream(hipStream_t s, StreamParams& sp, int N) {
+    constexpr int G = (E % 4 == 0) ? 4 : 2;
+    constexpr int P = 4 * E + G;
+    constexpr int HPIX = (16 + KS - 1) * (16 + KS - 1);
+    constexpr size_t lds = (size_t)HPIX * P * sizeof(float);
+    ConvParams& p = sp.c;
+    p.tiles_x = cdiv(p.W, 16);
+    p.tiles_y = cdiv(p.H, 16);
+    p.m_txy[0] = div_magic(p.tiles_x);
+    p.m_txy[1] = div_magic(p.tiles_y);
+    sp.ntiles = p.tiles_x * p.tiles_y * N;
+    sp.nblk = cdiv(p.Cout, 16 * NT);
+    sp.m_nblk = div_magic(sp.nblk);
+    sp.per_xcd = cdiv(sp.ntiles, 8);
+    auto kern = conv_stream_kernel<KS, E, NT>;
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    });
+    const unsigned grid = (unsigned)(8 * sp.per_xcd * sp.nblk);
+    const double px = (double)N * p.H * p.W;
+    ProfScope ps(s, "conv_stream<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + ">",
+                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sp);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int KS, int E>
+void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
+    switch (NT) {
+        case 1: launch_stream<KS, E, 1>(s, sp, N); break;
+        case 2: launch_stream<KS, E, 2>(s, sp, N); break;
+        case 3: launch_stream<KS, E, 3>(s, sp, N); break;
+        default: launch_stream<KS, E, 4>(s, sp, N); break;
+    }
+}
+
+}  // namespace
+
+bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
+                           const ConvEpilogue& ep) {
+    if (KS != 3) return false;
+    if (in.C < 16 || (long)in.H * in.W < 256) return false;
+    if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
+    if ((((uintptr_t)ep.bias) & 15) != 0) return false;
+    if ((long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N >= (1l << 20)) return false;          // fast_div range
+    // cout tiling: NT accumulator tiles per wave, lanes own NT consecutive couts -> needs Cout % NT == 0
+    int NT = 0;
+    long best = -1;
+    for (int nt = 1; nt <= 4; ++nt) {
+        if (out.C % nt) continue;
+        const long padded = (long)cdiv(out.C, 16 * nt) * 16 * nt;
+        if (best < 0 || padded < best || (padded == best && nt > NT)) { best = padded; NT = nt; }
+    }
+    if (out.C < NT) return false;
+    // channel chunk: E = CK/4 in {4, 6, 8, 10, 12}, least padded K, then the largest chunk
+    int E = 0;
+    long bestk = -1;
+    for (int e = 4; e <= 12; e += 2) {
+        const long padded = (long)cdiv(in.C, 4 * e) * 4 * e;
+        if (bestk < 0 || padded < bestk || (padded == bestk && e > E)) { bestk = padded; E = e; }
+    }
+    StreamParams sp;
+    ConvParams& p = sp.c;
+    p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
+    p.w = w; p.bias = ep.bias;
+    p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
+    p.relu = ep.relu; p.accumulate = ep.accumulate;
+    p.wvec = 0; p.dbg = 0; p.CK = 4 * E; p.TPS = 0;
+    switch (E) {
+        case 4: dispatch_nt<3, 4>(s, sp, in.N, NT); break;
+        case 6: dispatch_nt<3, 6>(s, sp, in.N, NT); break;
+        case 8: dispatch_nt<3, 8>(s, sp, in.N, NT); break;
+        case 10: dispatch_nt<3, 10>(s, sp, in.N, NT); break;
+        default: dispatch_nt<3, 12>(s, sp, in.N, NT); break;
+    }
+    return true;
+}

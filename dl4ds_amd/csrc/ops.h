@@ -29,6 +29,9 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
 // 3x3 wgrad with Cin <= 8, Cout <= 16 (two taps per MFMA tile); same slab protocol as the direct path
 int conv2d_narrow_wgrad_slabs(const TView& x, const TView& dz, int KS);
 int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int max_slabs);
+// 3x3, Cin >= 16: filter streamed from L2 into the MFMA operands, no barriers in the K loop (conv_stream.hip)
+bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
+                           const ConvEpilogue& ep);
 int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS);
 // writes at most `slabs` partial slabs (the workspace bound); returns how many it wrote
 int conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs);

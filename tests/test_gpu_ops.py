@@ -45,6 +45,9 @@ CONV_CASES = [
     # register-resident-filter MFMA path (conv_narrow.hip): Cin, Cout <= 16, Cin % 4 == 0
     (2, 40, 35, 8, 8, 3), (1, 33, 20, 16, 12, 3), (2, 70, 18, 4, 16, 3), (1, 64, 64, 12, 8, 3), (1, 5, 3, 8, 16, 3),
     (6, 32, 16, 16, 16, 3),
+    # streamed-filter MFMA path (conv_stream.hip): Cin >= 16, Cin % 4 == 0, Cout % 4 == 0, H*W >= 256
+    (1, 16, 16, 48, 48, 3), (2, 20, 33, 48, 192, 3), (1, 16, 16, 192, 48, 3), (1, 17, 19, 24, 32, 3),
+    (1, 18, 16, 32, 64, 3), (1, 16, 17, 64, 24, 3), (1, 16, 16, 96, 40, 3), (2, 32, 32, 40, 40, 3), (1, 16, 16, 20, 36, 3),
 ]
 
 
@@ -55,8 +58,9 @@ def test_conv2d_forward(ops, n, h, w, ci, co, ks):
     close(ops.conv2d(x, wt, b), ref)
 
 
-def test_conv2d_fused_epilogues(ops):
-    n, h, w, ci, co = 2, 12, 20, 16, 24
+@pytest.mark.parametrize('h,w', [(12, 20), (16, 20)])      # 16x20: streamed-filter kernel, 12x20: LDS-staged kernel
+def test_conv2d_fused_epilogues(ops, h, w):
+    n, ci, co = 2, 16, 24
     x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
     ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
     close(ops.conv2d(x, wt, b, relu=True), np.maximum(ref, 0))
@@ -81,9 +85,10 @@ def test_conv2d_fused_epilogues_stencil_path(ops, ci, co):
     np.testing.assert_array_equal(a, ops.conv2d_wgrad(x, dz, 3))   # bitwise reproducible
 
 
-@pytest.mark.parametrize('ci,co,r', [(8, 32, 2), (48, 192, 2), (4, 50, 5), (6, 36, 3)])
-def test_conv2d_fused_depth_to_space(ops, ci, co, r):
-    x, wt, b = R(2, 10, 18, ci), R(3, 3, ci, co) * 0.2, R(co)
+@pytest.mark.parametrize('ci,co,r,h', [(8, 32, 2, 10), (48, 192, 2, 10), (4, 50, 5, 10), (6, 36, 3, 10), (48, 192, 2, 16),
+                                        (16, 100, 5, 20), (32, 72, 3, 16)])
+def test_conv2d_fused_depth_to_space(ops, ci, co, r, h):
+    x, wt, b = R(2, h, 18, ci), R(3, 3, ci, co) * 0.2, R(co)
     ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
     close(ops.conv2d(x, wt, b, d2s=r), ref)
 
@@ -106,8 +111,9 @@ def test_conv2d_dgrad_wgrad(ops, n, h, w, ci, co, ks):
     close(ops.conv2d_wgrad(x, dz, ks), gw)
 
 
-def test_conv2d_grads_through_d2s_and_accumulate(ops):
-    n, h, w, ci, co, r = 2, 9, 17, 48, 192, 2
+@pytest.mark.parametrize('h,w', [(9, 17), (16, 20)])        # 16x20: dgrad through the streamed-filter kernel
+def test_conv2d_grads_through_d2s_and_accumulate(ops, h, w):
+    n, ci, co, r = 2, 48, 192, 2
     x, wt = R(n, h, w, ci), R(3, 3, ci, co) * 0.2
     dz = R(n, h * r, w * r, co // (r * r))
     gx, gw = _torch_conv_grads(x, wt, dz, d2s=r)
