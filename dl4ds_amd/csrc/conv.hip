@@ -826,6 +826,186 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
     }
 }
 
+// Row-walking variant of the 3x3 weight gradient (all layers except the small-channel prefetch variants).
+// The k-slot of an MFMA is mapped to pixel column q + 4*slot of a 16-pixel row segment (q = 0..3) instead of 4q + slot.
+// With that mapping the x fragment of (quad q, tap column kx) is the fragment of column group c = q + kx, so ONE input
+// row needs 6 fragment reads per cin tile (c = 0..5) for its 4 quads x 3 tap columns, and it is used by the three
+// output rows it feeds (ky = 0..2); a dz row fragment is read once and kept for three input rows.  22 LDS reads per 108
+// MFMAs (CIT = 3) instead of 28 per 27: the general kernel above was LDS-read bound, this one is MFMA bound.  All LDS
+// addresses are immediates off two per-lane bases; pitches are 4 mod 8 floats so the four k-slots of a fragment read
+// (4 pixels apart) fall on two disjoint bank halves.
+template <int CIT, int WCO>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradParams a) {
+    constexpr int KS = 3, COT = 1;
+    constexpr int TW = 16, TH = 8;
+    constexpr int WK = 4 / WCO, RW = TH / WK;            // output rows per wave
+    constexpr int PAD = 1;
+    constexpr int TWH = TW + 2, THH = TH + 2, HPIX = TWH * THH;
+    constexpr int KK = 9;
+    constexpr int CIB = 16 * CIT, COB = 16 * WCO;
+    constexpr int PX = CIB + 4, PZ = COB + 4;
+    constexpr int NPIX = TW * TH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* x_tile = smem;                       // [HPIX][PX]
+    float* z_tile = smem + HPIX * PX;           // [NPIX][PZ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wco = wave % WCO, wk = wave / WCO;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ci0 = blockIdx.z * CIB;
+    const int co0 = blockIdx.y * COB;
+
+    f32x4 acc[KK][CIT][COT];
+    float bsum[COT];
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) acc[t][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bsum[0] = 0.f;
+
+    const float* xf = x_tile + ((wk * RW) * TWH + lq * 4) * PX + l15;
+    const float* zf = z_tile + ((wk * RW) * TW + lq * 4) * PZ + wco * 16 + l15;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int n = t / a.tiles_y;
+        const int x0 = tx * TW, y0 = ty * TH;
+        __syncthreads();
+        staged_copy<4, 256>(
+            HPIX * (CIB / 4), tid,
+            [&](int idx, bool ok) {
+                const int pix = idx / (CIB / 4);
+                const int q = idx - pix * (CIB / 4);
+                const int r = pix / TWH, c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                return view_load4_raw(a.x, n, gy, gx, ci0 + q * 4,
+                                      ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin);
+            },
+            [&](int idx) {
+                const int pix = idx / (CIB / 4);
+                const int q = idx - pix * (CIB / 4);
+                const int r = pix / TWH, c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                return valid4(ci0 + q * 4, a.Cin, gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);
+            },
+            [&](int idx, float4 v) {
+                const int pix = idx / (CIB / 4);
+                const int q = idx - pix * (CIB / 4);
+                *reinterpret_cast<float4*>(x_tile + pix * PX + q * 4) = v;
+            });
+        staged_copy<4, 256>(
+            NPIX * (COB / 4), tid,
+            [&](int idx, bool ok) {
+                const int pix = idx / (COB / 4);
+                const int q = idx - pix * (COB / 4);
+                const int r = pix / TW, c = pix - r * TW;
+                const int gy = y0 + r, gx = x0 + c;
+                return view_load4_raw(a.dz, n, gy, gx, co0 + q * 4, ok && gy < a.H && gx < a.W && co0 + q * 4 < a.Cout);
+            },
+            [&](int idx) {
+                const int pix = idx / (COB / 4);
+                const int q = idx - pix * (COB / 4);
+                const int r = pix / TW, c = pix - r * TW;
+                return valid4(co0 + q * 4, a.Cout, y0 + r < a.H && x0 + c < a.W);
+            },
+            [&](int idx, float4 v) {
+                const int pix = idx / (COB / 4);
+                const int q = idx - pix * (COB / 4);
+                *reinterpret_cast<float4*>(z_tile + pix * PZ + q * 4) = v;
+            });
+        __syncthreads();
+
+        float zr[3][4];                 // dz fragments of the last three output rows (ring)
+#pragma unroll
+        for (int rr = 0; rr < RW + 2; ++rr) {          // input row wk*RW + rr of the halo tile
+            float fx[6][CIT];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) fx[c][i] = xf[(rr * TWH + c) * PX + i * 16];
+            if (rr < RW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zr[rr % 3][q] = zf[(rr * TW + q) * PZ];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (rr < RW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bsum[0] += zr[rr % 3][q];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int r = rr - ky;                  // output row fed through taps (ky, *)
+                if (r >= 0 && r < RW) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int i = 0; i < CIT; ++i)
+                                acc[ky * 3 + kx][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q + kx][i], zr[r % 3][q],
+                                                                                              acc[ky * 3 + kx][i][0], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // K-split waves: pairwise tree reduction through LDS so the block emits ONE slab
+    if (WK > 1) {
+        constexpr int SLOTF = (KK * CIT * COT * 4 + COT) * 64;      // floats per wave image
+        for (int half = WK / 2; half >= 1; half >>= 1) {
+            __syncthreads();
+            if (wk >= half && wk < 2 * half) {
+                float* dst = smem + (size_t)((wk - half) * WCO + wco) * SLOTF + lane;
+                int o = 0;
+#pragma unroll
+                for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) { dst[o * 64] = acc[tp][i][0][rg]; ++o; }
+                dst[o * 64] = bsum[0];
+            }
+            __syncthreads();
+            if (wk < half) {
+                const float* src = smem + (size_t)(wk * WCO + wco) * SLOTF + lane;
+                int o = 0;
+#pragma unroll
+                for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) { acc[tp][i][0][rg] += src[o * 64]; ++o; }
+                bsum[0] += src[o * 64];
+            }
+        }
+        if (wk != 0) return;
+    }
+    // write the partial slab: D row = ci (lq*4+reg), col = co (l15)
+    const size_t nw = (size_t)KK * a.Cin * a.Cout;
+    float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
+    const int co = co0 + wco * 16 + l15;
+#pragma unroll
+    for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ci = ci0 + i * 16 + lq * 4 + rg;
+                if (co < a.Cout && ci < a.Cin) slab[((size_t)tp * a.Cin + ci) * a.Cout + co] = acc[tp][i][0][rg];
+            }
+        }
+    if (blockIdx.z == 0) {
+        float v = bsum[0];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lq == 0 && co < a.Cout) slab[nw + co] = v;
+    }
+}
+
 // out0[e] (+)= sum_k partial[k*n + e] for e < n0 ; out1[e-n0] likewise for e >= n0.
 // One block reduces 16 consecutive elements: thread = (slab sub-index 0..15, element 0..15) -> 64-byte row
 // segments per slab, 16 slabs in flight per block, fixed summation order (deterministic).
@@ -891,18 +1071,29 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     constexpr int PZ = (COB % 32 == 16) ? COB : COB + 16;
     constexpr int WK = 4 / WCO;
     constexpr size_t red_bytes = (size_t)(WK / 2) * WCO * (KS * KS * CIT * COT * 4 + COT) * 64 * sizeof(float);
-    const size_t lds = std::max((size_t)(PF ? 2 : 1) * (HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
-    auto kern = conv_wgrad_kernel<KS, CIT, COT, WCO, PF>;
+    // 3x3 layers beyond the small-channel prefetch variants: row-walking kernel (MFMA bound instead of LDS-read bound)
+    static const bool no_rows = getenv("DL4DS_NO_WGRAD_ROWS") != nullptr;
+    constexpr bool ROWS_OK = (KS == 3) && !PF && COT == 1;
+    const bool rows = ROWS_OK && !no_rows;
+    const size_t lds = rows ? std::max((size_t)(HPIX * (CIB + 4) + 128 * (COB + 4)) * sizeof(float), red_bytes)
+                            : std::max((size_t)(PF ? 2 : 1) * (HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
+    void (*kern)(const WgradParams) = conv_wgrad_kernel<KS, CIT, COT, WCO, PF>;
+    if constexpr (ROWS_OK) {
+        if (rows) kern = conv_wgrad_rows_kernel<CIT, WCO>;
+    }
     static std::once_flag once;
     std::call_once(once, [&]() {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, CIT, COT, WCO, PF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        if constexpr (ROWS_OK)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<CIT, WCO>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     });
     DL4DS_REQUIRE(lds <= (size_t)kLdsBudget, "wgrad tile does not fit in LDS");
     dim3 grid((unsigned)pl.S, (unsigned)cdiv(p.Cout, COB), (unsigned)cdiv(p.Cin, CIB));
     const double px = (double)p.x.N * p.H * p.W;
-    ProfScope ps(s, "conv_wgrad<" + std::to_string(KS) + "," + std::to_string(CIT) + "," + std::to_string(COT) + "," +
-                        std::to_string(WCO) + ">",
+    ProfScope ps(s, std::string(rows ? "conv_wgrad_rows<" : "conv_wgrad<") + std::to_string(KS) + "," + std::to_string(CIT) +
+                        "," + std::to_string(COT) + "," + std::to_string(WCO) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     HIP_CHECK(hipGetLastError());
