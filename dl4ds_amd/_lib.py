@@ -9,7 +9,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdl4ds_hip.so')
+# DL4DS_HIP_LIB: alternative build of the same library (kernel-variant experiments, tools/variant_build.sh)
+LIB_PATH = os.environ.get('DL4DS_HIP_LIB') or os.path.join(_HERE, 'libdl4ds_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dl4ds_hip.h')
 
 

@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
         } else {
         __syncthreads();
         // stage x halo tile (channels ci0 .. ci0+CIB)
-        staged_copy<4, 256>(
+        staged_copy<(KS == 1 && WCO == 1 ? 8 : 4), 256>(
             HPIX * (CIB / 4), tid,
             [&](int idx, bool ok) {
                 const int pix = idx / (CIB / 4);
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
                 *reinterpret_cast<float4*>(x_tile + pix * PX + q * 4) = v;
             });
         // stage dz tile (channels co0 .. co0+COB); zero outside the image so padded pixels add nothing
-        staged_copy<4, 256>(
+        staged_copy<(KS == 1 && WCO == 1 ? 8 : 4), 256>(
             NPIX * (COB / 4), tid,
             [&](int idx, bool ok) {
                 const int pix = idx / (COB / 4);

@@ -45,19 +45,28 @@ struct StreamParams {
     unsigned m_nblk;
 };
 
+#ifndef STREAM_MT
+#define STREAM_MT 4
+#endif
+constexpr int kStreamMT = STREAM_MT;                 // accumulator rows (of 16 pixels) per wave
+constexpr int kStreamThreads = 64 * (16 / kStreamMT);
+
 template <int KS, int E, int NT>
-__global__ void __launch_bounds__(256, 2) conv_stream_kernel(const StreamParams sp) {
+__global__ void __launch_bounds__(kStreamThreads, kStreamMT == 4 ? 2 : 4) conv_stream_kernel(const StreamParams sp) {
     const ConvParams& a = sp.c;
     constexpr int G = (E % 4 == 0) ? 4 : 2;          // k-steps fed by one LDS read
     constexpr int NGRP = E / G;
     constexpr int CK = 4 * E;                        // input channels per chunk
     constexpr int P = CK + G;                        // LDS pixel pitch: P/G odd -> conflict-free b128 / b64 reads
-    constexpr int TW = 16, TH = 16, MT = 4, PAD = KS / 2;
+    constexpr int TW = 16, TH = 16, MT = kStreamMT, NTHR = kStreamThreads, PAD = KS / 2;
     constexpr int TWH = TW + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
     constexpr int KK = KS * KS, NGS = KK * NGRP;     // group-steps per chunk
     constexpr int Q4 = CK / 4;
-    constexpr int TOTAL = HPIX * Q4, ITERS = (TOTAL + 255) / 256;
-    constexpr int WPD = 2;                           // filter prefetch distance in group-steps
+    constexpr int TOTAL = HPIX * Q4, ITERS = (TOTAL + NTHR - 1) / NTHR;
+#ifndef STREAM_WPD
+#define STREAM_WPD 2
+#endif
+    constexpr int WPD = STREAM_WPD;                  // filter prefetch distance in group-steps
     typedef typename WVec<NT>::T wvec_t;
     extern __shared__ __attribute__((aligned(16))) float tile[];
 
@@ -100,17 +109,21 @@ __global__ void __launch_bounds__(256, 2) conv_stream_kernel(const StreamParams 
             unsigned m[ITERS];
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) {
-                const int e = tid + u * 256;
+                const int e = tid + u * NTHR;
                 const int pix = e / Q4, c4 = e - pix * Q4;
                 const int hy = pix / TWH, hx = pix - hy * TWH;
                 const int gy = y0 - PAD + hy, gx = x0 - PAD + hx;
                 const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#ifdef STREAM_ABL_NO_STAGE
+                r[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
                 r[u] = view_load4_raw(a.in, n, gy, gx, c0 + c4 * 4, ok && c0 + c4 * 4 < a.Cin);
+#endif
                 m[u] = valid4(c0 + c4 * 4, a.Cin, ok);
             }
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) {
-                const int e = tid + u * 256;
+                const int e = tid + u * NTHR;
                 if (e < TOTAL) {
                     const int pix = e / Q4, c4 = e - pix * Q4;
                     const float4 v = mask4(r[u], m[u]);
@@ -134,6 +147,9 @@ __global__ void __launch_bounds__(256, 2) conv_stream_kernel(const StreamParams 
 #pragma unroll
             for (int s = 0; s < G; ++s) {
                 int row = tap * a.Cin + row_lane + g * G + s;
+#ifdef STREAM_ABL_NO_W
+                row = row_lane + s;
+#endif
                 if (tap == KK - 1) row = min(row, last_row);
                 dst[s] = *reinterpret_cast<const wvec_t*>(wlane + (size_t)row * a.Cout);
             }
@@ -164,6 +180,9 @@ __global__ void __launch_bounds__(256, 2) conv_stream_kernel(const StreamParams 
             if (gs + WPD < NGS) load_w(gs + WPD, wv[(gs + WPD) % (WPD + 1)]);
             if (gs + 1 < NGS) load_a(gs + 1, av[(gs + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef STREAM_SETPRIO
+            __builtin_amdgcn_s_setprio(STREAM_SETPRIO);
+#endif
 #pragma unroll
             for (int s = 0; s < G; ++s)
 #pragma unroll
@@ -176,6 +195,12 @@ __global__ void __launch_bounds__(256, 2) conv_stream_kernel(const StreamParams 
         }
     }
 
+#ifdef STREAM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef STREAM_ABL_NO_EPI
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     // ---- epilogue: lane (pixel column l15, k-slot lq) owns couts n0 + 4*NT*lq + [0, 4*NT) of rows wave*4 + i
     const int gx = x0 + l15;
     const int cb = n0 + 4 * NT * lq;
@@ -254,7 +279,7 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_stream<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sp);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kStreamThreads), lds, s, sp);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -272,7 +297,7 @@ void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
 
 bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep) {
-    if (KS != 3) return false;
+    if (KS != 3 && KS != 1) return false;
     if (in.C < 16 || (long)in.H * in.W < 256) return false;
     if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
     if ((((uintptr_t)ep.bias) & 15) != 0) return false;
@@ -300,12 +325,23 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.dbg = 0; p.CK = 4 * E; p.TPS = 0;
-    switch (E) {
-        case 4: dispatch_nt<3, 4>(s, sp, in.N, NT); break;
-        case 6: dispatch_nt<3, 6>(s, sp, in.N, NT); break;
-        case 8: dispatch_nt<3, 8>(s, sp, in.N, NT); break;
-        case 10: dispatch_nt<3, 10>(s, sp, in.N, NT); break;
-        default: dispatch_nt<3, 12>(s, sp, in.N, NT); break;
+    if (KS == 3) {
+        switch (E) {
+            case 4: dispatch_nt<3, 4>(s, sp, in.N, NT); break;
+            case 6: dispatch_nt<3, 6>(s, sp, in.N, NT); break;
+            case 8: dispatch_nt<3, 8>(s, sp, in.N, NT); break;
+            case 10: dispatch_nt<3, 10>(s, sp, in.N, NT); break;
+            default: dispatch_nt<3, 12>(s, sp, in.N, NT); break;
+        }
+    } else {
+        // 1x1 layers are HBM streaming: what matters is that a block's whole tile is in flight at once
+        switch (E) {
+            case 4: dispatch_nt<1, 4>(s, sp, in.N, NT); break;
+            case 6: dispatch_nt<1, 6>(s, sp, in.N, NT); break;
+            case 8: dispatch_nt<1, 8>(s, sp, in.N, NT); break;
+            case 10: dispatch_nt<1, 10>(s, sp, in.N, NT); break;
+            default: dispatch_nt<1, 12>(s, sp, in.N, NT); break;
+        }
     }
     return true;
 }
