@@ -76,17 +76,39 @@ SUP_CASES = [
 ]
 
 
+def tie_free_inputs(kind, P, ocfg, xs, ss, first_seed=5):
+    """Seeded inputs for which no ReLU input of the fp64 oracle lies within 3e-7 (relative, ~ fp32 rounding of a K-term sum) of zero.  Such a value
+    (seen: |pre| = 5e-8 at scale 0.7 for seed 5 on net_pin) takes either branch depending on fp32 summation order, so
+    the comparison would test the tie and not the kernels.  Returns (rng, x, s, oracle forward)."""
+    orig = N.relu
+    for seed in range(first_seed, first_seed + 20):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal(xs).astype(np.float32)
+        s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
+        margins = []
+
+        def spy(v):
+            a = np.abs(v)
+            margins.append(a.min() / max(a.max(), 1e-30))
+            return orig(v)
+        N.relu = spy
+        try:
+            ref = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), **ocfg)
+        finally:
+            N.relu = orig
+        if not margins or min(margins) > 3e-7:
+            return rng, x, s, ref
+    raise AssertionError('no tie-free seed found')
+
+
 @pytest.mark.parametrize('kind,cfg,xs,ss', SUP_CASES)
 @pytest.mark.parametrize('loss', ['mae', 'mse'])
 def test_supervised_forward_grads_and_adam_step(kind, cfg, xs, ss, loss):
     from dl4ds_amd.training import SupervisedEngine
     model, P, ocfg = build_pair(kind, cfg, xs, ss)
-    rng = np.random.default_rng(5)
-    x = rng.standard_normal(xs).astype(np.float32)
-    s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
+    rng, x, s, ref = tie_free_inputs(kind, P, ocfg, xs, ss)
     inputs = [x] if s is None else [x, s]
     # forward
-    ref = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), **ocfg)
     out = model(inputs)
     assert out.shape == ref.shape
     assert rel(out, ref) < 1e-3
@@ -101,9 +123,19 @@ def test_supervised_forward_grads_and_adam_step(kind, cfg, xs, ss, loss):
     l_hip, g_hip = eng.loss_and_grads(inputs, y)
     assert l_hip == pytest.approx(lv, rel=1e-4)
     gscale = max(float(g.abs().max()) for g in grads.values())
+    steady = {}
     for k in grads:
-        err = np.abs(g_hip[k] - grads[k].numpy()).max() / gscale
+        gr = grads[k].numpy()
+        err = np.abs(g_hip[k] - gr).max() / gscale
         assert err < 1e-3, (k, err)
+        # Elements whose gradient already differs by > 1 % of its own size: a pre-activation within fp32 rounding of 0
+        # takes the other ReLU branch in the fp64 oracle (seen: |pre| = 5e-8 at scale 0.7), which moves a handful of
+        # small gradient entries.  Adam divides by |g|, so those entries may move by a whole step; they are excluded
+        # from the update comparison below (and must stay a small minority).
+        steady[k] = np.abs(g_hip[k] - gr) <= 0.01 * (np.abs(gr) + 1e-3 * np.abs(gr).max())
+    n_all = sum(m.size for m in steady.values())
+    n_unsteady = sum(int((~m).sum()) for m in steady.values())
+    assert n_unsteady <= 0.02 * n_all, (n_unsteady, n_all)
     # three optimiser steps
     w0 = model.get_weights()
     for it in range(3):
@@ -117,7 +149,9 @@ def test_supervised_forward_grads_and_adam_step(kind, cfg, xs, ss, loss):
         upd_ref = PT[k].detach().numpy() - w0[k]
         upd = w[k] - w0[k]
         # Adam's first steps are ~lr*sign(g): compare the updates at 3 steps * lr scale
-        assert np.abs(upd - upd_ref).max() < 0.15 * 3e-3 + 1e-6, k
+        dev = np.abs(upd - upd_ref)
+        assert dev[steady[k]].max(initial=0.0) < 0.15 * 3e-3 + 1e-6, k
+        assert dev.max() < 3.3e-3, k              # never more than the three steps themselves
     m, v, step = eng.optimizer_state()
     assert step == 3
 

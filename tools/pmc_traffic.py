@@ -21,7 +21,9 @@ for k in fetch:
     args = m.group(2).replace(' ', '').split(',') if m else []
     if m and 'igemm_db' in m.group(1):
         args = args[:5]                      # bench.py's tag carries <KS,MT,NT,WM,WN> only
-    if m and 'wgrad' in m.group(1):
+    if m and m.group(1).startswith('conv_wgrad_rows'):
+        args = ['3', args[0], '1', args[1]]  # kernel <CIT,WCO> -> bench.py's tag <KS,CIT,COT,WCO>
+    elif m and m.group(1).startswith('conv_wgrad_kernel'):
         args = args[:4]                      # ... and <KS,CIT,COT,WCO> for wgrad (drop the prefetch flag)
     tag = (m.group(1).replace('_kernel', '') + '<' + ','.join(args) + '>') if m else k[:60]
     f = sum(fetch[k]) / len(fetch[k])
