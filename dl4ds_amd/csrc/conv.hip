@@ -501,6 +501,25 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
         long wk = (long)cdiv(p.Cout, bn) * bn;
         if (bestw < 0 || wk < bestw) { bestw = wk; best = bn; }
     }
+    // few pixels, many channels (deep U-Net / deconvolution levels): the grid is tiles x n-blocks, so take the widest
+    // cout tile that still gives every CU a block (and at most 1.5x the minimal padded work)
+    {
+        auto blocks_for = [&](int bn) {
+            const int th = (bn >= 96) ? 8 : 16;
+            return (long)cdiv(p.W, 16) * cdiv(p.H, th) * N * cdiv(p.Cout, bn);
+        };
+        if (blocks_for(best) < 256) {
+            int pick = best;
+            for (int bn : bns) {
+                if (bn >= pick) continue;
+                const long wk = (long)cdiv(p.Cout, bn) * bn;
+                if (wk * 2 > bestw * 3) continue;
+                pick = bn;
+                if (blocks_for(bn) >= 256) break;
+            }
+            best = pick;
+        }
+    }
     // MFMA-bound layers: double-buffered kernel (8 waves for wide Cout, 4 waves x two workgroups per CU otherwise)
     const bool db_ok = p.Cin >= 16 && (long)p.H * p.W >= 256;
     if (db_ok) {

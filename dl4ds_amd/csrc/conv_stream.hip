@@ -311,6 +311,16 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
         if (best < 0 || padded < best || (padded == best && nt > NT)) { best = padded; NT = nt; }
     }
     if (out.C < NT) return false;
+    // few pixels, many channels (deep U-Net levels: 256->256 at 8x8): the grid is tiles x n-blocks, so narrower
+    // n-blocks are the only parallelism there is; each block then streams its own slice of the filter
+    {
+        const long ntiles = (long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N;
+        while (NT > 1 && ntiles * cdiv(out.C, 16 * NT) < 512) {
+            int nt = NT - 1;
+            while (nt > 1 && out.C % nt) --nt;
+            NT = nt;
+        }
+    }
     // channel chunk: E = CK/4 in {4, 6, 8, 10, 12}, least padded K, then the largest chunk
     int E = 0;
     long bestk = -1;
