@@ -13,7 +13,8 @@
 // ---- internal functions defined in other translation units
 Trainer* trainer_create(Graph* g, int loss_kind, const AdamCfg& cfg);
 void graph_load_inputs(Graph& g, const float* const* inputs, int n_inputs, int B, bool is_host);
-void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host);
+void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host,
+                            bool reduce_across_ranks);
 void trainer_step(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host, float* loss_host);
 struct CganTrainer;
 CganTrainer* cgan_create(Graph* gen, Graph* disc, int px_loss_kind, float lr, float beta1, float lam);
@@ -542,7 +543,7 @@ int dl4ds_trainer_loss_and_grads(dl4ds_trainer* tr, const float* const* inputs, 
                                  int B, int is_host, float* loss_host) {
     API_BEGIN
     DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
-    trainer_loss_and_grads(*tr->t, inputs, n_inputs, y_true, B, is_host != 0);
+    trainer_loss_and_grads(*tr->t, inputs, n_inputs, y_true, B, is_host != 0, false);    // this rank's gradients
     if (loss_host) {
         HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
         HIP_CHECK(hipStreamSynchronize(S()));

@@ -4,8 +4,11 @@
 // cgan.py:633-637 (broadcast of variables and optimiser slots from rank 0), cgan.py:608-611.
 //
 // xGMI is point-to-point (7 links x ~153 GB/s per GPU); the gradient arena of the headline model is 0.82 MB,
-// i.e. latency-bound, so the whole arena goes out as ONE ncclAllReduce on the side stream; the 1/world average
-// is folded into the Adam kernel (adam.hip).
+// i.e. latency-bound.  The supervised trainer sends the arena as a few buckets (Graph::plan_buckets), each launched
+// on the side stream the moment the backward pass has finished the ops that own it -- the tail of the network
+// first -- so the collectives run under the remaining backward kernels (Horovod's DistributedOptimizer does the same
+// with its fusion buffer); the CGAN trainer, whose discriminator is back-propagated twice, sends each arena once.
+// The 1/world average is folded into the Adam kernel (adam.hip).
 #include "dist.h"
 #include "runtime.h"
 #include <rccl/rccl.h>
@@ -14,7 +17,7 @@
 namespace {
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_world = 1;
-hipEvent_t g_ev_ready = nullptr, g_ev_done = nullptr;
+hipEvent_t g_ev_ready = nullptr, g_ev_ready_aux = nullptr, g_ev_done = nullptr;
 
 #define NCCL_CHECK(expr)                                                                         \
     do {                                                                                         \
@@ -42,6 +45,7 @@ void dist_init(int rank, int world, const char id128[128]) {
     g_world = world;
     HIP_CHECK(hipEventCreateWithFlags(&g_ev_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&g_ev_ready_aux, hipEventDisableTiming));
 }
 
 void dist_world(int& rank, int& world) {
@@ -56,6 +60,26 @@ void dist_allreduce_grads(float* buf, size_t n, hipStream_t stream) {
     HIP_CHECK(hipStreamWaitEvent(cs, g_ev_ready, 0));
     NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, cs));
     HIP_CHECK(hipEventRecord(g_ev_done, cs));
+    HIP_CHECK(hipStreamWaitEvent(stream, g_ev_done, 0));
+}
+
+bool dist_active() { return g_comm != nullptr; }
+
+void dist_allreduce_bucket_async(float* buf, size_t n, hipStream_t stream, hipStream_t aux) {
+    if (g_comm == nullptr || n == 0) return;
+    hipStream_t cs = rt().comm_stream;
+    HIP_CHECK(hipEventRecord(g_ev_ready, stream));
+    HIP_CHECK(hipStreamWaitEvent(cs, g_ev_ready, 0));
+    if (aux) {
+        HIP_CHECK(hipEventRecord(g_ev_ready_aux, aux));
+        HIP_CHECK(hipStreamWaitEvent(cs, g_ev_ready_aux, 0));
+    }
+    NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, cs));
+}
+
+void dist_allreduce_wait(hipStream_t stream) {
+    if (g_comm == nullptr) return;
+    HIP_CHECK(hipEventRecord(g_ev_done, rt().comm_stream));
     HIP_CHECK(hipStreamWaitEvent(stream, g_ev_done, 0));
 }
 

@@ -41,6 +41,7 @@ struct GOp {
     virtual size_t workspace_bytes(Graph& g, int B) { return 0; }
     virtual size_t saved_floats_per_sample(Graph& g) { return 0; }   // op-private saved activations
     float* saved = nullptr;
+    std::vector<int> pids;     // parameters this op reads (set by the op constructors; drives gradient bucketing)
     virtual void on_finalize(Graph& g) {}
     virtual bool set_mask(Graph& g, const float* host, size_t n) { return false; }   // dropout keep-mask injection
     const char* kind = "op";
@@ -72,6 +73,17 @@ struct Graph {
     void join_aux();            // `stream` waits for everything enqueued on aux_stream
     hipStream_t stream = nullptr;
     std::vector<float*> allocations;
+    // Gradient buckets for the data-parallel all-reduce (contiguous arena ranges in creation = forward order).
+    // Bucket k is final once the backward pass has run op `ready_op` (the first forward op using any of its
+    // parameters); Graph::backward then calls grad_ready(offset, count) -- the trainer launches that bucket's
+    // ncclAllReduce on the communication stream while the rest of the backward pass is still running.
+    struct GradBucket { size_t off = 0, n = 0; int p_lo = 0, p_hi = 0; int ready_op = -1; };
+    std::vector<GradBucket> buckets;
+    // `aux` (may be null): second stream that also wrote into the bucket (weight gradients); the collective must
+    // wait for both, the compute streams wait for neither
+    void (*grad_ready)(void* ctx, float* grads, size_t n, hipStream_t stream, hipStream_t aux) = nullptr;
+    void* grad_ready_ctx = nullptr;
+    void plan_buckets(size_t target_bytes);
 
     ~Graph();
     int add_tensor(int H, int W, int C, int nmul, bool requires_grad, bool is_input);

@@ -71,6 +71,34 @@ void Graph::finalize() {
     for (auto& op : ops) op->on_finalize(*this);
     if (wt_floats) HIP_CHECK(hipMalloc((void**)&Wt, wt_floats * sizeof(float)));
     finalized = true;
+    // the headline model's arena is 0.82 MB (latency-bound collective): a few buckets; U-Net (54 MB): ~4 MB each
+    plan_buckets(std::max<size_t>(256 << 10, n_params * sizeof(float) / 12));
+}
+
+void Graph::plan_buckets(size_t target_bytes) {
+    buckets.clear();
+    if (params.empty()) return;
+    // first forward op that reads each parameter (-1: unused -> final from the start)
+    std::vector<int> first_use(params.size(), -1);
+    for (int i = (int)ops.size() - 1; i >= 0; --i)
+        for (int pid : ops[i]->pids)
+            if (pid >= 0 && pid < (int)params.size()) first_use[pid] = i;
+    GradBucket cur;
+    cur.p_lo = 0; cur.off = params[0].offset; cur.ready_op = (int)ops.size();
+    size_t end_prev = params[0].offset;
+    for (int pid = 0; pid < (int)params.size(); ++pid) {
+        cur.ready_op = std::min(cur.ready_op, first_use[pid]);
+        const size_t end = (pid + 1 < (int)params.size()) ? params[pid + 1].offset : n_params;
+        cur.p_hi = pid + 1;
+        cur.n = end - cur.off;
+        end_prev = end;
+        if (cur.n * sizeof(float) >= target_bytes || pid + 1 == (int)params.size()) {
+            buckets.push_back(cur);
+            cur = GradBucket();
+            cur.p_lo = pid + 1; cur.off = end; cur.ready_op = (int)ops.size();
+        }
+    }
+    (void)end_prev;
 }
 
 void Graph::prepare(int B) {
@@ -128,8 +156,24 @@ void Graph::zero_grad_flags() {
 void Graph::backward(const BwdCtx& c) {
     for (auto& t : tensors) t.grad_written = false;
     for (int o : outputs) tensors[o].grad_written = true;      // seeded by the loss
-    for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i]->backward(*this, c);
+    const bool bucketed = c.param_grads && grad_ready != nullptr && !buckets.empty();
+    std::vector<char> sent(bucketed ? buckets.size() : 0, 0);
+    auto flush_ready = [&](int done_op) {          // every op with index >= done_op has run its backward
+        for (size_t k = 0; k < buckets.size(); ++k) {
+            if (sent[k] || buckets[k].ready_op < done_op) continue;
+            for (int pid = buckets[k].p_lo; pid < buckets[k].p_hi; ++pid)
+                if (!params[pid].grad_written) { fill(stream, G + params[pid].offset, params[pid].n, 0.f); params[pid].grad_written = true; }
+            // weight gradients of the bucket may still be running on the aux stream: the collective waits for it too
+            grad_ready(grad_ready_ctx, G + buckets[k].off, buckets[k].n, stream, (aux_stream && aux_used) ? aux_stream : nullptr);
+            sent[k] = 1;
+        }
+    };
+    for (int i = (int)ops.size() - 1; i >= 0; --i) {
+        ops[i]->backward(*this, c);
+        if (bucketed) flush_ready(i);
+    }
     join_aux();
+    if (bucketed) flush_ready(-1);                   // buckets of parameters no op reads
     if (c.param_grads) {
         // parameters never reached by the backward pass get an explicit zero gradient
         for (auto& p : params)
@@ -438,6 +482,7 @@ int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu
     }
     ConvOp* op = push<ConvOp>(g);
     op->in = in; op->w = w; op->b = b; op->add = add; op->out = out; op->KS = KS; op->Cout = Cout; op->relu = relu;
+    op->pids = {w, b};
     op->d2s = d2s;
     return out;
 }
@@ -450,6 +495,7 @@ int g_chatt(Graph& g, int in, int w1, int b1, int w2, int b2, int Cr, int mode5d
     const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
     ChAttOp* op = push<ChAttOp>(g);
     op->in = in; op->out = out; op->w1 = w1; op->b1 = b1; op->w2 = w2; op->b2 = b2; op->Cr = Cr; op->T5 = mode5d_T;
+    op->pids = {w1, b1, w2, b2};
     return out;
 }
 
@@ -511,6 +557,7 @@ int g_localconv(Graph& g, int in, int w, int b, int F) {
     const int out = g.add_tensor(ti.H, ti.W, F, ti.nmul, true, false);
     LocalConvOp* op = push<LocalConvOp>(g);
     op->in = in; op->out = out; op->w = w; op->b = b;
+    op->pids = {w, b};
     return out;
 }
 

@@ -225,6 +225,7 @@ int g_conv2d_transpose(Graph& g, int in, int w, int KS, int stride, int Cout, in
     const int out = g.add_tensor(ti.H * stride, ti.W * stride, Cout, ti.nmul, true, false);
     ConvTOp* op = push<ConvTOp>(g);
     op->in = in; op->w = w; op->out = out; op->KS = KS; op->stride = stride; op->Cout = Cout; op->relu = relu;
+    op->pids = {w};
     return out;
 }
 
@@ -238,6 +239,7 @@ int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, in
     const int out = g.add_tensor(ti.H, ti.W, F, T, true, false);
     ConvLSTMOp* op = push<ConvLSTMOp>(g);
     op->in = in; op->out = out; op->wk = wk; op->wr = wr; op->b = b; op->KS = KS; op->F = F; op->T = T; op->relu = relu;
+    op->pids = {wk, wr, b};
     return out;
 }
 
@@ -257,6 +259,7 @@ int g_dense(Graph& g, int in, int w, int b, int F, int act) {
     const int out = g.add_tensor(1, 1, F, ti.nmul, true, false);
     DenseOp* op = push<DenseOp>(g);
     op->in = in; op->out = out; op->w = w; op->b = b; op->F = F; op->act = act;
+    op->pids = {w, b};
     return out;
 }
 

@@ -65,7 +65,7 @@ static void ensure_loss_buffers(Trainer& t, int B) {
 
 // forward + loss + backward; gradients land in g->G (un-averaged, this rank only)
 void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B,
-                            bool is_host) {
+                            bool is_host, bool reduce_across_ranks) {
     Graph& g = *t.g;
     graph_load_inputs(g, inputs, n_inputs, B, is_host);
     ensure_loss_buffers(t, B);
@@ -80,6 +80,15 @@ void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs
     loss_forward_backward(g.stream, t.loss_kind, yt, o.data, o.grad, B * o.nmul, o.H, o.W, o.C, 1.f, t.d_loss, 0,
                           t.loss_ws, t.loss_ws_bytes);
     BwdCtx c{B, 0, B, true, false};
+    // data parallel: buckets of the gradient arena are all-reduced on the communication stream as the backward pass
+    // finishes them; trainer_step waits for the last one before Adam
+    if (reduce_across_ranks && dist_active()) {
+        g.grad_ready = [](void*, float* grads, size_t n, hipStream_t st, hipStream_t aux) {
+            dist_allreduce_bucket_async(grads, n, st, aux);
+        };
+    } else {
+        g.grad_ready = nullptr;
+    }
     g.backward(c);
 }
 
@@ -104,8 +113,8 @@ void trainer_apply_adam(Trainer& t) {
 void trainer_step(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host,
                   float* loss_host) {
     Graph& g = *t.g;
-    trainer_loss_and_grads(t, inputs, n_inputs, y_true, B, is_host);
-    dist_allreduce_grads(g.G, g.n_params, g.stream);        // no-op for world == 1
+    trainer_loss_and_grads(t, inputs, n_inputs, y_true, B, is_host, true);
+    dist_allreduce_wait(g.stream);                          // buckets were launched during the backward pass
     trainer_apply_adam(t);
     if (loss_host) {
         HIP_CHECK(hipMemcpyAsync(loss_host, t.d_loss, sizeof(float), hipMemcpyDeviceToHost, g.stream));

@@ -28,6 +28,7 @@ def init_with_id(rank, world, id_bytes):
     try:
         os.dup2(2, 1)
         st = lib.dl4ds_dist_init(int(rank), int(world), buf)
+        ctypes.CDLL(None).fflush(None)        # the banner sits in C stdio's buffer: push it out while fd 1 is stderr
     finally:
         os.dup2(saved, 1)
         os.close(saved)

@@ -50,3 +50,37 @@ def test_cgan_trainer_runs():
     assert len(t.gentotal) == 8 and np.isfinite(t.gentotal).all() and np.isfinite(t.disc).all()
     assert t.generator.name == 'unet_pin'
     assert all(abs(a - (b + 100 * c)) < 1e-3 * abs(a) for a, b, c in zip(t.gentotal, t.gengan, t.genpxloss))
+
+
+def test_bucketed_rccl_allreduce_single_rank_matches_local_step():
+    """The data-parallel step (gradient buckets all-reduced on the communication stream while the backward pass is
+    still running, 1/world folded into Adam) on a 1-rank RCCL communicator must reproduce the plain step bit for bit:
+    sum over one rank and 1/1 are exact.  Run in a child process so the communicator does not leak into other tests."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import dl4ds_amd.models as PM
+        from dl4ds_amd.training import SupervisedEngine
+        from dl4ds_amd import parallel
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal((2, 16, 16, 1)).astype(np.float32)
+        y = rng.standard_normal((2, 64, 64, 1)).astype(np.float32)
+        def run(dist):
+            m = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (16, 16), n_blocks=3, seed=5)
+            e = SupervisedEngine(m, loss='mae', learning_rate=1e-3)
+            if dist:
+                parallel.broadcast_trainer(e)
+            losses = [e.step([x], y) for _ in range(3)]
+            return losses, m.get_weights()
+        l0, w0 = run(False)
+        parallel.init_with_id(0, 1, parallel.unique_id())
+        l1, w1 = run(True)
+        parallel.finalize()
+        assert l0 == l1, (l0, l1)
+        for k in w0:
+            np.testing.assert_array_equal(w0[k], w1[k], err_msg=k)
+        print('BUCKETS-OK')
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert 'BUCKETS-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
