@@ -1,5 +1,6 @@
 // Graph runtime + op implementations (forward and hand-written backward) -- see graph.h.
 #include "graph.h"
+#include <cstdlib>
 #include "prof.h"
 #include <algorithm>
 #include <cstring>
@@ -193,7 +194,15 @@ struct ConvOp : GOp {
     int in, w, b, add, out, KS, Cout, relu, d2s;
     size_t wt_off = 0;
     ConvOp() { kind = "conv2d"; }
-    void on_finalize(Graph& g) override { wt_off = g.reserve_wt(g.params[w].n); }
+    void on_finalize(Graph& g) override {
+        wt_off = g.reserve_wt(g.params[w].n);
+        // ReLU backward fused into the consumers' dgrad stores when every consumer is a Conv2D reading this tensor
+        // as its convolved input (DL4DS_NO_MASK_FUSION=1 keeps the separate pass, for A/B measurements)
+        GTensor& t = g.tensors[out];
+        bool is_output = false;
+        for (int o : g.outputs) is_output |= (o == out);
+        t.grad_masked = relu && !is_output && t.n_conv_in >= 1 && t.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
+    }
     TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
         const GTensor& ti = g.tensors[in];
         const GTensor& to = g.tensors[out];
@@ -217,7 +226,7 @@ struct ConvOp : GOp {
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;      // nothing flowed into this op
         TView dY = out_view(g, true, c.B, c.b_off, c.b_cnt);
-        if (relu) {      // dZ = dY * [y > 0], in place (every consumer of y has already contributed to dY)
+        if (relu && !g.tensors[out].grad_masked) {      // dZ = dY * [y > 0], in place (every consumer of y has contributed)
             bias_act_backward(g.stream, dY, out_view(g, false, c.B, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace,
                               g.workspace_bytes);
         }
@@ -244,6 +253,8 @@ struct ConvOp : GOp {
             conv2d_dgrad_weights(g.stream, g.wp(w), wt, KS, g.tensors[in].C, Cout);
             ConvEpilogue ep;
             ep.accumulate = g.tensors[in].grad_written;
+            // the producer's ReLU backward rides on this store (saves a read-modify-write pass over the gradient)
+            if (g.tensors[in].grad_masked) ep.mask = g.view(in, c.B, false, c.b_off, c.b_cnt);
             conv2d_forward(g.stream, dY, wt, KS, g.view(in, c.B, true, c.b_off, c.b_cnt), ep);
             g.tensors[in].grad_written = true;
         }
@@ -483,6 +494,8 @@ int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu
     ConvOp* op = push<ConvOp>(g);
     op->in = in; op->w = w; op->b = b; op->add = add; op->out = out; op->KS = KS; op->Cout = Cout; op->relu = relu;
     op->pids = {w, b};
+    g.tensors[in].n_conv_in++;
+    if (add >= 0) g.tensors[add].n_other++;
     op->d2s = d2s;
     return out;
 }
@@ -496,6 +509,7 @@ int g_chatt(Graph& g, int in, int w1, int b1, int w2, int b2, int Cr, int mode5d
     ChAttOp* op = push<ChAttOp>(g);
     op->in = in; op->out = out; op->w1 = w1; op->b1 = b1; op->w2 = w2; op->b2 = b2; op->Cr = Cr; op->T5 = mode5d_T;
     op->pids = {w1, b1, w2, b2};
+    g.tensors[in].n_other++;
     return out;
 }
 
@@ -513,6 +527,7 @@ int g_concat(Graph& g, const int* ins, int n) {
     ConcatOp* op = push<ConcatOp>(g);
     op->ins.assign(ins, ins + n);
     op->out = out;
+    for (int i = 0; i < n; ++i) g.tensors[ins[i]].n_other++;
     return out;
 }
 
@@ -522,6 +537,8 @@ int g_add(Graph& g, int a, int b, int relu) {
     const int out = g.add_tensor(ta.H, ta.W, ta.C, ta.nmul, true, false);
     AddOp* op = push<AddOp>(g);
     op->a = a; op->b = b; op->out = out; op->relu = relu;
+    g.tensors[a].n_other++;
+    g.tensors[b].n_other++;
     return out;
 }
 
@@ -530,6 +547,7 @@ int g_act(Graph& g, int in, int kind) {
     const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
     ActOp* op = push<ActOp>(g);
     op->in = in; op->out = out; op->act = kind;
+    g.tensors[in].n_other++;
     return out;
 }
 
@@ -539,6 +557,7 @@ int g_maxpool2(Graph& g, int in) {
     const int out = g.add_tensor(ti.H / 2, ti.W / 2, ti.C, ti.nmul, true, false);
     MaxPoolOp* op = push<MaxPoolOp>(g);
     op->in = in; op->out = out;
+    g.tensors[in].n_other++;
     return out;
 }
 
@@ -547,6 +566,7 @@ int g_resize(Graph& g, int in, int Ho, int Wo) {
     const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
     ResizeOp* op = push<ResizeOp>(g);
     op->in = in; op->out = out;
+    g.tensors[in].n_other++;
     return out;
 }
 
@@ -558,6 +578,7 @@ int g_localconv(Graph& g, int in, int w, int b, int F) {
     LocalConvOp* op = push<LocalConvOp>(g);
     op->in = in; op->out = out; op->w = w; op->b = b;
     op->pids = {w, b};
+    g.tensors[in].n_other++;
     return out;
 }
 
@@ -567,5 +588,6 @@ int g_repeat_time(Graph& g, int in, int T) {
     const int out = g.add_tensor(ti.H, ti.W, ti.C, T, true, false);
     RepeatTimeOp* op = push<RepeatTimeOp>(g);
     op->in = in; op->out = out; op->T = T;
+    g.tensors[in].n_other++;
     return out;
 }

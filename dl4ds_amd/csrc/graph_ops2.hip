@@ -225,6 +225,7 @@ int g_conv2d_transpose(Graph& g, int in, int w, int KS, int stride, int Cout, in
     const int out = g.add_tensor(ti.H * stride, ti.W * stride, Cout, ti.nmul, true, false);
     ConvTOp* op = push<ConvTOp>(g);
     op->in = in; op->w = w; op->out = out; op->KS = KS; op->stride = stride; op->Cout = Cout; op->relu = relu;
+    g.tensors[in].n_other++;
     op->pids = {w};
     return out;
 }
@@ -239,6 +240,7 @@ int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, in
     const int out = g.add_tensor(ti.H, ti.W, F, T, true, false);
     ConvLSTMOp* op = push<ConvLSTMOp>(g);
     op->in = in; op->out = out; op->wk = wk; op->wr = wr; op->b = b; op->KS = KS; op->F = F; op->T = T; op->relu = relu;
+    g.tensors[in].n_other++;
     op->pids = {wk, wr, b};
     return out;
 }
@@ -248,6 +250,7 @@ int g_gap(Graph& g, int in, int) {
     const int out = g.add_tensor(1, 1, ti.C, ti.nmul, true, false);
     GapOp* op = push<GapOp>(g);
     op->in = in; op->out = out;
+    g.tensors[in].n_other++;
     return out;
 }
 
@@ -259,6 +262,7 @@ int g_dense(Graph& g, int in, int w, int b, int F, int act) {
     const int out = g.add_tensor(1, 1, F, ti.nmul, true, false);
     DenseOp* op = push<DenseOp>(g);
     op->in = in; op->out = out; op->w = w; op->b = b; op->F = F; op->act = act;
+    g.tensors[in].n_other++;
     op->pids = {w, b};
     return out;
 }
@@ -269,6 +273,7 @@ int g_dropout(Graph& g, int in, float rate) {
     const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
     DropoutOp* op = push<DropoutOp>(g);
     op->in = in; op->out = out; op->rate = rate;
+    g.tensors[in].n_other++;
     g.dropout_ops.push_back(op);
     return out;
 }
