@@ -336,7 +336,10 @@ int dl4ds_graph_create(dl4ds_graph** g) {
     API_BEGIN
     *g = new dl4ds_graph();
     (*g)->g.stream = S();
-    if (!getenv("DL4DS_NO_AUX_STREAM")) (*g)->g.aux_stream = rt().aux_stream;
+    // Weight-gradient kernels on a second stream (concurrent with the dgrad chain) paid off with the LDS-staged conv
+    // kernels (+2-3 %); with the streamed-filter / row-walking kernels two co-resident MFMA kernels only take matrix-core
+    // and L1 bandwidth from each other (-2 % measured), so the single-stream order is the default now.
+    if (getenv("DL4DS_AUX_STREAM")) (*g)->g.aux_stream = rt().aux_stream;
     API_END
 }
 int dl4ds_graph_destroy(dl4ds_graph* g) {

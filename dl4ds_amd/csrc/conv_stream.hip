@@ -45,20 +45,19 @@ struct StreamParams {
     unsigned m_nblk;
 };
 
-#ifndef STREAM_MT
-#define STREAM_MT 4
-#endif
-constexpr int kStreamMT = STREAM_MT;                 // accumulator rows (of 16 pixels) per wave
-constexpr int kStreamThreads = 64 * (16 / kStreamMT);
+constexpr int kStreamThreads = 256;
 
-template <int KS, int E, int NT>
-__global__ void __launch_bounds__(kStreamThreads, kStreamMT == 4 ? 2 : 4) conv_stream_kernel(const StreamParams sp) {
+// MT = accumulator rows (of 16 pixels) per wave; tile = 16 x (4*MT) pixels.  MT = 8 halves the filter traffic per MFMA
+// (each streamed fragment now feeds 8 x NT tiles); its 16x32 halo tile only fits two-per-CU for channel chunks
+// <= 24 (E <= 6), so 48-channel layers run as two chunks.  Measured on the 192->48 dgrad: 102 -> 115 TFLOP/s.
+template <int KS, int E, int NT, int MT>
+__global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const StreamParams sp) {
     const ConvParams& a = sp.c;
     constexpr int G = (E % 4 == 0) ? 4 : 2;          // k-steps fed by one LDS read
     constexpr int NGRP = E / G;
     constexpr int CK = 4 * E;                        // input channels per chunk
     constexpr int P = CK + G;                        // LDS pixel pitch: P/G odd -> conflict-free b128 / b64 reads
-    constexpr int TW = 16, TH = 16, MT = kStreamMT, NTHR = kStreamThreads, PAD = KS / 2;
+    constexpr int TW = 16, TH = 4 * MT, NTHR = kStreamThreads, PAD = KS / 2;
     constexpr int TWH = TW + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
     constexpr int KK = KS * KS, NGS = KK * NGRP;     // group-steps per chunk
     constexpr int Q4 = CK / 4;
@@ -254,22 +253,22 @@ __global__ void __launch_bounds__(kStreamThreads, kStreamMT == 4 ? 2 : 4) conv_s
     }
 }
 
-template <int KS, int E, int NT>
+template <int KS, int E, int NT, int MT>
 void launch_stream(hipStream_t s, StreamParams& sp, int N) {
     constexpr int G = (E % 4 == 0) ? 4 : 2;
     constexpr int P = 4 * E + G;
-    constexpr int HPIX = (16 + KS - 1) * (16 + KS - 1);
+    constexpr int HPIX = (16 + KS - 1) * (4 * MT + KS - 1);
     constexpr size_t lds = (size_t)HPIX * P * sizeof(float);
     ConvParams& p = sp.c;
     p.tiles_x = cdiv(p.W, 16);
-    p.tiles_y = cdiv(p.H, 16);
+    p.tiles_y = cdiv(p.H, 4 * MT);
     p.m_txy[0] = div_magic(p.tiles_x);
     p.m_txy[1] = div_magic(p.tiles_y);
     sp.ntiles = p.tiles_x * p.tiles_y * N;
     sp.nblk = cdiv(p.Cout, 16 * NT);
     sp.m_nblk = div_magic(sp.nblk);
     sp.per_xcd = cdiv(sp.ntiles, 8);
-    auto kern = conv_stream_kernel<KS, E, NT>;
+    auto kern = conv_stream_kernel<KS, E, NT, MT>;
     static std::once_flag once;
     std::call_once(once, [&]() {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -277,7 +276,8 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
     });
     const unsigned grid = (unsigned)(8 * sp.per_xcd * sp.nblk);
     const double px = (double)N * p.H * p.W;
-    ProfScope ps(s, "conv_stream<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + ">",
+    ProfScope ps(s, "conv_stream<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + "," +
+                        std::to_string(MT) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kStreamThreads), lds, s, sp);
     HIP_CHECK(hipGetLastError());
@@ -286,10 +286,10 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
 template <int KS, int E>
 void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
     switch (NT) {
-        case 1: launch_stream<KS, E, 1>(s, sp, N); break;
-        case 2: launch_stream<KS, E, 2>(s, sp, N); break;
-        case 3: launch_stream<KS, E, 3>(s, sp, N); break;
-        default: launch_stream<KS, E, 4>(s, sp, N); break;
+        case 1: launch_stream<KS, E, 1, 4>(s, sp, N); break;
+        case 2: launch_stream<KS, E, 2, 4>(s, sp, N); break;
+        case 3: launch_stream<KS, E, 3, 4>(s, sp, N); break;
+        default: launch_stream<KS, E, 4, 4>(s, sp, N); break;
     }
 }
 
@@ -328,6 +328,26 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
         const long padded = (long)cdiv(in.C, 4 * e) * 4 * e;
         if (bestk < 0 || padded < bestk || (padded == bestk && e > E)) { bestk = padded; E = e; }
     }
+    // tall tiles (MT = 8): 3x3, cout tiling with NT <= 3 at no extra padding, a grid that still fills the chip, and a
+    // chunk width of 16 or 24 channels that does not pad K more than the wide chunk would
+    bool tall = false;
+    int NT8 = 0, E8 = 0;
+    if (KS == 3 && !getenv("DL4DS_STREAM_NO_TALL")) {
+        long bp = -1;
+        for (int nt = 1; nt <= 3; ++nt) {
+            if (out.C % nt) continue;
+            const long padded = (long)cdiv(out.C, 16 * nt) * 16 * nt;
+            if (bp < 0 || padded < bp || (padded == bp && nt > NT8)) { bp = padded; NT8 = nt; }
+        }
+        long bk = -1;
+        for (int e = 4; e <= 6; e += 2) {
+            const long padded = (long)cdiv(in.C, 4 * e) * 4 * e;
+            if (bk < 0 || padded < bk || (padded == bk && e > E8)) { bk = padded; E8 = e; }
+        }
+        const long ntiles8 = (long)cdiv(in.W, 16) * cdiv(in.H, 32) * in.N;
+        const bool big = ntiles8 * cdiv(out.C, 16 * NT8) >= 1024 || getenv("DL4DS_STREAM_FORCE_TALL") != nullptr;   // (tests)
+        tall = NT8 == 3 && E8 == 6 && bp <= best && bk <= bestk && big;     // (NT 2 / 16-channel chunks measured slower)
+    }
     StreamParams sp;
     ConvParams& p = sp.c;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
@@ -335,7 +355,14 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.dbg = 0; p.CK = 4 * E; p.TPS = 0;
-    if (KS == 3) {
+    if (tall) {
+        p.CK = 4 * E8;
+        if (E8 == 4) {
+            if (NT8 == 2) launch_stream<3, 4, 2, 8>(s, sp, in.N); else launch_stream<3, 4, 3, 8>(s, sp, in.N);
+        } else {
+            if (NT8 == 2) launch_stream<3, 6, 2, 8>(s, sp, in.N); else launch_stream<3, 6, 3, 8>(s, sp, in.N);
+        }
+    } else if (KS == 3) {
         switch (E) {
             case 4: dispatch_nt<3, 4>(s, sp, in.N, NT); break;
             case 6: dispatch_nt<3, 6>(s, sp, in.N, NT); break;

@@ -68,6 +68,34 @@ def test_conv2d_fused_epilogues(ops, h, w):
     close(ops.conv2d(x, wt, None, add=add), ref - b + add)
 
 
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 40, 33, 48, 48), (1, 32, 16, 48, 192), (1, 33, 17, 192, 48), (1, 64, 16, 24, 32),
+                                        (1, 32, 32, 16, 32), (1, 35, 20, 40, 96), (1, 16, 16, 20, 24)])
+def test_conv2d_stream_tall_tiles(ops, monkeypatch, n, h, w, ci, co):
+    """conv_stream_kernel<..., MT=8> (16x32-pixel tiles, 16/24-channel chunks) is only picked for large grids;
+    DL4DS_STREAM_FORCE_TALL makes it take these small ones: forward with fused epilogues, dgrad with accumulate."""
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_TALL', '1')
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    close(ops.conv2d(x, wt, b), ref)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    close(ops.conv2d_dgrad(dz, wt), gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+
+
+def test_conv2d_stream_tall_tiles_depth_to_space(ops, monkeypatch):
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_TALL', '1')
+    n, h, w, ci, co, r = 2, 34, 20, 48, 192, 2
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
+    close(ops.conv2d(x, wt, b, d2s=r), ref)
+    dz = R(n, h * r, w * r, co // (r * r))
+    gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
+    close(ops.conv2d_dgrad(dz, wt, d2s=r), gx)
+
+
 @pytest.mark.parametrize('ci,co', [(8, 1), (1, 8), (1, 1), (3, 2)])
 def test_conv2d_fused_epilogues_stencil_path(ops, ci, co):
     n, h, w = 2, 19, 45

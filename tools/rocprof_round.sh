@@ -6,10 +6,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# weight-gradient kernels normally run on a second stream concurrently with the dgrad chain (+2-3 % throughput);
-# that concurrency stretches every kernel's wall duration, so the profile is taken with it off -- the same setting
-# bench.py uses for its per-launch roofline measurement.
-export DL4DS_NO_AUX_STREAM=1
 CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats --output-format csv -- $CMD > $OUT/bench_under_rocprof.log 2>&1
 python $R/tools/rocprof_stats_summary.py /tmp/prof_stats > $OUT/kernel_stats_$TAG.txt
