@@ -46,9 +46,17 @@ __global__ void colsum_finish_kernel(const float* __restrict__ partial, float* _
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= GQ) return;
     const int g = e / Q, q = e - g * Q;
-    float s = 0.f;
-    for (int k = 0; k < nb; ++k) s += partial[((size_t)g * nb + k) * Q + q];
-    out[e] = s * scale;
+    // eight independent partial sums keep eight loads in flight (a single dependent chain took 40 us for nb = 256);
+    // fixed association order -> deterministic
+    const float* p = partial + (size_t)g * nb * Q + q;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nb; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(k + u) * Q];
+    }
+    for (; k < nb; ++k) s[0] += p[(size_t)k * Q];
+    out[e] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * scale;
 }
 
 // one thread per (instance, c)

@@ -42,9 +42,12 @@ __global__ void __launch_bounds__(256) pixel_loss_kernel(const float* __restrict
 // loss_out[0] (+)= wa*mean|d| + ws*mean d^2
 __global__ void pixel_loss_finish_kernel(const float* __restrict__ partial, int nb, float wa, float ws, float inv_n,
                                          float* loss_out, int accumulate) {
+    // one wave: lane-strided partial sums, then a fixed butterfly (deterministic; the single-thread chain took 53 us)
+    float a = 0.f, b = 0.f;
+    for (int k = threadIdx.x; k < nb; k += 64) { a += partial[2 * k]; b += partial[2 * k + 1]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-        for (int k = 0; k < nb; ++k) { a += partial[2 * k]; b += partial[2 * k + 1]; }
         const float v = wa * a * inv_n + ws * b * inv_n;
         loss_out[0] = accumulate ? loss_out[0] + v : v;
     }
