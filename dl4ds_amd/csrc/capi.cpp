@@ -242,6 +242,28 @@ int dl4ds_op_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, 
     conv2d_transpose_wgrad(S(), xv, dzv, KS, stride, dw, accumulate, scratch(ws), ws);
     API_END
 }
+int dl4ds_batch_prepare(const float* hr, const float* pred, const float* stat, const int* idx_host, const int* cy_host,
+                        const int* cx_host, float* out_lr, float* out_hr, float* out_stat, int H, int W, int C, int P, int S_,
+                        int T, int B, int scale, int psy, int psx, int pin, int static_in_lr) {
+    API_BEGIN
+    DL4DS_REQUIRE(B > 0 && idx_host && cy_host && cx_host, "batch_prepare: index lists missing");
+    // the three B-element index lists travel in one small upload (persistent device buffer, grown on demand)
+    static int* d_idx = nullptr;
+    static int cap = 0;
+    static std::vector<int> h_idx;
+    if (3 * B > cap) {
+        if (d_idx) HIP_CHECK(hipFree(d_idx));
+        cap = std::max(3 * B, 3 * 256);
+        HIP_CHECK(hipMalloc((void**)&d_idx, (size_t)cap * sizeof(int)));
+    }
+    // the upload is ordered on the library stream behind the previous batch's kernels, which read the old contents
+    h_idx.resize(3 * (size_t)B);
+    for (int b = 0; b < B; ++b) { h_idx[b] = idx_host[b]; h_idx[B + b] = cy_host[b]; h_idx[2 * B + b] = cx_host[b]; }
+    HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), 3 * (size_t)B * sizeof(int), hipMemcpyHostToDevice, S()));
+    batch_prepare(S(), hr, pred, stat, d_idx, d_idx + B, d_idx + 2 * B, out_lr, out_hr, out_stat, H, W, C, P, S_, T, B, scale,
+                  psy, psx, pin, static_in_lr);
+    API_END
+}
 int dl4ds_op_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r) {
     API_BEGIN
     depth_to_space(S(), x, y, N, H, W, C, r);

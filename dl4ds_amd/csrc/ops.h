@@ -103,3 +103,11 @@ void bce_forward_backward(hipStream_t s, const float* p, float label, int n, flo
 // Keras Adam on a flat arena. lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.
 void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, size_t n, float lr_t,
                  float beta1, float beta2, float eps, float grad_scale);
+
+// ------------------------------------------------------------- batch preparation (batchprep.hip), "next" row f1
+// Gathers one training batch from a device-resident dataset: block-mean coarsening (cv2 INTER_AREA at an integer
+// ratio), pixel replication back to the HR grid for 'pin', crops, predictor / static-variable channel stacking.
+// idx / cy / cx are DEVICE int arrays of length B (first frame, crop corner in HR pixels).
+void batch_prepare(hipStream_t s, const float* hr, const float* pred, const float* stat, const int* idx, const int* cy,
+                   const int* cx, float* out_lr, float* out_hr, float* out_stat, int H, int W, int C, int P, int S, int T,
+                   int B, int scale, int psy, int psx, int pin, int static_in_lr);

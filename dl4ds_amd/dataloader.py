@@ -199,3 +199,105 @@ class DataGenerator:
                                   scale=self.scale, batch_size=self.batch_size, patch_size=self.patch_size,
                                   time_window=self.time_window, static_vars=self.static_vars,
                                   predictors=self.predictors, interpolation=self.interpolation, rng=self.rng)
+
+
+class DeviceDataGenerator:
+    """DataGenerator whose dataset lives in HBM and whose batches are gathered by `dl4ds_batch_prepare`
+    (csrc/batchprep.hip) -- SURVEY section 8 "next" row f1.  Same constructor, same seeded permutation and the same
+    per-sample RNG calls as DataGenerator, so `gen[i]` holds exactly the batch `DataGenerator(...)[i]` would build
+    (block means agree to fp32 rounding).  Supported: interpolation='inter_area', no external LR array, field sizes
+    divisible by `scale`; anything else raises (use DataGenerator).
+
+    `gen[i]` returns ([lr(, static_hr)], [hr]) as DeviceArray objects that stay valid until the next `gen[...]` call
+    (two rotating output buffers, so the previous batch can still be in flight); `.numpy()` them for inspection.
+    """
+
+    def __init__(self, array, array_lr, backbone, upsampling, scale, batch_size=32, patch_size=None, time_window=None,
+                 static_vars=None, predictors=None, interpolation='inter_area', repeat=None, seed=None, rank=0,
+                 world=1):
+        from .device import DeviceArray
+        if array_lr is not None:
+            raise NotImplementedError('DeviceDataGenerator: an external LR array is not supported (use DataGenerator)')
+        if interpolation != 'inter_area':
+            raise NotImplementedError("DeviceDataGenerator: only interpolation='inter_area' is implemented on the device")
+        a = np.asarray(getattr(array, 'values', array), np.float32)
+        if a.ndim == 3:
+            a = a[..., None]
+        self.N, self.H, self.W, self.C = a.shape
+        self.scale, self.batch_size, self.upsampling, self.backbone = int(scale), int(batch_size), upsampling, backbone
+        if self.H % self.scale or self.W % self.scale:
+            raise ValueError('DeviceDataGenerator: field size must be divisible by `scale`')
+        self.pin = upsampling == 'pin'
+        if not self.pin and upsampling not in POSTUPSAMPLING_METHODS:
+            raise ValueError(f'unknown upsampling {upsampling}')
+        self.patch_size, self.time_window = patch_size, time_window
+        if patch_size is not None and not self.pin and patch_size % self.scale != 0:
+            raise ValueError('`patch_size` must be divisible by `scale`')
+        self.T = 1 if time_window is None else int(time_window)
+        self.spt = time_window is not None
+        self._hr = DeviceArray.from_numpy(a)
+        self._pred, self.P = None, 0
+        if predictors is not None:
+            p = np.concatenate([np.asarray(q, np.float32) for q in predictors], axis=-1)
+            assert p.shape[:3] == a.shape[:3], 'predictors must share the HR grid'
+            self._pred, self.P = DeviceArray.from_numpy(p), p.shape[-1]
+        self._stat, self.S = None, 0
+        if static_vars is not None:
+            sv = [checkarray_ndim(np.squeeze(np.asarray(getattr(v, 'values', v), np.float32)), 3) for v in static_vars]
+            st = np.concatenate(sv, axis=-1)
+            assert st.shape[:2] == (self.H, self.W), 'static variables must share the HR grid'
+            self._stat, self.S = DeviceArray.from_numpy(st), st.shape[-1]
+        self.n = self.N - self.T if self.spt else self.N
+        self.rng = np.random.default_rng(seed)
+        perm = self.rng.permutation(self.n)
+        self.indices = perm[rank::world] if world > 1 else perm
+        if repeat is not None and isinstance(repeat, int):
+            self.indices = np.hstack([self.indices for _ in range(repeat)])
+        self.psy, self.psx = (self.H, self.W) if patch_size is None else (int(patch_size), int(patch_size))
+        self.static_in_lr = bool(self.S and not self.spt)
+        cl = self.C + self.P + (self.S if self.static_in_lr else 0)
+        oy, ox = (self.psy, self.psx) if self.pin else (self.psy // self.scale, self.psx // self.scale)
+        B, T = self.batch_size, self.T
+        lead = (B, T) if self.spt else (B,)
+        self._bufs = []
+        for _ in range(2):
+            lr = DeviceArray(lead + (oy, ox, cl))
+            hr = DeviceArray(lead + (self.psy, self.psx, self.C))
+            st = DeviceArray((B, self.psy, self.psx, self.S)) if self.S else None
+            self._bufs.append((lr, hr, st))
+        self._turn = 0
+
+    def __len__(self):
+        return len(self.indices) // self.batch_size
+
+    def _draw(self, index):
+        """Sample indices and crop corners (HR pixels) with the RNG calls of create_pair_hr_lr / crop_array."""
+        idx = np.asarray(self.indices[index * self.batch_size:(index + 1) * self.batch_size], np.int32)
+        cy = np.zeros(len(idx), np.int32)
+        cx = np.zeros(len(idx), np.int32)
+        if self.patch_size is not None:
+            for b in range(len(idx)):
+                if self.pin:
+                    cy[b] = int(self.rng.integers(0, self.H - self.patch_size + 1))
+                    cx[b] = int(self.rng.integers(0, self.W - self.patch_size + 1))
+                else:
+                    ps_lr = self.patch_size // self.scale
+                    cy[b] = int(self.rng.integers(0, self.H // self.scale - ps_lr + 1)) * self.scale
+                    cx[b] = int(self.rng.integers(0, self.W // self.scale - ps_lr + 1)) * self.scale
+        return idx, cy, cx
+
+    def __getitem__(self, index):
+        from . import _lib
+        idx, cy, cx = self._draw(index)
+        if len(idx) != self.batch_size:
+            raise IndexError('incomplete batch')
+        lr, hr, st = self._bufs[self._turn]
+        self._turn ^= 1
+        ip = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data
+        _lib.check(_lib.lib().dl4ds_batch_prepare(
+            self._hr.ptr, None if self._pred is None else self._pred.ptr, None if self._stat is None else self._stat.ptr,
+            ip(idx), ip(cy), ip(cx), lr.ptr, hr.ptr, None if st is None else st.ptr, self.H, self.W, self.C, self.P, self.S,
+            self.T, self.batch_size, self.scale, self.psy, self.psx, int(self.pin), int(self.static_in_lr)))
+        if st is not None:
+            return [lr, st], [hr]
+        return [lr], [hr]

@@ -76,6 +76,14 @@ class SupervisedEngine:
     def evaluate(self, inputs, y_true):
         return self.loss_and_grads(inputs, y_true)[0]
 
+    def evaluate_device(self, input_ptrs, y_ptr, batch):
+        """Loss on HBM-resident buffers (no update)."""
+        ptrs = (ctypes.c_void_p * len(input_ptrs))(*input_ptrs)
+        loss = ctypes.c_float()
+        _lib.check(self._l.dl4ds_trainer_loss_and_grads(self.h, ptrs, len(input_ptrs), y_ptr, int(batch), 0,
+                                                        ctypes.byref(loss)))
+        return float(loss.value)
+
     def last_loss(self):
         loss = ctypes.c_float()
         _lib.check(self._l.dl4ds_trainer_last_loss(self.h, ctypes.byref(loss)))

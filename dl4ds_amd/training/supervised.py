@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 from .. import POSTUPSAMPLING_METHODS
-from ..dataloader import DataGenerator
+from ..dataloader import DataGenerator, DeviceDataGenerator
 from .. import models as M
 from .. import parallel
 from .base import Trainer
@@ -47,9 +47,18 @@ class SupervisedTrainer(Trainer):
         kw = dict(backbone=self.backbone, upsampling=self.upsampling, scale=self.scale,
                   batch_size=self.global_batch_size, static_vars=self.static_vars, patch_size=self.patch_size,
                   interpolation=self.interpolation, time_window=self.time_window, rank=self.rank, world=self.world)
-        self.ds_train = DataGenerator(self.data_train, self.data_train_lr, predictors=self.predictors_train, seed=1, **kw)
-        self.ds_val = DataGenerator(self.data_val, self.data_val_lr, predictors=self.predictors_val, seed=2, **kw)
-        self.ds_test = DataGenerator(self.data_test, self.data_test_lr, predictors=self.predictors_test, seed=3, **kw)
+        def make(data, data_lr, predictors, seed):
+            # datasets live in HBM and batches are gathered on the device (csrc/batchprep.hip) whenever the request is
+            # the default 'inter_area' pipeline; the numpy loop remains for external LR arrays / other interpolations
+            if getattr(self, 'device_data', True) and data_lr is None and self.interpolation == 'inter_area':
+                try:
+                    return DeviceDataGenerator(data, None, predictors=predictors, seed=seed, **kw)
+                except (NotImplementedError, ValueError):
+                    pass
+            return DataGenerator(data, data_lr, predictors=predictors, seed=seed, **kw)
+        self.ds_train = make(self.data_train, self.data_train_lr, self.predictors_train, 1)
+        self.ds_val = make(self.data_val, self.data_val_lr, self.predictors_val, 2)
+        self.ds_test = make(self.data_test, self.data_test_lr, self.predictors_test, 3)
 
     def setup_model(self):
         """supervised.py:242-325."""
@@ -87,7 +96,12 @@ class SupervisedTrainer(Trainer):
         tot = 0.0
         for i in range(n):
             x, y = ds[i]
-            tot += self.engine.step(x, y[0]) if train else self.engine.evaluate(x, y[0])
+            if isinstance(ds, DeviceDataGenerator):
+                ptrs, b = [a.ptr for a in x], ds.batch_size
+                tot += (self.engine.step_device(ptrs, y[0].ptr, b, want_loss=True) if train
+                        else self.engine.evaluate_device(ptrs, y[0].ptr, b))
+            else:
+                tot += self.engine.step(x, y[0]) if train else self.engine.evaluate(x, y[0])
         return tot / max(n, 1), n
 
     def run(self):

@@ -169,6 +169,23 @@ int dl4ds_cgan_step(dl4ds_trainer* tr, const float* const* gen_inputs, int n_gen
                     int is_host, const float* dropout_keep_host, int apply_update, float* losses_host);
 int dl4ds_cgan_get_disc_grad(dl4ds_trainer* tr, int param_id, float* dst_host);
 
+/* ---------------------------------------------------------------- batch preparation (SURVEY section 8 "next" row f1)
+ * One training batch gathered from a DEVICE-resident dataset; replaces the per-sample numpy/cv2 loop of
+ * create_batch_hr_lr / create_pair_hr_lr (dataloader.py:297-360, 11-294) and crop_array / resize_array
+ * (utils.py:251-401) for interpolation='inter_area' (integer ratio: block mean; re-expansion for 'pin': replication)
+ * and no external LR array.
+ *   hr_dev [N][H][W][C], pred_dev [N][H][W][P] or NULL, static_dev [H][W][S] or NULL (all float32, device)
+ *   idx_host / cy_host / cx_host [B]: first frame of each sample and its crop corner in HR pixels (host ints; the
+ *   caller draws them with the RNG calls of the reference's loop so both paths produce the same batch)
+ *   T frames per sample (time_window, 1 for spatial models); patch psy x psx HR pixels (== H x W when not cropping)
+ *   pin = 0: out_lr [B][T][psy/scale][psx/scale][C+P(+S)]     pin = 1: out_lr [B][T][psy][psx][C+P(+S)]
+ *   static_in_lr: append the (block-mean / raw) static variables to lr (spatial models, dataloader.py:261-289)
+ *   out_hr [B][T][psy][psx][C], out_static [B][psy][psx][S] (NULL when S == 0).  Asynchronous on the library stream. */
+int dl4ds_batch_prepare(const float* hr_dev, const float* pred_dev, const float* static_dev, const int* idx_host,
+                        const int* cy_host, const int* cx_host, float* out_lr_dev, float* out_hr_dev,
+                        float* out_static_dev, int H, int W, int C, int P, int S, int T, int B, int scale, int psy,
+                        int psx, int pin, int static_in_lr);
+
 /* ---------------------------------------------------------------- data parallelism (RCCL over xGMI)
  * replaces Horovod: hvd.init/rank/size (base.py:97-107), DistributedOptimizer / DistributedGradientTape
  * gradient averaging (supervised.py:365; cgan.py:608-611), broadcast of variables + optimiser slots from

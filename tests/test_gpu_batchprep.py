@@ -1,0 +1,69 @@
+"""On-device batch preparation (SURVEY section 8 "next" row f1) against the numpy port of the reference's host loop:
+same seed -> same permutation, same crops, same batches (block means to fp32 rounding, copies bit-exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(n, h, w, c, seed):
+    return np.random.default_rng(seed).standard_normal((n, h, w, c)).astype(np.float32)
+
+
+CASES = [
+    # upsampling, scale, H, W, C, predictors, n_static, patch, time_window, batch
+    ('spc', 4, 32, 32, 1, None, 0, None, None, 4),
+    ('spc', 4, 48, 64, 2, 3, 2, 16, None, 3),
+    ('rc', 2, 40, 40, 1, 2, 1, 20, None, 5),
+    ('pin', 4, 32, 48, 1, 2, 1, 20, None, 4),
+    ('pin', 2, 24, 24, 3, None, 0, None, None, 2),
+    ('spc', 4, 32, 32, 1, 1, 1, 16, 3, 2),
+    ('pin', 2, 20, 20, 2, None, 1, 12, 4, 3),
+]
+
+
+@pytest.mark.parametrize('ups,scale,H,W,C,P,S,patch,tw,B', CASES)
+def test_device_batches_equal_host_batches(ups, scale, H, W, C, P, S, patch, tw, B):
+    from dl4ds_amd.dataloader import DataGenerator, DeviceDataGenerator
+    n = 13
+    hr = _fields(n, H, W, C, 1)
+    preds = None if P is None else [_fields(n, H, W, P, 2)]
+    stat = None if S == 0 else [np.random.default_rng(3 + i).standard_normal((H, W)).astype(np.float32) for i in range(S)]
+    kw = dict(backbone='resnet', upsampling=ups, scale=scale, batch_size=B, patch_size=patch, time_window=tw,
+              static_vars=stat, predictors=preds, interpolation='inter_area', seed=11)
+    host = DataGenerator(hr, None, **kw)
+    dev = DeviceDataGenerator(hr, None, **kw)
+    assert len(dev) == len(host) and len(dev) >= 2
+    for i in range(len(dev)):
+        xs_h, ys_h = host[i]
+        xs_d, ys_d = dev[i]
+        assert len(xs_h) == len(xs_d)
+        lr_d = xs_d[0].numpy()
+        assert lr_d.shape == xs_h[0].shape, (lr_d.shape, xs_h[0].shape)
+        np.testing.assert_allclose(lr_d, xs_h[0], rtol=0, atol=2e-6 * max(np.abs(xs_h[0]).max(), 1.0))
+        np.testing.assert_array_equal(ys_d[0].numpy(), ys_h[0])             # crops are copies: bit-exact
+        if len(xs_h) == 2:
+            np.testing.assert_array_equal(xs_d[1].numpy(), xs_h[1])
+
+
+def test_device_batches_feed_the_train_step_without_host_copies():
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import SupervisedEngine
+    from dl4ds_amd.dataloader import DataGenerator, DeviceDataGenerator
+    hr = _fields(16, 32, 32, 1, 5)
+    kw = dict(backbone='resnet', upsampling='spc', scale=4, batch_size=4, seed=3)
+
+    def run(gen_cls):
+        model = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (8, 8), n_blocks=2, seed=2)
+        eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
+        gen = gen_cls(hr, None, **kw)
+        losses = []
+        for i in range(len(gen)):
+            xs, ys = gen[i]
+            if gen_cls is DeviceDataGenerator:
+                losses.append(eng.step_device([xs[0].ptr], ys[0].ptr, 4, want_loss=True))
+            else:
+                losses.append(eng.step(xs, ys[0]))
+        return losses
+    l_host, l_dev = run(DataGenerator), run(DeviceDataGenerator)
+    np.testing.assert_allclose(l_dev, l_host, rtol=2e-5)
