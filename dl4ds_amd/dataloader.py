@@ -271,8 +271,11 @@ class DeviceDataGenerator:
         return len(self.indices) // self.batch_size
 
     def _draw(self, index):
-        """Sample indices and crop corners (HR pixels) with the RNG calls of create_pair_hr_lr / crop_array."""
-        idx = np.asarray(self.indices[index * self.batch_size:(index + 1) * self.batch_size], np.int32)
+        return self._draw_for(self.indices[index * self.batch_size:(index + 1) * self.batch_size])
+
+    def _draw_for(self, sample_indices):
+        """Crop corners (HR pixels) for the given samples, with the RNG calls of create_pair_hr_lr / crop_array."""
+        idx = np.asarray(sample_indices, np.int32)
         cy = np.zeros(len(idx), np.int32)
         cx = np.zeros(len(idx), np.int32)
         if self.patch_size is not None:
@@ -287,8 +290,12 @@ class DeviceDataGenerator:
         return idx, cy, cx
 
     def __getitem__(self, index):
+        return self.prepare(self.indices[index * self.batch_size:(index + 1) * self.batch_size])
+
+    def prepare(self, sample_indices):
+        """One batch for an explicit list of `batch_size` sample indices (the CGAN loop shards its own indices)."""
         from . import _lib
-        idx, cy, cx = self._draw(index)
+        idx, cy, cx = self._draw_for(sample_indices)
         if len(idx) != self.batch_size:
             raise IndexError('incomplete batch')
         lr, hr, st = self._bufs[self._turn]

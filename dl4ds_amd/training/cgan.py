@@ -5,7 +5,7 @@ import time
 import numpy as np
 
 from .. import POSTUPSAMPLING_METHODS
-from ..dataloader import create_batch_hr_lr
+from ..dataloader import create_batch_hr_lr, DeviceDataGenerator
 from .. import models as M
 from .. import parallel
 from .base import Trainer
@@ -82,11 +82,33 @@ class CGANTrainer(Trainer):
             self.steps_per_epoch = n_samples // self.batch_size
         rng = np.random.default_rng(17)
         preds = None if self.predictors_train is None else np.concatenate(self.predictors_train, axis=-1)
+        # dataset in HBM, batches gathered by csrc/batchprep.hip for the default 'inter_area' pipeline (same crops as
+        # the numpy loop: it draws them from the same generator); otherwise the host loop below
+        dev = None
+        if self.data_train_lr is None and self.interpolation == 'inter_area' and self.static_vars is not None:
+            try:
+                dev = DeviceDataGenerator(self.data_train, None, self.backbone, self.upsampling, self.scale,
+                                          batch_size=self.batch_size, patch_size=self.patch_size,
+                                          time_window=self.time_window, static_vars=self.static_vars,
+                                          predictors=self.predictors_train, interpolation=self.interpolation)
+                dev.rng = rng
+            except (NotImplementedError, ValueError):
+                dev = None
         first = True
         for epoch in range(self.epochs):
             idx = parallel.shard_indices(n_samples, self.rank, self.world, seed=17, epoch=epoch)
             steps = min(self.steps_per_epoch // self.world, len(idx) // self.batch_size)
             for i in range(steps):
+                if dev is not None:
+                    (lr_dev, aux_dev), (hr_dev,) = dev.prepare(idx[i * self.batch_size:(i + 1) * self.batch_size])
+                    losses = self.engine.step_device([lr_dev.ptr, aux_dev.ptr], hr_dev.ptr, self.batch_size,
+                                                     want_losses=True)
+                    if first and self.world > 1:
+                        parallel.broadcast_trainer(self.engine)
+                    first = False
+                    for lst, v in zip((self.gentotal, self.gengan, self.genpxloss, self.disc), losses):
+                        lst.append(v)
+                    continue
                 (lr_array, aux_hr), (hr_array,) = create_batch_hr_lr(
                     idx, i, self.data_train, self.data_train_lr, upsampling=self.upsampling, scale=self.scale,
                     batch_size=self.batch_size, patch_size=self.patch_size, time_window=self.time_window,
