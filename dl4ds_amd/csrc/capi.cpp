@@ -165,6 +165,11 @@ int dl4ds_profile_enable(int on) {
     prof().on = (on != 0);
     API_END
 }
+int dl4ds_profile_filter(const char* tag_prefix) {
+    API_BEGIN
+    prof().filter = tag_prefix ? tag_prefix : "";
+    API_END
+}
 int dl4ds_profile_report(char* buf, size_t buflen) {
     API_BEGIN
     const std::string r = prof().report_json(S());

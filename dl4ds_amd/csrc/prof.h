@@ -13,6 +13,8 @@ struct ProfEntry {
 
 struct Profiler {
     bool on = false;
+    std::string filter;       // non-empty: only launches whose tag starts with it are timed (bench.py: the dominant
+                              // kernel, measured inside the timed region at negligible cost)
     std::vector<ProfEntry> entries;
     std::vector<hipEvent_t> pool;
     hipEvent_t get_event();
@@ -27,6 +29,7 @@ struct ProfScope {
     ProfScope(hipStream_t stream, const std::string& tag, double flops, double bytes) : s(stream) {
         Profiler& p = prof();
         if (!p.on) return;
+        if (!p.filter.empty() && tag.compare(0, p.filter.size(), p.filter) != 0) return;
         ProfEntry e;
         e.tag = tag; e.flops = flops; e.bytes = bytes;
         e.e0 = p.get_event();

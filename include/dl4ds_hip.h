@@ -44,6 +44,9 @@ int dl4ds_event_timer_stop(float* ms);            /* record + synchronize + elap
  * {"<kernel tag>": {"n": launches, "ms": total, "flops": algorithmic, "bytes": algorithmic}, ...};
  * synchronises and clears the log. */
 int dl4ds_profile_enable(int on);
+/* restrict the timing to launches whose tag starts with `tag_prefix` (NULL / "" = all): lets a benchmark time its
+ * dominant kernel inside the measured region without paying two events for every other launch */
+int dl4ds_profile_filter(const char* tag_prefix);
 int dl4ds_profile_report(char* json_buf, size_t buflen);
 
 /* ---------------------------------------------------------------- single-op entry points
