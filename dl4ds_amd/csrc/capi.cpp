@@ -591,6 +591,18 @@ int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, lon
     if (step) *step = t.step;
     API_END
 }
+int dl4ds_trainer_set_state(dl4ds_trainer* tr, const float* m_host, const float* v_host, long step) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
+    DL4DS_REQUIRE(m_host && v_host && step >= 0, "set_state: missing arrays / negative step");
+    Trainer& t = *tr->t;
+    const size_t bytes = t.g->n_params * sizeof(float);
+    HIP_CHECK(hipMemcpyAsync(t.m, m_host, bytes, hipMemcpyHostToDevice, S()));
+    HIP_CHECK(hipMemcpyAsync(t.v, v_host, bytes, hipMemcpyHostToDevice, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    t.step = step;
+    API_END
+}
 int dl4ds_trainer_last_loss(dl4ds_trainer* tr, float* loss_host) {
     API_BEGIN
     DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");

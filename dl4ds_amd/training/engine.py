@@ -84,6 +84,38 @@ class SupervisedEngine:
                                                         ctypes.byref(loss)))
         return float(loss.value)
 
+    def save_checkpoint(self, path):
+        """Weights (by variable name) + Adam slots + optimizer.iterations in one .npz -- the native counterpart of the
+        reference's tf.train.Checkpoint (cgan.py:288-292) / saved model + trained_epochs (supervised.py:322-325)."""
+        m, v, step = self.optimizer_state()
+        blob = {'w/' + k: a for k, a in self.model.get_weights().items()}
+        blob.update({'m/' + k: a for k, a in m.items()})
+        blob.update({'v/' + k: a for k, a in v.items()})
+        blob['step'] = np.int64(step)
+        np.savez(path, **blob)
+
+    def load_checkpoint(self, path):
+        """Restore a `save_checkpoint` file into this engine (same architecture); returns optimizer.iterations."""
+        z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        names = list(self.model.get_weights().keys())
+        missing = [k for k in names if 'w/' + k not in z]
+        if missing:
+            raise ValueError(f'checkpoint lacks variables {missing[:3]}...')
+        self.model.set_weights({k: z['w/' + k] for k in names})
+        n_arena = ctypes.c_size_t()
+        n_params = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_param_count(self.model.graph.h, ctypes.byref(n_arena), ctypes.byref(n_params)))
+        m = np.zeros(n_arena.value, np.float32)
+        v = np.zeros(n_arena.value, np.float32)
+        for name, p in self.model.graph.params.items():
+            off, n = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(self._l.dl4ds_graph_param_info(self.model.graph.h, p['pid'], ctypes.byref(off), ctypes.byref(n)))
+            m[off.value:off.value + n.value] = np.asarray(z['m/' + name], np.float32).ravel()
+            v[off.value:off.value + n.value] = np.asarray(z['v/' + name], np.float32).ravel()
+        step = int(z['step'])
+        _lib.check(self._l.dl4ds_trainer_set_state(self.h, m.ctypes.data, v.ctypes.data, step))
+        return step
+
     def last_loss(self):
         loss = ctypes.c_float()
         _lib.check(self._l.dl4ds_trainer_last_loss(self.h, ctypes.byref(loss)))

@@ -2,6 +2,7 @@
 compile/fit/evaluate become an explicit epoch/step loop around libdl4ds_hip's fused train step; Horovod's
 DistributedOptimizer / BroadcastGlobalVariablesCallback become one RCCL all-reduce per step and one
 broadcast before the first step."""
+import os
 import time
 
 import numpy as np
@@ -22,7 +23,7 @@ class SupervisedTrainer(Trainer):
                  device='GPU', gpu_memory_growth=True, use_multiprocessing=False, model_list=None,
                  learning_rate=(1e-3, 1e-4), lr_decay_after=1e5, early_stopping=False, patience=6, min_delta=0,
                  show_plot=True, save=False, save_path=None, save_bestmodel=False, trained_model=None,
-                 trained_epochs=0, verbose=True, **architecture_params):
+                 trained_epochs=0, verbose=True, checkpoint=None, device_data=True, **architecture_params):
         super().__init__(backbone=backbone, upsampling=upsampling, data_train=data_train, data_train_lr=data_train_lr,
                          time_window=time_window, loss=loss, batch_size=batch_size, patch_size=patch_size, scale=scale,
                          device=device, gpu_memory_growth=gpu_memory_growth, use_multiprocessing=use_multiprocessing,
@@ -41,6 +42,7 @@ class SupervisedTrainer(Trainer):
         self.early_stopping, self.patience, self.min_delta = early_stopping, patience, min_delta
         self.architecture_params = architecture_params
         self.trained_model, self.trained_epochs, self.save_bestmodel = trained_model, trained_epochs, save_bestmodel
+        self.checkpoint, self.device_data = checkpoint, device_data
 
     def setup_datagen(self):
         """supervised.py:220-240."""
@@ -116,6 +118,12 @@ class SupervisedTrainer(Trainer):
         else:
             lr = float(lr) * self.world
         self.engine = SupervisedEngine(self.model, loss=self.lossf, learning_rate=lr, lr_decay_after=self.lr_decay_after)
+        # resume: `checkpoint` (a file written by SupervisedEngine.save_checkpoint / a previous run with save=True)
+        # restores weights, Adam slots and the iteration count, so that trained_epochs + remaining epochs continues the
+        # same optimisation (the reference only re-loads the weights of `trained_model`, supervised.py:322-325)
+        ckpt = getattr(self, 'checkpoint', None)
+        if ckpt is not None:
+            self.engine.load_checkpoint(ckpt)
         if self.world > 1:
             parallel.broadcast_trainer(self.engine)            # BroadcastGlobalVariablesCallback(0)
         steps = self.steps_per_epoch
@@ -144,6 +152,8 @@ class SupervisedTrainer(Trainer):
                 print(f'\nScore on the test set: {self.test_loss}')
         self.running_time = time.time() - t0
         self.save_results(self.model)
+        if self.save and self.running_on_first_worker and self.save_path is not None:
+            self.engine.save_checkpoint(os.path.join(self.save_path, 'checkpoint.npz'))
         return self
 
     fit = run     # BASELINE.json calls it fit(); the reference method is run()

@@ -160,6 +160,9 @@ int dl4ds_trainer_step(dl4ds_trainer* tr, const float* const* inputs, int n_inpu
 int dl4ds_trainer_loss_and_grads(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true,
                                  int B, int is_host, float* loss_host);
 int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, long* step);
+/* restore the Adam slots (arena-sized host arrays) and optimizer.iterations -- resume from a checkpoint
+ * (the reference resumes through tf.train.Checkpoint, cgan.py:288-292; supervised.py:322-325 re-uses a trained model) */
+int dl4ds_trainer_set_state(dl4ds_trainer* tr, const float* m_host, const float* v_host, long step);
 int dl4ds_trainer_last_loss(dl4ds_trainer* tr, float* loss_host);   /* synchronises */
 
 /* CGAN step -- cgan.py:575-639 with generator_loss (:525-553, lambda) and discriminator_loss (:556-572).
