@@ -20,6 +20,7 @@
 #include "conv_kernels.h"
 #include "launch.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -138,6 +139,149 @@ void launch_narrow(hipStream_t s, ConvParams& p, int N) {
     ProfScope ps(s, "conv_narrow<" + std::to_string(CI) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
     hipLaunchKernelGGL((conv_narrow_kernel<CI>), dim3(blocks), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+// --------------------------------------------------------------------------------------------
+// Cin <= 8, Cout <= 8: two output pixels per MFMA column.  With 8 couts only half of the 16 MFMA rows carry data; here
+// rows are (h, cout): h = 0 computes pixel (y, 2j), h = 1 pixel (y, 2j+1) of column j's pixel PAIR.  Both share the
+// second operand x[(y+dy), 2j+ux][cin] with ux = 0..3 (the union of the two 3-wide windows); the filter operand of row
+// (h, co) at (dy, ux) is W[dy][ux-h][cin][co] (zero outside the 3 taps).  K grows from 72 to 96 but a tile of 16 columns
+// now covers 32 pixels: 24 MFMAs per 32 pixels instead of 36, and after the MFMA every lane holds four couts of one
+// pixel, so all 64 lanes store (the 16-pixel variant idles half of them).
+template <int NR>
+__global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvParams a) {
+    constexpr int PTW = 32, PTH = 4 * NR;            // tile: 32 x (4 waves x NR rows)
+    constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
+    constexpr int P = 10;                            // LDS pixel pitch (floats): lanes 2 pixels apart -> all 32 banks
+    constexpr int TOTAL = HPIX * 2, ITERS = (TOTAL + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[HPIX * P];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // filter fragments: row l15 = (h, co), k-slot lq owns cin 2*lq, 2*lq+1
+    float wr[3][4][2];
+    {
+        const int h = l15 >> 3, co = l15 & 7;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ux = 0; ux < 4; ++ux)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kx = ux - h, ci = 2 * lq + e;
+                    const bool ok = kx >= 0 && kx <= 2 && ci < a.Cin && co < a.Cout;
+                    const float v = a.w[((size_t)(dy * 3 + (ok ? kx : 0)) * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? co : 0)];
+                    wr[dy][ux][e] = ok ? v : 0.f;
+                }
+    }
+    const float* rd = tile + ((wave * NR) * TWH + 2 * l15) * P + 2 * lq;
+
+    // epilogue constants: lane (pair column l15, k-slot lq) holds rows 4*lq + r = (h = lq >> 1, couts 4*(lq & 1) + r)
+    const int eh = lq >> 1, ec = 4 * (lq & 1);
+    const bool c_ok = ec < a.Cout;
+    const size_t q_out = view_chan_off(a.out, c_ok ? ec : 0);
+    const size_t q_add = a.add.p ? view_chan_off(a.add, c_ok ? ec : 0) : 0;
+    const size_t q_mask = a.mask.p ? view_chan_off(a.mask, c_ok ? ec : 0) : 0;
+    const float4 bias_v = (a.bias && c_ok) ? *reinterpret_cast<const float4*>(a.bias + ec) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int t = blockIdx.x; t < a.tiles_x * a.tiles_y * a.in.N; t += gridDim.x) {
+        const int q = fast_div(t, a.m_txy[0]);
+        const int bx = t - q * a.tiles_x;
+        const int n = fast_div(q, a.m_txy[1]);
+        const int by = q - n * a.tiles_y;
+        const int x0 = bx * PTW, y0 = by * PTH;
+        {
+            float4 r[ITERS];
+            unsigned m[ITERS];
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                const int e = tid + u * 256;
+                const int pix = e >> 1, c4 = e & 1;
+                const int hy = pix / TWH, hx = pix - hy * TWH;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool cok = ok && c4 * 4 < a.Cin;
+                const size_t off = (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld +
+                                   (cok ? c4 * 4 : 0);
+                r[u] = *reinterpret_cast<const float4*>(a.in.p + off);
+                m[u] = valid4(c4 * 4, a.Cin, ok);
+            }
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                const int e = tid + u * 256;
+                if (e < TOTAL) {
+                    const float4 v = mask4(r[u], m[u]);
+                    float2* d = reinterpret_cast<float2*>(tile + (size_t)(e >> 1) * P + (e & 1) * 4);
+                    d[0] = make_float2(v.x, v.y);
+                    d[1] = make_float2(v.z, v.w);
+                }
+            }
+        }
+        __syncthreads();
+
+        f32x4 acc[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rho = 0; rho < NR + 2; ++rho) {
+            if (rho % 2 == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ux = 0; ux < 4; ++ux) {
+                const float2 v = *reinterpret_cast<const float2*>(rd + (rho * TWH + ux) * P);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = rho - dy;
+                    if (r >= 0 && r < NR) {
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][0], v.x, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][1], v.y, acc[r], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int gx = x0 + 2 * l15 + eh;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int gy = y0 + wave * NR + i;
+            if (c_ok && gy < a.H && gx < a.W) {
+                float4 v = make_float4(acc[i][0] + bias_v.x, acc[i][1] + bias_v.y, acc[i][2] + bias_v.z, acc[i][3] + bias_v.w);
+                if (a.add.p) {
+                    const float4 ad = *reinterpret_cast<const float4*>(a.add.p + view_pix_base(a.add, n, gy, gx) + q_add);
+                    v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                }
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (a.mask.p) {
+                    const float4 mk = *reinterpret_cast<const float4*>(a.mask.p + view_pix_base(a.mask, n, gy, gx) + q_mask);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                float4* dst = reinterpret_cast<float4*>(a.out.p + view_pix_base(a.out, n, gy, gx) + q_out);
+                if (a.accumulate) {
+                    const float4 old = *dst;
+                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                }
+                *dst = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NR>
+void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
+    p.tiles_x = cdiv(p.W, 32);
+    p.tiles_y = cdiv(p.H, 4 * NR);
+    p.m_txy[0] = div_magic(p.tiles_x);
+    p.m_txy[1] = div_magic(p.tiles_y);
+    const int ntiles = p.tiles_x * p.tiles_y * N;
+    if (ntiles == 0) return;
+    const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_kernel<NR>>(256));
+    const double px = (double)N * p.H * p.W;
+    ProfScope ps(s, "conv_narrow_pair<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
+                 4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+    hipLaunchKernelGGL((conv_narrow_pair_kernel<NR>), dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -331,6 +475,16 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.dbg = 0; p.CK = 0; p.TPS = 1;
+    // <= 8 x <= 8 channels with float4-able outputs: two pixels per MFMA column (1.5x fewer MFMAs, all lanes store)
+    const bool pair_ok = in.C <= 8 && out.C <= 8 && (out.C & 3) == 0 && out.vec && (!ep.add.p || ep.add.vec) &&
+                         (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) && !getenv("DL4DS_NO_PAIR");
+    if (pair_ok) {
+#ifndef NARROW_PAIR_ROWS
+#define NARROW_PAIR_ROWS 4
+#endif
+        launch_narrow_pair<NARROW_PAIR_ROWS>(s, p, in.N);
+        return true;
+    }
     if (in.C <= 8) launch_narrow<8>(s, p, in.N);
     else launch_narrow<16>(s, p, in.N);
     return true;

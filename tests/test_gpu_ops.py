@@ -45,6 +45,8 @@ CONV_CASES = [
     # register-resident-filter MFMA path (conv_narrow.hip): Cin, Cout <= 16, Cin % 4 == 0
     (2, 40, 35, 8, 8, 3), (1, 33, 20, 16, 12, 3), (2, 70, 18, 4, 16, 3), (1, 64, 64, 12, 8, 3), (1, 5, 3, 8, 16, 3),
     (6, 32, 16, 16, 16, 3),
+    # ... and its two-pixels-per-MFMA-column variant (Cin <= 8, Cout in {4, 8}): ragged 32x16 tiles
+    (2, 21, 70, 8, 8, 3), (1, 9, 33, 4, 8, 3), (1, 17, 40, 8, 4, 3), (1, 5, 3, 4, 4, 3), (3, 33, 31, 8, 8, 3),
     # streamed-filter MFMA path (conv_stream.hip): Cin >= 16, Cin % 4 == 0, Cout % 4 == 0, H*W >= 256
     (1, 16, 16, 48, 48, 3), (2, 20, 33, 48, 192, 3), (1, 16, 16, 192, 48, 3), (1, 17, 19, 24, 32, 3),
     (1, 18, 16, 32, 64, 3), (1, 16, 17, 64, 24, 3), (1, 16, 16, 96, 40, 3), (2, 32, 32, 40, 40, 3), (1, 16, 16, 20, 36, 3),
@@ -94,6 +96,20 @@ def test_conv2d_stream_tall_tiles_depth_to_space(ops, monkeypatch):
     dz = R(n, h * r, w * r, co // (r * r))
     gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
     close(ops.conv2d_dgrad(dz, wt, d2s=r), gx)
+
+
+@pytest.mark.parametrize('ci,co', [(8, 8), (4, 8), (8, 4)])
+def test_conv2d_fused_epilogues_pair_path(ops, ci, co):
+    n, h, w = 2, 19, 45
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    close(ops.conv2d(x, wt, b, relu=True), np.maximum(ref, 0))
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
 
 
 @pytest.mark.parametrize('ci,co', [(8, 1), (1, 8), (1, 1), (3, 2)])
