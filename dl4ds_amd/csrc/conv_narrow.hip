@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
                 }
     }
     const float* rd = tile + ((wave * NR) * TWH + 2 * l15) * P + 2 * lq;
+    const bool vec_in = a.in.vec != 0;               // uniform
 
     // epilogue constants: lane (pair column l15, k-slot lq) holds rows 4*lq + r = (h = lq >> 1, couts 4*(lq & 1) + r)
     const int eh = lq >> 1, ec = 4 * (lq & 1);
@@ -196,18 +197,36 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
         {
             float4 r[ITERS];
             unsigned m[ITERS];
+            // the vec / scalar choice is made OUTSIDE the unrolled load loops: a (uniform) branch per load keeps the
+            // loads in separate basic blocks and cost 13 % on the aligned case
+            if (vec_in) {
 #pragma unroll
-            for (int u = 0; u < ITERS; ++u) {
-                const int e = tid + u * 256;
-                const int pix = e >> 1, c4 = e & 1;
-                const int hy = pix / TWH, hx = pix - hy * TWH;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                const bool cok = ok && c4 * 4 < a.Cin;
-                const size_t off = (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld +
-                                   (cok ? c4 * 4 : 0);
-                r[u] = *reinterpret_cast<const float4*>(a.in.p + off);
-                m[u] = valid4(c4 * 4, a.Cin, ok);
+                for (int u = 0; u < ITERS; ++u) {
+                    const int e = tid + u * 256;
+                    const int pix = e >> 1, c4 = e & 1;
+                    const int hy = pix / TWH, hx = pix - hy * TWH;
+                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                    const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    const bool cok = ok && c4 * 4 < a.Cin;
+                    const size_t off = (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld +
+                                       (cok ? c4 * 4 : 0);
+                    r[u] = *reinterpret_cast<const float4*>(a.in.p + off);
+                    m[u] = valid4(c4 * 4, a.Cin, ok);
+                }
+            } else {
+                // Cin not a multiple of 4 (e.g. the 5 + 1 input channels of the U-Net): four clamped scalar loads
+#pragma unroll
+                for (int u = 0; u < ITERS; ++u) {
+                    const int e = tid + u * 256;
+                    const int pix = e >> 1, c4 = e & 1;
+                    const int hy = pix / TWH, hx = pix - hy * TWH;
+                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                    const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    const float* px = a.in.p + (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld;
+                    const int cm = a.Cin - 1;
+                    r[u] = make_float4(px[min(c4 * 4, cm)], px[min(c4 * 4 + 1, cm)], px[min(c4 * 4 + 2, cm)], px[min(c4 * 4 + 3, cm)]);
+                    m[u] = valid4(c4 * 4, a.Cin, ok);
+                }
             }
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) {
@@ -302,7 +321,7 @@ struct NarrowWgradParams {
     unsigned m_tx, m_ty;
 };
 
-template <int PZ>     // dz channels per pixel in LDS: 8 (Cout <= 8) or 16
+template <int PZ, bool XVEC>     // PZ: dz channels per pixel in LDS: 8 (Cout <= 8) or 16; XVEC: x is float4-loadable
 __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowWgradParams a) {
     constexpr int TWH = NTW + 2, THH = NTH + 2, HPIX = TWH * THH;
     constexpr int XQ = HPIX * 2;                        // float4s in the x halo tile (8 channels per pixel)
@@ -338,31 +357,59 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
         {
             float4 xr[XIT], zr[ZIT];
             unsigned xm[XIT], zm[ZIT];
+            if constexpr (XVEC) {
 #pragma unroll
-            for (int u = 0; u < XIT; ++u) {
-                const int e = tid + u * 256;
-                const int pix = e >> 1, c4 = e & 1;
-                const int hy = pix / TWH, hx = pix - hy * TWH;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                const bool ok = e < XQ && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                const bool cok = ok && c4 * 4 < a.Cin;
-                const size_t off = (size_t)n * a.x.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.x.ld +
-                                   (cok ? c4 * 4 : 0);
-                xr[u] = *reinterpret_cast<const float4*>(a.x.p + off);
-                xm[u] = valid4(c4 * 4, a.Cin, ok);
-            }
+                for (int u = 0; u < XIT; ++u) {
+                    const int e = tid + u * 256;
+                    const int pix = e >> 1, c4 = e & 1;
+                    const int hy = pix / TWH, hx = pix - hy * TWH;
+                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                    const bool ok = e < XQ && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    const bool cok = ok && c4 * 4 < a.Cin;
+                    const size_t off = (size_t)n * a.x.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.x.ld +
+                                       (cok ? c4 * 4 : 0);
+                    xr[u] = *reinterpret_cast<const float4*>(a.x.p + off);
+                    xm[u] = valid4(c4 * 4, a.Cin, ok);
+                }
 #pragma unroll
-            for (int u = 0; u < ZIT; ++u) {
-                const int e = tid + u * 256;
-                const int pix = e / ZQ4, c4 = e - pix * ZQ4;
-                const int ry = pix / NTW, rx = pix - ry * NTW;
-                const int gy = y0 + ry, gx = x0 + rx;
-                const bool ok = e < ZQ && gy < a.H && gx < a.W;
-                const bool cok = ok && c4 * 4 < a.Cout;
-                const size_t off = (size_t)n * a.dz.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.dz.ld +
-                                   (cok ? c4 * 4 : 0);
-                zr[u] = *reinterpret_cast<const float4*>(a.dz.p + off);
-                zm[u] = valid4(c4 * 4, a.Cout, ok);
+                for (int u = 0; u < ZIT; ++u) {
+                    const int e = tid + u * 256;
+                    const int pix = e / ZQ4, c4 = e - pix * ZQ4;
+                    const int ry = pix / NTW, rx = pix - ry * NTW;
+                    const int gy = y0 + ry, gx = x0 + rx;
+                    const bool ok = e < ZQ && gy < a.H && gx < a.W;
+                    const bool cok = ok && c4 * 4 < a.Cout;
+                    const size_t off = (size_t)n * a.dz.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.dz.ld +
+                                       (cok ? c4 * 4 : 0);
+                    zr[u] = *reinterpret_cast<const float4*>(a.dz.p + off);
+                    zm[u] = valid4(c4 * 4, a.Cout, ok);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < XIT; ++u) {
+                    const int e = tid + u * 256;
+                    const int pix = e >> 1, c4 = e & 1;
+                    const int hy = pix / TWH, hx = pix - hy * TWH;
+                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                    const bool ok = e < XQ && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    const float* px = a.x.p + (size_t)n * a.x.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.x.ld;
+                    const int cm = a.Cin - 1;
+                    xr[u] = make_float4(px[min(c4 * 4, cm)], px[min(c4 * 4 + 1, cm)], px[min(c4 * 4 + 2, cm)], px[min(c4 * 4 + 3, cm)]);
+                    xm[u] = valid4(c4 * 4, a.Cin, ok);
+                }
+#pragma unroll
+                for (int u = 0; u < ZIT; ++u) {
+                    const int e = tid + u * 256;
+                    const int pix = e / ZQ4, c4 = e - pix * ZQ4;
+                    const int ry = pix / NTW, rx = pix - ry * NTW;
+                    const int gy = y0 + ry, gx = x0 + rx;
+                    const bool ok = e < ZQ && gy < a.H && gx < a.W;
+                    const bool cok = ok && c4 * 4 < a.Cout;
+                    const size_t off = (size_t)n * a.dz.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.dz.ld +
+                                       (cok ? c4 * 4 : 0);
+                    zr[u] = *reinterpret_cast<const float4*>(a.dz.p + off);
+                    zm[u] = valid4(c4 * 4, a.Cout, ok);
+                }
             }
 #pragma unroll
             for (int u = 0; u < XIT; ++u) {
@@ -432,7 +479,7 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
 }
 
 bool narrow_wgrad_eligible(const TView& x, const TView& dz, int KS) {
-    if (KS != 3 || x.C > 8 || dz.C > 16 || x.d2s > 1 || dz.d2s > 1 || !x.vec || !dz.vec) return false;
+    if (KS != 3 || x.C > 8 || dz.C > 16 || x.d2s > 1 || dz.d2s > 1 || !dz.vec) return false;    // x may be unaligned / Cin % 4 != 0
     return (long)cdiv(x.W, NTW) * cdiv(x.H, NTH) * x.N < (1l << 20);                   // fast_div range
 }
 
@@ -454,20 +501,28 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
     p.m_tx = div_magic(p.tiles_x);
     p.m_ty = div_magic(p.tiles_y);
     const bool wide = dz.C > 8;
-    const int resident = wide ? resident_blocks<conv_narrow_wgrad_kernel<16>>(256) : resident_blocks<conv_narrow_wgrad_kernel<8>>(256);
+    void (*kern)(const NarrowWgradParams) =
+        wide ? (x.vec ? conv_narrow_wgrad_kernel<16, true> : conv_narrow_wgrad_kernel<16, false>)
+             : (x.vec ? conv_narrow_wgrad_kernel<8, true> : conv_narrow_wgrad_kernel<8, false>);
+    const int resident = wide ? (x.vec ? resident_blocks<conv_narrow_wgrad_kernel<16, true>>(256) : resident_blocks<conv_narrow_wgrad_kernel<16, false>>(256))
+                              : (x.vec ? resident_blocks<conv_narrow_wgrad_kernel<8, true>>(256) : resident_blocks<conv_narrow_wgrad_kernel<8, false>>(256));
     const int blocks = std::max(1, std::min(std::min(max_slabs, p.ntiles), resident));
     const double px = (double)x.N * p.H * p.W;
     ProfScope ps(s, std::string("conv_narrow_wgrad<") + (wide ? "16>" : "8>"), 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * px * (p.Cin + p.Cout));
-    if (wide) hipLaunchKernelGGL((conv_narrow_wgrad_kernel<16>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_narrow_wgrad_kernel<8>), dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
     return blocks;
 }
 
 bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep) {
-    if (KS != 3 || in.C > 16 || out.C > 16 || in.d2s > 1 || !in.vec) return false;
+    if (KS != 3 || in.C > 16 || out.C > 16 || in.d2s > 1) return false;
+    // <= 8 x <= 8 channels with float4-able outputs: two pixels per MFMA column (1.5x fewer MFMAs, all lanes store);
+    // the only variant that also takes inputs whose channel count is not a multiple of 4
+    const bool pair_ok = in.C <= 8 && out.C <= 8 && (out.C & 3) == 0 && out.vec && (!ep.add.p || ep.add.vec) &&
+                         (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) && !getenv("DL4DS_NO_PAIR");
+    if (!in.vec && !pair_ok) return false;
     if ((long)cdiv(in.W, NTW) * cdiv(in.H, NTH) * in.N >= (1l << 20)) return false;    // fast_div range
     ConvParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
@@ -475,9 +530,6 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.dbg = 0; p.CK = 0; p.TPS = 1;
-    // <= 8 x <= 8 channels with float4-able outputs: two pixels per MFMA column (1.5x fewer MFMAs, all lanes store)
-    const bool pair_ok = in.C <= 8 && out.C <= 8 && (out.C & 3) == 0 && out.vec && (!ep.add.p || ep.add.vec) &&
-                         (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) && !getenv("DL4DS_NO_PAIR");
     if (pair_ok) {
 #ifndef NARROW_PAIR_ROWS
 #define NARROW_PAIR_ROWS 4

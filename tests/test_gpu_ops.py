@@ -47,6 +47,8 @@ CONV_CASES = [
     (6, 32, 16, 16, 16, 3),
     # ... and its two-pixels-per-MFMA-column variant (Cin <= 8, Cout in {4, 8}): ragged 32x16 tiles
     (2, 21, 70, 8, 8, 3), (1, 9, 33, 4, 8, 3), (1, 17, 40, 8, 4, 3), (1, 5, 3, 4, 4, 3), (3, 33, 31, 8, 8, 3),
+    # ... with channel counts that are not multiples of 4 on the input side (scalar staging loads)
+    (2, 21, 70, 5, 8, 3), (1, 16, 20, 6, 8, 3), (1, 9, 17, 3, 4, 3), (2, 12, 33, 7, 8, 3),
     # streamed-filter MFMA path (conv_stream.hip): Cin >= 16, Cin % 4 == 0, Cout % 4 == 0, H*W >= 256
     (1, 16, 16, 48, 48, 3), (2, 20, 33, 48, 192, 3), (1, 16, 16, 192, 48, 3), (1, 17, 19, 24, 32, 3),
     (1, 18, 16, 32, 64, 3), (1, 16, 17, 64, 24, 3), (1, 16, 16, 96, 40, 3), (2, 32, 32, 40, 40, 3), (1, 16, 16, 20, 36, 3),
@@ -98,7 +100,7 @@ def test_conv2d_stream_tall_tiles_depth_to_space(ops, monkeypatch):
     close(ops.conv2d_dgrad(dz, wt, d2s=r), gx)
 
 
-@pytest.mark.parametrize('ci,co', [(8, 8), (4, 8), (8, 4)])
+@pytest.mark.parametrize('ci,co', [(8, 8), (4, 8), (8, 4), (6, 8)])
 def test_conv2d_fused_epilogues_pair_path(ops, ci, co):
     n, h, w = 2, 19, 45
     x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
