@@ -1151,7 +1151,6 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = ((out.C & 3) == 0) && ((((uintptr_t)w) & 15) == 0);
-    p.dbg = getenv("DL4DS_CONV_DBG") ? atoi(getenv("DL4DS_CONV_DBG")) : 0;
     p.CK = 0; p.TPS = 1; p.tiles_x = p.tiles_y = 0;
     switch (KS) {
         case 1: dispatch_fwd<1>(s, p, in.N); break;

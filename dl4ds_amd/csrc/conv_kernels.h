@@ -32,7 +32,6 @@ struct ConvParams {
     int relu, accumulate;
     int wvec;
     unsigned m_txy[2];      // magic dividers for tiles_x, tiles_y
-    int dbg;                // ablation flags (DL4DS_CONV_DBG): 1 skip re-staging weights, 2 skip epilogue, 4 skip MFMA
 };
 
 // Epilogue shared by the forward/dgrad kernels.  The MFMA is issued as D = W^T-fragment x pixel-fragment, so with the

@@ -529,7 +529,7 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
     p.w = w; p.bias = ep.bias;
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
-    p.wvec = 0; p.dbg = 0; p.CK = 0; p.TPS = 1;
+    p.wvec = 0; p.CK = 0; p.TPS = 1;
     if (pair_ok) {
 #ifndef NARROW_PAIR_ROWS
 #define NARROW_PAIR_ROWS 4

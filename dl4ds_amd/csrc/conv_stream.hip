@@ -354,7 +354,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     p.w = w; p.bias = ep.bias;
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
-    p.wvec = 0; p.dbg = 0; p.CK = 4 * E; p.TPS = 0;
+    p.wvec = 0; p.CK = 4 * E; p.TPS = 0;
     if (tall) {
         p.CK = 4 * E8;
         if (E8 == 4) {
