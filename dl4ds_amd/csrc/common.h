@@ -129,6 +129,12 @@ __device__ __forceinline__ float4 view_load4_raw(const TView& v, int n, int y, i
     r.w = v.p[view_off(v, n, ys, xs, min(c + 3, v.C - 1))];
     return r;
 }
+// same for views known to be float4-loadable (v.vec checked by the caller): no scalar arm, a quarter of the registers
+__device__ __forceinline__ float4 view_load4_vec(const TView& v, int n, int y, int x, int c, bool pred) {
+    const int ys = pred ? y : 0, xs = pred ? x : 0;
+    const int cs = (pred && c < v.C) ? c : 0;
+    return *reinterpret_cast<const float4*>(v.p + view_off(v, n, ys, xs, cs));
+}
 // floats [co, co+4) of a row of `Cout` floats
 __device__ __forceinline__ float4 row_load4_raw(const float* row, int co, int Cout, bool vec, bool pred) {
     if (vec) return *reinterpret_cast<const float4*>(row + ((pred && co < Cout) ? co : 0));

@@ -1025,6 +1025,216 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradPara
     }
 }
 
+// Producer / consumer ("warp-specialised") form of the row-walking kernel: ONE 8-wave workgroup per CU; waves 0-3 run the
+// MFMAs of tile t out of LDS buffer t&1 while waves 4-7 stage tile t+1 (x halo + dz) into the other buffer; one barrier
+// per tile.  With two independent 4-wave workgroups per CU the staging phases were NOT hidden (measured: 1.72 ms as is,
+// 1.26 ms with the loads removed, and no re-ordering of the loads changed the sum) -- here the overlap is by
+// construction and the MFMA waves never issue a global load.
+template <int CIT, int WCO>
+__global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradParams a) {
+    constexpr int KS = 3, COT = 1;
+    constexpr int TW = 16, TH = 8;
+    constexpr int WK = 4 / WCO, RW = TH / WK;            // output rows per wave
+    constexpr int PAD = 1;
+    constexpr int TWH = TW + 2, THH = TH + 2, HPIX = TWH * THH;
+    constexpr int KK = 9;
+    constexpr int CIB = 16 * CIT, COB = 16 * WCO;
+    constexpr int PX = CIB + 4, PZ = COB + 4;
+    constexpr int NPIX = TW * TH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TILE_FLOATS = HPIX * PX + NPIX * PZ;          // one buffer: x halo tile [HPIX][PX] + dz tile [NPIX][PZ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave8 = tid >> 6;
+    const bool producer = wave8 >= 4;            // waves 4-7: staging only
+    const int wave = wave8 & 3, stid = tid & 255;
+    const int wco = wave % WCO, wk = wave / WCO;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ci0 = blockIdx.z * CIB;
+    const int co0 = blockIdx.y * COB;
+
+    const float* xf0 = smem + ((wk * RW) * TWH + lq * 4) * PX + l15;
+    const float* zf0 = smem + HPIX * PX + ((wk * RW) * TW + lq * 4) * PZ + wco * 16 + l15;
+
+    // staging (waves 4-7): the whole tile is requested at once (the staging waves hold no accumulators, so its 17 float4
+    // registers are free) and a full tile period ahead of its use
+    constexpr int XR = (HPIX * (CIB / 4) + 255) / 256, ZR = (NPIX * (COB / 4) + 255) / 256;
+    float4 xr[XR], zq[ZR];                          // (live in the staging waves only)
+    auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        n = t / a.tiles_y;
+        x0 = tx * TW;
+        y0 = ty * TH;
+    };
+    auto stage_load = [&](int tile) {
+        int n, y0, x0;
+        tile_origin(tile, n, y0, x0);
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            const int idx0 = stid + u * 256;
+            const bool ok = idx0 < HPIX * (CIB / 4);
+            const int idx = ok ? idx0 : 0;
+            const int pix = idx / (CIB / 4), q = idx - pix * (CIB / 4);
+            const int r = pix / TWH, c = pix - r * TWH;
+            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+            xr[u] = view_load4_vec(a.x, n, gy, gx, ci0 + q * 4,
+                                   ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin);
+        }
+#pragma unroll
+        for (int u = 0; u < ZR; ++u) {
+            const int idx0 = stid + u * 256;
+            const bool ok = idx0 < NPIX * (COB / 4);
+            const int idx = ok ? idx0 : 0;
+            const int pix = idx / (COB / 4), q = idx - pix * (COB / 4);
+            const int r = pix / TW, c = pix - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            zq[u] = view_load4_vec(a.dz, n, gy, gx, co0 + q * 4, ok && gy < a.H && gx < a.W && co0 + q * 4 < a.Cout);
+        }
+    };
+    auto stage_store = [&](int tile, int buf) {
+        float* x_tile = smem + buf * TILE_FLOATS;
+        float* z_tile = x_tile + HPIX * PX;
+        int n, y0, x0;
+        tile_origin(tile, n, y0, x0);
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            const int idx = stid + u * 256;
+            if (idx < HPIX * (CIB / 4)) {
+                const int pix = idx / (CIB / 4), q = idx - pix * (CIB / 4);
+                const int r = pix / TWH, c = pix - r * TWH;
+                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+                *reinterpret_cast<float4*>(x_tile + pix * PX + q * 4) =
+                    mask4(xr[u], valid4(ci0 + q * 4, a.Cin, gy >= 0 && gy < a.H && gx >= 0 && gx < a.W));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ZR; ++u) {
+            const int idx = stid + u * 256;
+            if (idx < NPIX * (COB / 4)) {
+                const int pix = idx / (COB / 4), q = idx - pix * (COB / 4);
+                const int r = pix / TW, c = pix - r * TW;
+                *reinterpret_cast<float4*>(z_tile + pix * PZ + q * 4) =
+                    mask4(zq[u], valid4(co0 + q * 4, a.Cout, y0 + r < a.H && x0 + c < a.W));
+            }
+        }
+    };
+    if (producer) {
+        // staging waves: own code path, so that their load registers never coexist with the 108 accumulator registers
+        // (issuing the loads a further tile ahead, across the barrier, measured 3 % slower than load + store per iteration)
+        if ((int)blockIdx.x < a.ntiles) { stage_load(blockIdx.x); stage_store(blockIdx.x, 0); }
+        __syncthreads();
+        int itp = 0;
+        for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S, ++itp) {
+            if (tile + a.S < a.ntiles) { stage_load(tile + a.S); stage_store(tile + a.S, (itp & 1) ^ 1); }
+            __syncthreads();
+        }
+        return;                                        // (finished waves no longer take part in barriers)
+    }
+    f32x4 acc[KK][CIT][COT];
+    float bsum[COT];
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) acc[t][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bsum[0] = 0.f;
+
+    __syncthreads();                                   // tile 0 is staged
+    int it = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S, ++it) {
+        const int buf = it & 1;
+        const float* xf = xf0 + buf * TILE_FLOATS;
+        const float* zf = zf0 + buf * TILE_FLOATS;
+        float zr[3][4];                 // dz fragments of the last three output rows (ring)
+#pragma unroll
+        for (int rr = 0; rr < RW + 2; ++rr) {          // input row wk*RW + rr of the halo tile
+            float fx[6][CIT];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) fx[c][i] = xf[(rr * TWH + c) * PX + i * 16];
+            if (rr < RW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zr[rr % 3][q] = zf[(rr * TW + q) * PZ];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (rr < RW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bsum[0] += zr[rr % 3][q];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int r = rr - ky;                  // output row fed through taps (ky, *)
+                if (r >= 0 && r < RW) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int i = 0; i < CIT; ++i)
+                                acc[ky * 3 + kx][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q + kx][i], zr[r % 3][q],
+                                                                                              acc[ky * 3 + kx][i][0], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                               // buffer `buf` is free, buffer `buf ^ 1` is filled
+    }
+    // K-split waves: pairwise tree reduction through LDS so the block emits ONE slab
+    if (WK > 1) {
+        constexpr int SLOTF = (KK * CIT * COT * 4 + COT) * 64;      // floats per wave image
+        for (int half = WK / 2; half >= 1; half >>= 1) {
+            __syncthreads();
+            if (wk >= half && wk < 2 * half) {
+                float* dst = smem + (size_t)((wk - half) * WCO + wco) * SLOTF + lane;
+                int o = 0;
+#pragma unroll
+                for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) { dst[o * 64] = acc[tp][i][0][rg]; ++o; }
+                dst[o * 64] = bsum[0];
+            }
+            __syncthreads();
+            if (wk < half) {
+                const float* src = smem + (size_t)(wk * WCO + wco) * SLOTF + lane;
+                int o = 0;
+#pragma unroll
+                for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) { acc[tp][i][0][rg] += src[o * 64]; ++o; }
+                bsum[0] += src[o * 64];
+            }
+        }
+        if (wk != 0) return;
+    }
+    // write the partial slab: D row = ci (lq*4+reg), col = co (l15)
+    const size_t nw = (size_t)KK * a.Cin * a.Cout;
+    float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
+    const int co = co0 + wco * 16 + l15;
+#pragma unroll
+    for (int tp = 0; tp < KK; ++tp)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ci = ci0 + i * 16 + lq * 4 + rg;
+                if (co < a.Cout && ci < a.Cin) slab[((size_t)tp * a.Cin + ci) * a.Cout + co] = acc[tp][i][0][rg];
+            }
+        }
+    if (blockIdx.z == 0) {
+        float v = bsum[0];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lq == 0 && co < a.Cout) slab[nw + co] = v;
+    }
+}
+
 // out0[e] (+)= sum_k partial[k*n + e] for e < n0 ; out1[e-n0] likewise for e >= n0.
 // One block reduces 16 consecutive elements: thread = (slab sub-index 0..15, element 0..15) -> 64-byte row
 // segments per slab, 16 slabs in flight per block, fixed summation order (deterministic).
@@ -1059,7 +1269,7 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
     }
 }
 
-struct WgradPlan { int S, CIT, WCO, WK, tiles_x, tiles_y, ntiles; };
+struct WgradPlan { int S, CIT, WCO, WK, tiles_x, tiles_y, ntiles; bool ws; };
 
 WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     WgradPlan p;
@@ -1073,7 +1283,9 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
     // every block does the same amount of work, so the grid should be exactly one residency round:
     // 256 CUs x 2 workgroups (LDS / VGPR limited) = 512 blocks.  768 blocks ran as 1.5 rounds (+33 % time).
-    int target = std::max(1, 512 / (cob * cib));
+    // (the producer/consumer rows kernel runs ONE 8-wave workgroup per CU)
+    p.ws = KS == 3 && !(p.CIT == 1 && p.WCO == 1) && x.vec && dz.vec && !getenv("DL4DS_NO_WGRAD_ROWS") && !getenv("DL4DS_NO_WGRAD_WS");
+    int target = std::max(1, (p.ws ? 256 : 512) / (cob * cib));
     const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
     const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (slab * sizeof(float)));
     p.S = (int)std::min<size_t>(std::min<size_t>(target, p.ntiles), cap);
@@ -1094,27 +1306,31 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     static const bool no_rows = getenv("DL4DS_NO_WGRAD_ROWS") != nullptr;
     constexpr bool ROWS_OK = (KS == 3) && !PF && COT == 1;
     const bool rows = ROWS_OK && !no_rows;
-    const size_t lds = rows ? std::max((size_t)(HPIX * (CIB + 4) + 128 * (COB + 4)) * sizeof(float), red_bytes)
+    const bool ws = rows && pl.ws;            // producer/consumer form: float4-loadable views, one workgroup per CU
+    const size_t lds = rows ? std::max((size_t)(ws ? 2 : 1) * (HPIX * (CIB + 4) + 128 * (COB + 4)) * sizeof(float), red_bytes)
                             : std::max((size_t)(PF ? 2 : 1) * (HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
     void (*kern)(const WgradParams) = conv_wgrad_kernel<KS, CIT, COT, WCO, PF>;
     if constexpr (ROWS_OK) {
-        if (rows) kern = conv_wgrad_rows_kernel<CIT, WCO>;
+        if (rows) kern = ws ? conv_wgrad_rows_ws_kernel<CIT, WCO> : conv_wgrad_rows_kernel<CIT, WCO>;
     }
     static std::once_flag once;
     std::call_once(once, [&]() {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, CIT, COT, WCO, PF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-        if constexpr (ROWS_OK)
+        if constexpr (ROWS_OK) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_ws_kernel<CIT, WCO>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax));
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<CIT, WCO>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+        }
     });
-    DL4DS_REQUIRE(lds <= (size_t)kLdsBudget, "wgrad tile does not fit in LDS");
+    DL4DS_REQUIRE(lds <= (size_t)(ws ? kLdsMax : kLdsBudget), "wgrad tile does not fit in LDS");
     dim3 grid((unsigned)pl.S, (unsigned)cdiv(p.Cout, COB), (unsigned)cdiv(p.Cin, CIB));
     const double px = (double)p.x.N * p.H * p.W;
     ProfScope ps(s, std::string(rows ? "conv_wgrad_rows<" : "conv_wgrad<") + std::to_string(KS) + "," + std::to_string(CIT) +
                         "," + std::to_string(COT) + "," + std::to_string(WCO) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(ws ? 512 : 256), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
