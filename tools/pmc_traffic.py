@@ -25,7 +25,7 @@ for k in fetch:
         args = ['3', args[0], '1', args[1]]  # kernel <CIT,WCO> -> bench.py's tag <KS,CIT,COT,WCO>
     elif m and m.group(1).startswith('conv_wgrad_kernel'):
         args = args[:4]                      # ... and <KS,CIT,COT,WCO> for wgrad (drop the prefetch flag)
-    tag = (m.group(1).replace('_kernel', '') + '<' + ','.join(args) + '>') if m else k[:60]
+    tag = (m.group(1).replace('_kernel', '').replace('rows_ws', 'rows') + '<' + ','.join(args) + '>') if m else k[:60]
     f = sum(fetch[k]) / len(fetch[k])
     w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
     out[tag] = {'launches': len(fetch[k]), 'fetch_kib_raw': f, 'write_kib_raw': w,
