@@ -250,6 +250,297 @@ Layout layout(int N, int H, int W, int C) {
     l.total = o;
     return l;
 }
+
+// ============================================================================================ multi-scale DSSIM
+// msdssim of dl4ds/losses.py:92-130 (+ the mixes :133-149): tf.image.ssim_multiscale with four scales.  Scale k is the
+// shifted image pair halved k times (2x2 average, odd sizes SYMMETRIC-padded = edge row/column repeated).  Per scale and
+// per (n, c): cs_k = mean contrast-structure, and on the last scale ssim_3 = mean luminance*cs; relu'd,
+//     ms[n,c] = cs_0^w0 * cs_1^w1 * cs_2^w2 * ssim_3^w3 ,  loss = weight * mean_n (1 - mean_c ms) / 2 .
+// Passes: pooled pyramids -> per-tile (ssim, cs) sums per scale -> per-(n,c) means -> one block combines them into the
+// loss and the upstream weights G -> per scale: derivative maps (moments recomputed, weighted by G) -> transposed filter
+// into a per-scale image gradient -> coarse-to-fine accumulation through the pooling adjoint -> dpred, plus the same
+// drange / min-shift fix-ups as the single-scale loss.  All reductions have a fixed order (deterministic).
+constexpr int MS_SCALES = 4;
+struct MsDims { int H[MS_SCALES], W[MS_SCALES]; };
+
+// dst (Hd, Wd) = 2x2 average of src (Hs, Ws) minus `shift` (scale 0 -> 1 applies the positivity shift), edge repeated
+__global__ void ms_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Hs, int Ws, int Hd, int Wd,
+                               int C, const Stats* __restrict__ st, int which) {      // which: 0 none, 1 y_true, 2 y_pred
+    const float sh = which == 1 ? (st->minT < 0.f ? st->minT : 0.f) : which == 2 ? (st->minP < 0.f ? st->minP : 0.f) : 0.f;
+    const size_t total = (size_t)N * Hd * Wd * C;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        size_t r = e / C;
+        const int x = (int)(r % Wd); r /= Wd;
+        const int y = (int)(r % Hd);
+        const int n = (int)(r / Hd);
+        const int y0 = 2 * y, y1 = min(2 * y + 1, Hs - 1), x0 = 2 * x, x1 = min(2 * x + 1, Ws - 1);
+        const float* b = src + (size_t)n * Hs * Ws * C + c;
+        const float v = b[((size_t)y0 * Ws + x0) * C] + b[((size_t)y0 * Ws + x1) * C] + b[((size_t)y1 * Ws + x0) * C] +
+                        b[((size_t)y1 * Ws + x1) * C];
+        dst[e] = 0.25f * v - sh;
+    }
+}
+
+// fine (Hs, Ws) += pooling adjoint of coarse (Hd, Wd): each of the four (possibly repeated) sources gets 1/4
+__global__ void ms_unpool_add_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int N, int Hs, int Ws, int Hd,
+                                     int Wd, int C) {
+    const size_t total = (size_t)N * Hs * Ws * C;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        size_t r = e / C;
+        const int x = (int)(r % Ws); r /= Ws;
+        const int y = (int)(r % Hs);
+        const int n = (int)(r / Hs);
+        const float wy = ((Hs & 1) && y == Hs - 1) ? 2.f : 1.f;      // the repeated edge row counts twice
+        const float wx = ((Ws & 1) && x == Ws - 1) ? 2.f : 1.f;
+        fine[e] += 0.25f * wy * wx * coarse[(((size_t)n * Hd + y / 2) * Wd + x / 2) * C + c];
+    }
+}
+
+// moments of one output pixel from the LDS tiles (shared by the sum and the maps pass)
+struct MsMoments { float mx, my, A, Bq; };
+__device__ __forceinline__ MsMoments ms_moments(const float (*sx)[TL + 1], const float (*sq)[TL + 1], int ly, int lx, const Gauss& gk) {
+    MsMoments m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KF; ++i) {
+        float rx = 0.f, ry = 0.f, ra = 0.f, rb = 0.f;
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            const float a = sx[ly + i][lx + j], q = sq[ly + i][lx + j], w = gk.g[j];
+            rx += w * a; ry += w * q; ra += w * a * q; rb += w * (a * a + q * q);
+        }
+        m.mx += gk.g[i] * rx; m.my += gk.g[i] * ry; m.A += gk.g[i] * ra; m.Bq += gk.g[i] * rb;
+    }
+    return m;
+}
+
+// MODE 0: partial[block] = (sum ssim, sum cs) of the tile.  MODE 1: derivative maps weighted by gs[n,c] (ssim) and gc[n,c]
+// (cs), partial[block] = (d/dc1, d/dc2).  x / q: scale images (scale 0: raw y_true / y_pred, shifted here).
+template <int MODE>
+__global__ void __launch_bounds__(256) ms_ssim_kernel(const float* __restrict__ x, const float* __restrict__ q, int raw, int H, int W,
+                                                      int C, int Ho, int Wo, int tiles_x, int tiles_y, Gauss gk,
+                                                      const Stats* __restrict__ st, const float* __restrict__ gs,
+                                                      const float* __restrict__ gc, float* __restrict__ dmu, float* __restrict__ da,
+                                                      float* __restrict__ db, float* __restrict__ partial) {
+    __shared__ float sx[TL][TL + 1], sq[TL][TL + 1];
+    __shared__ float red[2][256];
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const int c = b % C, n = b / C;
+    const float shT = (raw && st->minT < 0.f) ? st->minT : 0.f, shP = (raw && st->minP < 0.f) ? st->minP : 0.f;
+    const float drange = fmaxf(st->maxT, st->maxP) - fminf(st->minT, st->minP);
+    const float c1 = (0.01f * drange) * (0.01f * drange), c2 = (0.03f * drange) * (0.03f * drange);
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    for (int i = threadIdx.x; i < TL * TL; i += 256) {
+        const int r = i / TL, cc = i % TL;
+        const int y = oy0 + r, xx = ox0 + cc;
+        float a = 0.f, v = 0.f;
+        if (y < H && xx < W) {
+            const size_t o = (((size_t)n * H + y) * W + xx) * C + c;
+            a = x[o] - shT; v = q[o] - shP;
+        }
+        sx[r][cc] = a; sq[r][cc] = v;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    float r0 = 0.f, r1 = 0.f;
+    if (oy < Ho && ox < Wo) {
+        const MsMoments m = ms_moments(sx, sq, ly, lx, gk);
+        const float N1 = 2.f * m.mx * m.my + c1, D1 = m.mx * m.mx + m.my * m.my + c1;
+        const float N2 = 2.f * m.A - 2.f * m.mx * m.my + c2, D2 = m.Bq - m.mx * m.mx - m.my * m.my + c2;
+        const float lum = N1 / D1, cs = N2 / D2;
+        if (MODE == 0) {
+            r0 = lum * cs; r1 = cs;
+        } else {
+            const float inv_m = 1.f / ((float)Ho * (float)Wo);
+            const float ws = gs[n * C + c] * inv_m, wc = gc[n * C + c] * inv_m;
+            const float dcs_dmy = -2.f * m.mx / D2 + N2 * 2.f * m.my / (D2 * D2);
+            const float dlum_dmy = 2.f * m.mx / D1 - N1 * 2.f * m.my / (D1 * D1);
+            const size_t o = (((size_t)n * C + c) * Ho + oy) * Wo + ox;
+            dmu[o] = ws * (cs * dlum_dmy + lum * dcs_dmy) + wc * dcs_dmy;
+            da[o] = (ws * lum + wc) * 2.f / D2;
+            db[o] = -(ws * lum + wc) * N2 / (D2 * D2);
+            r0 = ws * cs * (D1 - N1) / (D1 * D1);                        // d/dc1
+            r1 = (ws * lum + wc) * (D2 - N2) / (D2 * D2);                // d/dc2
+        }
+    }
+    red[0][threadIdx.x] = r0; red[1][threadIdx.x] = r1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[(size_t)blockIdx.x * 2] = red[0][0]; partial[(size_t)blockIdx.x * 2 + 1] = red[1][0]; }
+}
+
+// mean_ssim[nc], mean_cs[nc] of one scale from its per-tile sums (tiles of a plane are consecutive blocks)
+__global__ void ms_means_kernel(const float* __restrict__ partial, int tiles, int NC, float inv_m, float* __restrict__ mean_ssim,
+                                float* __restrict__ mean_cs) {
+    const int nc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nc >= NC) return;
+    double a = 0, b = 0;
+    for (int k = 0; k < tiles; ++k) { a += partial[((size_t)nc * tiles + k) * 2]; b += partial[((size_t)nc * tiles + k) * 2 + 1]; }
+    mean_ssim[nc] = (float)(a * inv_m);
+    mean_cs[nc] = (float)(b * inv_m);
+}
+
+// one block: loss value and the upstream weights gs[k][nc] (only the last scale), gc[k][nc] (the other scales)
+__global__ void __launch_bounds__(256) ms_combine_kernel(const float* __restrict__ mean_ssim, const float* __restrict__ mean_cs, int NC,
+                                                         float weight, float* __restrict__ gs, float* __restrict__ gc,
+                                                         float* __restrict__ loss_out, int accumulate_loss) {
+    const float pw[MS_SCALES] = {0.0448f, 0.2856f, 0.3001f, 0.2363f};
+    __shared__ double red[256];
+    double acc = 0;
+    for (int nc = threadIdx.x; nc < NC; nc += 256) {
+        float v[MS_SCALES], ms = 1.f;
+#pragma unroll
+        for (int k = 0; k < MS_SCALES; ++k) {
+            v[k] = fmaxf(k == MS_SCALES - 1 ? mean_ssim[k * NC + nc] : mean_cs[k * NC + nc], 0.f);
+            ms *= powf(v[k], pw[k]);
+        }
+        acc += ms;
+        const float up = -0.5f * weight / (float)NC;                       // dL/dms[n,c]
+#pragma unroll
+        for (int k = 0; k < MS_SCALES; ++k) {
+            const float g = v[k] > 0.f ? up * pw[k] * ms / v[k] : 0.f;
+            gs[k * NC + nc] = (k == MS_SCALES - 1) ? g : 0.f;
+            gc[k * NC + nc] = (k == MS_SCALES - 1) ? 0.f : g;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = weight * (0.5f - 0.5f * (float)(red[0] / NC));
+        loss_out[0] = accumulate_loss ? loss_out[0] + v : v;
+    }
+}
+
+// transposed 11x11 filter of the derivative maps -> gradient w.r.t. the scale's q image (stored, not accumulated)
+__global__ void __launch_bounds__(256) ms_bwd_kernel(const float* __restrict__ x, const float* __restrict__ q, int raw, int H, int W, int C,
+                                                     int Ho, int Wo, int tiles_x, int tiles_y, Gauss gk, const Stats* __restrict__ st,
+                                                     const float* __restrict__ dmu, const float* __restrict__ da,
+                                                     const float* __restrict__ db, float* __restrict__ gq) {
+    __shared__ float s1[TL][TL + 1], s2[TL][TL + 1], s3[TL][TL + 1];
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const int c = b % C, n = b / C;
+    const float shT = (raw && st->minT < 0.f) ? st->minT : 0.f, shP = (raw && st->minP < 0.f) ? st->minP : 0.f;
+    const int y0 = ty * TS, x0 = tx * TS;
+    for (int i = threadIdx.x; i < TL * TL; i += 256) {
+        const int r = i / TL, cc = i % TL;
+        const int oy = y0 - (KF - 1) + r, ox = x0 - (KF - 1) + cc;
+        float a = 0.f, bb = 0.f, d = 0.f;
+        if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+            const size_t o = (((size_t)n * C + c) * Ho + oy) * Wo + ox;
+            a = dmu[o]; bb = da[o]; d = db[o];
+        }
+        s1[r][cc] = a; s2[r][cc] = bb; s3[r][cc] = d;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+    const int y = y0 + ly, xx = x0 + lx;
+    if (y < H && xx < W) {
+        float T1 = 0.f, T2 = 0.f, T3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KF; ++i) {
+            float r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < KF; ++j) {
+                const float w = gk.g[j];
+                r1 += w * s1[ly + (KF - 1) - i][lx + (KF - 1) - j];
+                r2 += w * s2[ly + (KF - 1) - i][lx + (KF - 1) - j];
+                r3 += w * s3[ly + (KF - 1) - i][lx + (KF - 1) - j];
+            }
+            T1 += gk.g[i] * r1; T2 += gk.g[i] * r2; T3 += gk.g[i] * r3;
+        }
+        const size_t o = (((size_t)n * H + y) * W + xx) * C + c;
+        gq[o] = T1 + (x[o] - shT) * T2 + 2.f * (q[o] - shP) * T3;
+    }
+}
+
+// dpred (+)= g0 ; partial[block] = sum of g0 over the block's elements (for the min-shift term)
+__global__ void __launch_bounds__(256) ms_apply_kernel(const float* __restrict__ g0, float* __restrict__ dpred, size_t n, int accumulate,
+                                                       float* __restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float g = g0[e];
+        dpred[e] = accumulate ? dpred[e] + g : g;
+        s += g;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// scalar fix-ups: drange enters every scale's c1, c2; the prediction's minimum shifts the whole image
+__global__ void __launch_bounds__(256) ms_finish_kernel(const float* __restrict__ sum_partial, int nb_sum, const float* __restrict__ gcp,
+                                                        int ng, const Stats* __restrict__ st, float* __restrict__ dpred) {
+    __shared__ double red[3][256];
+    double a = 0, g1 = 0, g2 = 0;
+    for (int k = threadIdx.x; k < nb_sum; k += 256) a += sum_partial[k];
+    for (int k = threadIdx.x; k < ng; k += 256) { g1 += gcp[(size_t)k * 2]; g2 += gcp[(size_t)k * 2 + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = g1; red[2][threadIdx.x] = g2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int j = 0; j < 3; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const float drange = fmaxf(st->maxT, st->maxP) - fminf(st->minT, st->minP);
+    const float ddr = (float)red[1][0] * 2.f * 0.01f * 0.01f * drange + (float)red[2][0] * 2.f * 0.03f * 0.03f * drange;
+    if (st->maxP > st->maxT) dpred[st->argmaxP] += ddr;
+    if (st->minP < st->minT) dpred[st->argminP] -= ddr;
+    if (st->minP < 0.f) dpred[st->argminP] -= (float)red[0][0];
+}
+
+struct MsLayout {
+    size_t stats, pf, pi, imgs, grads, maps, part, gcp, means, gw, total;
+    size_t img_off[MS_SCALES], grad_off[MS_SCALES], gcp_off[MS_SCALES];
+    MsDims d;
+    int nb_mm;
+};
+MsLayout ms_layout(int N, int H, int W, int C) {
+    MsLayout l;
+    l.d.H[0] = H; l.d.W[0] = W;
+    for (int k = 1; k < MS_SCALES; ++k) { l.d.H[k] = (l.d.H[k - 1] + 1) / 2; l.d.W[k] = (l.d.W[k - 1] + 1) / 2; }
+    l.nb_mm = 512;
+    size_t o = 0;
+    auto bump = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    l.stats = bump(sizeof(Stats));
+    l.pf = bump((size_t)l.nb_mm * 4 * sizeof(float));
+    l.pi = bump((size_t)l.nb_mm * 2 * sizeof(unsigned long long));
+    size_t img = 0, grad = 0, gcp = 0;
+    for (int k = 0; k < MS_SCALES; ++k) {
+        const size_t n = (size_t)N * l.d.H[k] * l.d.W[k] * C;
+        if (k > 0) { l.img_off[k] = img; img += 2 * n; } else l.img_off[k] = 0;      // x_k then q_k (k >= 1)
+        l.grad_off[k] = grad; grad += n;
+        l.gcp_off[k] = gcp;
+        gcp += (size_t)N * C * cdiv(l.d.H[k] - KF + 1, TS) * cdiv(l.d.W[k] - KF + 1, TS);
+    }
+    l.imgs = bump(img * sizeof(float));
+    l.grads = bump(grad * sizeof(float));
+    l.maps = bump(3 * (size_t)N * C * (H - KF + 1) * (W - KF + 1) * sizeof(float));
+    l.part = bump(std::max<size_t>((size_t)N * C * cdiv(H - KF + 1, TS) * cdiv(W - KF + 1, TS) * 2, 4096) * sizeof(float));
+    l.gcp = bump(gcp * 2 * sizeof(float));
+    l.means = bump((size_t)2 * MS_SCALES * N * C * sizeof(float));
+    l.gw = bump((size_t)2 * MS_SCALES * N * C * sizeof(float));
+    l.total = o;
+    return l;
+}
 }  // namespace
 
 size_t dssim_workspace_bytes(int N, int H, int W, int C) { return layout(N, H, W, C).total; }
@@ -291,5 +582,88 @@ void dssim_forward_backward(hipStream_t s, const float* y_true, const float* y_p
     }
     hipLaunchKernelGGL(dssim_finish_kernel, dim3(1), dim3(256), 0, s, part, nbb, st, weight, inv_m, coef, dpred, loss_out,
                        accumulate_loss);
+    HIP_CHECK(hipGetLastError());
+}
+
+size_t msdssim_workspace_bytes(int N, int H, int W, int C) { return ms_layout(N, H, W, C).total; }
+
+void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y_pred, float* dpred, int N, int H, int W, int C,
+                              float weight, float* loss_out, int accumulate_loss, float* workspace, size_t workspace_bytes) {
+    DL4DS_REQUIRE(((H + 7) / 8) >= KF && ((W + 7) / 8) >= KF,
+                  "msdssim needs grids of at least 81x81 (four scales, 11-tap filter on the coarsest)");
+    const MsLayout l = ms_layout(N, H, W, C);
+    DL4DS_REQUIRE(workspace_bytes >= l.total, "msdssim workspace too small");
+    char* base = reinterpret_cast<char*>(workspace);
+    Stats* st = reinterpret_cast<Stats*>(base + l.stats);
+    float* pf = reinterpret_cast<float*>(base + l.pf);
+    unsigned long long* pi = reinterpret_cast<unsigned long long*>(base + l.pi);
+    float* imgs = reinterpret_cast<float*>(base + l.imgs);
+    float* grads = reinterpret_cast<float*>(base + l.grads);
+    float* maps = reinterpret_cast<float*>(base + l.maps);
+    float* part = reinterpret_cast<float*>(base + l.part);
+    float* gcp = reinterpret_cast<float*>(base + l.gcp);
+    float* means = reinterpret_cast<float*>(base + l.means);       // [ssim: scales x NC][cs: scales x NC]
+    float* gw = reinterpret_cast<float*>(base + l.gw);             // [gs: scales x NC][gc: scales x NC]
+    const int NC = N * C;
+    const size_t n0 = (size_t)N * H * W * C;
+    static const Gauss gk = make_gauss();
+    ProfScope ps(s, "msdssim", 0.0, 4.0 * (double)n0 * 12);
+    const int nb = (int)std::min<size_t>(l.nb_mm, cdivz(n0, 256));
+    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n0, pf, pi);
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(64), 0, s, pf, pi, nb, st);
+    auto ew = [](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 8192)); };
+    const float* xk[MS_SCALES];
+    const float* qk[MS_SCALES];
+    xk[0] = y_true; qk[0] = y_pred;
+    // ---- pyramids
+    for (int k = 1; k < MS_SCALES; ++k) {
+        const size_t n = (size_t)N * l.d.H[k] * l.d.W[k] * C;
+        float* xd = imgs + l.img_off[k];
+        float* qd = xd + n;
+        hipLaunchKernelGGL(ms_pool_kernel, dim3(ew(n)), dim3(256), 0, s, xk[k - 1], xd, N, l.d.H[k - 1], l.d.W[k - 1], l.d.H[k],
+                           l.d.W[k], C, st, k == 1 ? 1 : 0);
+        hipLaunchKernelGGL(ms_pool_kernel, dim3(ew(n)), dim3(256), 0, s, qk[k - 1], qd, N, l.d.H[k - 1], l.d.W[k - 1], l.d.H[k],
+                           l.d.W[k], C, st, k == 1 ? 2 : 0);
+        xk[k] = xd; qk[k] = qd;
+    }
+    // ---- per-scale (ssim, cs) means
+    for (int k = 0; k < MS_SCALES; ++k) {
+        const int Ho = l.d.H[k] - KF + 1, Wo = l.d.W[k] - KF + 1;
+        const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
+        hipLaunchKernelGGL(ms_ssim_kernel<0>, dim3(NC * txo * tyo), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, l.d.H[k], l.d.W[k],
+                           C, Ho, Wo, txo, tyo, gk, st, nullptr, nullptr, nullptr, nullptr, nullptr, part);
+        hipLaunchKernelGGL(ms_means_kernel, dim3(cdiv(NC, 64)), dim3(64), 0, s, part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo),
+                           means + (size_t)k * NC, means + (size_t)(MS_SCALES + k) * NC);
+    }
+    hipLaunchKernelGGL(ms_combine_kernel, dim3(1), dim3(256), 0, s, means, means + (size_t)MS_SCALES * NC, NC, weight, gw,
+                       gw + (size_t)MS_SCALES * NC, loss_out, accumulate_loss);
+    HIP_CHECK(hipGetLastError());
+    if (!dpred) return;
+    // ---- per-scale gradients (coarse to fine), pooled scales folded into the finer one
+    float* dmu = maps;
+    size_t gcp_total = 0;
+    for (int k = MS_SCALES - 1; k >= 0; --k) {
+        const int Hk = l.d.H[k], Wk = l.d.W[k], Ho = Hk - KF + 1, Wo = Wk - KF + 1;
+        const size_t msz = (size_t)NC * Ho * Wo;
+        float* da = dmu + msz;
+        float* db = da + msz;
+        const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
+        hipLaunchKernelGGL(ms_ssim_kernel<1>, dim3(NC * txo * tyo), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, Hk, Wk, C, Ho, Wo,
+                           txo, tyo, gk, st, gw + (size_t)k * NC, gw + (size_t)(MS_SCALES + k) * NC, dmu, da, db,
+                           gcp + l.gcp_off[k] * 2);
+        gcp_total = std::max(gcp_total, l.gcp_off[k] + (size_t)NC * txo * tyo);
+        const int txi = cdiv(Wk, TS), tyi = cdiv(Hk, TS);
+        float* gk_img = grads + l.grad_off[k];
+        hipLaunchKernelGGL(ms_bwd_kernel, dim3(NC * txi * tyi), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, Hk, Wk, C, Ho, Wo, txi,
+                           tyi, gk, st, dmu, da, db, gk_img);
+        if (k < MS_SCALES - 1) {
+            const size_t n = (size_t)N * Hk * Wk * C;
+            hipLaunchKernelGGL(ms_unpool_add_kernel, dim3(ew(n)), dim3(256), 0, s, gk_img, grads + l.grad_off[k + 1], N, Hk, Wk,
+                               l.d.H[k + 1], l.d.W[k + 1], C);
+        }
+    }
+    const int nba = (int)std::min<size_t>(cdivz(n0, 256), 2048);
+    hipLaunchKernelGGL(ms_apply_kernel, dim3(nba), dim3(256), 0, s, grads + l.grad_off[0], dpred, n0, 1, part);
+    hipLaunchKernelGGL(ms_finish_kernel, dim3(1), dim3(256), 0, s, part, nba, gcp, (int)gcp_total, st, dpred);
     HIP_CHECK(hipGetLastError());
 }

@@ -84,9 +84,13 @@ void dssim_forward_backward(hipStream_t s, const float* y_true, const float* y_p
                             int C, float weight, float* loss_out, int accumulate_loss, float* workspace,
                             size_t workspace_bytes);
 size_t dssim_workspace_bytes(int N, int H, int W, int C);
+void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y_pred, float* dpred, int N, int H, int W,
+                              int C, float weight, float* loss_out, int accumulate_loss, float* workspace,
+                              size_t workspace_bytes);
+size_t msdssim_workspace_bytes(int N, int H, int W, int C);
 
-static void loss_weights(int kind, float& wd, float& wa, float& ws) {
-    wd = wa = ws = 0.f;
+static void loss_weights(int kind, float& wd, float& wa, float& ws, float& wm) {
+    wd = wa = ws = wm = 0.f;
     switch (kind) {
         case LOSS_MAE: wa = 1.f; break;
         case LOSS_MSE: ws = 1.f; break;
@@ -94,23 +98,27 @@ static void loss_weights(int kind, float& wd, float& wa, float& ws) {
         case LOSS_DSSIM_MAE: wd = 0.8f; wa = 0.2f; break;
         case LOSS_DSSIM_MSE: wd = 0.8f; ws = 0.2f; break;
         case LOSS_DSSIM_MAE_MSE: wd = 0.6f; wa = 0.2f; ws = 0.2f; break;
+        case LOSS_MSDSSIM: wm = 1.f; break;                                   // losses.py:92-130
+        case LOSS_MSDSSIM_MAE: wm = 0.8f; wa = 0.2f; break;                   // :133-139
+        case LOSS_MSDSSIM_MAE_MSE: wm = 0.6f; wa = 0.2f; ws = 0.2f; break;    // :142-149
         default: throw Dl4dsError("unknown loss kind " + std::to_string(kind));
     }
 }
 
 size_t loss_workspace_bytes(int kind, int N, int H, int W, int C) {
-    float wd, wa, ws;
-    loss_weights(kind, wd, wa, ws);
+    float wd, wa, ws, wm;
+    loss_weights(kind, wd, wa, ws, wm);
     size_t b = 2 * 1024 * sizeof(float);
     if (wd != 0.f) b += dssim_workspace_bytes(N, H, W, C);
+    if (wm != 0.f) b += msdssim_workspace_bytes(N, H, W, C);
     return b;
 }
 
 void loss_forward_backward(hipStream_t s, int kind, const float* y_true, const float* y_pred, float* dpred, int N,
                            int H, int W, int C, float scale, float* loss_out, int accumulate, float* workspace,
                            size_t workspace_bytes) {
-    float wd, wa, ws;
-    loss_weights(kind, wd, wa, ws);
+    float wd, wa, ws, wm;
+    loss_weights(kind, wd, wa, ws, wm);
     const size_t n = (size_t)N * H * W * C;
     DL4DS_REQUIRE(workspace_bytes >= loss_workspace_bytes(kind, N, H, W, C), "loss workspace too small");
     const int nb = loss_blocks(n);
@@ -125,6 +133,10 @@ void loss_forward_backward(hipStream_t s, int kind, const float* y_true, const f
     if (wd != 0.f) {
         dssim_forward_backward(s, y_true, y_pred, dpred, N, H, W, C, scale * wd, loss_out, 1, workspace + 2 * 1024,
                                workspace_bytes - 2 * 1024 * sizeof(float));
+    }
+    if (wm != 0.f) {
+        msdssim_forward_backward(s, y_true, y_pred, dpred, N, H, W, C, scale * wm, loss_out, 1, workspace + 2 * 1024,
+                                 workspace_bytes - 2 * 1024 * sizeof(float));
     }
 }
 

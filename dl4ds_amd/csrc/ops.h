@@ -89,7 +89,7 @@ size_t chatt_workspace_bytes(const AttShape& sh);
 
 // ----------------------------------------------------------------------- losses (losses.hip)
 enum LossKind { LOSS_MAE = 0, LOSS_MSE = 1, LOSS_DSSIM = 2, LOSS_DSSIM_MAE = 3, LOSS_DSSIM_MSE = 4,
-                LOSS_DSSIM_MAE_MSE = 5 };
+                LOSS_DSSIM_MAE_MSE = 5, LOSS_MSDSSIM = 6, LOSS_MSDSSIM_MAE = 7, LOSS_MSDSSIM_MAE_MSE = 8 };
 // loss_out[0] = scale * loss ; dpred (+)= scale * dloss/dpred.  y_true,y_pred: (N,H,W,C) contiguous.
 size_t loss_workspace_bytes(int kind, int N, int H, int W, int C);
 void loss_forward_backward(hipStream_t s, int kind, const float* y_true, const float* y_pred,

@@ -9,7 +9,8 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray
 
-LOSS_KINDS = {'mae': 0, 'mse': 1, 'dssim': 2, 'dssim_mae': 3, 'dssim_mse': 4, 'dssim_mae_mse': 5}
+LOSS_KINDS = {'mae': 0, 'mse': 1, 'dssim': 2, 'dssim_mae': 3, 'dssim_mse': 4, 'dssim_mae_mse': 5,
+              'msdssim': 6, 'msdssim_mae': 7, 'msdssim_mae_mse': 8}
 
 
 def _d(a):

@@ -50,8 +50,6 @@ def checkarg_loss(loss):
     if isinstance(loss, str):
         if loss not in LOSS_FUNCTIONS:
             raise ValueError(f'`loss` must be one of {LOSS_FUNCTIONS}, got {loss}')
-        if loss.startswith('msdssim'):
-            raise NotImplementedError('multi-scale DSSIM losses are not implemented on the MI355X path yet')
         return loss
     raise TypeError(f'`loss` must be a string, one of {LOSS_FUNCTIONS}')
 

@@ -94,7 +94,8 @@ int dl4ds_op_chatt_fwd(const float* x_dev, float* y_dev, int G, int R, int P, in
 int dl4ds_op_chatt_bwd(const float* x_dev, const float* dy_dev, float* dx_dev, int G, int R, int P, int C, int Cr,
                        const float* w1_dev, const float* w2_dev, const float* saved_dev, float* dw1_dev,
                        float* db1_dev, float* dw2_dev, float* db2_dev);
-/* dl4ds/losses.py:5-89.  kind: 0 mae 1 mse 2 dssim 3 dssim_mae 4 dssim_mse 5 dssim_mae_mse.
+/* dl4ds/losses.py:5-149.  kind: 0 mae 1 mse 2 dssim 3 dssim_mae 4 dssim_mse 5 dssim_mae_mse
+ * 6 msdssim 7 msdssim_mae 8 msdssim_mae_mse (tf.image.ssim_multiscale, four scales: grids of at least 81x81).
  * loss_dev[0] = loss ; dpred_dev = dloss/dpred (may be NULL). */
 int dl4ds_op_loss(int kind, const float* y_true_dev, const float* y_pred_dev, float* dpred_dev, int N, int H,
                   int W, int C, float* loss_dev);

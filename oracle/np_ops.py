@@ -332,6 +332,72 @@ def dssim_mae_mse(y_true, y_pred):
     return 0.6 * dssim(y_true, y_pred) + 0.2 * mae(y_true, y_pred) + 0.2 * mse(y_true, y_pred)
 
 
+MS_POWER_FACTORS = (0.0448, 0.2856, 0.3001, 0.2363)      # losses.py:126 (four of Wang et al.'s five scales)
+
+
+def _ssim_per_channel(img1, img2, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    """tf.image's _ssim_per_channel: (mean luminance*cs, mean cs) over the VALID region, each (N, C)."""
+    g = _gauss_kernel(filter_size, filter_sigma, img1.dtype)
+    c1 = (k1 * max_val) ** 2
+    c2 = (k2 * max_val) ** 2
+    mean0 = _valid_depthwise(img1, g)
+    mean1 = _valid_depthwise(img2, g)
+    num0 = mean0 * mean1 * 2.0
+    den0 = mean0 ** 2 + mean1 ** 2
+    lum = (num0 + c1) / (den0 + c1)
+    num1 = _valid_depthwise(img1 * img2, g) * 2.0
+    den1 = _valid_depthwise(img1 ** 2 + img2 ** 2, g)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return (lum * cs).mean(axis=(1, 2)), cs.mean(axis=(1, 2))
+
+
+def _downsample2_symmetric(x):
+    """tf.image.ssim_multiscale's downsampling: SYMMETRIC-pad odd sizes at the bottom/right, then 2x2 VALID average."""
+    n, h, w, c = x.shape
+    if (h % 2) or (w % 2):
+        x = np.pad(x, ((0, 0), (0, h % 2), (0, w % 2), (0, 0)), mode='symmetric')
+        n, h, w, c = x.shape
+    return x.reshape(n, h // 2, 2, w // 2, 2, c).mean(axis=(2, 4))
+
+
+def ssim_multiscale(img1, img2, max_val, power_factors=MS_POWER_FACTORS, filter_size=11, filter_sigma=1.5, k1=0.01,
+                    k2=0.03):
+    """tf.image.ssim_multiscale (third-party in the reference; algorithm as published in TF's image_ops_impl.py):
+    per scale k (image halved k times) cs_k = relu(mean cs); the last scale contributes relu(mean ssim) instead;
+    ms_ssim[n, c] = prod_k value_k ** power_factors[k]; result = mean over channels -> (N,)."""
+    imgs = [img1, img2]
+    mcs = []
+    for k in range(len(power_factors)):
+        if k > 0:
+            imgs = [_downsample2_symmetric(x) for x in imgs]
+        ssim_pc, cs = _ssim_per_channel(imgs[0], imgs[1], max_val, filter_size, filter_sigma, k1, k2)
+        mcs.append(np.maximum(cs, 0))
+    mcs.pop()
+    vals = np.stack(mcs + [np.maximum(ssim_pc, 0)], axis=-1)              # (N, C, scales)
+    ms = np.prod(vals ** np.asarray(power_factors, vals.dtype), axis=-1)
+    return ms.mean(axis=-1)
+
+
+def msdssim(y_true, y_pred):
+    """losses.py:92-130."""
+    maxv = max(y_true.max(), y_pred.max())
+    minv = min(y_true.min(), y_pred.min())
+    drange = maxv - minv
+    yt = y_true - y_true.min() if y_true.min() < 0 else y_true
+    yp = y_pred - y_pred.min() if y_pred.min() < 0 else y_pred
+    return ((1 - ssim_multiscale(yt, yp, drange)) / 2.0).mean()
+
+
+def msdssim_mae(y_true, y_pred):
+    """losses.py:133-139."""
+    return 0.8 * msdssim(y_true, y_pred) + 0.2 * mae(y_true, y_pred)
+
+
+def msdssim_mae_mse(y_true, y_pred):
+    """losses.py:142-149."""
+    return 0.6 * msdssim(y_true, y_pred) + 0.2 * mae(y_true, y_pred) + 0.2 * mse(y_true, y_pred)
+
+
 def bce(y_true, p):
     """tf.keras.losses.BinaryCrossentropy(from_logits=False), cgan.py:546-549,567-571:
     p clipped to [eps, 1-eps], eps=1e-7; mean over all elements."""

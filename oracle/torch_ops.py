@@ -262,6 +262,66 @@ def dssim(y_true, y_pred):
     return ((1 - s) / 2.0).mean()
 
 
+MS_POWER_FACTORS = (0.0448, 0.2856, 0.3001, 0.2363)
+
+
+def _ssim_per_channel(img1, img2, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    g = _gauss_kernel(filter_size, filter_sigma, img1.dtype)
+    c1 = (k1 * max_val) ** 2
+    c2 = (k2 * max_val) ** 2
+    mean0 = _valid_depthwise(img1, g)
+    mean1 = _valid_depthwise(img2, g)
+    num0 = mean0 * mean1 * 2.0
+    den0 = mean0 ** 2 + mean1 ** 2
+    lum = (num0 + c1) / (den0 + c1)
+    num1 = _valid_depthwise(img1 * img2, g) * 2.0
+    den1 = _valid_depthwise(img1 ** 2 + img2 ** 2, g)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return (lum * cs).mean(dim=(1, 2)), cs.mean(dim=(1, 2))
+
+
+def _downsample2_symmetric(x):
+    n, h, w, c = x.shape
+    if h % 2:
+        x = torch.cat([x, x[:, -1:]], dim=1)          # SYMMETRIC pad of one row repeats the edge row
+    if w % 2:
+        x = torch.cat([x, x[:, :, -1:]], dim=2)
+    n, h, w, c = x.shape
+    return x.reshape(n, h // 2, 2, w // 2, 2, c).mean(dim=(2, 4))
+
+
+def ssim_multiscale(img1, img2, max_val, power_factors=MS_POWER_FACTORS, filter_size=11, filter_sigma=1.5, k1=0.01,
+                    k2=0.03):
+    imgs = [img1, img2]
+    mcs = []
+    for k in range(len(power_factors)):
+        if k > 0:
+            imgs = [_downsample2_symmetric(x) for x in imgs]
+        ssim_pc, cs = _ssim_per_channel(imgs[0], imgs[1], max_val, filter_size, filter_sigma, k1, k2)
+        mcs.append(torch.relu(cs))
+    mcs.pop()
+    vals = torch.stack(mcs + [torch.relu(ssim_pc)], dim=-1)
+    pf = torch.as_tensor(power_factors, dtype=vals.dtype)
+    return torch.prod(vals ** pf, dim=-1).mean(dim=-1)
+
+
+def msdssim(y_true, y_pred):
+    maxv = torch.maximum(y_true.max(), y_pred.max())
+    minv = torch.minimum(y_true.min(), y_pred.min())
+    drange = maxv - minv
+    yt = y_true - y_true.min() if y_true.min() < 0 else y_true
+    yp = y_pred - y_pred.min() if y_pred.min() < 0 else y_pred
+    return ((1 - ssim_multiscale(yt, yp, drange)) / 2.0).mean()
+
+
+def msdssim_mae(y_true, y_pred):
+    return 0.8 * msdssim(y_true, y_pred) + 0.2 * mae(y_true, y_pred)
+
+
+def msdssim_mae_mse(y_true, y_pred):
+    return 0.6 * msdssim(y_true, y_pred) + 0.2 * mae(y_true, y_pred) + 0.2 * mse(y_true, y_pred)
+
+
 def dssim_mae(y_true, y_pred):
     return 0.8 * dssim(y_true, y_pred) + 0.2 * mae(y_true, y_pred)
 

@@ -331,3 +331,31 @@ def test_dssim_losses(ops, kind, case):
     a, g = ops.loss(kind, yt, yp)
     assert a == pytest.approx(float(lv.detach()), rel=2e-4, abs=1e-6)
     close(g, t.grad.numpy(), 1e-3)
+
+
+@pytest.mark.parametrize('kind', ['msdssim', 'msdssim_mae', 'msdssim_mae_mse'])
+@pytest.mark.parametrize('case', ['positive', 'negative_min', 'pred_sets_range', 'multichannel_odd'])
+def test_msdssim_losses(ops, kind, case):
+    """tf.image.ssim_multiscale-based losses (losses.py:92-149): four scales, odd sizes (SYMMETRIC padding of the
+    pooling), min-shift and dynamic-range gradients -- loss and gradient against the torch fp64 oracle."""
+    c = 2 if case == 'multichannel_odd' else 1
+    h, w = (93, 101) if case == 'multichannel_odd' else (96, 104)
+    yt = rng.random((2, h, w, c)).astype(np.float32)
+    yp = (yt + 0.1 * rng.standard_normal(yt.shape)).astype(np.float32)
+    if case == 'positive':
+        yp = np.abs(yp) + 0.01
+    elif case == 'negative_min':
+        yp = yp - 0.3
+        yt = yt - 0.1
+    elif case == 'pred_sets_range':
+        yp[1, 5, 7, 0] = 3.0
+        yp[0, 20, 3, 0] = -1.0
+    t = torch.tensor(yp, dtype=torch.float64, requires_grad=True)
+    lv = getattr(T, kind)(torch.tensor(yt, dtype=torch.float64), t)
+    lv.backward()
+    a, g = ops.loss(kind, yt, yp)
+    assert a == pytest.approx(float(lv.detach()), rel=2e-4, abs=1e-6)
+    close(g, t.grad.numpy(), 1e-3)
+    a2, g2 = ops.loss(kind, yt, yp)
+    assert a2 == a
+    np.testing.assert_array_equal(g, g2)                    # deterministic reductions

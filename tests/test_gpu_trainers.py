@@ -29,6 +29,18 @@ def test_supervised_trainer_and_predictor():
     assert y.shape == (8, 32, 32, 1) and y.dtype == np.float32 and np.isfinite(y).all()
 
 
+def test_supervised_trainer_msdssim_loss():
+    """loss='msdssim_mae' through the whole trainer (losses.py:133-139): HR grid 96 px so that all four scales hold
+    the 11-tap window; the loss must fall and stay finite."""
+    from dl4ds_amd.training import SupervisedTrainer
+    tr, va, te = _fields(16, 96, 0), _fields(4, 96, 1), _fields(4, 96, 2)
+    t = SupervisedTrainer('resnet', 'spc', tr, va, te, scale=2, batch_size=4, loss='msdssim_mae', epochs=4,
+                          learning_rate=2e-3, verbose=False, n_blocks=2, n_filters=8, save=False)
+    t.run()
+    assert np.isfinite(t.fithist['loss']).all() and t.fithist['loss'][-1] < t.fithist['loss'][0]
+    assert np.isfinite(t.test_loss)
+
+
 def test_supervised_trainer_spatiotemporal_pin():
     from dl4ds_amd.training import SupervisedTrainer
     tr, va, te = _fields(12, 16, 0), _fields(8, 16, 1), _fields(8, 16, 2)

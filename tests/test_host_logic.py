@@ -35,6 +35,7 @@ def test_checkargs_raise_like_the_reference():
     with pytest.raises(TypeError):
         U.checkarg_loss(None)
     assert U.checkarg_loss('dssim_mae') == 'dssim_mae'
+    assert U.checkarg_loss('msdssim_mae_mse') == 'msdssim_mae_mse'
     with pytest.raises(ValueError):
         U.checkarg_dropout_variant('bernoulli')
 

@@ -169,3 +169,24 @@ def test_activations_backends():
     for k in (None, 'relu', 'sigmoid', 'tanh', 'elu', 'leaky_relu', 'selu', 'gelu'):
         np.testing.assert_allclose(N.activation(x, k), T.to_numpy(T.activation(T.asarray(x), k)),
                                    rtol=1e-7, atol=1e-12, err_msg=str(k))
+
+
+def test_msdssim_numpy_matches_torch_and_known_answers():
+    """tf.image.ssim_multiscale restatement: numpy vs torch (independent conv / pooling code), identical images -> 0,
+    odd sizes use the edge-repeating (SYMMETRIC) padding before the 2x2 average."""
+    import torch
+    from oracle import torch_ops as T
+    rng = np.random.default_rng(4)
+    for shp in [(2, 96, 100, 1), (1, 89, 93, 2)]:
+        y = rng.standard_normal(shp)
+        p = y + 0.3 * rng.standard_normal(shp)
+        for name in ('msdssim', 'msdssim_mae', 'msdssim_mae_mse'):
+            a = getattr(N, name)(y, p)
+            b = float(getattr(T, name)(torch.tensor(y), torch.tensor(p)))
+            assert a == pytest.approx(b, rel=1e-10)
+        assert N.msdssim(y, y) == pytest.approx(0.0, abs=1e-12)
+    x = np.arange(15, dtype=np.float64).reshape(1, 3, 5, 1)
+    d = N._downsample2_symmetric(x)[0, :, :, 0]
+    assert d.shape == (2, 3)
+    assert d[1, 2] == pytest.approx(x[0, 2, 4, 0])          # corner: the edge pixel repeated four times
+    assert d[0, 2] == pytest.approx((x[0, 0, 4, 0] + x[0, 1, 4, 0]) / 2)
