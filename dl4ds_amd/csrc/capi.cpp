@@ -13,6 +13,7 @@
 // ---- internal functions defined in other translation units
 Trainer* trainer_create(Graph* g, int loss_kind, const AdamCfg& cfg);
 void graph_load_inputs(Graph& g, const float* const* inputs, int n_inputs, int B, bool is_host);
+void trainer_evaluate(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host);
 void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host,
                             bool reduce_across_ranks);
 void trainer_step(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host, float* loss_host);
@@ -292,6 +293,34 @@ int dl4ds_op_maxpool2_bwd(const float* x, const float* y, const float* dy, float
                       make_view(nc(dy), N, H / 2, W / 2, C), make_view(dx, N, H, W, C), acc);
     API_END
 }
+int dl4ds_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, size_t npix, int C, float eps,
+                           int relu) {
+    API_BEGIN
+    layernorm_forward(S(), x, gamma, beta, y, npix, C, eps, relu);
+    API_END
+}
+int dl4ds_op_layernorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, float* dx, float* dgamma,
+                           float* dbeta, size_t npix, int C, float eps, int relu, int accumulate) {
+    API_BEGIN
+    const size_t ws = norm_workspace_bytes(C);
+    layernorm_backward(S(), x, y, dy, gamma, dx, accumulate, dgamma, dbeta, accumulate, npix, C, eps, relu, scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                           float* y, float* saved, size_t npix, int C, float eps, float momentum, int training, int relu) {
+    API_BEGIN
+    const size_t ws = norm_workspace_bytes(C);
+    batchnorm_forward(S(), x, gamma, beta, moving_mean, moving_var, y, saved, npix, C, eps, momentum, training, relu,
+                      scratch(ws), ws);
+    API_END
+}
+int dl4ds_op_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* saved, float* dx,
+                           float* dgamma, float* dbeta, size_t npix, int C, int relu, int accumulate) {
+    API_BEGIN
+    const size_t ws = norm_workspace_bytes(C);
+    batchnorm_backward(S(), x, y, dy, gamma, saved, dx, accumulate, dgamma, dbeta, accumulate, npix, C, relu, scratch(ws), ws);
+    API_END
+}
 int dl4ds_op_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo) {
     API_BEGIN
     resize_bilinear_forward(S(), make_view(nc(x), N, H, W, C), make_view(y, N, Ho, Wo, C));
@@ -462,6 +491,47 @@ int dl4ds_graph_dropout(dl4ds_graph* g, int in, float rate, int* out) {
     *out = g_dropout(g->g, in, rate);
     API_END
 }
+int dl4ds_graph_dropout_variant(dl4ds_graph* g, int in, float rate, int variant, int mc, int spatial_dim, int* out) {
+    API_BEGIN
+    *out = g_dropout(g->g, in, rate, variant, mc, spatial_dim);
+    API_END
+}
+int dl4ds_graph_dropout_count(dl4ds_graph* g, int* n) {
+    API_BEGIN
+    *n = (int)g->g.dropout_ops.size();
+    API_END
+}
+static GOp* dropout_op(dl4ds_graph* g, int index, int B) {
+    DL4DS_REQUIRE(index >= 0 && index < (int)g->g.dropout_ops.size(), "dropout op index out of range");
+    DL4DS_REQUIRE(g->g.finalized && B > 0 && B <= g->g.maxB, "dropout mask: graph not prepared for this batch size");
+    return g->g.dropout_ops[index];
+}
+int dl4ds_graph_dropout_mask_size(dl4ds_graph* g, int index, int B, size_t* n) {
+    API_BEGIN
+    DL4DS_REQUIRE(index >= 0 && index < (int)g->g.dropout_ops.size(), "dropout op index out of range");
+    *n = g->g.dropout_ops[index]->mask_floats(g->g, B);
+    API_END
+}
+int dl4ds_graph_dropout_get_mask(dl4ds_graph* g, int index, int B, float* dst_host) {
+    API_BEGIN
+    GOp* op = dropout_op(g, index, B);
+    HIP_CHECK(hipMemcpyAsync(dst_host, op->saved, op->mask_floats(g->g, B) * sizeof(float), hipMemcpyDeviceToHost, g->g.stream));
+    HIP_CHECK(hipStreamSynchronize(g->g.stream));
+    API_END
+}
+int dl4ds_graph_dropout_set_mask(dl4ds_graph* g, int index, int B, const float* src_host) {
+    API_BEGIN
+    GOp* op = dropout_op(g, index, B);
+    op->set_mask(g->g, src_host, op->mask_floats(g->g, B));
+    HIP_CHECK(hipStreamSynchronize(g->g.stream));
+    API_END
+}
+int dl4ds_graph_norm(dl4ds_graph* g, int in, int gamma, int beta, int mov_mean, int mov_var, int batch, float eps, int relu,
+                     int* out) {
+    API_BEGIN
+    *out = g_norm(g->g, in, gamma, beta, mov_mean, mov_var, batch, eps, relu);
+    API_END
+}
 int dl4ds_graph_output(dl4ds_graph* g, int tid) {
     API_BEGIN
     DL4DS_REQUIRE(tid >= 0 && tid < (int)g->g.tensors.size(), "bad tensor id");
@@ -578,6 +648,16 @@ int dl4ds_trainer_loss_and_grads(dl4ds_trainer* tr, const float* const* inputs, 
         HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
         HIP_CHECK(hipStreamSynchronize(S()));
     }
+    API_END
+}
+int dl4ds_trainer_evaluate(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true, int B,
+                           int is_host, float* loss_host) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
+    DL4DS_REQUIRE(loss_host, "evaluate: loss_host is required");
+    trainer_evaluate(*tr->t, inputs, n_inputs, y_true, B, is_host != 0);
+    HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
     API_END
 }
 int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, long* step) {

@@ -187,34 +187,55 @@ struct DenseOp : GOp {
 struct DropoutOp : GOp {
     int in, out;
     float rate;
+    int variant = 0;           // 0 Dropout, 1 GaussianDropout, 2 SpatialDropout2D/3D (blocks.py:679-701)
+    int spatial_dim = 2;       // SpatialDropout3D shares the channel mask over the time axis too
+    bool mc = false;           // MC* layers stay active at inference (blocks.py:658-676)
     bool injected = false;
     unsigned long long counter = 0;
     DropoutOp() { kind = "dropout"; }
-    size_t saved_floats_per_sample(Graph& g) override { return g.tensors[in].per_sample(); }
+    // mask entries per sample: one per element, or one per (frame, channel) / (sample, channel) for the spatial variants
+    size_t mask_per_sample(Graph& g) const {
+        const GTensor& t = g.tensors[in];
+        if (variant != 2) return t.per_sample();
+        return (size_t)(spatial_dim == 3 ? 1 : t.nmul) * t.C;
+    }
+    size_t inner(Graph& g) const {
+        const GTensor& t = g.tensors[in];
+        return (size_t)t.H * t.W * (spatial_dim == 3 ? t.nmul : 1);
+    }
+    float scale() const { return variant == 1 ? 1.f : 1.f / (1.f - rate); }
+    size_t saved_floats_per_sample(Graph& g) override { return mask_per_sample(g); }
+    size_t mask_floats(Graph& g, int B) override { return mask_per_sample(g) * B; }
     bool set_mask(Graph& g, const float* host, size_t n) override {
         HIP_CHECK(hipMemcpyAsync(saved, host, n * sizeof(float), hipMemcpyHostToDevice, g.stream));
         injected = true;
         return true;
     }
+    void apply(Graph& g, const float* x, const float* mask, float* y, size_t n, int acc) {
+        if (variant == 2) dropout_apply_bcast(g.stream, x, mask, y, n, scale(), acc, g.tensors[in].C, inner(g));
+        else dropout_apply(g.stream, x, mask, y, n, scale(), acc);
+    }
     void forward(Graph& g, int B, bool training) override {
         const size_t n = g.tensors[in].per_sample() * B;
-        if (!training) {
+        if (!training && !mc) {
             HIP_CHECK(hipMemcpyAsync(g.tensors[out].data, g.tensors[in].data, n * sizeof(float), hipMemcpyDeviceToDevice,
                                      g.stream));
             return;
         }
-        if (!injected) dropout_make_mask(g.stream, saved, n, rate, 0x5DEECE66Dull + (++counter) * 0x1000003ull);
+        if (!injected)
+            dropout_make_mask(g.stream, saved, mask_per_sample(g) * B, rate, seed + (++counter) * 0x1000003ull, variant == 1);
         injected = false;
-        dropout_apply(g.stream, g.tensors[in].data, saved, g.tensors[out].data, n, 1.f / (1.f - rate), 0);
+        apply(g, g.tensors[in].data, saved, g.tensors[out].data, n, 0);
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
         const size_t ps = g.tensors[in].per_sample();
         const size_t off = (size_t)c.b_off * ps, n = (size_t)(c.b_cnt < 0 ? c.B : c.b_cnt) * ps;
-        dropout_apply(g.stream, g.tensors[out].grad + off, saved + off, g.tensors[in].grad + off, n, 1.f / (1.f - rate),
-                      g.tensors[in].grad_written);
+        apply(g, g.tensors[out].grad + off, saved + (size_t)c.b_off * mask_per_sample(g), g.tensors[in].grad + off, n,
+              g.tensors[in].grad_written);
         g.tensors[in].grad_written = true;
     }
+    unsigned long long seed = 0x5DEECE66Dull;
 };
 
 }  // namespace
@@ -267,12 +288,14 @@ int g_dense(Graph& g, int in, int w, int b, int F, int act) {
     return out;
 }
 
-int g_dropout(Graph& g, int in, float rate) {
+int g_dropout(Graph& g, int in, float rate, int variant, int mc, int spatial_dim) {
     const GTensor ti = g.tensors.at(in);
     DL4DS_REQUIRE(rate >= 0.f && rate < 1.f, "dropout: rate must be in [0,1)");
+    DL4DS_REQUIRE(variant >= 0 && variant <= 2 && (spatial_dim == 2 || spatial_dim == 3), "dropout: bad variant");
     const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
     DropoutOp* op = push<DropoutOp>(g);
-    op->in = in; op->out = out; op->rate = rate;
+    op->in = in; op->out = out; op->rate = rate; op->variant = variant; op->mc = mc != 0; op->spatial_dim = spatial_dim;
+    op->seed += 0x9E3779B97F4A7C15ull * (g.dropout_ops.size() + 1);
     g.tensors[in].n_other++;
     g.dropout_ops.push_back(op);
     return out;

@@ -6,7 +6,9 @@ void dense_forward(hipStream_t s, const float* x, const float* w, const float* b
 // dy is overwritten with dz = dy*act'(y) for rows [b0, b0+B)
 void dense_backward(hipStream_t s, const float* x, const float* w, const float* y, float* dy, float* dx, int acc_dx,
                     float* dw, float* db, int acc_dw, int want_dw, int b0, int B, int Cin, int F, int act);
-void dropout_make_mask(hipStream_t s, float* mask, size_t n, float rate, unsigned long long seed);
+void dropout_make_mask(hipStream_t s, float* mask, size_t n, float rate, unsigned long long seed, int gaussian = 0);
+void dropout_apply_bcast(hipStream_t s, const float* x, const float* mask, float* y, size_t n, float scale, int accumulate, int C,
+                         size_t inner);
 void dropout_apply(hipStream_t s, const float* x, const float* mask, float* y, size_t n, float scale, int accumulate);
 // ConvLSTM2D gate math (convlstm.hip)
 void convlstm_gates_forward(hipStream_t s, const TView& z, const TView& c_prev, const TView& c, const TView& h,

@@ -89,15 +89,33 @@ __global__ void __launch_bounds__(256) dense_bwd_kernel(const float* __restrict_
         }
 }
 
-// counter-based keep mask (splitmix-style hash of (seed, index)); keep with probability 1-rate
-__global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float rate, unsigned long long seed) {
+// counter-based noise (splitmix-style hash of (seed, index)).  gaussian == 0: keep mask, 1 with probability 1-rate
+// (Dropout / SpatialDropout, blocks.py:679-701); gaussian == 1: the multiplicative noise of GaussianDropout,
+// N(1, rate / (1 - rate)) by Box-Muller on the two 24-bit halves of the hash.
+__global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float rate, unsigned long long seed, int gaussian) {
+    const float sigma = sqrtf(rate / (1.f - rate));
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (e + 1);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z ^= z >> 31;
         const float u = (float)(z >> 40) * (1.f / 16777216.f);
-        mask[e] = (u >= rate) ? 1.f : 0.f;
+        if (gaussian) {
+            const float u2 = (float)((z >> 16) & 0xFFFFFFull) * (1.f / 16777216.f);
+            const float r = sqrtf(-2.f * logf(1.f - u));                      // 1 - u in (0, 1]
+            mask[e] = 1.f + sigma * r * cospif(2.f * u2);
+        } else {
+            mask[e] = (u >= rate) ? 1.f : 0.f;
+        }
+    }
+}
+// mask broadcast over `inner` positions: element e of sample block q = e / (inner * C) uses mask[q * C + e % C]
+__global__ void dropout_apply_bcast_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
+                                           size_t n, float scale, int accumulate, int C, size_t inner) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t q = e / (inner * C);
+        const float v = x[e] * mask[q * C + e % C] * scale;
+        y[e] = accumulate ? y[e] + v : v;
     }
 }
 __global__ void dropout_apply_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
@@ -132,8 +150,13 @@ void dense_backward(hipStream_t s, const float* x, const float* w, const float* 
                        Cin, F, act);
     HIP_CHECK(hipGetLastError());
 }
-void dropout_make_mask(hipStream_t s, float* mask, size_t n, float rate, unsigned long long seed) {
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, mask, n, rate, seed);
+void dropout_make_mask(hipStream_t s, float* mask, size_t n, float rate, unsigned long long seed, int gaussian) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, mask, n, rate, seed, gaussian);
+    HIP_CHECK(hipGetLastError());
+}
+void dropout_apply_bcast(hipStream_t s, const float* x, const float* mask, float* y, size_t n, float scale, int accumulate, int C,
+                         size_t inner) {
+    hipLaunchKernelGGL(dropout_apply_bcast_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, mask, y, n, scale, accumulate, C, inner);
     HIP_CHECK(hipGetLastError());
 }
 void dropout_apply(hipStream_t s, const float* x, const float* mask, float* y, size_t n, float scale, int accumulate) {

@@ -60,6 +60,19 @@ void act_forward(hipStream_t s, const float* x, float* y, size_t n, int kind);
 void act_backward(hipStream_t s, const float* x, const float* dy, float* dx, size_t n, int kind,
                   int accumulate);
 void fill(hipStream_t s, float* p, size_t n, float v);
+// LayerNormalization / BatchNormalization over the channel axis of [npix][C] (norm.hip), optional fused ReLU
+size_t norm_workspace_bytes(int C);
+void layernorm_forward(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, size_t npix, int C,
+                       float eps, int relu);
+void layernorm_backward(hipStream_t s, const float* x, const float* y, const float* dy, const float* gamma, float* dx, int acc_dx,
+                        float* dgamma, float* dbeta, int acc_dw, size_t npix, int C, float eps, int relu, float* ws,
+                        size_t ws_bytes);
+void batchnorm_forward(hipStream_t s, const float* x, const float* gamma, const float* beta, float* mov_mean, float* mov_var,
+                       float* y, float* saved, size_t npix, int C, float eps, float momentum, int training, int relu, float* ws,
+                       size_t ws_bytes);
+void batchnorm_backward(hipStream_t s, const float* x, const float* y, const float* dy, const float* gamma, const float* saved,
+                        float* dx, int acc_dx, float* dgamma, float* dbeta, int acc_dw, size_t npix, int C, int relu, float* ws,
+                        size_t ws_bytes);
 // depth_to_space standalone (used by tests and unfused fallbacks)
 void depth_to_space(hipStream_t s, const float* x, float* y, int N, int H, int W, int C, int r);
 void space_to_depth(hipStream_t s, const float* y, float* x, int N, int H, int W, int C, int r);

@@ -92,6 +92,24 @@ void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs
     g.backward(c);
 }
 
+// model.evaluate: inference-mode forward (dropout off unless MC, BatchNormalization on its moving statistics, which are
+// left untouched) + the loss value; no backward pass
+void trainer_evaluate(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host) {
+    Graph& g = *t.g;
+    graph_load_inputs(g, inputs, n_inputs, B, is_host);
+    ensure_loss_buffers(t, B);
+    const GTensor& o = g.tensors[g.outputs[0]];
+    const float* yt = y_true;
+    if (is_host) {
+        HIP_CHECK(hipMemcpyAsync(t.y_true, y_true, o.per_sample() * B * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        yt = t.y_true;
+    }
+    g.forward(B, false);
+    // the fused loss kernels always emit dL/dpred; it lands in the output's gradient buffer and is never read
+    loss_forward_backward(g.stream, t.loss_kind, yt, o.data, o.grad, B * o.nmul, o.H, o.W, o.C, 1.f, t.d_loss, 0,
+                          t.loss_ws, t.loss_ws_bytes);
+}
+
 static float current_lr(const Trainer& t) {
     // PiecewiseConstantDecay: lr0 while iterations <= boundary, else lr1 (supervised.py:340-346)
     return ((double)t.step <= t.cfg.boundary) ? t.cfg.lr0 : t.cfg.lr1;

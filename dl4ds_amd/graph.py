@@ -63,7 +63,7 @@ class GraphBuilder:
         self.inputs.append(t)
         return t
 
-    def param(self, name, shape, init='glorot'):
+    def param(self, name, shape, init='glorot', trainable=True):
         shape = tuple(int(s) for s in shape)
         if name in self.params:                 # shared weights (e.g. spc conv2x applied twice)
             p = self.params[name]
@@ -72,7 +72,7 @@ class GraphBuilder:
             return p['pid']
         pid = ctypes.c_int()
         _lib.check(self._l.dl4ds_graph_param(self.h, int(np.prod(shape)), ctypes.byref(pid)))
-        self.params[name] = dict(pid=pid.value, shape=shape, init=init)
+        self.params[name] = dict(pid=pid.value, shape=shape, init=init, trainable=trainable)
         return pid.value
 
     def _out(self, tid, kind, name):
@@ -186,10 +186,70 @@ class GraphBuilder:
                                              ctypes.byref(out)))
         return self._out(out.value, 'dense', name)
 
-    def dropout(self, x, rate, name='dropout'):
+    def dropout(self, x, rate, name='dropout', variant=None, dim=2):
+        """get_dropout_layer -- blocks.py:679-706: identity for rate 0; 'vanilla' / 'gaussian' / 'spatial' and their
+        'mc*' forms that stay active at inference.  ``dim=3``: SpatialDropout3D (mask shared over the time axis)."""
+        if not rate or rate <= 0:
+            return x
+        kinds = {None: (0, 0), 'vanilla': (0, 0), 'gaussian': (1, 0), 'spatial': (2, 0), 'mcdrop': (0, 1),
+                 'mcgaussiandrop': (1, 1), 'mcspatialdrop': (2, 1)}
+        if variant not in kinds:
+            raise ValueError(f'dropout variant {variant!r} not supported')
+        kind, mc = kinds[variant]
         out = ctypes.c_int()
-        _lib.check(self._l.dl4ds_graph_dropout(self.h, x.id, float(rate), ctypes.byref(out)))
-        return self._out(out.value, 'dropout', name)
+        _lib.check(self._l.dl4ds_graph_dropout_variant(self.h, x.id, float(rate), kind, mc, int(dim), ctypes.byref(out)))
+        return self._out(out.value, 'dropout' if variant is None else variant, name)
+
+    def norm(self, x, name, kind, activation=None, epsilon=1e-3):
+        """LayerNormalization() ('ln') / BatchNormalization() ('bn') with Keras variable names; a ReLU that follows is
+        fused, any other activation is appended."""
+        activation = _check_activation(activation)
+        if kind not in ('bn', 'ln'):
+            raise ValueError(f'Normalization not supported, got {kind}')
+        gamma = self.param(name + '/gamma', (x.C,), 'ones')
+        beta = self.param(name + '/beta', (x.C,), 'zeros')
+        mm = mv = -1
+        if kind == 'bn':
+            mm = self.param(name + '/moving_mean', (x.C,), 'zeros', trainable=False)
+            mv = self.param(name + '/moving_variance', (x.C,), 'ones', trainable=False)
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_norm(self.h, x.id, gamma, beta, mm, mv, int(kind == 'bn'), float(epsilon),
+                                            int(activation == 'relu'), ctypes.byref(out)))
+        y = self._out(out.value, 'batch_norm' if kind == 'bn' else 'layer_norm', name)
+        if activation not in (None, 'relu'):
+            y = self.act(y, activation, name + '/act')
+        return y
+
+    def norm_variables(self, name, channels, kind):
+        """Variables of a normalisation layer the reference builds and calls but whose output it discards
+        (DenseBlock.norm1, blocks.py:263-267): present in the weight list, absent from the graph."""
+        self.param(name + '/gamma', (channels,), 'ones')
+        self.param(name + '/beta', (channels,), 'zeros')
+        if kind == 'bn':
+            self.param(name + '/moving_mean', (channels,), 'zeros', trainable=False)
+            self.param(name + '/moving_variance', (channels,), 'ones', trainable=False)
+
+    # ---------------------------------------------------------------- dropout noise (tests / reproducibility)
+    def dropout_count(self):
+        n = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_dropout_count(self.h, ctypes.byref(n)))
+        return n.value
+
+    def dropout_mask(self, index, batch):
+        """Noise the last forward pass of dropout op ``index`` used (flat array, see include/dl4ds_hip.h)."""
+        n = ctypes.c_size_t()
+        _lib.check(self._l.dl4ds_graph_dropout_mask_size(self.h, int(index), int(batch), ctypes.byref(n)))
+        out = np.empty(n.value, np.float32)
+        _lib.check(self._l.dl4ds_graph_dropout_get_mask(self.h, int(index), int(batch), out.ctypes.data))
+        return out
+
+    def set_dropout_mask(self, index, batch, mask):
+        n = ctypes.c_size_t()
+        _lib.check(self._l.dl4ds_graph_dropout_mask_size(self.h, int(index), int(batch), ctypes.byref(n)))
+        mask = np.ascontiguousarray(mask, np.float32).ravel()
+        if mask.size != n.value:
+            raise ValueError(f'dropout op {index}: mask of {n.value} entries expected, got {mask.size}')
+        _lib.check(self._l.dl4ds_graph_dropout_set_mask(self.h, int(index), int(batch), mask.ctypes.data))
 
     # ---------------------------------------------------------------- finish
     def finalize(self, output, seed=None):
@@ -207,6 +267,8 @@ class GraphBuilder:
             shape, init = p['shape'], p['init']
             if init == 'zeros':
                 val = np.zeros(shape, np.float32)
+            elif init == 'ones':
+                val = np.ones(shape, np.float32)
             elif init == 'lstm_bias':
                 f = shape[0] // 4
                 val = np.zeros(shape, np.float32)
@@ -280,10 +342,14 @@ class Model:
         return OrderedDict((k, self.graph.get_param(k, grad=True)) for k in self.graph.params)
 
     @property
-    def trainable_variables(self):
+    def variables(self):
         return list(self.get_weights().items())
 
-    variables = trainable_variables
+    @property
+    def trainable_variables(self):
+        """Everything but the BatchNormalization moving statistics (they live in the same arena; their gradient is
+        identically zero, so Adam leaves them to the forward pass that maintains them)."""
+        return [(k, v) for k, v in self.get_weights().items() if self.graph.params[k].get('trainable', True)]
 
     # --- forward
     def _prep_inputs(self, inputs):

@@ -2,28 +2,41 @@
 
 Each function takes the GraphBuilder ``g``, a layer-name prefix and the input Tensor(s) and returns
 the output Tensor.  Fusions are decided here: Conv2D+bias+ReLU(+residual Add) is one kernel launch,
-SubpixelConvolution's depth_to_space is the conv's store pattern.  Only the configuration space the
-hot path covers is accepted (normalization None, dropout 0): anything else raises.
+SubpixelConvolution's depth_to_space is the conv's store pattern, LayerNormalization /
+BatchNormalization carry the ReLU that follows them.
 """
 from ..utils import checkarg_dropout_variant
 
 
+def _check_normalization(normalization):
+    if normalization is not None and normalization not in ['bn', 'ln']:
+        raise ValueError(f'Normalization not supported, got {normalization}')
+    return normalization
+
+
 def _reject_unsupported(normalization, dropout_rate, dropout_variant=None):
+    """Kept for the builders that have no normalised / dropout form in the reference either."""
     checkarg_dropout_variant(dropout_variant)
-    if normalization is not None:
-        if normalization not in ['bn', 'ln']:
-            raise ValueError(f'Normalization not supported, got {normalization}')
-        raise NotImplementedError("normalization='bn'/'ln' is not implemented on the MI355X path yet")
-    if dropout_rate and dropout_rate > 0:
-        raise NotImplementedError('dropout_rate > 0 is not implemented on the MI355X path yet')
+    _check_normalization(normalization)
+
+
+def _conv_norm_act(g, name, norm_name, x, filters, ks, activation, normalization):
+    """Conv2D(use_bias = normalization is None) -> [norm] -> activation (blocks.py:50-62,90-93)."""
+    if normalization is None:
+        return g.conv2d(x, name, filters, ks, activation=activation)
+    y = g.conv2d(x, name, filters, ks, use_bias=False)
+    return g.norm(y, norm_name, normalization, activation=activation)
 
 
 def conv_block(g, name, x, filters, ks_cl1=3, ks_cl2=3, activation='relu', normalization=None,
                attention=False, dropout_rate=0, dropout_variant=None, time_window_5d=0):
-    """ConvBlock.call -- blocks.py:87-103."""
-    _reject_unsupported(normalization, dropout_rate, dropout_variant)
-    y = g.conv2d(x, name + '/conv1', filters, ks_cl1, activation=activation)
-    y = g.conv2d(y, name + '/conv2', filters, ks_cl2, activation=activation)
+    """ConvBlock.call -- blocks.py:87-103: [drop] conv1 [norm1] act [drop] conv2 [norm2] act [att]."""
+    _check_normalization(normalization)
+    dropout_variant = checkarg_dropout_variant(dropout_variant)
+    y = g.dropout(x, dropout_rate, name + '/dropout1', dropout_variant)
+    y = _conv_norm_act(g, name + '/conv1', name + '/norm1', y, filters, ks_cl1, activation, normalization)
+    y = g.dropout(y, dropout_rate, name + '/dropout2', dropout_variant)
+    y = _conv_norm_act(g, name + '/conv2', name + '/norm2', y, filters, ks_cl2, activation, normalization)
     if attention:
         y = g.channel_attention(y, name + '/att', filters, time_window_5d=time_window_5d)
     return y
@@ -31,13 +44,20 @@ def conv_block(g, name, x, filters, ks_cl1=3, ks_cl2=3, activation='relu', norma
 
 def residual_block(g, name, x, filters, activation='relu', normalization=None, attention=False,
                    dropout_rate=0, dropout_variant=None, use_1x1conv=False):
-    """ResidualBlock.call -- blocks.py:210-230: conv1 -> act -> conv2 -> [att] -> (+ conv1x1(X) | X) -> act."""
-    _reject_unsupported(normalization, dropout_rate, dropout_variant)
-    y = g.conv2d(x, name + '/conv1', filters, 3, activation=activation)
+    """ResidualBlock.call -- blocks.py:210-230:
+    [drop] conv1 [norm1] act [drop] conv2 [norm2] [att] -> (+ conv1x1(X) | X) -> act."""
+    _check_normalization(normalization)
+    dropout_variant = checkarg_dropout_variant(dropout_variant)
+    y = g.dropout(x, dropout_rate, name + '/dropout1', dropout_variant)
+    y = _conv_norm_act(g, name + '/conv1', name + '/norm1', y, filters, 3, activation, normalization)
+    y = g.dropout(y, dropout_rate, name + '/dropout2', dropout_variant)
     skip = g.conv2d(x, name + '/conv1x1', filters, 1) if use_1x1conv else x
-    if attention:
-        y = g.conv2d(y, name + '/conv2', filters, 3)
-        y = g.channel_attention(y, name + '/att', filters)
+    if attention or normalization is not None:
+        y = g.conv2d(y, name + '/conv2', filters, 3, use_bias=normalization is None)
+        if normalization is not None:
+            y = g.norm(y, name + '/norm2', normalization)
+        if attention:
+            y = g.channel_attention(y, name + '/att', filters)
         if activation in (None, 'relu', 'linear'):
             return g.add(y, skip, relu=(activation == 'relu'), name=name + '/add')
         return g.act(g.add(y, skip, name=name + '/add'), activation, name + '/act')
@@ -47,9 +67,17 @@ def residual_block(g, name, x, filters, activation='relu', normalization=None, a
 
 def dense_block(g, name, x, filters, activation='relu', normalization=None, attention=False,
                 dropout_rate=0, dropout_variant=None):
-    """DenseBlock.call -- blocks.py:262-277.  conv1 consumes the RAW X (line 267)."""
-    _reject_unsupported(normalization, dropout_rate, dropout_variant)
-    y = g.conv2d(x, name + '/conv1', 4 * filters, 1, activation=activation)
+    """DenseBlock.call -- blocks.py:262-277.  conv1 consumes the RAW X (line 267): norm1 / dropout1 are
+    evaluated by the reference and their result dropped, so norm1 only contributes its variables here.
+    Both convolutions keep their bias (they are re-created without use_bias, lines 249-258)."""
+    _check_normalization(normalization)
+    dropout_variant = checkarg_dropout_variant(dropout_variant)
+    if normalization is not None:
+        g.norm_variables(name + '/norm1', x.C, normalization)
+    y = g.conv2d(x, name + '/conv1', 4 * filters, 1, activation=None if normalization else activation)
+    if normalization is not None:
+        y = g.norm(y, name + '/norm2', normalization, activation=activation)
+    y = g.dropout(y, dropout_rate, name + '/dropout2', dropout_variant)
     y = g.conv2d(y, name + '/conv2', filters, 3)
     if attention:
         y = g.channel_attention(y, name + '/att', filters)
@@ -57,9 +85,10 @@ def dense_block(g, name, x, filters, activation='relu', normalization=None, atte
 
 
 def transition_block(g, name, x, filters, activation='relu', normalization=None):
-    """TransitionBlock.call without BN: 1x1 conv -> act -- blocks.py:301-309."""
+    """TransitionBlock.call -- blocks.py:301-309: 1x1 conv -> act, or (only for 'bn') BN -> act -> 1x1 conv."""
     if normalization == 'bn':
-        raise NotImplementedError("normalization='bn' is not implemented on the MI355X path yet")
+        y = g.norm(x, name + '/batch_norm', 'bn', activation=activation)
+        return g.conv2d(y, name + '/conv', filters, 1)
     return g.conv2d(x, name + '/conv', filters, 1, activation=activation)
 
 
@@ -72,9 +101,19 @@ def localized_conv_block(g, name, x, filters=2):
 def recurrent_conv_block(g, name, x, filters, time_window, activation='relu', normalization=None,
                          dropout_rate=0, dropout_variant=None):
     """RecurrentConvBlock.call -- blocks.py:380-398: ConvLSTM2D 5x5 -> act -> ConvLSTM2D 3x3 -> act."""
-    _reject_unsupported(normalization, dropout_rate, dropout_variant)
-    y = g.convlstm(x, name + '/convlstm1', filters, 5, time_window, activation=activation)
-    return g.convlstm(y, name + '/convlstm2', filters, 3, time_window, activation=activation)
+    _check_normalization(normalization)
+    dropout_variant = checkarg_dropout_variant(dropout_variant)
+    y = g.dropout(x, dropout_rate, name + '/dropout1', dropout_variant, dim=3)
+    if normalization is None:
+        y = g.convlstm(y, name + '/convlstm1', filters, 5, time_window, activation=activation)
+    else:
+        y = g.norm(g.convlstm(y, name + '/convlstm1', filters, 5, time_window), name + '/norm1', normalization,
+                   activation=activation)
+    y = g.dropout(y, dropout_rate, name + '/dropout2', dropout_variant, dim=3)
+    if normalization is None:
+        return g.convlstm(y, name + '/convlstm2', filters, 3, time_window, activation=activation)
+    return g.norm(g.convlstm(y, name + '/convlstm2', filters, 3, time_window), name + '/norm2', normalization,
+                  activation=activation)
 
 
 def subpixel_block(g, name, x, scale, n_filters):

@@ -12,28 +12,29 @@ def backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, n
         raise NotImplementedError(f"backbone_block={backbone_block!r} is not implemented for this builder on the "
                                   "MI355X path")
     _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    blk = dict(activation=activation, normalization=normalization, attention=attention, dropout_rate=dropout_rate,
+               dropout_variant=dropout_variant)
     init_n_filters = n_filters
     x = b = g.conv2d(x_in, 'stem', n_filters, 3)
     for i in range(n_blocks):
         n_filters = init_n_filters * (i + 1)
         if backbone_block == 'convnet':
-            b = conv_block(g, f'ConvBlock{i+1}', b, n_filters, activation=activation, attention=attention)
+            b = conv_block(g, f'ConvBlock{i+1}', b, n_filters, **blk)
         elif backbone_block == 'resnet':
-            b = residual_block(g, f'ResidualBlock{i+1}', b, n_filters, activation=activation,
-                               attention=attention, use_1x1conv=(i != 0))
+            b = residual_block(g, f'ResidualBlock{i+1}', b, n_filters, use_1x1conv=(i != 0), **blk)
         elif backbone_block == 'densenet':
-            b = dense_block(g, f'DenseBlock{i+1}', b, n_filters, activation=activation, attention=attention)
+            b = dense_block(g, f'DenseBlock{i+1}', b, n_filters, **blk)
             b = transition_block(g, f'Transition{i+1}', b, b.C // 2)
+    b = g.conv2d(b, 'backbone_last', n_filters, 3, activation=activation)
+    b = g.dropout(b, dropout_rate, 'backbone_dropout', dropout_variant)          # sp_postups.py:155
     if backbone_block == 'convnet':
-        x = g.conv2d(b, 'backbone_last', n_filters, 3, activation=activation)
+        x = b
     elif backbone_block == 'resnet':
         # x = TransitionBlock(x) ; x = Add()([x, b]) with b = act(conv(b)): the Add is fused into the 1x1 conv's
         # epilogue only when no activation separates them, so keep it explicit: b first, then skip + b.
-        b = g.conv2d(b, 'backbone_last', n_filters, 3, activation=activation)
         x = transition_block(g, 'TransitionSkip', x, n_filters, activation)
         x = g.add(x, b, name='backbone_add')
     elif backbone_block == 'densenet':
-        b = g.conv2d(b, 'backbone_last', n_filters, 3, activation=activation)
         x = g.concat([x, b], 'backbone_concat')
         x = transition_block(g, 'TransitionBackboneLast', x, n_filters, activation)
     return x, n_filters

@@ -42,6 +42,7 @@ def unet_pin(backbone_block, n_channels, n_aux_channels, n_filters, n_blocks, hr
     backbone_block = checkarg_backbone(backbone_block)
     dropout_variant = checkarg_dropout_variant(dropout_variant)
     _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    blk = dict(activation=activation, normalization=normalization, attention=attention, dropout_variant=dropout_variant)
     n_blocks = _check_nblocks(hr_size, n_blocks)
     h_hr, w_hr = int(hr_size[0]), int(hr_size[1])
     g = GraphBuilder()
@@ -51,12 +52,14 @@ def unet_pin(backbone_block, n_channels, n_aux_channels, n_filters, n_blocks, hr
     x = x_in
     skips, nfl = [], []
     for i in range(n_blocks):
-        y = conv_block(g, f'EncoderBlock{i+1}/conv', x, n_filters, activation=activation, attention=attention)
+        # EncoderBlock: the reference's `droprate = dropout_rate if i == n_blocks else 0` never fires (sp_preups.py:255)
+        y = conv_block(g, f'EncoderBlock{i+1}/conv', x, n_filters, dropout_rate=0, **blk)
         x = g.maxpool2(y, f'EncoderBlock{i+1}/maxpool')
         skips.append(y)
         nfl.append(n_filters)
         n_filters = min(width_cap, n_filters * 2)
-    x = conv_block(g, 'Bottleneck', x, n_filters, activation=activation)
+    x = conv_block(g, 'Bottleneck', x, n_filters, activation=activation, dropout_rate=dropout_rate,
+                   dropout_variant=dropout_variant, normalization=None)             # "following Isola et al 2016"
     nfl = nfl[::-1]
     for j, skip in enumerate(reversed(skips)):
         n_filters = nfl[j]
@@ -69,7 +72,8 @@ def unet_pin(backbone_block, n_channels, n_aux_channels, n_filters, n_blocks, hr
         else:
             raise ValueError(f'decoder_upsampling must be spc, rc or dc, got {decoder_upsampling}')
         x = pad_concat(g, f'Concatenate_SkipConnection{j+1}', x, skip)
-        x = conv_block(g, f'DecoderConvBlock{j+1}', x, n_filters, activation=activation, attention=attention)
+        x = conv_block(g, f'DecoderConvBlock{j+1}', x, n_filters, dropout_rate=0, **blk)
+    x = g.dropout(x, dropout_rate, 'decoder_dropout', dropout_variant)                # sp_preups.py:287
     x = tail_section(g, x, s_in, init_n_filters, n_filters, n_channels_out, activation, output_activation,
                      normalization, dropout_rate, localcon_layer)
     g.finalize(x, seed)

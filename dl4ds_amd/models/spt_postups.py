@@ -12,6 +12,7 @@ def rec_backbone(g, x_in, backbone_block, n_filters, n_blocks, time_window, acti
     for i in range(n_blocks):
         b = recurrent_conv_block(g, f'RecurrentConvBlock{i+2}', b, n_filters, time_window, activation,
                                  normalization, dropout_rate, dropout_variant)
+    b = g.dropout(b, dropout_rate, 'backbone_dropout', dropout_variant, dim=3)      # spt_postups.py:113
     if backbone_block == 'convnet':
         return b, n_filters
     if backbone_block == 'resnet':

@@ -129,6 +129,39 @@ def maxpool2_bwd(x, y, dy):
     return dx.numpy()
 
 
+def layernorm(x, gamma, beta, eps=1e-3, relu=False, dy=None):
+    """LayerNormalization(axis=-1)(x) [+ ReLU]; with ``dy`` also (dx, dgamma, dbeta)."""
+    c = x.shape[-1]
+    npix = x.size // c
+    dx_, dg_, db_ = _d(x), _d(gamma), _d(beta)
+    y = DeviceArray.zeros(x.shape)
+    _lib.check(_lib.lib().dl4ds_op_layernorm_fwd(dx_.ptr, dg_.ptr, db_.ptr, y.ptr, npix, c, float(eps), int(relu)))
+    if dy is None:
+        return y.numpy()
+    ddy = _d(dy)
+    dx, dgam, dbet = DeviceArray.zeros(x.shape), DeviceArray.zeros((c,)), DeviceArray.zeros((c,))
+    _lib.check(_lib.lib().dl4ds_op_layernorm_bwd(dx_.ptr, y.ptr, ddy.ptr, dg_.ptr, dx.ptr, dgam.ptr, dbet.ptr, npix, c,
+                                                 float(eps), int(relu), 0))
+    return y.numpy(), dx.numpy(), dgam.numpy(), dbet.numpy()
+
+
+def batchnorm(x, gamma, beta, moving_mean, moving_var, eps=1e-3, momentum=0.99, training=True, relu=False, dy=None):
+    """BatchNormalization(axis=-1)(x, training) [+ ReLU] -> (y, new moving_mean, new moving_var[, dx, dgamma, dbeta])."""
+    c = x.shape[-1]
+    npix = x.size // c
+    dx_, dg_, db_, dmm, dmv = _d(x), _d(gamma), _d(beta), _d(moving_mean), _d(moving_var)
+    y, saved = DeviceArray.zeros(x.shape), DeviceArray.zeros((2 * c,))
+    _lib.check(_lib.lib().dl4ds_op_batchnorm_fwd(dx_.ptr, dg_.ptr, db_.ptr, dmm.ptr, dmv.ptr, y.ptr, saved.ptr, npix, c,
+                                                 float(eps), float(momentum), int(training), int(relu)))
+    if dy is None:
+        return y.numpy(), dmm.numpy(), dmv.numpy()
+    ddy = _d(dy)
+    dx, dgam, dbet = DeviceArray.zeros(x.shape), DeviceArray.zeros((c,)), DeviceArray.zeros((c,))
+    _lib.check(_lib.lib().dl4ds_op_batchnorm_bwd(dx_.ptr, y.ptr, ddy.ptr, dg_.ptr, saved.ptr, dx.ptr, dgam.ptr, dbet.ptr,
+                                                 npix, c, int(relu), 0))
+    return y.numpy(), dmm.numpy(), dmv.numpy(), dx.numpy(), dgam.numpy(), dbet.numpy()
+
+
 def resize_bilinear(x, ho, wo):
     n, h, w, c = x.shape
     dx = _d(x)

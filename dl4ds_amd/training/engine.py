@@ -74,14 +74,18 @@ class SupervisedEngine:
         return float(loss.value), self.model.get_gradients()
 
     def evaluate(self, inputs, y_true):
-        return self.loss_and_grads(inputs, y_true)[0]
+        """model.evaluate: inference-mode forward + loss (no dropout, BatchNormalization on its moving statistics)."""
+        inputs, y, ptrs, b = self._host_args(inputs, y_true)
+        loss = ctypes.c_float()
+        _lib.check(self._l.dl4ds_trainer_evaluate(self.h, ptrs, len(inputs), y.ctypes.data, b, 1, ctypes.byref(loss)))
+        return float(loss.value)
 
     def evaluate_device(self, input_ptrs, y_ptr, batch):
         """Loss on HBM-resident buffers (no update)."""
         ptrs = (ctypes.c_void_p * len(input_ptrs))(*input_ptrs)
         loss = ctypes.c_float()
-        _lib.check(self._l.dl4ds_trainer_loss_and_grads(self.h, ptrs, len(input_ptrs), y_ptr, int(batch), 0,
-                                                        ctypes.byref(loss)))
+        _lib.check(self._l.dl4ds_trainer_evaluate(self.h, ptrs, len(input_ptrs), y_ptr, int(batch), 0,
+                                                  ctypes.byref(loss)))
         return float(loss.value)
 
     def save_checkpoint(self, path):

@@ -79,6 +79,20 @@ int dl4ds_op_space_to_depth(const float* y_dev, float* x_dev, int N, int H, int 
 int dl4ds_op_maxpool2_fwd(const float* x_dev, float* y_dev, int N, int H, int W, int C);
 int dl4ds_op_maxpool2_bwd(const float* x_dev, const float* y_dev, const float* dy_dev, float* dx_dev, int N,
                           int H, int W, int C);
+/* LayerNormalization(axis=-1) / BatchNormalization(axis=-1) over [npix][C] -- blocks.py:63-71,151-159,293-296.
+ * relu: fuse the activation that follows.  bwd: y is only read when relu != 0; dx / dgamma / dbeta may be NULL;
+ * accumulate != 0 adds into dx, dgamma, dbeta.  batchnorm: `saved` (2*C floats: batch mean, 1/std) is written by a
+ * training-mode forward and read by the backward; moving statistics are updated in place when training. */
+int dl4ds_op_layernorm_fwd(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, size_t npix, int C,
+                           float eps, int relu);
+int dl4ds_op_layernorm_bwd(const float* x_dev, const float* y_dev, const float* dy_dev, const float* gamma_dev, float* dx_dev,
+                           float* dgamma_dev, float* dbeta_dev, size_t npix, int C, float eps, int relu, int accumulate);
+int dl4ds_op_batchnorm_fwd(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* moving_mean_dev,
+                           float* moving_var_dev, float* y_dev, float* saved_dev, size_t npix, int C, float eps,
+                           float momentum, int training, int relu);
+int dl4ds_op_batchnorm_bwd(const float* x_dev, const float* y_dev, const float* dy_dev, const float* gamma_dev,
+                           const float* saved_dev, float* dx_dev, float* dgamma_dev, float* dbeta_dev, size_t npix, int C,
+                           int relu, int accumulate);
 /* Resizing(..., 'bilinear') -- blocks.py:489; discriminator.py:62-63 */
 int dl4ds_op_resize_bilinear_fwd(const float* x_dev, float* y_dev, int N, int H, int W, int C, int Ho, int Wo);
 int dl4ds_op_resize_bilinear_bwd(const float* dy_dev, float* dx_dev, int N, int H, int W, int C, int Ho, int Wo);
@@ -130,6 +144,20 @@ int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, 
 int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out);
 int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out);
 int dl4ds_graph_dropout(dl4ds_graph* g, int in, float rate, int* out);
+/* get_dropout_layer (blocks.py:679-706).  variant: 0 Dropout, 1 GaussianDropout, 2 SpatialDropout2D/3D (spatial_dim);
+ * mc != 0: the MC* layers of blocks.py:658-676, active at inference too. */
+int dl4ds_graph_dropout_variant(dl4ds_graph* g, int in, float rate, int variant, int mc, int spatial_dim, int* out);
+/* noise of dropout op `index` (creation order) for a batch of B samples: the keep mask (variants 0, 2; one entry per
+ * element resp. per (frame|sample, channel)) or the multiplicative Gaussian noise (variant 1).  get: the one the last
+ * forward pass used; set: used by the NEXT training-mode forward instead of drawing a new one. */
+int dl4ds_graph_dropout_count(dl4ds_graph* g, int* n);
+int dl4ds_graph_dropout_mask_size(dl4ds_graph* g, int index, int B, size_t* n);
+int dl4ds_graph_dropout_get_mask(dl4ds_graph* g, int index, int B, float* dst_host);
+int dl4ds_graph_dropout_set_mask(dl4ds_graph* g, int index, int B, const float* src_host);
+/* LayerNormalization(axis=-1) (batch == 0; mov_* ignored) / BatchNormalization(axis=-1, momentum=0.99) (batch != 0)
+ * as instantiated by blocks.py:63-71,151-159,293-296; relu != 0 fuses the activation that follows the layer. */
+int dl4ds_graph_norm(dl4ds_graph* g, int in, int gamma, int beta, int mov_mean, int mov_var, int batch, float eps, int relu,
+                     int* out);
 int dl4ds_graph_output(dl4ds_graph* g, int tensor_id);
 int dl4ds_graph_finalize(dl4ds_graph* g);
 int dl4ds_graph_tensor_shape(dl4ds_graph* g, int tensor_id, int shape4[4]);   /* nmul,H,W,C */
@@ -160,6 +188,10 @@ int dl4ds_trainer_step(dl4ds_trainer* tr, const float* const* inputs, int n_inpu
 /* loss/gradients without the optimiser update (tests; model.evaluate analogue) */
 int dl4ds_trainer_loss_and_grads(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true,
                                  int B, int is_host, float* loss_host);
+/* model.evaluate (supervised.py:396-409 validation / test loss): inference-mode forward + loss, no gradients, no
+ * BatchNormalization moving-average update, dropout inactive unless it is an MC variant */
+int dl4ds_trainer_evaluate(dl4ds_trainer* tr, const float* const* inputs, int n_inputs, const float* y_true, int B,
+                           int is_host, float* loss_host);
 int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, long* step);
 /* restore the Adam slots (arena-sized host arrays) and optimizer.iterations -- resume from a checkpoint
  * (the reference resumes through tf.train.Checkpoint, cgan.py:288-292; supervised.py:322-325 re-uses a trained model) */

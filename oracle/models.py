@@ -30,6 +30,8 @@ class Params(OrderedDict):
             shape = tuple(int(s) for s in shape)
             if init == 'zeros':
                 val = np.zeros(shape, self.dtype)
+            elif init == 'ones':
+                val = np.ones(shape, self.dtype)
             elif init == 'lstm_bias':       # unit_forget_bias=True: (i,f,c,o) -> f slice = 1
                 f = shape[0] // 4
                 val = np.zeros(shape, self.dtype)
@@ -46,6 +48,80 @@ class Params(OrderedDict):
         v = self[name]
         assert tuple(v.shape) == tuple(shape), (name, tuple(v.shape), tuple(shape))
         return v
+
+
+class Ctx:
+    """What the layers that depend on the call mode need: ``training`` (Keras' training flag), the model-level
+    ``normalization`` / ``dropout_rate`` / ``dropout_variant`` builder arguments, the dropout noise to inject (one
+    array per active dropout layer, in call order -- the oracle never draws random numbers itself) and, filled in by
+    a training-mode call, the BatchNormalization moving-average updates ``bn_updates[name] = (mean, variance)``."""
+
+    def __init__(self, training=False, normalization=None, dropout_rate=0, dropout_variant=None, noises=None):
+        self.training = training
+        self.normalization = normalization
+        self.dropout_rate = dropout_rate
+        self.dropout_variant = dropout_variant
+        self.noises = list(noises) if noises is not None else None
+        self.k = 0
+        self.bn_updates = OrderedDict()
+        self.noise_shapes = []           # shapes the injected arrays must have, in call order (for the tests)
+
+    def next_noise(self, shape):
+        self.noise_shapes.append(tuple(shape))
+        if self.noises is None:
+            return np.ones(shape)        # tracing / parameter creation
+        v = self.noises[self.k]
+        self.k += 1
+        return v
+
+
+_NO_CTX = Ctx()
+
+
+def _dropout(ops, ctx, x, rate, variant, dim=2):
+    """get_dropout_layer(rate, variant, dim)(x) -- blocks.py:679-706; MC* layers run with training=True always."""
+    ctx = ctx or _NO_CTX
+    if not rate or rate <= 0:
+        return x
+    base = {None: 'vanilla', 'vanilla': 'vanilla', 'gaussian': 'gaussian', 'spatial': 'spatial', 'mcdrop': 'vanilla',
+            'mcgaussiandrop': 'gaussian', 'mcspatialdrop': 'spatial'}[variant]
+    if not (ctx.training or (variant or '').startswith('mc')):
+        return x
+    if base == 'spatial':
+        # SpatialDropout2D: noise_shape (N,1,1,C); SpatialDropout3D (dim=3): (B,1,1,1,C)
+        shape = (x.shape[0], x.shape[-1])
+    else:
+        shape = tuple(x.shape)
+    return ops.dropout_noise(x, ctx.next_noise(shape), rate, base)
+
+
+def _norm(ops, P, ctx, name, x, kind, eps=1e-3):
+    """LayerNormalization() / BatchNormalization() with Keras defaults (axis=-1, momentum 0.99, epsilon 1e-3).
+    Training-mode BN normalises with the batch statistics and records the moving-average update; the moving variance
+    is fed the Bessel-corrected batch variance, as the fused Keras kernel does for 4-D inputs."""
+    ctx = ctx or _NO_CTX
+    c = x.shape[-1]
+    gamma = P.get(ops, name + '/gamma', (c,), 'ones')
+    beta = P.get(ops, name + '/beta', (c,), 'zeros')
+    if kind == 'ln':
+        return ops.layer_norm(x, gamma, beta, eps)
+    mm = P.get(ops, name + '/moving_mean', (c,), 'zeros')
+    mv = P.get(ops, name + '/moving_variance', (c,), 'ones')
+    if not ctx.training:
+        return ops.batch_norm(x, gamma, beta, mm, mv, eps)
+    mu, var = ops.channel_moments(x)
+    n = int(np.prod(x.shape[:-1]))
+    unbiased = var * (n / (n - 1.0)) if n > 1 else var
+    ctx.bn_updates[name] = (mm * 0.99 + mu * 0.01, mv * 0.99 + unbiased * 0.01)
+    return ops.batch_norm(x, gamma, beta, mu, var, eps)
+
+
+def _norm_variables(ops, P, name, c, kind):
+    P.get(ops, name + '/gamma', (c,), 'ones')
+    P.get(ops, name + '/beta', (c,), 'zeros')
+    if kind == 'bn':
+        P.get(ops, name + '/moving_mean', (c,), 'zeros')
+        P.get(ops, name + '/moving_variance', (c,), 'ones')
 
 
 # ----------------------------------------------------------------------------
@@ -74,11 +150,17 @@ def channel_attention(ops, P, name, x, nf, r=4):
 
 
 def conv_block(ops, P, name, x, filters, ks1=3, ks2=3, activation='relu',
-               attention=False):
-    """ConvBlock.call (normalization=None, dropout 0) -- blocks.py:87-103."""
-    y = _conv(ops, P, name + '/conv1', x, filters, ks1)
+               attention=False, normalization=None, dropout_rate=0, dropout_variant=None, ctx=None):
+    """ConvBlock.call -- blocks.py:87-103 (convs lose their bias when normalised, :50-62)."""
+    y = _dropout(ops, ctx, x, dropout_rate, dropout_variant)
+    y = _conv(ops, P, name + '/conv1', y, filters, ks1, bias=normalization is None)
+    if normalization is not None:
+        y = _norm(ops, P, ctx, name + '/norm1', y, normalization)
     y = ops.activation(y, activation)
-    y = _conv(ops, P, name + '/conv2', y, filters, ks2)
+    y = _dropout(ops, ctx, y, dropout_rate, dropout_variant)
+    y = _conv(ops, P, name + '/conv2', y, filters, ks2, bias=normalization is None)
+    if normalization is not None:
+        y = _norm(ops, P, ctx, name + '/norm2', y, normalization)
     y = ops.activation(y, activation)
     if attention:
         y = channel_attention(ops, P, name + '/att', y, filters)
@@ -86,11 +168,17 @@ def conv_block(ops, P, name, x, filters, ks1=3, ks2=3, activation='relu',
 
 
 def residual_block(ops, P, name, x, filters, activation='relu', attention=False,
-                   use_1x1conv=False):
+                   use_1x1conv=False, normalization=None, dropout_rate=0, dropout_variant=None, ctx=None):
     """ResidualBlock.call -- blocks.py:210-230."""
-    y = _conv(ops, P, name + '/conv1', x, filters, 3)
+    y = _dropout(ops, ctx, x, dropout_rate, dropout_variant)
+    y = _conv(ops, P, name + '/conv1', y, filters, 3, bias=normalization is None)
+    if normalization is not None:
+        y = _norm(ops, P, ctx, name + '/norm1', y, normalization)
     y = ops.activation(y, activation)
-    y = _conv(ops, P, name + '/conv2', y, filters, 3)
+    y = _dropout(ops, ctx, y, dropout_rate, dropout_variant)
+    y = _conv(ops, P, name + '/conv2', y, filters, 3, bias=normalization is None)
+    if normalization is not None:
+        y = _norm(ops, P, ctx, name + '/norm2', y, normalization)
     if attention:
         y = channel_attention(ops, P, name + '/att', y, filters)
     if use_1x1conv:
@@ -99,18 +187,29 @@ def residual_block(ops, P, name, x, filters, activation='relu', attention=False,
     return ops.activation(y, activation)
 
 
-def dense_block(ops, P, name, x, filters, activation='relu', attention=False):
-    """DenseBlock.call -- blocks.py:262-277.  NB conv1 consumes the RAW X (line 267)."""
+def dense_block(ops, P, name, x, filters, activation='relu', attention=False, normalization=None,
+                dropout_rate=0, dropout_variant=None, ctx=None):
+    """DenseBlock.call -- blocks.py:262-277.  NB conv1 consumes the RAW X (line 267): norm1(X), its activation and
+    dropout1 are computed and dropped, so norm1 only owns variables here (its BN moving averages would still be
+    updated by the reference; nothing reads them).  conv1 / conv2 are re-created WITH bias (lines 249-258)."""
+    if normalization is not None:
+        _norm_variables(ops, P, name + '/norm1', x.shape[-1], normalization)
     y = _conv(ops, P, name + '/conv1', x, 4 * filters, 1)
+    if normalization is not None:
+        y = _norm(ops, P, ctx, name + '/norm2', y, normalization)
     y = ops.activation(y, activation)
+    y = _dropout(ops, ctx, y, dropout_rate, dropout_variant)
     y = _conv(ops, P, name + '/conv2', y, filters, 3)
     if attention:
         y = channel_attention(ops, P, name + '/att', y, filters)
     return ops.concat([y, x])
 
 
-def transition_block(ops, P, name, x, filters, activation='relu'):
-    """TransitionBlock.call (no BN): 1x1 conv -> act -- blocks.py:301-309."""
+def transition_block(ops, P, name, x, filters, activation='relu', normalization=None, ctx=None):
+    """TransitionBlock.call -- blocks.py:301-309: 1x1 conv -> act; only 'bn' switches to BN -> act -> conv."""
+    if normalization == 'bn':
+        y = ops.activation(_norm(ops, P, ctx, name + '/batch_norm', x, 'bn'), activation)
+        return _conv(ops, P, name + '/conv', y, filters, 1)
     y = _conv(ops, P, name + '/conv', x, filters, 1)
     return ops.activation(y, activation)
 
@@ -131,17 +230,24 @@ def localized_conv_block(ops, P, name, x, filters=2):
     return y
 
 
-def recurrent_conv_block(ops, P, name, x, filters, activation='relu'):
-    """RecurrentConvBlock.call (norm None, dropout 0) -- blocks.py:380-398."""
+def recurrent_conv_block(ops, P, name, x, filters, activation='relu', normalization=None, dropout_rate=0,
+                         dropout_variant=None, ctx=None):
+    """RecurrentConvBlock.call -- blocks.py:380-398 (dropout layers built with dim=3)."""
     def lstm(nm, z, k):
         cin = z.shape[-1]
         kern = P.get(ops, nm + '/kernel', (k, k, cin, 4 * filters))
         rk = P.get(ops, nm + '/recurrent_kernel', (k, k, filters, 4 * filters))
         b = P.get(ops, nm + '/bias', (4 * filters,), 'lstm_bias')
         return ops.conv_lstm2d(z, kern, rk, b)
-    y = lstm(name + '/convlstm1', x, 5)
+    y = _dropout(ops, ctx, x, dropout_rate, dropout_variant, dim=3)
+    y = lstm(name + '/convlstm1', y, 5)
+    if normalization is not None:
+        y = _norm(ops, P, ctx, name + '/norm1', y, normalization)
     y = ops.activation(y, activation)
+    y = _dropout(ops, ctx, y, dropout_rate, dropout_variant, dim=3)
     y = lstm(name + '/convlstm2', y, 3)
+    if normalization is not None:
+        y = _norm(ops, P, ctx, name + '/norm2', y, normalization)
     return ops.activation(y, activation)
 
 
@@ -205,26 +311,30 @@ def pad_concat(ops, t1, t2):
 
 # ----------------------------------------------------------------------------
 # spatial post-upsampling  (dl4ds/models/sp_postups.py:95-217)
-def _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention):
+def _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention, ctx=None):
     """Shared by sp_postups.py:132-168 and sp_preups.py:115-151."""
+    ctx = ctx or _NO_CTX
+    blk = dict(normalization=ctx.normalization, dropout_rate=ctx.dropout_rate, dropout_variant=ctx.dropout_variant,
+               ctx=ctx)
     init_nf = n_filters
     x = b = _conv(ops, P, 'stem', x_in, n_filters, 3)
     for i in range(n_blocks):
         n_filters = init_nf * (i + 1)
         if backbone_block == 'convnet':
             b = conv_block(ops, P, f'ConvBlock{i+1}', b, n_filters, activation=activation,
-                           attention=attention)
+                           attention=attention, **blk)
         elif backbone_block == 'resnet':
             b = residual_block(ops, P, f'ResidualBlock{i+1}', b, n_filters,
                                activation=activation, attention=attention,
-                               use_1x1conv=(i != 0))
+                               use_1x1conv=(i != 0), **blk)
         elif backbone_block == 'densenet':
             b = dense_block(ops, P, f'DenseBlock{i+1}', b, n_filters, activation=activation,
-                            attention=attention)
+                            attention=attention, **blk)
             b = transition_block(ops, P, f'Transition{i+1}', b, b.shape[-1] // 2)
         else:
             raise ValueError(backbone_block)
     b = ops.activation(_conv(ops, P, 'backbone_last', b, n_filters, 3), activation)
+    b = _dropout(ops, ctx, b, ctx.dropout_rate, ctx.dropout_variant)           # sp_postups.py:155
     if backbone_block == 'convnet':
         x = b
     elif backbone_block == 'resnet':
@@ -237,25 +347,29 @@ def _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, att
 
 
 def _tail(ops, P, x, s_in, init_nf, n_filters_aux, n_channels_out, activation,
-          output_activation, localcon_layer, aux_attention=False):
-    """sp_postups.py:184-212 / sp_preups.py:155-183."""
+          output_activation, localcon_layer, aux_attention=False, ctx=None):
+    """sp_postups.py:184-212 / sp_preups.py:155-183.  ConvBlock_att gets dropout_rate but not the variant."""
+    ctx = ctx or _NO_CTX
+    nrm = ctx.normalization
     if localcon_layer:
         lws = localized_conv_block(ops, P, 'LocalizedConvBlock', x)
         x = ops.concat([x, lws])
     if s_in is not None:
         s = conv_block(ops, P, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
-                       attention=aux_attention)
+                       attention=aux_attention, normalization=nrm, ctx=ctx)
         x = ops.concat([x, s])
     x = transition_block(ops, P, 'TransitionLast', x, init_nf)
-    x = conv_block(ops, P, 'ConvBlock_att', x, init_nf, activation=None, attention=True)
-    x = conv_block(ops, P, 'ConvBlock_out', x, n_channels_out, activation=output_activation)
+    x = conv_block(ops, P, 'ConvBlock_att', x, init_nf, activation=None, attention=True, normalization=nrm,
+                   dropout_rate=ctx.dropout_rate, ctx=ctx)
+    x = conv_block(ops, P, 'ConvBlock_out', x, n_channels_out, activation=output_activation, normalization=nrm,
+                   ctx=ctx)
     return x
 
 
 def net_postupsampling(ops, P, x_in, s_in=None, *, backbone_block, upsampling, scale,
                        n_channels_out=1, n_filters=8, n_blocks=6, attention=False,
-                       activation='relu', output_activation=None, localcon_layer=False):
-    x, nf = _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention)
+                       activation='relu', output_activation=None, localcon_layer=False, ctx=None):
+    x, nf = _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention, ctx)
     if upsampling == 'spc':
         x = subpixel_block(ops, P, 'SubpixelConvolution', x, scale, nf)
     elif upsampling == 'rc':
@@ -264,22 +378,25 @@ def net_postupsampling(ops, P, x_in, s_in=None, *, backbone_block, upsampling, s
         x = transition_block(ops, P, 'TransitionDC', x, n_filters, activation)
         x = deconv_block(ops, P, 'Deconvolution', x, scale, nf, activation)
     return _tail(ops, P, x, s_in, n_filters, nf, n_channels_out, activation,
-                 output_activation, localcon_layer)
+                 output_activation, localcon_layer, ctx=ctx)
 
 
 def net_pin(ops, P, x_in, s_in=None, *, backbone_block, n_channels_out=1, n_filters=8,
             n_blocks=6, attention=False, activation='relu', output_activation=None,
-            localcon_layer=False):
+            localcon_layer=False, ctx=None):
     """sp_preups.py:83-189."""
-    x, nf = _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention)
+    x, nf = _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention, ctx)
     return _tail(ops, P, x, s_in, n_filters, nf, n_channels_out, activation,
-                 output_activation, localcon_layer)
+                 output_activation, localcon_layer, ctx=ctx)
 
 
 def unet_pin(ops, P, x_in, s_in=None, *, n_filters, n_blocks, n_channels_out=1,
              activation='relu', attention=False, decoder_upsampling='rc',
-             output_activation=None, width_cap=256, localcon_layer=False):
-    """sp_preups.py:230-315."""
+             output_activation=None, width_cap=256, localcon_layer=False, ctx=None):
+    """sp_preups.py:230-315.  Encoder blocks never receive dropout (`i == n_blocks` is never true, :255), the
+    bottleneck is built with normalization=None (:265-268), one dropout layer follows the decoder (:287)."""
+    ctx = ctx or _NO_CTX
+    nrm = ctx.normalization
     h, w = x_in.shape[1], x_in.shape[2]
     while h // 2 ** n_blocks < 2 or w // 2 ** n_blocks < 2:     # _check_nblocks :318-324
         n_blocks -= 1
@@ -288,12 +405,13 @@ def unet_pin(ops, P, x_in, s_in=None, *, n_filters, n_blocks, n_channels_out=1,
     skips, nfl = [], []
     for i in range(n_blocks):
         y = conv_block(ops, P, f'EncoderBlock{i+1}/conv', x, n_filters, activation=activation,
-                       attention=attention)
+                       attention=attention, normalization=nrm, ctx=ctx)
         x = ops.max_pool2(y)
         skips.append(y)
         nfl.append(n_filters)
         n_filters = min(width_cap, n_filters * 2)
-    x = conv_block(ops, P, 'Bottleneck', x, n_filters, activation=activation)
+    x = conv_block(ops, P, 'Bottleneck', x, n_filters, activation=activation, dropout_rate=ctx.dropout_rate,
+                   dropout_variant=ctx.dropout_variant, ctx=ctx)
     nfl = nfl[::-1]
     for j, skip in enumerate(reversed(skips)):
         n_filters = nfl[j]
@@ -305,17 +423,23 @@ def unet_pin(ops, P, x_in, s_in=None, *, n_filters, n_blocks, n_channels_out=1,
             x = deconv_block(ops, P, f'Deconvolution{j+1}', x, 2, n_filters, activation)
         x = pad_concat(ops, x, skip)
         x = conv_block(ops, P, f'DecoderConvBlock{j+1}', x, n_filters, activation=activation,
-                       attention=attention)
+                       attention=attention, normalization=nrm, ctx=ctx)
+    x = _dropout(ops, ctx, x, ctx.dropout_rate, ctx.dropout_variant)
     return _tail(ops, P, x, s_in, init_nf, n_filters, n_channels_out, activation,
-                 output_activation, localcon_layer)
+                 output_activation, localcon_layer, ctx=ctx)
 
 
 # ----------------------------------------------------------------------------
 # spatio-temporal  (spt_postups.py:96-163, spt_preups.py:85-144)
-def _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation):
-    x = b = recurrent_conv_block(ops, P, 'RecurrentConvBlock1', x_in, n_filters, activation)
+def _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, ctx=None):
+    ctx = ctx or _NO_CTX
+    x = b = recurrent_conv_block(ops, P, 'RecurrentConvBlock1', x_in, n_filters, activation,
+                                 normalization=ctx.normalization, ctx=ctx)
     for i in range(n_blocks):
-        b = recurrent_conv_block(ops, P, f'RecurrentConvBlock{i+2}', b, n_filters, activation)
+        b = recurrent_conv_block(ops, P, f'RecurrentConvBlock{i+2}', b, n_filters, activation,
+                                 normalization=ctx.normalization, dropout_rate=ctx.dropout_rate,
+                                 dropout_variant=ctx.dropout_variant, ctx=ctx)
+    b = _dropout(ops, ctx, b, ctx.dropout_rate, ctx.dropout_variant, dim=3)      # spt_postups.py:113
     if backbone_block == 'convnet':
         return b, n_filters
     if backbone_block == 'resnet':
@@ -326,19 +450,22 @@ def _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation)
     raise ValueError(backbone_block)
 
 
-def _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation, transition_filters=None):
+def _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation, transition_filters=None, ctx=None):
     """spt_postups.py:150-157 (TransitionLast = C//2) / spt_preups.py:131-138 (TransitionLast = n_filters)."""
+    ctx = ctx or _NO_CTX
     tf_ = x.shape[-1] // 2 if transition_filters is None else transition_filters
     x = transition_block(ops, P, 'TransitionLast', x, tf_)
-    x = conv_block(ops, P, 'ConvBlock_att', x, n_filters, activation=None, attention=True)
-    return conv_block(ops, P, 'ConvBlock_out', x, n_channels_out, activation=output_activation)
+    x = conv_block(ops, P, 'ConvBlock_att', x, n_filters, activation=None, attention=True,
+                   normalization=ctx.normalization, dropout_rate=ctx.dropout_rate, ctx=ctx)
+    return conv_block(ops, P, 'ConvBlock_out', x, n_channels_out, activation=output_activation,
+                      normalization=ctx.normalization, ctx=ctx)
 
 
 def recnet_postupsampling(ops, P, x_in, s_in=None, *, backbone_block, upsampling, scale,
                           time_window, n_channels_out=1, n_filters=8, n_blocks=4,
                           attention=False, activation='relu', output_activation=None,
-                          localcon_layer=False):
-    x, nf_ups = _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation)
+                          localcon_layer=False, ctx=None):
+    x, nf_ups = _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, ctx)
     if upsampling == 'spc':
         x = time_distributed(lambda z: subpixel_block(ops, P, 'upsampling_spc', z, scale, nf_ups), x)
     elif upsampling == 'rc':
@@ -353,13 +480,13 @@ def recnet_postupsampling(ops, P, x_in, s_in=None, *, backbone_block, upsampling
     if localcon_layer:
         lws = localized_conv_block(ops, P, 'LocalizedConvBlock', x)
         x = ops.concat([x, lws])
-    return _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation)
+    return _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation, ctx=ctx)
 
 
 def recnet_pin(ops, P, x_in, s_in=None, *, backbone_block, time_window, n_channels_out=1,
                n_filters=8, n_blocks=6, attention=False, activation='relu',
-               output_activation=None, localcon_layer=False):
-    x, _ = _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation)
+               output_activation=None, localcon_layer=False, ctx=None):
+    x, _ = _rec_backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, ctx)
     if s_in is not None:
         s = conv_block(ops, P, 'ConvBlock_aux', s_in, n_filters, activation=activation,
                        attention=attention)
@@ -368,7 +495,8 @@ def recnet_pin(ops, P, x_in, s_in=None, *, backbone_block, time_window, n_channe
     if localcon_layer:
         lws = localized_conv_block(ops, P, 'LocalizedConvBlock', x)
         x = ops.concat([x, lws])
-    return _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation, transition_filters=n_filters)
+    return _rec_tail(ops, P, x, n_filters, n_channels_out, output_activation, transition_filters=n_filters,
+                     ctx=ctx)
 
 
 # ----------------------------------------------------------------------------

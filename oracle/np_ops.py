@@ -256,6 +256,38 @@ def dropout_apply(x, mask, rate):
     return x * mask / (1.0 - rate)
 
 
+def dropout_noise(x, noise, rate, variant):
+    """Dropout family of get_dropout_layer (blocks.py:679-706) with the noise injected:
+    'vanilla' / 'spatial' -- keep mask (1 = keep), x * mask / (1 - rate); the spatial mask has one entry per
+    (leading index, channel) and is broadcast over the axes in between (SpatialDropout2D: (N, C) over H, W;
+    SpatialDropout3D: (B, C) over T, H, W);  'gaussian' -- x * noise with noise ~ N(1, rate / (1 - rate))."""
+    noise = asarray(noise, x.dtype)
+    if variant == 'gaussian':
+        return x * noise.reshape(x.shape)
+    if variant == 'spatial':
+        shp = (x.shape[0],) + (1,) * (len(x.shape) - 2) + (x.shape[-1],)
+        return x * noise.reshape(shp) / (1.0 - rate)
+    return x * noise.reshape(x.shape) / (1.0 - rate)
+
+
+def layer_norm(x, gamma, beta, eps=1e-3):
+    """tf.keras.layers.LayerNormalization(axis=-1): biased variance over the channel axis."""
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * gamma + beta
+
+
+def channel_moments(x):
+    """Batch statistics of BatchNormalization(axis=-1): mean and biased variance over all other axes."""
+    axes = tuple(range(len(x.shape) - 1))
+    mu = x.mean(axis=axes)
+    return mu, ((x - mu) ** 2).mean(axis=axes)
+
+
+def batch_norm(x, gamma, beta, mean, var, eps=1e-3):
+    return (x - mean) / np.sqrt(var + eps) * gamma + beta
+
+
 # ----------------------------------------------------------------------------
 # losses  (dl4ds/losses.py)
 def mae(y_true, y_pred):

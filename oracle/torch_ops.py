@@ -215,6 +215,32 @@ def dropout_apply(x, mask, rate):
     return x * mask / (1.0 - rate)
 
 
+def dropout_noise(x, noise, rate, variant):
+    noise = asarray(noise, x.dtype)
+    if variant == 'gaussian':
+        return x * noise.reshape(x.shape)
+    if variant == 'spatial':
+        shp = (x.shape[0],) + (1,) * (len(x.shape) - 2) + (x.shape[-1],)
+        return x * noise.reshape(shp) / (1.0 - rate)
+    return x * noise.reshape(x.shape) / (1.0 - rate)
+
+
+def layer_norm(x, gamma, beta, eps=1e-3):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * gamma + beta
+
+
+def channel_moments(x):
+    axes = tuple(range(x.dim() - 1))
+    mu = x.mean(dim=axes)
+    return mu, ((x - mu) ** 2).mean(dim=axes)
+
+
+def batch_norm(x, gamma, beta, mean, var, eps=1e-3):
+    return (x - mean) / torch.sqrt(var + eps) * gamma + beta
+
+
 # ----------------------------------------------------------------------------
 def mae(y_true, y_pred):
     return (y_pred - y_true).abs().mean()

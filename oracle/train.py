@@ -18,6 +18,7 @@ from . import models as M
 LOSSES = {
     'mae': T.mae, 'mse': T.mse, 'dssim': T.dssim, 'dssim_mae': T.dssim_mae,
     'dssim_mse': T.dssim_mse, 'dssim_mae_mse': T.dssim_mae_mse,
+    'msdssim': T.msdssim, 'msdssim_mae': T.msdssim_mae, 'msdssim_mae_mse': T.msdssim_mae_mse,
 }
 
 

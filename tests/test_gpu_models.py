@@ -18,10 +18,12 @@ def rel(a, ref):
     return np.abs(np.asarray(a, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-12)
 
 
-def build_pair(kind, cfg, x_shape, s_shape, seed=11):
-    """Product model + oracle params holding the same weights."""
+def build_pair(kind, cfg, x_shape, s_shape, seed=11, ctx_kw=None):
+    """Product model + oracle params holding the same weights.  ``ctx_kw``: the normalization / dropout builder
+    arguments, which the oracle takes through its ``Ctx``."""
     import dl4ds_amd.models as PM
-    hw = {}
+    ocfg_in = dict(cfg)
+    cfg = dict(cfg, **(ctx_kw or {}))
     if kind == 'net_postupsampling':
         model = PM.net_postupsampling(n_channels=x_shape[-1], n_aux_channels=0 if s_shape is None else s_shape[-1],
                                       lr_size=x_shape[1:3], seed=seed, **cfg)
@@ -40,14 +42,19 @@ def build_pair(kind, cfg, x_shape, s_shape, seed=11):
     rng = np.random.default_rng(seed + 1)
     w = model.get_weights()
     for k in w:                                   # make biases non-zero so they are exercised
-        if w[k].ndim == 1 or k.endswith('bias'):
+        if k.endswith('moving_variance'):
+            w[k] = (0.5 + rng.random(w[k].shape)).astype(np.float32)
+        elif k.endswith('gamma'):
+            w[k] = (1 + rng.standard_normal(w[k].shape) * 0.1).astype(np.float32)
+        elif w[k].ndim == 1 or k.endswith('bias'):
             w[k] = (rng.standard_normal(w[k].shape) * 0.05).astype(np.float32)
     model.set_weights(w)
-    ocfg = {k: v for k, v in cfg.items() if k not in ('rc_interpolation',)}
+    ocfg = {k: v for k, v in ocfg_in.items() if k not in ('rc_interpolation',)}
     if kind == 'unet_pin':
         ocfg.pop('backbone_block', None)
+    extra = dict(ctx=M.Ctx(**ctx_kw)) if ctx_kw else {}
     P0 = M.init_params(kind, (1,) + tuple(x_shape[1:]), None if s_shape is None else (1,) + tuple(s_shape[1:]),
-                       dtype=np.float64, **ocfg)
+                       dtype=np.float64, **ocfg, **extra)
     assert set(P0.keys()) == set(w.keys()), (sorted(set(P0) ^ set(w)))
     P = M.Params()
     for k in P0:
@@ -217,3 +224,124 @@ def test_cgan_step_matches_oracle():
         w = m.get_weights()
         for k in w:
             assert np.abs((w[k] - P0[k]) - (Pt[k].detach().numpy() - P0[k])).max() < 0.2 * 2e-4 + 1e-7, k
+
+
+# ------------------------------------------------------------------------------------------------ block variants (f2)
+def _oracle_pass(kind, ocfg, P, x, s, y, loss, ctx_kw, noises, training=True):
+    """Training-mode oracle pass (torch fp64) with the dropout noise the device drew: loss, grads, prediction, ctx."""
+    ctx = M.Ctx(training=training, noises=None if noises is None else [n.astype(np.float64) for n in noises], **ctx_kw)
+    PT = M.convert(P, T, requires_grad=True)
+    pred = M.MODELS[kind](T, PT, T.asarray(x.astype(np.float64)), None if s is None else T.asarray(s.astype(np.float64)),
+                          ctx=ctx, **ocfg)
+    lv = TR.LOSSES[loss](T.asarray(y.astype(np.float64)), pred)
+    keys = [k for k in PT if not k.endswith(('moving_mean', 'moving_variance'))]
+    gs = torch.autograd.grad(lv, [PT[k] for k in keys], allow_unused=True)
+    grads = {k: (np.zeros(PT[k].shape) if g is None else g.numpy()) for k, g in zip(keys, gs)}
+    return float(lv.detach()), grads, pred.detach().numpy(), ctx
+
+
+VARIANT_CASES = [
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=2, n_blocks=2, n_filters=8),
+     dict(normalization='ln'), (2, 12, 16, 2), (2, 24, 32, 1)),
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=2, n_blocks=2, n_filters=8, attention=True),
+     dict(normalization='bn'), (3, 12, 16, 1), None),
+    ('net_postupsampling', dict(backbone_block='convnet', upsampling='rc', scale=2, n_blocks=1, n_filters=6,
+                                activation='elu'), dict(normalization='bn', dropout_rate=0.2), (2, 10, 14, 3), None),
+    ('net_postupsampling', dict(backbone_block='densenet', upsampling='spc', scale=2, n_blocks=2, n_filters=8),
+     dict(normalization='ln', dropout_rate=0.3, dropout_variant='spatial'), (2, 10, 14, 1), (2, 20, 28, 2)),
+    ('net_pin', dict(backbone_block='densenet', n_blocks=1, n_filters=8), dict(normalization='bn'), (2, 16, 16, 2), None),
+    ('net_pin', dict(backbone_block='resnet', n_blocks=2, n_filters=8),
+     dict(dropout_rate=0.25, dropout_variant='gaussian'), (2, 16, 16, 2), None),
+    ('net_pin', dict(backbone_block='convnet', n_blocks=2, n_filters=8), dict(dropout_rate=0.5, dropout_variant='mcdrop'),
+     (2, 16, 16, 1), (2, 16, 16, 1)),
+    ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='spc'),
+     dict(normalization='bn', dropout_rate=0.2, dropout_variant='spatial'), (2, 16, 24, 2), None),
+    ('recnet_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=2, time_window=2, n_filters=4,
+                                   n_blocks=1), dict(normalization='ln', dropout_rate=0.3, dropout_variant='spatial'),
+     (2, 2, 10, 6, 2), None),
+    ('recnet_pin', dict(backbone_block='convnet', time_window=3, n_filters=4, n_blocks=1),
+     dict(normalization='bn', dropout_rate=0.2), (2, 3, 8, 8, 2), None),
+]
+
+
+@pytest.mark.parametrize('kind,cfg,var,xs,ss', VARIANT_CASES)
+def test_normalization_and_dropout_variants(kind, cfg, var, xs, ss):
+    """Builders with normalization= / dropout_rate= / dropout_variant= (blocks.py:63-103,210-277,380-398,679-706):
+    training-mode forward, loss and gradients against the oracle fed with the SAME dropout noise (read back from the
+    device), BatchNormalization moving averages after the step, and the inference-mode forward afterwards."""
+    from dl4ds_amd.training import SupervisedEngine
+    model, P, ocfg = build_pair(kind, cfg, xs, ss, ctx_kw=var)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(xs).astype(np.float32)
+    s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
+    inputs = [x] if s is None else [x, s]
+    B = xs[0]
+    # the oracle declares how many noise arrays it consumes and their shapes
+    probe = M.Ctx(training=True, **var)
+    ref_shape = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), ctx=probe,
+                               **ocfg).shape
+    g = model.graph
+    y = rng.standard_normal(ref_shape).astype(np.float32)
+    eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
+    w_before = model.get_weights()
+    l_hip, g_hip = eng.loss_and_grads(inputs, y)
+    n_drop = g.dropout_count()
+    assert n_drop == len(probe.noise_shapes)
+    noises = [g.dropout_mask(i, B).reshape(shp) for i, shp in enumerate(probe.noise_shapes)]
+    rate = var.get('dropout_rate', 0)
+    for nz in noises:                                        # the noise has the statistics the layer promises
+        if set(np.unique(nz)) <= {0.0, 1.0}:                 # keep mask (ConvBlock_att always uses plain Dropout)
+            if nz.size > 2000:
+                assert abs(nz.mean() - (1 - rate)) < 0.05
+        else:
+            assert var.get('dropout_variant') in ('gaussian', 'mcgaussiandrop')
+            if nz.size > 2000:
+                assert abs(nz.mean() - 1) < 0.05 and abs(nz.std() - np.sqrt(rate / (1 - rate))) < 0.05
+    lv, grads, pred, ctx = _oracle_pass(kind, ocfg, P, x, s, y, 'mae', var, noises)
+    assert l_hip == pytest.approx(lv, rel=1e-4)
+    gscale = max(np.abs(v).max() for v in grads.values())
+    for k, gr in grads.items():
+        assert np.abs(g_hip[k] - gr).max() / gscale < 1e-3, k
+    w_after = model.get_weights()
+    for k in w_after:
+        if k.endswith(('moving_mean', 'moving_variance')):
+            lname = k.rsplit('/', 1)[0]
+            if lname in ctx.bn_updates:
+                upd = ctx.bn_updates[lname][0 if k.endswith('moving_mean') else 1].detach().numpy()
+                np.testing.assert_allclose(w_after[k], upd, rtol=2e-4, atol=2e-6, err_msg=k)
+            else:                                            # DenseBlock.norm1: variables only
+                np.testing.assert_array_equal(w_after[k], w_before[k])
+            assert np.abs(g_hip[k]).max() == 0.0             # never trained
+        else:
+            np.testing.assert_array_equal(w_after[k], w_before[k])
+    # inference: moving statistics, dropout off unless MC
+    P2 = M.Params()
+    for k, v in w_after.items():
+        P2[k] = v.astype(np.float64)
+    mc = (var.get('dropout_variant') or '').startswith('mc')
+    out = model(inputs, training=False)
+    noises2 = [g.dropout_mask(i, B).reshape(shp) for i, shp in enumerate(probe.noise_shapes)] if mc else None
+    ctx2 = M.Ctx(training=False, noises=noises2, **var)
+    ref = M.MODELS[kind](N, P2, x.astype(np.float64), None if s is None else s.astype(np.float64), ctx=ctx2, **ocfg)
+    assert rel(out, ref) < 1e-3
+    if mc:
+        assert any(not np.array_equal(a, b) for a, b in zip(noises, noises2))      # a fresh draw per call
+    if not mc:
+        assert eng.evaluate(inputs, y) == pytest.approx(float(np.abs(ref - y).mean()), rel=1e-4)
+
+
+def test_injected_dropout_mask_is_used_once():
+    import dl4ds_amd.models as PM
+    m = PM.net_pin('convnet', 1, 0, (8, 8), n_blocks=1, n_filters=4, dropout_rate=0.5, seed=1)
+    g = m.graph
+    x = np.random.default_rng(0).standard_normal((2, 8, 8, 1)).astype(np.float32)
+    m(x, training=True)
+    keep = [np.ones_like(g.dropout_mask(i, 2)) for i in range(g.dropout_count())]
+    for i, k in enumerate(keep):
+        g.set_dropout_mask(i, 2, k)
+    a = m(x, training=True)                      # all-ones keep mask: the inference output scaled through 1/(1-p) chains
+    for i, k in enumerate(keep):
+        np.testing.assert_array_equal(g.dropout_mask(i, 2), k)
+    b = m(x, training=True)                      # the next call draws again
+    assert not np.array_equal(a, b)
+    assert any(not np.array_equal(g.dropout_mask(i, 2), keep[i]) for i in range(len(keep)))

@@ -359,3 +359,66 @@ def test_msdssim_losses(ops, kind, case):
     a2, g2 = ops.loss(kind, yt, yp)
     assert a2 == a
     np.testing.assert_array_equal(g, g2)                    # deterministic reductions
+
+
+NORM_SHAPES = [(2, 9, 7, 3), (1, 16, 16, 64), (3, 5, 11, 20), (2, 4, 6, 130), (1, 33, 17, 256), (2, 3, 5, 1), (1, 8, 8, 1000)]
+
+
+@pytest.mark.parametrize('shape', NORM_SHAPES)
+@pytest.mark.parametrize('relu', [False, True])
+def test_layernorm(ops, shape, relu):
+    """LayerNormalization(axis=-1) (+ fused ReLU), blocks.py:69-71,158-159: y, dx, dgamma, dbeta vs torch fp64
+    autograd; scalar (C % 4 != 0) and float4 lane layouts, C below / above one wavefront of packs."""
+    c = shape[-1]
+    x = (rng.standard_normal(shape) * 2 + 0.7).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+    dy = rng.standard_normal(shape).astype(np.float32)
+    for eps in (1e-3, 1e-6):
+        tx, tg, tb = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, gamma, beta)]
+        ty = T.layer_norm(tx, tg, tb, eps)
+        if relu:
+            ty = torch.relu(ty)
+        ty.backward(torch.tensor(dy, dtype=torch.float64))
+        y, dx, dg, db = ops.layernorm(x, gamma, beta, eps=eps, relu=relu, dy=dy)
+        close(y, ty.detach().numpy(), 1e-4)
+        if c == 1:          # a single channel normalises to exactly beta: dx is identically 0, up to rounding / sqrt(eps)
+            assert np.abs(dx).max() < 1e-6 / np.sqrt(eps)
+        else:
+            close(dx, tx.grad.numpy(), 1e-3)
+        close(dg, tg.grad.numpy(), 1e-3)
+        close(db, tb.grad.numpy(), 1e-3)
+
+
+@pytest.mark.parametrize('shape', NORM_SHAPES)
+@pytest.mark.parametrize('relu', [False, True])
+def test_batchnorm(ops, shape, relu):
+    """BatchNormalization(axis=-1), momentum 0.99, eps 1e-3 (blocks.py:66-68): training-mode output, gradients and
+    moving-average update (Bessel-corrected variance), then the inference-mode output; a channel offset of 50 sigma
+    checks the shifted-sum statistics."""
+    c = shape[-1]
+    x = (rng.standard_normal(shape) * 0.5 + 25.0 * rng.standard_normal(c)).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+    mm = rng.standard_normal(c).astype(np.float32)
+    mv = (0.5 + rng.random(c)).astype(np.float32)
+    dy = rng.standard_normal(shape).astype(np.float32)
+    tx, tg, tb = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, gamma, beta)]
+    mu, var = T.channel_moments(tx)
+    ty = T.batch_norm(tx, tg, tb, mu, var, 1e-3)
+    if relu:
+        ty = torch.relu(ty)
+    ty.backward(torch.tensor(dy, dtype=torch.float64))
+    y, mm2, mv2, dx, dg, db = ops.batchnorm(x, gamma, beta, mm, mv, training=True, relu=relu, dy=dy)
+    n = x.size // c
+    close(y, ty.detach().numpy(), 2e-4)
+    close(dx, tx.grad.numpy(), 1e-3)
+    close(dg, tg.grad.numpy(), 1e-3)
+    close(db, tb.grad.numpy(), 1e-3)
+    np.testing.assert_allclose(mm2, 0.99 * mm + 0.01 * mu.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mv2, 0.99 * mv + 0.01 * var.detach().numpy() * n / (n - 1), rtol=1e-4, atol=1e-6)
+    yi, mm3, mv3 = ops.batchnorm(x, gamma, beta, mm, mv, training=False, relu=relu)
+    ref = (x.astype(np.float64) - mm) / np.sqrt(mv.astype(np.float64) + 1e-3) * gamma + beta
+    close(yi, np.maximum(ref, 0) if relu else ref, 1e-4)
+    np.testing.assert_array_equal(mm3, mm)
+    np.testing.assert_array_equal(mv3, mv)
