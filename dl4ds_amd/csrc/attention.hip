@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) chatt_mlp_bwd_kernel(
         }
     }
     __syncthreads();
+    if (dw1 == nullptr) return;        // input gradient only (CGAN generator pass through the discriminator)
     // dW1[c][j] = sum_inst mean[c]*dpre1[j] ; dW2[j][c] = sum_inst h[j]*dpre2[c]
     for (int e = threadIdx.x; e < C * Cr; e += blockDim.x) {
         const int c = e / Cr, j = e - c * Cr;

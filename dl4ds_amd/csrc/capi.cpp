@@ -481,6 +481,16 @@ int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out) {
     *out = g_gap(g->g, in, 0);
     API_END
 }
+int dl4ds_graph_gap3d(dl4ds_graph* g, int in, int* out) {
+    API_BEGIN
+    *out = g_gap(g->g, in, 1);
+    API_END
+}
+int dl4ds_graph_slice(dl4ds_graph* g, int in, int oy, int ox, int step, int Ho, int Wo, int* out) {
+    API_BEGIN
+    *out = g_slice(g->g, in, oy, ox, step, Ho, Wo);
+    API_END
+}
 int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out) {
     API_BEGIN
     *out = g_dense(g->g, in, w, b, F, act);

@@ -115,8 +115,18 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
     D.backward(c1);
     // ---- pass 2: generator's adversarial loss through D (fake half, inputs only)
     bce_forward_backward(s, p_fake, 1.f, B, 1.f, t.d_losses + 0, dout.grad + B, 0);
-    BwdCtx c2{2 * B, B, B, false, true};
-    D.backward(c2);
+    bool partial = true;
+    for (auto& op : D.ops) partial = partial && op->partial_batch_ok();
+    if (partial) {
+        BwdCtx c2{2 * B, B, B, false, true};
+        D.backward(c2);
+    } else {
+        // ConvLSTM2D / channel attention back-propagate whole batches only: run the full batch with a zero output
+        // gradient on the real half (samples are independent in D, so the fake half's input gradient is unchanged)
+        fill(s, dout.grad, (size_t)B, 0.f);
+        BwdCtx c2{2 * B, 0, 2 * B, false, true};
+        D.backward(c2);
+    }
     // ---- generator backward: lambda * dpx/dgen + dgan/dgen
     G.zero_grad_flags();
     loss_forward_backward(s, t.px_kind, t.hr, go.data, go.grad, B * go.nmul, go.H, go.W, go.C, t.lam, t.d_losses + 1, 0,

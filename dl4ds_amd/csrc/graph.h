@@ -48,6 +48,7 @@ struct GOp {
     float* saved = nullptr;
     std::vector<int> pids;     // parameters this op reads (set by the op constructors; drives gradient bucketing)
     virtual void on_finalize(Graph& g) {}
+    virtual bool partial_batch_ok() const { return true; }   // backward over a sample sub-range (BwdCtx::b_off / b_cnt)
     virtual bool set_mask(Graph& g, const float* host, size_t n) { return false; }   // dropout keep-mask injection
     virtual size_t mask_floats(Graph& g, int B) { return 0; }                         // size of the mask of the last forward
     const char* kind = "op";
@@ -120,6 +121,7 @@ int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, in
 int g_gap(Graph& g, int in, int T);
 int g_dense(Graph& g, int in, int w, int b, int F, int act);
 int g_dropout(Graph& g, int in, float rate, int variant = 0, int mc = 0, int spatial_dim = 2);
+int g_slice(Graph& g, int in, int oy, int ox, int step, int Ho, int Wo);
 int g_norm(Graph& g, int in, int gamma, int beta, int mov_mean, int mov_var, int batch, float eps, int relu);
 
 // ---- trainer (trainer.hip)

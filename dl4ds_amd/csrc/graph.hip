@@ -290,6 +290,7 @@ struct ChAttOp : GOp {
         chatt_forward(g.stream, g.tensors[in].data, g.tensors[out].data, shape(g, B), g.wp(w1), g.wp(b1), g.wp(w2),
                       g.wp(b2), mean, hidden, scale, g.workspace);
     }
+    bool partial_batch_ok() const override { return false; }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
         DL4DS_REQUIRE(c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B), "chatt: partial-batch backward not supported");
@@ -300,10 +301,12 @@ struct ChAttOp : GOp {
         const int accw = g.params[w1].grad_written;
         chatt_backward(g.stream, g.tensors[in].data, g.tensors[out].grad, g.tensors[in].grad,
                        g.tensors[in].grad_written, shape(g, c.B), g.wp(w1), g.wp(w2), mean, hidden, scale,
-                       g.gp(w1), g.gp(b1), g.gp(w2), g.gp(b2), accw, g.workspace);
+                       c.param_grads ? g.gp(w1) : nullptr, g.gp(b1), g.gp(w2), g.gp(b2), accw, g.workspace);
         g.tensors[in].grad_written = true;
-        g.params[w1].grad_written = g.params[b1].grad_written = true;
-        g.params[w2].grad_written = g.params[b2].grad_written = true;
+        if (c.param_grads) {
+            g.params[w1].grad_written = g.params[b1].grad_written = true;
+            g.params[w2].grad_written = g.params[b2].grad_written = true;
+        }
     }
 };
 

@@ -100,6 +100,7 @@ struct ConvLSTMOp : GOp {
                                    frame(g, bf.H, B, t, F), frame(g, g.tensors[out].data, B, t, F), relu, t == 0);
         }
     }
+    bool partial_batch_ok() const override { return false; }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
         DL4DS_REQUIRE(c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B), "convlstm: partial-batch backward not supported");
@@ -144,17 +145,20 @@ struct ConvLSTMOp : GOp {
 // ============================================================================================ GlobalAveragePooling2D
 struct GapOp : GOp {
     int in, out;
+    bool over_time = false;    // GlobalAveragePooling3D: the frames of a sample are averaged too (discriminator.py:74)
     GapOp() { kind = "gap"; }
     void forward(Graph& g, int B, bool) override {
         const GTensor& ti = g.tensors[in];
-        gap_forward(g.stream, ti.data, g.tensors[out].data, B * ti.nmul, ti.H * ti.W, ti.C);
+        const int fr = over_time ? ti.nmul : 1;
+        gap_forward(g.stream, ti.data, g.tensors[out].data, B * ti.nmul / fr, ti.H * ti.W * fr, ti.C);
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
         const GTensor& ti = g.tensors[in];
-        const int cnt = (c.b_cnt < 0 ? c.B : c.b_cnt) * ti.nmul;
-        gap_backward(g.stream, g.tensors[out].grad + (size_t)c.b_off * ti.nmul * ti.C,
-                     ti.grad + (size_t)c.b_off * ti.per_sample(), cnt, ti.H * ti.W, ti.C, ti.grad_written);
+        const int fr = over_time ? ti.nmul : 1;
+        const int cnt = (c.b_cnt < 0 ? c.B : c.b_cnt) * ti.nmul / fr;
+        gap_backward(g.stream, g.tensors[out].grad + (size_t)c.b_off * (ti.nmul / fr) * ti.C,
+                     ti.grad + (size_t)c.b_off * ti.per_sample(), cnt, ti.H * ti.W * fr, ti.C, ti.grad_written);
         g.tensors[in].grad_written = true;
     }
 };
@@ -266,11 +270,11 @@ int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, in
     return out;
 }
 
-int g_gap(Graph& g, int in, int) {
+int g_gap(Graph& g, int in, int over_time) {
     const GTensor ti = g.tensors.at(in);
-    const int out = g.add_tensor(1, 1, ti.C, ti.nmul, true, false);
+    const int out = g.add_tensor(1, 1, ti.C, over_time ? 1 : ti.nmul, true, false);
     GapOp* op = push<GapOp>(g);
-    op->in = in; op->out = out;
+    op->in = in; op->out = out; op->over_time = over_time != 0;
     g.tensors[in].n_other++;
     return out;
 }

@@ -29,6 +29,7 @@ struct NormOp : GOp {
         else
             layernorm_forward(g.stream, t.data, g.wp(gamma), g.wp(beta), g.tensors[out].data, npix(g, B), t.C, eps, relu);
     }
+    bool partial_batch_ok() const override { return !batch; }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
         const GTensor& t = g.tensors[in];
@@ -53,7 +54,78 @@ struct NormOp : GOp {
     }
 };
 
+// ============================================================================================ strided slice (H, W)
+// y[n, i, j, :] = x[n, oy + i*step, ox + j*step, :].  With the stride-1 'same' convolution in front of it this is
+// Conv2D(strides=2) (discriminator.py:53-60): TF's 'same' padding for stride 2 puts the window of output i at rows
+// 2i-pt .. 2i-pt+2 with pt = (H odd), i.e. the stride-1 output at row 2i + 1 - pt; 'valid' reads row 2i + 1.
+// step == 1 is Cropping2D (discriminator.py:56).
+__global__ void slice_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int Ho, int Wo, int oy,
+                                 int ox, int step, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        size_t r = e / C;
+        const int j = (int)(r % Wo); r /= Wo;
+        const int i = (int)(r % Ho);
+        const size_t n = r / Ho;
+        y[e] = x[((n * H + oy + i * step) * W + ox + j * step) * C + c];
+    }
+}
+// dx (+)= scatter(dy): every input element looks up whether an output reads it
+__global__ void slice_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C, int Ho, int Wo, int oy,
+                                 int ox, int step, size_t total, int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        size_t r = e / C;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const size_t n = r / H;
+        const int di = yy - oy, dj = xx - ox;
+        float v = 0.f;
+        if (di >= 0 && dj >= 0 && di % step == 0 && dj % step == 0 && di / step < Ho && dj / step < Wo)
+            v = dy[((n * Ho + di / step) * Wo + dj / step) * C + c];
+        dx[e] = accumulate ? dx[e] + v : v;
+    }
+}
+inline int ew_grid(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 8192)); }
+
+struct SliceOp : GOp {
+    int in, out, oy, ox, step;
+    SliceOp() { kind = "slice"; }
+    void forward(Graph& g, int B, bool) override {
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        const size_t total = to.per_sample() * B;
+        hipLaunchKernelGGL(slice_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, ti.data, to.data, ti.H, ti.W, ti.C,
+                           to.H, to.W, oy, ox, step, total);
+        HIP_CHECK(hipGetLastError());
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        const int cnt = c.b_cnt < 0 ? c.B : c.b_cnt;
+        const size_t total = ti.per_sample() * cnt;
+        hipLaunchKernelGGL(slice_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream,
+                           to.grad + (size_t)c.b_off * to.per_sample(), ti.grad + (size_t)c.b_off * ti.per_sample(), ti.H, ti.W,
+                           ti.C, to.H, to.W, oy, ox, step, total, (int)ti.grad_written);
+        HIP_CHECK(hipGetLastError());
+        g.tensors[in].grad_written = true;
+    }
+};
+
 }  // namespace
+
+int g_slice(Graph& g, int in, int oy, int ox, int step, int Ho, int Wo) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(step >= 1 && oy >= 0 && ox >= 0 && Ho >= 1 && Wo >= 1, "slice: bad arguments");
+    DL4DS_REQUIRE(oy + (Ho - 1) * step < ti.H && ox + (Wo - 1) * step < ti.W, "slice: window leaves the input grid");
+    const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
+    SliceOp* op = new SliceOp();
+    g.ops.emplace_back(op);
+    op->in = in; op->out = out; op->oy = oy; op->ox = ox; op->step = step;
+    g.tensors[in].n_other++;
+    return out;
+}
 
 int g_norm(Graph& g, int in, int gamma, int beta, int mov_mean, int mov_var, int batch, float eps, int relu) {
     const GTensor ti = g.tensors.at(in);

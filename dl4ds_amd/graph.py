@@ -172,10 +172,33 @@ class GraphBuilder:
             y = self.act(y, activation, name + '/act')
         return y
 
-    def gap(self, x, name='gap'):
+    def gap(self, x, name='gap', over_time=False):
         out = ctypes.c_int()
-        _lib.check(self._l.dl4ds_graph_gap(self.h, x.id, ctypes.byref(out)))
+        fn = self._l.dl4ds_graph_gap3d if over_time else self._l.dl4ds_graph_gap
+        _lib.check(fn(self.h, x.id, ctypes.byref(out)))
         return self._out(out.value, 'global_avg_pool', name)
+
+    def slice2d(self, x, oy, ox, step, ho, wo, name='slice'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_slice(self.h, x.id, int(oy), int(ox), int(step), int(ho), int(wo), ctypes.byref(out)))
+        return self._out(out.value, 'slice', name)
+
+    def conv2d_strided(self, x, name, filters, ks, stride, padding='same'):
+        """Conv2D(filters, ks, strides=stride, padding=...) as the stride-1 'same' convolution (MFMA path) followed by
+        the sub-sampling slice; see csrc/graph_ops3.hip for the index algebra."""
+        if padding not in ('same', 'valid'):
+            raise ValueError(padding)
+        half = ks // 2
+
+        def geom(n):
+            if padding == 'same':
+                out = -(-n // stride)
+                pad = max((out - 1) * stride + ks - n, 0)
+                return out, half - pad // 2
+            return (n - ks) // stride + 1, half
+        (ho, oy), (wo, ox) = geom(x.H), geom(x.W)
+        y = self.conv2d(x, name, filters, ks)
+        return self.slice2d(y, oy, ox, stride, ho, wo, name + '/stride')
 
     def dense(self, x, name, units, activation=None):
         activation = _check_activation(activation)

@@ -66,7 +66,8 @@ class CGANTrainer(Trainer):
                                        hr_size=hr_size, **gp)
         self.discriminator = M.residual_discriminator(n_channels=n_channels, upsampling=self.upsampling,
                                                       is_spatiotemporal=self.model_is_spatiotemporal, scale=self.scale,
-                                                      lr_size=lr_size, hr_size=hr_size, **self.discriminator_params)
+                                                      lr_size=lr_size, hr_size=hr_size, time_window=self.time_window,
+                                                      **self.discriminator_params)
         if self.verbose == 1 and self.running_on_first_worker:
             self.generator.summary(line_length=150)
             self.discriminator.summary(line_length=150)

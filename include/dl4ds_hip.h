@@ -142,6 +142,11 @@ int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out)
 int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out);
 int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out);
 int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out);
+/* GlobalAveragePooling3D over the (time, H, W) axes of a time-distributed tensor -- discriminator.py:73-74 */
+int dl4ds_graph_gap3d(dl4ds_graph* g, int in, int* out);
+/* y[:, i, j, :] = x[:, oy + i*step, ox + j*step, :] (i < Ho, j < Wo): the sub-sampling half of Conv2D(strides=2)
+ * (the stride-1 convolution runs on the MFMA kernels) and Cropping2D -- discriminator.py:53-60 */
+int dl4ds_graph_slice(dl4ds_graph* g, int in, int oy, int ox, int step, int Ho, int Wo, int* out);
 int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out);
 int dl4ds_graph_dropout(dl4ds_graph* g, int in, float rate, int* out);
 /* get_dropout_layer (blocks.py:679-706).  variant: 0 Dropout, 1 GaussianDropout, 2 SpatialDropout2D/3D (spatial_dim);

@@ -503,17 +503,22 @@ def recnet_pin(ops, P, x_in, s_in=None, *, backbone_block, time_window, n_channe
 # discriminator  (dl4ds/models/discriminator.py:25-80), spatial 'pin' + scale-4 'same' branches
 def residual_discriminator(ops, P, x_in, x_ref, dropout_mask=None, *, upsampling, scale,
                            lr_size=None, n_filters=8, n_res_blocks=4, activation='relu',
-                           attention=False):
-    x1 = b = _conv(ops, P, 'branch1_in', x_in, n_filters, 3)
+                           attention=False, normalization=None):
+    """discriminator.py:25-80.  5-D inputs (B,T,H,W,C) select the spatio-temporal form: RecurrentConvBlock with
+    LayerNormalization on the conditioning branch (:31-33), Conv2D / ResidualBlock applied frame-wise (Keras Conv2D
+    treats the leading axes as batch), GlobalAveragePooling3D (:73-74)."""
+    rb = dict(attention=attention, normalization=normalization)
+    if len(x_in.shape) == 5:
+        x1 = b = recurrent_conv_block(ops, P, 'RecurrentConvBlock', x_in, n_filters, activation, normalization='ln')
+    else:
+        x1 = b = _conv(ops, P, 'branch1_in', x_in, n_filters, 3)
     for i in range(n_res_blocks):
-        b = residual_block(ops, P, f'ResidualBlock{i+1}_branch1', b, n_filters,
-                           attention=attention)
+        b = residual_block(ops, P, f'ResidualBlock{i+1}_branch1', b, n_filters, **rb)
     b = _conv(ops, P, 'branch1_out', b, n_filters, 3)
     x1 = ops.add(x1, b)
     x2 = c = _conv(ops, P, 'branch2_in', x_ref, n_filters, 3)
     for i in range(n_res_blocks):
-        c = residual_block(ops, P, f'ResidualBlock{i+1}_branch2', c, n_filters,
-                           attention=attention)
+        c = residual_block(ops, P, f'ResidualBlock{i+1}_branch2', c, n_filters, **rb)
     if upsampling in ('spc', 'rc', 'dc'):
         if scale == 4:
             c = _conv(ops, P, 'branch2_down1', c, n_filters, 3, stride=2)
@@ -521,14 +526,15 @@ def residual_discriminator(ops, P, x_in, x_ref, dropout_mask=None, *, upsampling
         elif scale == 5:
             c = _conv(ops, P, 'branch2_down1', c, n_filters, 3, stride=2, padding='valid')
             x2 = _conv(ops, P, 'branch2_down2', c, n_filters, 3, stride=2, padding='valid')
-            x2 = x2[:, :-1, :-1, :]
+            x2 = x2[..., :-1, :-1, :]
         else:
-            x2 = ops.resize_bilinear(c, lr_size[0], lr_size[1])
+            rs = lambda z: ops.resize_bilinear(z, lr_size[0], lr_size[1])
+            x2 = time_distributed(rs, c) if len(c.shape) == 5 else rs(c)
     else:  # 'pin'
         c = _conv(ops, P, 'branch2_out', c, n_filters, 3)
         x2 = ops.add(x2, c)
     x = ops.concat([x1, x2])
-    x = residual_block(ops, P, 'ResidualBlock_merge', x, x.shape[-1], attention=attention)
+    x = residual_block(ops, P, 'ResidualBlock_merge', x, x.shape[-1], **rb)
     x = ops.global_avg_pool(x)
     if dropout_mask is not None:                      # Dropout(0.4), training=True
         x = ops.dropout_apply(x, dropout_mask, 0.4)

@@ -226,6 +226,78 @@ def test_cgan_step_matches_oracle():
             assert np.abs((w[k] - P0[k]) - (Pt[k].detach().numpy() - P0[k])).max() < 0.2 * 2e-4 + 1e-7, k
 
 
+CGAN_CASES = [
+    # generator kind, generator cfg, discriminator cfg (oracle), LR grid, scale, time window
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4, n_blocks=1, n_filters=4),
+     dict(upsampling='spc', scale=4, n_filters=4, n_res_blocks=1), (6, 8), 4, None),
+    ('net_postupsampling', dict(backbone_block='convnet', upsampling='rc', scale=5, n_blocks=1, n_filters=4),
+     dict(upsampling='rc', scale=5, n_filters=4, n_res_blocks=1, normalization='ln'), (8, 8), 5, None),
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=2, n_blocks=1, n_filters=4),
+     dict(upsampling='spc', scale=2, n_filters=4, n_res_blocks=2, attention=True), (8, 7), 2, None),
+    ('recnet_pin', dict(backbone_block='convnet', time_window=2, n_filters=4, n_blocks=1),
+     dict(upsampling='pin', scale=2, n_filters=4, n_res_blocks=1), (8, 8), 1, 2),
+    ('recnet_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4, time_window=3, n_filters=4,
+                                   n_blocks=1), dict(upsampling='spc', scale=4, n_filters=4, n_res_blocks=1), (4, 6), 4, 3),
+]
+
+
+@pytest.mark.parametrize('gkind,gcfg,dcfg,lr_hw,scale,tw', CGAN_CASES)
+def test_cgan_step_discriminator_variants(gkind, gcfg, dcfg, lr_hw, scale, tw):
+    """CGAN step with the discriminator forms of discriminator.py:31-33,52-63,73-74: post-upsampling generators (HR
+    branch reduced by stride-2 convolutions -- 'same' for scale 4, 'valid' + crop for scale 5 -- or bilinear resizing),
+    LayerNormalization in the residual blocks, and the spatio-temporal form (ConvLSTM + LN stem, 3-D pooling)."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import CGANEngine
+    B = 2
+    h, w = lr_hw
+    H, W = h * scale, w * scale
+    lead = () if tw is None else (tw,)
+    n_ch = 2
+    if gkind == 'net_postupsampling':
+        gen = PM.net_postupsampling(n_channels=n_ch, n_aux_channels=1, lr_size=(h, w), seed=3, **gcfg)
+    elif gkind == 'recnet_pin':
+        gen = PM.recnet_pin(n_channels=n_ch, n_aux_channels=1, hr_size=(H, W), seed=3, **gcfg)
+    else:
+        gen = PM.recnet_postupsampling(n_channels=n_ch, n_aux_channels=1, lr_size=(h, w), seed=3, **gcfg)
+    dkw = {k: v for k, v in dcfg.items() if k not in ('upsampling', 'scale')}
+    disc = PM.residual_discriminator(n_ch, dcfg['upsampling'], tw is not None, dcfg['scale'], (h, w), hr_size=(H, W),
+                                     time_window=tw, seed=4, **dkw)
+    rng = np.random.default_rng(9)
+    for m in (gen, disc):
+        wts = m.get_weights()
+        for k in wts:
+            if k.endswith('bias') or k.endswith('beta'):
+                wts[k] = (rng.standard_normal(wts[k].shape) * 0.05).astype(np.float32)
+        m.set_weights(wts)
+    PG = M.Params(); PD = M.Params()
+    for k, v in gen.get_weights().items():
+        PG[k] = v.astype(np.float64)
+    for k, v in disc.get_weights().items():
+        PD[k] = v.astype(np.float64)
+    lr = rng.random((B,) + lead + (h, w, n_ch)).astype(np.float32)
+    st = rng.random((B, H, W, 1)).astype(np.float32)
+    hr = rng.random((B,) + lead + (H, W, 1)).astype(np.float32)
+    nf_merge = 2 * dcfg['n_filters']
+    mask = (rng.random((2 * B, nf_merge)) > 0.4).astype(np.float32)
+    PGt, PDt = M.convert(PG, T, requires_grad=True), M.convert(PD, T, requires_grad=True)
+    t64 = lambda a: T.asarray(a.astype(np.float64))
+    ocfg = dict(dcfg, lr_size=(h, w))
+    ref = TR.cgan_step(gkind, gcfg, PGt, ocfg, PDt, t64(lr), t64(hr), t64(st),
+                       dropout_masks=(t64(mask[:B]), t64(mask[B:])))
+    assert set(PD.keys()) == set(ref['gradsD'].keys())
+    eng = CGANEngine(gen, disc, loss='mae', learning_rate=2e-4, beta_1=0.5)
+    out = eng.step([lr, st], hr, dropout_keep=mask, apply_update=False)
+    for i, k in enumerate(('gen_total', 'gen_gan', 'gen_px', 'disc')):
+        assert out[i] == pytest.approx(ref[k], rel=1e-4), k
+    gg, gd = gen.get_gradients(), disc.get_gradients()
+    sg = max(float(v.abs().max()) for v in ref['gradsG'].values())
+    sd = max(float(v.abs().max()) for v in ref['gradsD'].values())
+    for k, v in ref['gradsG'].items():
+        assert np.abs(gg[k] - v.numpy()).max() / sg < 1e-3, k
+    for k, v in ref['gradsD'].items():
+        assert np.abs(gd[k] - v.numpy()).max() / sd < 1e-3, k
+
+
 # ------------------------------------------------------------------------------------------------ block variants (f2)
 def _oracle_pass(kind, ocfg, P, x, s, y, loss, ctx_kw, noises, training=True):
     """Training-mode oracle pass (torch fp64) with the dropout noise the device drew: loss, grads, prediction, ctx."""

@@ -361,6 +361,18 @@ def test_msdssim_losses(ops, kind, case):
     np.testing.assert_array_equal(g, g2)                    # deterministic reductions
 
 
+def untie(x, pre_fn, thr=2e-4):
+    """Move the inputs whose fp64 pre-activation lies within ``thr`` of zero: in fp32 such an element takes either
+    ReLU branch, so the comparison would test the tie and not the kernel."""
+    for _ in range(8):
+        bad = np.abs(pre_fn(x.astype(np.float64))) < thr
+        if not bad.any():
+            return x
+        x = x.copy()
+        x[bad] += np.float32(0.03)
+    raise AssertionError('could not remove the ReLU ties')
+
+
 NORM_SHAPES = [(2, 9, 7, 3), (1, 16, 16, 64), (3, 5, 11, 20), (2, 4, 6, 130), (1, 33, 17, 256), (2, 3, 5, 1), (1, 8, 8, 1000)]
 
 
@@ -375,6 +387,8 @@ def test_layernorm(ops, shape, relu):
     beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
     dy = rng.standard_normal(shape).astype(np.float32)
     for eps in (1e-3, 1e-6):
+        if relu and c > 1:
+            x = untie(x, lambda v: N.layer_norm(v, gamma.astype(np.float64), beta.astype(np.float64), eps))
         tx, tg, tb = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, gamma, beta)]
         ty = T.layer_norm(tx, tg, tb, eps)
         if relu:
@@ -395,11 +409,17 @@ def test_layernorm(ops, shape, relu):
 def test_batchnorm(ops, shape, relu):
     """BatchNormalization(axis=-1), momentum 0.99, eps 1e-3 (blocks.py:66-68): training-mode output, gradients and
     moving-average update (Bessel-corrected variance), then the inference-mode output; a channel offset of 50 sigma
-    checks the shifted-sum statistics."""
+    checks the shifted-sum statistics (without ReLU: at that offset fp32 cannot resolve the sign of the smallest
+    pre-activations)."""
     c = shape[-1]
-    x = (rng.standard_normal(shape) * 0.5 + 25.0 * rng.standard_normal(c)).astype(np.float32)
+    x = (rng.standard_normal(shape) * 0.5 + (0.3 if relu else 25.0) * rng.standard_normal(c)).astype(np.float32)
     gamma = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32)
     beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+    if relu:
+        def pre(v):
+            mu, var = N.channel_moments(v)
+            return N.batch_norm(v, gamma.astype(np.float64), beta.astype(np.float64), mu, var, 1e-3)
+        x = untie(x, pre)
     mm = rng.standard_normal(c).astype(np.float32)
     mv = (0.5 + rng.random(c)).astype(np.float32)
     dy = rng.standard_normal(shape).astype(np.float32)

@@ -64,6 +64,47 @@ def test_cgan_trainer_runs():
     assert all(abs(a - (b + 100 * c)) < 1e-3 * abs(a) for a, b, c in zip(t.gentotal, t.gengan, t.genpxloss))
 
 
+def test_cgan_trainer_postupsampling_and_spatiotemporal():
+    """CGANTrainer with a post-upsampling generator (discriminator HR branch reduced by stride-2 convolutions,
+    discriminator.py:52-60), with normalised / dropout generator blocks, and the spatio-temporal pair (:31-33,73-74)."""
+    from dl4ds_amd.training import CGANTrainer
+    tr, te = _fields(16, 32, 0), _fields(6, 32, 1)
+    topo = np.random.default_rng(3).random((32, 32)).astype(np.float32)
+    t = CGANTrainer('resnet', 'spc', tr, te, static_vars=[topo], scale=4, batch_size=4, epochs=2, verbose=False,
+                    generator_params=dict(n_filters=4, n_blocks=1, normalization='ln', dropout_rate=0.1),
+                    discriminator_params=dict(n_filters=4, n_res_blocks=1, normalization='ln'))
+    t.run()
+    assert t.generator.name == 'resnet_spc' and len(t.gentotal) == 8
+    assert np.isfinite(t.gentotal).all() and np.isfinite(t.disc).all()
+    t = CGANTrainer('convnet', 'pin', tr, te, static_vars=[topo], scale=2, time_window=2, batch_size=2, epochs=1,
+                    verbose=False, generator_params=dict(n_filters=4, n_blocks=1),
+                    discriminator_params=dict(n_filters=4, n_res_blocks=1))
+    t.run()
+    assert t.generator.name == 'recconvnet_pin'
+    assert np.isfinite(t.gentotal).all() and np.isfinite(t.disc).all()
+
+
+def test_supervised_trainer_batchnorm_dropout():
+    """normalization='bn' + Gaussian dropout through SupervisedTrainer: training uses batch statistics and noise, the
+    validation / test losses and Predictor run in inference mode on the moving statistics."""
+    from dl4ds_amd.training import SupervisedTrainer
+    from dl4ds_amd.inference import Predictor
+    tr, va, te = _fields(24, 32, 0), _fields(8, 32, 1), _fields(8, 32, 2)
+    t = SupervisedTrainer('resnet', 'spc', tr, va, te, scale=4, batch_size=4, epochs=3, learning_rate=2e-3, verbose=False,
+                          n_blocks=2, n_filters=4, normalization='bn', dropout_rate=0.1, dropout_variant='gaussian',
+                          save=False)
+    t.run()
+    assert np.isfinite(t.fithist['loss']).all() and np.isfinite(t.fithist['val_loss']).all() and np.isfinite(t.test_loss)
+    w = t.model.get_weights()
+    mv = [k for k in w if k.endswith('moving_variance')]
+    assert mv and any(not np.allclose(w[k], 1.0) for k in mv)                 # moving statistics were maintained
+    assert len(t.model.trainable_variables) == len(w) - 2 * len(mv)
+    lr = te.reshape(8, 8, 4, 8, 4, 1).mean(axis=(2, 4))
+    y1 = Predictor(t, lr, scale=4, batch_size=3).run()
+    y2 = Predictor(t, lr, scale=4, batch_size=8).run()
+    np.testing.assert_allclose(y1, y2, rtol=1e-5, atol=1e-6)                   # inference does not depend on the batch
+
+
 def test_bucketed_rccl_allreduce_single_rank_matches_local_step():
     """The data-parallel step (gradient buckets all-reduced on the communication stream while the backward pass is
     still running, 1/world folded into Adam) on a 1-rank RCCL communicator must reproduce the plain step bit for bit:
