@@ -293,6 +293,21 @@ int dl4ds_op_maxpool2_bwd(const float* x, const float* y, const float* dy, float
                       make_view(nc(dy), N, H / 2, W / 2, C), make_view(dx, N, H, W, C), acc);
     API_END
 }
+int dl4ds_op_dwconv_fwd(const float* x, const float* k, const float* bias, float* y, int N, int H, int W, int C, int KS) {
+    API_BEGIN
+    dwconv_forward(S(), x, k, bias, y, N, H, W, C, KS, 0, 0);
+    API_END
+}
+int dl4ds_op_dwconv_bwd(const float* x, const float* k, const float* dy, float* dx, float* dk, float* db, int N, int H, int W, int C,
+                        int KS, int accumulate) {
+    API_BEGIN
+    if (dx) dwconv_forward(S(), dy, k, nullptr, dx, N, H, W, C, KS, 1, accumulate);
+    if (dk) {
+        const size_t ws = dwconv_wgrad_workspace_bytes(C, KS);
+        dwconv_wgrad(S(), x, dy, dk, db, accumulate, N, H, W, C, KS, scratch(ws), ws);
+    }
+    API_END
+}
 int dl4ds_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, size_t npix, int C, float eps,
                            int relu) {
     API_BEGIN
@@ -479,6 +494,11 @@ int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, 
 int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out) {
     API_BEGIN
     *out = g_gap(g->g, in, 0);
+    API_END
+}
+int dl4ds_graph_dwconv(dl4ds_graph* g, int in, int w, int b, int KS, int* out) {
+    API_BEGIN
+    *out = g_dwconv(g->g, in, w, b, KS);
     API_END
 }
 int dl4ds_graph_gap3d(dl4ds_graph* g, int in, int* out) {

@@ -1277,7 +1277,7 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     p.tiles_y = cdiv(x.H, 8);
     p.ntiles = p.tiles_x * p.tiles_y * x.N;
     p.CIT = (x.C > 32) ? 3 : (x.C > 16 ? 2 : 1);
-    if (KS == 5) p.CIT = 1;
+    if (KS >= 5) p.CIT = 1;
     p.WCO = (dz.C <= 16) ? 1 : (dz.C <= 32 ? 2 : 4);
     p.WK = 4 / p.WCO;
     const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
@@ -1315,8 +1315,9 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     }
     static std::once_flag once;
     std::call_once(once, [&]() {
+        // 7x7 (ConvNext stem / tail): the cross-wave reduction buffer alone is 100 KB -> one workgroup per CU
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, CIT, COT, WCO, PF>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, KS >= 7 ? kLdsMax : kLdsBudget));
         if constexpr (ROWS_OK) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_ws_kernel<CIT, WCO>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax));
@@ -1324,7 +1325,7 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         }
     });
-    DL4DS_REQUIRE(lds <= (size_t)(ws ? kLdsMax : kLdsBudget), "wgrad tile does not fit in LDS");
+    DL4DS_REQUIRE(lds <= (size_t)((ws || KS >= 7) ? kLdsMax : kLdsBudget), "wgrad tile does not fit in LDS");
     dim3 grid((unsigned)pl.S, (unsigned)cdiv(p.Cout, COB), (unsigned)cdiv(p.Cin, CIB));
     const double px = (double)p.x.N * p.H * p.W;
     ProfScope ps(s, std::string(rows ? "conv_wgrad_rows<" : "conv_wgrad<") + std::to_string(KS) + "," + std::to_string(CIT) +
@@ -1372,7 +1373,8 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
         case 1: dispatch_fwd<1>(s, p, in.N); break;
         case 3: dispatch_fwd<3>(s, p, in.N); break;
         case 5: dispatch_fwd<5>(s, p, in.N); break;
-        default: throw Dl4dsError("conv2d: kernel size " + std::to_string(KS) + " not supported (1,3,5)");
+        case 7: dispatch_fwd<7>(s, p, in.N); break;       // ConvNext stem / tail (sp_postups.py:121,205-210)
+        default: throw Dl4dsError("conv2d: kernel size " + std::to_string(KS) + " not supported (1,3,5,7)");
     }
 }
 
@@ -1414,7 +1416,8 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
             case 1: dispatch_wgrad<1>(s, p, pl); break;
             case 3: dispatch_wgrad<3>(s, p, pl); break;
             case 5: dispatch_wgrad_wco<5, 1>(s, p, pl); break;
-            default: throw Dl4dsError("wgrad: kernel size not supported (1,3,5)");
+            case 7: dispatch_wgrad_wco<7, 1>(s, p, pl); break;
+            default: throw Dl4dsError("wgrad: kernel size not supported (1,3,5,7)");
         }
     }
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 16), 8192));

@@ -479,7 +479,7 @@ T* push(Graph& g) {
 // ============================================================================================ constructors
 int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu, int d2s) {
     const GTensor ti = g.tensors.at(in);
-    DL4DS_REQUIRE(KS == 1 || KS == 3 || KS == 5, "conv2d: kernel size must be 1, 3 or 5");
+    DL4DS_REQUIRE(KS == 1 || KS == 3 || KS == 5 || KS == 7, "conv2d: kernel size must be 1, 3, 5 or 7");
     DL4DS_REQUIRE(g.params.at(w).n == (size_t)KS * KS * ti.C * Cout, "conv2d: kernel parameter size mismatch");
     if (b >= 0) DL4DS_REQUIRE(g.params.at(b).n == (size_t)Cout, "conv2d: bias size mismatch");
     int out;

@@ -113,7 +113,50 @@ struct SliceOp : GOp {
     }
 };
 
+// ============================================================================================ DepthwiseConv2D 7x7
+struct DwConvOp : GOp {
+    int in, out, w, b, KS;
+    DwConvOp() { kind = "dwconv"; }
+    size_t workspace_bytes(Graph& g, int) override { return dwconv_wgrad_workspace_bytes(g.tensors[in].C, KS); }
+    void forward(Graph& g, int B, bool) override {
+        const GTensor& t = g.tensors[in];
+        dwconv_forward(g.stream, t.data, g.wp(w), b >= 0 ? g.wp(b) : nullptr, g.tensors[out].data, B * t.nmul, t.H, t.W, t.C, KS,
+                       0, 0);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        const GTensor& t = g.tensors[in];
+        const int cnt = (c.b_cnt < 0 ? c.B : c.b_cnt) * t.nmul;
+        const size_t off = (size_t)c.b_off * t.per_sample();
+        const float* dy = g.tensors[out].grad + off;
+        if (c.param_grads) {
+            dwconv_wgrad(g.stream, t.data + off, dy, g.gp(w), b >= 0 ? g.gp(b) : nullptr, g.params[w].grad_written, cnt, t.H, t.W,
+                         t.C, KS, g.workspace, g.workspace_bytes);
+            g.params[w].grad_written = true;
+            if (b >= 0) g.params[b].grad_written = true;
+        }
+        if (wants_grad(g, in, c)) {
+            dwconv_forward(g.stream, dy, g.wp(w), nullptr, t.grad + off, cnt, t.H, t.W, t.C, KS, 1, t.grad_written);
+            g.tensors[in].grad_written = true;
+        }
+    }
+};
+
 }  // namespace
+
+int g_dwconv(Graph& g, int in, int w, int b, int KS) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(KS == 7, "depthwise conv: kernel size must be 7");
+    DL4DS_REQUIRE(g.params.at(w).n == (size_t)KS * KS * ti.C, "depthwise conv: kernel size mismatch");
+    DL4DS_REQUIRE(b < 0 || g.params.at(b).n == (size_t)ti.C, "depthwise conv: bias size mismatch");
+    const int out = g.add_tensor(ti.H, ti.W, ti.C, ti.nmul, true, false);
+    DwConvOp* op = new DwConvOp();
+    g.ops.emplace_back(op);
+    op->in = in; op->out = out; op->w = w; op->b = b; op->KS = KS;
+    g.tensors[in].n_other++;
+    op->pids = b >= 0 ? std::vector<int>{w, b} : std::vector<int>{w};
+    return out;
+}
 
 int g_slice(Graph& g, int in, int oy, int ox, int step, int Ho, int Wo) {
     const GTensor ti = g.tensors.at(in);

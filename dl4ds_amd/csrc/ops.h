@@ -60,6 +60,12 @@ void act_forward(hipStream_t s, const float* x, float* y, size_t n, int kind);
 void act_backward(hipStream_t s, const float* x, const float* dy, float* dx, size_t n, int kind,
                   int accumulate);
 void fill(hipStream_t s, float* p, size_t n, float v);
+// DepthwiseConv2D(7, 'same') of ConvNextBlock (dwconv.hip).  flip != 0: mirrored taps = the input gradient.
+void dwconv_forward(hipStream_t s, const float* x, const float* k, const float* bias, float* y, int N, int H, int W, int C,
+                    int KS, int flip, int accumulate);
+size_t dwconv_wgrad_workspace_bytes(int C, int KS);
+void dwconv_wgrad(hipStream_t s, const float* x, const float* dy, float* dk, float* db, int accumulate, int N, int H, int W, int C,
+                  int KS, float* ws, size_t ws_bytes);
 // LayerNormalization / BatchNormalization over the channel axis of [npix][C] (norm.hip), optional fused ReLU
 size_t norm_workspace_bytes(int C);
 void layernorm_forward(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, size_t npix, int C,

@@ -83,9 +83,11 @@ class GraphBuilder:
         return t
 
     # ---------------------------------------------------------------- ops
-    def conv2d(self, x, name, filters, ks, use_bias=True, activation=None, add=None, d2s=0):
+    def conv2d(self, x, name, filters, ks, use_bias=True, activation=None, add=None, d2s=0, dense=False):
+        """``dense=True``: a Keras Dense layer applied to the channel axis (ConvNextBlock.pwconv1/2, blocks.py:146,149)
+        -- a 1x1 convolution whose kernel variable keeps the Dense shape (Cin, units)."""
         activation = _check_activation(activation)
-        w = self.param(name + '/kernel', (ks, ks, x.C, filters))
+        w = self.param(name + '/kernel', (x.C, filters) if dense else (ks, ks, x.C, filters))
         b = self.param(name + '/bias', (filters,), 'zeros') if use_bias else -1
         out = ctypes.c_int()
         _lib.check(self._l.dl4ds_graph_conv2d(self.h, x.id, w, b, -1 if add is None else add.id, int(ks),
@@ -94,6 +96,14 @@ class GraphBuilder:
         if activation not in (None, 'relu'):
             y = self.act(y, activation, name + '/act')
         return y
+
+    def dwconv(self, x, name, ks=7, use_bias=True):
+        """DepthwiseConv2D(kernel_size=ks, padding='same', depth_multiplier=1) -- blocks.py:143-144."""
+        w = self.param(name + '/depthwise_kernel', (ks, ks, x.C, 1))
+        b = self.param(name + '/bias', (x.C,), 'zeros') if use_bias else -1
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_dwconv(self.h, x.id, w, b, int(ks), ctypes.byref(out)))
+        return self._out(out.value, 'depthwise_conv2d', name)
 
     def conv2d_transpose(self, x, name, filters, ks, stride, activation=None):
         activation = _check_activation(activation)

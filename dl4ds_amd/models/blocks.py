@@ -65,6 +65,24 @@ def residual_block(g, name, x, filters, activation='relu', normalization=None, a
     return g.conv2d(y, name + '/conv2', filters, 3, activation=activation, add=skip)
 
 
+def convnext_block(g, name, x, filters, use_1x1conv=False, activation='gelu', normalization='ln'):
+    """ConvNextBlock.call -- blocks.py:175-187 as the builders instantiate it (drop_path=0, layer_scale_init_value=0:
+    no DropPath, no gamma): dwconv 7x7 -> norm (LayerNormalization(epsilon=1e-6) | BatchNormalization()) -> Dense(4f)
+    -> activation -> Dense(f) -> + (conv1x1(input) | input).  The reference only defines ``self.norm`` for 'bn' / 'ln'
+    (:155-159) and then calls it unconditionally (:177), so normalization=None fails there with AttributeError; the
+    same request is refused here."""
+    if normalization not in ('bn', 'ln'):
+        raise ValueError("ConvNextBlock needs normalization='ln' or 'bn' (the reference raises AttributeError for None: "
+                         "blocks.py:155-159,177)")
+    y = g.dwconv(x, name + '/dwconv', 7)
+    y = g.norm(y, name + '/norm', normalization, epsilon=1e-6 if normalization == 'ln' else 1e-3)
+    y = g.conv2d(y, name + '/pwconv1', 4 * filters, 1, activation=activation, dense=True)
+    skip = g.conv2d(x, name + '/conv1x1', filters, 1) if use_1x1conv else x
+    if skip.C != filters:
+        raise ValueError(f'ConvNextBlock: input has {skip.C} channels but filters={filters}; use_1x1conv=True is needed')
+    return g.conv2d(y, name + '/pwconv2', filters, 1, add=skip, dense=True)
+
+
 def dense_block(g, name, x, filters, activation='relu', normalization=None, attention=False,
                 dropout_rate=0, dropout_variant=None):
     """DenseBlock.call -- blocks.py:262-277.  conv1 consumes the RAW X (line 267): norm1 / dropout1 are

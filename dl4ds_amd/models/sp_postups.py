@@ -2,16 +2,26 @@
 from ..graph import GraphBuilder, Model
 from ..utils import checkarg_backbone, checkarg_upsampling, checkarg_dropout_variant
 from .blocks import (conv_block, residual_block, dense_block, transition_block, localized_conv_block,
-                     subpixel_block, resize_conv_block, deconv_block, _reject_unsupported)
+                     subpixel_block, resize_conv_block, deconv_block, convnext_block, _reject_unsupported)
 
 
 def backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, normalization, attention,
                      dropout_rate, dropout_variant):
     """Backbone shared by sp_postups.py:132-168 and sp_preups.py:115-151."""
-    if backbone_block in ('convnext', 'unet'):
-        raise NotImplementedError(f"backbone_block={backbone_block!r} is not implemented for this builder on the "
-                                  "MI355X path")
+    if backbone_block == 'unet':
+        raise ValueError("backbone_block='unet' is built by unet_pin")
     _reject_unsupported(normalization, dropout_rate, dropout_variant)
+    if backbone_block == 'convnext':
+        # sp_postups.py:120-131 / sp_preups.py:104-114: 7x7 stem, ConvNext blocks (no dropout, no attention), then
+        # TransitionBlock(stem) + blocks
+        init_n_filters = n_filters
+        x = b = g.conv2d(x_in, 'stem', n_filters, 7)
+        for i in range(n_blocks):
+            n_filters = init_n_filters * (i + 1)
+            b = convnext_block(g, f'ConvNextBlock{i+1}', b, n_filters, use_1x1conv=(i != 0), activation=activation,
+                               normalization=normalization)
+        x = transition_block(g, 'TransitionSkip', x, n_filters, activation)
+        return g.add(x, b, name='backbone_add'), n_filters
     blk = dict(activation=activation, normalization=normalization, attention=attention, dropout_rate=dropout_rate,
                dropout_variant=dropout_variant)
     init_n_filters = n_filters
@@ -41,19 +51,25 @@ def backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, n
 
 
 def tail_section(g, x, s_in, init_n_filters, n_filters_aux, n_channels_out, activation, output_activation,
-                 normalization, dropout_rate, localcon_layer):
-    """sp_postups.py:184-212 / sp_preups.py:155-183 / :289-309."""
+                 normalization, dropout_rate, localcon_layer, convnext=False):
+    """sp_postups.py:184-212 / sp_preups.py:155-183 / :289-309.  ``convnext``: the auxiliary branch is a ConvNextBlock
+    and the two closing ConvBlocks use 7x7 kernels (`ks`, sp_postups.py:121,193-210)."""
+    ks = 7 if convnext else 3
     if localcon_layer:
         lws = localized_conv_block(g, 'LocalizedConvBlock', x)
         x = g.concat([x, lws], 'lcb_concat')
     if s_in is not None:
-        s = conv_block(g, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
-                       normalization=normalization, attention=False)
+        if convnext:
+            s = convnext_block(g, 'ConvNextBlock_aux', s_in, n_filters_aux, use_1x1conv=True, activation=activation,
+                               normalization=normalization)
+        else:
+            s = conv_block(g, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
+                           normalization=normalization, attention=False)
         x = g.concat([x, s], 'aux_concat')
     x = transition_block(g, 'TransitionLast', x, init_n_filters)
-    x = conv_block(g, 'ConvBlock_att', x, init_n_filters, activation=None, normalization=normalization,
-                   attention=True, dropout_rate=dropout_rate)
-    return conv_block(g, 'ConvBlock_out', x, n_channels_out, activation=output_activation,
+    x = conv_block(g, 'ConvBlock_att', x, init_n_filters, ks_cl1=ks, ks_cl2=ks, activation=None,
+                   normalization=normalization, attention=True, dropout_rate=dropout_rate)
+    return conv_block(g, 'ConvBlock_out', x, n_channels_out, ks_cl1=ks, ks_cl2=ks, activation=output_activation,
                       normalization=normalization, attention=False)
 
 
@@ -83,7 +99,7 @@ def net_postupsampling(backbone_block, upsampling, scale, n_channels, n_aux_chan
     else:
         raise ValueError("net_postupsampling needs a post-upsampling method ('spc', 'rc' or 'dc')")
     x = tail_section(g, x, s_in, n_filters, nf, n_channels_out, activation, output_activation,
-                     normalization, dropout_rate, localcon_layer)
+                     normalization, dropout_rate, localcon_layer, convnext=(backbone_block == 'convnext'))
     g.finalize(x, seed)
     shapes = [(h_lr, w_lr, n_channels)] + ([(h_hr, w_hr, n_aux_channels)] if s_in is not None else [])
     return Model(g, model_name, shapes)

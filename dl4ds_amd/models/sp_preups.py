@@ -19,7 +19,7 @@ def net_pin(backbone_block, n_channels, n_aux_channels, hr_size, n_channels_out=
     x, nf = backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, normalization,
                              attention, dropout_rate, dropout_variant)
     x = tail_section(g, x, s_in, n_filters, nf, n_channels_out, activation, output_activation,
-                     normalization, dropout_rate, localcon_layer)
+                     normalization, dropout_rate, localcon_layer, convnext=(backbone_block == 'convnext'))
     g.finalize(x, seed)
     shapes = [(h_hr, w_hr, n_channels)] + ([(h_hr, w_hr, n_aux_channels)] if s_in is not None else [])
     return Model(g, backbone_block + '_pin', shapes)

@@ -129,6 +129,24 @@ def maxpool2_bwd(x, y, dy):
     return dx.numpy()
 
 
+def dwconv(x, k, bias=None, dy=None, accumulate_into=None):
+    """DepthwiseConv2D(7, 'same')(x); with ``dy`` also (dx, dk, db).  k: (7,7,C,1) or (7,7,C)."""
+    n, h, w, c = x.shape
+    ks = k.shape[0]
+    dx_, dk_ = _d(x), _d(np.ascontiguousarray(k, np.float32).reshape(ks, ks, c))
+    db_ = None if bias is None else _d(bias)
+    y = DeviceArray.zeros(x.shape)
+    _lib.check(_lib.lib().dl4ds_op_dwconv_fwd(dx_.ptr, dk_.ptr, None if db_ is None else db_.ptr, y.ptr, n, h, w, c, ks))
+    if dy is None:
+        return y.numpy()
+    ddy = _d(dy)
+    gx = DeviceArray.zeros(x.shape) if accumulate_into is None else _d(accumulate_into)
+    gk, gb = DeviceArray.zeros((ks, ks, c)), DeviceArray.zeros((c,))
+    _lib.check(_lib.lib().dl4ds_op_dwconv_bwd(dx_.ptr, dk_.ptr, ddy.ptr, gx.ptr, gk.ptr, gb.ptr, n, h, w, c, ks,
+                                              int(accumulate_into is not None)))
+    return y.numpy(), gx.numpy(), gk.numpy().reshape(k.shape), gb.numpy()
+
+
 def layernorm(x, gamma, beta, eps=1e-3, relu=False, dy=None):
     """LayerNormalization(axis=-1)(x) [+ ReLU]; with ``dy`` also (dx, dgamma, dbeta)."""
     c = x.shape[-1]

@@ -79,6 +79,12 @@ int dl4ds_op_space_to_depth(const float* y_dev, float* x_dev, int N, int H, int 
 int dl4ds_op_maxpool2_fwd(const float* x_dev, float* y_dev, int N, int H, int W, int C);
 int dl4ds_op_maxpool2_bwd(const float* x_dev, const float* y_dev, const float* dy_dev, float* dx_dev, int N,
                           int H, int W, int C);
+/* DepthwiseConv2D(kernel_size=7, padding='same', depth_multiplier=1) -- ConvNextBlock.dwconv, blocks.py:143-144.
+ * k: (7,7,C) taps (Keras (7,7,C,1)), bias (C) or NULL.  bwd: dx / dk (+ db) may be NULL; accumulate adds into them. */
+int dl4ds_op_dwconv_fwd(const float* x_dev, const float* k_dev, const float* bias_dev, float* y_dev, int N, int H, int W, int C,
+                        int KS);
+int dl4ds_op_dwconv_bwd(const float* x_dev, const float* k_dev, const float* dy_dev, float* dx_dev, float* dk_dev, float* db_dev,
+                        int N, int H, int W, int C, int KS, int accumulate);
 /* LayerNormalization(axis=-1) / BatchNormalization(axis=-1) over [npix][C] -- blocks.py:63-71,151-159,293-296.
  * relu: fuse the activation that follows.  bwd: y is only read when relu != 0; dx / dgamma / dbeta may be NULL;
  * accumulate != 0 adds into dx, dgamma, dbeta.  batchnorm: `saved` (2*C floats: batch mean, 1/std) is written by a
@@ -142,6 +148,8 @@ int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out)
 int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out);
 int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out);
 int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out);
+/* DepthwiseConv2D(7, 'same') + bias -- blocks.py:143-144 */
+int dl4ds_graph_dwconv(dl4ds_graph* g, int in, int w, int b, int KS, int* out);
 /* GlobalAveragePooling3D over the (time, H, W) axes of a time-distributed tensor -- discriminator.py:73-74 */
 int dl4ds_graph_gap3d(dl4ds_graph* g, int in, int* out);
 /* y[:, i, j, :] = x[:, oy + i*step, ox + j*step, :] (i < Ho, j < Wo): the sub-sampling half of Conv2D(strides=2)

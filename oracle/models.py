@@ -187,6 +187,27 @@ def residual_block(ops, P, name, x, filters, activation='relu', attention=False,
     return ops.activation(y, activation)
 
 
+def convnext_block(ops, P, name, x, filters, use_1x1conv=False, activation='gelu', normalization='ln', ctx=None):
+    """ConvNextBlock.call -- blocks.py:175-187 with drop_path=0 and layer_scale_init_value=0 (what every builder passes:
+    DropPath is the identity, gamma is None).  LayerNormalization(epsilon=1e-6) | BatchNormalization() (:155-159)."""
+    if normalization not in ('bn', 'ln'):
+        raise ValueError('ConvNextBlock has no norm layer for normalization=None (blocks.py:155-159,177)')
+    c = x.shape[-1]
+    k = P.get(ops, name + '/dwconv/depthwise_kernel', (7, 7, c, 1))
+    kb = P.get(ops, name + '/dwconv/bias', (c,), 'zeros')
+    y = ops.depthwise_conv2d(x, k, kb)
+    y = _norm(ops, P, ctx, name + '/norm', y, normalization, eps=1e-6 if normalization == 'ln' else 1e-3)
+    w1 = P.get(ops, name + '/pwconv1/kernel', (c, 4 * filters))
+    b1 = P.get(ops, name + '/pwconv1/bias', (4 * filters,), 'zeros')
+    y = ops.activation(ops.conv2d(y, w1.reshape((1, 1, c, 4 * filters)), b1), activation)
+    w2 = P.get(ops, name + '/pwconv2/kernel', (4 * filters, filters))
+    b2 = P.get(ops, name + '/pwconv2/bias', (filters,), 'zeros')
+    y = ops.conv2d(y, w2.reshape((1, 1, 4 * filters, filters)), b2)
+    if use_1x1conv:
+        x = _conv(ops, P, name + '/conv1x1', x, filters, 1)
+    return ops.add(x, y)
+
+
 def dense_block(ops, P, name, x, filters, activation='relu', attention=False, normalization=None,
                 dropout_rate=0, dropout_variant=None, ctx=None):
     """DenseBlock.call -- blocks.py:262-277.  NB conv1 consumes the RAW X (line 267): norm1(X), its activation and
@@ -317,6 +338,14 @@ def _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, att
     blk = dict(normalization=ctx.normalization, dropout_rate=ctx.dropout_rate, dropout_variant=ctx.dropout_variant,
                ctx=ctx)
     init_nf = n_filters
+    if backbone_block == 'convnext':                    # sp_postups.py:120-131
+        x = b = _conv(ops, P, 'stem', x_in, n_filters, 7)
+        for i in range(n_blocks):
+            n_filters = init_nf * (i + 1)
+            b = convnext_block(ops, P, f'ConvNextBlock{i+1}', b, n_filters, use_1x1conv=(i != 0),
+                               activation=activation, normalization=ctx.normalization, ctx=ctx)
+        x = transition_block(ops, P, 'TransitionSkip', x, n_filters, activation)
+        return ops.add(x, b), n_filters
     x = b = _conv(ops, P, 'stem', x_in, n_filters, 3)
     for i in range(n_blocks):
         n_filters = init_nf * (i + 1)
@@ -347,22 +376,28 @@ def _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, att
 
 
 def _tail(ops, P, x, s_in, init_nf, n_filters_aux, n_channels_out, activation,
-          output_activation, localcon_layer, aux_attention=False, ctx=None):
-    """sp_postups.py:184-212 / sp_preups.py:155-183.  ConvBlock_att gets dropout_rate but not the variant."""
+          output_activation, localcon_layer, aux_attention=False, ctx=None, convnext=False):
+    """sp_postups.py:184-212 / sp_preups.py:155-183.  ConvBlock_att gets dropout_rate but not the variant; the
+    'convnext' backbone switches the aux branch to a ConvNextBlock and the closing ConvBlocks to 7x7 kernels."""
     ctx = ctx or _NO_CTX
     nrm = ctx.normalization
+    ks = 7 if convnext else 3
     if localcon_layer:
         lws = localized_conv_block(ops, P, 'LocalizedConvBlock', x)
         x = ops.concat([x, lws])
     if s_in is not None:
-        s = conv_block(ops, P, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
-                       attention=aux_attention, normalization=nrm, ctx=ctx)
+        if convnext:
+            s = convnext_block(ops, P, 'ConvNextBlock_aux', s_in, n_filters_aux, use_1x1conv=True,
+                               activation=activation, normalization=nrm, ctx=ctx)
+        else:
+            s = conv_block(ops, P, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
+                           attention=aux_attention, normalization=nrm, ctx=ctx)
         x = ops.concat([x, s])
     x = transition_block(ops, P, 'TransitionLast', x, init_nf)
-    x = conv_block(ops, P, 'ConvBlock_att', x, init_nf, activation=None, attention=True, normalization=nrm,
-                   dropout_rate=ctx.dropout_rate, ctx=ctx)
-    x = conv_block(ops, P, 'ConvBlock_out', x, n_channels_out, activation=output_activation, normalization=nrm,
-                   ctx=ctx)
+    x = conv_block(ops, P, 'ConvBlock_att', x, init_nf, ks1=ks, ks2=ks, activation=None, attention=True,
+                   normalization=nrm, dropout_rate=ctx.dropout_rate, ctx=ctx)
+    x = conv_block(ops, P, 'ConvBlock_out', x, n_channels_out, ks1=ks, ks2=ks, activation=output_activation,
+                   normalization=nrm, ctx=ctx)
     return x
 
 
@@ -378,7 +413,7 @@ def net_postupsampling(ops, P, x_in, s_in=None, *, backbone_block, upsampling, s
         x = transition_block(ops, P, 'TransitionDC', x, n_filters, activation)
         x = deconv_block(ops, P, 'Deconvolution', x, scale, nf, activation)
     return _tail(ops, P, x, s_in, n_filters, nf, n_channels_out, activation,
-                 output_activation, localcon_layer, ctx=ctx)
+                 output_activation, localcon_layer, ctx=ctx, convnext=(backbone_block == 'convnext'))
 
 
 def net_pin(ops, P, x_in, s_in=None, *, backbone_block, n_channels_out=1, n_filters=8,
@@ -387,7 +422,7 @@ def net_pin(ops, P, x_in, s_in=None, *, backbone_block, n_channels_out=1, n_filt
     """sp_preups.py:83-189."""
     x, nf = _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention, ctx)
     return _tail(ops, P, x, s_in, n_filters, nf, n_channels_out, activation,
-                 output_activation, localcon_layer, ctx=ctx)
+                 output_activation, localcon_layer, ctx=ctx, convnext=(backbone_block == 'convnext'))
 
 
 def unet_pin(ops, P, x_in, s_in=None, *, n_filters, n_blocks, n_channels_out=1,

@@ -270,6 +270,19 @@ def dropout_noise(x, noise, rate, variant):
     return x * noise.reshape(x.shape) / (1.0 - rate)
 
 
+def depthwise_conv2d(x, k, b=None):
+    """tf.keras.layers.DepthwiseConv2D(padding='same', depth_multiplier=1): k (K,K,C,1), blocks.py:143-144."""
+    kh, kw, c, _ = k.shape
+    ph, pw = kh // 2, kw // 2
+    xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
+    h, w = x.shape[1], x.shape[2]
+    y = np.zeros(x.shape, dtype=np.result_type(x.dtype, k.dtype))
+    for ky in range(kh):
+        for kx in range(kw):
+            y += xp[:, ky:ky + h, kx:kx + w, :] * k[ky, kx, :, 0]
+    return y if b is None else y + b
+
+
 def layer_norm(x, gamma, beta, eps=1e-3):
     """tf.keras.layers.LayerNormalization(axis=-1): biased variance over the channel axis."""
     mu = x.mean(axis=-1, keepdims=True)

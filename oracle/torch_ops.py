@@ -225,6 +225,14 @@ def dropout_noise(x, noise, rate, variant):
     return x * noise.reshape(x.shape) / (1.0 - rate)
 
 
+def depthwise_conv2d(x, k, b=None):
+    kh, kw, c, _ = k.shape
+    w = k.permute(2, 3, 0, 1)                                   # (C, 1, K, K)
+    y = F.conv2d(_nchw(x), w, None, padding=(kh // 2, kw // 2), groups=c)
+    y = _nhwc(y)
+    return y if b is None else y + b
+
+
 def layer_norm(x, gamma, beta, eps=1e-3):
     mu = x.mean(dim=-1, keepdim=True)
     var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)

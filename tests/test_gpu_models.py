@@ -333,6 +333,14 @@ VARIANT_CASES = [
      (2, 2, 10, 6, 2), None),
     ('recnet_pin', dict(backbone_block='convnet', time_window=3, n_filters=4, n_blocks=1),
      dict(normalization='bn', dropout_rate=0.2), (2, 3, 8, 8, 2), None),
+    # ConvNext backbone (sp_postups.py:120-131,193-210): 7x7 stem, depthwise 7x7 + LN(1e-6) + Dense/act/Dense blocks,
+    # ConvNextBlock aux branch, 7x7 closing ConvBlocks
+    ('net_postupsampling', dict(backbone_block='convnext', upsampling='spc', scale=2, n_blocks=2, n_filters=8),
+     dict(normalization='ln'), (2, 12, 16, 2), (2, 24, 32, 1)),
+    ('net_postupsampling', dict(backbone_block='convnext', upsampling='rc', scale=2, n_blocks=1, n_filters=4,
+                                activation='gelu'), dict(normalization='bn', dropout_rate=0.2), (2, 10, 14, 1), None),
+    ('net_pin', dict(backbone_block='convnext', n_blocks=2, n_filters=8), dict(normalization='ln'), (2, 16, 16, 3),
+     (2, 16, 16, 2)),
 ]
 
 

@@ -39,6 +39,8 @@ CONV_CASES = [
     (1, 8, 16, 48, 192, 3), (1, 24, 24, 50, 40, 3), (2, 16, 32, 40, 48, 3), (1, 12, 12, 192, 48, 3),
     (2, 17, 16, 8, 48, 1), (1, 16, 16, 48, 8, 1), (1, 10, 10, 24, 200, 1), (1, 16, 16, 6, 12, 5),
     (1, 9, 9, 16, 32, 5), (1, 8, 8, 130, 128, 3), (1, 6, 6, 256, 100, 3),
+    # 7x7: ConvNext stem and closing ConvBlocks (sp_postups.py:121,205-210)
+    (2, 13, 19, 2, 8, 7), (1, 16, 16, 8, 8, 7), (1, 20, 17, 8, 1, 7), (1, 12, 12, 24, 24, 7), (1, 9, 9, 64, 16, 7),
     # stencil path (conv_direct.hip): pad2(Cin) * pad2(Cout) <= 8, ragged tiles, several tiles per block
     (2, 21, 70, 1, 1, 3), (1, 9, 33, 3, 1, 3), (2, 8, 32, 1, 3, 3), (1, 17, 40, 2, 4, 3), (1, 5, 5, 4, 2, 3),
     (3, 40, 100, 7, 1, 3), (1, 11, 65, 2, 2, 3), (1, 16, 31, 1, 7, 3), (1, 3, 2, 5, 1, 3),
@@ -442,3 +444,25 @@ def test_batchnorm(ops, shape, relu):
     close(yi, np.maximum(ref, 0) if relu else ref, 1e-4)
     np.testing.assert_array_equal(mm3, mm)
     np.testing.assert_array_equal(mv3, mv)
+
+
+@pytest.mark.parametrize('shape', [(2, 9, 7, 3), (1, 16, 16, 8), (2, 5, 20, 20), (1, 33, 17, 64), (1, 6, 6, 130), (1, 3, 2, 4),
+                                   (2, 40, 35, 48)])
+def test_depthwise_conv7(ops, shape):
+    """DepthwiseConv2D(7, 'same') of ConvNextBlock (blocks.py:143-144): forward, input gradient (mirrored taps, with
+    and without accumulation), kernel and bias gradients vs torch fp64; grids smaller than the kernel, channel counts
+    off the float4 path, more channel packs than one wgrad block holds."""
+    c = shape[-1]
+    x, k, b, dy = R(*shape), R(7, 7, c, 1) * 0.2, R(c), R(*shape)
+    tx, tk, tb = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, k, b)]
+    ty = T.depthwise_conv2d(tx, tk, tb)
+    ty.backward(torch.tensor(dy, dtype=torch.float64))
+    close(ops.dwconv(x, k, b), ty.detach().numpy())
+    close(ops.dwconv(x, k, None), N.depthwise_conv2d(x.astype(np.float64), k.astype(np.float64)))
+    y, gx, gk, gb = ops.dwconv(x, k, b, dy=dy)
+    close(gx, tx.grad.numpy())
+    close(gk, tk.grad.numpy(), 1e-3)
+    close(gb, tb.grad.numpy(), 1e-3)
+    base = R(*shape)
+    _, gx2, _, _ = ops.dwconv(x, k, b, dy=dy, accumulate_into=base)
+    close(gx2, tx.grad.numpy() + base)
