@@ -3,8 +3,9 @@
 //   x = y - min(y) if min(y) < 0 else y ;  q = p - min(p) if min(p) < 0 else p
 //   ssim   = tf.image.ssim(x, q, max_val=drange, 11x11 gaussian sigma 1.5, VALID, k1=.01, k2=.03)
 //   dssim  = mean_n((1 - ssim_n)/2)
-// Kernels: (1) min/max(+arg) reduction, (2) 16x16-tile SSIM map from an LDS halo tile (121 taps, four
-// filtered moments) emitting the three per-map derivatives, (3) the transposed 11x11 filter of those
+// Kernels: (1) min/max(+arg) reduction, (2) 16x16-tile SSIM map from an LDS halo tile -- the 11x11 Gaussian is applied
+// separably (row pass over the 26 halo rows into LDS, then the column pass per output: 2 x 11 taps instead of 121) to the
+// four moments -- emitting the three per-map derivatives, (3) the transposed (again separable) filter of those
 // derivatives per input pixel, (4) scalar fix-ups (drange and shift terms routed to arg-max / arg-min).
 #include "ops.h"
 #include "prof.h"
@@ -13,6 +14,8 @@
 namespace {
 
 constexpr int KF = 11, KH = 5, TS = 16, TL = TS + KF - 1;    // filter, half, tile, tile+halo
+constexpr int PT = 48;      // LDS pitch of the halo tiles: consecutive rows start 16 banks apart, so the 2 rows x 16 columns
+                            // a 32-lane LDS pass touches are conflict-free (the row-filtered tiles use pitch TS = 16 likewise)
 
 struct Gauss { float g[KF]; };
 Gauss make_gauss() {
@@ -59,18 +62,80 @@ __global__ void __launch_bounds__(256) minmax_kernel(const float* __restrict__ t
         pi[blockIdx.x * 2 + 1] = si[1][0];
     }
 }
-__global__ void minmax_finish_kernel(const float* __restrict__ pf, const unsigned long long* __restrict__ pi, int nb,
-                                     Stats* st) {
-    if (threadIdx.x || blockIdx.x) return;
-    float mnT = pf[0], mxT = pf[1], mnP = pf[2], mxP = pf[3];
-    unsigned long long amn = pi[0], amx = pi[1];
-    for (int k = 1; k < nb; ++k) {
+__global__ void __launch_bounds__(256) minmax_finish_kernel(const float* __restrict__ pf, const unsigned long long* __restrict__ pi,
+                                                            int nb, Stats* st) {
+    __shared__ float s[4][256];
+    __shared__ unsigned long long si[2][256];
+    const int i = threadIdx.x;
+    float mnT = 3.4e38f, mxT = -3.4e38f, mnP = 3.4e38f, mxP = -3.4e38f;
+    unsigned long long amn = ~0ull, amx = ~0ull;
+    for (int k = i; k < nb; k += 256) {
         mnT = fminf(mnT, pf[4 * k]); mxT = fmaxf(mxT, pf[4 * k + 1]);
         if (pf[4 * k + 2] < mnP || (pf[4 * k + 2] == mnP && pi[2 * k] < amn)) { mnP = pf[4 * k + 2]; amn = pi[2 * k]; }
         if (pf[4 * k + 3] > mxP || (pf[4 * k + 3] == mxP && pi[2 * k + 1] < amx)) { mxP = pf[4 * k + 3]; amx = pi[2 * k + 1]; }
     }
-    st->minT = mnT; st->maxT = mxT; st->minP = mnP; st->maxP = mxP; st->argminP = amn; st->argmaxP = amx;
+    s[0][i] = mnT; s[1][i] = mxT; s[2][i] = mnP; s[3][i] = mxP; si[0][i] = amn; si[1][i] = amx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {          // ties go to the smallest flat index, as a serial scan would pick
+        if (i < o) {
+            s[0][i] = fminf(s[0][i], s[0][i + o]);
+            s[1][i] = fmaxf(s[1][i], s[1][i + o]);
+            if (s[2][i + o] < s[2][i] || (s[2][i + o] == s[2][i] && si[0][i + o] < si[0][i])) { s[2][i] = s[2][i + o]; si[0][i] = si[0][i + o]; }
+            if (s[3][i + o] > s[3][i] || (s[3][i + o] == s[3][i] && si[1][i + o] < si[1][i])) { s[3][i] = s[3][i + o]; si[1][i] = si[1][i + o]; }
+        }
+        __syncthreads();
+    }
+    if (i) return;
+    st->minT = s[0][0]; st->maxT = s[1][0]; st->minP = s[2][0]; st->maxP = s[3][0]; st->argminP = si[0][0]; st->argmaxP = si[1][0];
     st->sumS = 0.f; st->gc1 = 0.f; st->gc2 = 0.f; st->sumdy = 0.f;
+}
+
+// Gaussian-filtered moments (mean x, mean q, E[xq], E[x^2 + q^2]) of this thread's output pixel of the tile: row pass of
+// all TL halo rows into h (all 256 threads; contains a barrier), then the column pass.
+struct MsMoments { float mx, my, A, Bq; };
+__device__ __forceinline__ MsMoments sep_moments(const float (*sx)[PT], const float (*sq)[PT], float (*h)[TL][TS], const Gauss& gk) {
+    for (int it = threadIdx.x; it < TL * TS; it += 256) {
+        const int r = it / TS, cx = it % TS;
+        float rx = 0.f, ry = 0.f, ra = 0.f, rb = 0.f;
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            const float a = sx[r][cx + j], q = sq[r][cx + j], w = gk.g[j];
+            rx += w * a; ry += w * q; ra += w * a * q; rb += w * (a * a + q * q);
+        }
+        h[0][r][cx] = rx; h[1][r][cx] = ry; h[2][r][cx] = ra; h[3][r][cx] = rb;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+    MsMoments m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KF; ++i) {
+        const float w = gk.g[i];
+        m.mx += w * h[0][ly + i][lx]; m.my += w * h[1][ly + i][lx]; m.A += w * h[2][ly + i][lx]; m.Bq += w * h[3][ly + i][lx];
+    }
+    return m;
+}
+// transposed filter of three derivative maps held as halo tiles starting (KF-1) pixels before the tile:
+// T_k = sum_{i,j} g[i] g[j] s_k[ly + KF-1 - i][lx + KF-1 - j]
+__device__ __forceinline__ void sep_transposed3(const float (*s1)[PT], const float (*s2)[PT], const float (*s3)[PT],
+                                                float (*h)[TL][TS], const Gauss& gk, float& T1, float& T2, float& T3) {
+    for (int it = threadIdx.x; it < TL * TS; it += 256) {
+        const int r = it / TS, cx = it % TS;
+        float r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            const float w = gk.g[j];
+            r1 += w * s1[r][cx + (KF - 1) - j]; r2 += w * s2[r][cx + (KF - 1) - j]; r3 += w * s3[r][cx + (KF - 1) - j];
+        }
+        h[0][r][cx] = r1; h[1][r][cx] = r2; h[2][r][cx] = r3;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+    T1 = T2 = T3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < KF; ++i) {
+        const float w = gk.g[i];
+        T1 += w * h[0][ly + (KF - 1) - i][lx]; T2 += w * h[1][ly + (KF - 1) - i][lx]; T3 += w * h[2][ly + (KF - 1) - i][lx];
+    }
 }
 
 // one block = one 16x16 tile of the (Ho,Wo) SSIM map of plane (n,c)
@@ -79,7 +144,7 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__
                                                        const Stats* __restrict__ st, float* __restrict__ dmu,
                                                        float* __restrict__ da, float* __restrict__ db,
                                                        float* __restrict__ partial) {
-    __shared__ float sx[TL][TL + 1], sq[TL][TL + 1];
+    __shared__ float sx[TL][PT], sq[TL][PT], hrow[4][TL][TS];
     __shared__ float red[3][256];
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
@@ -103,18 +168,9 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__
     const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
     const int oy = oy0 + ly, ox = ox0 + lx;
     float S = 0.f, g1 = 0.f, g2 = 0.f;
+    const MsMoments mom = sep_moments(sx, sq, hrow, gk);
     if (oy < Ho && ox < Wo) {
-        float mx = 0.f, my = 0.f, A = 0.f, Bq = 0.f;
-#pragma unroll
-        for (int i = 0; i < KF; ++i) {
-            float rx = 0.f, ry = 0.f, ra = 0.f, rb = 0.f;
-#pragma unroll
-            for (int j = 0; j < KF; ++j) {
-                const float a = sx[ly + i][lx + j], q = sq[ly + i][lx + j], w = gk.g[j];
-                rx += w * a; ry += w * q; ra += w * a * q; rb += w * (a * a + q * q);
-            }
-            mx += gk.g[i] * rx; my += gk.g[i] * ry; A += gk.g[i] * ra; Bq += gk.g[i] * rb;
-        }
+        const float mx = mom.mx, my = mom.my, A = mom.A, Bq = mom.Bq;
         const float N1 = 2.f * mx * my + c1, D1 = mx * mx + my * my + c1;
         const float N2 = 2.f * A - 2.f * mx * my + c2, D2 = Bq - mx * mx - my * my + c2;
         const float lum = N1 / D1, cs = N2 / D2;
@@ -135,6 +191,34 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__
     }
     if (threadIdx.x == 0)
         for (int k = 0; k < 3; ++k) partial[(size_t)blockIdx.x * 3 + k] = red[k][0];
+}
+
+// First stage of the long partial-sum reductions: out[g][k] = sum of in[r][k] over the g-th slice of the nb rows (fixed
+// order, double accumulation), so the single-block finishing kernels read COMPACT_G rows instead of one per tile.
+constexpr int COMPACT_G = 64;
+template <int K>
+__global__ void __launch_bounds__(256) compact_partials_kernel(const float* __restrict__ in, int nb, float* __restrict__ out) {
+    __shared__ double red[K][256];
+    const int chunk = (nb + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, nb);
+    double a[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = 0.0;
+    for (int r = r0 + threadIdx.x; r < r1; r += 256)
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] += (double)in[(size_t)r * K + k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[(size_t)blockIdx.x * K + k] = (float)red[k][0];
 }
 
 __global__ void sum3_kernel(const float* __restrict__ partial, int nb, Stats* st) {
@@ -159,7 +243,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ da, const float* __restrict__ db,
                                                        float coef, float* __restrict__ dpred, int accumulate,
                                                        float* __restrict__ partial) {
-    __shared__ float s1[TL][TL + 1], s2[TL][TL + 1], s3[TL][TL + 1];
+    __shared__ float s1[TL][PT], s2[TL][PT], s3[TL][PT], hrow[3][TL][TS];
     __shared__ float red[256];
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
@@ -182,20 +266,9 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__
     const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
     const int y = y0 + ly, x = x0 + lx;
     float g = 0.f;
+    float T1, T2, T3;
+    sep_transposed3(s1, s2, s3, hrow, gk, T1, T2, T3);
     if (y < H && x < W) {
-        float T1 = 0.f, T2 = 0.f, T3 = 0.f;
-#pragma unroll
-        for (int i = 0; i < KF; ++i) {
-            float r1 = 0.f, r2 = 0.f, r3 = 0.f;
-#pragma unroll
-            for (int j = 0; j < KF; ++j) {
-                const float w = gk.g[j];
-                r1 += w * s1[ly + (KF - 1) - i][lx + (KF - 1) - j];
-                r2 += w * s2[ly + (KF - 1) - i][lx + (KF - 1) - j];
-                r3 += w * s3[ly + (KF - 1) - i][lx + (KF - 1) - j];
-            }
-            T1 += gk.g[i] * r1; T2 += gk.g[i] * r2; T3 += gk.g[i] * r3;
-        }
         const size_t o = (((size_t)n * H + y) * W + x) * C + c;
         const float xv = t[o] - shT, qv = p[o] - shP;
         g = coef * (T1 + xv * T2 + 2.f * qv * T3);
@@ -234,7 +307,7 @@ __global__ void dssim_finish_kernel(const float* __restrict__ partial, int nb, S
     if (st->minP < 0.f) dpred[st->argminP] -= sumdy;         // q = p - min(p)
 }
 
-struct Layout { size_t stats, pf, pi, maps, part, total; int nb_mm; };
+struct Layout { size_t stats, pf, pi, maps, part, part2, total; int nb_mm; };
 Layout layout(int N, int H, int W, int C) {
     Layout l;
     const int Ho = H - KF + 1, Wo = W - KF + 1;
@@ -247,6 +320,7 @@ Layout layout(int N, int H, int W, int C) {
     l.maps = bump(3 * (size_t)N * C * Ho * Wo * sizeof(float));
     const size_t tiles = (size_t)N * C * cdiv(H, TS) * cdiv(W, TS);
     l.part = bump(tiles * 3 * sizeof(float));
+    l.part2 = bump((size_t)COMPACT_G * 3 * sizeof(float));
     l.total = o;
     return l;
 }
@@ -298,23 +372,6 @@ __global__ void ms_unpool_add_kernel(float* __restrict__ fine, const float* __re
     }
 }
 
-// moments of one output pixel from the LDS tiles (shared by the sum and the maps pass)
-struct MsMoments { float mx, my, A, Bq; };
-__device__ __forceinline__ MsMoments ms_moments(const float (*sx)[TL + 1], const float (*sq)[TL + 1], int ly, int lx, const Gauss& gk) {
-    MsMoments m{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < KF; ++i) {
-        float rx = 0.f, ry = 0.f, ra = 0.f, rb = 0.f;
-#pragma unroll
-        for (int j = 0; j < KF; ++j) {
-            const float a = sx[ly + i][lx + j], q = sq[ly + i][lx + j], w = gk.g[j];
-            rx += w * a; ry += w * q; ra += w * a * q; rb += w * (a * a + q * q);
-        }
-        m.mx += gk.g[i] * rx; m.my += gk.g[i] * ry; m.A += gk.g[i] * ra; m.Bq += gk.g[i] * rb;
-    }
-    return m;
-}
-
 // MODE 0: partial[block] = (sum ssim, sum cs) of the tile.  MODE 1: derivative maps weighted by gs[n,c] (ssim) and gc[n,c]
 // (cs), partial[block] = (d/dc1, d/dc2).  x / q: scale images (scale 0: raw y_true / y_pred, shifted here).
 template <int MODE>
@@ -323,7 +380,7 @@ __global__ void __launch_bounds__(256) ms_ssim_kernel(const float* __restrict__ 
                                                       const Stats* __restrict__ st, const float* __restrict__ gs,
                                                       const float* __restrict__ gc, float* __restrict__ dmu, float* __restrict__ da,
                                                       float* __restrict__ db, float* __restrict__ partial) {
-    __shared__ float sx[TL][TL + 1], sq[TL][TL + 1];
+    __shared__ float sx[TL][PT], sq[TL][PT], hrow[4][TL][TS];
     __shared__ float red[2][256];
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
@@ -347,8 +404,8 @@ __global__ void __launch_bounds__(256) ms_ssim_kernel(const float* __restrict__ 
     const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
     const int oy = oy0 + ly, ox = ox0 + lx;
     float r0 = 0.f, r1 = 0.f;
+    const MsMoments m = sep_moments(sx, sq, hrow, gk);
     if (oy < Ho && ox < Wo) {
-        const MsMoments m = ms_moments(sx, sq, ly, lx, gk);
         const float N1 = 2.f * m.mx * m.my + c1, D1 = m.mx * m.mx + m.my * m.my + c1;
         const float N2 = 2.f * m.A - 2.f * m.mx * m.my + c2, D2 = m.Bq - m.mx * m.mx - m.my * m.my + c2;
         const float lum = N1 / D1, cs = N2 / D2;
@@ -376,15 +433,19 @@ __global__ void __launch_bounds__(256) ms_ssim_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) { partial[(size_t)blockIdx.x * 2] = red[0][0]; partial[(size_t)blockIdx.x * 2 + 1] = red[1][0]; }
 }
 
-// mean_ssim[nc], mean_cs[nc] of one scale from its per-tile sums (tiles of a plane are consecutive blocks)
-__global__ void ms_means_kernel(const float* __restrict__ partial, int tiles, int NC, float inv_m, float* __restrict__ mean_ssim,
-                                float* __restrict__ mean_cs) {
-    const int nc = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nc >= NC) return;
+// mean_ssim[nc], mean_cs[nc] of one scale from its per-tile sums (tiles of a plane are consecutive blocks); one wavefront
+// per plane: lane-strided loads, fixed shuffle tree
+__global__ void __launch_bounds__(64) ms_means_kernel(const float* __restrict__ partial, int tiles, int NC, float inv_m,
+                                                      float* __restrict__ mean_ssim, float* __restrict__ mean_cs) {
+    const int nc = blockIdx.x;
     double a = 0, b = 0;
-    for (int k = 0; k < tiles; ++k) { a += partial[((size_t)nc * tiles + k) * 2]; b += partial[((size_t)nc * tiles + k) * 2 + 1]; }
-    mean_ssim[nc] = (float)(a * inv_m);
-    mean_cs[nc] = (float)(b * inv_m);
+    for (int k = threadIdx.x; k < tiles; k += 64) { a += partial[((size_t)nc * tiles + k) * 2]; b += partial[((size_t)nc * tiles + k) * 2 + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (threadIdx.x == 0) {
+        mean_ssim[nc] = (float)(a * inv_m);
+        mean_cs[nc] = (float)(b * inv_m);
+    }
 }
 
 // one block: loss value and the upstream weights gs[k][nc] (only the last scale), gc[k][nc] (the other scales)
@@ -427,7 +488,7 @@ __global__ void __launch_bounds__(256) ms_bwd_kernel(const float* __restrict__ x
                                                      int Ho, int Wo, int tiles_x, int tiles_y, Gauss gk, const Stats* __restrict__ st,
                                                      const float* __restrict__ dmu, const float* __restrict__ da,
                                                      const float* __restrict__ db, float* __restrict__ gq) {
-    __shared__ float s1[TL][TL + 1], s2[TL][TL + 1], s3[TL][TL + 1];
+    __shared__ float s1[TL][PT], s2[TL][PT], s3[TL][PT], hrow[3][TL][TS];
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y; b /= tiles_y;
@@ -447,20 +508,9 @@ __global__ void __launch_bounds__(256) ms_bwd_kernel(const float* __restrict__ x
     __syncthreads();
     const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
     const int y = y0 + ly, xx = x0 + lx;
+    float T1, T2, T3;
+    sep_transposed3(s1, s2, s3, hrow, gk, T1, T2, T3);
     if (y < H && xx < W) {
-        float T1 = 0.f, T2 = 0.f, T3 = 0.f;
-#pragma unroll
-        for (int i = 0; i < KF; ++i) {
-            float r1 = 0.f, r2 = 0.f, r3 = 0.f;
-#pragma unroll
-            for (int j = 0; j < KF; ++j) {
-                const float w = gk.g[j];
-                r1 += w * s1[ly + (KF - 1) - i][lx + (KF - 1) - j];
-                r2 += w * s2[ly + (KF - 1) - i][lx + (KF - 1) - j];
-                r3 += w * s3[ly + (KF - 1) - i][lx + (KF - 1) - j];
-            }
-            T1 += gk.g[i] * r1; T2 += gk.g[i] * r2; T3 += gk.g[i] * r3;
-        }
         const size_t o = (((size_t)n * H + y) * W + xx) * C + c;
         gq[o] = T1 + (x[o] - shT) * T2 + 2.f * (q[o] - shP) * T3;
     }
@@ -508,7 +558,7 @@ __global__ void __launch_bounds__(256) ms_finish_kernel(const float* __restrict_
 }
 
 struct MsLayout {
-    size_t stats, pf, pi, imgs, grads, maps, part, gcp, means, gw, total;
+    size_t stats, pf, pi, imgs, grads, maps, part, part2, gcp, means, gw, total;
     size_t img_off[MS_SCALES], grad_off[MS_SCALES], gcp_off[MS_SCALES];
     MsDims d;
     int nb_mm;
@@ -535,6 +585,7 @@ MsLayout ms_layout(int N, int H, int W, int C) {
     l.grads = bump(grad * sizeof(float));
     l.maps = bump(3 * (size_t)N * C * (H - KF + 1) * (W - KF + 1) * sizeof(float));
     l.part = bump(std::max<size_t>((size_t)N * C * cdiv(H - KF + 1, TS) * cdiv(W - KF + 1, TS) * 2, 4096) * sizeof(float));
+    l.part2 = bump((size_t)COMPACT_G * 2 * sizeof(float));
     l.gcp = bump(gcp * 2 * sizeof(float));
     l.means = bump((size_t)2 * MS_SCALES * N * C * sizeof(float));
     l.gw = bump((size_t)2 * MS_SCALES * N * C * sizeof(float));
@@ -565,12 +616,14 @@ void dssim_forward_backward(hipStream_t s, const float* y_true, const float* y_p
     ProfScope ps(s, "dssim", 0.0, 4.0 * (double)n * 8);
     const int nb = (int)std::min<size_t>(l.nb_mm, cdivz(n, 256));
     hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n, pf, pi);
-    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(64), 0, s, pf, pi, nb, st);
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
     const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
     const int nbf = N * C * txo * tyo;
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(nbf), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txo, tyo, gk, st, dmu, da,
                        db, part);
-    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(256), 0, s, part, nbf, st);
+    float* part2 = reinterpret_cast<float*>(base + l.part2);
+    hipLaunchKernelGGL(compact_partials_kernel<3>, dim3(COMPACT_G), dim3(256), 0, s, part, nbf, part2);
+    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(256), 0, s, part2, COMPACT_G, st);
     const float inv_m = 1.f / (float)msz;
     const float coef = -0.5f * weight * inv_m;
     int nbb = 0;
@@ -580,8 +633,9 @@ void dssim_forward_backward(hipStream_t s, const float* y_true, const float* y_p
         hipLaunchKernelGGL(ssim_bwd_kernel, dim3(nbb), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txi, tyi, gk, st, dmu, da,
                            db, coef, dpred, 1, part);
     }
-    hipLaunchKernelGGL(dssim_finish_kernel, dim3(1), dim3(256), 0, s, part, nbb, st, weight, inv_m, coef, dpred, loss_out,
-                       accumulate_loss);
+    if (nbb) hipLaunchKernelGGL(compact_partials_kernel<1>, dim3(COMPACT_G), dim3(256), 0, s, part, nbb, part2);
+    hipLaunchKernelGGL(dssim_finish_kernel, dim3(1), dim3(256), 0, s, part2, nbb ? COMPACT_G : 0, st, weight, inv_m, coef, dpred,
+                       loss_out, accumulate_loss);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -610,7 +664,7 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
     ProfScope ps(s, "msdssim", 0.0, 4.0 * (double)n0 * 12);
     const int nb = (int)std::min<size_t>(l.nb_mm, cdivz(n0, 256));
     hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n0, pf, pi);
-    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(64), 0, s, pf, pi, nb, st);
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
     auto ew = [](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 8192)); };
     const float* xk[MS_SCALES];
     const float* qk[MS_SCALES];
@@ -632,7 +686,7 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
         const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
         hipLaunchKernelGGL(ms_ssim_kernel<0>, dim3(NC * txo * tyo), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, l.d.H[k], l.d.W[k],
                            C, Ho, Wo, txo, tyo, gk, st, nullptr, nullptr, nullptr, nullptr, nullptr, part);
-        hipLaunchKernelGGL(ms_means_kernel, dim3(cdiv(NC, 64)), dim3(64), 0, s, part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo),
+        hipLaunchKernelGGL(ms_means_kernel, dim3(NC), dim3(64), 0, s, part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo),
                            means + (size_t)k * NC, means + (size_t)(MS_SCALES + k) * NC);
     }
     hipLaunchKernelGGL(ms_combine_kernel, dim3(1), dim3(256), 0, s, means, means + (size_t)MS_SCALES * NC, NC, weight, gw,
@@ -664,6 +718,8 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
     }
     const int nba = (int)std::min<size_t>(cdivz(n0, 256), 2048);
     hipLaunchKernelGGL(ms_apply_kernel, dim3(nba), dim3(256), 0, s, grads + l.grad_off[0], dpred, n0, 1, part);
-    hipLaunchKernelGGL(ms_finish_kernel, dim3(1), dim3(256), 0, s, part, nba, gcp, (int)gcp_total, st, dpred);
+    float* part2 = reinterpret_cast<float*>(base + l.part2);
+    hipLaunchKernelGGL(compact_partials_kernel<2>, dim3(COMPACT_G), dim3(256), 0, s, gcp, (int)gcp_total, part2);
+    hipLaunchKernelGGL(ms_finish_kernel, dim3(1), dim3(256), 0, s, part, nba, part2, COMPACT_G, st, dpred);
     HIP_CHECK(hipGetLastError());
 }

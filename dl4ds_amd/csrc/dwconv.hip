@@ -160,9 +160,12 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restri
 __global__ void dwconv_reduce_kernel(const float* __restrict__ partial, int nchunks, int KK, int C, float* __restrict__ dk,
                                      float* __restrict__ db, int accumulate) {
     const int n = (KK + 1) * C;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {       // one wavefront per output
         double s = 0.0;
-        for (int b = 0; b < nchunks; ++b) s += (double)partial[(size_t)b * n + e];
+        for (int b = threadIdx.x & 63; b < nchunks; b += 64) s += (double)partial[(size_t)b * n + e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (threadIdx.x & 63) continue;
         float* d = e < KK * C ? dk + e : (db ? db + (e - KK * C) : nullptr);
         if (d) *d = accumulate ? *d + (float)s : (float)s;
     }
@@ -219,6 +222,6 @@ void dwconv_wgrad(hipStream_t s, const float* x, const float* dy, float* dk, flo
     else hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 1>), dim3(g.nchunks, g.groups), dim3(256), 0, s, x, dy, ws, N, H, W, C, g.CPB, g.LANES, g.chunk);
     HIP_CHECK(hipGetLastError());
     const int n = (KS * KS + 1) * C;
-    hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, g.nchunks, KS * KS, C, dk, db, accumulate);
+    hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, g.nchunks, KS * KS, C, dk, db, accumulate);
     HIP_CHECK(hipGetLastError());
 }

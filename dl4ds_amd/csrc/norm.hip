@@ -39,6 +39,16 @@ __device__ __forceinline__ float group_sum(float v, int L) {
     return v;
 }
 
+// sum over b < nb of partial[b * stride + col], computed by one full wavefront (lane-strided loads, then a fixed
+// shuffle tree: the order of additions depends only on nb, so the result is reproducible); every lane returns it
+__device__ __forceinline__ double wave_col_sum(const float* __restrict__ partial, int nb, size_t stride, int col) {
+    double t = 0.0;
+    for (int b = threadIdx.x & 63; b < nb; b += 64) t += (double)partial[(size_t)b * stride + col];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // L lanes (power of two <= 64) share one pixel; lane j owns the channel packs j, j+L, j+2L, ... (V floats each).
 template <int V>
@@ -173,15 +183,16 @@ __global__ void __launch_bounds__(NORM_THREADS) ln_bwd_kernel(const float* __res
     }
 }
 
-// dst[c] (+)= sum over blocks of partial[b][c], c in [0, n); fixed order, double accumulation
-__global__ void partial_reduce_kernel(const float* __restrict__ partial, int nb, int n, float* __restrict__ d0, float* __restrict__ d1,
-                                      int half, int acc) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-        if (d0 == nullptr) continue;
-        double t = 0.0;
-        for (int b = 0; b < nb; ++b) t += (double)partial[(size_t)b * n + c];
-        float* d = c < half ? d0 + c : d1 + (c - half);
-        *d = acc ? *d + (float)t : (float)t;
+// dst[c] (+)= sum over blocks of partial[b][c], c in [0, n); one wavefront per output
+__global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __restrict__ partial, int nb, int n, float* __restrict__ d0,
+                                                             float* __restrict__ d1, int half, int acc) {
+    if (d0 == nullptr) return;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n; c += gridDim.x * 4) {
+        const double t = wave_col_sum(partial, nb, (size_t)n, c);
+        if ((threadIdx.x & 63) == 0) {
+            float* d = c < half ? d0 + c : d1 + (c - half);
+            *d = acc ? *d + (float)t : (float)t;
+        }
     }
 }
 
@@ -243,14 +254,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mov_mean,
                                    float* __restrict__ mov_var, float eps, float momentum, int training,
                                    float* __restrict__ stats, float* __restrict__ saved) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < C; c += gridDim.x * 4) {      // one wavefront per channel
         float mean, invstd;
         if (training) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int b = 0; b < nb; ++b) {
-                s1 += (double)partial[((size_t)b * 2) * C + c];
-                s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
-            }
+            const double s1 = wave_col_sum(partial, nb, (size_t)2 * C, c);
+            const double s2 = wave_col_sum(partial, nb, (size_t)2 * C, C + c);
+            if (threadIdx.x & 63) continue;
             const double n = (double)npix, m = s1 / n;
             const double var = fmax(s2 / n - m * m, 0.0);
             mean = (float)((double)x[c] + m);
@@ -261,6 +270,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
             saved[c] = mean;
             saved[C + c] = invstd;
         } else {
+            if (threadIdx.x & 63) continue;
             mean = mov_mean[c];
             invstd = rsqrtf(mov_var[c] + eps);
         }
@@ -334,12 +344,10 @@ __global__ void __launch_bounds__(NORM_THREADS) bn_bwd_reduce_kernel(const float
 // sums[0][c] = sum dy*xhat / n, sums[1][c] = sum dy / n;  dgamma / dbeta written or accumulated
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, size_t npix, int C, float* __restrict__ sums,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int acc) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            s1 += (double)partial[((size_t)b * 2) * C + c];
-            s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
-        }
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < C; c += gridDim.x * 4) {      // one wavefront per channel
+        const double s1 = wave_col_sum(partial, nb, (size_t)2 * C, c);
+        const double s2 = wave_col_sum(partial, nb, (size_t)2 * C, C + c);
+        if (threadIdx.x & 63) continue;
         sums[c] = (float)(s1 / (double)npix);
         sums[C + c] = (float)(s2 / (double)npix);
         if (dgamma) {
@@ -430,7 +438,7 @@ void layernorm_backward(hipStream_t s, const float* x, const float* y, const flo
     if (v4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, dx, acc_dx, ws, npix, C, L, eps, relu);
     else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, dx, acc_dx, ws, npix, C, L, eps, relu);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, ws, nb, 2 * C, dgamma, dbeta, C, acc_dw);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, s, ws, nb, 2 * C, dgamma, dbeta, C, acc_dw);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -451,7 +459,7 @@ void batchnorm_forward(hipStream_t s, const float* x, const float* gamma, const 
         else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, partial, npix, C, g);
         HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, partial, g.nb, npix, C, gamma, beta, mov_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, x, partial, g.nb, npix, C, gamma, beta, mov_mean,
                        mov_var, eps, momentum, training, stats, saved);
     HIP_CHECK(hipGetLastError());
     if (v4) hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, stats, y, npix, C, g, relu);
@@ -474,7 +482,7 @@ void batchnorm_backward(hipStream_t s, const float* x, const float* y, const flo
     if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, saved, partial, npix, C, g, relu);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, saved, partial, npix, C, g, relu);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, g.nb, npix, C, sums, dgamma, dbeta, acc_dw);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.nb, npix, C, sums, dgamma, dbeta, acc_dw);
     HIP_CHECK(hipGetLastError());
     if (dx) {
         if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, saved, sums, dx, acc_dx, npix, C, g, relu);
