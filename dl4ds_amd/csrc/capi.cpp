@@ -506,6 +506,11 @@ int dl4ds_graph_gap3d(dl4ds_graph* g, int in, int* out) {
     *out = g_gap(g->g, in, 1);
     API_END
 }
+int dl4ds_graph_pad(dl4ds_graph* g, int in, int Ho, int Wo, int* out) {
+    API_BEGIN
+    *out = g_pad(g->g, in, Ho, Wo);
+    API_END
+}
 int dl4ds_graph_slice(dl4ds_graph* g, int in, int oy, int ox, int step, int Ho, int Wo, int* out) {
     API_BEGIN
     *out = g_slice(g->g, in, oy, ox, step, Ho, Wo);

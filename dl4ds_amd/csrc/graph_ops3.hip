@@ -86,6 +86,19 @@ __global__ void slice_bwd_kernel(const float* __restrict__ dy, float* __restrict
         dx[e] = accumulate ? dx[e] + v : v;
     }
 }
+// y (+)= x[:, :Ho, :Wo, :]  (crop of an (H, W) tensor; the gradient of the zero padding)
+__global__ void slice_acc_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int Ho, int Wo, size_t total,
+                                 int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        size_t r = e / C;
+        const int j = (int)(r % Wo); r /= Wo;
+        const int i = (int)(r % Ho);
+        const size_t n = r / Ho;
+        const float v = x[((n * H + i) * W + j) * C + c];
+        y[e] = accumulate ? y[e] + v : v;
+    }
+}
 inline int ew_grid(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 8192)); }
 
 struct SliceOp : GOp {
@@ -108,6 +121,35 @@ struct SliceOp : GOp {
         hipLaunchKernelGGL(slice_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream,
                            to.grad + (size_t)c.b_off * to.per_sample(), ti.grad + (size_t)c.b_off * ti.per_sample(), ti.H, ti.W,
                            ti.C, to.H, to.W, oy, ox, step, total, (int)ti.grad_written);
+        HIP_CHECK(hipGetLastError());
+        g.tensors[in].grad_written = true;
+    }
+};
+
+// ============================================================================================ ZeroPadding2D (bottom / right)
+// PadConcat (blocks.py:629-656) pads the smaller of two tensors with zeros at the bottom / right before concatenating:
+// the adjoint pair of the slice above (forward = its scatter, backward = its gather, step 1, offset 0).
+struct PadOp : GOp {
+    int in, out;
+    PadOp() { kind = "pad"; }
+    void forward(Graph& g, int B, bool) override {
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        const size_t total = to.per_sample() * B;
+        hipLaunchKernelGGL(slice_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, ti.data, to.data, to.H, to.W, to.C, ti.H,
+                           ti.W, 0, 0, 1, total, 0);
+        HIP_CHECK(hipGetLastError());
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        const int cnt = c.b_cnt < 0 ? c.B : c.b_cnt;
+        const size_t total = ti.per_sample() * cnt;
+        float* dx = ti.grad + (size_t)c.b_off * ti.per_sample();
+        const float* dy = to.grad + (size_t)c.b_off * to.per_sample();
+        hipLaunchKernelGGL(slice_acc_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, dy, dx, to.H, to.W, to.C, ti.H, ti.W, total,
+                           (int)ti.grad_written);
         HIP_CHECK(hipGetLastError());
         g.tensors[in].grad_written = true;
     }
@@ -143,6 +185,17 @@ struct DwConvOp : GOp {
 };
 
 }  // namespace
+
+int g_pad(Graph& g, int in, int Ho, int Wo) {
+    const GTensor ti = g.tensors.at(in);
+    DL4DS_REQUIRE(Ho >= ti.H && Wo >= ti.W, "pad: the padded grid must not be smaller than the input");
+    const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
+    PadOp* op = new PadOp();
+    g.ops.emplace_back(op);
+    op->in = in; op->out = out;
+    g.tensors[in].n_other++;
+    return out;
+}
 
 int g_dwconv(Graph& g, int in, int w, int b, int KS) {
     const GTensor ti = g.tensors.at(in);

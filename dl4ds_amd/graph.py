@@ -193,6 +193,11 @@ class GraphBuilder:
         _lib.check(self._l.dl4ds_graph_slice(self.h, x.id, int(oy), int(ox), int(step), int(ho), int(wo), ctypes.byref(out)))
         return self._out(out.value, 'slice', name)
 
+    def pad_bottom_right(self, x, ho, wo, name='zero_padding'):
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_pad(self.h, x.id, int(ho), int(wo), ctypes.byref(out)))
+        return self._out(out.value, 'zero_padding', name)
+
     def conv2d_strided(self, x, name, filters, ks, stride, padding='same'):
         """Conv2D(filters, ks, strides=stride, padding=...) as the stride-1 'same' convolution (MFMA path) followed by
         the sub-sampling slice; see csrc/graph_ops3.hip for the index algebra."""

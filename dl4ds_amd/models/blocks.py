@@ -167,5 +167,11 @@ def deconv_block(g, name, x, scale, n_filters, output_activation=None):
 
 
 def pad_concat(g, name, t1, t2):
-    """PadConcat.call -- blocks.py:629-656 (zero padding only needed for odd grids)."""
+    """PadConcat.call -- blocks.py:629-656: the smaller tensor is zero-padded at the bottom / right (odd grids lose a
+    row / column in MaxPooling2D that the decoder's x2 upsampling does not bring back), then both are concatenated."""
+    h, w = max(t1.H, t2.H), max(t1.W, t2.W)
+    if (t1.H, t1.W) != (h, w):
+        t1 = g.pad_bottom_right(t1, h, w, name + '/pad1')
+    if (t2.H, t2.W) != (h, w):
+        t2 = g.pad_bottom_right(t2, h, w, name + '/pad2')
     return g.concat([t1, t2], name)

@@ -155,6 +155,8 @@ int dl4ds_graph_gap3d(dl4ds_graph* g, int in, int* out);
 /* y[:, i, j, :] = x[:, oy + i*step, ox + j*step, :] (i < Ho, j < Wo): the sub-sampling half of Conv2D(strides=2)
  * (the stride-1 convolution runs on the MFMA kernels) and Cropping2D -- discriminator.py:53-60 */
 int dl4ds_graph_slice(dl4ds_graph* g, int in, int oy, int ox, int step, int Ho, int Wo, int* out);
+/* ZeroPadding2D(((0, Ho - H), (0, Wo - W))) -- PadConcat, blocks.py:639-647 */
+int dl4ds_graph_pad(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
 int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out);
 int dl4ds_graph_dropout(dl4ds_graph* g, int in, float rate, int* out);
 /* get_dropout_layer (blocks.py:679-706).  variant: 0 Dropout, 1 GaussianDropout, 2 SpatialDropout2D/3D (spatial_dim);

@@ -75,6 +75,9 @@ SUP_CASES = [
     ('unet_pin', dict(n_filters=4, n_blocks=3, decoder_upsampling='dc'), (2, 32, 32, 3), (2, 32, 32, 1)),
     ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='spc', attention=True), (1, 16, 24, 2), None),
     ('unet_pin', dict(n_filters=8, n_blocks=2, decoder_upsampling='rc'), (1, 16, 16, 5), (1, 16, 16, 1)),
+    # odd grids: MaxPooling2D drops a row / column, PadConcat zero-pads the decoder side back (blocks.py:629-656)
+    ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='rc'), (2, 25, 30, 2), None),
+    ('unet_pin', dict(n_filters=4, n_blocks=3, decoder_upsampling='spc'), (1, 37, 23, 1), (1, 37, 23, 1)),
     ('recnet_postupsampling', dict(backbone_block='densenet', upsampling='rc', scale=2, time_window=3, n_filters=4,
                                    n_blocks=1, attention=True, localcon_layer=True), (2, 3, 8, 8, 1), (2, 16, 16, 1)),
     ('recnet_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=2, time_window=2, n_filters=4,
