@@ -1,7 +1,9 @@
 // Graph ops of the block variants: LayerNormalization / BatchNormalization with the fused
 // activation that follows them in every dl4ds block.  See graph.h for the runtime contract, norm.hip for the kernels.
 #include "graph.h"
+#include "prof.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -51,6 +53,166 @@ struct NormOp : GOp {
         }
         if (dx) g.tensors[in].grad_written = true;
         if (c.param_grads) g.params[gamma].grad_written = g.params[beta].grad_written = true;
+    }
+};
+
+// ============================================================================================ Conv2D -> Conv2D 1x1, folded
+// A KSxKS convolution (optionally storing through depth_to_space(r)) that is followed by a 1x1 convolution with nothing
+// in between -- no activation, no other consumer -- is ONE linear map of the input:
+//   W_eff[ky,kx,ci,(ij,co)] = sum_cm W1[ky,kx,ci,(ij,cm)] * W2[cm,co],   b_eff[(ij,co)] = sum_cm b1[(ij,cm)] * W2[cm,co] + b2[co]
+// (ij = the r*r sub-pixel positions of depth_to_space; r = 1: plain).  This is the closing pair of every
+// post-upsampling model without auxiliary / localized branches: SubpixelConvolutionBlock's last conv2x (48 -> 4 x 48
+// at half the HR grid) or ResizeConvolutionBlock's conv (48 -> 48 at the HR grid) followed by TransitionBlock
+// 'TransitionLast' (1x1, 48 -> 8)  (sp_postups.py:172-177,203; blocks.py:433-454,485-491,301-309).  Evaluating the
+// composition needs Cm / Co times fewer multiply-adds on the largest grid of the model and never materialises the
+// Cm-channel HR activation or its gradient.  The trainable variables stay W1, b1, W2, b2: W_eff / b_eff are rebuilt from
+// them in every forward pass, and the backward pass unfolds the gradient of the effective filter by the chain rule
+//   dW1[k,(ij,cm)] += sum_co dW_eff[k,(ij,co)] W2[cm,co]      dW2[cm,co] += sum_{k,ij} W1[k,(ij,cm)] dW_eff[k,(ij,co)]
+//   db1[(ij,cm)]   += sum_co db_eff[(ij,co)] W2[cm,co]                      + sum_ij b1[(ij,cm)] db_eff[(ij,co)]
+//   db2[co]        += sum_ij db_eff[(ij,co)]
+// so losses, gradients and Adam updates equal the unfolded graph's up to fp32 rounding (tests/test_gpu_models.py runs
+// both against the unfolded oracle).  DL4DS_NO_FOLD=1 makes the builders emit the two separate convolutions.
+__global__ void fold_weights_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                    const float* __restrict__ b2, float* __restrict__ weff, float* __restrict__ beff, int K, int R2,
+                                    int Cm, int Co) {
+    const int ncol = R2 * Co;
+    const int total = (K + 1) * ncol;                  // row K: the bias
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int col = e % ncol, k = e / ncol;
+        const int ij = col / Co, co = col - ij * Co;
+        const float* src = (k < K) ? w1 + (size_t)k * R2 * Cm + ij * Cm : b1 + ij * Cm;
+        float a = 0.f;
+        if (k < K || b1) for (int cm = 0; cm < Cm; ++cm) a = fmaf(src[cm], w2[cm * Co + co], a);
+        if (k < K) weff[(size_t)k * ncol + col] = a;
+        else beff[col] = a + (b2 ? b2[co] : 0.f);
+    }
+}
+// dW1 / db1 part of the unfolding: one thread per (k | bias row, ij, cm)
+__global__ void unfold_w1_kernel(const float* __restrict__ dweff, const float* __restrict__ dbeff, const float* __restrict__ w2,
+                                 float* __restrict__ dw1, float* __restrict__ db1, int K, int R2, int Cm, int Co, int acc_w, int acc_b) {
+    const int total = (K + 1) * R2 * Cm;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int cm = e % Cm;
+        const int ij = (e / Cm) % R2;
+        const int k = e / (Cm * R2);
+        if (k == K && !db1) continue;
+        const float* src = (k < K) ? dweff + (size_t)k * R2 * Co + ij * Co : dbeff + ij * Co;
+        float a = 0.f;
+        for (int co = 0; co < Co; ++co) a = fmaf(src[co], w2[cm * Co + co], a);
+        float* d = (k < K) ? dw1 + (size_t)k * R2 * Cm + ij * Cm + cm : db1 + ij * Cm + cm;
+        const int acc = (k < K) ? acc_w : acc_b;
+        *d = acc ? *d + a : a;
+    }
+}
+// dW2 / db2: one wavefront per (cm, co) (and one per co for db2), lanes stride over the K * R2 (+ R2 bias) terms
+__global__ void __launch_bounds__(256) unfold_w2_kernel(const float* __restrict__ dweff, const float* __restrict__ dbeff,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        float* __restrict__ dw2, float* __restrict__ db2, int K, int R2, int Cm, int Co,
+                                                        int acc_w, int acc_b) {
+    const int lane = threadIdx.x & 63;
+    const int nout = Cm * Co + Co;
+    for (int o = blockIdx.x * 4 + (threadIdx.x >> 6); o < nout; o += gridDim.x * 4) {
+        double a = 0.0;
+        if (o < Cm * Co) {
+            const int cm = o / Co, co = o - cm * Co;
+            for (int t = lane; t < K * R2; t += 64) {
+                const int k = t / R2, ij = t - k * R2;
+                a += (double)w1[(size_t)k * R2 * Cm + ij * Cm + cm] * (double)dweff[(size_t)k * R2 * Co + ij * Co + co];
+            }
+            if (b1)
+                for (int ij = lane; ij < R2; ij += 64) a += (double)b1[ij * Cm + cm] * (double)dbeff[ij * Co + co];
+        } else if (db2) {
+            const int co = o - Cm * Co;
+            for (int ij = lane; ij < R2; ij += 64) a += (double)dbeff[ij * Co + co];
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (lane) continue;
+        if (o < Cm * Co) dw2[o] = acc_w ? dw2[o] + (float)a : (float)a;
+        else if (db2) { const int co = o - Cm * Co; db2[co] = acc_b ? db2[co] + (float)a : (float)a; }
+    }
+}
+
+struct FoldedConvOp : GOp {
+    int in, out, w1, b1, w2, b2, KS, r, Cm, Co, relu;
+    size_t weff_off = 0, beff_off = 0, dweff_off = 0, wt_off = 0;
+    FoldedConvOp() { kind = "conv2d_folded"; }
+    int ncol() const { return r * r * Co; }
+    int krows(Graph& g) const { return KS * KS * g.tensors[in].C; }
+    void on_finalize(Graph& g) override {
+        const size_t n = (size_t)krows(g) * ncol();
+        weff_off = g.reserve_wt(n);
+        beff_off = g.reserve_wt(ncol());
+        dweff_off = g.reserve_wt(n + ncol());          // [dW_eff | db_eff]
+        wt_off = g.reserve_wt(n);                      // dgrad arrangement of W_eff
+        GTensor& t = g.tensors[out];
+        bool is_output = false;
+        for (int o : g.outputs) is_output |= (o == out);
+        t.grad_masked = relu && !is_output && t.n_conv_in >= 1 && t.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
+    }
+    TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        float* base = (grad ? to.grad : to.data) + (size_t)bo * to.per_sample();
+        const int N = (bc < 0 ? B : bc) * to.nmul;
+        if (r > 1) return make_view_d2s(base, N, ti.H, ti.W, ncol(), r);
+        return make_view(base, N, ti.H, ti.W, ncol());
+    }
+    size_t workspace_bytes(Graph& g, int B) override {
+        TView x = g.view(in, B, false);
+        TView dz = make_view(nullptr, x.N, x.H, x.W, ncol());
+        return std::max(conv2d_wgrad_workspace_bytes(x, dz, KS), bias_grad_workspace_bytes(dz));
+    }
+    void forward(Graph& g, int B, bool) override {
+        const int K = krows(g);
+        float* weff = g.Wt + weff_off;
+        float* beff = g.Wt + beff_off;
+        {
+            ProfScope ps(g.stream, "fold_weights", 2.0 * (K + 1) * ncol() * Cm, 4.0 * ((double)K * r * r * Cm + (double)K * ncol()));
+            const int total = (K + 1) * ncol();
+            hipLaunchKernelGGL(fold_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, g.stream, g.wp(w1),
+                               b1 >= 0 ? g.wp(b1) : nullptr, g.wp(w2), b2 >= 0 ? g.wp(b2) : nullptr, weff, beff, K, r * r, Cm, Co);
+            HIP_CHECK(hipGetLastError());
+        }
+        ConvEpilogue ep;
+        ep.bias = (b1 >= 0 || b2 >= 0) ? beff : nullptr;
+        ep.relu = relu;
+        conv2d_forward(g.stream, g.view(in, B, false), weff, KS, out_view(g, false, B, 0, -1), ep);
+    }
+    void backward(Graph& g, const BwdCtx& c) override {
+        if (!g.tensors[out].grad_written) return;
+        const int K = krows(g), R2 = r * r;
+        TView dY = out_view(g, true, c.B, c.b_off, c.b_cnt);
+        if (relu && !g.tensors[out].grad_masked)
+            bias_act_backward(g.stream, dY, out_view(g, false, c.B, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace, g.workspace_bytes);
+        float* weff = g.Wt + weff_off;
+        if (c.param_grads) {
+            float* dweff = g.Wt + dweff_off;
+            float* dbeff = dweff + (size_t)K * ncol();
+            conv2d_wgrad(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, dweff, 0, dbeff, 0, g.workspace, g.workspace_bytes);
+            ProfScope ps(g.stream, "unfold_weight_grads", 4.0 * K * ncol() * Cm, 4.0 * 3 * (double)K * R2 * Cm);
+            const int n1 = (K + 1) * R2 * Cm;
+            hipLaunchKernelGGL(unfold_w1_kernel, dim3((n1 + 255) / 256), dim3(256), 0, g.stream, dweff, dbeff, g.wp(w2), g.gp(w1),
+                               b1 >= 0 ? g.gp(b1) : nullptr, K, R2, Cm, Co, (int)g.params[w1].grad_written,
+                               b1 >= 0 ? (int)g.params[b1].grad_written : 0);
+            const int n2 = Cm * Co + Co;
+            hipLaunchKernelGGL(unfold_w2_kernel, dim3((n2 + 3) / 4), dim3(256), 0, g.stream, dweff, dbeff, g.wp(w1),
+                               b1 >= 0 ? g.wp(b1) : nullptr, g.gp(w2), b2 >= 0 ? g.gp(b2) : nullptr, K, R2, Cm, Co,
+                               (int)g.params[w2].grad_written, b2 >= 0 ? (int)g.params[b2].grad_written : 0);
+            HIP_CHECK(hipGetLastError());
+            g.params[w1].grad_written = g.params[w2].grad_written = true;
+            if (b1 >= 0) g.params[b1].grad_written = true;
+            if (b2 >= 0) g.params[b2].grad_written = true;
+        }
+        if (wants_grad(g, in, c)) {
+            float* wt = g.Wt + wt_off;
+            conv2d_dgrad_weights(g.stream, weff, wt, KS, g.tensors[in].C, ncol());
+            ConvEpilogue ep;
+            ep.accumulate = g.tensors[in].grad_written;
+            if (g.tensors[in].grad_masked) ep.mask = g.view(in, c.B, false, c.b_off, c.b_cnt);
+            conv2d_forward(g.stream, dY, wt, KS, g.view(in, c.B, true, c.b_off, c.b_cnt), ep);
+            g.tensors[in].grad_written = true;
+        }
     }
 };
 
@@ -185,6 +347,24 @@ struct DwConvOp : GOp {
 };
 
 }  // namespace
+
+int g_conv2d_folded(Graph& g, int in, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout, int relu, int d2s) {
+    const GTensor ti = g.tensors.at(in);
+    const int r = d2s > 1 ? d2s : 1;
+    DL4DS_REQUIRE(KS == 1 || KS == 3 || KS == 5 || KS == 7, "conv2d_folded: kernel size must be 1, 3, 5 or 7");
+    DL4DS_REQUIRE(g.params.at(w1).n == (size_t)KS * KS * ti.C * r * r * Cmid, "conv2d_folded: first kernel size mismatch");
+    DL4DS_REQUIRE(g.params.at(w2).n == (size_t)Cmid * Cout, "conv2d_folded: 1x1 kernel size mismatch");
+    if (b1 >= 0) DL4DS_REQUIRE(g.params.at(b1).n == (size_t)r * r * Cmid, "conv2d_folded: first bias size mismatch");
+    if (b2 >= 0) DL4DS_REQUIRE(g.params.at(b2).n == (size_t)Cout, "conv2d_folded: 1x1 bias size mismatch");
+    const int out = g.add_tensor(ti.H * r, ti.W * r, Cout, ti.nmul, true, false);
+    FoldedConvOp* op = new FoldedConvOp();
+    g.ops.emplace_back(op);
+    op->in = in; op->out = out; op->w1 = w1; op->b1 = b1; op->w2 = w2; op->b2 = b2; op->KS = KS; op->r = r; op->Cm = Cmid;
+    op->Co = Cout; op->relu = relu;
+    op->pids = {w1, b1, w2, b2};
+    g.tensors[in].n_conv_in++;
+    return out;
+}
 
 int g_pad(Graph& g, int in, int Ho, int Wo) {
     const GTensor ti = g.tensors.at(in);

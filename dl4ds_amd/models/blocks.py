@@ -134,21 +134,28 @@ def recurrent_conv_block(g, name, x, filters, time_window, activation='relu', no
                   activation=activation)
 
 
-def subpixel_block(g, name, x, scale, n_filters):
+def subpixel_block(g, name, x, scale, n_filters, fold_into=None):
     """SubpixelConvolutionBlock.call -- blocks.py:433-454.  ``conv2x`` is ONE weight set applied at
-    every x2 stage; depth_to_space is fused into the conv store."""
+    every x2 stage; depth_to_space is fused into the conv store.  ``fold_into=(name, filters, activation)``: the 1x1
+    TransitionBlock that consumes the block's output directly is composed with the last stage's filter
+    (GraphBuilder.conv2d_folded) instead of being run on the n_filters-channel HR tensor."""
     seq = {2: [2], 4: [2, 2], 8: [2, 2, 2], 10: [2, 5], 20: [2, 2, 5]}.get(scale, [scale])
-    for f in seq:
+    for i, f in enumerate(seq):
         sub = {2: 'conv2x', 5: 'conv5x'}.get(f, 'conv')
-        x = g.conv2d(x, f'{name}/{sub}', n_filters * f * f, 3, d2s=f)
+        if fold_into is not None and i == len(seq) - 1:
+            x = g.conv2d_folded(x, f'{name}/{sub}', n_filters, 3, f, fold_into[0] + '/conv', fold_into[1], fold_into[2])
+        else:
+            x = g.conv2d(x, f'{name}/{sub}', n_filters * f * f, 3, d2s=f)
     return x
 
 
-def resize_conv_block(g, name, x, scale, n_filters, interpolation='bilinear'):
-    """ResizeConvolutionBlock.call -- blocks.py:485-491."""
+def resize_conv_block(g, name, x, scale, n_filters, interpolation='bilinear', fold_into=None):
+    """ResizeConvolutionBlock.call -- blocks.py:485-491 (``fold_into``: see subpixel_block)."""
     if interpolation != 'bilinear':
         raise NotImplementedError(f"rc_interpolation={interpolation!r}: only 'bilinear' is implemented")
     y = g.resize(x, int(x.H * scale), int(x.W * scale), name + '/resize')
+    if fold_into is not None:
+        return g.conv2d_folded(y, name + '/conv', n_filters, 3, 0, fold_into[0] + '/conv', fold_into[1], fold_into[2])
     return g.conv2d(y, name + '/conv', n_filters, 3)
 
 

@@ -1,4 +1,5 @@
 """net_postupsampling -- same signature as dl4ds/models/sp_postups.py:14-32, graph per :95-217."""
+import os
 from ..graph import GraphBuilder, Model
 from ..utils import checkarg_backbone, checkarg_upsampling, checkarg_dropout_variant
 from .blocks import (conv_block, residual_block, dense_block, transition_block, localized_conv_block,
@@ -51,7 +52,7 @@ def backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, n
 
 
 def tail_section(g, x, s_in, init_n_filters, n_filters_aux, n_channels_out, activation, output_activation,
-                 normalization, dropout_rate, localcon_layer, convnext=False):
+                 normalization, dropout_rate, localcon_layer, convnext=False, transition_done=False):
     """sp_postups.py:184-212 / sp_preups.py:155-183 / :289-309.  ``convnext``: the auxiliary branch is a ConvNextBlock
     and the two closing ConvBlocks use 7x7 kernels (`ks`, sp_postups.py:121,193-210)."""
     ks = 7 if convnext else 3
@@ -66,7 +67,8 @@ def tail_section(g, x, s_in, init_n_filters, n_filters_aux, n_channels_out, acti
             s = conv_block(g, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
                            normalization=normalization, attention=False)
         x = g.concat([x, s], 'aux_concat')
-    x = transition_block(g, 'TransitionLast', x, init_n_filters)
+    if not transition_done:          # else: composed with the upsampling block's last convolution (see net_postupsampling)
+        x = transition_block(g, 'TransitionLast', x, init_n_filters)
     x = conv_block(g, 'ConvBlock_att', x, init_n_filters, ks_cl1=ks, ks_cl2=ks, activation=None,
                    normalization=normalization, attention=True, dropout_rate=dropout_rate)
     return conv_block(g, 'ConvBlock_out', x, n_channels_out, ks_cl1=ks, ks_cl2=ks, activation=output_activation,
@@ -89,17 +91,23 @@ def net_postupsampling(backbone_block, upsampling, scale, n_channels, n_aux_chan
     x, nf = backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, normalization,
                              attention, dropout_rate, dropout_variant)
     model_name = backbone_block + '_' + upsampling
+    # Without auxiliary / localized branches 'TransitionLast' (1x1, nf -> n_filters, ReLU) reads the upsampling block's
+    # output directly and nothing else does: the two linear layers are evaluated as one convolution with the composed
+    # filter (same variables, same gradients; csrc/graph_ops3.hip).  DL4DS_NO_FOLD=1 keeps them separate.
+    fold = (s_in is None and not localcon_layer and upsampling in ('spc', 'rc') and not os.environ.get('DL4DS_NO_FOLD'))
+    fold_into = ('TransitionLast', n_filters, 'relu') if fold else None
     if upsampling == 'spc':
-        x = subpixel_block(g, 'SubpixelConvolution', x, scale, nf)
+        x = subpixel_block(g, 'SubpixelConvolution', x, scale, nf, fold_into=fold_into)
     elif upsampling == 'rc':
-        x = resize_conv_block(g, 'ResizeConvolution', x, scale, nf, rc_interpolation)
+        x = resize_conv_block(g, 'ResizeConvolution', x, scale, nf, rc_interpolation, fold_into=fold_into)
     elif upsampling == 'dc':
         x = transition_block(g, 'TransitionDC', x, n_filters, activation)
         x = deconv_block(g, 'Deconvolution', x, scale, nf, activation)
     else:
         raise ValueError("net_postupsampling needs a post-upsampling method ('spc', 'rc' or 'dc')")
     x = tail_section(g, x, s_in, n_filters, nf, n_channels_out, activation, output_activation,
-                     normalization, dropout_rate, localcon_layer, convnext=(backbone_block == 'convnext'))
+                     normalization, dropout_rate, localcon_layer, convnext=(backbone_block == 'convnext'),
+                     transition_done=fold)
     g.finalize(x, seed)
     shapes = [(h_lr, w_lr, n_channels)] + ([(h_hr, w_hr, n_aux_channels)] if s_in is not None else [])
     return Model(g, model_name, shapes)

@@ -155,6 +155,12 @@ int dl4ds_graph_gap3d(dl4ds_graph* g, int in, int* out);
 /* y[:, i, j, :] = x[:, oy + i*step, ox + j*step, :] (i < Ho, j < Wo): the sub-sampling half of Conv2D(strides=2)
  * (the stride-1 convolution runs on the MFMA kernels) and Cropping2D -- discriminator.py:53-60 */
 int dl4ds_graph_slice(dl4ds_graph* g, int in, int oy, int ox, int step, int Ho, int Wo, int* out);
+/* Conv2D(KSxKS, d2s*d2s*Cmid filters) [+ depth_to_space(d2s)] immediately followed by Conv2D(1x1, Cout) (+ optional ReLU)
+ * evaluated as one convolution with the composed filter; parameters and their gradients stay those of the two layers
+ * (w1 (KS,KS,Cin,d2s^2*Cmid), b1, w2 (Cmid,Cout), b2; biases may be -1).  SubpixelConvolutionBlock / ResizeConvolutionBlock
+ * + TransitionBlock 'TransitionLast' -- sp_postups.py:172-177,203. */
+int dl4ds_graph_conv2d_folded(dl4ds_graph* g, int in, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout, int relu,
+                              int d2s, int* out);
 /* ZeroPadding2D(((0, Ho - H), (0, Wo - W))) -- PadConcat, blocks.py:639-647 */
 int dl4ds_graph_pad(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
 int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out);
