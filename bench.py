@@ -96,6 +96,7 @@ def main():
                     help='per-GPU batch (weak scaling); 64 = the reference default (training/supervised.py:49)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-unfolded', action='store_true', help='skip the 5-step comparison run of the unfolded graph')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -235,6 +236,28 @@ def main():
         }
         if breakdown is not None and os.environ.get('DL4DS_BENCH_BREAKDOWN'):
             out['breakdown'] = breakdown
+        if world == 1 and not os.environ.get('DL4DS_NO_FOLD') and not args.no_unfolded:
+            # the same step with every layer evaluated separately (the reference's evaluation order, DL4DS_NO_FOLD=1),
+            # measured in the same run so that both figures sit side by side; `value` above is the product path
+            try:
+                os.environ['DL4DS_NO_FOLD'] = '1'
+                m2 = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (128, 128), seed=7)
+                e2 = SupervisedEngine(m2, loss='mae', learning_rate=(1e-3, 1e-4), lr_decay_after=1e5)
+                for _ in range(2):
+                    e2.step_device([dx.ptr], dy.ptr, B)
+                L.check(lib.dl4ds_sync())
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    e2.step_device([dx.ptr], dy.ptr, B)
+                L.check(lib.dl4ds_sync())
+                dt2 = (time.perf_counter() - t1) / 5
+                out['unfolded_graph'] = {'value': B / dt2, 'ms_per_step': 1e3 * dt2, 'steps': 5,
+                                         'note': 'DL4DS_NO_FOLD=1: conv2x#2 and TransitionLast as two layers (55 GFLOP/sample)'}
+                del e2, m2
+            except Exception as e:
+                out['unfolded_graph'] = {'error': repr(e)}
+            finally:
+                os.environ.pop('DL4DS_NO_FOLD', None)
         if w0 is not None:
             try:
                 out['cpu_baseline'] = cpu_baseline(w0)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-unfolded"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats --output-format csv -- $CMD > $OUT/bench_under_rocprof.log 2>&1
 python $R/tools/rocprof_stats_summary.py /tmp/prof_stats > $OUT/kernel_stats_$TAG.txt
 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch --output-format csv -- $CMD > /dev/null 2>&1
