@@ -347,6 +347,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
         const long ntiles8 = (long)cdiv(in.W, 16) * cdiv(in.H, 32) * in.N;
         const bool big = ntiles8 * cdiv(out.C, 16 * NT8) >= 1024 || getenv("DL4DS_STREAM_FORCE_TALL") != nullptr;   // (tests)
         tall = NT8 == 3 && E8 == 6 && bp <= best && bk <= bestk && big;     // (NT 2 / 16-channel chunks measured slower)
+        if (getenv("DL4DS_STREAM_TALL_ANY")) tall = NT8 >= 2 && bp <= best && bk <= bestk && big;     // (experiments)
     }
     StreamParams sp;
     ConvParams& p = sp.c;

@@ -5,7 +5,7 @@ import numpy as np
 import dl4ds_amd._lib as L
 from dl4ds_amd.device import DeviceArray
 lib = L.lib()
-N, H, W, CI, CO = 16, 256, 256, 48, 192
+N, H, W, CI, CO = (int(os.environ.get(k, d)) for k, d in (('MB_N', 16), ('MB_H', 256), ('MB_W', 256), ('MB_CI', 48), ('MB_CO', 192)))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 which = sys.argv[2] if len(sys.argv) > 2 else 'fwd,dgrad,wgrad'
 rng = np.random.default_rng(0)
