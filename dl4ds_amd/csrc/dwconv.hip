@@ -6,7 +6,7 @@
 // inputs and K weights feeds PW * K FMAs; the 7 x 7 halo re-reads stay in L1/L2, HBM sees x once and y once.
 //   forward : taps as stored;        dgrad : the same kernel with the taps mirrored (flip = 1), optional accumulate;
 //   wgrad   : thread = (channel pack, ky, pixel lane) keeps the K taps of row ky in registers and walks a chunk of
-//             pixels; lanes are combined through LDS, chunks through fixed-order partial sums (bit-reproducible).
+//             PW-pixel row segments (K + PW - 1 inputs and PW gradients per K * PW FMAs); lanes are combined through LDS, chunks through fixed-order partial sums (bit-reproducible).
 #include "ops.h"
 #include "prof.h"
 #include <algorithm>
@@ -106,8 +106,8 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restri
     const int cp = blockIdx.y * CPB + cb;
     const int CP = C / V;
     const bool active = lane < LANES && cp < CP;
-    const size_t npix = (size_t)N * H * W;
-    const size_t p0 = (size_t)blockIdx.x * chunk, p1 = min(p0 + chunk, npix);
+    const size_t nitems = (size_t)N * H * ((W + DW_PW - 1) / DW_PW);
+    const size_t p0 = (size_t)blockIdx.x * chunk, p1 = min(p0 + chunk, nitems);
     float acc[K][V], bsum[V];
 #pragma unroll
     for (int j = 0; j < K; ++j)
@@ -116,26 +116,49 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < V; ++i) bsum[i] = 0.f;
     if (active) {
-        for (size_t p = p0 + lane; p < p1; p += LANES) {
-            const int w = (int)(p % W);
-            const size_t q = p / W;
+        // work item = DW_PW consecutive pixels of one row: K + DW_PW - 1 inputs and DW_PW gradients feed K * DW_PW FMAs
+        const int WG = (W + DW_PW - 1) / DW_PW;
+        for (size_t it = p0 + lane; it < p1; it += LANES) {
+            const int wg = (int)(it % WG);
+            const size_t q = it / WG;                     // n * H + h
             const int h = (int)(q % H);
-            const Pk<V> d = ldp<V>(dy + p * C + cp * V);
+            const int w0 = wg * DW_PW;
+            Pk<V> d[DW_PW];
+#pragma unroll
+            for (int p = 0; p < DW_PW; ++p) {
+                if (w0 + p < W) {
+                    d[p] = ldp<V>(dy + (q * W + w0 + p) * C + cp * V);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) d[p].v[i] = 0.f;
+                }
+            }
             if (ky == 0) {
 #pragma unroll
-                for (int i = 0; i < V; ++i) bsum[i] += d.v[i];
+                for (int p = 0; p < DW_PW; ++p)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) bsum[i] += d[p].v[i];
             }
             const int yy = h + ky - R;
             if (yy < 0 || yy >= H) continue;
             const float* row = x + ((q - h + yy) * (size_t)W) * C + cp * V;     // (n*H + yy) * W
+            Pk<V> a[DW_PW + K - 1];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int xx = w + kx - R;
-                if (xx < 0 || xx >= W) continue;
-                const Pk<V> a = ldp<V>(row + (size_t)xx * C);
+            for (int j = 0; j < DW_PW + K - 1; ++j) {
+                const int xx = w0 + j - R;
+                if (xx >= 0 && xx < W) {
+                    a[j] = ldp<V>(row + (size_t)xx * C);
+                } else {
 #pragma unroll
-                for (int i = 0; i < V; ++i) acc[kx][i] = fmaf(a.v[i], d.v[i], acc[kx][i]);
+                    for (int i = 0; i < V; ++i) a[j].v[i] = 0.f;
+                }
             }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int p = 0; p < DW_PW; ++p)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[kx][i] = fmaf(a[p + kx].v[i], d[p].v[i], acc[kx][i]);
         }
     }
     float* out = partial + (size_t)blockIdx.x * (K * K + 1) * C;
@@ -179,13 +202,13 @@ inline bool vec_ok(int C, std::initializer_list<const void*> ptrs) {
 }
 
 struct WgradGeom { int CPB, LANES, groups, nchunks; size_t chunk; };
-inline WgradGeom wgrad_geom(size_t npix, int C, int V, int K) {
+inline WgradGeom wgrad_geom(size_t npix, int C, int V, int K) {     // npix: work items (DW_PW-pixel row segments)
     WgradGeom g;
     const int CP = C / V;
     g.CPB = std::min(CP, 256 / K);                       // channel packs per block
     g.LANES = std::max(1, 256 / (g.CPB * K));
     g.groups = (CP + g.CPB - 1) / g.CPB;
-    const size_t want = std::max<size_t>(1, std::min<size_t>(DW_MAX_CHUNKS, npix / (size_t)(g.LANES * 16) + 1));
+    const size_t want = std::max<size_t>(1, std::min<size_t>(DW_MAX_CHUNKS, npix / (size_t)(g.LANES * 4) + 1));
     g.chunk = (npix + want - 1) / want;
     g.nchunks = (int)((npix + g.chunk - 1) / g.chunk);
     return g;
@@ -217,7 +240,7 @@ void dwconv_wgrad(hipStream_t s, const float* x, const float* dy, float* dk, flo
     if (npix == 0) return;
     ProfScope ps(s, "dwconv_wgrad", 2.0 * KS * KS * (double)npix * C, 8.0 * (double)npix * C);
     const bool v4 = vec_ok(C, {x, dy, ws});
-    const WgradGeom g = wgrad_geom(npix, C, v4 ? 4 : 1, KS);
+    const WgradGeom g = wgrad_geom((size_t)N * H * ((W + DW_PW - 1) / DW_PW), C, v4 ? 4 : 1, KS);
     if (v4) hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 4>), dim3(g.nchunks, g.groups), dim3(256), 0, s, x, dy, ws, N, H, W, C, g.CPB, g.LANES, g.chunk);
     else hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 1>), dim3(g.nchunks, g.groups), dim3(256), 0, s, x, dy, ws, N, H, W, C, g.CPB, g.LANES, g.chunk);
     HIP_CHECK(hipGetLastError());
