@@ -22,6 +22,7 @@
 #include "conv_kernels.h"
 #include <algorithm>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -43,6 +44,7 @@ struct StreamParams {
     int ntiles;         // spatial tiles * batch
     int per_xcd;        // tiles per XCD (contiguous range)
     unsigned m_nblk;
+    int cw;             // filter row stride = Cout, or Cout padded up to whole 16*NT blocks (zero columns) when Cout % NT != 0
 };
 
 constexpr int kStreamThreads = 256;
@@ -88,7 +90,7 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
     const int n0 = nb * 16 * NT;
 
     // ---- filter addressing: lane (row l15, k-slot lq) reads floats [co, co+NT) of row (tap*Cin + c0 + E*lq + e)
-    const int co_lane = min(n0 + NT * l15, a.Cout - NT);          // rows beyond Cout are never stored
+    const int co_lane = min(n0 + NT * l15, sp.cw - NT);           // rows beyond Cout are never stored
     const int last_row = KK * a.Cin - 1;
     const float* wlane = a.w + co_lane;
 
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
                 row = row_lane + s;
 #endif
                 if (tap == KK - 1) row = min(row, last_row);
-                dst[s] = *reinterpret_cast<const wvec_t*>(wlane + (size_t)row * a.Cout);
+                dst[s] = *reinterpret_cast<const wvec_t*>(wlane + (size_t)row * sp.cw);
             }
         };
         auto load_a = [&](int gs, float (&dst)[MT][G]) {
@@ -253,6 +255,38 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
     }
 }
 
+// Output-channel counts that no NT divides (40 = RB5 of the headline backbone) used to fall back to NT = 1: 16 couts per
+// block, one dword of filter per lane and k-step, 65 TFLOP/s.  They now run with the widest NT that pads Cout no further
+// than NT = 1 would (40 -> 48 with NT = 3) on a zero-padded copy of the filter ([rows][cw], cw = whole blocks), so
+// a lane's NT consecutive couts never straddle the end of a row; the padded columns are computed and never stored.
+__global__ void pad_filter_kernel(const float* __restrict__ w, float* __restrict__ wp, int rows, int Cout, int cw) {
+    const int total = rows * cw;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int r = e / cw, c = e - r * cw;
+        wp[e] = c < Cout ? w[(size_t)r * Cout + c] : 0.f;
+    }
+}
+struct PadScratch { hipStream_t stream; float* buf; size_t floats; };
+float* pad_scratch(hipStream_t s, size_t floats) {       // grow-only, one buffer per stream (launches on a stream are ordered)
+    static std::mutex mu;
+    static std::vector<PadScratch> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : all) {
+        if (e.stream != s) continue;
+        if (e.floats < floats) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipFree(e.buf));
+            HIP_CHECK(hipMalloc((void**)&e.buf, floats * sizeof(float)));
+            e.floats = floats;
+        }
+        return e.buf;
+    }
+    PadScratch e{s, nullptr, std::max<size_t>(floats, 1 << 16)};
+    HIP_CHECK(hipMalloc((void**)&e.buf, e.floats * sizeof(float)));
+    all.push_back(e);
+    return e.buf;
+}
+
 template <int KS, int E, int NT, int MT>
 void launch_stream(hipStream_t s, StreamParams& sp, int N) {
     constexpr int G = (E % 4 == 0) ? 4 : 2;
@@ -267,6 +301,16 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
     sp.ntiles = p.tiles_x * p.tiles_y * N;
     sp.nblk = cdiv(p.Cout, 16 * NT);
     sp.m_nblk = div_magic(sp.nblk);
+    sp.cw = p.Cout;
+    if (p.Cout % NT) {
+        sp.cw = sp.nblk * 16 * NT;
+        const int rows = KS * KS * p.Cin;
+        float* wp = pad_scratch(s, (size_t)rows * sp.cw);
+        ProfScope pp(s, "pad_filter", 0.0, 4.0 * rows * (p.Cout + sp.cw));
+        hipLaunchKernelGGL(pad_filter_kernel, dim3(std::min(cdiv(rows * sp.cw, 256), 1024)), dim3(256), 0, s, p.w, wp, rows, p.Cout, sp.cw);
+        HIP_CHECK(hipGetLastError());
+        p.w = wp;
+    }
     sp.per_xcd = cdiv(sp.ntiles, 8);
     auto kern = conv_stream_kernel<KS, E, NT, MT>;
     static std::once_flag once;
@@ -305,8 +349,9 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     // cout tiling: NT accumulator tiles per wave, lanes own NT consecutive couts -> needs Cout % NT == 0
     int NT = 0;
     long best = -1;
+    static const bool no_ragged = getenv("DL4DS_STREAM_NO_RAGGED") != nullptr;      // (A/B measurements)
     for (int nt = 1; nt <= 4; ++nt) {
-        if (out.C % nt) continue;
+        if ((out.C % nt) && (no_ragged || out.C < 16)) continue;     // Cout % nt != 0: runs on a zero-padded filter copy
         const long padded = (long)cdiv(out.C, 16 * nt) * 16 * nt;
         if (best < 0 || padded < best || (padded == best && nt > NT)) { best = padded; NT = nt; }
     }
@@ -317,7 +362,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
         const long ntiles = (long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N;
         while (NT > 1 && ntiles * cdiv(out.C, 16 * NT) < 512) {
             int nt = NT - 1;
-            while (nt > 1 && out.C % nt) --nt;
+            while (nt > 1 && (out.C % nt) && no_ragged) --nt;
             NT = nt;
         }
     }
@@ -335,7 +380,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     if (KS == 3 && !getenv("DL4DS_STREAM_NO_TALL")) {
         long bp = -1;
         for (int nt = 1; nt <= 3; ++nt) {
-            if (out.C % nt) continue;
+            if ((out.C % nt) && (no_ragged || out.C < 16)) continue;
             const long padded = (long)cdiv(out.C, 16 * nt) * 16 * nt;
             if (bp < 0 || padded < bp || (padded == bp && nt > NT8)) { bp = padded; NT8 = nt; }
         }

@@ -39,6 +39,8 @@ CONV_CASES = [
     (1, 8, 16, 48, 192, 3), (1, 24, 24, 50, 40, 3), (2, 16, 32, 40, 48, 3), (1, 12, 12, 192, 48, 3),
     (2, 17, 16, 8, 48, 1), (1, 16, 16, 48, 8, 1), (1, 10, 10, 24, 200, 1), (1, 16, 16, 6, 12, 5),
     (1, 9, 9, 16, 32, 5), (1, 8, 8, 130, 128, 3), (1, 6, 6, 256, 100, 3),
+    # Cout that no NT divides (conv_stream.hip: zero-padded filter copy, NT = 3 on 40 / 44 couts), 3x3 and 1x1
+    (2, 16, 20, 32, 40, 3), (1, 16, 16, 40, 40, 3), (1, 24, 16, 48, 40, 3), (1, 16, 16, 16, 44, 3), (2, 17, 16, 32, 40, 1),
     # 7x7: ConvNext stem and closing ConvBlocks (sp_postups.py:121,205-210)
     (2, 13, 19, 2, 8, 7), (1, 16, 16, 8, 8, 7), (1, 20, 17, 8, 1, 7), (1, 12, 12, 24, 24, 7), (1, 9, 9, 64, 16, 7),
     # stencil path (conv_direct.hip): pad2(Cin) * pad2(Cout) <= 8, ragged tiles, several tiles per block
