@@ -1279,6 +1279,7 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     p.CIT = (x.C > 32) ? 3 : (x.C > 16 ? 2 : 1);
     if (KS >= 5) p.CIT = 1;
     p.WCO = (dz.C <= 16) ? 1 : (dz.C <= 32 ? 2 : 4);
+    if (const char* e = getenv("DL4DS_WGRAD_WCO")) p.WCO = atoi(e);      // (experiments)
     p.WK = 4 / p.WCO;
     const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
     // every block does the same amount of work, so the grid should be exactly one residency round:
