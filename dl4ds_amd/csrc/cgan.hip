@@ -112,7 +112,11 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
     bce_forward_backward(s, p_real, 1.f, B, 1.f, t.d_losses + 2, dout.grad, 0);
     bce_forward_backward(s, p_fake, 0.f, B, 1.f, t.d_losses + 3, dout.grad + B, 0);
     BwdCtx c1{2 * B, 0, 2 * B, true, false};
+    D.grad_ready = nullptr;
     D.backward(c1);
+    // data parallel: the discriminator's gradients are final here (the generator pass below only propagates to D's
+    // inputs), so their all-reduce runs on the communication stream underneath pass 2 and the generator's backward
+    if (apply_update) dist_allreduce_bucket_async(D.G, D.n_params, s, nullptr);
     // ---- pass 2: generator's adversarial loss through D (fake half, inputs only)
     bce_forward_backward(s, p_fake, 1.f, B, 1.f, t.d_losses + 0, dout.grad + B, 0);
     bool partial = true;
@@ -135,11 +139,18 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
     TView dst = make_view(go.grad, B * go.nmul, go.H, go.W, go.C);
     view_axpy(s, src, dst, 1.f, 1);
     BwdCtx cg{B, 0, B, true, false};
+    // the generator's gradient buckets follow as its backward pass completes them (Graph::plan_buckets)
+    if (apply_update && dist_active()) {
+        G.grad_ready = [](void*, float* grads, size_t n, hipStream_t st, hipStream_t aux) {
+            dist_allreduce_bucket_async(grads, n, st, aux);
+        };
+    } else {
+        G.grad_ready = nullptr;
+    }
     G.backward(cg);
-    // ---- data-parallel average + the two Adam updates (cgan.py:608-617)
+    // ---- data-parallel average (1/world folded into Adam) + the two Adam updates (cgan.py:608-617)
     if (apply_update) {
-        dist_allreduce_grads(G.G, G.n_params, s);
-        dist_allreduce_grads(D.G, D.n_params, s);
+        dist_allreduce_wait(s);
         trainer_apply_adam(*t.G);
         trainer_apply_adam(*t.D);
     }

@@ -139,6 +139,44 @@ def test_bucketed_rccl_allreduce_single_rank_matches_local_step():
     assert 'BUCKETS-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_cgan_overlapped_allreduce_single_rank_matches_local_step():
+    """CGAN data-parallel step: the discriminator's gradients are all-reduced on the communication stream underneath
+    the generator pass, the generator's buckets as its backward completes them; on a 1-rank RCCL communicator (sum over
+    one rank, 1/1) three steps must reproduce the local steps bit for bit -- losses and both weight sets."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import dl4ds_amd.models as PM
+        from dl4ds_amd.training import CGANEngine
+        from dl4ds_amd import parallel
+        rng = np.random.default_rng(0)
+        B, H = 2, 32
+        lr = rng.random((B, H, H, 2)).astype(np.float32)
+        st = rng.random((B, H, H, 1)).astype(np.float32)
+        hr = rng.random((B, H, H, 1)).astype(np.float32)
+        mask = (rng.random((2 * B, 8)) > 0.4).astype(np.float32)
+        def run():
+            gen = PM.unet_pin('unet', 2, 1, hr_size=(H, H), n_filters=4, n_blocks=3, decoder_upsampling='dc', seed=3)
+            disc = PM.residual_discriminator(2, 'pin', False, 8, (H // 8, H // 8), n_filters=4, n_res_blocks=2,
+                                             hr_size=(H, H), seed=4)
+            e = CGANEngine(gen, disc, loss='mae')
+            losses = [e.step([lr, st], hr, dropout_keep=mask) for _ in range(3)]
+            return losses, gen.get_weights(), disc.get_weights()
+        l0, g0, d0 = run()
+        parallel.init_with_id(0, 1, parallel.unique_id())
+        l1, g1, d1 = run()
+        parallel.finalize()
+        assert l0 == l1, (l0, l1)
+        for a, b in ((g0, g1), (d0, d1)):
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        print('CGAN-DP-OK')
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert 'CGAN-DP-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_checkpoint_resume_continues_the_same_optimisation(tmp_path):
     """Weights + Adam slots + iteration count round-trip through SupervisedEngine.save_checkpoint / load_checkpoint:
     3 + 3 steps with a restore in between equal 6 uninterrupted steps bit for bit."""
