@@ -1388,10 +1388,12 @@ void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int 
 }
 
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS) {
-    if (const int ds = conv2d_direct_wgrad_slabs(x, dz, KS)) return (size_t)ds * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
-    if (const int ns = conv2d_narrow_wgrad_slabs(x, dz, KS)) return (size_t)ns * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
-    WgradPlan pl = plan_wgrad(x, dz, KS);
-    return (size_t)pl.S * ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
+    const size_t slab = ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
+    if (const int ds = conv2d_direct_wgrad_slabs(x, dz, KS)) return (size_t)ds * slab;
+    // (the narrow path can be switched off for A/B runs: size for whichever of the two plans needs more)
+    const size_t general = (size_t)plan_wgrad(x, dz, KS).S * slab;
+    if (const int ns = conv2d_narrow_wgrad_slabs(x, dz, KS)) return std::max((size_t)ns * slab, general);
+    return general;
 }
 
 void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate, float* db,

@@ -176,6 +176,7 @@ def test_folded_upsampling_tail_equals_unfolded(monkeypatch, ups, scale):
     from dl4ds_amd.training import SupervisedEngine
     cfg = dict(backbone_block='resnet', upsampling=ups, scale=scale, n_channels=2, n_aux_channels=0, lr_size=(12, 10),
                n_blocks=2, n_filters=8, seed=5)
+    monkeypatch.delenv('DL4DS_NO_FOLD', raising=False)
     folded = PM.net_postupsampling(**cfg)
     monkeypatch.setenv('DL4DS_NO_FOLD', '1')
     plain = PM.net_postupsampling(**cfg)
