@@ -210,6 +210,37 @@ __global__ void resize_fwd_kernel(TView x, TView y, float sy, float sx, size_t t
         y.p[view_off(y, n, oy, ox, c)] = top * (1.f - fy) + bot * fy;
     }
 }
+// Resizing(..., interpolation='nearest') = tf.image.resize(method='nearest') with half-pixel centres:
+// src = min(floor((dst + 0.5) * in / out), in - 1)   (blocks.py:473-489 with rc_interpolation='nearest')
+__device__ __forceinline__ int nearest_src(int o, float scale, int in_size) {
+    return min((int)floorf(((float)o + 0.5f) * scale), in_size - 1);
+}
+__global__ void resize_nearest_fwd_kernel(TView x, TView y, float sy, float sx, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % y.C);
+        int n, oy, ox;
+        unflatten_pix(y, e / y.C, n, oy, ox);
+        y.p[view_off(y, n, oy, ox, c)] = x.p[view_off(x, n, nearest_src(oy, sy, x.H), nearest_src(ox, sx, x.W), c)];
+    }
+}
+// gather form: one thread per INPUT element sums the outputs that copied it (those within one source step of it)
+__global__ void resize_nearest_bwd_kernel(TView dy, TView dx, float sy, float sx, int accumulate, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % dx.C);
+        int n, iy, ix;
+        unflatten_pix(dx, e / dx.C, n, iy, ix);
+        const int oy_lo = max(0, (int)floorf((float)iy / sy - 0.5f) - 1), oy_hi = min(dy.H - 1, (int)ceilf((float)(iy + 1) / sy - 0.5f) + 1);
+        const int ox_lo = max(0, (int)floorf((float)ix / sx - 0.5f) - 1), ox_hi = min(dy.W - 1, (int)ceilf((float)(ix + 1) / sx - 0.5f) + 1);
+        float g = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (nearest_src(oy, sy, dx.H) != iy) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox)
+                if (nearest_src(ox, sx, dx.W) == ix) g += dy.p[view_off(dy, n, oy, ox, c)];
+        }
+        const size_t o = view_off(dx, n, iy, ix, c);
+        dx.p[o] = accumulate ? dx.p[o] + g : g;
+    }
+}
 // gather form (deterministic): one thread per INPUT element sums the output pixels that read it
 __global__ void resize_bwd_kernel(TView dy, TView dx, float sy, float sx, int accumulate, size_t total) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -409,6 +440,19 @@ void resize_bilinear_forward(hipStream_t s, const TView& x, const TView& y) {
 void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate) {
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
     hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
+                       (float)dx.W / (float)dy.W, accumulate, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void resize_nearest_forward(hipStream_t s, const TView& x, const TView& y) {
+    const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    hipLaunchKernelGGL(resize_nearest_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
+                       (float)x.W / (float)y.W, total);
+    HIP_CHECK(hipGetLastError());
+}
+void resize_nearest_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate) {
+    const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
+    hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
                        (float)dx.W / (float)dy.W, accumulate, total);
     HIP_CHECK(hipGetLastError());
 }

@@ -114,7 +114,7 @@ int g_concat(Graph& g, const int* ins, int n);
 int g_add(Graph& g, int a, int b, int relu);
 int g_act(Graph& g, int in, int kind);
 int g_maxpool2(Graph& g, int in);
-int g_resize(Graph& g, int in, int Ho, int Wo);
+int g_resize(Graph& g, int in, int Ho, int Wo, int nearest = 0);
 int g_localconv(Graph& g, int in, int w, int b, int F);
 int g_repeat_time(Graph& g, int in, int T);
 int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, int relu);

@@ -406,13 +406,15 @@ struct MaxPoolOp : GOp {
 // ============================================================================================ Bilinear resize
 struct ResizeOp : GOp {
     int in, out;
+    bool nearest = false;
     ResizeOp() { kind = "resize"; }
     void forward(Graph& g, int B, bool) override {
-        resize_bilinear_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
+        if (nearest) resize_nearest_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
+        else resize_bilinear_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
-        resize_bilinear_backward(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt),
+        (nearest ? resize_nearest_backward : resize_bilinear_backward)(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt),
                                  g.view(in, c.B, true, c.b_off, c.b_cnt), g.tensors[in].grad_written);
         g.tensors[in].grad_written = true;
     }
@@ -564,11 +566,11 @@ int g_maxpool2(Graph& g, int in) {
     return out;
 }
 
-int g_resize(Graph& g, int in, int Ho, int Wo) {
+int g_resize(Graph& g, int in, int Ho, int Wo, int nearest) {
     const GTensor ti = g.tensors.at(in);
     const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
     ResizeOp* op = push<ResizeOp>(g);
-    op->in = in; op->out = out;
+    op->in = in; op->out = out; op->nearest = nearest != 0;
     g.tensors[in].n_other++;
     return out;
 }

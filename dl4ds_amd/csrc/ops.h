@@ -88,6 +88,8 @@ void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TVie
                        int accumulate);
 // bilinear resize (half-pixel centres)
 void resize_bilinear_forward(hipStream_t s, const TView& x, const TView& y);
+void resize_nearest_forward(hipStream_t s, const TView& x, const TView& y);
+void resize_nearest_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate);
 void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate);
 // LocallyConnected2D 1x1: y[n,h,w,f] = b[h,w,f] + sum_c x[n,h,w,c] W[h,w,c,f]
 void localconv_forward(hipStream_t s, const TView& x, const float* w, const float* b, const TView& y);

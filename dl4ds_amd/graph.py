@@ -169,10 +169,13 @@ class GraphBuilder:
         _lib.check(self._l.dl4ds_graph_maxpool2(self.h, x.id, ctypes.byref(out)))
         return self._out(out.value, 'maxpool2', name)
 
-    def resize(self, x, ho, wo, name='resize'):
+    def resize(self, x, ho, wo, name='resize', interpolation='bilinear'):
+        if interpolation not in ('bilinear', 'nearest'):
+            raise NotImplementedError(f"Resizing(interpolation={interpolation!r}): only 'bilinear' and 'nearest' are implemented")
         out = ctypes.c_int()
-        _lib.check(self._l.dl4ds_graph_resize(self.h, x.id, int(ho), int(wo), ctypes.byref(out)))
-        return self._out(out.value, 'resize_bilinear', name)
+        fn = self._l.dl4ds_graph_resize if interpolation == 'bilinear' else self._l.dl4ds_graph_resize_nearest
+        _lib.check(fn(self.h, x.id, int(ho), int(wo), ctypes.byref(out)))
+        return self._out(out.value, 'resize_' + interpolation, name)
 
     def localconv(self, x, name, filters=2, use_bias=True):
         w = self.param(name + '/kernel', (x.H, x.W, x.C, filters))

@@ -151,9 +151,7 @@ def subpixel_block(g, name, x, scale, n_filters, fold_into=None):
 
 def resize_conv_block(g, name, x, scale, n_filters, interpolation='bilinear', fold_into=None):
     """ResizeConvolutionBlock.call -- blocks.py:485-491 (``fold_into``: see subpixel_block)."""
-    if interpolation != 'bilinear':
-        raise NotImplementedError(f"rc_interpolation={interpolation!r}: only 'bilinear' is implemented")
-    y = g.resize(x, int(x.H * scale), int(x.W * scale), name + '/resize')
+    y = g.resize(x, int(x.H * scale), int(x.W * scale), name + '/resize', interpolation)
     if fold_into is not None:
         return g.conv2d_folded(y, name + '/conv', n_filters, 3, 0, fold_into[0] + '/conv', fold_into[1], fold_into[2])
     return g.conv2d(y, name + '/conv', n_filters, 3)

@@ -144,6 +144,8 @@ int dl4ds_graph_add(dl4ds_graph* g, int a, int b, int relu, int* out);
 int dl4ds_graph_act(dl4ds_graph* g, int in, int kind, int* out);   /* 1 relu 2 sigmoid 3 tanh 4 elu 5 leaky 6 selu 7 gelu */
 int dl4ds_graph_maxpool2(dl4ds_graph* g, int in, int* out);
 int dl4ds_graph_resize(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
+/* Resizing(Ho, Wo, interpolation='nearest') (half-pixel centres) -- ResizeConvolutionBlock(interpolation='nearest'), blocks.py:473-489 */
+int dl4ds_graph_resize_nearest(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
 int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out);
 int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out);
 int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out);

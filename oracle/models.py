@@ -284,10 +284,11 @@ def subpixel_block(ops, P, name, x, scale, n_filters):
     return x
 
 
-def resize_conv_block(ops, P, name, x, scale, n_filters):
-    """ResizeConvolutionBlock.call (bilinear) -- blocks.py:485-491."""
+def resize_conv_block(ops, P, name, x, scale, n_filters, interpolation='bilinear'):
+    """ResizeConvolutionBlock.call -- blocks.py:485-491 (Resizing with 'bilinear' or 'nearest')."""
     h, w = x.shape[1], x.shape[2]
-    y = ops.resize_bilinear(x, int(h * scale), int(w * scale))
+    rs = ops.resize_bilinear if interpolation == 'bilinear' else ops.resize_nearest
+    y = rs(x, int(h * scale), int(w * scale))
     return _conv(ops, P, name + '/conv', y, n_filters, 3)
 
 
@@ -403,12 +404,13 @@ def _tail(ops, P, x, s_in, init_nf, n_filters_aux, n_channels_out, activation,
 
 def net_postupsampling(ops, P, x_in, s_in=None, *, backbone_block, upsampling, scale,
                        n_channels_out=1, n_filters=8, n_blocks=6, attention=False,
-                       activation='relu', output_activation=None, localcon_layer=False, ctx=None):
+                       activation='relu', output_activation=None, localcon_layer=False, ctx=None,
+                       rc_interpolation='bilinear'):
     x, nf = _backbone(ops, P, x_in, backbone_block, n_filters, n_blocks, activation, attention, ctx)
     if upsampling == 'spc':
         x = subpixel_block(ops, P, 'SubpixelConvolution', x, scale, nf)
     elif upsampling == 'rc':
-        x = resize_conv_block(ops, P, 'ResizeConvolution', x, scale, nf)
+        x = resize_conv_block(ops, P, 'ResizeConvolution', x, scale, nf, rc_interpolation)
     elif upsampling == 'dc':
         x = transition_block(ops, P, 'TransitionDC', x, n_filters, activation)
         x = deconv_block(ops, P, 'Deconvolution', x, scale, nf, activation)
@@ -427,7 +429,7 @@ def net_pin(ops, P, x_in, s_in=None, *, backbone_block, n_channels_out=1, n_filt
 
 def unet_pin(ops, P, x_in, s_in=None, *, n_filters, n_blocks, n_channels_out=1,
              activation='relu', attention=False, decoder_upsampling='rc',
-             output_activation=None, width_cap=256, localcon_layer=False, ctx=None):
+             output_activation=None, width_cap=256, localcon_layer=False, ctx=None, rc_interpolation='bilinear'):
     """sp_preups.py:230-315.  Encoder blocks never receive dropout (`i == n_blocks` is never true, :255), the
     bottleneck is built with normalization=None (:265-268), one dropout layer follows the decoder (:287)."""
     ctx = ctx or _NO_CTX
@@ -453,7 +455,7 @@ def unet_pin(ops, P, x_in, s_in=None, *, n_filters, n_blocks, n_channels_out=1,
         if decoder_upsampling == 'spc':
             x = subpixel_block(ops, P, f'SubpixelConvolution{j+1}', x, 2, n_filters)
         elif decoder_upsampling == 'rc':
-            x = resize_conv_block(ops, P, f'ResizeConvolution{j+1}', x, 2, n_filters)
+            x = resize_conv_block(ops, P, f'ResizeConvolution{j+1}', x, 2, n_filters, rc_interpolation)
         elif decoder_upsampling == 'dc':
             x = deconv_block(ops, P, f'Deconvolution{j+1}', x, 2, n_filters, activation)
         x = pad_concat(ops, x, skip)

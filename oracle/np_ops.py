@@ -101,6 +101,14 @@ def depth_to_space(x, r):
     return y.reshape(n, h * r, w * r, cp)
 
 
+def resize_nearest(x, ho, wo):
+    """tf.image.resize(method='nearest') (half_pixel_centers=True): src = min(floor((dst + 0.5) * in / out), in - 1)."""
+    h, w = x.shape[1], x.shape[2]
+    iy = np.minimum(np.floor((np.arange(ho) + 0.5) * (h / ho)).astype(int), h - 1)
+    ix = np.minimum(np.floor((np.arange(wo) + 0.5) * (w / wo)).astype(int), w - 1)
+    return x[:, iy][:, :, ix]
+
+
 def resize_bilinear(x, ho, wo):
     """tf.keras.layers.Resizing(..., 'bilinear') = tf.image.resize, half-pixel
     centres, no antialias.  dl4ds/models/blocks.py:489; discriminator.py:62-63.

@@ -86,6 +86,13 @@ def depth_to_space(x, r):
     return y.reshape(n, h * r, w * r, cp)
 
 
+def resize_nearest(x, ho, wo):
+    h, w = x.shape[1], x.shape[2]
+    iy = torch.clamp(torch.floor((torch.arange(ho, dtype=torch.float64) + 0.5) * (h / ho)).long(), max=h - 1)
+    ix = torch.clamp(torch.floor((torch.arange(wo, dtype=torch.float64) + 0.5) * (w / wo)).long(), max=w - 1)
+    return x[:, iy][:, :, ix]
+
+
 def resize_bilinear(x, ho, wo):
     n, h, w, c = x.shape
 

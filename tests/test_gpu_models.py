@@ -49,7 +49,7 @@ def build_pair(kind, cfg, x_shape, s_shape, seed=11, ctx_kw=None):
         elif w[k].ndim == 1 or k.endswith('bias'):
             w[k] = (rng.standard_normal(w[k].shape) * 0.05).astype(np.float32)
     model.set_weights(w)
-    ocfg = {k: v for k, v in ocfg_in.items() if k not in ('rc_interpolation',)}
+    ocfg = dict(ocfg_in)
     if kind == 'unet_pin':
         ocfg.pop('backbone_block', None)
     extra = dict(ctx=M.Ctx(**ctx_kw)) if ctx_kw else {}
@@ -75,6 +75,10 @@ SUP_CASES = [
     ('unet_pin', dict(n_filters=4, n_blocks=3, decoder_upsampling='dc'), (2, 32, 32, 3), (2, 32, 32, 1)),
     ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='spc', attention=True), (1, 16, 24, 2), None),
     ('unet_pin', dict(n_filters=8, n_blocks=2, decoder_upsampling='rc'), (1, 16, 16, 5), (1, 16, 16, 1)),
+    # Resizing(interpolation='nearest') in the resize-convolution upsamplers (blocks.py:473-489)
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='rc', scale=3, n_blocks=1, n_filters=4,
+                                rc_interpolation='nearest'), (2, 7, 9, 2), (2, 21, 27, 1)),
+    ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='rc', rc_interpolation='nearest'), (1, 16, 20, 2), None),
     # odd grids: MaxPooling2D drops a row / column, PadConcat zero-pads the decoder side back (blocks.py:629-656)
     ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='rc'), (2, 25, 30, 2), None),
     ('unet_pin', dict(n_filters=4, n_blocks=3, decoder_upsampling='spc'), (1, 37, 23, 1), (1, 37, 23, 1)),

@@ -468,3 +468,30 @@ def test_depthwise_conv7(ops, shape):
     base = R(*shape)
     _, gx2, _, _ = ops.dwconv(x, k, b, dy=dy, accumulate_into=base)
     close(gx2, tx.grad.numpy() + base)
+
+
+@pytest.mark.parametrize('shape,out', [((2, 5, 7, 3), (10, 14)), ((1, 8, 6, 4), (20, 15)), ((2, 9, 9, 1), (27, 27)), ((1, 12, 10, 2), (5, 4))])
+def test_resize_nearest_in_graph(shape, out):
+    """Resizing(interpolation='nearest') (tf.image.resize half-pixel nearest): forward and input gradient through a one-op
+    graph + identity 1x1 convolution, integer and fractional ratios, down-sampling included."""
+    import dl4ds_amd.graph as G
+    from dl4ds_amd.training import SupervisedEngine
+    n, h, w, c = shape
+    g = G.GraphBuilder()
+    x_in = g.input(h, w, c)
+    y = g.conv2d(g.resize(x_in, out[0], out[1], interpolation='nearest'), 'id', c, 1, use_bias=False)
+    g.finalize(y, seed=0)
+    m = G.Model(g, 'resize', [(h, w, c)])
+    eye = np.eye(c, dtype=np.float32).reshape(1, 1, c, c)
+    m.set_weights({'id/kernel': eye})
+    x = R(*shape)
+    ref = N.resize_nearest(x.astype(np.float64), *out)
+    np.testing.assert_array_equal(m([x]), ref.astype(np.float32))
+    # gradient w.r.t. the identity kernel = sum over pixels of resized(x)_ci * dy_co: exercises the forward; the input
+    # gradient is exercised by the model tests (rc_interpolation='nearest')
+    yt = R(n, out[0], out[1], c)
+    eng = SupervisedEngine(m, loss='mse', learning_rate=1e-3)
+    _, grads = eng.loss_and_grads([x], yt)
+    d = 2.0 * (ref - yt.astype(np.float64)) / ref.size
+    gw = np.einsum('nhwi,nhwo->io', ref, d).reshape(1, 1, c, c)
+    close(grads['id/kernel'], gw, 1e-3)
