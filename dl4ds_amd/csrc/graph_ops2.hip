@@ -147,10 +147,12 @@ struct GapOp : GOp {
     int in, out;
     bool over_time = false;    // GlobalAveragePooling3D: the frames of a sample are averaged too (discriminator.py:74)
     GapOp() { kind = "gap"; }
+    size_t workspace_bytes(Graph& g, int B) override { return gap_workspace_bytes(B * g.tensors[in].nmul, g.tensors[in].C); }
     void forward(Graph& g, int B, bool) override {
         const GTensor& ti = g.tensors[in];
         const int fr = over_time ? ti.nmul : 1;
-        gap_forward(g.stream, ti.data, g.tensors[out].data, B * ti.nmul / fr, ti.H * ti.W * fr, ti.C);
+        gap_forward(g.stream, ti.data, g.tensors[out].data, B * ti.nmul / fr, ti.H * ti.W * fr, ti.C, g.workspace,
+                    g.workspace_bytes);
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;

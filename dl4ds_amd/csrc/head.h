@@ -1,6 +1,7 @@
 #pragma once
 #include "common.h"
-void gap_forward(hipStream_t s, const float* x, float* out, int N, int HW, int C);
+size_t gap_workspace_bytes(int N, int C);
+void gap_forward(hipStream_t s, const float* x, float* out, int N, int HW, int C, float* ws = nullptr, size_t ws_bytes = 0);
 void gap_backward(hipStream_t s, const float* dy, float* dx, int N, int HW, int C, int accumulate);
 void dense_forward(hipStream_t s, const float* x, const float* w, const float* b, float* y, int B, int Cin, int F, int act);
 // dy is overwritten with dz = dy*act'(y) for rows [b0, b0+B)

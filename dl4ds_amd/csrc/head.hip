@@ -24,6 +24,54 @@ __global__ void __launch_bounds__(256) gap_fwd_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) out[(size_t)n * C + c] = red[0] / (float)HW;
 }
 
+// Coalesced form for feature maps (the discriminator's merge tensor is 2B x 512 x 512 x 16): a block owns a chunk of
+// consecutive pixels of one image, thread t the channel pack t % CP on the pixel rows t / CP, t / CP + R, ...; rows are
+// combined through LDS, chunks by gap_finish_kernel in a fixed order.  (The per-(n, c) kernel above reads one float per
+// 4*C-byte stride: 0.56 ms for that tensor vs 0.03 ms here.)
+constexpr int GAP_CHUNKS = 128;
+template <int V>
+__global__ void __launch_bounds__(256) gap_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int HW, int C) {
+    __shared__ float red[256 * V];
+    const int CP = C / V, R = 256 / CP, T = R * CP;
+    const int t = threadIdx.x, cp = t % CP, row = t / CP;
+    const int n = blockIdx.y;
+    const int chunk = (HW + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    if (t < T) {
+        const float* base = x + (size_t)n * HW * C + cp * V;
+        for (int p = p0 + row; p < p1; p += R) {
+            if constexpr (V == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            } else {
+                acc[0] += base[(size_t)p * C];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[t * V + i] = acc[i];
+    __syncthreads();
+    if (t < CP) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float a = 0.f;
+            for (int r = 0; r < R; ++r) a += red[(r * CP + t) * V + i];
+            partial[((size_t)n * gridDim.x + blockIdx.x) * C + t * V + i] = a;
+        }
+    }
+}
+__global__ void gap_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunks, int C, int total, float inv) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int n = e / C, c = e - n * C;
+    double a = 0.0;
+    for (int k = 0; k < nchunks; ++k) a += (double)partial[((size_t)n * nchunks + k) * C + c];
+    out[e] = (float)(a * (double)inv);
+}
+
 __global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int C, size_t total,
                                int accumulate) {
     const float inv = 1.f / (float)HW;
@@ -129,9 +177,21 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, const float* _
 inline int ew_blocks(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 4096)); }
 }  // namespace
 
-void gap_forward(hipStream_t s, const float* x, float* out, int N, int HW, int C) {
+size_t gap_workspace_bytes(int N, int C) { return (size_t)N * GAP_CHUNKS * C * sizeof(float); }
+
+void gap_forward(hipStream_t s, const float* x, float* out, int N, int HW, int C, float* ws, size_t ws_bytes) {
     ProfScope ps(s, "gap_fwd", 0.0, 4.0 * (double)N * HW * C);
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, C), dim3(256), 0, s, x, out, HW, C);
+    const bool v4 = (C & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+    const int CP = v4 ? C / 4 : C;
+    if (ws == nullptr || ws_bytes < gap_workspace_bytes(N, C) || CP > 256 || HW < 4096) {
+        hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, C), dim3(256), 0, s, x, out, HW, C);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (v4) hipLaunchKernelGGL(gap_partial_kernel<4>, dim3(GAP_CHUNKS, N), dim3(256), 0, s, x, ws, HW, C);
+    else hipLaunchKernelGGL(gap_partial_kernel<1>, dim3(GAP_CHUNKS, N), dim3(256), 0, s, x, ws, HW, C);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(gap_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ws, out, GAP_CHUNKS, C, N * C, 1.f / (float)HW);
     HIP_CHECK(hipGetLastError());
 }
 void gap_backward(hipStream_t s, const float* dy, float* dx, int N, int HW, int C, int accumulate) {

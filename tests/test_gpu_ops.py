@@ -495,3 +495,31 @@ def test_resize_nearest_in_graph(shape, out):
     d = 2.0 * (ref - yt.astype(np.float64)) / ref.size
     gw = np.einsum('nhwi,nhwo->io', ref, d).reshape(1, 1, c, c)
     close(grads['id/kernel'], gw, 1e-3)
+
+
+@pytest.mark.parametrize('shape,over_time', [((3, 1, 80, 72, 12), False), ((2, 1, 64, 64, 6), False), ((2, 3, 48, 40, 16), True),
+                                             ((2, 1, 9, 7, 5), False)])
+def test_global_average_pooling_in_graph(shape, over_time):
+    """GlobalAveragePooling2D / 3D (discriminator.py:72-74): the coalesced chunked kernel (feature maps of >= 4096
+    pixels; float4 and scalar channel packs) and the per-(n, c) kernel for small maps, forward and gradient."""
+    import dl4ds_amd.graph as G
+    from dl4ds_amd.training import SupervisedEngine
+    n, t, h, w, c = shape
+    g = G.GraphBuilder()
+    x_in = g.input(h, w, c, nmul=t)
+    feat = g.conv2d(x_in, 'id', c, 1, use_bias=False)
+    y = g.gap(feat, 'gap', over_time=over_time)
+    g.finalize(y, seed=0)
+    m = G.Model(g, 'gap', [(t, h, w, c) if t > 1 else (h, w, c)])
+    m.set_weights({'id/kernel': np.eye(c, dtype=np.float32).reshape(1, 1, c, c)})
+    x = R(*((n, t, h, w, c) if t > 1 else (n, h, w, c)))
+    out = m([x])
+    ref = x.astype(np.float64).mean(axis=(1, 2, 3) if (t > 1 and over_time) else ((2, 3) if t > 1 else (1, 2)))
+    close(out.reshape(ref.shape), ref, 1e-5)
+    # d loss / d kernel through the pooling backward: loss = mse(gap(x W), yt)
+    yt = R(*out.shape)
+    eng = SupervisedEngine(m, loss='mse', learning_rate=1e-3)
+    _, grads = eng.loss_and_grads([x], yt)
+    d = 2.0 * (ref - yt.reshape(ref.shape).astype(np.float64)) / ref.size         # (n[, t], c)
+    gw = (ref.reshape(-1, c).T @ d.reshape(-1, c)).reshape(1, 1, c, c)             # gap(x W) = mean(x) W
+    close(grads['id/kernel'], gw, 1e-3)
