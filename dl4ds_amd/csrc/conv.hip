@@ -19,6 +19,7 @@
 #include "conv_kernels.h"
 #include <algorithm>
 #include <mutex>
+#include <vector>
 #include <cstdlib>
 
 namespace {
@@ -71,7 +72,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+    // split-K: this block's share of the channel chunks (the whole range when kchunks == 0)
+    const int c_begin = a.kchunks ? (int)blockIdx.z * a.kchunks * CK : 0;
+    const int c_end = a.kchunks ? min(a.Cin, c_begin + a.kchunks * CK) : a.Cin;
+    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
         const int ck = min(CK, a.Cin - c0);
         const int ck4 = (ck + 3) >> 2;
         const unsigned m4 = div_magic(ck4);
@@ -178,8 +182,49 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) accp.v[i][j] = acc[i][j];
-        conv_epilogue<MT, NT>(a, accp, n, x0, y0, n0, wm, wn, l15, lq);
+        conv_epilogue<MT, NT>(a, accp, a.kchunks ? (int)blockIdx.z * a.nimg + n : n, x0, y0, n0, wm, wn, l15, lq);
     }
+}
+
+// out = epilogue(sum of the S split-K slabs): bias, residual add, ReLU, ReLU-backward mask, accumulate -- through the
+// real output view (plain or depth_to_space).  One thread per output element; the tensors here are tiny.
+__global__ void splitk_combine_kernel(const float* __restrict__ slabs, int S, size_t slab_stride, const ConvParams a, int N) {
+    const size_t total = (size_t)N * a.H * a.W * a.Cout;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % a.Cout);
+        size_t r = e / a.Cout;
+        const int x = (int)(r % a.W); r /= a.W;
+        const int y = (int)(r % a.H);
+        const int n = (int)(r / a.H);
+        float v = a.bias ? a.bias[c] : 0.f;
+        for (int z = 0; z < S; ++z) v += slabs[(size_t)z * slab_stride + e];
+        if (a.add.p) v += a.add.p[view_off(a.add, n, y, x, c)];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.mask.p && !(a.mask.p[view_off(a.mask, n, y, x, c)] > 0.f)) v = 0.f;
+        const size_t o = view_off(a.out, n, y, x, c);
+        a.out.p[o] = a.accumulate ? a.out.p[o] + v : v;
+    }
+}
+
+struct StreamScratch { hipStream_t stream; float* buf; size_t floats; };
+float* splitk_scratch(hipStream_t s, size_t floats) {     // grow-only, one buffer per stream (launches on a stream are ordered)
+    static std::mutex mu;
+    static std::vector<StreamScratch> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : all) {
+        if (e.stream != s) continue;
+        if (e.floats < floats) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipFree(e.buf));
+            HIP_CHECK(hipMalloc((void**)&e.buf, floats * sizeof(float)));
+            e.floats = floats;
+        }
+        return e.buf;
+    }
+    StreamScratch e{s, nullptr, std::max<size_t>(floats, (size_t)1 << 20)};
+    HIP_CHECK(hipMalloc((void**)&e.buf, e.floats * sizeof(float)));
+    all.push_back(e);
+    return e.buf;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -484,9 +529,36 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
     });
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * N), (unsigned)cdiv(p.Cout, BN));
     const double px = (double)N * p.H * p.W;
+    // Deep U-Net levels (256 -> 256 at 8x8, the 9x9 transposed convolutions as 5x5 convolutions with 1024 couts): a few
+    // dozen blocks each walking thousands of k-steps.  Split the channel chunks over blockIdx.z into plain slabs and let
+    // a small kernel sum them and apply the epilogue (fixed order: deterministic).
+    static const bool no_splitk = getenv("DL4DS_NO_SPLITK") != nullptr;
+    const long blocks = (long)grid.x * grid.y;
+    const int nchunks = cdiv(p.Cin, CK);
+    int S = 1;
+    if (!no_splitk && blocks < 256 && nchunks >= 2) S = (int)std::min<long>(nchunks, std::max<long>(2, 512 / blocks));
     ProfScope ps(s, "conv_igemm<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
-                        std::to_string(WM) + "," + std::to_string(WN) + ">",
+                        std::to_string(WM) + "," + std::to_string(WN) + (S > 1 ? ",splitk>" : ">"),
                  2.0 * px * KK * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KK * p.Cin * p.Cout));
+    p.kchunks = 0; p.nimg = N;
+    if (S > 1) {
+        const int cps = cdiv(nchunks, S);
+        S = cdiv(nchunks, cps);
+        const size_t slab = (size_t)N * p.H * p.W * p.Cout;
+        float* slabs = splitk_scratch(s, slab * S);
+        ConvParams q = p;
+        q.out = make_view(slabs, N * S, p.H, p.W, p.Cout);
+        q.bias = nullptr; q.add.p = nullptr; q.mask.p = nullptr; q.relu = 0; q.accumulate = 0;
+        q.kchunks = cps;
+        grid.z = (unsigned)S;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, q);
+        HIP_CHECK(hipGetLastError());
+        const size_t total = slab;
+        hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, s, slabs, S,
+                           slab, p, N);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }

@@ -32,6 +32,9 @@ struct ConvParams {
     int relu, accumulate;
     int wvec;
     unsigned m_txy[2];      // magic dividers for tiles_x, tiles_y
+    // split-K (conv_igemm_kernel on grids with too few tiles to fill the chip): blockIdx.z owns `kchunks` consecutive
+    // channel chunks and writes its partial result as image (z * nimg + n) of a plain slab buffer; 0 = off
+    int kchunks = 0, nimg = 0;
 };
 
 // Epilogue shared by the forward/dgrad kernels.  The MFMA is issued as D = W^T-fragment x pixel-fragment, so with the
