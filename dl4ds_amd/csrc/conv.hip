@@ -1451,11 +1451,71 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     }
 }
 
+// the same map for large filters (deep U-Net levels: 25 x 256 x 1024): 32 x 32 tiles through LDS so that both the read
+// (rows of Cout floats) and the write (rows of Cin floats) are coalesced
+__global__ void __launch_bounds__(256) dgrad_weights_tiled_kernel(const float* __restrict__ w, float* __restrict__ wt, int KK, int Cin,
+                                                                  int Cout) {
+    __shared__ float tile[32][33];
+    const int tp = blockIdx.z;                                   // destination tap
+    const float* src = w + (size_t)(KK - 1 - tp) * Cin * Cout;   // [Cin][Cout]
+    float* dst = wt + (size_t)tp * Cout * Cin;                   // [Cout][Cin]
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < Cin && co < Cout) ? src[(size_t)ci * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = tile[tx][r];
+    }
+}
+
+// one launch for a list of filters: block b belongs to the job with block0 <= b < next job's block0 and transposes a
+// 32 x 32 (cin x cout) tile of one tap
+__global__ void __launch_bounds__(256) dgrad_weights_batched_kernel(const DgradWeightsJob* __restrict__ jobs, int nj) {
+    __shared__ float tile[32][33];
+    int j = 0;
+    while (j + 1 < nj && (int)blockIdx.x >= jobs[j + 1].block0) ++j;         // a few dozen jobs: linear scan
+    const DgradWeightsJob job = jobs[j];
+    int b = (int)blockIdx.x - job.block0;
+    const int nci = (job.Cin + 31) / 32, nco = (job.Cout + 31) / 32;
+    const int bi = b % nci; b /= nci;
+    const int bo = b % nco;
+    const int tp = b / nco;
+    const float* src = job.src + (size_t)(job.KK - 1 - tp) * job.Cin * job.Cout;
+    float* dst = job.dst + (size_t)tp * job.Cout * job.Cin;
+    const int ci0 = bi * 32, co0 = bo * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < job.Cin && co < job.Cout) ? src[(size_t)ci * job.Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < job.Cout && ci < job.Cin) dst[(size_t)co * job.Cin + ci] = tile[tx][r];
+    }
+}
+int dgrad_weights_job_blocks(int KK, int Cin, int Cout) { return cdiv(Cin, 32) * cdiv(Cout, 32) * KK; }
+void conv2d_dgrad_weights_batched(hipStream_t s, const DgradWeightsJob* jobs_dev, int nj, int blocks) {
+    if (nj == 0 || blocks == 0) return;
+    ProfScope ps(s, "dgrad_weights_batched", 0.0, 0.0);
+    hipLaunchKernelGGL(dgrad_weights_batched_kernel, dim3(blocks), dim3(256), 0, s, jobs_dev, nj);
+    HIP_CHECK(hipGetLastError());
+}
+
 void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int Cin, int Cout) {
     const size_t total = (size_t)KS * KS * Cin * Cout;
-    const int blocks = (int)std::min<size_t>(cdivz(total, 256), 2048);
     ProfScope ps(s, "dgrad_weights", 0.0, 8.0 * (double)total);
-    hipLaunchKernelGGL(dgrad_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wt, KS * KS, Cin, Cout);
+    if ((size_t)Cin * Cout >= 4096 && Cin >= 16 && Cout >= 16) {
+        hipLaunchKernelGGL(dgrad_weights_tiled_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), KS * KS), dim3(256), 0, s, w, wt, KS * KS,
+                           Cin, Cout);
+    } else {
+        const int blocks = (int)std::min<size_t>(cdivz(total, 256), 2048);
+        hipLaunchKernelGGL(dgrad_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wt, KS * KS, Cin, Cout);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

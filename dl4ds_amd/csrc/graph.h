@@ -80,6 +80,18 @@ struct Graph {
     void join_aux();            // `stream` waits for everything enqueued on aux_stream
     hipStream_t stream = nullptr;
     std::vector<float*> allocations;
+    // dgrad filter arrangements (flipped taps, cin <-> cout) of every convolution: registered by the ops at finalize
+    // and produced by ONE launch at the start of the first backward pass after a forward (the filters only change in
+    // the optimiser step), instead of one tiny launch per layer
+    struct WtJob { size_t src_off; bool src_in_wt; size_t dst_off; int KK, Cin, Cout; };
+    std::vector<WtJob> wt_jobs;
+    void* wt_jobs_dev = nullptr;
+    int wt_job_blocks = 0;
+    bool wt_fresh = false;
+    void add_wt_job(size_t src_off, bool src_in_wt, size_t dst_off, int KK, int Cin, int Cout) {
+        wt_jobs.push_back({src_off, src_in_wt, dst_off, KK, Cin, Cout});
+    }
+    void refresh_dgrad_weights();
     // Gradient buckets for the data-parallel all-reduce (contiguous arena ranges in creation = forward order).
     // Bucket k is final once the backward pass has run op `ready_op` (the first forward op using any of its
     // parameters); Graph::backward then calls grad_ready(offset, count) -- the trainer launches that bucket's

@@ -13,6 +13,7 @@ Graph::~Graph() {
         if (G) (void)hipFree(G);
     }
     if (Wt) (void)hipFree(Wt);
+    if (wt_jobs_dev) (void)hipFree(wt_jobs_dev);
     if (workspace) (void)hipFree(workspace);
     if (aux_workspace) (void)hipFree(aux_workspace);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -146,7 +147,30 @@ TView Graph::view(int tid, int B, bool grad, int b_off, int b_cnt) const {
 
 void Graph::forward(int B, bool training) {
     prepare(B);
+    wt_fresh = false;          // the filters may have been updated since the last backward pass
     for (auto& op : ops) op->forward(*this, B, training);
+}
+
+void Graph::refresh_dgrad_weights() {
+    if (wt_fresh || wt_jobs.empty()) { wt_fresh = true; return; }
+    if (wt_jobs_dev == nullptr) {
+        std::vector<DgradWeightsJob> host;
+        int blocks = 0;
+        for (const WtJob& j : wt_jobs) {
+            DgradWeightsJob d;
+            d.src = (j.src_in_wt ? Wt : W) + j.src_off;
+            d.dst = Wt + j.dst_off;
+            d.KK = j.KK; d.Cin = j.Cin; d.Cout = j.Cout; d.block0 = blocks;
+            blocks += dgrad_weights_job_blocks(j.KK, j.Cin, j.Cout);
+            host.push_back(d);
+        }
+        HIP_CHECK(hipMalloc(&wt_jobs_dev, host.size() * sizeof(DgradWeightsJob)));
+        HIP_CHECK(hipMemcpyAsync(wt_jobs_dev, host.data(), host.size() * sizeof(DgradWeightsJob), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));            // `host` goes out of scope
+        wt_job_blocks = blocks;
+    }
+    conv2d_dgrad_weights_batched(stream, static_cast<const DgradWeightsJob*>(wt_jobs_dev), (int)wt_jobs.size(), wt_job_blocks);
+    wt_fresh = true;
 }
 
 void Graph::zero_grad_flags() {
@@ -155,6 +179,7 @@ void Graph::zero_grad_flags() {
 }
 
 void Graph::backward(const BwdCtx& c) {
+    refresh_dgrad_weights();
     for (auto& t : tensors) t.grad_written = false;
     for (int o : outputs) tensors[o].grad_written = true;      // seeded by the loss
     const bool bucketed = c.param_grads && grad_ready != nullptr && !buckets.empty();
@@ -196,6 +221,7 @@ struct ConvOp : GOp {
     ConvOp() { kind = "conv2d"; }
     void on_finalize(Graph& g) override {
         wt_off = g.reserve_wt(g.params[w].n);
+        g.add_wt_job(g.params[w].offset, false, wt_off, KS * KS, g.tensors[in].C, Cout);
         // ReLU backward fused into the consumers' dgrad stores when every consumer is a Conv2D reading this tensor
         // as its convolved input (DL4DS_NO_MASK_FUSION=1 keeps the separate pass, for A/B measurements)
         GTensor& t = g.tensors[out];
@@ -249,8 +275,7 @@ struct ConvOp : GOp {
             if (need_db) g.params[b].grad_written = true;
         }
         if (wants_grad(g, in, c)) {
-            float* wt = g.Wt + wt_off;
-            conv2d_dgrad_weights(g.stream, g.wp(w), wt, KS, g.tensors[in].C, Cout);
+            float* wt = g.Wt + wt_off;              // (filled by Graph::refresh_dgrad_weights at the start of this pass)
             ConvEpilogue ep;
             ep.accumulate = g.tensors[in].grad_written;
             // the producer's ReLU backward rides on this store (saves a read-modify-write pass over the gradient)

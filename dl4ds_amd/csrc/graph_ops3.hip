@@ -144,7 +144,8 @@ struct FoldedConvOp : GOp {
         weff_off = g.reserve_wt(n);
         beff_off = g.reserve_wt(ncol());
         dweff_off = g.reserve_wt(n + ncol());          // [dW_eff | db_eff]
-        wt_off = g.reserve_wt(n);                      // dgrad arrangement of W_eff
+        wt_off = g.reserve_wt(n);                      // dgrad arrangement of W_eff (W_eff itself is rebuilt in forward)
+        g.add_wt_job(weff_off, true, wt_off, KS * KS, g.tensors[in].C, ncol());
         GTensor& t = g.tensors[out];
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
@@ -205,8 +206,7 @@ struct FoldedConvOp : GOp {
             if (b2 >= 0) g.params[b2].grad_written = true;
         }
         if (wants_grad(g, in, c)) {
-            float* wt = g.Wt + wt_off;
-            conv2d_dgrad_weights(g.stream, weff, wt, KS, g.tensors[in].C, ncol());
+            float* wt = g.Wt + wt_off;              // (Graph::refresh_dgrad_weights)
             ConvEpilogue ep;
             ep.accumulate = g.tensors[in].grad_written;
             if (g.tensors[in].grad_masked) ep.mask = g.view(in, c.B, false, c.b_off, c.b_cnt);

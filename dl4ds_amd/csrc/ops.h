@@ -15,6 +15,10 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
                     const ConvEpilogue& ep);
 // wt[(KS*KS-1-tap)][co][ci] = w[tap][ci][co] : conv2d_forward(dz, wt) == dgrad
 void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int Cin, int Cout);
+// several of them in one launch: jobs_dev = nj x DgradWeightsJob on the device, blocks = sum of their block counts
+struct DgradWeightsJob { const float* src; float* dst; int KK, Cin, Cout, block0; };
+int dgrad_weights_job_blocks(int KK, int Cin, int Cout);
+void conv2d_dgrad_weights_batched(hipStream_t s, const DgradWeightsJob* jobs_dev, int nj, int blocks);
 // dw[tap][ci][co] (+)= sum_{n,y,x} x[n,y+ky-p,x+kx-p,ci] * dz[n,y,x,co] ; db[co] (+)= sum dz[n,y,x,co] (db may be null)
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS);
 void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate, float* db,
