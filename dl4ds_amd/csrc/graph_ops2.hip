@@ -58,6 +58,8 @@ struct ConvLSTMOp : GOp {
     void on_finalize(Graph& g) override {
         wt_k = g.reserve_wt(g.params[wk].n);
         wt_r = g.reserve_wt(g.params[wr].n);
+        g.add_wt_job(g.params[wk].offset, false, wt_k, KS * KS, g.tensors[in].C, 4 * F);     // Graph::refresh_dgrad_weights
+        g.add_wt_job(g.params[wr].offset, false, wt_r, KS * KS, F, 4 * F);
     }
     size_t hw(Graph& g) { return (size_t)g.tensors[in].H * g.tensors[in].W; }
     size_t saved_floats_per_sample(Graph& g) override {
@@ -108,7 +110,6 @@ struct ConvLSTMOp : GOp {
         const GTensor& ti = g.tensors[in];
         Bufs bf = bufs(g, B);
         float* Ut = g.Wt + wt_r;
-        conv2d_dgrad_weights(g.stream, g.wp(wr), Ut, KS, F, 4 * F);
         TView dh = make_view(bf.dh, B, ti.H, ti.W, F), dc = make_view(bf.dc, B, ti.H, ti.W, F);
         for (int t = T - 1; t >= 0; --t) {
             TView dzt = frame(g, bf.dZ, B, t, 4 * F);
@@ -133,7 +134,6 @@ struct ConvLSTMOp : GOp {
         }
         if (wants_grad(g, in, c)) {
             float* Kt = g.Wt + wt_k;
-            conv2d_dgrad_weights(g.stream, g.wp(wk), Kt, KS, ti.C, 4 * F);
             ConvEpilogue ep;
             ep.accumulate = g.tensors[in].grad_written;
             conv2d_forward(g.stream, dZall, Kt, KS, g.view(in, B, true), ep);
