@@ -26,10 +26,13 @@ namespace {
 
 constexpr int kLdsBudget = 80 * 1024;   // 2 workgroups per CU (160 KiB LDS)
 
-template <int KS, int MT, int NT, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvParams a) {
+// KSP = 2: a second set of WM x WN waves takes every other tap of the staged filter slice and the two partial accumulator
+// sets are added through LDS before the epilogue -- two waves per SIMD for the launches that cannot fill the chip with
+// blocks (ConvLSTM2D's per-time-step recurrent convolutions: 128 blocks of 1600 MFMAs each, LDS latency exposed).
+template <int KS, int MT, int NT, int WM, int WN, int KSP = 1>
+__global__ void __launch_bounds__(64 * WM * WN * KSP, KSP > 2 ? 1 : 2) conv_igemm_kernel(const ConvParams a) {
     constexpr int TW = 16;
-    constexpr int NTHR = 64 * WM * WN;
+    constexpr int NTHR = 64 * WM * WN * KSP;
     constexpr int BM = WM * MT * 16;
     constexpr int TH = BM / TW;
     constexpr int BN = WN * NT * 16;
@@ -49,7 +52,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) % (WM * WN), ksl = (tid >> 6) / (WM * WN);      // ksl: which tap subset (KSP = 2)
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lq = lane >> 4;
 
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
             }
             __syncthreads();
             // ---- MFMA over the staged taps
-            for (int tl = 0; tl < ntap; ++tl) {
+            for (int tl = ksl; tl < ntap; tl += KSP) {
                 const int tap = tg + tl;
                 const int ky = tap / KS, kx = tap - ky * KS;
                 const float* ap = in_tile + (ky * TWH + kx) * P;
@@ -176,6 +179,26 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_igemm_kernel(const ConvP
         }
     }
 
+    if constexpr (KSP > 1) {
+        // add the second tap subset's accumulators (through the now idle tile memory), first subset runs the epilogue
+        __syncthreads();
+        constexpr int SET = WM * WN * 64 * MT * NT * 4;             // floats per accumulator set
+        float* red = smem + (size_t)(wave * 64 + lane) * (MT * NT * 4);
+        if (ksl >= 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(red + (size_t)(ksl - 1) * SET + (i * NT + j) * 4) = acc[i][j];
+        }
+        __syncthreads();
+        if (ksl != 0) return;
+#pragma unroll
+        for (int k = 0; k < KSP - 1; ++k)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(red + (size_t)k * SET + (i * NT + j) * 4);
+    }
     {
         AccPack<MT, NT> accp;
 #pragma unroll
@@ -494,13 +517,13 @@ bool try_launch_db(hipStream_t s, ConvParams& p, int N, size_t lds_limit) {
 }
 
 // --------------------------------------------------------------------------------------------
-template <int KS, int MT, int NT, int WM, int WN>
+template <int KS, int MT, int NT, int WM, int WN, int KSP = 1>
 void launch_fwd(hipStream_t s, ConvParams& p, int N) {
     constexpr int BM = WM * MT * 16, TH = BM / 16, BN = WN * NT * 16;
     constexpr int TWH = 16 + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
     constexpr int NP = (BN % 32 == 0) ? BN + 16 : BN;
     constexpr int KK = KS * KS;
-    auto kern = conv_igemm_kernel<KS, MT, NT, WM, WN>;
+    auto kern = conv_igemm_kernel<KS, MT, NT, WM, WN, KSP>;
     // pick the channel chunk CK (multiple of 4) and taps-per-stage under the LDS budget
     const int cin4 = (p.Cin + 3) & ~3;
     int CK = 0, TPS = 1;
@@ -521,7 +544,7 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
     p.TPS = TPS;
     p.tiles_x = cdiv(p.W, 16);
     p.tiles_y = cdiv(p.H, TH);
-    const size_t lds = bytes(CK, TPS);
+    const size_t lds = std::max(bytes(CK, TPS), KSP > 1 ? (size_t)(KSP - 1) * WM * WN * 64 * MT * NT * 4 * sizeof(float) : (size_t)0);
     static std::once_flag once;
     std::call_once(once, [&]() {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -551,7 +574,7 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
         q.bias = nullptr; q.add.p = nullptr; q.mask.p = nullptr; q.relu = 0; q.accumulate = 0;
         q.kchunks = cps;
         grid.z = (unsigned)S;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, q);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN * KSP), lds, s, q);
         HIP_CHECK(hipGetLastError());
         const size_t total = slab;
         hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, s, slabs, S,
@@ -559,7 +582,7 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
         HIP_CHECK(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN * KSP), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -610,7 +633,12 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
         case 96:  launch_fwd<KS, 4, 3, 2, 2>(s, p, N); break;   // 8x16 x 96
         case 48:  launch_fwd<KS, 4, 3, 4, 1>(s, p, N); break;   // 16x16 x 48
         case 32:  launch_fwd<KS, 4, 2, 4, 1>(s, p, N); break;   // 16x16 x 32
-        default:  launch_fwd<KS, 4, 1, 4, 1>(s, p, N); break;   // 16x16 x 16
+        default:                                                // 16x16 x 16; under-filled multi-tap launches: 2 waves/SIMD
+            if (KS > 1 && (long)cdiv(p.W, 16) * cdiv(p.H, 16) * N * cdiv(p.Cout, 16) < 256 && !getenv("DL4DS_NO_KSP"))
+                launch_fwd<KS, 4, 1, 4, 1, 2>(s, p, N);       // (four wave sets measured no better than two)
+            else
+                launch_fwd<KS, 4, 1, 4, 1>(s, p, N);
+            break;
     }
 }
 
