@@ -115,26 +115,34 @@ __global__ void __launch_bounds__(256) chatt_mlp_bwd_kernel(
     }
     __syncthreads();
     if (dw1 == nullptr) return;        // input gradient only (CGAN generator pass through the discriminator)
-    // dW1[c][j] = sum_inst mean[c]*dpre1[j] ; dW2[j][c] = sum_inst h[j]*dpre2[c]
-    for (int e = threadIdx.x; e < C * Cr; e += blockDim.x) {
-        const int c = e / Cr, j = e - c * Cr;
-        float a1 = 0.f, a2 = 0.f;
-        for (int inst = 0; inst < ninst; ++inst) {
-            a1 += mean[(size_t)inst * C + c] * dpre1[(size_t)inst * Cr + j];
-            a2 += hidden[(size_t)inst * Cr + j] * dpre2[(size_t)inst * C + c];
+    // dW1[c][j] = sum_inst mean[c]*dpre1[j] ; dW2[j][c] = sum_inst h[j]*dpre2[c] ; db1 = sum dpre1 ; db2 = sum dpre2.
+    // One wavefront per output element, lanes stride the instances (1024 of them in the 5-D form: the former
+    // one-thread-per-output loops took 0.14 ms), fixed shuffle tree.
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int nout = 2 * C * Cr + Cr + C;
+    for (int o = threadIdx.x >> 6; o < nout; o += nw) {
+        float a = 0.f;
+        float* dst;
+        if (o < C * Cr) {
+            const int c = o / Cr, j = o - c * Cr;
+            for (int inst = lane; inst < ninst; inst += 64) a += mean[(size_t)inst * C + c] * dpre1[(size_t)inst * Cr + j];
+            dst = dw1 + c * Cr + j;
+        } else if (o < 2 * C * Cr) {
+            const int e = o - C * Cr, c = e / Cr, j = e - c * Cr;
+            for (int inst = lane; inst < ninst; inst += 64) a += hidden[(size_t)inst * Cr + j] * dpre2[(size_t)inst * C + c];
+            dst = dw2 + j * C + c;
+        } else if (o < 2 * C * Cr + Cr) {
+            const int j = o - 2 * C * Cr;
+            for (int inst = lane; inst < ninst; inst += 64) a += dpre1[(size_t)inst * Cr + j];
+            dst = db1 + j;
+        } else {
+            const int c = o - 2 * C * Cr - Cr;
+            for (int inst = lane; inst < ninst; inst += 64) a += dpre2[(size_t)inst * C + c];
+            dst = db2 + c;
         }
-        dw1[c * Cr + j] = accumulate ? dw1[c * Cr + j] + a1 : a1;
-        dw2[j * C + c] = accumulate ? dw2[j * C + c] + a2 : a2;
-    }
-    for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
-        float a = 0.f;
-        for (int inst = 0; inst < ninst; ++inst) a += dpre1[(size_t)inst * Cr + j];
-        db1[j] = accumulate ? db1[j] + a : a;
-    }
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float a = 0.f;
-        for (int inst = 0; inst < ninst; ++inst) a += dpre2[(size_t)inst * C + c];
-        db2[c] = accumulate ? db2[c] + a : a;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (lane == 0) *dst = accumulate ? *dst + a : a;
     }
 }
 
