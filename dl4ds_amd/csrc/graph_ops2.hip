@@ -69,7 +69,9 @@ struct ConvLSTMOp : GOp {
         const GTensor& ti = g.tensors[in];
         TView xa = make_view(nullptr, B * T, ti.H, ti.W, ti.C), za = make_view(nullptr, B * T, ti.H, ti.W, 4 * F);
         TView hf = make_view(nullptr, B, ti.H, ti.W, F), zf = make_view(nullptr, B, ti.H, ti.W, 4 * F);
-        return std::max(conv2d_wgrad_workspace_bytes(xa, za, KS), conv2d_wgrad_workspace_bytes(hf, zf, KS));
+        TView ht = make_view(nullptr, std::max(T - 1, 1), ti.H, ti.W, F), zt = make_view(nullptr, std::max(T - 1, 1), ti.H, ti.W, 4 * F);
+        return std::max(conv2d_wgrad_workspace_bytes(xa, za, KS),
+                        std::max(conv2d_wgrad_workspace_bytes(hf, zf, KS), conv2d_wgrad_workspace_bytes(ht, zt, KS)));
     }
     struct Bufs { float *Z, *C, *H, *dZ, *dh, *dc; };
     Bufs bufs(Graph& g, int B) {
@@ -126,10 +128,24 @@ struct ConvLSTMOp : GOp {
             conv2d_wgrad(g.stream, g.view(in, B, false), dZall, KS, g.gp(wk), g.params[wk].grad_written, g.gp(b),
                          g.params[b].grad_written, g.workspace, g.workspace_bytes);
             g.params[wk].grad_written = g.params[b].grad_written = true;
-            for (int t = 1; t < T; ++t) {
-                conv2d_wgrad(g.stream, frame(g, bf.H, B, t - 1, F), frame(g, bf.dZ, B, t, 4 * F), KS, g.gp(wr),
-                             g.params[wr].grad_written, nullptr, 0, g.workspace, g.workspace_bytes);
-                g.params[wr].grad_written = true;
+            // recurrent kernel: sum over (sample, t >= 1) of wgrad(h_{t-1}, dZ_t).  The buffers are (B, T, ...): either one
+            // launch per time step over the B samples, or one per sample over its T-1 consecutive frame pairs --
+            // whichever needs fewer launches (these are 30 us kernels, the launch count is what matters)
+            if (B < T - 1) {
+                const size_t fs = hw(g);
+                for (int b = 0; b < B; ++b) {
+                    TView hx = make_view(bf.H + (size_t)b * T * fs * F, T - 1, ti.H, ti.W, F);
+                    TView dz = make_view(bf.dZ + ((size_t)b * T + 1) * fs * 4 * F, T - 1, ti.H, ti.W, 4 * F);
+                    conv2d_wgrad(g.stream, hx, dz, KS, g.gp(wr), g.params[wr].grad_written, nullptr, 0, g.workspace,
+                                 g.workspace_bytes);
+                    g.params[wr].grad_written = true;
+                }
+            } else {
+                for (int t = 1; t < T; ++t) {
+                    conv2d_wgrad(g.stream, frame(g, bf.H, B, t - 1, F), frame(g, bf.dZ, B, t, 4 * F), KS, g.gp(wr),
+                                 g.params[wr].grad_written, nullptr, 0, g.workspace, g.workspace_bytes);
+                    g.params[wr].grad_written = true;
+                }
             }
         }
         if (wants_grad(g, in, c)) {
