@@ -523,3 +523,38 @@ def test_global_average_pooling_in_graph(shape, over_time):
     d = 2.0 * (ref - yt.reshape(ref.shape).astype(np.float64)) / ref.size         # (n[, t], c)
     gw = (ref.reshape(-1, c).T @ d.reshape(-1, c)).reshape(1, 1, c, c)             # gap(x W) = mean(x) W
     close(grads['id/kernel'], gw, 1e-3)
+
+
+def _random_conv_case(i):
+    r = np.random.default_rng(9000 + i)
+    pick = lambda xs: xs[int(r.integers(len(xs)))]
+    ks = pick([1, 3, 3, 3, 5, 7])
+    n = int(pick([1, 2, 3]))
+    h, w = int(r.integers(3, 41)), int(r.integers(3, 41))
+    chans = [1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 40, 44, 48, 56, 64, 72, 96, 130]
+    ci, co = int(pick(chans)), int(pick(chans))
+    if ks >= 5:                      # keep the CPU oracle quick
+        ci, co = min(ci, 32), min(co, 48)
+    d2s = 2 if (ks == 3 and co % 4 == 0 and r.integers(4) == 0) else 0
+    return n, h, w, ci, co, ks, d2s
+
+
+@pytest.mark.parametrize('i', range(48))
+def test_conv2d_random_shapes(ops, i):
+    """48 seeded draws of (batch, grid, channels, kernel size, depth_to_space): forward with the fused epilogue (bias,
+    residual add where allowed, ReLU), dgrad with accumulation, wgrad -- whatever kernel the dispatcher picks (stencil,
+    narrow, pair, stream incl. zero-padded filters, LDS-staged fallback incl. split-K and the two-wave-set form)."""
+    n, h, w, ci, co, ks, d2s = _random_conv_case(i)
+    x, wt, b = R(n, h, w, ci), R(ks, ks, ci, co) * (0.5 / ks), R(co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    if d2s:
+        close(ops.conv2d(x, wt, b, relu=True, d2s=d2s), np.maximum(N.depth_to_space(ref, d2s), 0))
+        dz = R(n, h * d2s, w * d2s, co // (d2s * d2s))
+    else:
+        add = R(n, h, w, co)
+        close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+        dz = R(n, h, w, co)
+    gx, gw = _torch_conv_grads(x, wt, dz, d2s=d2s)
+    base = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, d2s=d2s, accumulate_into=base), gx + base)
+    close(ops.conv2d_wgrad(x, dz, ks, d2s=d2s), gw, 5e-4)
