@@ -32,7 +32,7 @@ DROPOUT_VARIANTS = ['vanilla', 'gaussian', 'spatial', 'mcdrop', 'mcgaussiandrop'
 def __getattr__(name):
     # lazy: importing the package must not need the GPU library (tests/test_abi.py runs on CPU)
     import importlib
-    lazy = {'SupervisedTrainer': '.training', 'CGANTrainer': '.training', 'Predictor': '.inference',
+    lazy = {'SupervisedTrainer': '.training', 'CGANTrainer': '.training', 'Predictor': '.inference', 'compute_metrics': '.metrics',
             'predict': '.inference', 'net_postupsampling': '.models', 'net_pin': '.models', 'unet_pin': '.models',
             'recnet_postupsampling': '.models', 'recnet_pin': '.models', 'residual_discriminator': '.models',
             'DataGenerator': '.dataloader', 'create_batch_hr_lr': '.dataloader', 'create_pair_hr_lr': '.dataloader'}

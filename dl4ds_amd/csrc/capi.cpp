@@ -388,6 +388,13 @@ int dl4ds_op_loss(int kind, const float* yt, const float* yp, float* dpred, int 
     loss_forward_backward(S(), kind, yt, yp, dpred, N, H, W, C, 1.f, loss_dev, 0, scratch(ws), ws);
     API_END
 }
+int dl4ds_metrics(const float* yt, const float* yp, int N, int H, int W, int C, float* pair_out_dev, float* grid_out_dev,
+                  float* range_out_dev) {
+    API_BEGIN
+    const size_t ws = metrics_workspace_bytes(N, H, W, C);
+    image_metrics(S(), yt, yp, N, H, W, C, pair_out_dev, grid_out_dev, range_out_dev, scratch(ws), ws);
+    API_END
+}
 int dl4ds_op_bce(const float* p, float label, int n, float* loss_dev, float* dp) {
     API_BEGIN
     bce_forward_backward(S(), p, label, n, 1.f, loss_dev, dp, 0);

@@ -723,3 +723,129 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
     hipLaunchKernelGGL(ms_finish_kernel, dim3(1), dim3(256), 0, s, part, nba, part2, COMPACT_G, st, dpred);
     HIP_CHECK(hipGetLastError());
 }
+
+// ============================================================================================ post-hoc image metrics
+// dl4ds/metrics.py:166-185,196-262 (compute_metrics) without the plotting: per test pair PSNR (tf.image.psnr with the
+// joint dynamic range), SSIM (tf.image.ssim, no min-shift here), MAE, RMSE and Pearson correlation over the grid; per grid
+// point RMSE, mean bias and Pearson correlation over the pairs.  Everything is a streaming pass over the two arrays:
+//   pair sums   : blocks of one pair reduce (|d|, d^2, x, y, xy, x^2, y^2) -> fixed-order partials -> one thread per pair;
+//   grid points : one thread per (pixel, channel) walks the pairs (coalesced across pixels);
+//   SSIM        : the tile kernel of the multi-scale loss at scale 0 (separable Gaussian moments) + its per-plane means.
+namespace {
+constexpr int MET_CHUNKS = 64, MET_K = 7;
+
+__global__ void __launch_bounds__(256) met_pair_partial_kernel(const float* __restrict__ t, const float* __restrict__ p, size_t per,
+                                                               float* __restrict__ partial) {
+    __shared__ double red[MET_K][256];
+    const int n = blockIdx.y;
+    const size_t chunk = (per + gridDim.x - 1) / gridDim.x;
+    const size_t e0 = (size_t)blockIdx.x * chunk, e1 = min(e0 + chunk, per);
+    const float* a = t + (size_t)n * per;
+    const float* b = p + (size_t)n * per;
+    double s[MET_K] = {0, 0, 0, 0, 0, 0, 0};
+    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const double x = a[e], y = b[e], d = y - x;
+        s[0] += fabs(d); s[1] += d * d; s[2] += x; s[3] += y; s[4] += x * y; s[5] += x * x; s[6] += y * y;
+    }
+    for (int k = 0; k < MET_K; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < MET_K; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < MET_K) partial[((size_t)n * gridDim.x + blockIdx.x) * MET_K + threadIdx.x] = (float)red[threadIdx.x][0];
+}
+// out[n] = (mae, mse, pearson over the grid)
+__global__ void met_pair_finish_kernel(const float* __restrict__ partial, int nchunks, int N, double per, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s[MET_K] = {0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < nchunks; ++c)
+        for (int k = 0; k < MET_K; ++k) s[k] += (double)partial[((size_t)n * nchunks + c) * MET_K + k];
+    const double mx = s[2] / per, my = s[3] / per;
+    const double cov = s[4] / per - mx * my, vx = s[5] / per - mx * mx, vy = s[6] / per - my * my;
+    out[n * 3 + 0] = (float)(s[0] / per);
+    out[n * 3 + 1] = (float)(s[1] / per);
+    out[n * 3 + 2] = (float)(cov / sqrt(fmax(vx * vy, 1e-300)));
+}
+// maps[0][e] = sqrt(mean_n d^2), maps[1][e] = mean_n d, maps[2][e] = pearson over the pairs
+__global__ void met_grid_kernel(const float* __restrict__ t, const float* __restrict__ p, int N, size_t per, float* __restrict__ maps) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
+        double sd = 0, sdd = 0, sx = 0, sy = 0, sxy = 0, sxx = 0, syy = 0;
+        for (int n = 0; n < N; ++n) {
+            const double x = t[(size_t)n * per + e], y = p[(size_t)n * per + e], d = y - x;
+            sd += d; sdd += d * d; sx += x; sy += y; sxy += x * y; sxx += x * x; syy += y * y;
+        }
+        const double nn = (double)N, mx = sx / nn, my = sy / nn;
+        const double cov = sxy / nn - mx * my, vx = sxx / nn - mx * mx, vy = syy / nn - my * my;
+        maps[e] = (float)sqrt(sdd / nn);
+        maps[per + e] = (float)(sd / nn);
+        maps[2 * per + e] = (vx > 0 && vy > 0) ? (float)(cov / sqrt(vx * vy)) : NAN;
+    }
+}
+__global__ void met_assemble_kernel(const float* __restrict__ pair3, const float* __restrict__ means, int N, int C, int has_ssim,
+                                    const Stats* __restrict__ st, float* __restrict__ out, float* __restrict__ range) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) {
+        range[0] = fminf(st->minT, st->minP);
+        range[1] = fmaxf(st->maxT, st->maxP);
+    }
+    if (n >= N) return;
+    float sm = 0.f;
+    for (int c = 0; c < C; ++c) sm += has_ssim ? means[n * C + c] : NAN;
+    out[n * 4 + 0] = pair3[n * 3 + 0];
+    out[n * 4 + 1] = pair3[n * 3 + 1];
+    out[n * 4 + 2] = pair3[n * 3 + 2];
+    out[n * 4 + 3] = sm / (float)C;
+}
+}  // namespace
+
+size_t metrics_workspace_bytes(int N, int H, int W, int C) {
+    const size_t per = (size_t)H * W * C;
+    const int Ho = H - KF + 1, Wo = W - KF + 1;
+    const size_t tiles = (Ho > 0 && Wo > 0) ? (size_t)N * C * cdiv(Ho, TS) * cdiv(Wo, TS) : 0;
+    return sizeof(Stats) + 256 + (size_t)512 * (4 * sizeof(float) + 2 * sizeof(unsigned long long)) + 256 +
+           ((size_t)N * MET_CHUNKS * MET_K + (size_t)N * 3 + 3 * per + tiles * 2 + (size_t)2 * N * C + 64) * sizeof(float);
+}
+
+// pair_out: [N][4] = (mae, mse, pearson, ssim)   grid_out: [3][H*W*C] = (rmse, mean bias, pearson)   stats_out: Stats
+void image_metrics(hipStream_t s, const float* y_true, const float* y_pred, int N, int H, int W, int C, float* pair_out_dev,
+                   float* grid_out_dev, float* range_out_dev, float* workspace, size_t workspace_bytes) {
+    DL4DS_REQUIRE(workspace_bytes >= metrics_workspace_bytes(N, H, W, C), "metrics workspace too small");
+    const size_t per = (size_t)H * W * C, n0 = per * N;
+    char* base = reinterpret_cast<char*>(workspace);
+    Stats* st = reinterpret_cast<Stats*>(base);
+    float* pf = reinterpret_cast<float*>(base + 256);
+    unsigned long long* pi = reinterpret_cast<unsigned long long*>(base + 256 + 512 * 4 * sizeof(float));
+    float* f = reinterpret_cast<float*>(base + 256 + 512 * (4 * sizeof(float) + 2 * sizeof(unsigned long long)) + 256);
+    float* partial = f;                                   f += (size_t)N * MET_CHUNKS * MET_K;
+    float* pair3 = f;                                     f += (size_t)N * 3;
+    float* tile_part = f;
+    static const Gauss gk = make_gauss();
+    ProfScope ps(s, "image_metrics", 0.0, 4.0 * (double)n0 * 6);
+    const int nb = (int)std::min<size_t>(512, cdivz(n0, 256));
+    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n0, pf, pi);
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
+    hipLaunchKernelGGL(met_pair_partial_kernel, dim3(MET_CHUNKS, N), dim3(256), 0, s, y_true, y_pred, per, partial);
+    hipLaunchKernelGGL(met_pair_finish_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, partial, MET_CHUNKS, N, (double)per, pair3);
+    hipLaunchKernelGGL(met_grid_kernel, dim3((unsigned)std::min<size_t>(cdivz(per, 256), 4096)), dim3(256), 0, s, y_true, y_pred, N,
+                       per, grid_out_dev);
+    // SSIM per pair = mean over channels of the per-plane mean SSIM (needs an 11x11 window)
+    const int Ho = H - KF + 1, Wo = W - KF + 1;
+    float* means = tile_part;           // set below when the window fits
+    const int NC = N * C;
+    if (Ho > 0 && Wo > 0) {
+        const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
+        means = tile_part + (size_t)NC * txo * tyo * 2;
+        hipLaunchKernelGGL(ms_ssim_kernel<0>, dim3(NC * txo * tyo), dim3(256), 0, s, y_true, y_pred, 0, H, W, C, Ho, Wo, txo, tyo, gk, st,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, tile_part);
+        hipLaunchKernelGGL(ms_means_kernel, dim3(NC), dim3(64), 0, s, tile_part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo), means,
+                           means + NC);
+    }
+    HIP_CHECK(hipGetLastError());
+    // assemble [N][4] and the range on the device (tiny)
+    hipLaunchKernelGGL(met_assemble_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, pair3, means, N, C, (Ho > 0 && Wo > 0) ? 1 : 0, st, pair_out_dev,
+                       range_out_dev);
+    HIP_CHECK(hipGetLastError());
+}

@@ -70,6 +70,11 @@ void dwconv_forward(hipStream_t s, const float* x, const float* k, const float* 
 size_t dwconv_wgrad_workspace_bytes(int C, int KS);
 void dwconv_wgrad(hipStream_t s, const float* x, const float* dy, float* dk, float* db, int accumulate, int N, int H, int W, int C,
                   int KS, float* ws, size_t ws_bytes);
+// post-hoc test metrics of dl4ds/metrics.py:166-262 (dssim.hip): pair_out [N][4] = (mae, mse, pearson over the grid, ssim),
+// grid_out [3][H*W*C] = (rmse, mean bias, pearson over the pairs), range_out [2] = joint (min, max)
+size_t metrics_workspace_bytes(int N, int H, int W, int C);
+void image_metrics(hipStream_t s, const float* y_true, const float* y_pred, int N, int H, int W, int C, float* pair_out_dev,
+                   float* grid_out_dev, float* range_out_dev, float* workspace, size_t workspace_bytes);
 // LayerNormalization / BatchNormalization over the channel axis of [npix][C] (norm.hip), optional fused ReLU
 size_t norm_workspace_bytes(int C);
 void layernorm_forward(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, size_t npix, int C,

@@ -119,6 +119,14 @@ int dl4ds_op_chatt_bwd(const float* x_dev, const float* dy_dev, float* dx_dev, i
  * loss_dev[0] = loss ; dpred_dev = dloss/dpred (may be NULL). */
 int dl4ds_op_loss(int kind, const float* y_true_dev, const float* y_pred_dev, float* dpred_dev, int N, int H,
                   int W, int C, float* loss_dev);
+/* compute_metrics (metrics.py:166-262) without the plots, on device-resident test arrays (N,H,W,C):
+ *   pair_out_dev  [N][4]       per test pair: MAE, MSE, Pearson correlation over the grid, SSIM (tf.image.ssim with the
+ *                              joint dynamic range; NaN when the grid is smaller than the 11x11 window).
+ *                              PSNR = 10 log10(range^2 / MSE) follows on the host (tf.image.psnr, metrics.py:168-169)
+ *   grid_out_dev  [3][H*W*C]   per grid point over the pairs: RMSE (metrics.py:188), mean bias (:219), Pearson (:247)
+ *   range_out_dev [2]          joint (min, max) of both arrays (metrics.py:166) */
+int dl4ds_metrics(const float* y_true_dev, const float* y_pred_dev, int N, int H, int W, int C, float* pair_out_dev,
+                  float* grid_out_dev, float* range_out_dev);
 /* Keras BinaryCrossentropy(from_logits=False) vs a constant label -- cgan.py:546-549,567-571 */
 int dl4ds_op_bce(const float* p_dev, float label, int n, float* loss_dev, float* dp_dev);
 /* tf.keras.optimizers.Adam step t (1-based) -- supervised.py:353; cgan.py:277-278 */

@@ -476,3 +476,26 @@ def piecewise_lr(step, boundary, lr0, lr1):
     """PiecewiseConstantDecay([boundary],[lr0,lr1]) (supervised.py:340-346):
     lr0 while step <= boundary else lr1; step = optimizer.iterations (0-based)."""
     return lr0 if step <= boundary else lr1
+
+
+def image_metrics(y, p):
+    """dl4ds/metrics.py:166-262 restated (TEST INFRASTRUCTURE): joint range, per-pair PSNR (tf.image.psnr), SSIM
+    (tf.image.ssim with max_val = range, no shift), MAE, RMSE, Pearson over the grid; per-grid-point RMSE, mean bias and
+    Pearson over the pairs."""
+    y = np.asarray(y, np.float64)
+    p = np.asarray(p, np.float64)
+    n = y.shape[0]
+    drange = max(y.max(), p.max()) - min(y.min(), p.min())
+    d = p - y
+    mse = (d ** 2).reshape(n, -1).mean(1)
+    out = dict(drange=drange, mse=mse, rmse=np.sqrt(mse), mae=np.abs(d).reshape(n, -1).mean(1),
+               psnr=20 * np.log10(drange) - 10 * np.log10(mse), ssim=ssim(y, p, drange))
+    yf, pf = y.reshape(n, -1), p.reshape(n, -1)
+    yc, pc = yf - yf.mean(1, keepdims=True), pf - pf.mean(1, keepdims=True)
+    out['pearson'] = (yc * pc).sum(1) / np.sqrt((yc ** 2).sum(1) * (pc ** 2).sum(1))
+    out['rmse_map'] = np.sqrt((d ** 2).mean(0))
+    out['bias_map'] = d.mean(0)
+    yc, pc = y - y.mean(0), p - p.mean(0)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        out['pearson_map'] = (yc * pc).sum(0) / np.sqrt((yc ** 2).sum(0) * (pc ** 2).sum(0))
+    return out

@@ -558,3 +558,29 @@ def test_conv2d_random_shapes(ops, i):
     base = R(*gx.shape)
     close(ops.conv2d_dgrad(dz, wt, d2s=d2s, accumulate_into=base), gx + base)
     close(ops.conv2d_wgrad(x, dz, ks, d2s=d2s), gw, 5e-4)
+
+
+@pytest.mark.parametrize('shape', [(5, 40, 36, 1), (3, 24, 50, 2), (4, 9, 8, 1)])
+def test_image_metrics(shape):
+    """compute_metrics' reductions (metrics.py:166-262) on the device vs the numpy restatement: PSNR / SSIM / MAE / RMSE /
+    Pearson per test pair, RMSE / bias / Pearson per grid point; a grid below the 11x11 SSIM window reports NaN there."""
+    from dl4ds_amd.metrics import image_metrics, compute_metrics
+    y = (R(*shape) * 2 + 1).astype(np.float32)
+    p = (y + 0.3 * R(*shape)).astype(np.float32)
+    m = image_metrics(y, p)
+    ref = N.image_metrics(y, p) if min(shape[1:3]) >= 11 else None
+    if ref is None:
+        assert np.isnan(m['ssim']).all()
+        d = p.astype(np.float64) - y
+        np.testing.assert_allclose(m['mae'], np.abs(d).reshape(shape[0], -1).mean(1), rtol=1e-5)
+        np.testing.assert_allclose(m['rmse_map'], np.sqrt((d ** 2).mean(0)), rtol=1e-5, atol=1e-7)
+        return
+    assert m['drange'] == pytest.approx(ref['drange'], rel=1e-6)
+    for k in ('mae', 'mse', 'rmse', 'psnr', 'pearson'):
+        np.testing.assert_allclose(m[k], ref[k], rtol=2e-5, err_msg=k)
+    np.testing.assert_allclose(m['ssim'], ref['ssim'], rtol=2e-4, err_msg='ssim')
+    for k in ('rmse_map', 'bias_map', 'pearson_map'):
+        np.testing.assert_allclose(m[k], ref[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    rmse_map, corr_map, nmb, full = compute_metrics(y, p, verbose=False)
+    assert rmse_map.shape == shape[1:] and full['summary']['PSNR'][0] == pytest.approx(ref['psnr'].mean(), rel=1e-5)
+    np.testing.assert_allclose(nmb, ref['bias_map'] / (y.mean() * 100), rtol=2e-4, atol=1e-8)
