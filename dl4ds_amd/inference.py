@@ -46,6 +46,9 @@ def predict(trainer, array, scale, array_in_hr=False, static_vars=None, predicto
                                   predictors=preds, interpolation=interpolation)
         inputs = x
     y = model.predict(inputs, batch_size=batch_size, verbose=0)
+    if y.ndim == 5 and time_window is not None:                  # inference.py:241-242
+        from .utils import spatiotemporal_to_spatial_samples
+        y = spatiotemporal_to_spatial_samples(y, time_window)
     if scaler is not None:
         y = scaler.inverse_transform(y)
     y = np.asarray(y, np.float32)

@@ -57,3 +57,20 @@ def checkarg_loss(loss):
 def not_on_hot_path(what):
     raise NotImplementedError(f'{what} is outside the MI355X hot path implemented by dl4ds_amd '
                               '(see DESIGN.md, "out of scope")')
+
+
+def spatial_to_spatiotemporal_samples(array, time_window):
+    """[n_samples, lat, lon, vars] -> [n_samples - time_window + 1, time_window, lat, lon, vars] (utils.py:20-29)."""
+    import numpy as np
+    n_samples = array.shape[0]
+    n_t = n_samples - (time_window - 1)
+    return np.stack([array[i:i + time_window] for i in range(n_t)]).astype(np.float64)
+
+
+def spatiotemporal_to_spatial_samples(array, time_window):
+    """Collapse the time-window axis of [n_samples, time_window, lat, lon, vars] back into a sequence of grids: the first
+    frame of every window, then the remaining frames of the last window (utils.py:32-45)."""
+    import numpy as np
+    if array.shape[1] != time_window:
+        raise ValueError('`time_window` must be located in the second position [n_samples, time_window, lat, lon, vars]')
+    return np.concatenate([array[:, 0], array[-1, 1:]], axis=0)

@@ -49,6 +49,10 @@ def test_supervised_trainer_spatiotemporal_pin():
     t.run()
     assert t.model.name == 'recresnet_pin' and t.model.output_shape == (3, 16, 16, 1)
     assert np.isfinite(t.fithist['loss']).all()
+    # Predictor on a spatio-temporal model: windows are collapsed back into a frame sequence (inference.py:241-242)
+    from dl4ds_amd.inference import Predictor
+    y = Predictor(t, te, scale=2, array_in_hr=True, time_window=3, batch_size=2).run()
+    assert y.ndim == 4 and y.shape[1:] == (16, 16, 1) and y.shape[0] == (te.shape[0] - 3) + 2 and np.isfinite(y).all()
 
 
 def test_cgan_trainer_runs():

@@ -94,3 +94,13 @@ def test_lr_schedule_plumbing():
     assert _lr_schedule((1e-3, 1e-4), 1e5) == (1e-3, 1e-4, 1e5)
     assert _lr_schedule(2e-4, 1e5)[:2] == (2e-4, 2e-4)
     assert _lr_schedule([5e-4], 10)[:2] == (5e-4, 5e-4)
+
+
+def test_spatiotemporal_sample_helpers_round_trip():
+    """utils.py:20-45: windows of consecutive frames and their collapse back into the frame sequence."""
+    a = np.arange(7 * 2 * 3 * 1, dtype=np.float64).reshape(7, 2, 3, 1)
+    w = U.spatial_to_spatiotemporal_samples(a, 3)
+    assert w.shape == (5, 3, 2, 3, 1) and np.array_equal(w[2, 1], a[3])
+    np.testing.assert_array_equal(U.spatiotemporal_to_spatial_samples(w, 3), a)
+    with pytest.raises(ValueError):
+        U.spatiotemporal_to_spatial_samples(w, 4)
