@@ -736,6 +736,32 @@ int dl4ds_trainer_set_state(dl4ds_trainer* tr, const float* m_host, const float*
     t.step = step;
     API_END
 }
+static Trainer& cgan_side(dl4ds_trainer* tr, int which) {
+    DL4DS_REQUIRE(tr && tr->c, "not a CGAN trainer");
+    DL4DS_REQUIRE(which == 0 || which == 1, "which: 0 generator, 1 discriminator");
+    return which == 0 ? *cgan_gen_trainer(tr->c) : *cgan_disc_trainer(tr->c);
+}
+int dl4ds_cgan_get_state(dl4ds_trainer* tr, int which, float* m_host, float* v_host, long* step) {
+    API_BEGIN
+    Trainer& t = cgan_side(tr, which);
+    const size_t bytes = t.g->n_params * sizeof(float);
+    if (m_host) HIP_CHECK(hipMemcpyAsync(m_host, t.m, bytes, hipMemcpyDeviceToHost, S()));
+    if (v_host) HIP_CHECK(hipMemcpyAsync(v_host, t.v, bytes, hipMemcpyDeviceToHost, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    if (step) *step = t.step;
+    API_END
+}
+int dl4ds_cgan_set_state(dl4ds_trainer* tr, int which, const float* m_host, const float* v_host, long step) {
+    API_BEGIN
+    Trainer& t = cgan_side(tr, which);
+    DL4DS_REQUIRE(m_host && v_host && step >= 0, "set_state: missing arrays / negative step");
+    const size_t bytes = t.g->n_params * sizeof(float);
+    HIP_CHECK(hipMemcpyAsync(t.m, m_host, bytes, hipMemcpyHostToDevice, S()));
+    HIP_CHECK(hipMemcpyAsync(t.v, v_host, bytes, hipMemcpyHostToDevice, S()));
+    HIP_CHECK(hipStreamSynchronize(S()));
+    t.step = step;
+    API_END
+}
 int dl4ds_trainer_last_loss(dl4ds_trainer* tr, float* loss_host) {
     API_BEGIN
     DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");

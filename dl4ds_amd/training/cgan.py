@@ -120,13 +120,26 @@ class CGANTrainer(Trainer):
                 first = False
                 for lst, v in zip((self.gentotal, self.gengan, self.genpxloss, self.disc), losses):
                     lst.append(v)
+            # cgan.py:370-377: a checkpoint (both models + both optimisers) and the generator's weights every
+            # `checkpoints_frequency` epochs, written by the first worker only
+            if self.checkpoints_frequency > 0 and self.running_on_first_worker and (epoch + 1) % self.checkpoints_frequency == 0:
+                self._save_checkpoint(epoch + 1)
             if self.verbose and self.running_on_first_worker and steps:
                 print(f'Epoch {epoch + 1}/{self.epochs} - gen_total {self.gentotal[-1]:.4f} gen_gan {self.gengan[-1]:.4f} '
                       f'gen_px {self.genpxloss[-1]:.4f} disc {self.disc[-1]:.4f}')
+        if self.checkpoints_frequency > 0 and self.running_on_first_worker:          # cgan.py:379-382: the last state
+            self._save_checkpoint(self.epochs)
         self.running_time = time.time() - t0
         if self.save_loss_history and self.save and self.running_on_first_worker:
             np.save(self.save_path + 'losses.npy', np.array([self.gentotal, self.gengan, self.genpxloss, self.disc]))
         self.save_results(self.generator, folder_prefix='cgan_')
         return self
+
+    def _save_checkpoint(self, epoch):
+        import os
+        d = os.path.join(getattr(self, 'savecheckpoint_path', None) or self.save_path or './', 'checkpoints')
+        os.makedirs(d, exist_ok=True)
+        self.engine.save_checkpoint(os.path.join(d, f'checkpoint_epoch-{epoch}.npz'))
+        np.savez(os.path.join(d, f'save_epoch{epoch}_generator_weights.npz'), **self.generator.get_weights())
 
     fit = run

@@ -182,6 +182,53 @@ class CGANEngine:
                                            None if mask is None else mask.ctypes.data, int(apply_update), out))
         return tuple(float(v) for v in out)
 
+    # --- optimiser state / checkpoints (tf.train.Checkpoint of both optimisers and both models, cgan.py:288-292,370-382)
+    def _arena(self, model):
+        n_arena, n_params = ctypes.c_size_t(), ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_param_count(model.graph.h, ctypes.byref(n_arena), ctypes.byref(n_params)))
+        spans = {}
+        for name, p in model.graph.params.items():
+            off, n = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(self._l.dl4ds_graph_param_info(model.graph.h, p['pid'], ctypes.byref(off), ctypes.byref(n)))
+            spans[name] = (off.value, n.value, p['shape'])
+        return n_arena.value, spans
+
+    def optimizer_state(self, which):
+        """(m, v, iterations) of the generator (``which='generator'``) or discriminator optimiser, by variable name."""
+        model = self.generator if which == 'generator' else self.discriminator
+        n, spans = self._arena(model)
+        m, v, step = np.empty(n, np.float32), np.empty(n, np.float32), ctypes.c_long()
+        _lib.check(self._l.dl4ds_cgan_get_state(self.h, 0 if which == 'generator' else 1, m.ctypes.data, v.ctypes.data,
+                                                ctypes.byref(step)))
+        return (OrderedDict((k, m[o:o + c].reshape(s)) for k, (o, c, s) in spans.items()),
+                OrderedDict((k, v[o:o + c].reshape(s)) for k, (o, c, s) in spans.items()), int(step.value))
+
+    def save_checkpoint(self, path):
+        blob = {}
+        for which, model in (('generator', self.generator), ('discriminator', self.discriminator)):
+            m, v, step = self.optimizer_state(which)
+            blob.update({f'{which}/w/{k}': a for k, a in model.get_weights().items()})
+            blob.update({f'{which}/m/{k}': a for k, a in m.items()})
+            blob.update({f'{which}/v/{k}': a for k, a in v.items()})
+            blob[f'{which}/step'] = np.int64(step)
+        np.savez(path, **blob)
+
+    def load_checkpoint(self, path):
+        """Restore a `save_checkpoint` file (same architectures) -- cgan.py:447-522 `load_checkpoint`."""
+        z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        for idx, (which, model) in enumerate((('generator', self.generator), ('discriminator', self.discriminator))):
+            names = list(model.get_weights().keys())
+            missing = [k for k in names if f'{which}/w/{k}' not in z]
+            if missing:
+                raise ValueError(f'checkpoint lacks {which} variables {missing[:3]}...')
+            model.set_weights({k: z[f'{which}/w/{k}'] for k in names})
+            n, spans = self._arena(model)
+            m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+            for k, (o, c, s) in spans.items():
+                m[o:o + c] = np.asarray(z[f'{which}/m/{k}'], np.float32).ravel()
+                v[o:o + c] = np.asarray(z[f'{which}/v/{k}'], np.float32).ravel()
+            _lib.check(self._l.dl4ds_cgan_set_state(self.h, idx, m.ctypes.data, v.ctypes.data, int(z[f'{which}/step'])))
+
     def step_device(self, input_ptrs, hr_ptr, batch, want_losses=False):
         ptrs = (ctypes.c_void_p * len(input_ptrs))(*input_ptrs)
         out = (ctypes.c_float * 4)()

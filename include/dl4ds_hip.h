@@ -237,6 +237,11 @@ int dl4ds_cgan_create(dl4ds_graph* gen, dl4ds_graph* disc, int px_loss_kind, flo
                       dl4ds_trainer** tr);
 int dl4ds_cgan_step(dl4ds_trainer* tr, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B,
                     int is_host, const float* dropout_keep_host, int apply_update, float* losses_host);
+/* Adam slots + optimizer.iterations of the generator (which = 0) / discriminator (which = 1) optimiser -- the contents of
+ * the reference's tf.train.Checkpoint(generator_optimizer, discriminator_optimizer, generator, discriminator)
+ * (cgan.py:288-292) and what load_checkpoint restores (cgan.py:447-522) */
+int dl4ds_cgan_get_state(dl4ds_trainer* tr, int which, float* m_host, float* v_host, long* step);
+int dl4ds_cgan_set_state(dl4ds_trainer* tr, int which, const float* m_host, const float* v_host, long step);
 int dl4ds_cgan_get_disc_grad(dl4ds_trainer* tr, int param_id, float* dst_host);
 
 /* ---------------------------------------------------------------- batch preparation (SURVEY section 8 "next" row f1)

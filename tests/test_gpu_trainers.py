@@ -207,3 +207,45 @@ def test_checkpoint_resume_continues_the_same_optimisation(tmp_path):
     for k, v in m_a.get_weights().items():
         np.testing.assert_array_equal(m_c.get_weights()[k], v, err_msg=k)
     assert e_c.optimizer_state()[2] == 6
+
+
+def test_cgan_checkpoint_resume_and_trainer_files(tmp_path):
+    """CGANEngine.save_checkpoint / load_checkpoint (both models, both Adam states; cgan.py:288-292,447-522): 2 + 2 steps
+    with a restore in between equal 4 uninterrupted steps bit for bit; CGANTrainer(checkpoints_frequency=1) writes the
+    per-epoch and final files (cgan.py:370-382)."""
+    import os
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import CGANEngine, CGANTrainer
+    rng = np.random.default_rng(0)
+    B, H = 2, 16
+    lr, st, hr = (rng.random((B, H, H, c)).astype(np.float32) for c in (2, 1, 1))
+    mask = (rng.random((2 * B, 8)) > 0.4).astype(np.float32)
+
+    def fresh():
+        gen = PM.unet_pin('unet', 2, 1, hr_size=(H, H), n_filters=4, n_blocks=2, decoder_upsampling='dc', seed=3)
+        disc = PM.residual_discriminator(2, 'pin', False, 8, (H // 8, H // 8), n_filters=4, n_res_blocks=1, hr_size=(H, H), seed=4)
+        return gen, disc, CGANEngine(gen, disc, loss='mae')
+
+    g_a, d_a, e_a = fresh()
+    ref = [e_a.step([lr, st], hr, dropout_keep=mask) for _ in range(4)]
+    g_b, d_b, e_b = fresh()
+    first = [e_b.step([lr, st], hr, dropout_keep=mask) for _ in range(2)]
+    e_b.save_checkpoint(str(tmp_path / 'ck.npz'))
+    g_c, d_c, e_c = fresh()
+    e_c.load_checkpoint(str(tmp_path / 'ck.npz'))
+    assert e_c.optimizer_state('generator')[2] == 2 and e_c.optimizer_state('discriminator')[2] == 2
+    rest = [e_c.step([lr, st], hr, dropout_keep=mask) for _ in range(2)]
+    assert first + rest == ref
+    for a, b in ((g_a, g_c), (d_a, d_c)):
+        wa, wb = a.get_weights(), b.get_weights()
+        for k in wa:
+            np.testing.assert_array_equal(wa[k], wb[k], err_msg=k)
+    tr, te = _fields(8, 32, 0), _fields(4, 32, 1)
+    topo = rng.random((32, 32)).astype(np.float32)
+    t = CGANTrainer('unet', 'pin', tr, te, static_vars=[topo], scale=4, batch_size=4, epochs=2, verbose=False,
+                    checkpoints_frequency=1, save_path=str(tmp_path) + '/',
+                    generator_params=dict(n_filters=4, n_blocks=2, decoder_upsampling='dc'),
+                    discriminator_params=dict(n_filters=4, n_res_blocks=1))
+    t.run()
+    files = sorted(os.listdir(tmp_path / 'checkpoints'))
+    assert 'checkpoint_epoch-1.npz' in files and 'checkpoint_epoch-2.npz' in files and 'save_epoch2_generator_weights.npz' in files
