@@ -35,7 +35,11 @@ def __getattr__(name):
     lazy = {'SupervisedTrainer': '.training', 'CGANTrainer': '.training', 'Predictor': '.inference', 'compute_metrics': '.metrics',
             'predict': '.inference', 'net_postupsampling': '.models', 'net_pin': '.models', 'unet_pin': '.models',
             'recnet_postupsampling': '.models', 'recnet_pin': '.models', 'residual_discriminator': '.models',
-            'DataGenerator': '.dataloader', 'create_batch_hr_lr': '.dataloader', 'create_pair_hr_lr': '.dataloader'}
+            'DataGenerator': '.dataloader', 'create_batch_hr_lr': '.dataloader', 'create_pair_hr_lr': '.dataloader',
+            'crop_array': '.dataloader', 'resize_array': '.dataloader', 'checkarray_ndim': '.dataloader',
+            'spatial_to_spatiotemporal_samples': '.utils', 'spatiotemporal_to_spatial_samples': '.utils',
+            'checkarg_backbone': '.utils', 'checkarg_upsampling': '.utils', 'checkarg_loss': '.utils',
+            'checkarg_dropout_variant': '.utils', 'check_compatibility_upsbackb': '.utils'}
     if name in lazy:
         return getattr(importlib.import_module(lazy[name], __name__), name)
     raise AttributeError(name)
