@@ -70,6 +70,31 @@ __global__ void __launch_bounds__(256) relu_mask_flat4_kernel(const float4* __re
     }
 }
 
+// dst (+)= dy * [y > 0] on contiguous tensors: the ReLU backward of an Add operand folded into the Add's gradient copy
+__global__ void __launch_bounds__(256) masked_axpy4_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                           float4* __restrict__ dst, size_t n4, int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        float4 g = dy[e];
+        const float4 m = y[e];
+        g.x = m.x > 0.f ? g.x : 0.f;
+        g.y = m.y > 0.f ? g.y : 0.f;
+        g.z = m.z > 0.f ? g.z : 0.f;
+        g.w = m.w > 0.f ? g.w : 0.f;
+        if (accumulate) {
+            const float4 o = dst[e];
+            g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+        }
+        dst[e] = g;
+    }
+}
+__global__ void masked_axpy1_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dst, size_t n,
+                                    int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float g = y[e] > 0.f ? dy[e] : 0.f;
+        dst[e] = accumulate ? dst[e] + g : g;
+    }
+}
+
 int bias_blocks(size_t npix, int TY) { return (int)std::min<size_t>(cdivz(npix, (size_t)TY * 8), 1024); }
 
 int pick_tx(int C) { return C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64)); }
@@ -381,6 +406,17 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
     } else {
         hipLaunchKernelGGL(view_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, dst, alpha, accumulate, total);
     }
+    HIP_CHECK(hipGetLastError());
+}
+
+void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate) {
+    if (n == 0) return;
+    ProfScope ps(s, "masked_axpy", 0.0, 4.0 * (double)n * (3 + (accumulate ? 1 : 0)));
+    if ((n & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dst)) & 15) == 0)
+        hipLaunchKernelGGL(masked_axpy4_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
+                           reinterpret_cast<const float4*>(y), reinterpret_cast<float4*>(dst), n / 4, accumulate);
+    else
+        hipLaunchKernelGGL(masked_axpy1_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, y, dst, n, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -21,7 +21,8 @@ struct GTensor {
     bool grad_written = false;
     // consumers: as the convolved input of a Conv2D / as anything else (residual operand, concat, pooling, ...)
     int n_conv_in = 0, n_other = 0;
-    // ReLU backward fused into the writers: every consumer is a Conv2D, whose dgrad epilogue zeroes the gradient
+    int n_add_in = 0;          // ... as an operand of an Add (which can apply the ReLU mask while copying its gradient)
+    // ReLU backward fused into the writers: every consumer is a Conv2D (or an Add), whose dgrad epilogue zeroes the gradient
     // where this activation is <= 0 (the mask is linear, so each accumulating writer applies it independently)
     bool grad_masked = false;
     size_t per_sample() const { return (size_t)nmul * H * W * C; }

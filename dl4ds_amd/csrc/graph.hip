@@ -227,7 +227,7 @@ struct ConvOp : GOp {
         GTensor& t = g.tensors[out];
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
-        t.grad_masked = relu && !is_output && t.n_conv_in >= 1 && t.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
+        t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_add_in) >= 1 && t.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
     }
     TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
         const GTensor& ti = g.tensors[in];
@@ -382,7 +382,15 @@ struct AddOp : GOp {
         }
         for (int t : {a, b}) {
             if (!wants_grad(g, t, c)) continue;
-            view_axpy(g.stream, dY, g.view(t, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[t].grad_written);
+            if (g.tensors[t].grad_masked) {
+                // the operand is a ReLU output whose mask its consumers apply: fold it into this copy
+                const size_t ps = g.tensors[t].per_sample();
+                const size_t off = (size_t)c.b_off * ps, n = (size_t)(c.b_cnt < 0 ? c.B : c.b_cnt) * ps;
+                masked_axpy(g.stream, g.tensors[out].grad + off, g.tensors[t].data + off, g.tensors[t].grad + off, n,
+                            g.tensors[t].grad_written);
+            } else {
+                view_axpy(g.stream, dY, g.view(t, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[t].grad_written);
+            }
             g.tensors[t].grad_written = true;
         }
     }
@@ -567,8 +575,8 @@ int g_add(Graph& g, int a, int b, int relu) {
     const int out = g.add_tensor(ta.H, ta.W, ta.C, ta.nmul, true, false);
     AddOp* op = push<AddOp>(g);
     op->a = a; op->b = b; op->out = out; op->relu = relu;
-    g.tensors[a].n_other++;
-    g.tensors[b].n_other++;
+    g.tensors[a].n_add_in++;
+    g.tensors[b].n_add_in++;
     return out;
 }
 

@@ -55,6 +55,8 @@ void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TVi
                        int accumulate_db, float* workspace, size_t workspace_bytes);
 // dst (+)= alpha * src  (same logical shape; either side may be a strided / d2s view)
 void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, int accumulate);
+// dst (+)= dy * [y > 0]  (flat, contiguous)
+void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate);
 // out = act(a + b)
 void add_act(hipStream_t s, const float* a, const float* b, float* out, size_t n, int relu);
 // in-place / out-of-place activation forward y = f(x) and backward dx (+)= dy * f'(x)
