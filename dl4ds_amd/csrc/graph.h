@@ -49,6 +49,7 @@ struct GOp {
     float* saved = nullptr;
     std::vector<int> pids;     // parameters this op reads (set by the op constructors; drives gradient bucketing)
     virtual void on_finalize(Graph& g) {}
+    virtual void on_prepare(Graph& g) {}      // after (re)allocation of the activation / gradient buffers
     virtual bool partial_batch_ok() const { return true; }   // backward over a sample sub-range (BwdCtx::b_off / b_cnt)
     virtual bool set_mask(Graph& g, const float* host, size_t n) { return false; }   // dropout keep-mask injection
     virtual size_t mask_floats(Graph& g, int B) { return 0; }                         // size of the mask of the last forward

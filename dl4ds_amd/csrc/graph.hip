@@ -135,6 +135,7 @@ void Graph::prepare(int B) {
     HIP_CHECK(hipMalloc((void**)&workspace, ws));
     if (aux_stream) HIP_CHECK(hipMalloc((void**)&aux_workspace, ws));
     maxB = B;
+    for (auto& op : ops) op->on_prepare(*this);
 }
 
 TView Graph::view(int tid, int B, bool grad, int b_off, int b_cnt) const {
@@ -218,8 +219,21 @@ inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
 struct ConvOp : GOp {
     int in, w, b, add, out, KS, Cout, relu, d2s;
     size_t wt_off = 0;
+    bool add_grad_shared = false;   // the residual operand's gradient IS this op's (masked) output gradient: no copy
     ConvOp() { kind = "conv2d"; }
+    void on_prepare(Graph& g) override {
+        if (add_grad_shared) g.tensors[add].grad = g.tensors[out].grad;
+    }
     void on_finalize(Graph& g) override {
+        // y = act(conv(x) + r): dL/dr = dZ.  When this add is r's only consumer (the 1x1-projected skip of a residual
+        // block) r's gradient buffer can simply be dZ's -- nothing writes it again before r's producer has read it
+        if (add >= 0 && d2s <= 1 && !getenv("DL4DS_NO_GRAD_SHARE")) {
+            const GTensor& r = g.tensors[add];
+            bool is_output = false;
+            for (int o : g.outputs) is_output |= (o == add);
+            add_grad_shared = !r.is_input && !is_output && r.requires_grad && r.n_conv_in == 0 && r.n_add_in == 0 &&
+                              r.n_other == 1 && r.per_sample() == g.tensors[out].per_sample();
+        }
         wt_off = g.reserve_wt(g.params[w].n);
         g.add_wt_job(g.params[w].offset, false, wt_off, KS * KS, g.tensors[in].C, Cout);
         // ReLU backward fused into the consumers' dgrad stores when every consumer is a Conv2D reading this tensor
@@ -257,7 +271,8 @@ struct ConvOp : GOp {
                               g.workspace_bytes);
         }
         if (add >= 0 && wants_grad(g, add, c)) {
-            view_axpy(g.stream, dY, g.view(add, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[add].grad_written);
+            if (!add_grad_shared)
+                view_axpy(g.stream, dY, g.view(add, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[add].grad_written);
             g.tensors[add].grad_written = true;
         }
         if (c.param_grads) {     // weight gradient; the bias gradient (column sums of dZ) rides along
