@@ -1,21 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark: HR samples/s of one full train step (forward + MAE + backward + [RCCL gradient
 all-reduce] + Keras-Adam) of dl4ds's 4x residual-backbone sub-pixel SR model at 128->512 grids
-(BASELINE.json configs[1]; configs[2] when launched on N GPUs).
+(BASELINE.json configs[1]; configs[2] when run on N GPUs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--config cfg2|cfg4|cfg5]
+
+`python bench.py --gpus N` (N > 1) starts the N ranks itself -- one process per GPU with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- and works just as well under a launcher that already did
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+--gpus N ...`).  Rank bring-up is dl4ds_amd.parallel.init_from_env (RCCL id over a TCP socket); barriers and the
+max-over-ranks time are RCCL collectives.  torch is imported only by the CPU baseline (the oracle) on rank 0 at N=1.
 
 One JSON line on rank 0.  Inputs are synthetic, resident in HBM before the timed
 region; weights are random-init (glorot) -- there is no dataset / checkpoint access.  fp32 throughout.
-torch is used ONLY for the multi-process rendezvous (gloo, CPU) and, on rank 0 at N=1, by the oracle that
-provides the CPU baseline; every GPU kernel is in libdl4ds_hip.so.
+`--config cfg4` / `cfg5` time BASELINE.json configs[3] / configs[4] at their full sizes on one GPU (secondary
+lines, same fields; the default and the driver's line is cfg2).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,28 +31,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-FWD_GFLOP_PER_SAMPLE = 18.336
-STEP_GFLOP_PER_SAMPLE = 55.0           # fwd + dgrad + wgrad of the graph AS THE REFERENCE EVALUATES IT (layer by layer)
-# The product composes spc.conv2x#2 (48 -> 4x48 at 256^2) with TransitionLast (1x1, 48 -> 8) into one 48 -> 4x8
-# convolution (csrc/graph_ops3.hip; DL4DS_NO_FOLD=1 disables it), which removes 27.2 of those 55 GFLOP per sample.
-# Utilisation figures below therefore use the FLOPs the kernels actually execute, taken from the library's profiler.
+PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E spec (about 6.3 TB/s is achievable)
+# the cfg2 graph AS THE REFERENCE EVALUATES IT (layer by layer) is 18.336 GFLOP forward and
+# 55.0 GFLOP per train step and sample.  The product composes spc.conv2x#2 (48 -> 4x48 at 256^2) with TransitionLast
+# (1x1, 48 -> 8) into one 48 -> 4x8 convolution (csrc/graph_ops3.hip; DL4DS_NO_FOLD=1 disables it), which removes 27.2
+# of those GFLOP.  Utilisation figures below use the FLOPs the kernels actually execute (library profiler).
+
+# tags (prefixes) of the kernels north_star calls memory-bound: upsampling / attention / stencil tail / losses / Adam
+HBM_KERNEL_PREFIXES = ('chatt', 'conv_direct', 'conv_narrow', 'resize', 'maxpool', 'localconv', 'pixel_loss', 'dssim',
+                       'msdssim', 'bce', 'adam', 'relu_mask', 'view_axpy', 'masked_axpy', 'add_act', 'act_', 'bias_act',
+                       'convlstm_gates', 'layernorm', 'batchnorm', 'gap', 'tail_')
+
+
+def box_blur_fields(rng, shape_bhw, channels=1):
+    """U[0,1) fields smoothed by a 5x5 box blur: (B,H,W,C) float64."""
+    b, h, w = shape_bhw
+    raw = rng.random((b, h + 4, w + 4, channels))
+    cs = np.pad(raw.cumsum(axis=1).cumsum(axis=2), ((0, 0), (1, 0), (1, 0), (0, 0)))
+    return (cs[:, 5:, 5:] - cs[:, :-5, 5:] - cs[:, 5:, :-5] + cs[:, :-5, :-5]) / 25.0
+
+
+def block_mean(a, s):
+    b, h, w, c = a.shape
+    return a.reshape(b, h // s, s, w // s, s, c).mean(axis=(2, 4))
 
 
 def synthetic_batch(seed, batch, hr=512, scale=4):
-    """HR y in U[0,1) box-blurred 5x5; LR x = scale x scale block mean."""
-    rng = np.random.default_rng(seed)
-    raw = rng.random((batch, hr + 4, hr + 4, 1))
-    cs = np.pad(raw.cumsum(axis=1).cumsum(axis=2), ((0, 0), (1, 0), (1, 0), (0, 0)))
-    y = (cs[:, 5:, 5:] - cs[:, :-5, 5:] - cs[:, 5:, :-5] + cs[:, :-5, :-5]) / 25.0
-    x = y.reshape(batch, hr // scale, scale, hr // scale, scale, 1).mean(axis=(2, 4))
-    return x.astype(np.float32), y.astype(np.float32)
+    """cfg2: HR y in U[0,1) box-blurred 5x5; LR x = scale x scale block mean."""
+    y = box_blur_fields(np.random.default_rng(seed), (batch, hr, hr))
+    return block_mean(y, scale).astype(np.float32), y.astype(np.float32)
 
 
 def cpu_baseline(weights, budget_s=25.0):
-    """The oracle (torch-CPU restatement of the identical graph, fp32, all host cores) timed on a bounded
-    sample of the same workload: B=2 at 128->512, 1 warm-up + up to 3 timed steps."""
+    """The oracle (torch-CPU restatement of the identical graph, fp32) timed on a bounded sample of the same workload:
+    B=4 at 128->512, thread count = fastest of 16/32/64, median of 3 steps after warm-up."""
     import torch
-    from oracle import torch_ops as T
+    from oracle import torch_ops as T  # noqa: F401
     from oracle import models as M
     from oracle import train as TR
     ncpu = os.cpu_count() or 1
@@ -82,9 +102,110 @@ def cpu_baseline(weights, budget_s=25.0):
     torch.set_num_threads(threads)
     times = [step() for _ in range(3)]
     dt = float(np.median(times))
-    return {'value': b / dt, 'unit': 'HR samples/s', 'cores': threads, 'kind': 'port',
+    return {'value': b / dt, 'unit': 'HR samples/s', 'cores': threads, 'cores_total': ncpu, 'kind': 'port',
             'sample': f'oracle torch-CPU (oneDNN) fp32 train step (fwd+MAE+bwd+Adam), B={b} at 128->512, median of '
-                      f'3 steps after warm-up; {threads} threads = fastest of 16/32/64 on a {ncpu}-thread host'}
+                      f'3 steps after warm-up; {threads} threads = fastest of 16/32/64 on a host with {ncpu} hardware '
+                      'threads (oneDNN gets slower beyond that on this graph)'}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def make_workload(name, B, rank, world):
+    """-> dict(step=callable, describe=str, engine=..., model=..., metric=str, cfg2=bool)."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.device import DeviceArray
+    from dl4ds_amd.training import SupervisedEngine, CGANEngine
+    if name == 'cfg2':
+        model = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (128, 128), seed=7)
+        eng = SupervisedEngine(model, loss='mae', learning_rate=(1e-3 * world, 1e-4 * world), lr_decay_after=1e5)
+        x, y = synthetic_batch(1002 + rank, B)
+        dx, dy = DeviceArray.from_numpy(x), DeviceArray.from_numpy(y)
+        return dict(step=lambda: eng.step_device([dx.ptr], dy.ptr, B), engine=eng, model=model, keep=(dx, dy),
+                    metric='HR samples/s (train step) at 4x 128->512 residual SR',
+                    describe=('configs[1]: net_postupsampling(resnet, spc, scale=4, lr 128x128 -> hr 512x512, 204405 '
+                              'params), MAE, Adam' if world == 1 else 'configs[2]: same model, data-parallel over RCCL'),
+                    loss=lambda: eng.last_loss())
+    if name == 'cfg4':
+        T, h, s = 8, 64, 4
+        model = PM.recnet_postupsampling('densenet', 'rc', s, 1, 1, (h, h), time_window=T, attention=True,
+                                         localcon_layer=True, seed=7)
+        eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3 * world)
+        rng = np.random.default_rng(1004 + rank)
+        y = np.stack([box_blur_fields(rng, (B, h * s, h * s)) for _ in range(T)], axis=1)          # (B,T,256,256,1)
+        x = np.stack([block_mean(y[:, t], s) for t in range(T)], axis=1)
+        aux = box_blur_fields(rng, (B, h * s, h * s))
+        dx, da, dy = (DeviceArray.from_numpy(a.astype(np.float32)) for a in (x, aux, y))
+        return dict(step=lambda: eng.step_device([dx.ptr, da.ptr], dy.ptr, B), engine=eng, model=model, keep=(dx, da, dy),
+                    metric='HR samples/s (train step), spatio-temporal dense + attention + LCB, resize-conv 4x, T=8, 64->256',
+                    describe=f'configs[3]: recnet_postupsampling(densenet, rc, scale=4, lr 64x64, T=8, attention, LCB, 1 aux; '
+                             f'{model.count_params()} params), MAE, Adam',
+                    loss=lambda: eng.last_loss())
+    if name == 'cfg5':
+        H = 512
+        gen = PM.unet_pin('unet', 5, 1, hr_size=(H, H), n_filters=8, n_blocks=6, decoder_upsampling='dc', seed=7)
+        disc = PM.residual_discriminator(5, 'pin', False, 8, (H // 8, H // 8), n_filters=8, hr_size=(H, H), seed=8)
+        eng = CGANEngine(gen, disc, loss='mae', learning_rate=(2e-4, 2e-4))
+        rng = np.random.default_rng(1005 + rank)
+        y = box_blur_fields(rng, (B, H, H))
+        f = box_blur_fields(rng, (B, H, H), channels=5)
+        x = np.repeat(np.repeat(block_mean(f, 8), 8, axis=1), 8, axis=2)            # 64^2 fields re-expanded ('pin')
+        aux = box_blur_fields(rng, (B, H, H))
+        dx, da, dy = (DeviceArray.from_numpy(a.astype(np.float32)) for a in (x, aux, y))
+        return dict(step=lambda: eng.step_device([dx.ptr, da.ptr], dy.ptr, B), engine=eng, model=gen, keep=(dx, da, dy),
+                    metric='HR samples/s (CGAN train step), U-Net(deconv) generator + residual discriminator, 8x 64->512',
+                    describe=f'configs[4]: unet_pin(unet, dc, 5+1 channels, hr 512x512; G {gen.count_params()} + '
+                             f'D {disc.count_params()} params), CGAN step (MAE x100 + BCE), 2 x Adam(2e-4, beta1 0.5)',
+                    loss=lambda: None)
+    raise SystemExit(f'unknown --config {name}')
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port_pair():
+    for _ in range(64):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        p = s.getsockname()[1]
+        s2 = socket.socket()
+        try:
+            s2.bind(('127.0.0.1', p + 1))
+        except OSError:
+            continue
+        finally:
+            s.close()
+            s2.close()
+        return p
+    raise RuntimeError('no free port pair found')
+
+
+def spawn_ranks(n, argv):
+    """One child per GPU (rank i -> LOCAL_RANK i); rank 0's stdout is this process's stdout (the JSON line)."""
+    import dl4ds_amd._lib as L
+    cnt = ctypes.c_int(0)
+    if L.load().dl4ds_device_count(ctypes.byref(cnt)) != 0 or cnt.value < n:
+        raise SystemExit(f'bench.py --gpus {n}: only {cnt.value} HIP device(s) visible')
+    port = _free_port_pair()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:              # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
 
 
 def main():
@@ -92,66 +213,60 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64,
-                    help='per-GPU batch (weak scaling); 64 = the reference default (training/supervised.py:49)')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='per-GPU batch (weak scaling); default 64 for cfg2 (the reference default, '
+                         'training/supervised.py:49) and 16 for cfg4 / cfg5 (training/cgan.py:48)')
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-unfolded', action='store_true', help='skip the 5-step comparison run of the unfolded graph')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
-        args.gpus = world
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
-    dist = None
-    force_dist = bool(os.environ.get('DL4DS_FORCE_DIST'))      # exercise the RCCL path even with one rank
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-
     import dl4ds_amd._lib as L
-    from dl4ds_amd.device import DeviceArray
-    import dl4ds_amd.models as PM
-    from dl4ds_amd.training import SupervisedEngine
     from dl4ds_amd import parallel
 
     lib = L.lib()                       # binds LOCAL_RANK -> device, fails loudly without a GPU
-    if dist is not None:
-        parallel.init_from_torch_distributed(dist, rank, world)
+    force_dist = bool(os.environ.get('DL4DS_FORCE_DIST'))      # exercise the RCCL path even with one rank
+    if world > 1:
+        parallel.init_from_env()
+    elif force_dist:
+        parallel.init_with_id(0, 1, parallel.unique_id())
+    comm = parallel.comm_info()
+    dist_on = comm['nranks'] > 0
 
-    B = args.batch
-    model = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (128, 128), seed=7)
-    eng = SupervisedEngine(model, loss='mae', learning_rate=(1e-3 * world, 1e-4 * world), lr_decay_after=1e5)
-    if dist is not None:
+    B = args.batch or (64 if args.config == 'cfg2' else 16)
+    wl = make_workload(args.config, B, rank, world)
+    eng, model, step = wl['engine'], wl['model'], wl['step']
+    if dist_on:
         parallel.broadcast_trainer(eng)
-    x, y = synthetic_batch(1002 + rank, B)
-    dx, dy = DeviceArray.from_numpy(x), DeviceArray.from_numpy(y)
-    w0 = model.get_weights() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    is_cfg2 = args.config == 'cfg2'
+    w0 = model.get_weights() if (rank == 0 and world == 1 and is_cfg2 and not args.no_cpu_baseline) else None
 
     def barrier():
         L.check(lib.dl4ds_sync())
-        if dist is not None:
-            dist.barrier()
+        if dist_on:
+            parallel.barrier()
 
     # ---- warm-up; on rank 0 its last steps are timed per launch (HIP events on the library stream) to find the kernel
-    #      with the largest share of step time and to provide the optional per-kernel breakdown
+    #      with the largest share of step time and to provide the per-kernel figures
     prof_on = rank == 0 and not args.no_profile
     nprof = min(3, args.warmup) if prof_on else 0
     if prof_on and nprof == 0:
         nprof = 2            # --warmup 0: two extra (untimed) steps are needed to pick the kernel to instrument
     for _ in range(max(args.warmup - nprof, 0)):
-        eng.step_device([dx.ptr], dy.ptr, B)
-    breakdown, dom = None, None
+        step()
+    breakdown, dom, dom_share = None, None, None
     executed_gflop_per_step = mfma_gflop_per_step = None
+    hbm_kernels = None
 
     def report():
-        buf = ctypes.create_string_buffer(1 << 16)
+        buf = ctypes.create_string_buffer(1 << 17)
         L.check(lib.dl4ds_profile_report(buf, len(buf)))
         return json.loads(buf.value.decode())
 
@@ -159,7 +274,7 @@ def main():
         L.check(lib.dl4ds_profile_filter(b''))
         L.check(lib.dl4ds_profile_enable(1))
         for _ in range(nprof):
-            eng.step_device([dx.ptr], dy.ptr, B)
+            step()
         rep = report()
         L.check(lib.dl4ds_profile_enable(0))
         tot = sum(v['ms'] for v in rep.values())
@@ -169,26 +284,32 @@ def main():
                      for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms'])}
         executed_gflop_per_step = sum(v['flops'] for v in rep.values()) / nprof / 1e9
         mfma_gflop_per_step = sum(v['flops'] for k, v in rep.items()
-                                  if k.startswith(('conv_stream', 'conv_wgrad', 'conv_igemm', 'conv_narrow'))) / nprof / 1e9
+                                  if k.startswith(('conv_stream', 'conv_wgrad', 'conv_igemm', 'conv_narrow', 'conv_pack'))
+                                  ) / nprof / 1e9
+        # memory-bound kernels (north_star: "achieved HBM GB/s for the memory-bound upsampling/attention kernels"):
+        # algorithmic bytes (one read of each input + one write of each output) / HIP-event duration, vs the 8 TB/s spec
+        hbm_kernels = {}
+        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms']):
+            if k.startswith(HBM_KERNEL_PREFIXES) and v['bytes'] > 0 and v['ms'] / nprof >= 0.02:
+                gbps = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+                hbm_kernels[k] = {'gbps': round(gbps, 1), 'frac_of_8TBps': round(gbps / PEAK_HBM_GBPS, 3),
+                                  'ms_per_step': round(v['ms'] / nprof, 4), 'launches_per_step': v['n'] / nprof}
         dom = max((k for k in rep if rep[k]['flops'] > 0), key=lambda k: rep[k]['ms'])
         dom_share = rep[dom]['ms'] / tot
         # ---- the dominant kernel alone stays instrumented during the timed region (two events per launch of that one
-        #      kernel: ~10 launches per 40 ms step)
+        #      kernel: a handful of launches per step)
         L.check(lib.dl4ds_profile_filter(dom.encode()))
         L.check(lib.dl4ds_profile_enable(1))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.step_device([dx.ptr], dy.ptr, B)
+        step()
     L.check(lib.dl4ds_sync())
     dt = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    loss = eng.last_loss()
+    if dist_on:
+        dt = parallel.allreduce_host([dt], 'max')[0]            # slowest rank
+    loss = wl['loss']()
 
     roofline = None
     if dom is not None:
@@ -197,15 +318,22 @@ def main():
         L.check(lib.dl4ds_profile_filter(b''))
         if d and d['n']:
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-            traffic = None
+            traffic, traffic_source = None, None
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get(dom)
+                    tj = json.load(open(tfile))
+                    traffic = tj.get(dom)
+                    if traffic is not None:
+                        traffic_source = ('profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                                          'command on an earlier run (' + str(tj.get('_round', 'r01')) + '), not measured in '
+                                          'this run')
                 except Exception:
                     traffic = None
             roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                        'traffic_source': traffic_source,
+                        'algorithmic_bytes_per_launch': d['bytes'] / d['n'],
                         'launches': d['n'], 'avg_launch_ms': d['ms'] / d['n'],
                         'algorithmic_gflop_per_launch': d['flops'] / d['n'] / 1e9,
                         'share_of_step_time': dom_share,
@@ -213,47 +341,43 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
+        ms_step = 1e3 * dt / args.steps
         out = {
-            'metric': 'HR samples/s (train step) at 4x 128->512 residual SR',
+            'metric': wl['metric'],
             'value': value, 'unit': 'HR samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: net_postupsampling(resnet, spc, scale=4, lr 128x128 -> hr 512x512, '
-                                   '204405 params), MAE, Adam' if world == 1 else
-                                   'configs[2]: same model, data-parallel over RCCL',
-                       'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'loss_after_run': loss},
-            # executed FLOPs (profiler, rank 0) over the measured step time; the reference formulation of the same
-            # step is 55 GFLOP per sample, i.e. 'reference_equivalent_tflops' is what an unfolded graph would need
-            'step_tflops_per_gpu': (executed_gflop_per_step / (1e3 * dt / args.steps)) if executed_gflop_per_step else None,
-            'mfma_conv_frac_of_peak': (mfma_gflop_per_step / (1e3 * dt / args.steps) / PEAK_FP32_MFMA_TFLOPS)
-                                      if mfma_gflop_per_step else None,
+            'config': {'workload': wl['describe'], 'per_gpu_batch': B, 'global_batch': B * world,
+                       'parallelism': f'dp{world}', 'loss_after_run': loss},
+            'rccl': {'nranks': comm['nranks'], 'launcher_world': world} if dist_on else None,
+            # executed FLOPs (library profiler, rank 0) over the measured step time
+            'step_tflops_per_gpu': (executed_gflop_per_step / ms_step) if executed_gflop_per_step else None,
+            'mfma_conv_frac_of_peak': (mfma_gflop_per_step / ms_step / PEAK_FP32_MFMA_TFLOPS) if mfma_gflop_per_step else None,
             'executed_gflop_per_sample': (executed_gflop_per_step / B) if executed_gflop_per_step else None,
-            'reference_equivalent_tflops': value / world * STEP_GFLOP_PER_SAMPLE / 1e3,
             'conv_folding': not bool(os.environ.get('DL4DS_NO_FOLD')),
             'roofline': roofline,
+            'hbm_kernels': hbm_kernels,
             'cpu_baseline': None,
         }
         if breakdown is not None and os.environ.get('DL4DS_BENCH_BREAKDOWN'):
             out['breakdown'] = breakdown
-        if world == 1 and not os.environ.get('DL4DS_NO_FOLD') and not args.no_unfolded:
+        if world == 1 and is_cfg2 and not os.environ.get('DL4DS_NO_FOLD') and not args.no_unfolded:
             # the same step with every layer evaluated separately (the reference's evaluation order, DL4DS_NO_FOLD=1),
             # measured in the same run so that both figures sit side by side; `value` above is the product path
             try:
                 os.environ['DL4DS_NO_FOLD'] = '1'
-                m2 = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (128, 128), seed=7)
-                e2 = SupervisedEngine(m2, loss='mae', learning_rate=(1e-3, 1e-4), lr_decay_after=1e5)
+                wl2 = make_workload('cfg2', B, rank, world)
                 for _ in range(2):
-                    e2.step_device([dx.ptr], dy.ptr, B)
+                    wl2['step']()
                 L.check(lib.dl4ds_sync())
                 t1 = time.perf_counter()
                 for _ in range(5):
-                    e2.step_device([dx.ptr], dy.ptr, B)
+                    wl2['step']()
                 L.check(lib.dl4ds_sync())
                 dt2 = (time.perf_counter() - t1) / 5
                 out['unfolded_graph'] = {'value': B / dt2, 'ms_per_step': 1e3 * dt2, 'steps': 5,
                                          'note': 'DL4DS_NO_FOLD=1: conv2x#2 and TransitionLast as two layers (55 GFLOP/sample)'}
-                del e2, m2
+                del wl2
             except Exception as e:
                 out['unfolded_graph'] = {'error': repr(e)}
             finally:
@@ -264,11 +388,10 @@ def main():
                 out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
             except Exception as e:          # the baseline must never kill the GPU number
                 out['cpu_baseline'] = {'error': repr(e)}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        parallel.barrier()
         parallel.finalize()
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

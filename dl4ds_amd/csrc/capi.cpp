@@ -24,6 +24,7 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
                const float* dropout_keep_host, bool apply_update, float* losses_host);
 Trainer* cgan_disc_trainer(CganTrainer* t);
 Trainer* cgan_gen_trainer(CganTrainer* t);
+void cgan_set_learning_rates(CganTrainer* t, float gen_lr, float disc_lr);
 
 namespace {
 thread_local std::string g_last_error;
@@ -778,6 +779,13 @@ int dl4ds_cgan_create(dl4ds_graph* gen, dl4ds_graph* disc, int px_loss_kind, flo
     *tr = h;
     API_END
 }
+int dl4ds_cgan_set_learning_rates(dl4ds_trainer* tr, float gen_lr, float disc_lr) {
+    API_BEGIN
+    DL4DS_REQUIRE(tr && tr->c, "not a CGAN trainer");
+    DL4DS_REQUIRE(gen_lr > 0.f && disc_lr > 0.f, "learning rates must be positive");
+    cgan_set_learning_rates(tr->c, gen_lr, disc_lr);
+    API_END
+}
 int dl4ds_cgan_step(dl4ds_trainer* tr, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B,
                     int is_host, const float* dropout_keep_host, int apply_update, float* losses_host) {
     API_BEGIN
@@ -813,6 +821,8 @@ int dl4ds_dist_world(int* rank, int* world) {
 }
 int dl4ds_dist_broadcast_trainer(dl4ds_trainer* tr, int root) {
     API_BEGIN
+    DL4DS_REQUIRE(tr, "broadcast_trainer: null trainer");
+    dist_require_ready("dl4ds_dist_broadcast_trainer");
     std::vector<Trainer*> ts;
     if (tr->t) ts.push_back(tr->t);
     if (tr->c) { ts.push_back(cgan_gen_trainer(tr->c)); ts.push_back(cgan_disc_trainer(tr->c)); }
@@ -822,6 +832,29 @@ int dl4ds_dist_broadcast_trainer(dl4ds_trainer* tr, int root) {
         dist_broadcast(t->v, t->g->n_params, root, S());
     }
     HIP_CHECK(hipStreamSynchronize(S()));
+    for (Trainer* t : ts) dist_broadcast_i64(&t->step, root);     // optimizer.iterations (a resumed rank 0)
+    API_END
+}
+int dl4ds_dist_expected_world(int* world) {
+    API_BEGIN
+    *world = dist_expected_world();
+    API_END
+}
+int dl4ds_dist_comm_info(int* nranks, int* rank, int* device) {
+    API_BEGIN
+    dist_comm_info(*nranks, *rank, *device);
+    API_END
+}
+int dl4ds_dist_allreduce_host(float* values_host, int n, int op) {
+    API_BEGIN
+    rt_ensure_init();
+    dist_allreduce_host(values_host, n, op);
+    API_END
+}
+int dl4ds_dist_barrier(void) {
+    API_BEGIN
+    rt_ensure_init();
+    dist_barrier();
     API_END
 }
 int dl4ds_dist_allreduce_sum(float* buf, size_t n) {

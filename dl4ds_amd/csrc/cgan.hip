@@ -58,12 +58,18 @@ void cgan_destroy(CganTrainer* t) {
 }
 Trainer* cgan_disc_trainer(CganTrainer* t) { return t->D; }
 Trainer* cgan_gen_trainer(CganTrainer* t) { return t->G; }
+// genlr, dislr = learning_rates (cgan.py:271-278): one Adam per model, each with its own rate
+void cgan_set_learning_rates(CganTrainer* t, float gen_lr, float disc_lr) {
+    t->G->cfg.lr0 = t->G->cfg.lr1 = gen_lr;
+    t->D->cfg.lr0 = t->D->cfg.lr1 = disc_lr;
+}
 
 void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B, bool is_host,
                const float* dropout_keep_host, bool apply_update, float* losses_host) {
     Graph& G = *t.G->g;
     Graph& D = *t.D->g;
     hipStream_t s = G.stream;
+    if (apply_update) dist_require_ready("dl4ds_cgan_step");   // WORLD_SIZE > 1 without a communicator is an error
     const GTensor& go = G.tensors[G.outputs[0]];
     const size_t hr_n = go.per_sample() * B;
     // ---- generator forward

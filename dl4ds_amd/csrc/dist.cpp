@@ -13,11 +13,14 @@
 #include "runtime.h"
 #include <rccl/rccl.h>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_world = 1;
 hipEvent_t g_ev_ready = nullptr, g_ev_ready_aux = nullptr, g_ev_done = nullptr;
+float* g_small = nullptr;            // device scratch of the host-side reductions
+constexpr int kSmallFloats = 1024;
 
 #define NCCL_CHECK(expr)                                                                         \
     do {                                                                                         \
@@ -88,7 +91,70 @@ void dist_broadcast(float* buf, size_t n, int root, hipStream_t stream) {
     NCCL_CHECK(ncclBroadcast(buf, buf, n, ncclFloat32, root, g_comm, stream));
 }
 
+int dist_expected_world() {
+    const char* allow = std::getenv("DL4DS_ALLOW_UNSYNCED");
+    if (allow && allow[0] && allow[0] != '0') return 1;
+    const char* w = std::getenv("WORLD_SIZE");
+    const int n = w ? std::atoi(w) : 1;
+    return n > 1 ? n : 1;
+}
+
+void dist_require_ready(const char* what) {
+    const int expect = dist_expected_world();
+    if (g_comm != nullptr) {
+        if (expect > 1 && expect != g_world)
+            throw Dl4dsError(std::string(what) + ": the launcher started WORLD_SIZE=" + std::to_string(expect) +
+                             " ranks but the RCCL communicator has " + std::to_string(g_world));
+        return;
+    }
+    if (expect > 1)
+        throw Dl4dsError(std::string(what) + ": this process is rank " + (std::getenv("RANK") ? std::getenv("RANK") : "?") +
+                         " of WORLD_SIZE=" + std::to_string(expect) +
+                         " but no RCCL communicator exists (dl4ds_dist_init / dl4ds_amd.parallel.init_from_env was not "
+                         "called): refusing to train an unsynchronised replica.  Set DL4DS_ALLOW_UNSYNCED=1 to run "
+                         "independent replicas on purpose.");
+}
+
+void dist_allreduce_host(float* host, int n, int op) {
+    if (g_comm == nullptr || n <= 0) return;
+    DL4DS_REQUIRE(n <= kSmallFloats, "dist_allreduce_host: at most 1024 values");
+    DL4DS_REQUIRE(op >= 0 && op <= 2, "dist_allreduce_host: op must be 0 (sum), 1 (max) or 2 (min)");
+    hipStream_t s = rt().stream;
+    if (!g_small) HIP_CHECK(hipMalloc((void**)&g_small, kSmallFloats * sizeof(float)));
+    HIP_CHECK(hipMemcpyAsync(g_small, host, n * sizeof(float), hipMemcpyHostToDevice, s));
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+    NCCL_CHECK(ncclAllReduce(g_small, g_small, n, ncclFloat32, ops[op], g_comm, s));
+    HIP_CHECK(hipMemcpyAsync(host, g_small, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void dist_barrier() {
+    HIP_CHECK(hipStreamSynchronize(rt().stream));
+    float one = 1.f;
+    dist_allreduce_host(&one, 1, 0);
+}
+
+void dist_comm_info(int& nranks, int& rank, int& device) {
+    nranks = 0; rank = 0; device = -1;
+    if (g_comm == nullptr) return;
+    NCCL_CHECK(ncclCommCount(g_comm, &nranks));
+    NCCL_CHECK(ncclCommUserRank(g_comm, &rank));
+    NCCL_CHECK(ncclCommCuDevice(g_comm, &device));
+}
+
+void dist_broadcast_i64(long* host_value, int root) {
+    if (g_comm == nullptr) return;
+    static_assert(sizeof(long) == 8, "long is 64-bit on this platform");
+    hipStream_t s = rt().stream;
+    if (!g_small) HIP_CHECK(hipMalloc((void**)&g_small, kSmallFloats * sizeof(float)));
+    HIP_CHECK(hipMemcpyAsync(g_small, host_value, 8, hipMemcpyHostToDevice, s));
+    NCCL_CHECK(ncclBroadcast(g_small, g_small, 1, ncclInt64, root, g_comm, s));
+    HIP_CHECK(hipMemcpyAsync(host_value, g_small, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
 void dist_finalize() {
+    if (g_small) { (void)hipFree(g_small); g_small = nullptr; }
     if (g_comm) {
         (void)ncclCommDestroy(g_comm);
         g_comm = nullptr;

@@ -456,6 +456,7 @@ void space_to_depth(hipStream_t s, const float* y, float* x, int N, int H, int W
 void maxpool2_forward(hipStream_t s, const TView& x, const TView& y) {
     DL4DS_REQUIRE(y.H == x.H / 2 && y.W == x.W / 2 && y.C == x.C && y.N == x.N, "maxpool2: shapes");
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    ProfScope ps(s, "maxpool2_fwd", 0.0, 4.0 * (double)total * 5);
     hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, total);
     HIP_CHECK(hipGetLastError());
 }
@@ -463,18 +464,21 @@ void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TVie
     DL4DS_REQUIRE((x.H % 2 == 0 && x.W % 2 == 0) || accumulate,
                   "maxpool2 backward with odd sizes needs a pre-zeroed accumulate target");
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    ProfScope ps(s, "maxpool2_bwd", 0.0, 4.0 * (double)total * (2 + 4 + 4 + (accumulate ? 4 : 0)));
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, dy, dx, accumulate, total);
     HIP_CHECK(hipGetLastError());
 }
 
 void resize_bilinear_forward(hipStream_t s, const TView& x, const TView& y) {
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    ProfScope ps(s, "resize_bilinear_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
     hipLaunchKernelGGL(resize_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
                        (float)x.W / (float)y.W, total);
     HIP_CHECK(hipGetLastError());
 }
 void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate) {
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
+    ProfScope ps(s, "resize_bilinear_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
     hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
                        (float)dx.W / (float)dy.W, accumulate, total);
     HIP_CHECK(hipGetLastError());
@@ -482,12 +486,14 @@ void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, i
 
 void resize_nearest_forward(hipStream_t s, const TView& x, const TView& y) {
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    ProfScope ps(s, "resize_nearest_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
     hipLaunchKernelGGL(resize_nearest_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
                        (float)x.W / (float)y.W, total);
     HIP_CHECK(hipGetLastError());
 }
 void resize_nearest_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate) {
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
+    ProfScope ps(s, "resize_nearest_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
     hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
                        (float)dx.W / (float)dy.W, accumulate, total);
     HIP_CHECK(hipGetLastError());
@@ -496,6 +502,7 @@ void resize_nearest_backward(hipStream_t s, const TView& dy, const TView& dx, in
 void localconv_forward(hipStream_t s, const TView& x, const float* w, const float* b, const TView& y) {
     DL4DS_REQUIRE(x.C <= kLcMax && y.C <= kLcMax, "localconv: at most 8 channels in/out");
     const size_t npix = (size_t)x.N * x.H * x.W;
+    ProfScope ps(s, "localconv_fwd", 2.0 * npix * x.C * y.C, 4.0 * ((double)npix * (x.C + y.C) + (double)x.H * x.W * (x.C + 1) * y.C));
     hipLaunchKernelGGL(localconv_fwd_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, w, b, y, npix);
     HIP_CHECK(hipGetLastError());
 }
@@ -503,6 +510,8 @@ void localconv_backward(hipStream_t s, const TView& x, const float* w, const TVi
                         int accumulate_dx, float* dw, float* db, int accumulate_dw) {
     DL4DS_REQUIRE(x.C <= kLcMax && dy.C <= kLcMax, "localconv: at most 8 channels in/out");
     const size_t nhw = (size_t)x.H * x.W;
+    ProfScope ps(s, "localconv_bwd", 4.0 * nhw * x.N * x.C * dy.C,
+                 4.0 * ((double)nhw * x.N * (2 * x.C + dy.C) + 2.0 * (double)nhw * (x.C + 1) * dy.C));
     hipLaunchKernelGGL(localconv_bwd_kernel, dim3(ew_blocks(nhw)), dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db,
                        accumulate_dw);
     HIP_CHECK(hipGetLastError());

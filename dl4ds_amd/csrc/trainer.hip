@@ -131,6 +131,7 @@ void trainer_apply_adam(Trainer& t) {
 void trainer_step(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host,
                   float* loss_host) {
     Graph& g = *t.g;
+    dist_require_ready("dl4ds_trainer_step");               // WORLD_SIZE > 1 without a communicator is an error, not a no-op
     trainer_loss_and_grads(t, inputs, n_inputs, y_true, B, is_host, true);
     dist_allreduce_wait(g.stream);                          // buckets were launched during the backward pass
     trainer_apply_adam(t);

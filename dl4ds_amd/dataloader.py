@@ -12,6 +12,15 @@ import numpy as np
 from . import POSTUPSAMPLING_METHODS, INTERPOLATION_METHODS
 
 
+def equal_shard(perm, rank, world):
+    """perm[rank::world] after dropping the n % world remainder (same rule as dl4ds_amd.parallel.equal_shard; repeated
+    here so the host loader does not import the GPU binding)."""
+    if world <= 1:
+        return perm
+    n = (len(perm) // world) * world
+    return perm[:n][rank::world]
+
+
 def checkarray_ndim(array, ndim=3, add_axis_position=-1):
     """utils.py:46-55."""
     if array.ndim < ndim:
@@ -184,7 +193,9 @@ class DataGenerator:
         self.n = self.array.shape[0] - self.time_window if self.time_window is not None else self.array.shape[0]
         self.rng = np.random.default_rng(seed)
         perm = self.rng.permutation(self.n)
-        self.indices = perm[rank::world] if world > 1 else perm      # rank-strided shard of one seeded permutation
+        # rank-strided shard of one seeded permutation, the same length on every rank (unequal step counts would leave
+        # ranks waiting in the gradient all-reduce)
+        self.indices = equal_shard(perm, rank, world)
         if self.repeat is not None and isinstance(self.repeat, int):
             self.indices = np.hstack([self.indices for _ in range(self.repeat)])
         if patch_size is not None and upsampling in POSTUPSAMPLING_METHODS and patch_size % scale != 0:
@@ -250,7 +261,7 @@ class DeviceDataGenerator:
         self.n = self.N - self.T if self.spt else self.N
         self.rng = np.random.default_rng(seed)
         perm = self.rng.permutation(self.n)
-        self.indices = perm[rank::world] if world > 1 else perm
+        self.indices = equal_shard(perm, rank, world)
         if repeat is not None and isinstance(repeat, int):
             self.indices = np.hstack([self.indices for _ in range(repeat)])
         self.psy, self.psx = (self.H, self.W) if patch_size is None else (int(patch_size), int(patch_size))

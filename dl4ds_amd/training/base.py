@@ -39,8 +39,16 @@ class Trainer(ABC):
         self.show_plot = show_plot
         if device != 'GPU':
             raise ValueError("device not recognized: dl4ds_amd runs on MI355X only (device='GPU'); there is no CPU path")
-        # one process per GPU (replaces hvd.init / set_visible_gpus(hvd.local_rank()))
+        # one process per GPU.  hvd.init() + set_visible_gpus(hvd.local_rank()) (base.py:97-107): bind LOCAL_RANK's GPU and
+        # bring the RCCL communicator up HERE, as the reference does -- a process launched as one of WORLD_SIZE ranks never
+        # trains without it (the library refuses the step, csrc/dist.cpp::dist_require_ready)
         self.rank, self.world, self.local_rank = parallel.rank_world_from_env()
+        if self.world > 1 and not os.environ.get('DL4DS_ALLOW_UNSYNCED'):
+            r, w = parallel.init_from_env()
+            if (r, w) != (self.rank, self.world):
+                raise RuntimeError(f'RCCL communicator is rank {r}/{w}, launcher says {self.rank}/{self.world}')
+        elif self.world > 1:
+            self.rank, self.world = 0, 1            # independent replicas on purpose: behave as a single process
         n_devices = 1           # per process; the reference's list_physical_devices quirk (base.py:108-116) is not kept
         self.global_batch_size = self.batch_size * n_devices
         self.running_on_first_worker = self.rank == 0

@@ -76,8 +76,9 @@ class CGANTrainer(Trainer):
         """cgan.py:264-444: epoch/step loop around train_step."""
         t0 = time.time()
         self.setup_model()
+        # genlr, dislr = learning_rates; a float / 1-tuple sets both (cgan.py:271-278)
         self.engine = CGANEngine(self.generator, self.discriminator, loss=self.lossf,
-                                 learning_rate=self.learning_rates[0], beta_1=0.5)
+                                 learning_rate=self.learning_rates, beta_1=0.5)
         n_samples = self.data_train.shape[0] - (self.time_window or 0)
         if self.steps_per_epoch is None:
             self.steps_per_epoch = n_samples // self.batch_size
@@ -129,11 +130,44 @@ class CGANTrainer(Trainer):
                       f'gen_px {self.genpxloss[-1]:.4f} disc {self.disc[-1]:.4f}')
         if self.checkpoints_frequency > 0 and self.running_on_first_worker:          # cgan.py:379-382: the last state
             self._save_checkpoint(self.epochs)
+        self._test_loss()
         self.running_time = time.time() - t0
         if self.save_loss_history and self.save and self.running_on_first_worker:
             np.save(self.save_path + 'losses.npy', np.array([self.gentotal, self.gengan, self.genpxloss, self.disc]))
         self.save_results(self.generator, folder_prefix='cgan_')
         return self
+
+    def _test_loss(self, max_batch=None):
+        """cgan.py:386-440: pixel loss of generator.predict on the whole test set, on the first worker only (no
+        collective is involved, so the other ranks simply skip it).  The reference builds ONE batch of n_test samples;
+        here the same samples go through the generator in chunks of `batch_size` and the per-chunk losses are averaged
+        with their sample counts (identical for the mean-type pixel losses; for the DSSIM family, whose dynamic range is
+        taken over the batch, it is the mean of per-chunk values)."""
+        if self.data_test is None or not self.running_on_first_worker:
+            return
+        data_test = np.asarray(getattr(self.data_test, 'values', self.data_test))
+        data_test_lr = None if self.data_test_lr is None else np.asarray(getattr(self.data_test_lr, 'values', self.data_test_lr))
+        preds = None if self.predictors_test is None else np.concatenate(self.predictors_test, axis=-1)
+        n_test = data_test.shape[0] - (self.time_window or 0)
+        if n_test <= 0:
+            return
+        rng = np.random.default_rng(23)
+        idx = rng.permutation(n_test)
+        from .engine import SupervisedEngine
+        ev = SupervisedEngine(self.generator, loss=self.lossf, learning_rate=1e-3)     # evaluate() only: no update is made
+        bs = int(max_batch or self.batch_size)
+        tot, cnt = 0.0, 0
+        for i in range(0, n_test, bs):
+            chunk = idx[i:i + bs]
+            (lr_array, aux_hr), (hr_array,) = create_batch_hr_lr(
+                chunk, 0, data_test, data_test_lr, upsampling=self.upsampling, scale=self.scale, batch_size=len(chunk),
+                patch_size=self.patch_size, time_window=self.time_window, static_vars=self.static_vars, predictors=preds,
+                interpolation=self.interpolation, rng=rng)
+            tot += ev.evaluate([lr_array, aux_hr], hr_array) * len(chunk)
+            cnt += len(chunk)
+        self.test_loss = tot / cnt
+        if self.verbose:
+            print(f'\n{self.lossf} on the test set: {self.test_loss}')
 
     def _save_checkpoint(self, epoch):
         import os

@@ -142,21 +142,36 @@ class SupervisedEngine:
         return out_m, out_v, int(step.value)
 
 
+def cgan_learning_rates(learning_rates):
+    """cgan.py:271-278: ``genlr, dislr = learning_rates`` for a pair; a float or a 1-tuple sets both."""
+    if isinstance(learning_rates, (tuple, list)) and len(learning_rates) > 1:
+        if len(learning_rates) != 2:
+            raise ValueError('`learning_rates` must be a float or a (generator, discriminator) pair')
+        genlr, dislr = learning_rates
+    elif isinstance(learning_rates, (tuple, list)) and len(learning_rates) == 1:
+        genlr = dislr = learning_rates[0]
+    elif isinstance(learning_rates, (int, float, np.floating)):
+        genlr = dislr = learning_rates
+    else:
+        raise TypeError('`learning_rates` must be a float or a tuple/list of one or two floats')
+    return float(genlr), float(dislr)
+
+
 class CGANEngine:
     """train_step of the CGAN trainer (cgan.py:575-639): one simultaneous generator + discriminator update."""
 
     def __init__(self, generator, discriminator, loss='mae', learning_rate=2e-4, beta_1=0.5, lambda_scaling_factor=100.0):
         if loss not in LOSS_KINDS:
             raise ValueError(f'loss {loss!r} not available on the MI355X path; one of {sorted(LOSS_KINDS)}')
-        if isinstance(learning_rate, (tuple, list)):
-            learning_rate = learning_rate[0]
+        genlr, dislr = cgan_learning_rates(learning_rate)
         self.generator, self.discriminator = generator, discriminator
+        self.learning_rates = (genlr, dislr)
         self._l = _lib.lib()
         h = ctypes.c_void_p()
         _lib.check(self._l.dl4ds_cgan_create(generator.graph.h, discriminator.graph.h, LOSS_KINDS[loss],
-                                             float(learning_rate), float(beta_1), float(lambda_scaling_factor),
-                                             ctypes.byref(h)))
+                                             genlr, float(beta_1), float(lambda_scaling_factor), ctypes.byref(h)))
         self.h = h
+        _lib.check(self._l.dl4ds_cgan_set_learning_rates(self.h, genlr, dislr))
 
     def __del__(self):
         try:

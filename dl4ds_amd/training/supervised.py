@@ -94,6 +94,10 @@ class SupervisedTrainer(Trainer):
             self.model.summary(line_length=150)
 
     def _epoch_loss(self, ds, steps, train):
+        """Mean loss over the epoch's batches.  Data parallel: every rank walks the same number of batches of its own
+        shard (dataloader.equal_shard) and the epoch mean is averaged over the ranks (one RCCL all-reduce of two floats),
+        so that early stopping and the reported val/test losses are the same everywhere -- ranks deciding on their own
+        shard's val_loss would leave the epoch loop at different epochs and strand the others in the all-reduce."""
         n = len(ds) if steps is None else min(int(steps), len(ds))
         tot = 0.0
         for i in range(n):
@@ -104,6 +108,9 @@ class SupervisedTrainer(Trainer):
                         else self.engine.evaluate_device(ptrs, y[0].ptr, b))
             else:
                 tot += self.engine.step(x, y[0]) if train else self.engine.evaluate(x, y[0])
+        if self.world > 1:
+            tot, cnt = parallel.allreduce_host([tot, float(n)], 'sum')
+            return tot / max(cnt, 1.0), n
         return tot / max(n, 1), n
 
     def run(self):
@@ -138,18 +145,30 @@ class SupervisedTrainer(Trainer):
             hist['val_loss'].append(vl)
             if self.verbose and self.running_on_first_worker:
                 print(f'Epoch {epoch + 1}/{self.epochs} - {n} steps - loss: {tl:.6f} - val_loss: {vl:.6f}')
-            if self.early_stopping:
+            # ModelCheckpoint(savecheckpoint_path/best_model, monitor='val_loss', save_best_only=False), first worker only
+            # (supervised.py:379-390): with save_best_only=False Keras rewrites the file at the end of EVERY epoch; the
+            # native format is the named-weights .npz + optimiser state of SupervisedEngine.save_checkpoint
+            if self.save_bestmodel and self.running_on_first_worker:
+                d = os.path.join(self.savecheckpoint_path, 'best_model')
+                os.makedirs(d, exist_ok=True)
+                self.engine.save_checkpoint(os.path.join(d, 'checkpoint.npz'))
+                np.savez(os.path.join(d, 'model_weights.npz'), **self.model.get_weights())
+                np.savetxt(os.path.join(d, 'epoch_val_loss.txt'), [epoch + 1, vl])
+            if self.early_stopping:                            # EarlyStopping(monitor='val_loss', mode='min'); vl is rank-averaged
                 if vl < best - self.min_delta:
                     best, wait = vl, 0
                 else:
                     wait += 1
                     if wait >= self.patience:
+                        if self.verbose and self.running_on_first_worker:
+                            print(f'Epoch {epoch + 1}: early stopping')
                         break
         self.fithist = hist
-        if self.running_on_first_worker:
-            self.test_loss, _ = self._epoch_loss(self.ds_test, self.test_steps, False)
-            if self.verbose:
-                print(f'\nScore on the test set: {self.test_loss}')
+        # model.evaluate(ds_test) -- the reference scores on the first worker only (supervised.py:409-411); here every rank
+        # scores its shard of the test set and the mean over ranks is reported (all ranks must enter the collective)
+        self.test_loss, _ = self._epoch_loss(self.ds_test, self.test_steps, False)
+        if self.verbose and self.running_on_first_worker:
+            print(f'\nScore on the test set: {self.test_loss}')
         self.running_time = time.time() - t0
         self.save_results(self.model)
         if self.save and self.running_on_first_worker and self.save_path is not None:

@@ -235,6 +235,8 @@ int dl4ds_trainer_last_loss(dl4ds_trainer* tr, float* loss_host);   /* synchroni
  * dropout_keep_host: optional 2*B*C keep-mask (real rows first) for the discriminator's Dropout(0.4). */
 int dl4ds_cgan_create(dl4ds_graph* gen, dl4ds_graph* disc, int px_loss_kind, float lr, float beta1, float lam,
                       dl4ds_trainer** tr);
+/* genlr, dislr = learning_rates (cgan.py:271-278): one Adam(beta_1=0.5) per model, each with its own rate */
+int dl4ds_cgan_set_learning_rates(dl4ds_trainer* tr, float gen_lr, float disc_lr);
 int dl4ds_cgan_step(dl4ds_trainer* tr, const float* const* gen_inputs, int n_gen_inputs, const float* hr, int B,
                     int is_host, const float* dropout_keep_host, int apply_update, float* losses_host);
 /* Adam slots + optimizer.iterations of the generator (which = 0) / discriminator (which = 1) optimiser -- the contents of
@@ -271,6 +273,17 @@ int dl4ds_dist_world(int* rank, int* world);
 int dl4ds_dist_broadcast_trainer(dl4ds_trainer* tr, int root);   /* params + Adam m,v + step */
 int dl4ds_dist_allreduce_sum(float* buf_dev, size_t n);          /* on the library stream */
 int dl4ds_dist_finalize(void);
+/* Fail-safe: the launcher's WORLD_SIZE (1 when unset or DL4DS_ALLOW_UNSYNCED=1).  dl4ds_trainer_step, dl4ds_cgan_step and
+ * dl4ds_dist_broadcast_trainer return an error -- they do NOT fall back to local training -- when it is > 1 and no
+ * communicator of that size exists (hvd.init() is unconditional in the reference, base.py:97-107). */
+int dl4ds_dist_expected_world(int* world);
+/* what RCCL reports for the communicator: ncclCommCount / ncclCommUserRank / ncclCommCuDevice (nranks 0: none) */
+int dl4ds_dist_comm_info(int* nranks, int* rank, int* device);
+/* in-place reduction of n <= 1024 host floats across the ranks; op: 0 sum, 1 max, 2 min; synchronous; identity without a
+ * communicator.  Validation / test losses and the early-stopping decision (hvd.callbacks.MetricAverageCallback,
+ * supervised.py:366-368), max-over-ranks timing. */
+int dl4ds_dist_allreduce_host(float* values_host, int n, int op);
+int dl4ds_dist_barrier(void);                                    /* stream sync + a 1-float all-reduce */
 
 #ifdef __cplusplus
 }

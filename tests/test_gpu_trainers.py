@@ -52,7 +52,77 @@ def test_supervised_trainer_spatiotemporal_pin():
     # Predictor on a spatio-temporal model: windows are collapsed back into a frame sequence (inference.py:241-242)
     from dl4ds_amd.inference import Predictor
     y = Predictor(t, te, scale=2, array_in_hr=True, time_window=3, batch_size=2).run()
-    assert y.ndim == 4 and y.shape[1:] == (16, 16, 1) and y.shape[0] == (te.shape[0] - 3) + 2 and np.isfinite(y).all()
+    # n - (time_window - 1) windows (inference.py:187-189) collapse back into exactly n frames (utils.py:32-45)
+    assert y.ndim == 4 and y.shape == (te.shape[0], 16, 16, 1) and np.isfinite(y).all()
+
+
+def test_predictor_on_pin_models_with_lr_input():
+    """array_in_hr=False on a 'pin' model -- the LR array is first re-expanded to the HR grid and handed over
+    as array_lr (inference.py:196-203); the prediction must equal the one obtained from the HR-side construction of the
+    same inputs."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.inference import Predictor, predict
+    hr = _fields(6, 32, 5)
+    lr = hr.reshape(6, 8, 4, 8, 4, 1).mean(axis=(2, 4)).astype(np.float32)
+    for model in (PM.net_pin('resnet', 1, 0, hr_size=(32, 32), n_blocks=2, n_filters=4, seed=1),
+                  PM.unet_pin('unet', 1, 0, hr_size=(32, 32), n_blocks=2, n_filters=4, seed=2)):
+        y_lr = Predictor(model, lr, scale=4, batch_size=4).run()                       # array_in_hr=False (class default)
+        assert y_lr.shape == (6, 32, 32, 1) and np.isfinite(y_lr).all()
+        # the same model input built by hand: block means replicated back to the HR grid
+        x = np.repeat(np.repeat(lr, 4, axis=1), 4, axis=2)
+        np.testing.assert_allclose(y_lr, model.predict([x], batch_size=3), rtol=1e-5, atol=1e-6)
+        y_hr, x_used = predict(model, hr, scale=4, return_lr=True)                      # array_in_hr=True (function default)
+        np.testing.assert_allclose(x_used, x, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(y_hr, y_lr, rtol=1e-4, atol=1e-5)
+
+
+def test_cgan_learning_rates_forms():
+    """cgan.py:271-278: a (genlr, dislr) pair gives the two optimisers their own rates; a float or a 1-tuple sets both."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import CGANEngine
+    from dl4ds_amd.training.engine import cgan_learning_rates
+    assert cgan_learning_rates(2e-4) == (2e-4, 2e-4) and cgan_learning_rates((1e-3,)) == (1e-3, 1e-3)
+    assert cgan_learning_rates([2e-4, 1e-4]) == (2e-4, 1e-4)
+    with pytest.raises(TypeError):
+        cgan_learning_rates('fast')
+    rng = np.random.default_rng(0)
+    B, H = 2, 16
+    lr, st, hr = (rng.random((B, H, H, c)).astype(np.float32) for c in (2, 1, 1))
+    mask = (rng.random((2 * B, 8)) > 0.4).astype(np.float32)
+
+    def one_step(rates):
+        gen = PM.unet_pin('unet', 2, 1, hr_size=(H, H), n_filters=4, n_blocks=2, decoder_upsampling='dc', seed=3)
+        disc = PM.residual_discriminator(2, 'pin', False, 8, (H // 8, H // 8), n_filters=4, n_res_blocks=1, hr_size=(H, H), seed=4)
+        g0, d0 = gen.get_weights(), disc.get_weights()
+        CGANEngine(gen, disc, loss='mae', learning_rate=rates).step([lr, st], hr, dropout_keep=mask)
+        dg = max(float(np.abs(gen.get_weights()[k] - g0[k]).max()) for k in g0)
+        dd = max(float(np.abs(disc.get_weights()[k] - d0[k]).max()) for k in d0)
+        return dg, dd
+
+    # the first Adam step moves a weight by at most lr (|m| / sqrt(v) = 1): the step sizes expose the two rates
+    dg, dd = one_step((4e-4, 1e-4))
+    assert 3.9e-4 < dg < 4.01e-4 and 0.97e-4 < dd < 1.01e-4, (dg, dd)
+    dg, dd = one_step(3e-4)
+    assert 2.9e-4 < dg < 3.01e-4 and 2.9e-4 < dd < 3.01e-4, (dg, dd)
+
+
+def test_supervised_trainer_early_stopping_and_best_model_files(tmp_path):
+    """EarlyStopping(monitor='val_loss', patience) and ModelCheckpoint(best_model) (supervised.py:356-390)."""
+    import os
+    from dl4ds_amd.training import SupervisedTrainer
+    tr, va, te = _fields(8, 16, 0), _fields(4, 16, 1), _fields(4, 16, 2)
+    t = SupervisedTrainer('resnet', 'spc', tr, va, te, scale=2, batch_size=4, epochs=6, learning_rate=1e-3, verbose=False,
+                          n_blocks=1, n_filters=4, save=True, save_path=str(tmp_path), save_bestmodel=True,
+                          early_stopping=True, patience=2, min_delta=10.0)        # nothing improves by 10: stops after 1 + 2 epochs
+    t.run()
+    assert len(t.fithist['val_loss']) == 3
+    files = set(os.listdir(tmp_path / 'best_model'))
+    assert {'checkpoint.npz', 'model_weights.npz', 'epoch_val_loss.txt'} <= files
+    ep, vl = np.loadtxt(tmp_path / 'best_model' / 'epoch_val_loss.txt')
+    assert int(ep) == 3 and abs(vl - t.fithist['val_loss'][-1]) < 1e-6
+    w = np.load(tmp_path / 'best_model' / 'model_weights.npz')
+    for k, v in t.model.get_weights().items():
+        np.testing.assert_array_equal(w[k], v)
 
 
 def test_cgan_trainer_runs():
@@ -66,6 +136,7 @@ def test_cgan_trainer_runs():
     assert len(t.gentotal) == 8 and np.isfinite(t.gentotal).all() and np.isfinite(t.disc).all()
     assert t.generator.name == 'unet_pin'
     assert all(abs(a - (b + 100 * c)) < 1e-3 * abs(a) for a, b, c in zip(t.gentotal, t.gengan, t.genpxloss))
+    assert np.isfinite(t.test_loss) and t.test_loss > 0          # pixel loss of generator.predict on the test set (cgan.py:386-440)
 
 
 def test_cgan_trainer_postupsampling_and_spatiotemporal():

@@ -79,14 +79,17 @@ def test_dataloader_shapes_and_block_mean():
 
 
 def test_rank_sharding_is_a_partition():
+    """Disjoint, equally long shards covering all but the n % world remainder (unequal step counts would leave ranks
+    waiting in the gradient all-reduce)."""
     n, world = 37, 4
     parts = [parallel.shard_indices(n, r, world, seed=5, epoch=2) for r in range(world)]
     allidx = np.concatenate(parts)
-    assert sorted(allidx.tolist()) == list(range(n))
+    assert len(set(allidx.tolist())) == len(allidx) == 36 and {len(p) for p in parts} == {9}
     gens = [DataGenerator(np.zeros((n, 8, 8, 1)), None, 'resnet', 'spc', 4, batch_size=2, seed=9, rank=r, world=world)
             for r in range(world)]
     seen = np.concatenate([g.indices for g in gens])
-    assert sorted(seen.tolist()) == list(range(n))
+    assert len(set(seen.tolist())) == len(seen) == 36 and {len(g) for g in gens} == {4}
+    assert sorted(parallel.shard_indices(n, 0, 1, seed=5).tolist()) == list(range(n))
 
 
 def test_lr_schedule_plumbing():

@@ -1,0 +1,123 @@
+"""CPU tests of the multi-process control plane that needs no GPU: the TCP hand-over of the 128-byte RCCL id
+(dl4ds_amd.parallel.exchange_bytes -- the id exchange of init_from_env, this package's hvd.init()), equal-length
+rank shards, and bench.py's own rank launcher.  Two real processes, world_size 2 (and 3)."""
+import multiprocessing as mp
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rdzv_worker(rank, world, port, q, delay):
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop('DL4DS_RDZV_PORT', None)
+    from dl4ds_amd import parallel
+    time.sleep(delay)                                   # rank 0 late / early: both orders must work
+    assert parallel.rendezvous_endpoint() == ('127.0.0.1', port + 1)
+    payload = bytes(range(128)) if rank == 0 else b''
+    got = parallel.exchange_bytes(payload, rank, world, timeout=60.0)
+    q.put((rank, got, parallel.rank_world_from_env()))
+
+
+@pytest.mark.parametrize('world,late_root', [(2, False), (2, True), (3, False)])
+def test_tcp_id_exchange(world, late_root):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, port, q, (0.5 if (r == 0) == late_root else 0.0)))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[1] == bytes(range(128)) for r in res)
+    assert [r[2] for r in res] == [(i, world, i) for i in range(world)]
+
+
+def test_rendezvous_times_out_when_a_rank_is_missing():
+    from dl4ds_amd import parallel
+    port = _free_port()
+    with pytest.raises(TimeoutError, match='only 1 of 2 ranks'):
+        parallel.exchange_bytes(b'x' * 128, 0, 2, timeout=0.5, endpoint=('127.0.0.1', port))
+    with pytest.raises(TimeoutError, match='could not reach rank 0'):
+        parallel.exchange_bytes(b'', 1, 2, timeout=0.5, endpoint=('127.0.0.1', port))
+
+
+def test_rendezvous_port_in_use_is_reported():
+    from dl4ds_amd import parallel
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    s.listen(1)
+    try:
+        with pytest.raises(RuntimeError, match='DL4DS_RDZV_PORT'):
+            parallel.exchange_bytes(b'x' * 128, 0, 2, timeout=1.0, endpoint=('127.0.0.1', s.getsockname()[1]))
+    finally:
+        s.close()
+
+
+def test_equal_shards():
+    from dl4ds_amd import parallel
+    from dl4ds_amd.dataloader import equal_shard
+    for n in (10, 11, 17, 64):
+        for world in (1, 2, 3, 8):
+            perm = np.random.default_rng(n).permutation(n)
+            shards = [equal_shard(perm, r, world) for r in range(world)]
+            assert len({len(s) for s in shards}) == 1                     # same step count on every rank
+            allv = np.concatenate(shards)
+            assert len(set(allv.tolist())) == len(allv) == (n // world) * world
+            for r in range(world):
+                np.testing.assert_array_equal(parallel.equal_shard(perm, r, world), shards[r])
+            a = parallel.shard_indices(n, 0, world, seed=3, epoch=1)
+            assert len(a) == n // world
+
+
+def test_data_generators_have_equal_length_on_every_rank():
+    from dl4ds_amd.dataloader import DataGenerator
+    data = np.random.default_rng(0).random((23, 8, 8, 1)).astype(np.float32)
+    lens, seen = [], []
+    for r in range(3):
+        g = DataGenerator(data, None, 'resnet', 'spc', 2, batch_size=2, seed=1, rank=r, world=3)
+        lens.append(len(g))
+        seen += g.indices.tolist()
+    assert lens == [3, 3, 3] and len(set(seen)) == 21
+
+
+def test_bench_launcher_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus 2` invoked directly (no launcher): it must start the ranks itself; in this container
+    there is no HIP device, so it has to stop with a clear message instead of an argparse / launcher error."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs visible: covered by the gpu tests')
+    assert r.returncode != 0
+    assert 'HIP device(s) visible' in (r.stderr + r.stdout) or 'no HIP device' in (r.stderr + r.stdout)
+
+
+def test_bench_port_pair_is_free():
+    sys.path.insert(0, ROOT)
+    import bench
+    p = bench._free_port_pair()
+    for port in (p, p + 1):
+        s = socket.socket()
+        s.bind(('127.0.0.1', port))
+        s.close()
