@@ -59,6 +59,24 @@ __global__ void colsum_finish_kernel(const float* __restrict__ partial, float* _
     out[e] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * scale;
 }
 
+// mean[g*C + c] = scale * sum_k partial[(g*tiles + k)*8 + c]: the per-tile channel sums the narrow pair convolution
+// wrote from its epilogue (ConvEpilogue::pool), same eight-way fixed association order as colsum_finish_kernel
+__global__ void pool_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int tiles, int C, int GC,
+                                   float scale) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= GC) return;
+    const int g = e / C, c = e - g * C;
+    const float* p = partial + (size_t)g * tiles * 8 + c;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= tiles; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(k + u) * 8];
+    }
+    for (; k < tiles; ++k) s[0] += p[(size_t)k * 8];
+    out[e] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * scale;
+}
+
 // one thread per (instance, c)
 __global__ void chatt_mlp_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
                                      const float* __restrict__ b1, const float* __restrict__ w2,
@@ -186,14 +204,25 @@ size_t chatt_workspace_bytes(const AttShape& sh) {
 }
 
 void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, const float* w1, const float* b1,
-                   const float* w2, const float* b2, float* mean, float* hidden, float* scale, float* workspace) {
+                   const float* w2, const float* b2, float* mean, float* hidden, float* scale, float* workspace,
+                   const float* pool_partial, int pool_tiles) {
     const int Q = sh.P * sh.C;
     const int ninst = sh.G * sh.P;
-    ProfScope ps(s, "chatt_fwd", 0.0, 12.0 * (double)sh.G * sh.R * Q);
-    colsum(s, x, nullptr, workspace, mean, sh.G, sh.R, Q, 1.f / (float)sh.R);
+    // algorithmic traffic: one read of x for the pooling unless the producer supplied it, one read + one write for the scale
+    // unless the consumer applies it while loading (y == nullptr)
+    ProfScope ps(s, "chatt_fwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * ((pool_partial ? 0 : 1) + (y ? 2 : 0)));
+    if (pool_partial) {
+        DL4DS_REQUIRE(sh.P == 1 && sh.C <= 8, "chatt: pooling partials come from the 8-channel pair convolution");
+        hipLaunchKernelGGL(pool_finish_kernel, dim3(cdiv(sh.G * sh.C, 256)), dim3(256), 0, s, pool_partial, mean, pool_tiles,
+                           sh.C, sh.G * sh.C, 1.f / (float)sh.R);
+        HIP_CHECK(hipGetLastError());
+    } else {
+        colsum(s, x, nullptr, workspace, mean, sh.G, sh.R, Q, 1.f / (float)sh.R);
+    }
     hipLaunchKernelGGL(chatt_mlp_fwd_kernel, dim3(cdiv(ninst * sh.C, 256)), dim3(256), 0, s, mean, w1, b1, w2, b2,
                        hidden, scale, ninst, sh.C, sh.Cr);
     HIP_CHECK(hipGetLastError());
+    if (y == nullptr) return;                  // the consumer reads x through a view carrying `scale` (TView::sc)
     const size_t total = (size_t)sh.G * sh.R * Q;
     hipLaunchKernelGGL(chatt_scale_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, scale, y, sh.R, Q, total);
     HIP_CHECK(hipGetLastError());
@@ -201,7 +230,7 @@ void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, 
 
 void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, int accumulate_dx, const AttShape& sh,
                     const float* w1, const float* w2, const float* mean, const float* hidden, const float* scale,
-                    float* dw1, float* db1, float* dw2, float* db2, int accumulate_dw, float* workspace) {
+                    float* dw1, float* db1, float* dw2, float* db2, int accumulate_dw, float* workspace, float* dmean_out) {
     const int Q = sh.P * sh.C;
     const int ninst = sh.G * sh.P;
     float* partial = workspace;
@@ -209,11 +238,13 @@ void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, i
     float* dmean = ds + (size_t)sh.G * Q;
     float* dpre1 = dmean + (size_t)sh.G * Q;
     float* dpre2 = dpre1 + (size_t)ninst * sh.Cr;
-    ProfScope ps(s, "chatt_bwd", 0.0, 16.0 * (double)sh.G * sh.R * Q);
+    if (dmean_out) dmean = dmean_out;           // kept by the caller: the producer reads dX = dY * scale + dmean lazily
+    ProfScope ps(s, "chatt_bwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * (2 + (dx ? 2 + (accumulate_dx ? 1 : 0) : 0)));
     colsum(s, dy, x, partial, ds, sh.G, sh.R, Q, 1.f);
     hipLaunchKernelGGL(chatt_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, ds, mean, hidden, scale, w1, w2, dpre1, dpre2,
                        dmean, dw1, db1, dw2, db2, ninst, sh.C, sh.Cr, 1.f / (float)sh.R, accumulate_dw);
     HIP_CHECK(hipGetLastError());
+    if (dx == nullptr) return;                  // dX is not materialised (TView::sc / sh on the producer's dY view)
     const size_t total = (size_t)sh.G * sh.R * Q;
     hipLaunchKernelGGL(chatt_dx_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, scale, dmean, dx, sh.R, Q, total,
                        accumulate_dx);

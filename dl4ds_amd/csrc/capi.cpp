@@ -658,6 +658,21 @@ int dl4ds_graph_forward(dl4ds_graph* g, const float* const* inputs, int n_inputs
     }
     API_END
 }
+int dl4ds_graph_fusion_report(dl4ds_graph* g, int B, char* json_buf, size_t buflen) {
+    API_BEGIN
+    g->g.prepare(B);                       // fusion decisions need the allocated buffers (alignment of the real views)
+    std::string out = "[";
+    for (auto& op : g->g.ops) {
+        const std::string d = op->describe_fusion(g->g);
+        if (d.empty()) continue;
+        if (out.size() > 1) out += ",";
+        out += d;
+    }
+    out += "]";
+    DL4DS_REQUIRE(out.size() + 1 <= buflen, "fusion_report: buffer too small");
+    std::memcpy(json_buf, out.c_str(), out.size() + 1);
+    API_END
+}
 int dl4ds_graph_tensor_ptr(dl4ds_graph* g, int tid, int grad, float** p) {
     API_BEGIN
     const GTensor& t = g->g.tensors.at(tid);

@@ -27,6 +27,14 @@ struct TView {
     unsigned mcp, mr;    // d2s: magic multipliers for exact n/cp and n/r (fast_div)
     size_t nstride;      // floats between consecutive images n (default: contiguous); lets a view pick
                          // frame t of every sample of a (B,T,H,W,C) buffer without a copy
+    // Optional per-image channel affine of a READ view: logical value = mem * sc[n*C + c] + sh[n*C + c] inside the tensor
+    // (the SAME zero padding outside it).  ChannelAttention2D's broadcast scale (blocks.py:585-593) and its backward
+    // dX = dY * scale + dmean are carried this way into the staging loads of the neighbouring convolutions instead of
+    // being materialised by a pass over the HR tensor.  sc == nullptr: plain view; sh may be null on its own (scale only).
+    // Only the kernels that say so honour it (conv_direct*, conv_narrow_pair, conv_narrow_wgrad's dz operand); every other
+    // dispatch path rejects a view that carries one.
+    const float* sc;
+    const float* sh;
 };
 
 // exact n / d for 0 <= n < 2^20, 1 <= d <= 4096 with magic = 2^32/d + 1 (0 encodes d == 1)
@@ -39,6 +47,7 @@ __host__ __device__ inline TView make_view(float* p, int N, int H, int W, int C)
     v.vec = ((C & 3) == 0) && ((((uintptr_t)p) & 15) == 0);
     v.cp = C; v.mcp = 0; v.mr = 0;
     v.nstride = (size_t)H * W * C;
+    v.sc = nullptr; v.sh = nullptr;
     return v;
 }
 
@@ -50,7 +59,22 @@ __host__ __device__ inline TView make_view_d2s(float* p, int N, int H, int W, in
     v.vec = ((cp & 3) == 0) && ((((uintptr_t)p) & 15) == 0);
     v.cp = cp; v.mcp = div_magic(cp); v.mr = div_magic(r);
     v.nstride = (size_t)H * W * C;
+    v.sc = nullptr; v.sh = nullptr;
     return v;
+}
+
+// float4 of the view's channel affine for image n, channels [c, c+4) (c % 4 == 0, C % 4 == 0); identity when absent
+__device__ __forceinline__ void view_affine4(const TView& v, int n, int c, float4& s4, float4& h4) {
+    s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v.sc) {
+        const int cs = (c + 3 < v.C) ? c : 0;
+        s4 = *reinterpret_cast<const float4*>(v.sc + (size_t)n * v.C + cs);
+        if (v.sh) h4 = *reinterpret_cast<const float4*>(v.sh + (size_t)n * v.C + cs);
+    }
+}
+__device__ __forceinline__ float4 affine4(float4 r, const float4& s4, const float4& h4) {
+    return make_float4(fmaf(r.x, s4.x, h4.x), fmaf(r.y, s4.y, h4.y), fmaf(r.z, s4.z, h4.z), fmaf(r.w, s4.w, h4.w));
 }
 
 __device__ __forceinline__ size_t view_off(const TView& v, int n, int y, int x, int c) {

@@ -1462,6 +1462,8 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     DL4DS_REQUIRE(in.N == out.N && in.H == out.H && in.W == out.W, "conv2d: stride-1 SAME shapes differ");
     if (conv2d_direct_forward(s, in, w, KS, out, ep)) return;      // a handful of channels: HBM-bound stencil
     if (!getenv("DL4DS_NO_NARROW") && conv2d_narrow_forward(s, in, w, KS, out, ep)) return;
+    DL4DS_REQUIRE(!in.sc && !ep.pool, "conv2d: channel-affine input / pooling partials are only implemented by the direct "
+                                     "and narrow-pair kernels (the caller must check conv2d_direct_eligible / conv2d_narrow_pair_ok)");
     if (!getenv("DL4DS_NO_STREAM") && conv2d_stream_forward(s, in, w, KS, out, ep)) return;
     ConvParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
@@ -1564,6 +1566,8 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     const size_t n = nw + dz.C;
     const int direct_slabs = conv2d_direct_wgrad_slabs(x, dz, KS);
     const int narrow_slabs = (direct_slabs || getenv("DL4DS_NO_NARROW")) ? 0 : conv2d_narrow_wgrad_slabs(x, dz, KS);
+    DL4DS_REQUIRE(direct_slabs || ((!x.sc) && (narrow_slabs || !dz.sc)),
+                  "wgrad: channel-affine operands are only implemented by the direct (x) and narrow (dz) kernels");
     int nslabs = direct_slabs ? direct_slabs : (narrow_slabs ? narrow_slabs : pl.S);
     DL4DS_REQUIRE(workspace_bytes >= (size_t)nslabs * n * sizeof(float), "wgrad: workspace too small");
     WgradParams p;

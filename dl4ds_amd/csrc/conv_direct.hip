@@ -55,6 +55,14 @@ __device__ __forceinline__ void stage_tile(const TView& v, int Cin, int H, int W
             r[u] = view_load4_raw(v, n, gy, gx, pl * 4, ok);
             m[u] = valid4(pl * 4, Cin, ok);
         }
+        if (v.sc) {
+            // channel affine of the view (ChannelAttention2D's scale folded into this load, see TView): NPL divides 256,
+            // so the thread's plane (channel quad) is fixed; the image is fixed for the tile
+            float4 s4, h4;
+            view_affine4(v, n, (tid % NPL) * 4, s4, h4);
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) r[u] = affine4(r[u], s4, h4);
+        }
 #pragma unroll
         for (int u = 0; u < ITERS; ++u) {
             const int e = tid + u * 256;
@@ -342,9 +350,15 @@ int dispatch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks
 
 }  // namespace
 
+// a view with a channel affine is only read by the float4 staging path (Cin % 4 == 0, 16-byte aligned)
+static bool affine_ok(const TView& v) { return !v.sc || (v.vec && (v.C & 3) == 0 && v.C >= 4); }
+
+bool conv2d_direct_eligible(const TView& in, const TView& out, int KS) { return eligible(in, out, KS) && affine_ok(in); }
+
 bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep) {
     if (!eligible(in, out, KS)) return false;
+    DL4DS_REQUIRE(affine_ok(in) && !ep.pool, "conv_direct: channel-affine input needs float4-loadable channels; no pooling partials");
     if ((ep.add.p && ep.add.d2s > 1) || (ep.mask.p && ep.mask.d2s > 1)) return false;
     DirectParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
@@ -359,6 +373,7 @@ bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int K
 
 int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS) {
     if (!eligible(x, dz, KS)) return 0;
+    DL4DS_REQUIRE(affine_ok(x) && !dz.sc, "conv_direct wgrad: only a float4-loadable x operand may carry a channel affine");
     const int ntiles = cdiv(x.W, DTX) * cdiv(x.H, DTY) * x.N;
     return std::max(1, std::min(ntiles, 1024));
 }

@@ -35,6 +35,7 @@ struct ConvParams {
     // split-K (conv_igemm_kernel on grids with too few tiles to fill the chip): blockIdx.z owns `kchunks` consecutive
     // channel chunks and writes its partial result as image (z * nimg + n) of a plain slab buffer; 0 = off
     int kchunks = 0, nimg = 0;
+    float* pool = nullptr;  // conv_narrow_pair only: [tile][8] channel sums of the values stored (ChannelAttention2D pooling)
 };
 
 // Epilogue shared by the forward/dgrad kernels.  The MFMA is issued as D = W^T-fragment x pixel-fragment, so with the

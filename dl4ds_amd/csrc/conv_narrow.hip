@@ -25,6 +25,9 @@
 namespace {
 
 constexpr int NTW = 16, NTH = 32, NROWS = 8;      // tile width / height, rows per wave
+#ifndef NARROW_PAIR_ROWS
+#define NARROW_PAIR_ROWS 4
+#endif
 
 template <int CI>
 __global__ void __launch_bounds__(256, CI == 8 ? 4 : 2) conv_narrow_kernel(const ConvParams a) {
@@ -156,6 +159,8 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
     constexpr int P = 10;                            // LDS pixel pitch (floats): lanes 2 pixels apart -> all 32 banks
     constexpr int TOTAL = HPIX * 2, ITERS = (TOTAL + 255) / 256;
     __shared__ __attribute__((aligned(16))) float tile[HPIX * P];
+    __shared__ __attribute__((aligned(16))) float pool_red[2][32];     // a.pool: [parity][wave][channel]
+    int it = 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -213,6 +218,14 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
                     r[u] = *reinterpret_cast<const float4*>(a.in.p + off);
                     m[u] = valid4(c4 * 4, a.Cin, ok);
                 }
+                if (a.in.sc) {
+                    // channel affine of the view (ChannelAttention2D's scale / its backward, see TView): the thread's
+                    // channel quad is fixed (e & 1 == tid & 1), the image is fixed for the tile
+                    float4 s4, h4;
+                    view_affine4(a.in, n, (tid & 1) * 4, s4, h4);
+#pragma unroll
+                    for (int u = 0; u < ITERS; ++u) r[u] = affine4(r[u], s4, h4);
+                }
             } else {
                 // Cin not a multiple of 4 (e.g. the 5 + 1 input channels of the U-Net): four clamped scalar loads
 #pragma unroll
@@ -261,6 +274,7 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
             }
         }
         const int gx = x0 + 2 * l15 + eh;
+        float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);      // a.pool: this lane's share of the tile's channel sums
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int gy = y0 + wave * NR + i;
@@ -282,9 +296,29 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
                     v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
                 }
                 *dst = v;
+                psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
             }
         }
+        if (a.pool) {
+            // GlobalAveragePooling of ChannelAttention2D (blocks.py:585-588) without a pass over the tensor just written:
+            // per-tile channel sums in a fixed order -- 16 pair columns (xor shuffles), the two pixels of a pair (lanes 32
+            // apart), the four waves through LDS -- one 8-float record per tile, summed per image by colsum_finish_kernel
+#pragma unroll
+            for (int mk = 1; mk < 16; mk <<= 1) {
+                psum.x += __shfl_xor(psum.x, mk, 64); psum.y += __shfl_xor(psum.y, mk, 64);
+                psum.z += __shfl_xor(psum.z, mk, 64); psum.w += __shfl_xor(psum.w, mk, 64);
+            }
+            psum.x += __shfl_xor(psum.x, 32, 64); psum.y += __shfl_xor(psum.y, 32, 64);
+            psum.z += __shfl_xor(psum.z, 32, 64); psum.w += __shfl_xor(psum.w, 32, 64);
+            float* red = pool_red[it & 1];
+            if (lane == 0 || lane == 16) *reinterpret_cast<float4*>(red + wave * 8 + (lane >> 4) * 4) = psum;
+        }
         __syncthreads();
+        if (a.pool && tid < 8) {
+            const float* red = pool_red[it & 1];
+            a.pool[(size_t)t * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
+        }
+        ++it;
     }
 }
 
@@ -411,6 +445,14 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
                     zm[u] = valid4(c4 * 4, a.Cout, ok);
                 }
             }
+            if (a.dz.sc) {
+                // dz carries a channel affine (ChannelAttention2D backward: dX = dY * scale + dmean): ZQ4 divides 256, so
+                // the thread's channel quad is fixed; the image is fixed for the tile
+                float4 s4, h4;
+                view_affine4(a.dz, n, (tid % ZQ4) * 4, s4, h4);
+#pragma unroll
+                for (int u = 0; u < ZIT; ++u) zr[u] = affine4(zr[u], s4, h4);
+            }
 #pragma unroll
             for (int u = 0; u < XIT; ++u) {
                 const int e = tid + u * 256;
@@ -479,6 +521,7 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
 }
 
 bool narrow_wgrad_eligible(const TView& x, const TView& dz, int KS) {
+    if (x.sc) return false;                                   // only the dz operand takes a channel affine here
     if (KS != 3 || x.C > 8 || dz.C > 16 || x.d2s > 1 || dz.d2s > 1 || !dz.vec) return false;    // x may be unaligned / Cin % 4 != 0
     return (long)cdiv(x.W, NTW) * cdiv(x.H, NTH) * x.N < (1l << 20);                   // fast_div range
 }
@@ -515,25 +558,32 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
     return blocks;
 }
 
+// <= 8 x <= 8 channels with float4-able outputs: two pixels per MFMA column (1.5x fewer MFMAs, all lanes store);
+// the only variant that also takes inputs whose channel count is not a multiple of 4.  Also the only narrow variant that
+// reads a view with a channel affine (float4-loadable inputs only) and emits the pooling partial sums.
+bool conv2d_narrow_pair_ok(const TView& in, const TView& out, int KS, const ConvEpilogue& ep) {
+    if (KS != 3 || in.d2s > 1 || getenv("DL4DS_NO_PAIR") || getenv("DL4DS_NO_NARROW")) return false;
+    if ((long)cdiv(in.W, NTW) * cdiv(in.H, NTH) * in.N >= (1l << 20)) return false;    // fast_div range
+    return in.C <= 8 && out.C <= 8 && (out.C & 3) == 0 && out.vec && (!ep.add.p || ep.add.vec) &&
+           (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) && (!in.sc || (in.vec && (in.C & 3) == 0));
+}
+int conv2d_narrow_pair_tiles_per_image(int H, int W) { return cdiv(W, 32) * cdiv(H, 4 * NARROW_PAIR_ROWS); }
+
 bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep) {
     if (KS != 3 || in.C > 16 || out.C > 16 || in.d2s > 1) return false;
-    // <= 8 x <= 8 channels with float4-able outputs: two pixels per MFMA column (1.5x fewer MFMAs, all lanes store);
-    // the only variant that also takes inputs whose channel count is not a multiple of 4
-    const bool pair_ok = in.C <= 8 && out.C <= 8 && (out.C & 3) == 0 && out.vec && (!ep.add.p || ep.add.vec) &&
-                         (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) && !getenv("DL4DS_NO_PAIR");
+    const bool pair_ok = conv2d_narrow_pair_ok(in, out, KS, ep);
     if (!in.vec && !pair_ok) return false;
     if ((long)cdiv(in.W, NTW) * cdiv(in.H, NTH) * in.N >= (1l << 20)) return false;    // fast_div range
+    DL4DS_REQUIRE(pair_ok || (!in.sc && !ep.pool), "conv_narrow: channel-affine input / pooling partials need the pair kernel");
     ConvParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
     p.w = w; p.bias = ep.bias;
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.CK = 0; p.TPS = 1;
+    p.pool = ep.pool;
     if (pair_ok) {
-#ifndef NARROW_PAIR_ROWS
-#define NARROW_PAIR_ROWS 4
-#endif
         launch_narrow_pair<NARROW_PAIR_ROWS>(s, p, in.N);
         return true;
     }

@@ -7,6 +7,7 @@
 #pragma once
 #include "ops.h"
 #include <memory>
+#include <string>
 #include <vector>
 
 struct Graph;
@@ -54,6 +55,7 @@ struct GOp {
     virtual bool set_mask(Graph& g, const float* host, size_t n) { return false; }   // dropout keep-mask injection
     virtual size_t mask_floats(Graph& g, int B) { return 0; }                         // size of the mask of the last forward
     const char* kind = "op";
+    virtual std::string describe_fusion(Graph& g) { return ""; }    // non-empty: JSON object describing what this op handed to its neighbours
 };
 
 struct Graph {

@@ -215,12 +215,52 @@ inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
     return t.requires_grad && (!t.is_input || c.input_grads);
 }
 
+// ChannelAttention2D between two convolutions (ConvBlock(attention=True) followed by another conv: blocks.py:87-103,
+// sp_postups.py:204-211) costs three passes over the HR tensor when run as its own kernels.  Where the neighbouring
+// convolutions run on kernels that can take over (decided in ChAttOp::on_prepare, per piece):
+//   fuse_pool  : the producing conv emits the pooling partial sums from its epilogue       (no pooling pass)
+//   fuse_scale : the consuming conv reads the attention INPUT through TView::sc = scale     (no scale pass, y never stored)
+//   fuse_dx    : the producing conv's backward reads dY = att.out.grad * scale + dmean lazily (no dX pass)
+// DL4DS_NO_TAIL_FUSION=1 keeps the three passes (A/B measurements, tests).
+struct AttFusion {
+    bool fuse_pool = false, fuse_scale = false, fuse_dx = false;
+    float* pool = nullptr;      // [G][tiles][8]
+    int pool_tiles = 0;
+    float* scale = nullptr;     // [G][C]
+    float* dmean = nullptr;     // [G][C]
+    int att_in = -1, att_out = -1;
+};
+
 // ============================================================================================ Conv2D
 struct ConvOp : GOp {
     int in, w, b, add, out, KS, Cout, relu, d2s;
     size_t wt_off = 0;
     bool add_grad_shared = false;   // the residual operand's gradient IS this op's (masked) output gradient: no copy
+    AttFusion* att_after = nullptr;    // a ChannelAttention2D consumes this op's output (this op = its producer)
+    AttFusion* att_before = nullptr;   // this op convolves the output of a ChannelAttention2D (this op = its consumer)
     ConvOp() { kind = "conv2d"; }
+    // the convolved input: the tensor itself, or -- behind a fused attention -- the attention's INPUT seen through its scale
+    TView in_view(Graph& g, int B, int bo, int bc) {
+        if (att_before && att_before->fuse_scale) {
+            TView v = g.view(att_before->att_in, B, false, bo, bc);
+            const GTensor& t = g.tensors[in];
+            v.sc = att_before->scale + (size_t)bo * t.nmul * t.C;
+            return v;
+        }
+        return g.view(in, B, false, bo, bc);
+    }
+    // the output gradient: the tensor's gradient buffer, or -- under a fused attention backward -- the attention
+    // output's gradient seen through dX = dY * scale + dmean
+    TView dy_view(Graph& g, int B, int bo, int bc) {
+        if (att_after && att_after->fuse_dx) {
+            DL4DS_REQUIRE(d2s <= 1 && bo == 0 && (bc < 0 || bc == B), "fused attention backward: whole batches, no depth_to_space");
+            TView v = g.view(att_after->att_out, B, true, bo, bc);
+            v.sc = att_after->scale;
+            v.sh = att_after->dmean;
+            return v;
+        }
+        return out_view(g, true, B, bo, bc);
+    }
     void on_prepare(Graph& g) override {
         if (add_grad_shared) g.tensors[add].grad = g.tensors[out].grad;
     }
@@ -256,7 +296,8 @@ struct ConvOp : GOp {
         ep.bias = (b >= 0) ? g.wp(b) : nullptr;
         if (add >= 0) ep.add = g.view(add, B, false);
         ep.relu = relu;
-        conv2d_forward(g.stream, g.view(in, B, false), g.wp(w), KS, out_view(g, false, B, 0, -1), ep);
+        if (att_after && att_after->fuse_pool) ep.pool = att_after->pool;
+        conv2d_forward(g.stream, in_view(g, B, 0, -1), g.wp(w), KS, out_view(g, false, B, 0, -1), ep);
     }
     size_t workspace_bytes(Graph& g, int B) override {
         TView x = g.view(in, B, false);
@@ -265,8 +306,9 @@ struct ConvOp : GOp {
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;      // nothing flowed into this op
-        TView dY = out_view(g, true, c.B, c.b_off, c.b_cnt);
+        TView dY = dy_view(g, c.B, c.b_off, c.b_cnt);
         if (relu && !g.tensors[out].grad_masked) {      // dZ = dY * [y > 0], in place (every consumer of y has contributed)
+            DL4DS_REQUIRE(!dY.sc, "fused attention backward needs a linear producer");
             bias_act_backward(g.stream, dY, out_view(g, false, c.B, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace,
                               g.workspace_bytes);
         }
@@ -283,7 +325,7 @@ struct ConvOp : GOp {
             const bool on_aux = aux_enabled(g);
             hipStream_t ws_stream = on_aux ? g.aux_stream : g.stream;
             float* ws_buf = on_aux ? g.aux_workspace : g.workspace;
-            conv2d_wgrad(ws_stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, g.gp(w),
+            conv2d_wgrad(ws_stream, in_view(g, c.B, c.b_off, c.b_cnt), dY, KS, g.gp(w),
                          g.params[w].grad_written, need_db ? g.gp(b) : nullptr,
                          need_db ? (int)g.params[b].grad_written : 0, ws_buf, g.workspace_bytes);
             g.params[w].grad_written = true;
@@ -304,6 +346,9 @@ struct ConvOp : GOp {
 // ============================================================================================ ChannelAttention
 struct ChAttOp : GOp {
     int in, out, w1, b1, w2, b2, Cr, T5;   // T5 > 0: 5-D mode (B,T,H,W,C), mean over (T,H)
+    AttFusion fz;
+    ConvOp* producer = nullptr;            // ConvOp writing `in` (found at finalize), ConvOp reading `out`
+    ConvOp* consumer = nullptr;
     ChAttOp() { kind = "chatt"; }
     AttShape shape(Graph& g, int B) {
         const GTensor& t = g.tensors[in];
@@ -313,35 +358,105 @@ struct ChAttOp : GOp {
         s.C = t.C; s.Cr = Cr;
         return s;
     }
+    int pool_tiles(Graph& g) { const GTensor& t = g.tensors[in]; return conv2d_narrow_pair_tiles_per_image(t.H, t.W); }
     size_t saved_floats_per_sample(Graph& g) override {
         const GTensor& t = g.tensors[in];
         const size_t inst = (T5 > 0) ? (size_t)t.W : (size_t)t.nmul;
-        return inst * (2 * (size_t)t.C + Cr);
+        // mean, scale, dmean (C each) + hidden (Cr) per instance; 4-D mode: room for the producer's pooling partial sums
+        return inst * (3 * (size_t)t.C + Cr) + (T5 > 0 ? 0 : (size_t)t.nmul * pool_tiles(g) * 8 + 16);
     }
     size_t workspace_bytes(Graph& g, int B) override { return chatt_workspace_bytes(shape(g, B)); }
-    void ptrs(Graph& g, int B, float*& mean, float*& hidden, float*& scale) {
-        AttShape s = shape(g, B);
+    void ptrs(Graph& g, int, float*& mean, float*& hidden, float*& scale, float*& dmean, float*& pool) {
+        // laid out for the LARGEST batch the buffers were allocated for, so that the addresses handed to the neighbouring
+        // convolutions (AttFusion) stay put when a smaller batch runs
+        AttShape s = shape(g, g.maxB);
         const size_t inst = (size_t)s.G * s.P;
-        mean = saved; scale = mean + inst * s.C; hidden = scale + inst * s.C;
+        mean = saved; scale = mean + inst * s.C; hidden = scale + inst * s.C; dmean = hidden + inst * s.Cr;
+        pool = dmean + ((inst * s.C + 3) & ~(size_t)3);        // keep the float4 records 16-byte aligned
+    }
+    void on_finalize(Graph& g) override {
+        // neighbours: the convolution producing `in` and the (single) convolution reading `out`
+        for (auto& op : g.ops) {
+            ConvOp* c = dynamic_cast<ConvOp*>(op.get());
+            if (!c) continue;
+            if (c->out == in) producer = c;
+            if (c->in == out) consumer = c;
+        }
+        fz.att_in = in; fz.att_out = out;
+    }
+    // which pieces can be handed to the neighbours: needs the real views (alignment), so decided once the buffers exist
+    void on_prepare(Graph& g) override {
+        fz.fuse_pool = fz.fuse_scale = fz.fuse_dx = false;
+        if (producer) producer->att_after = &fz;
+        if (consumer) consumer->att_before = &fz;
+        if (T5 > 0 || getenv("DL4DS_NO_TAIL_FUSION")) return;
+        const int B = g.maxB;
+        float *mean, *hidden, *scale, *dmean, *pool;
+        ptrs(g, B, mean, hidden, scale, dmean, pool);
+        fz.scale = scale; fz.dmean = dmean; fz.pool = pool; fz.pool_tiles = pool_tiles(g);
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
+        const bool in_private = !is_output(in) && ti.n_conv_in == 0 && ti.n_add_in == 0 && ti.n_other == 1;     // only this op reads it
+        // ---- pooling partials from the producer's epilogue
+        if (producer && producer->d2s <= 1 && ti.C <= 8) {
+            ConvEpilogue ep;
+            ep.bias = producer->b >= 0 ? g.wp(producer->b) : nullptr;
+            if (producer->add >= 0) ep.add = g.view(producer->add, B, false);
+            TView pin = producer->in_view(g, B, 0, -1), pout = g.view(in, B, false);
+            fz.fuse_pool = !conv2d_direct_eligible(pin, pout, producer->KS) && conv2d_narrow_pair_ok(pin, pout, producer->KS, ep);
+        }
+        // ---- scale applied by the consumer's loads: `out` has exactly one reader, a 3x3 convolution on the stencil kernels
+        if (consumer && !is_output(out) && to.n_conv_in == 1 && to.n_add_in == 0 && to.n_other == 0 && consumer->KS == 3) {
+            TView x = g.view(in, B, false);
+            x.sc = scale;
+            TView y = make_view(nullptr, x.N, x.H, x.W, consumer->Cout);
+            fz.fuse_scale = conv2d_direct_eligible(x, y, 3);
+        }
+        // ---- dX applied by the producer's backward loads: linear producer without a residual operand, narrow kernels
+        if (producer && in_private && producer->relu == 0 && producer->add < 0 && producer->d2s <= 1 && producer->KS == 3 &&
+            !ti.grad_masked) {
+            TView dz = g.view(out, B, true);
+            dz.sc = scale; dz.sh = dmean;
+            TView px = producer->in_view(g, B, 0, -1);
+            TView dz_plain = dz;
+            dz_plain.sc = dz_plain.sh = nullptr;
+            // weight gradient: the narrow kernel takes the affine on its dz operand (the stencil wgrad does not)
+            bool ok = !px.sc && !conv2d_direct_eligible(px, dz_plain, 3) && conv2d_narrow_wgrad_slabs(px, dz, 3) > 0;
+            // input gradient = convolution of dY: stencil or pair kernel, both read the affine
+            ConvEpilogue ep;
+            const GTensor& tpi = g.tensors[producer->in];
+            TView dx = make_view(tpi.grad ? tpi.grad : tpi.data, px.N, px.H, px.W, px.C);
+            if (tpi.grad_masked) ep.mask = g.view(producer->in, B, false);
+            ok = ok && (conv2d_direct_eligible(dz, dx, 3) ||
+                        (!conv2d_direct_eligible(dz_plain, dx, 3) && conv2d_narrow_pair_ok(dz, dx, 3, ep)));
+            fz.fuse_dx = ok;
+        }
     }
     void forward(Graph& g, int B, bool) override {
-        float *mean, *hidden, *scale;
-        ptrs(g, B, mean, hidden, scale);
-        chatt_forward(g.stream, g.tensors[in].data, g.tensors[out].data, shape(g, B), g.wp(w1), g.wp(b1), g.wp(w2),
-                      g.wp(b2), mean, hidden, scale, g.workspace);
+        float *mean, *hidden, *scale, *dmean, *pool;
+        ptrs(g, B, mean, hidden, scale, dmean, pool);
+        chatt_forward(g.stream, g.tensors[in].data, fz.fuse_scale ? nullptr : g.tensors[out].data, shape(g, B), g.wp(w1),
+                      g.wp(b1), g.wp(w2), g.wp(b2), mean, hidden, scale, g.workspace, fz.fuse_pool ? pool : nullptr,
+                      fz.pool_tiles);
+    }
+    std::string describe_fusion(Graph&) override {
+        return std::string("{\"op\":\"chatt\",\"in\":") + std::to_string(in) + ",\"pool_from_producer\":" +
+               (fz.fuse_pool ? "true" : "false") + ",\"scale_in_consumer_load\":" + (fz.fuse_scale ? "true" : "false") +
+               ",\"dx_in_producer_backward\":" + (fz.fuse_dx ? "true" : "false") + "}";
     }
     bool partial_batch_ok() const override { return false; }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
         DL4DS_REQUIRE(c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B), "chatt: partial-batch backward not supported");
-        float *mean, *hidden, *scale;
-        ptrs(g, c.B, mean, hidden, scale);
+        float *mean, *hidden, *scale, *dmean, *pool;
+        ptrs(g, c.B, mean, hidden, scale, dmean, pool);
         const bool dx = wants_grad(g, in, c);
         DL4DS_REQUIRE(dx, "chatt: input must require grad");
         const int accw = g.params[w1].grad_written;
-        chatt_backward(g.stream, g.tensors[in].data, g.tensors[out].grad, g.tensors[in].grad,
+        chatt_backward(g.stream, g.tensors[in].data, g.tensors[out].grad, fz.fuse_dx ? nullptr : g.tensors[in].grad,
                        g.tensors[in].grad_written, shape(g, c.B), g.wp(w1), g.wp(w2), mean, hidden, scale,
-                       c.param_grads ? g.gp(w1) : nullptr, g.gp(b1), g.gp(w2), g.gp(b2), accw, g.workspace);
+                       c.param_grads ? g.gp(w1) : nullptr, g.gp(b1), g.gp(w2), g.gp(b2), accw, g.workspace, dmean);
         g.tensors[in].grad_written = true;
         if (c.param_grads) {
             g.params[w1].grad_written = g.params[b1].grad_written = true;

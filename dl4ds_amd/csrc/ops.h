@@ -10,6 +10,10 @@ struct ConvEpilogue {
     TView mask{nullptr, 0, 0, 0, 0, 0, 0, 0};   // optional: result zeroed where mask <= 0 (ReLU backward)
     int relu = 0;
     int accumulate = 0;            // out += result (gradient accumulation)
+    // optional [tiles][8] per-tile channel sums of the stored values (tiles of one image contiguous, see
+    // conv2d_narrow_pair_tiles_per_image): the pooling of a ChannelAttention2D that consumes this output.  Only the
+    // narrow pair kernel emits it; callers check conv2d_narrow_pair_ok first, every other path rejects it.
+    float* pool = nullptr;
 };
 void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                     const ConvEpilogue& ep);
@@ -30,6 +34,9 @@ bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int K
 // 3x3, Cin <= 16, Cout <= 16: register-resident filter, persistent MFMA kernel (conv_narrow.hip)
 bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep);
+bool conv2d_narrow_pair_ok(const TView& in, const TView& out, int KS, const ConvEpilogue& ep);
+int conv2d_narrow_pair_tiles_per_image(int H, int W);
+bool conv2d_direct_eligible(const TView& in, const TView& out, int KS);
 // 3x3 wgrad with Cin <= 8, Cout <= 16 (two taps per MFMA tile); same slab protocol as the direct path
 int conv2d_narrow_wgrad_slabs(const TView& x, const TView& dz, int KS);
 int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int max_slabs);
@@ -110,13 +117,17 @@ void localconv_backward(hipStream_t s, const TView& x, const float* w, const TVi
 // --------------------------------------------------------- channel attention (attention.hip)
 // x viewed as [G][R][Q]: mean over R, MLP over the last C channels of Q=(P*C), scale.
 struct AttShape { int G, R, P, C, Cr; };
+// pool_partial (optional): [G][pool_tiles][8] per-tile channel sums emitted by the producing convolution (ConvEpilogue::pool)
+// -> no pooling pass over x.  y == nullptr: the scale is not applied here (the consumer reads x through TView::sc = scale).
 void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, const float* w1,
                    const float* b1, const float* w2, const float* b2, float* mean, float* hidden,
-                   float* scale, float* workspace);
+                   float* scale, float* workspace, const float* pool_partial = nullptr, int pool_tiles = 0);
+// dx == nullptr: dX = dY * scale + dmean is not materialised; dmean is left in dmean_out ([G*P*C], caller-owned) for the
+// producer's lazy dY view (TView::sc = scale, TView::sh = dmean)
 void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, int accumulate_dx,
                     const AttShape& sh, const float* w1, const float* w2, const float* mean,
                     const float* hidden, const float* scale, float* dw1, float* db1, float* dw2,
-                    float* db2, int accumulate_dw, float* workspace);
+                    float* db2, int accumulate_dw, float* workspace, float* dmean_out = nullptr);
 size_t chatt_workspace_bytes(const AttShape& sh);
 
 // ----------------------------------------------------------------------- losses (losses.hip)

@@ -205,6 +205,10 @@ int dl4ds_graph_arena_ptrs(dl4ds_graph* g, float** w_dev, float** g_dev);
 int dl4ds_graph_forward(dl4ds_graph* g, const float* const* inputs, int n_inputs, int B, int training, int is_host,
                         float* out);
 int dl4ds_graph_tensor_ptr(dl4ds_graph* g, int tensor_id, int grad, float** p_dev);
+/* which passes of ChannelAttention2D (blocks.py:585-593) the neighbouring convolutions took over for batch size B
+ * (pooling from the producer's epilogue, scale in the consumer's loads, dX in the producer's backward loads): a JSON list,
+ * one object per attention layer.  Diagnostics / tests; DL4DS_NO_TAIL_FUSION=1 turns the hand-over off. */
+int dl4ds_graph_fusion_report(dl4ds_graph* g, int B, char* json_buf, size_t buflen);
 
 /* ---------------------------------------------------------------- training
  * replaces the Keras fit inner step configured by SupervisedTrainer.run (supervised.py:336-353,396-406):

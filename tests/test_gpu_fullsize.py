@@ -135,3 +135,86 @@ def test_cfg5_generator_full_size_batch_independence_and_gradient():
         ls.append(eng.evaluate([lr, st], hr))
     fd = (ls[0] - ls[1]) / (2 * eps)
     assert fd == pytest.approx(gd, rel=3e-2, abs=1e-4 * abs(loss0)), (fd, gd)
+
+
+def test_cfg1_full_size_against_the_oracle():
+    """BASELINE configs[0] at its own size (net_pin, residual backbone, 2 channels, 128 x 128, B = 2): forward, MAE loss and
+    every gradient against the fp64 torch-CPU oracle -- the oracle needs a few seconds here, so this config is compared
+    directly instead of through size-independent properties."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import SupervisedEngine
+    from oracle import torch_ops as T
+    from oracle import models as M
+    from oracle import train as TR
+    model = PM.net_pin('resnet', 2, 0, hr_size=(128, 128), seed=11)
+    assert model.count_params() == 121341
+    w = _randomise_biases(model)
+    rng = np.random.default_rng(1001)
+    x = rng.standard_normal((2, 128, 128, 2)).astype(np.float32)
+    y = rng.standard_normal((2, 128, 128, 1)).astype(np.float32)
+    P = M.Params()
+    for k, v in w.items():
+        P[k] = v.astype(np.float64)
+    PT = M.convert(P, T, requires_grad=True)
+    lv, grads, pred = TR.supervised_step('net_pin', dict(backbone_block='resnet'), PT, T.asarray(x.astype(np.float64)), None,
+                                         T.asarray(y.astype(np.float64)), loss='mae')
+    out = model([x])
+    ref = pred.numpy()
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-3          # north_star tolerance; observed ~1e-6
+    eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
+    l_hip, g_hip = eng.loss_and_grads([x], y)
+    assert l_hip == pytest.approx(lv, rel=1e-4)
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    for k in grads:
+        assert np.abs(g_hip[k] - grads[k].numpy()).max() / gscale < 1e-3, k
+
+
+def test_cfg5_full_size_cgan_step_properties():
+    """BASELINE configs[4] at its own size (U-Net(dc) generator 13.6 M parameters + residual discriminator at 512^2): the
+    WHOLE CGAN step through dl4ds_cgan_step(apply_update=0) -- D on [real; fake], both backward passes through D, the
+    adversarial gradient entering the generator -- checked by (1) batch independence: the losses of a 2-sample step are
+    the means of the 1-sample steps (same dropout rows), (2) bitwise repeatability, (3) directional derivatives:
+    d(disc loss)/d(theta_D) against D's gradients and d(gen total loss)/d(theta_G) -- which runs through the
+    discriminator's input gradient -- against G's gradients."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import CGANEngine
+    H, B = 512, 2
+    gen = PM.unet_pin('unet', 5, 1, hr_size=(H, H), n_filters=8, n_blocks=6, decoder_upsampling='dc', seed=3)
+    disc = PM.residual_discriminator(5, 'pin', False, 8, (H // 8, H // 8), n_filters=8, hr_size=(H, H), seed=4)
+    assert gen.count_params() == 13566325 and disc.count_params() == 16177
+    rng = np.random.default_rng(1005)
+    for m in (gen, disc):
+        _randomise_biases(m, seed=int(rng.integers(1 << 30)))
+    lr = rng.random((B, H, H, 5)).astype(np.float32)
+    st = rng.random((B, H, H, 1)).astype(np.float32)
+    hr = rng.random((B, H, H, 1)).astype(np.float32)
+    mask = (rng.random((2 * B, 16)) > 0.4).astype(np.float32)            # rows: real 0..B-1, fake 0..B-1
+    eng = CGANEngine(gen, disc, loss='mse')                              # smooth pixel loss for the finite differences
+    base = eng.step([lr, st], hr, dropout_keep=mask, apply_update=False)
+    assert all(np.isfinite(base))
+    assert base[0] == pytest.approx(base[1] + 100.0 * base[2], rel=1e-5)
+    gg, gd = gen.get_gradients(), disc.get_gradients()
+    # (2) repeatable bit for bit, losses and both gradient sets
+    again = eng.step([lr, st], hr, dropout_keep=mask, apply_update=False)
+    assert again == base
+    for a, b in ((gg, gen.get_gradients()), (gd, disc.get_gradients())):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    # (1) batch independence: every loss is a mean over the batch
+    singles = [eng.step([lr[i:i + 1], st[i:i + 1]], hr[i:i + 1], dropout_keep=mask[[i, B + i]], apply_update=False)
+               for i in range(B)]
+    for j in range(4):
+        assert base[j] == pytest.approx(np.mean([s[j] for s in singles]), rel=2e-5), j
+    # (3) directional derivatives, one model at a time (the other one's weights stay fixed)
+    for model, grads, idx, rel_tol in ((disc, gd, 3, 3e-2), (gen, gg, 0, 3e-2)):
+        w = model.get_weights()
+        d = {k: rng.standard_normal(v.shape).astype(np.float32) * (np.abs(v).mean() + 1e-3) for k, v in w.items()}
+        gdot = sum(float((grads[k].astype(np.float64) * d[k]).sum()) for k in w)
+        eps = 1e-3
+        ls = []
+        for sgn in (+1.0, -1.0):
+            model.set_weights({k: (w[k] + np.float32(sgn * eps) * d[k]).astype(np.float32) for k in w})
+            ls.append(eng.step([lr, st], hr, dropout_keep=mask, apply_update=False)[idx])
+        model.set_weights(w)
+        fd = (ls[0] - ls[1]) / (2 * eps)
+        assert fd == pytest.approx(gdot, rel=rel_tol, abs=1e-4 * abs(base[idx])), (model.name, fd, gdot)

@@ -557,3 +557,64 @@ def test_random_builder_combinations(i):
     gscale = max(np.abs(v).max() for v in grads.values())
     for k, gr in grads.items():
         assert np.abs(g_hip[k] - gr).max() / gscale < 2e-3, (k, kind, cfg, var)
+
+
+def _fusion_report(model, B):
+    import ctypes, json
+    from dl4ds_amd import _lib
+    buf = ctypes.create_string_buffer(1 << 14)
+    _lib.check(_lib.lib().dl4ds_graph_fusion_report(model.graph.h, B, buf, len(buf)))
+    return json.loads(buf.value.decode())
+
+
+@pytest.mark.parametrize('kind,kw', [
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4, lr_size=(12, 10), n_blocks=2)),
+    ('net_postupsampling', dict(backbone_block='convnet', upsampling='rc', scale=2, lr_size=(24, 20), n_blocks=1, attention=True)),
+    ('net_pin', dict(backbone_block='resnet', hr_size=(40, 36), n_blocks=2, attention=True)),
+])
+def test_attention_handed_to_neighbouring_convolutions_equals_separate_passes(monkeypatch, kind, kw):
+    """ChannelAttention2D between two convolutions (ConvBlock_att -> ConvBlock_out, sp_postups.py:204-211): pooling taken
+    from the producing convolution's epilogue, scale applied in the consumer's loads, dX = dY * scale + dmean applied in the
+    producer's backward loads -- against the same model with DL4DS_NO_TAIL_FUSION=1 (three separate passes): same forward
+    (the products are the same fp32 operations; only the pooling's summation order differs), same loss, gradients and
+    three Adam steps to fp32 rounding.  The report must show that the hand-over really happened."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import SupervisedEngine
+    build = getattr(PM, kind)
+    cfg = dict(n_channels=2, n_aux_channels=0, n_filters=8, seed=5, **kw)
+    monkeypatch.delenv('DL4DS_NO_TAIL_FUSION', raising=False)
+    fused = build(**cfg)
+    B = 3
+    rep = _fusion_report(fused, B)
+    tail = rep[-1]                                   # ConvBlock_att's attention is the last one of the graph
+    assert tail['pool_from_producer'] and tail['scale_in_consumer_load'] and tail['dx_in_producer_backward'], rep
+    monkeypatch.setenv('DL4DS_NO_TAIL_FUSION', '1')
+    plain = build(**cfg)
+    assert not any(r['pool_from_producer'] or r['scale_in_consumer_load'] or r['dx_in_producer_backward']
+                   for r in _fusion_report(plain, B))
+    rng = np.random.default_rng(3)
+    w = plain.get_weights()
+    for k in w:
+        if k.endswith('bias'):
+            w[k] = (rng.standard_normal(w[k].shape) * 0.1).astype(np.float32)
+    plain.set_weights(w); fused.set_weights(w)
+    xs = (B,) + fused.input_shapes[0]
+    x = rng.standard_normal(xs).astype(np.float32)
+    y = rng.standard_normal((B,) + fused.output_shape).astype(np.float32)
+    assert rel(fused(x), plain(x)) < 2e-6
+    ef = SupervisedEngine(fused, loss='mse', learning_rate=1e-3)
+    ep = SupervisedEngine(plain, loss='mse', learning_rate=1e-3)
+    lf, gf = ef.loss_and_grads([x], y)
+    lp, gp = ep.loss_and_grads([x], y)
+    assert lf == pytest.approx(lp, rel=1e-6)
+    gs = max(np.abs(v).max() for v in gp.values())
+    for k in gp:
+        assert np.abs(gf[k] - gp[k]).max() / gs < 2e-5, k
+    # a smaller batch after a larger one re-uses the buffers laid out for the larger (fusion addresses must stay valid)
+    assert rel(fused(x[:1]), plain(x[:1])) < 2e-6
+    for _ in range(3):
+        lf, lp = ef.step([x], y), ep.step([x], y)
+        assert lf == pytest.approx(lp, rel=1e-5)
+    wf, wp = fused.get_weights(), plain.get_weights()
+    for k in wf:
+        assert np.abs(wf[k] - wp[k]).max() < 2e-4, k          # three Adam steps of 1e-3 each; sign flips of ~0 gradients aside
