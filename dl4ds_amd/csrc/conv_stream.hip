@@ -45,6 +45,9 @@ struct StreamParams {
     int per_xcd;        // tiles per XCD (contiguous range)
     unsigned m_nblk;
     int cw;             // filter row stride = Cout, or Cout padded up to whole 16*NT blocks (zero columns) when Cout % NT != 0
+#ifdef STREAM_TRACE
+    unsigned long long* trace;   // diagnostics build: [workgroup][8] = s_memrealtime stamps at the phase boundaries + HW_ID
+#endif
 };
 
 constexpr int kStreamThreads = 256;
@@ -102,6 +105,18 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef STREAM_TRACE
+    // phase timeline of every workgroup (tools/stream_trace.py): start, [tile staged, chunk's MFMAs done] per chunk, end
+    int tr_k = 0;
+    auto stamp = [&]() {
+        if (tid == 0 && sp.trace && tr_k < 7) sp.trace[(size_t)blockIdx.x * 8 + tr_k++] = wall_clock64();
+    };
+    if (tid == 0 && sp.trace) sp.trace[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    stamp();
+#define STAMP() stamp()
+#else
+#define STAMP()
+#endif
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         if (c0 > 0) __syncthreads();
         // ---- stage the halo tile, channels [c0, c0+CK): all loads in flight, masked when written
@@ -139,6 +154,7 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
             }
         }
         __syncthreads();
+        STAMP();
 
         // ---- K loop over group-steps gs = tap*NGRP + g, software-pipelined: pixel fragments one group ahead,
         //      filter fragments WPD groups ahead (L2 latency)
@@ -194,6 +210,7 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
                                                                           acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP();
     }
 
 #ifdef STREAM_SETPRIO
@@ -253,6 +270,7 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
             }
         }
     }
+    STAMP();
 }
 
 // Output-channel counts that no NT divides (40 = RB5 of the headline backbone) used to fall back to NT = 1: 16 couts per
@@ -323,8 +341,29 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
     ProfScope ps(s, "conv_stream<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + "," +
                         std::to_string(MT) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+#ifdef STREAM_TRACE
+    // -DSTREAM_TRACE build (tools/variant_build.sh): the first launches of the tall NT = 3 variant dump their timeline
+    static unsigned long long* trace_buf = nullptr;
+    static int trace_n = 0;
+    sp.trace = nullptr;
+    if (MT == 8 && NT == 3 && trace_n < 4 && grid <= 65536) {
+        if (!trace_buf) HIP_CHECK(hipMalloc((void**)&trace_buf, (size_t)65536 * 8 * 8));
+        HIP_CHECK(hipMemsetAsync(trace_buf, 0, (size_t)65536 * 8 * 8, s));
+        sp.trace = trace_buf;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kStreamThreads), lds, s, sp);
     HIP_CHECK(hipGetLastError());
+#ifdef STREAM_TRACE
+    if (sp.trace) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)grid * 8);
+        HIP_CHECK(hipMemcpy(h.data(), trace_buf, h.size() * 8, hipMemcpyDeviceToHost));
+        char name[128];
+        std::snprintf(name, sizeof name, "gpurun_out/stream_trace_%d.bin", trace_n++);
+        if (FILE* f = std::fopen(name, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    }
+#endif
 }
 
 template <int KS, int E>
