@@ -34,10 +34,10 @@ struct PrepParams {
     int static_in_lr;       // append (block-mean / raw) static variables to lr
 };
 
-// mean over the scale x scale block (by, bx) (block coordinates in the FULL field) of channel c of a [H][W][Cn] image
-__device__ __forceinline__ float block_mean(const float* __restrict__ img, int W, int Cn, int c, int by, int bx, int s) {
+// mean over the scale x scale block whose top-left PIXEL is (py, px) of channel c of a [H][W][Cn] image
+__device__ __forceinline__ float block_mean(const float* __restrict__ img, int W, int Cn, int c, int py, int px, int s) {
     float acc = 0.f;
-    const float* p = img + ((size_t)(by * s) * W + (size_t)bx * s) * Cn + c;
+    const float* p = img + ((size_t)py * W + (size_t)px) * Cn + c;
     for (int dy = 0; dy < s; ++dy)
         for (int dx = 0; dx < s; ++dx) acc += p[((size_t)dy * W + dx) * Cn];
     return acc / (float)(s * s);
@@ -57,7 +57,10 @@ __global__ void prep_lr_kernel(const PrepParams a) {
         // absolute HR position of this output pixel (pin) or of its block's corner (post)
         const int Y = a.pin ? a.cy[b] + oy : a.cy[b] + oy * a.scale;
         const int X = a.pin ? a.cx[b] + ox : a.cx[b] + ox * a.scale;
-        const int by = Y / a.scale, bx = X / a.scale;
+        // 'pin': the WHOLE field is coarsened and re-expanded before the crop (dataloader.py:102-106), so the block is
+        // the one of the field's own LR grid that contains the pixel; post-upsampling: the crop is taken first (at any
+        // pixel) and the PATCH is coarsened (dataloader.py:201-205), so blocks are aligned with the crop corner
+        const int by = a.pin ? (Y / a.scale) * a.scale : Y, bx = a.pin ? (X / a.scale) * a.scale : X;
         const size_t frame = (size_t)(a.idx[b] + t) * a.H * a.W;
         float v;
         if (c < a.C) {

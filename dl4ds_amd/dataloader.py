@@ -3,9 +3,12 @@
 Mirrors dl4ds/dataloader.py:11-505 and dl4ds/utils.py:251-401 for the cases the trainers use: random
 square crops, coarsening by `scale` (cv2.INTER_AREA at an integer ratio == block mean), re-expansion for
 'pin' models, predictor / static-variable channel stacking, spatio-temporal windows.  OpenCV is not a
-dependency here: 'inter_area' down-scaling is an exact block mean for integer ratios; every other resize
-goes through scipy.ndimage.zoom (order 0/1/3), which is an approximation of cv2's kernels, documented in
-DESIGN.md ("next" row f1: on-device batch preparation).  Season/time-metadata channels are not implemented.
+dependency here: ``cv2.resize`` is evaluated from OpenCV's published formulas (resize.cpp) as separable
+gathers -- INTER_AREA (integer-ratio block mean; up-scaling through OpenCV's own bilinear-path coefficients,
+which replicate pixels at integer factors), INTER_NEAREST, INTER_LINEAR (half-pixel centres, edge clamp) and
+INTER_CUBIC (A = -0.75, replicated border); INTER_LANCZOS4 is refused.  oracle/dataprep.py restates the same
+formulas independently (dense per-pixel form) and tests/test_oracle_dataprep.py compares the two.
+Season/time-metadata channels are not implemented.
 """
 import numpy as np
 
@@ -28,6 +31,16 @@ def checkarray_ndim(array, ndim=3, add_axis_position=-1):
     return array
 
 
+def random_corner(sy, sx, size, rng=None):
+    """utils.py:303-304 draws ``np.random.randint(0, n - size)``: the upper bound is exclusive, so the last admissible
+    corner is never used (and a patch as large as the field raises there; here it gets corner 0).  y first, then x."""
+    rng = np.random if rng is None else rng
+    draw = (lambda hi: int(rng.randint(0, hi))) if hasattr(rng, 'randint') else (lambda hi: int(rng.integers(0, hi)))
+    y = draw(sy - size) if sy > size else 0
+    x = draw(sx - size) if sx > size else 0
+    return y, x
+
+
 def crop_array(array, size, yx=None, position=False, rng=None):
     """utils.py:251-327: square crop of a [y,x(,c)] or [t,y,x,c] array; random corner when yx is None."""
     if array.ndim not in [2, 3, 4, 5]:
@@ -41,28 +54,61 @@ def crop_array(array, size, yx=None, position=False, rng=None):
     if yx is not None:
         y, x = yx
     else:
-        rng = np.random if rng is None else rng
-        y = int(rng.randint(0, sy - size + 1)) if hasattr(rng, 'randint') else int(rng.integers(0, sy - size + 1))
-        x = int(rng.randint(0, sx - size + 1)) if hasattr(rng, 'randint') else int(rng.integers(0, sx - size + 1))
+        y, x = random_corner(sy, sx, size, rng)
     sl = [slice(None)] * array.ndim
     sl[ax], sl[ax + 1] = slice(y, y + size), slice(x, x + size)
     out = array[tuple(sl)]
     return (out, y, x) if position else out
 
 
+def _axis_taps(n_src, n_dst, interpolation):
+    """(indices [n_dst, k], weights [n_dst, k]) of cv2.resize along one axis (OpenCV resize.cpp)."""
+    d = np.arange(n_dst)
+    scale = n_src / n_dst
+    if interpolation == 'inter_area' and n_dst < n_src:
+        if n_src % n_dst:
+            raise NotImplementedError('inter_area down-scaling is implemented for integer ratios (block means)')
+        s = n_src // n_dst
+        return d[:, None] * s + np.arange(s)[None, :], np.full((n_dst, s), 1.0 / s)
+    if interpolation == 'nearest':
+        return np.minimum(np.floor(d * scale).astype(int), n_src - 1)[:, None], np.ones((n_dst, 1))
+    if interpolation in ('inter_area', 'bilinear'):
+        if interpolation == 'inter_area':        # up-scaling: OpenCV's "area" coefficients on the bilinear path
+            sx = np.floor(d * scale).astype(int)
+            f = (d + 1) - (sx + 1) / scale
+            f = np.where(f <= 0, 0.0, f - np.floor(f))
+        else:
+            c = (d + 0.5) * scale - 0.5
+            sx = np.floor(c).astype(int)
+            f = c - sx
+        lo = sx < 0
+        hi = sx >= n_src - 1
+        sx = np.where(lo, 0, np.where(hi, n_src - 1, sx))
+        f = np.where(lo | hi, 0.0, f)
+        return np.stack([sx, np.minimum(sx + 1, n_src - 1)], 1), np.stack([1.0 - f, f], 1)
+    if interpolation == 'bicubic':
+        A = -0.75
+        c = (d + 0.5) * scale - 0.5
+        sx = np.floor(c).astype(int)
+        t = c - sx
+        w0 = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A
+        w1 = ((A + 2) * t - (A + 3)) * t * t + 1
+        w2 = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
+        idx = np.clip(sx[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+        return idx, np.stack([w0, w1, w2, 1.0 - w0 - w1 - w2], 1)
+    raise NotImplementedError(f"interpolation '{interpolation}' (cv2.INTER_LANCZOS4) is not implemented")
+
+
 def _resize2d(a, size_y, size_x, interpolation):
-    """a: [y,x,c] float array."""
+    """cv2.resize of a [y,x,c] float array to (size_y, size_x), separable gathers."""
     h, w = a.shape[:2]
-    if (h, w) == (size_y, size_x):
-        return a
-    if interpolation == 'inter_area' and h % size_y == 0 and w % size_x == 0:
-        fy, fx = h // size_y, w // size_x
-        return a.reshape(size_y, fy, size_x, fx, -1).mean(axis=(1, 3))
-    if interpolation == 'inter_area' and size_y % h == 0 and size_x % w == 0:
-        return np.repeat(np.repeat(a, size_y // h, axis=0), size_x // w, axis=1)   # nearest-like up-scaling
-    from scipy import ndimage
-    order = {'nearest': 0, 'bilinear': 1, 'inter_area': 1, 'bicubic': 3, 'lanczos': 3}[interpolation]
-    return ndimage.zoom(a, (size_y / h, size_x / w, 1), order=order, mode='nearest', grid_mode=True)
+    if h != size_y:
+        idx, wt = _axis_taps(h, size_y, interpolation)
+        a = np.einsum('dk,dkxc->dxc', wt, a[idx])
+    if w != size_x:
+        idx, wt = _axis_taps(w, size_x, interpolation)
+        a = np.einsum('ek,yekc->yec', wt, a[:, idx])
+    return a
 
 
 def resize_array(array, newsize, interpolation='inter_area', squeezed=True, keep_dynamic_range=False):
@@ -116,19 +162,40 @@ def create_pair_hr_lr(array, array_lr, upsampling, scale, patch_size, static_var
             crop = (cy, cx)
     elif upsampling in POSTUPSAMPLING_METHODS:
         hr = checkarray_ndim(hr, nd)
+        ps_lr = None if patch_size is None else int(patch_size / scale)
         if lr_given:
             lr = checkarray_ndim(np.asarray(array_lr), nd)
+            lr_y, lr_x = (lr.shape[1], lr.shape[2]) if spt else (lr.shape[0], lr.shape[1])
         else:
-            lr = checkarray_ndim(resize_array(hr, (int(hr_x / scale), int(hr_y / scale)), interpolation, squeezed=False), nd)
-        lr_y, lr_x = (lr.shape[1], lr.shape[2]) if spt else (lr.shape[0], lr.shape[1])
+            lr = None
+            lr_x, lr_y = int(hr_x / scale), int(hr_y / scale)
+        p = None
         if predictors is not None:
-            p = checkarray_ndim(resize_array(predictors, (lr_x, lr_y), interpolation, squeezed=False), nd)
-            lr = np.concatenate([lr, p], axis=-1)
+            p = np.asarray(predictors)
+            if p.shape[-3] != lr_y or p.shape[-2] != lr_x:
+                p = resize_array(p, (lr_x, lr_y), interpolation, squeezed=False)
+            p = checkarray_ndim(p, nd)
         if patch_size is not None:
-            ps_lr = int(patch_size / scale)
-            lr, cy, cx = crop_array(lr, ps_lr, position=True, rng=rng)
-            hr = crop_array(hr, patch_size, yx=(int(cy * scale), int(cx * scale)))
-            crop = (int(cy * scale), int(cx * scale))
+            if lr_given or p is not None:
+                # the crop is drawn on the LR grid and scaled to the HR grid (dataloader.py:166-174,193-200)
+                cy_lr, cx_lr = random_corner(lr_y, lr_x, ps_lr, rng)
+                crop = (int(cy_lr * scale), int(cx_lr * scale))
+                hr = crop_array(hr, patch_size, yx=crop)
+                if lr_given:
+                    lr = crop_array(lr, ps_lr, yx=(cy_lr, cx_lr))
+                if p is not None:
+                    p = crop_array(p, ps_lr, yx=(cy_lr, cx_lr))
+            else:
+                # the HR field is cropped at ANY pixel and the PATCH is coarsened (dataloader.py:201-205)
+                hr, cy, cx = crop_array(hr, patch_size, position=True, rng=rng)
+                crop = (cy, cx)
+        if lr is None:
+            # (with predictors the reference resizes the cropped HR array to the FULL LR size, dataloader.py:177-178, and
+            # then fails to concatenate; the patch's own LR size is the only consistent reading)
+            ty, tx = (lr_y, lr_x) if patch_size is None else (ps_lr, ps_lr)
+            lr = checkarray_ndim(resize_array(hr, (tx, ty), interpolation, squeezed=False), nd)
+        if p is not None:
+            lr = np.concatenate([lr, p], axis=-1)
     else:
         raise ValueError(f'unknown upsampling {upsampling}')
     static_hr = None
@@ -285,19 +352,20 @@ class DeviceDataGenerator:
         return self._draw_for(self.indices[index * self.batch_size:(index + 1) * self.batch_size])
 
     def _draw_for(self, sample_indices):
-        """Crop corners (HR pixels) for the given samples, with the RNG calls of create_pair_hr_lr / crop_array."""
+        """Crop corners (HR pixels) for the given samples, with the RNG calls of create_pair_hr_lr / crop_array: 'pin' and
+        post-upsampling without predictors crop the HR field at any pixel (dataloader.py:107-112,201-205); with predictors
+        the corner is drawn on the LR grid and scaled (dataloader.py:166-174)."""
         idx = np.asarray(sample_indices, np.int32)
         cy = np.zeros(len(idx), np.int32)
         cx = np.zeros(len(idx), np.int32)
         if self.patch_size is not None:
             for b in range(len(idx)):
-                if self.pin:
-                    cy[b] = int(self.rng.integers(0, self.H - self.patch_size + 1))
-                    cx[b] = int(self.rng.integers(0, self.W - self.patch_size + 1))
+                if self.pin or self.P == 0:
+                    cy[b], cx[b] = random_corner(self.H, self.W, self.patch_size, self.rng)
                 else:
                     ps_lr = self.patch_size // self.scale
-                    cy[b] = int(self.rng.integers(0, self.H // self.scale - ps_lr + 1)) * self.scale
-                    cx[b] = int(self.rng.integers(0, self.W // self.scale - ps_lr + 1)) * self.scale
+                    y, x = random_corner(self.H // self.scale, self.W // self.scale, ps_lr, self.rng)
+                    cy[b], cx[b] = y * self.scale, x * self.scale
         return idx, cy, cx
 
     def __getitem__(self, index):

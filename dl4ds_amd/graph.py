@@ -431,13 +431,39 @@ class Model:
         return out
 
     def predict(self, inputs, batch_size=32, verbose=0):
+        """model.predict.  The reference builds its generators on ``Input(shape=(None, None, C))`` (sp_postups.py:112-115),
+        so a trained model predicts on ANY grid; the graph here is planned for the grid it was built with, so an input of
+        another size runs on a sibling graph planned for that size (cached per grid) that receives the current weights."""
         if isinstance(inputs, np.ndarray):
             inputs = [inputs]
-        n = inputs[0].shape[0]
+        first = np.asarray(inputs[0])
+        grid = tuple(first.shape[-3:-1])
+        if grid != tuple(self.input_shapes[0][-3:-1]):
+            return self.resized(grid).predict(inputs, batch_size=batch_size, verbose=verbose)
+        n = first.shape[0]
         outs = []
         for i in range(0, n, batch_size):
             outs.append(self([a[i:i + batch_size] for a in inputs], training=False))
         return np.concatenate(outs, axis=0)
+
+    def resized(self, grid):
+        """The same architecture planned for inputs of spatial size ``grid`` (size of the FIRST input: the LR grid of a
+        post-upsampling model, the HR grid of a 'pin' model), carrying this model's current weights."""
+        rb = getattr(self, '_rebuild', None)
+        if rb is None:
+            raise ValueError(f'model {self.name} was not built by a dl4ds_amd.models builder: cannot re-plan it for grid {grid}')
+        fn, kwargs, size_key = rb
+        if kwargs.get('localcon_layer'):
+            # LocallyConnected2D weights are per grid point: the reference fixes the Input shape too (sp_postups.py:106-115)
+            raise ValueError('a model with localcon_layer=True is tied to the grid it was built for')
+        cache = self.__dict__.setdefault('_resized_cache', {})
+        grid = (int(grid[0]), int(grid[1]))
+        m = cache.get(grid)
+        if m is None:
+            m = fn(**dict(kwargs, **{size_key: grid}))
+            cache[grid] = m
+        m.set_weights(self.get_weights())
+        return m
 
     def summary(self, line_length=100, print_fn=print):
         print_fn(f'Model: "{self.name}"')
@@ -446,3 +472,23 @@ class Model:
             print_fn(f'{name[:50]:52s}{kind:24s}{str(shape)}')
         print_fn('=' * line_length)
         print_fn(f'Total params: {self.count_params():,}')
+
+
+def resizable(size_key):
+    """Decorator of the model builders: remembers the call so that ``Model.predict`` can re-plan the graph for another
+    grid (``size_key``: the builder argument that holds the grid of the first input, 'lr_size' or 'hr_size')."""
+    import functools
+    import inspect
+
+    def deco(fn):
+        sig = inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kw):
+            model = fn(*args, **kw)
+            bound = sig.bind(*args, **kw)
+            bound.apply_defaults()
+            model._rebuild = (wrapper, dict(bound.arguments), size_key)
+            return model
+        return wrapper
+    return deco

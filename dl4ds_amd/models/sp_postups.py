@@ -1,6 +1,6 @@
 """net_postupsampling -- same signature as dl4ds/models/sp_postups.py:14-32, graph per :95-217."""
 import os
-from ..graph import GraphBuilder, Model
+from ..graph import GraphBuilder, Model, resizable
 from ..utils import checkarg_backbone, checkarg_upsampling, checkarg_dropout_variant
 from .blocks import (conv_block, residual_block, dense_block, transition_block, localized_conv_block,
                      subpixel_block, resize_conv_block, deconv_block, convnext_block, _reject_unsupported)
@@ -75,6 +75,7 @@ def tail_section(g, x, s_in, init_n_filters, n_filters_aux, n_channels_out, acti
                       normalization=normalization, attention=False)
 
 
+@resizable('lr_size')
 def net_postupsampling(backbone_block, upsampling, scale, n_channels, n_aux_channels, lr_size,
                        n_channels_out=1, n_filters=8, n_blocks=6, normalization=None, dropout_rate=0,
                        dropout_variant=None, attention=False, activation='relu', output_activation=None,

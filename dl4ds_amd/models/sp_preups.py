@@ -1,11 +1,12 @@
 """net_pin / unet_pin -- same signatures as dl4ds/models/sp_preups.py:13-28,192-209."""
-from ..graph import GraphBuilder, Model
+from ..graph import GraphBuilder, Model, resizable
 from ..utils import checkarg_backbone, checkarg_dropout_variant
 from .blocks import (conv_block, subpixel_block, resize_conv_block, deconv_block, pad_concat,
                      _reject_unsupported)
 from .sp_postups import backbone_section, tail_section
 
 
+@resizable('hr_size')
 def net_pin(backbone_block, n_channels, n_aux_channels, hr_size, n_channels_out=1, n_filters=8, n_blocks=6,
             dropout_rate=0, dropout_variant=None, normalization=None, attention=False, activation='relu',
             output_activation=None, localcon_layer=False, seed=None):
@@ -34,6 +35,7 @@ def _check_nblocks(shape, power):
     return power
 
 
+@resizable('hr_size')
 def unet_pin(backbone_block, n_channels, n_aux_channels, n_filters, n_blocks, hr_size, n_channels_out=1,
              activation='relu', dropout_rate=0, dropout_variant=None, normalization=None, attention=False,
              decoder_upsampling='rc', rc_interpolation='bilinear', output_activation=None, width_cap=256,

@@ -1,6 +1,6 @@
 """recnet_postupsampling -- same signature as dl4ds/models/spt_postups.py:12-31, graph per :96-163.
 5-D tensors (B,T,H,W,C) are graph tensors with batch multiplier T (TimeDistributed = fold T into N)."""
-from ..graph import GraphBuilder, Model
+from ..graph import GraphBuilder, Model, resizable
 from ..utils import checkarg_backbone, checkarg_upsampling, checkarg_dropout_variant
 from .blocks import (recurrent_conv_block, conv_block, transition_block, localized_conv_block,
                      subpixel_block, resize_conv_block, deconv_block)
@@ -40,6 +40,7 @@ def rec_tail(g, x, s_in, n_filters, n_channels_out, time_window, activation, out
                       normalization=normalization)
 
 
+@resizable('lr_size')
 def recnet_postupsampling(backbone_block, upsampling, scale, n_channels, n_aux_channels, lr_size, time_window,
                           n_channels_out=1, n_filters=8, n_blocks=4, dropout_rate=0, dropout_variant=None,
                           normalization=None, attention=False, activation='relu', output_activation=None,

@@ -1,9 +1,10 @@
 """recnet_pin -- same signature as dl4ds/models/spt_preups.py:12-28, graph per :85-144."""
-from ..graph import GraphBuilder, Model
+from ..graph import GraphBuilder, Model, resizable
 from ..utils import checkarg_backbone, checkarg_dropout_variant
 from .spt_postups import rec_backbone, rec_tail
 
 
+@resizable('hr_size')
 def recnet_pin(backbone_block, n_channels, n_aux_channels, hr_size, time_window, n_channels_out=1, n_filters=8,
                n_blocks=6, dropout_rate=0, dropout_variant=None, normalization=None, attention=False,
                activation='relu', output_activation=None, localcon_layer=False, seed=None):

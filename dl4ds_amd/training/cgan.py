@@ -177,3 +177,114 @@ class CGANTrainer(Trainer):
         np.savez(os.path.join(d, f'save_epoch{epoch}_generator_weights.npz'), **self.generator.get_weights())
 
     fit = run
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's module-level functions of this file (cgan.py:447-639).  The arithmetic of all of them runs inside
+# libdl4ds_hip (csrc/cgan.hip, csrc/losses.hip); they are thin, same-named entry points over CGANEngine so that code
+# written against ``dl4ds.training.cgan`` finds them here.
+def _loss_name(f):
+    name = f if isinstance(f, str) else getattr(f, '__name__', None)
+    from ..ops import LOSS_KINDS
+    if name not in LOSS_KINDS:
+        raise ValueError(f'`gen_pxloss_function` must be one of dl4ds_amd.losses ({sorted(LOSS_KINDS)}), got {f!r}')
+    return name
+
+
+def generator_loss(disc_generated_output, gen_output, target, gen_pxloss_function, lambda_scaling_factor=100):
+    """cgan.py:525-553: (total, gan, px) with gan = BCE(ones, D(x, G(x))) and total = gan + lambda * px."""
+    from .. import ops
+    gan_loss, _ = ops.bce(np.asarray(disc_generated_output, np.float32), 1.0)
+    px_loss, _ = ops.loss(_loss_name(gen_pxloss_function), np.asarray(target, np.float32), np.asarray(gen_output, np.float32),
+                          want_grad=False)
+    return gan_loss + lambda_scaling_factor * px_loss, gan_loss, px_loss
+
+
+def discriminator_loss(disc_real_output, disc_generated_output):
+    """cgan.py:556-572: BCE(ones, D(x, y)) + BCE(zeros, D(x, G(x)))."""
+    from .. import ops
+    real_loss, _ = ops.bce(np.asarray(disc_real_output, np.float32), 1.0)
+    generated_loss, _ = ops.bce(np.asarray(disc_generated_output, np.float32), 0.0)
+    return real_loss + generated_loss
+
+
+class _OptimizerHandle:
+    """Stands in for the tf.keras.optimizers.Adam objects the reference threads through train_step / load_checkpoint:
+    both Adam states live inside one CGANEngine; the handle says which of them it is."""
+
+    def __init__(self, engine, which):
+        self.engine, self.which = engine, which
+
+    @property
+    def iterations(self):
+        return self.engine.optimizer_state(self.which)[2]
+
+    def variables(self):
+        m, v, step = self.engine.optimizer_state(self.which)
+        return [np.int64(step)] + [a for pair in zip(m.values(), v.values()) for a in pair]
+
+
+def make_optimizers(generator, discriminator, gen_pxloss_function='mae', learning_rates=(2e-4, 2e-4), beta_1=0.5):
+    """The two Adam(lr, beta_1=0.5) optimisers of cgan.py:271-278 as handles on one CGANEngine."""
+    eng = CGANEngine(generator, discriminator, loss=_loss_name(gen_pxloss_function), learning_rate=learning_rates, beta_1=beta_1)
+    return _OptimizerHandle(eng, 'generator'), _OptimizerHandle(eng, 'discriminator')
+
+
+def train_step(lr_array, hr_array, generator, discriminator, generator_optimizer, discriminator_optimizer, epoch=0,
+               gen_pxloss_function='mae', summary_writer=None, first_batch=False, static_array=None):
+    """cgan.py:575-639 with the same argument list: one simultaneous generator + discriminator update; returns
+    (gen_total_loss, gen_gan_loss, gen_px_loss, disc_loss).  The optimisers are the handles of ``make_optimizers`` (or of
+    ``load_checkpoint``); with several ranks the first batch broadcasts variables and optimiser slots from rank 0."""
+    eng = generator_optimizer.engine
+    if eng is not discriminator_optimizer.engine or eng.generator is not generator or eng.discriminator is not discriminator:
+        raise ValueError('train_step: the optimisers must come from make_optimizers / load_checkpoint for these two models')
+    inputs = [lr_array] if static_array is None else [lr_array, static_array]
+    out = eng.step(inputs, hr_array)
+    if first_batch and parallel.rank_world_from_env()[1] > 1 and parallel.is_initialized():
+        parallel.broadcast_trainer(eng)              # cgan.py:626-637
+    return out
+
+
+def load_checkpoint(checkpoint_dir, checkpoint_number, backbone, upsampling, scale, input_height_width, n_static_vars=0,
+                    n_predictors=0, time_window=None, n_blocks=(20, 4), n_filters=(8, 32), attention=False,
+                    localcon_layer=False):
+    """cgan.py:447-522: rebuild generator + discriminator with the same arguments, restore the checkpoint
+    ``<checkpoint_dir>/checkpoint_epoch-<checkpoint_number>`` (the .npz this package's CGANTrainer writes,
+    training/cgan.py::_save_checkpoint) into them and both Adam states; returns
+    (generator, generator_optimizer, discriminator, discriminator_optimizer)."""
+    import os
+    n_channels, n_aux_channels = 1, 0
+    if n_static_vars > 0:
+        n_channels += n_static_vars
+        n_aux_channels += n_static_vars
+    if n_predictors > 0:
+        n_channels += n_predictors
+    spt = time_window is not None and time_window > 1
+    gkw = dict(n_filters=n_filters[0], n_blocks=n_blocks[0], n_channels_out=1, attention=attention, localcon_layer=localcon_layer)
+    if upsampling in POSTUPSAMPLING_METHODS:
+        if spt:
+            generator = M.recnet_postupsampling(backbone_block=backbone, upsampling=upsampling, scale=scale, n_channels=n_channels,
+                                                n_aux_channels=n_aux_channels, lr_size=input_height_width, time_window=time_window,
+                                                **gkw)
+        else:
+            generator = M.net_postupsampling(backbone_block=backbone, upsampling=upsampling, scale=scale, n_channels=n_channels,
+                                             n_aux_channels=n_aux_channels, lr_size=input_height_width, **gkw)
+        lr_size = tuple(input_height_width)
+        hr_size = (int(lr_size[0] * scale), int(lr_size[1] * scale))
+    elif upsampling == 'pin':
+        if spt:
+            generator = M.recnet_pin(backbone_block=backbone, n_channels=n_channels, n_aux_channels=n_aux_channels,
+                                     hr_size=input_height_width, time_window=time_window, **gkw)
+        else:
+            generator = M.net_pin(backbone_block=backbone, n_channels=n_channels, n_aux_channels=n_aux_channels,
+                                  hr_size=input_height_width, **gkw)
+        hr_size = tuple(input_height_width)
+        lr_size = hr_size
+    else:
+        raise ValueError(f'unknown upsampling {upsampling}')
+    discriminator = M.residual_discriminator(n_channels=n_channels, upsampling=upsampling, is_spatiotemporal=spt, scale=scale,
+                                             lr_size=lr_size, hr_size=hr_size, time_window=time_window, n_filters=n_filters[1],
+                                             n_res_blocks=n_blocks[1], attention=attention)
+    gopt, dopt = make_optimizers(generator, discriminator, 'mae', (2e-4, 2e-4), beta_1=0.5)       # cgan.py:513-514
+    gopt.engine.load_checkpoint(os.path.join(checkpoint_dir, f'checkpoint_epoch-{checkpoint_number}.npz'))
+    return generator, gopt, discriminator, dopt

@@ -320,3 +320,84 @@ def test_cgan_checkpoint_resume_and_trainer_files(tmp_path):
     t.run()
     files = sorted(os.listdir(tmp_path / 'checkpoints'))
     assert 'checkpoint_epoch-1.npz' in files and 'checkpoint_epoch-2.npz' in files and 'save_epoch2_generator_weights.npz' in files
+
+
+def test_cgan_module_level_functions(tmp_path):
+    """training/cgan.py:447-639: generator_loss, discriminator_loss, train_step and load_checkpoint under their own names."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import cgan as C
+    from dl4ds_amd import losses
+    rng = np.random.default_rng(0)
+    B, H = 2, 16
+    d_real, d_fake = rng.random((B, 1)).astype(np.float32) * 0.8 + 0.1, rng.random((B, 1)).astype(np.float32) * 0.8 + 0.1
+    gen_out, target = rng.random((B, H, H, 1)).astype(np.float32), rng.random((B, H, H, 1)).astype(np.float32)
+    tot, gan, px = C.generator_loss(d_fake, gen_out, target, losses.mae)
+    assert gan == pytest.approx(float(-np.log(d_fake).mean()), rel=1e-5)
+    assert px == pytest.approx(float(np.abs(gen_out - target).mean()), rel=1e-5) and tot == pytest.approx(gan + 100 * px, rel=1e-6)
+    tot10 = C.generator_loss(d_fake, gen_out, target, 'mse', lambda_scaling_factor=10)[0]
+    assert tot10 == pytest.approx(gan + 10 * float(((gen_out - target) ** 2).mean()), rel=1e-5)
+    dl = C.discriminator_loss(d_real, d_fake)
+    assert dl == pytest.approx(float(-np.log(d_real).mean() - np.log(1 - d_fake).mean()), rel=1e-5)
+    # train_step with optimiser handles; checkpoint written by CGANTrainer restored by load_checkpoint
+    tr, te = _fields(8, 16, 0), _fields(4, 16, 1)
+    topo = rng.random((16, 16)).astype(np.float32)
+    t = C.CGANTrainer('resnet', 'pin', tr, te, static_vars=[topo], scale=2, batch_size=4, epochs=1, verbose=False,
+                      checkpoints_frequency=1, save_path=str(tmp_path) + '/',
+                      generator_params=dict(n_filters=4, n_blocks=2), discriminator_params=dict(n_filters=4, n_res_blocks=1))
+    t.run()
+    g, gopt, d, dopt = C.load_checkpoint(str(tmp_path / 'checkpoints'), 1, 'resnet', 'pin', 2, (16, 16), n_static_vars=1,
+                                         n_blocks=(2, 1), n_filters=(4, 4))
+    for k, v in t.generator.get_weights().items():
+        np.testing.assert_array_equal(g.get_weights()[k], v)
+    for k, v in t.discriminator.get_weights().items():
+        np.testing.assert_array_equal(d.get_weights()[k], v)
+    assert gopt.iterations == dopt.iterations == t.engine.optimizer_state('generator')[2] == 2
+    lr_b = rng.random((4, 16, 16, 2)).astype(np.float32)
+    st_b = rng.random((4, 16, 16, 1)).astype(np.float32)
+    hr_b = rng.random((4, 16, 16, 1)).astype(np.float32)
+    out = C.train_step(lr_b, hr_b, g, d, gopt, dopt, 0, losses.mae, None, True, static_array=st_b)
+    assert len(out) == 4 and all(np.isfinite(out)) and gopt.iterations == 3
+    with pytest.raises(ValueError):
+        C.train_step(lr_b, hr_b, t.generator, d, gopt, dopt, 0, 'mae', None, False, static_array=st_b)
+
+
+def test_msdssim_loss_callables_exist_and_agree_with_the_kernels():
+    from dl4ds_amd import losses, ops
+    rng = np.random.default_rng(1)
+    a, b = rng.random((2, 96, 96, 1)).astype(np.float32), rng.random((2, 96, 96, 1)).astype(np.float32)
+    for name in ('msdssim', 'msdssim_mae', 'msdssim_mae_mse', 'dssim', 'mae'):
+        f = getattr(losses, name)
+        assert f.__name__ == name
+        assert f(a, b) == ops.loss(name, a, b, want_grad=False)[0]
+    assert losses.msdssim(a, a) == pytest.approx(0.0, abs=1e-6)
+
+
+def test_predict_on_a_grid_other_than_the_one_the_model_was_built_for():
+    """The reference generators take Input(shape=(None, None, C)) (sp_postups.py:112-115): a trained model predicts on any
+    grid.  Model.predict re-plans the graph for the new grid with the current weights -- the result must equal a model
+    built for that grid directly, and follow later weight changes."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.inference import Predictor
+    rng = np.random.default_rng(2)
+    m = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (16, 16), n_blocks=2, n_filters=8, seed=1)
+    w = m.get_weights()
+    for k in w:
+        if k.endswith('bias'):
+            w[k] = (rng.standard_normal(w[k].shape) * 0.1).astype(np.float32)
+    m.set_weights(w)
+    x = rng.standard_normal((3, 24, 20, 1)).astype(np.float32)
+    direct = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (24, 20), n_blocks=2, n_filters=8, seed=9)
+    direct.set_weights(w)
+    y = m.predict(x, batch_size=2)
+    assert y.shape == (3, 96, 80, 1)
+    np.testing.assert_array_equal(y, direct.predict(x, batch_size=2))
+    np.testing.assert_array_equal(Predictor(m, x, scale=4, batch_size=3).run(), y)       # LR array in, other domain size
+    w2 = {k: (v * np.float32(0.5)).astype(np.float32) for k, v in w.items()}
+    m.set_weights(w2); direct.set_weights(w2)
+    np.testing.assert_array_equal(m.predict(x), direct.predict(x))                        # cached sibling follows the weights
+    pin = PM.unet_pin('unet', 2, 1, hr_size=(32, 32), n_filters=4, n_blocks=2, seed=3)
+    xs = [rng.standard_normal((2, 48, 40, 2)).astype(np.float32), rng.standard_normal((2, 48, 40, 1)).astype(np.float32)]
+    assert pin.predict(xs).shape == (2, 48, 40, 1)
+    lcb = PM.net_postupsampling('resnet', 'spc', 2, 1, 0, (16, 16), n_blocks=1, localcon_layer=True, seed=1)
+    with pytest.raises(ValueError, match='localcon_layer'):
+        lcb.predict(rng.standard_normal((1, 20, 20, 1)).astype(np.float32))
