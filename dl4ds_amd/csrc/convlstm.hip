@@ -32,7 +32,7 @@ __global__ void gates_fwd_kernel(TView z, TView cp, TView c, TView h, TView out,
         if (!first) cc += fg * cp.p[view_off(cp, n, y, x, f)];
         const float hh = o * tanhf(cc);
         c.p[view_off(c, n, y, x, f)] = cc;
-        h.p[view_off(h, n, y, x, f)] = hh;
+        if (h.p) h.p[view_off(h, n, y, x, f)] = hh;        // (null at the last step: nobody reads h_{T-1} as a recurrent input)
         out.p[view_off(out, n, y, x, f)] = relu ? fmaxf(hh, 0.f) : hh;
     }
 }

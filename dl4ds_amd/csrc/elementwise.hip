@@ -111,6 +111,61 @@ __global__ void view_axpy_kernel(TView src, TView dst, float alpha, int accumula
     }
 }
 
+// channel-slice copies (Concatenate forward / backward: one side is a [C]-wide slice of a wider pixel): float4 per thread,
+// pixel-major so that a wave covers whole pixels back to back; pixel strides in floats, images contiguous (nstride = H*W*ld)
+__global__ void strided_axpy4_kernel(const float* __restrict__ src, int ld_s, float* __restrict__ dst, int ld_d, int c4n,
+                                     size_t step_pix, int step_c4, float alpha, int accumulate, size_t total4) {
+    // element e = pix * c4n + c4; one division per thread, then (pix, c4) advance by the grid stride's quotient / remainder
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t pix = e / (size_t)c4n;
+    int c4 = (int)(e - pix * (size_t)c4n);
+    for (; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4*>(src + pix * (size_t)ld_s + (size_t)c4 * 4);
+        v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        float4* d = reinterpret_cast<float4*>(dst + pix * (size_t)ld_d + (size_t)c4 * 4);
+        if (accumulate) {
+            const float4 o = *d;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *d = v;
+        pix += step_pix; c4 += step_c4;
+        if (c4 >= c4n) { c4 -= c4n; ++pix; }
+    }
+}
+
+// dst (+)= src * [mask > 0]: float4, strided pixels on all three sides (see strided_axpy4_kernel)
+__global__ void strided_masked_axpy4_kernel(const float* __restrict__ src, int ld_s, const float* __restrict__ mask, int ld_m,
+                                            float* __restrict__ dst, int ld_d, int c4n, size_t step_pix, int step_c4,
+                                            int accumulate, size_t total4) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t pix = e / (size_t)c4n;
+    int c4 = (int)(e - pix * (size_t)c4n);
+    for (; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4*>(src + pix * (size_t)ld_s + (size_t)c4 * 4);
+        const float4 m = *reinterpret_cast<const float4*>(mask + pix * (size_t)ld_m + (size_t)c4 * 4);
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        float4* d = reinterpret_cast<float4*>(dst + pix * (size_t)ld_d + (size_t)c4 * 4);
+        if (accumulate) {
+            const float4 o = *d;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *d = v;
+        pix += step_pix; c4 += step_c4;
+        if (c4 >= c4n) { c4 -= c4n; ++pix; }
+    }
+}
+__global__ void view_masked_axpy_kernel(TView src, TView mask, TView dst, int accumulate, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % src.C);
+        int n, y, x;
+        unflatten_pix(src, e / src.C, n, y, x);
+        float v = src.p[view_off(src, n, y, x, c)];
+        v = mask.p[view_off(mask, n, y, x, c)] > 0.f ? v : 0.f;
+        const size_t o = view_off(dst, n, y, x, c);
+        dst.p[o] = accumulate ? dst.p[o] + v : v;
+    }
+}
+
 __global__ void flat_axpy4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, float alpha,
                                   int accumulate, size_t n4) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
@@ -191,7 +246,7 @@ __global__ void maxpool2_fwd_kernel(TView x, TView y, size_t total) {
 // one thread per OUTPUT element writes its 2x2 input window (windows are disjoint -> no atomics);
 // gradient goes to the first maximum in row-major window order.  Rows/cols dropped by the VALID
 // pooling (odd H or W) must have been zero-filled / left untouched by the caller.
-__global__ void maxpool2_bwd_kernel(TView x, TView y, TView dy, TView dx, int accumulate, size_t total) {
+__global__ void maxpool2_bwd_kernel(TView x, TView y, TView dy, TView dx, int accumulate, int relu_mask, size_t total) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % y.C);
         int n, oy, ox;
@@ -205,6 +260,7 @@ __global__ void maxpool2_bwd_kernel(TView x, TView y, TView dy, TView dx, int ac
             const float xv = x.p[view_off(x, n, iy, ix, c)];
             float gv = 0.f;
             if (!found && xv == m) { gv = g; found = true; }
+            if (relu_mask && !(xv > 0.f)) gv = 0.f;
             const size_t o = view_off(dx, n, iy, ix, c);
             dx.p[o] = accumulate ? dx.p[o] + gv : gv;
         }
@@ -403,8 +459,38 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
     if (plain_contig(src) && plain_contig(dst) && (total & 3) == 0 && ((((uintptr_t)src.p) | ((uintptr_t)dst.p)) & 15) == 0) {
         hipLaunchKernelGGL(flat_axpy4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
                            reinterpret_cast<const float4*>(src.p), reinterpret_cast<float4*>(dst.p), alpha, accumulate, total / 4);
+    } else if (src.d2s <= 1 && dst.d2s <= 1 && (src.C & 3) == 0 && (src.ld & 3) == 0 && (dst.ld & 3) == 0 &&
+               ((((uintptr_t)src.p) | ((uintptr_t)dst.p)) & 15) == 0 && src.nstride == (size_t)src.H * src.W * src.ld &&
+               dst.nstride == (size_t)dst.H * dst.W * dst.ld) {
+        const int c4n = src.C / 4;
+        const int blocks = ew_blocks(total / 4);
+        const size_t stride = (size_t)blocks * 256;
+        hipLaunchKernelGGL(strided_axpy4_kernel, dim3(blocks), dim3(256), 0, s, src.p, src.ld, dst.p, dst.ld, c4n,
+                           stride / (size_t)c4n, (int)(stride % (size_t)c4n), alpha, accumulate, total / 4);
     } else {
         hipLaunchKernelGGL(view_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, dst, alpha, accumulate, total);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void view_axpy_masked(hipStream_t s, const TView& src, const TView& mask, const TView& dst, int accumulate) {
+    if (mask.p == nullptr) { view_axpy(s, src, dst, 1.f, accumulate); return; }
+    DL4DS_REQUIRE(src.N == dst.N && src.H == dst.H && src.W == dst.W && src.C == dst.C && mask.C == src.C && mask.N == src.N,
+                  "view_axpy_masked: shape mismatch");
+    const size_t total = (size_t)src.N * src.H * src.W * src.C;
+    if (total == 0) return;
+    ProfScope ps(s, "view_axpy_masked", 0.0, 4.0 * (double)total * (3 + (accumulate ? 1 : 0)));
+    auto ok4 = [](const TView& v) {
+        return v.d2s <= 1 && (v.ld & 3) == 0 && (((uintptr_t)v.p) & 15) == 0 && v.nstride == (size_t)v.H * v.W * v.ld;
+    };
+    if ((src.C & 3) == 0 && ok4(src) && ok4(mask) && ok4(dst)) {
+        const int c4n = src.C / 4;
+        const int blocks = ew_blocks(total / 4);
+        const size_t stride = (size_t)blocks * 256;
+        hipLaunchKernelGGL(strided_masked_axpy4_kernel, dim3(blocks), dim3(256), 0, s, src.p, src.ld, mask.p, mask.ld, dst.p,
+                           dst.ld, c4n, stride / (size_t)c4n, (int)(stride % (size_t)c4n), accumulate, total / 4);
+    } else {
+        hipLaunchKernelGGL(view_masked_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, mask, dst, accumulate, total);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -460,12 +546,13 @@ void maxpool2_forward(hipStream_t s, const TView& x, const TView& y) {
     hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, total);
     HIP_CHECK(hipGetLastError());
 }
-void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TView& dy, const TView& dx, int accumulate) {
+void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TView& dy, const TView& dx, int accumulate,
+                       int relu_mask) {
     DL4DS_REQUIRE((x.H % 2 == 0 && x.W % 2 == 0) || accumulate,
                   "maxpool2 backward with odd sizes needs a pre-zeroed accumulate target");
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     ProfScope ps(s, "maxpool2_bwd", 0.0, 4.0 * (double)total * (2 + 4 + 4 + (accumulate ? 4 : 0)));
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, dy, dx, accumulate, total);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, dy, dx, accumulate, relu_mask, total);
     HIP_CHECK(hipGetLastError());
 }
 

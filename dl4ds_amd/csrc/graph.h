@@ -23,6 +23,7 @@ struct GTensor {
     // consumers: as the convolved input of a Conv2D / as anything else (residual operand, concat, pooling, ...)
     int n_conv_in = 0, n_other = 0;
     int n_add_in = 0;          // ... as an operand of an Add (which can apply the ReLU mask while copying its gradient)
+    int n_masking = 0;         // ... as an input of a Concatenate / MaxPooling2D (their backward applies the mask, too)
     // ReLU backward fused into the writers: every consumer is a Conv2D (or an Add), whose dgrad epilogue zeroes the gradient
     // where this activation is <= 0 (the mask is linear, so each accumulating writer applies it independently)
     bool grad_masked = false;

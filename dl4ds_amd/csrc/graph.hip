@@ -272,7 +272,7 @@ struct ConvOp : GOp {
             bool is_output = false;
             for (int o : g.outputs) is_output |= (o == add);
             add_grad_shared = !r.is_input && !is_output && r.requires_grad && r.n_conv_in == 0 && r.n_add_in == 0 &&
-                              r.n_other == 1 && r.per_sample() == g.tensors[out].per_sample();
+                              r.n_masking == 0 && r.n_other == 1 && r.per_sample() == g.tensors[out].per_sample();
         }
         wt_off = g.reserve_wt(g.params[w].n);
         g.add_wt_job(g.params[w].offset, false, wt_off, KS * KS, g.tensors[in].C, Cout);
@@ -281,7 +281,8 @@ struct ConvOp : GOp {
         GTensor& t = g.tensors[out];
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
-        t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_add_in) >= 1 && t.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
+        t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_add_in + t.n_masking) >= 1 && t.n_other == 0 &&
+                        !getenv("DL4DS_NO_MASK_FUSION");
     }
     TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
         const GTensor& ti = g.tensors[in];
@@ -397,7 +398,7 @@ struct ChAttOp : GOp {
         const GTensor& ti = g.tensors[in];
         const GTensor& to = g.tensors[out];
         auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
-        const bool in_private = !is_output(in) && ti.n_conv_in == 0 && ti.n_add_in == 0 && ti.n_other == 1;     // only this op reads it
+        const bool in_private = !is_output(in) && ti.n_conv_in == 0 && ti.n_add_in == 0 && ti.n_masking == 0 && ti.n_other == 1;     // only this op reads it
         // ---- pooling partials from the producer's epilogue
         if (producer && producer->d2s <= 1 && ti.C <= 8) {
             ConvEpilogue ep;
@@ -407,7 +408,7 @@ struct ChAttOp : GOp {
             fz.fuse_pool = !conv2d_direct_eligible(pin, pout, producer->KS) && conv2d_narrow_pair_ok(pin, pout, producer->KS, ep);
         }
         // ---- scale applied by the consumer's loads: `out` has exactly one reader, a 3x3 convolution on the stencil kernels
-        if (consumer && !is_output(out) && to.n_conv_in == 1 && to.n_add_in == 0 && to.n_other == 0 && consumer->KS == 3) {
+        if (consumer && !is_output(out) && to.n_conv_in == 1 && to.n_add_in == 0 && to.n_masking == 0 && to.n_other == 0 && consumer->KS == 3) {
             TView x = g.view(in, B, false);
             x.sc = scale;
             TView y = make_view(nullptr, x.N, x.H, x.W, consumer->Cout);
@@ -487,8 +488,11 @@ struct ConcatOp : GOp {
         if (!g.tensors[out].grad_written) return;
         for (size_t k = 0; k < ins.size(); ++k) {
             if (!wants_grad(g, ins[k], c)) continue;
-            view_axpy(g.stream, slice(g, c.B, true, (int)k, c.b_off, c.b_cnt),
-                      g.view(ins[k], c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[ins[k]].grad_written);
+            // a ReLU output whose consumers apply the mask: this copy zeroes the gradient where the activation is <= 0
+            TView mask{nullptr, 0, 0, 0, 0, 0, 0, 0};
+            if (g.tensors[ins[k]].grad_masked) mask = g.view(ins[k], c.B, false, c.b_off, c.b_cnt);
+            view_axpy_masked(g.stream, slice(g, c.B, true, (int)k, c.b_off, c.b_cnt), mask,
+                             g.view(ins[k], c.B, true, c.b_off, c.b_cnt), g.tensors[ins[k]].grad_written);
             g.tensors[ins[k]].grad_written = true;
         }
     }
@@ -561,7 +565,7 @@ struct MaxPoolOp : GOp {
             acc = 1;
         }
         maxpool2_backward(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), g.view(out, c.B, false, c.b_off, c.b_cnt),
-                          g.view(out, c.B, true, c.b_off, c.b_cnt), dx, acc);
+                          g.view(out, c.B, true, c.b_off, c.b_cnt), dx, acc, t.grad_masked ? 1 : 0);
         g.tensors[in].grad_written = true;
     }
 };
@@ -695,7 +699,7 @@ int g_concat(Graph& g, const int* ins, int n) {
     ConcatOp* op = push<ConcatOp>(g);
     op->ins.assign(ins, ins + n);
     op->out = out;
-    for (int i = 0; i < n; ++i) g.tensors[ins[i]].n_other++;
+    for (int i = 0; i < n; ++i) g.tensors[ins[i]].n_masking++;
     return out;
 }
 
@@ -725,7 +729,7 @@ int g_maxpool2(Graph& g, int in) {
     const int out = g.add_tensor(ti.H / 2, ti.W / 2, ti.C, ti.nmul, true, false);
     MaxPoolOp* op = push<MaxPoolOp>(g);
     op->in = in; op->out = out;
-    g.tensors[in].n_other++;
+    g.tensors[in].n_masking++;
     return out;
 }
 

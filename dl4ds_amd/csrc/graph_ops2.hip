@@ -69,9 +69,9 @@ struct ConvLSTMOp : GOp {
         const GTensor& ti = g.tensors[in];
         TView xa = make_view(nullptr, B * T, ti.H, ti.W, ti.C), za = make_view(nullptr, B * T, ti.H, ti.W, 4 * F);
         TView hf = make_view(nullptr, B, ti.H, ti.W, F), zf = make_view(nullptr, B, ti.H, ti.W, 4 * F);
-        TView ht = make_view(nullptr, std::max(T - 1, 1), ti.H, ti.W, F), zt = make_view(nullptr, std::max(T - 1, 1), ti.H, ti.W, 4 * F);
+        TView ha = make_view(nullptr, B * T, ti.H, ti.W, F);
         return std::max(conv2d_wgrad_workspace_bytes(xa, za, KS),
-                        std::max(conv2d_wgrad_workspace_bytes(hf, zf, KS), conv2d_wgrad_workspace_bytes(ht, zt, KS)));
+                        std::max(conv2d_wgrad_workspace_bytes(hf, zf, KS), conv2d_wgrad_workspace_bytes(ha, za, KS)));
     }
     struct Bufs { float *Z, *C, *H, *dZ, *dh, *dc; };
     Bufs bufs(Graph& g, int B) {
@@ -93,15 +93,21 @@ struct ConvLSTMOp : GOp {
         ConvEpilogue ep;
         ep.bias = g.wp(b);
         conv2d_forward(g.stream, g.view(in, B, false), g.wp(wk), KS, make_view(bf.Z, B * T, ti.H, ti.W, 4 * F), ep);
+        // H holds the RECURRENT INPUT of every step: H[b, t] = h_{t-1}, H[b, 0] = 0 (zero initial state).  Stored that way
+        // the recurrent kernel's weight gradient sum_{b,t} wgrad(h_{t-1}, dZ_t) is ONE convolution-wgrad over the B*T frame
+        // pairs (H, dZ) -- frame 0 of every sample contributes nothing -- instead of T-1 launches of ~60 us.
+        HIP_CHECK(hipMemset2DAsync(bf.H, (size_t)T * hw(g) * F * sizeof(float), 0, hw(g) * F * sizeof(float), (size_t)B, g.stream));
         for (int t = 0; t < T; ++t) {
             TView zt = frame(g, bf.Z, B, t, 4 * F);
             if (t > 0) {
                 ConvEpilogue er;
                 er.accumulate = 1;
-                conv2d_forward(g.stream, frame(g, bf.H, B, t - 1, F), g.wp(wr), KS, zt, er);
+                conv2d_forward(g.stream, frame(g, bf.H, B, t, F), g.wp(wr), KS, zt, er);
             }
-            convlstm_gates_forward(g.stream, zt, frame(g, bf.C, B, t > 0 ? t - 1 : 0, F), frame(g, bf.C, B, t, F),
-                                   frame(g, bf.H, B, t, F), frame(g, g.tensors[out].data, B, t, F), relu, t == 0);
+            TView hnext = frame(g, bf.H, B, std::min(t + 1, T - 1), F);
+            if (t + 1 >= T) hnext.p = nullptr;
+            convlstm_gates_forward(g.stream, zt, frame(g, bf.C, B, t > 0 ? t - 1 : 0, F), frame(g, bf.C, B, t, F), hnext,
+                                   frame(g, g.tensors[out].data, B, t, F), relu, t == 0);
         }
     }
     bool partial_batch_ok() const override { return false; }
@@ -128,24 +134,12 @@ struct ConvLSTMOp : GOp {
             conv2d_wgrad(g.stream, g.view(in, B, false), dZall, KS, g.gp(wk), g.params[wk].grad_written, g.gp(b),
                          g.params[b].grad_written, g.workspace, g.workspace_bytes);
             g.params[wk].grad_written = g.params[b].grad_written = true;
-            // recurrent kernel: sum over (sample, t >= 1) of wgrad(h_{t-1}, dZ_t).  The buffers are (B, T, ...): either one
-            // launch per time step over the B samples, or one per sample over its T-1 consecutive frame pairs --
-            // whichever needs fewer launches (these are 30 us kernels, the launch count is what matters)
-            if (B < T - 1) {
-                const size_t fs = hw(g);
-                for (int b = 0; b < B; ++b) {
-                    TView hx = make_view(bf.H + (size_t)b * T * fs * F, T - 1, ti.H, ti.W, F);
-                    TView dz = make_view(bf.dZ + ((size_t)b * T + 1) * fs * 4 * F, T - 1, ti.H, ti.W, 4 * F);
-                    conv2d_wgrad(g.stream, hx, dz, KS, g.gp(wr), g.params[wr].grad_written, nullptr, 0, g.workspace,
-                                 g.workspace_bytes);
-                    g.params[wr].grad_written = true;
-                }
-            } else {
-                for (int t = 1; t < T; ++t) {
-                    conv2d_wgrad(g.stream, frame(g, bf.H, B, t - 1, F), frame(g, bf.dZ, B, t, 4 * F), KS, g.gp(wr),
-                                 g.params[wr].grad_written, nullptr, 0, g.workspace, g.workspace_bytes);
-                    g.params[wr].grad_written = true;
-                }
+            // recurrent kernel: sum over (sample, t) of wgrad(h_{t-1}, dZ_t) = one wgrad over the B*T frame pairs (H, dZ)
+            // (H[b, t] = h_{t-1}, H[b, 0] = 0: see forward)
+            if (T > 1) {
+                conv2d_wgrad(g.stream, make_view(bf.H, B * T, ti.H, ti.W, F), dZall, KS, g.gp(wr), g.params[wr].grad_written,
+                             nullptr, 0, g.workspace, g.workspace_bytes);
+                g.params[wr].grad_written = true;
             }
         }
         if (wants_grad(g, in, c)) {

@@ -149,7 +149,8 @@ struct FoldedConvOp : GOp {
         GTensor& t = g.tensors[out];
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
-        t.grad_masked = relu && !is_output && t.n_conv_in >= 1 && t.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
+        t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_masking) >= 1 && t.n_add_in == 0 && t.n_other == 0 &&
+                        !getenv("DL4DS_NO_MASK_FUSION");
     }
     TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
         const GTensor& ti = g.tensors[in];

@@ -62,6 +62,8 @@ void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TVi
                        int accumulate_db, float* workspace, size_t workspace_bytes);
 // dst (+)= alpha * src  (same logical shape; either side may be a strided / d2s view)
 void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, int accumulate);
+// dst (+)= src * [mask > 0] (mask.p == nullptr: plain copy): Concatenate backward of a ReLU output whose mask the consumers apply
+void view_axpy_masked(hipStream_t s, const TView& src, const TView& mask, const TView& dst, int accumulate);
 // dst (+)= dy * [y > 0]  (flat, contiguous)
 void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate);
 // out = act(a + b)
@@ -102,8 +104,9 @@ void depth_to_space(hipStream_t s, const float* x, float* y, int N, int H, int W
 void space_to_depth(hipStream_t s, const float* y, float* x, int N, int H, int W, int C, int r);
 // MaxPooling2D(2,2) valid
 void maxpool2_forward(hipStream_t s, const TView& x, const TView& y);
+// relu_mask != 0: x is a ReLU output whose backward rides on this store (gradient zeroed where x <= 0)
 void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TView& dy, const TView& dx,
-                       int accumulate);
+                       int accumulate, int relu_mask = 0);
 // bilinear resize (half-pixel centres)
 void resize_bilinear_forward(hipStream_t s, const TView& x, const TView& y);
 void resize_nearest_forward(hipStream_t s, const TView& x, const TView& y);
