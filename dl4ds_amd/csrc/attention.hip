@@ -230,7 +230,8 @@ void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, 
 
 void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, int accumulate_dx, const AttShape& sh,
                     const float* w1, const float* w2, const float* mean, const float* hidden, const float* scale,
-                    float* dw1, float* db1, float* dw2, float* db2, int accumulate_dw, float* workspace, float* dmean_out) {
+                    float* dw1, float* db1, float* dw2, float* db2, int accumulate_dw, float* workspace, float* dmean_out,
+                    const float* ds_given) {
     const int Q = sh.P * sh.C;
     const int ninst = sh.G * sh.P;
     float* partial = workspace;
@@ -239,9 +240,9 @@ void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, i
     float* dpre1 = dmean + (size_t)sh.G * Q;
     float* dpre2 = dpre1 + (size_t)ninst * sh.Cr;
     if (dmean_out) dmean = dmean_out;           // kept by the caller: the producer reads dX = dY * scale + dmean lazily
-    ProfScope ps(s, "chatt_bwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * (2 + (dx ? 2 + (accumulate_dx ? 1 : 0) : 0)));
-    colsum(s, dy, x, partial, ds, sh.G, sh.R, Q, 1.f);
-    hipLaunchKernelGGL(chatt_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, ds, mean, hidden, scale, w1, w2, dpre1, dpre2,
+    ProfScope ps(s, "chatt_bwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * ((ds_given ? 0 : 2) + (dx ? 2 + (accumulate_dx ? 1 : 0) : 0)));
+    if (ds_given == nullptr) colsum(s, dy, x, partial, ds, sh.G, sh.R, Q, 1.f);
+    hipLaunchKernelGGL(chatt_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, ds_given ? ds_given : ds, mean, hidden, scale, w1, w2, dpre1, dpre2,
                        dmean, dw1, db1, dw2, db2, ninst, sh.C, sh.Cr, 1.f / (float)sh.R, accumulate_dw);
     HIP_CHECK(hipGetLastError());
     if (dx == nullptr) return;                  // dX is not materialised (TView::sc / sh on the producer's dY view)

@@ -1222,6 +1222,9 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
         }
     };
     if (producer) {
+#ifdef WGRAD_PRODUCER_PRIO
+        __builtin_amdgcn_s_setprio(WGRAD_PRODUCER_PRIO);
+#endif
         // staging waves: own code path, so that their load registers never coexist with the 108 accumulator registers
         // (issuing the loads a further tile ahead, across the barrier, measured 3 % slower than load + store per iteration)
         if ((int)blockIdx.x < a.ntiles) { stage_load(blockIdx.x); stage_store(blockIdx.x, 0); }

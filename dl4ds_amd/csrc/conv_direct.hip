@@ -32,6 +32,7 @@ struct DirectParams {
     int tiles_x, tiles_y, ntiles;
     unsigned m_tx, m_ty;
     int relu, accumulate;
+    int bpi = 0;                         // wgrad only: > 0 = per-image slabs, `bpi` blocks per image (slab = blockIdx.x = n*bpi + b)
 };
 
 // Stage the (DTY+KS-1) x (DTX+KS-1) halo tile of `v` (CI padded channels) around (n, y0, x0) into LDS planes.
@@ -216,7 +217,14 @@ __global__ void __launch_bounds__(256) conv_direct_wgrad_kernel(const DirectPara
 #pragma unroll
     for (int e = 0; e < NACC; ++e) acc[e] = 0.f;
     const bool vec_dz = (CO % 4 == 0) && a.Cout == CO && a.out.vec;
-    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    // per-image mode (a.bpi > 0): block blockIdx.x = n*bpi + b walks tiles b, b + bpi, ... of image n only, so that its slab
+    // is the weight gradient of ONE sample (the attention backward needs those: conv2d_direct_wgrad_attention)
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int img = a.bpi > 0 ? (int)blockIdx.x / a.bpi : 0;
+    const int t_first = a.bpi > 0 ? img * tpi + ((int)blockIdx.x - img * a.bpi) : (int)blockIdx.x;
+    const int t_end = a.bpi > 0 ? (img + 1) * tpi : a.ntiles;
+    const int t_step = a.bpi > 0 ? a.bpi : (int)gridDim.x;
+    for (int t = t_first; t < t_end; t += t_step) {
         const int q = fast_div(t, a.m_tx);
         const int bx = t - q * a.tiles_x;
         const int n = fast_div(q, a.m_ty);
@@ -316,10 +324,11 @@ void fill_tiles(DirectParams& p, int N) {
 }
 
 template <int KS, int CI, int CO>
-int launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int max_blocks) {
-    // persistent kernels: one residency round (blocks do equal work)
-    const int blocks = std::min(max_blocks, wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256)
-                                                  : resident_blocks<conv_direct_kernel<KS, CI, CO>>(256));
+int launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int max_blocks, bool exact_grid = false) {
+    // persistent kernels: one residency round (blocks do equal work); exact_grid: per-image slabs need exactly that many blocks
+    const int blocks = exact_grid ? max_blocks
+                                  : std::min(max_blocks, wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256)
+                                                               : resident_blocks<conv_direct_kernel<KS, CI, CO>>(256));
     const double px = (double)p.in.N * p.H * p.W;
     const std::string tag = std::string(wgrad ? "conv_direct_wgrad<" : "conv_direct<") + std::to_string(KS) + "," +
                             std::to_string(CI) + "," + std::to_string(CO) + ">";
@@ -331,19 +340,19 @@ int launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int max_bloc
 }
 
 // returns the number of blocks launched (= partial slabs written, for wgrad)
-int dispatch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks) {
+int dispatch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int blocks, bool exact_grid = false) {
     const int ci = pad_pow2(p.Cin), co = pad_pow2(p.Cout);
     switch (ci * 16 + co) {
-        case 1 * 16 + 1: return launch_direct<3, 1, 1>(s, p, wgrad, blocks);
-        case 1 * 16 + 2: return launch_direct<3, 1, 2>(s, p, wgrad, blocks);
-        case 1 * 16 + 4: return launch_direct<3, 1, 4>(s, p, wgrad, blocks);
-        case 1 * 16 + 8: return launch_direct<3, 1, 8>(s, p, wgrad, blocks);
-        case 2 * 16 + 1: return launch_direct<3, 2, 1>(s, p, wgrad, blocks);
-        case 2 * 16 + 2: return launch_direct<3, 2, 2>(s, p, wgrad, blocks);
-        case 2 * 16 + 4: return launch_direct<3, 2, 4>(s, p, wgrad, blocks);
-        case 4 * 16 + 1: return launch_direct<3, 4, 1>(s, p, wgrad, blocks);
-        case 4 * 16 + 2: return launch_direct<3, 4, 2>(s, p, wgrad, blocks);
-        case 8 * 16 + 1: return launch_direct<3, 8, 1>(s, p, wgrad, blocks);
+        case 1 * 16 + 1: return launch_direct<3, 1, 1>(s, p, wgrad, blocks, exact_grid);
+        case 1 * 16 + 2: return launch_direct<3, 1, 2>(s, p, wgrad, blocks, exact_grid);
+        case 1 * 16 + 4: return launch_direct<3, 1, 4>(s, p, wgrad, blocks, exact_grid);
+        case 1 * 16 + 8: return launch_direct<3, 1, 8>(s, p, wgrad, blocks, exact_grid);
+        case 2 * 16 + 1: return launch_direct<3, 2, 1>(s, p, wgrad, blocks, exact_grid);
+        case 2 * 16 + 2: return launch_direct<3, 2, 2>(s, p, wgrad, blocks, exact_grid);
+        case 2 * 16 + 4: return launch_direct<3, 2, 4>(s, p, wgrad, blocks, exact_grid);
+        case 4 * 16 + 1: return launch_direct<3, 4, 1>(s, p, wgrad, blocks, exact_grid);
+        case 4 * 16 + 2: return launch_direct<3, 4, 2>(s, p, wgrad, blocks, exact_grid);
+        case 8 * 16 + 1: return launch_direct<3, 8, 1>(s, p, wgrad, blocks, exact_grid);
         default: throw Dl4dsError("conv_direct: unsupported channel combination");
     }
 }
@@ -376,6 +385,80 @@ int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS) {
     DL4DS_REQUIRE(affine_ok(x) && !dz.sc, "conv_direct wgrad: only a float4-loadable x operand may carry a channel affine");
     const int ntiles = cdiv(x.W, DTX) * cdiv(x.H, DTY) * x.N;
     return std::max(1, std::min(ntiles, 1024));
+}
+
+namespace {
+// per image n: sum of its bpi slabs -> perimg[n][.]; ds[n][ci] = sum_{tap,co} w[tap][ci][co] * perimg[n][(tap,ci,co)]
+__global__ void __launch_bounds__(256) att_wgrad_per_image_kernel(const float* __restrict__ partial, float* __restrict__ perimg,
+                                                                  const float* __restrict__ w, float* __restrict__ ds, int bpi,
+                                                                  int n_el, int nw, int KK, int Cin, int Cout) {
+    extern __shared__ float sh[];                 // [n_el]
+    const int n = blockIdx.x;
+    for (int e = threadIdx.x; e < n_el; e += blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < bpi; ++b) s += partial[((size_t)n * bpi + b) * n_el + e];      // fixed order
+        sh[e] = s;
+        perimg[(size_t)n * n_el + e] = s;
+    }
+    __syncthreads();
+    for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
+        float d = 0.f;
+        for (int tap = 0; tap < KK; ++tap)
+            for (int co = 0; co < Cout; ++co) {
+                const int e = (tap * Cin + ci) * Cout + co;
+                d += w[e] * sh[e];
+            }
+        ds[(size_t)n * Cin + ci] = d;
+    }
+}
+// dW[e] (+)= sum_n scale[n][ci(e)] * perimg[n][e] ; db[co] (+)= sum_n perimg[n][nw + co]
+__global__ void __launch_bounds__(256) att_wgrad_combine_kernel(const float* __restrict__ perimg, const float* __restrict__ scale,
+                                                                float* __restrict__ dw, float* __restrict__ db, int N, int n_el,
+                                                                int nw, int Cin, int Cout, int acc_w, int acc_b) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_el) return;
+    float s = 0.f;
+    if (e < nw) {
+        const int ci = (e / Cout) % Cin;
+        for (int n = 0; n < N; ++n) s += scale[(size_t)n * Cin + ci] * perimg[(size_t)n * n_el + e];
+        dw[e] = acc_w ? dw[e] + s : s;
+    } else if (db) {
+        for (int n = 0; n < N; ++n) s += perimg[(size_t)n * n_el + e];
+        db[e - nw] = acc_b ? db[e - nw] + s : s;
+    }
+}
+}  // namespace
+
+// Weight gradient of a stencil convolution that reads its input through a ChannelAttention2D scale (y = conv(x * s_n), s_n
+// per image and channel) TOGETHER with the attention's d(loss)/d(scale):
+//   dW[tap,ci,co]  = sum_n s[n,ci] * R_n[tap,ci,co],   R_n = wgrad(x_n, dz_n)  (the RAW, un-scaled input)
+//   ds[n,ci]       = sum_p x_n[p,ci] * dgrad(dz_n)[p,ci] = sum_{tap,co} W[tap,ci,co] * R_n[tap,ci,co]
+// so the per-image raw weight gradients give both, and the attention backward needs no pass over (dy * x) at all.
+// workspace: (N*bpi + N) * (KK*Cin*Cout + Cout) floats.  Returns false if the layer is not eligible (caller falls back).
+bool conv2d_direct_wgrad_attention(hipStream_t s, const TView& x_raw, const TView& dz, int KS, const float* scale, const float* w,
+                                   float* dw, int accumulate, float* db, int accumulate_db, float* ds, float* workspace,
+                                   size_t workspace_bytes) {
+    if (!eligible(x_raw, dz, KS) || x_raw.sc || dz.sc || !affine_ok(x_raw)) return false;
+    const int N = x_raw.N;
+    const int nw = KS * KS * x_raw.C * dz.C, n_el = nw + dz.C;
+    const int bpi = std::max(1, std::min(1024 / std::max(N, 1), cdiv(x_raw.W, DTX) * cdiv(x_raw.H, DTY)));
+    if (N > 1024 || (size_t)(N * bpi + N) * n_el * sizeof(float) > workspace_bytes || n_el * sizeof(float) > 48 * 1024) return false;
+    DirectParams p;
+    p.in = x_raw; p.out = dz; p.add = TView{nullptr, 0, 0, 0, 0, 0, 0, 0}; p.mask = p.add;
+    p.w = nullptr; p.bias = nullptr; p.partial = workspace;
+    p.Cin = x_raw.C; p.Cout = dz.C; p.H = x_raw.H; p.W = x_raw.W;
+    p.relu = 0; p.accumulate = 0;
+    p.bpi = bpi;
+    fill_tiles(p, N);
+    dispatch_direct(s, p, true, N * bpi, /*exact_grid=*/true);
+    float* perimg = workspace + (size_t)N * bpi * n_el;
+    hipLaunchKernelGGL(att_wgrad_per_image_kernel, dim3(N), dim3(256), n_el * sizeof(float), s, workspace, perimg, w, ds, bpi, n_el,
+                       nw, KS * KS, x_raw.C, dz.C);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(att_wgrad_combine_kernel, dim3(cdiv(n_el, 256)), dim3(256), 0, s, perimg, scale, dw, db, N, n_el, nw,
+                       x_raw.C, dz.C, accumulate, accumulate_db);
+    HIP_CHECK(hipGetLastError());
+    return true;
 }
 
 int conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int slabs) {

@@ -228,6 +228,8 @@ struct AttFusion {
     int pool_tiles = 0;
     float* scale = nullptr;     // [G][C]
     float* dmean = nullptr;     // [G][C]
+    float* ds = nullptr;        // [G][C] sum over pixels of (dy * x), written by the consumer's weight-gradient pass ...
+    bool ds_ready = false;      // ... when it ran before this attention's backward (then no pass over dy, x is needed)
     int att_in = -1, att_out = -1;
 };
 
@@ -303,7 +305,8 @@ struct ConvOp : GOp {
     size_t workspace_bytes(Graph& g, int B) override {
         TView x = g.view(in, B, false);
         TView dz = make_view(nullptr, x.N, x.H, x.W, Cout);
-        return std::max(conv2d_wgrad_workspace_bytes(x, dz, KS), bias_grad_workspace_bytes(dz));
+        const size_t att_ws = (size_t)(1024 + x.N) * ((size_t)KS * KS * x.C * Cout + Cout) * sizeof(float);   // per-image slabs
+        return std::max(std::max(conv2d_wgrad_workspace_bytes(x, dz, KS), bias_grad_workspace_bytes(dz)), att_before ? att_ws : 0);
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;      // nothing flowed into this op
@@ -326,9 +329,21 @@ struct ConvOp : GOp {
             const bool on_aux = aux_enabled(g);
             hipStream_t ws_stream = on_aux ? g.aux_stream : g.stream;
             float* ws_buf = on_aux ? g.aux_workspace : g.workspace;
-            conv2d_wgrad(ws_stream, in_view(g, c.B, c.b_off, c.b_cnt), dY, KS, g.gp(w),
-                         g.params[w].grad_written, need_db ? g.gp(b) : nullptr,
-                         need_db ? (int)g.params[b].grad_written : 0, ws_buf, g.workspace_bytes);
+            // behind a fused attention scale the stencil weight gradient is taken per image on the raw input: that yields
+            // dW, db AND the attention's d(loss)/d(scale) (conv2d_direct_wgrad_attention), on the main stream
+            bool done = false;
+            if (att_before && att_before->fuse_scale && c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B) &&
+                !getenv("DL4DS_NO_DS_FUSION")) {
+                done = conv2d_direct_wgrad_attention(g.stream, g.view(att_before->att_in, c.B, false), dY, KS, att_before->scale,
+                                                     g.wp(w), g.gp(w), g.params[w].grad_written, need_db ? g.gp(b) : nullptr,
+                                                     need_db ? (int)g.params[b].grad_written : 0, att_before->ds, g.workspace,
+                                                     g.workspace_bytes);
+                att_before->ds_ready = done;
+            }
+            if (!done)
+                conv2d_wgrad(ws_stream, in_view(g, c.B, c.b_off, c.b_cnt), dY, KS, g.gp(w),
+                             g.params[w].grad_written, need_db ? g.gp(b) : nullptr,
+                             need_db ? (int)g.params[b].grad_written : 0, ws_buf, g.workspace_bytes);
             g.params[w].grad_written = true;
             if (need_db) g.params[b].grad_written = true;
         }
@@ -363,17 +378,19 @@ struct ChAttOp : GOp {
     size_t saved_floats_per_sample(Graph& g) override {
         const GTensor& t = g.tensors[in];
         const size_t inst = (T5 > 0) ? (size_t)t.W : (size_t)t.nmul;
-        // mean, scale, dmean (C each) + hidden (Cr) per instance; 4-D mode: room for the producer's pooling partial sums
-        return inst * (3 * (size_t)t.C + Cr) + (T5 > 0 ? 0 : (size_t)t.nmul * pool_tiles(g) * 8 + 16);
+        // mean, scale, dmean, ds (C each) + hidden (Cr) per instance; 4-D mode: room for the producer's pooling partial sums
+        return inst * (4 * (size_t)t.C + Cr) + (T5 > 0 ? 0 : (size_t)t.nmul * pool_tiles(g) * 8 + 16);
     }
     size_t workspace_bytes(Graph& g, int B) override { return chatt_workspace_bytes(shape(g, B)); }
-    void ptrs(Graph& g, int, float*& mean, float*& hidden, float*& scale, float*& dmean, float*& pool) {
+    void ptrs(Graph& g, int, float*& mean, float*& hidden, float*& scale, float*& dmean, float*& pool, float** ds_out = nullptr) {
         // laid out for the LARGEST batch the buffers were allocated for, so that the addresses handed to the neighbouring
         // convolutions (AttFusion) stay put when a smaller batch runs
         AttShape s = shape(g, g.maxB);
         const size_t inst = (size_t)s.G * s.P;
         mean = saved; scale = mean + inst * s.C; hidden = scale + inst * s.C; dmean = hidden + inst * s.Cr;
-        pool = dmean + ((inst * s.C + 3) & ~(size_t)3);        // keep the float4 records 16-byte aligned
+        float* dsp = dmean + inst * s.C;
+        if (ds_out) *ds_out = dsp;
+        pool = dsp + ((inst * s.C + 3) & ~(size_t)3);          // keep the float4 records 16-byte aligned
     }
     void on_finalize(Graph& g) override {
         // neighbours: the convolution producing `in` and the (single) convolution reading `out`
@@ -384,16 +401,16 @@ struct ChAttOp : GOp {
             if (c->in == out) consumer = c;
         }
         fz.att_in = in; fz.att_out = out;
+        if (producer) producer->att_after = &fz;           // (the fuse_* flags stay false until on_prepare has seen the buffers)
+        if (consumer) consumer->att_before = &fz;
     }
     // which pieces can be handed to the neighbours: needs the real views (alignment), so decided once the buffers exist
     void on_prepare(Graph& g) override {
         fz.fuse_pool = fz.fuse_scale = fz.fuse_dx = false;
-        if (producer) producer->att_after = &fz;
-        if (consumer) consumer->att_before = &fz;
         if (T5 > 0 || getenv("DL4DS_NO_TAIL_FUSION")) return;
         const int B = g.maxB;
         float *mean, *hidden, *scale, *dmean, *pool;
-        ptrs(g, B, mean, hidden, scale, dmean, pool);
+        ptrs(g, B, mean, hidden, scale, dmean, pool, &fz.ds);
         fz.scale = scale; fz.dmean = dmean; fz.pool = pool; fz.pool_tiles = pool_tiles(g);
         const GTensor& ti = g.tensors[in];
         const GTensor& to = g.tensors[out];
@@ -444,7 +461,8 @@ struct ChAttOp : GOp {
     std::string describe_fusion(Graph&) override {
         return std::string("{\"op\":\"chatt\",\"in\":") + std::to_string(in) + ",\"pool_from_producer\":" +
                (fz.fuse_pool ? "true" : "false") + ",\"scale_in_consumer_load\":" + (fz.fuse_scale ? "true" : "false") +
-               ",\"dx_in_producer_backward\":" + (fz.fuse_dx ? "true" : "false") + "}";
+               ",\"dx_in_producer_backward\":" + (fz.fuse_dx ? "true" : "false") + ",\"dscale_from_consumer_wgrad\":" +
+               (fz.fuse_scale && !getenv("DL4DS_NO_DS_FUSION") ? "true" : "false") + "}";
     }
     bool partial_batch_ok() const override { return false; }
     void backward(Graph& g, const BwdCtx& c) override {
@@ -457,7 +475,9 @@ struct ChAttOp : GOp {
         const int accw = g.params[w1].grad_written;
         chatt_backward(g.stream, g.tensors[in].data, g.tensors[out].grad, fz.fuse_dx ? nullptr : g.tensors[in].grad,
                        g.tensors[in].grad_written, shape(g, c.B), g.wp(w1), g.wp(w2), mean, hidden, scale,
-                       c.param_grads ? g.gp(w1) : nullptr, g.gp(b1), g.gp(w2), g.gp(b2), accw, g.workspace, dmean);
+                       c.param_grads ? g.gp(w1) : nullptr, g.gp(b1), g.gp(w2), g.gp(b2), accw, g.workspace, dmean,
+                       fz.ds_ready ? fz.ds : nullptr);
+        fz.ds_ready = false;
         g.tensors[in].grad_written = true;
         if (c.param_grads) {
             g.params[w1].grad_written = g.params[b1].grad_written = true;

@@ -37,6 +37,11 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
 bool conv2d_narrow_pair_ok(const TView& in, const TView& out, int KS, const ConvEpilogue& ep);
 int conv2d_narrow_pair_tiles_per_image(int H, int W);
 bool conv2d_direct_eligible(const TView& in, const TView& out, int KS);
+// weight gradient of a stencil convolution behind a ChannelAttention2D scale + the attention's d(loss)/d(scale), both from
+// per-image raw weight gradients (conv_direct.hip); false: not eligible, nothing was launched
+bool conv2d_direct_wgrad_attention(hipStream_t s, const TView& x_raw, const TView& dz, int KS, const float* scale, const float* w,
+                                   float* dw, int accumulate, float* db, int accumulate_db, float* ds, float* workspace,
+                                   size_t workspace_bytes);
 // 3x3 wgrad with Cin <= 8, Cout <= 16 (two taps per MFMA tile); same slab protocol as the direct path
 int conv2d_narrow_wgrad_slabs(const TView& x, const TView& dz, int KS);
 int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int max_slabs);
@@ -130,7 +135,8 @@ void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, 
 void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, int accumulate_dx,
                     const AttShape& sh, const float* w1, const float* w2, const float* mean,
                     const float* hidden, const float* scale, float* dw1, float* db1, float* dw2,
-                    float* db2, int accumulate_dw, float* workspace, float* dmean_out = nullptr);
+                    float* db2, int accumulate_dw, float* workspace, float* dmean_out = nullptr,
+                    const float* ds_given = nullptr);     // ds_given ([G*P*C]): sum_r(dy * x) already known -> no pass over dy, x
 size_t chatt_workspace_bytes(const AttShape& sh);
 
 // ----------------------------------------------------------------------- losses (losses.hip)

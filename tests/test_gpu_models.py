@@ -588,6 +588,7 @@ def test_attention_handed_to_neighbouring_convolutions_equals_separate_passes(mo
     rep = _fusion_report(fused, B)
     tail = rep[-1]                                   # ConvBlock_att's attention is the last one of the graph
     assert tail['pool_from_producer'] and tail['scale_in_consumer_load'] and tail['dx_in_producer_backward'], rep
+    assert tail['dscale_from_consumer_wgrad'], rep
     monkeypatch.setenv('DL4DS_NO_TAIL_FUSION', '1')
     plain = build(**cfg)
     assert not any(r['pool_from_producer'] or r['scale_in_consumer_load'] or r['dx_in_producer_backward']
