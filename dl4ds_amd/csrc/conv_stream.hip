@@ -21,6 +21,7 @@
 #include "prof.h"
 #include "conv_kernels.h"
 #include <algorithm>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -273,6 +274,478 @@ __global__ void __launch_bounds__(kStreamThreads, 2) conv_stream_kernel(const St
     STAMP();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Producer / consumer form: ONE persistent 8-wave workgroup per CU.  Waves 0-3 (one per SIMD) issue nothing but the K
+// loop -- filter fragments from L2, pixel fragments from LDS, MFMAs -- and hand their accumulators over through LDS
+// (24 ds_write_b128 per item); waves 4-7 stage the NEXT chunk's halo tile into the other LDS buffer and run the epilogue
+// of the PREVIOUS item (bias / add / ReLU / mask / store) out of that hand-over area while the matrix pipe keeps going.
+// Why: with two independent 4-wave workgroups per CU the staging and epilogue phases of one workgroup are starved by the
+// other's MFMAs (one VALU issue per MFMA slot, tools/ubench/mfma_valu.hip) and stretch 3-6x, and 18 % of the time neither
+// workgroup is in its K loop (profiles/stream_trace_r02.txt).  Here the overlap is by construction: the helpers' work is
+// free for the matrix pipe as long as it fits into one chunk's K loop.
+// LDS: [tile A | spare | tile B]; the hand-over area of an item overlays the tile buffer its last chunk was read from
+// plus the spare (the other buffer already holds the next step's tile), so the helpers must drain it before they stage
+// the step after next into it -- a 4-wave counter barrier in LDS, the MFMA waves are not involved.
+template <int KS, int E, int NT, int MT>
+struct WsGeom {
+    static constexpr int G = (E % 4 == 0) ? 4 : 2, CK = 4 * E, P = CK + G;
+    static constexpr int TW = 16, TH = 4 * MT, TWH = TW + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
+    static constexpr int TILE = HPIX * P;                         // floats
+    static constexpr int CO = 16 * NT, NPIX = TW * TH, DUMP = NPIX * CO;
+    static constexpr int TOT = (2 * TILE > TILE + DUMP) ? 2 * TILE : TILE + DUMP;
+    static constexpr size_t LDS_BYTES = (size_t)(TOT + 4) * 4;    // + the helpers' counter
+    static constexpr bool fits = LDS_BYTES <= 160 * 1024 && TILE % 4 == 0;
+};
+
+typedef const char __attribute__((address_space(1)))* gcptr_t;
+typedef char __attribute__((address_space(1)))* gptr_t;
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;     // (builtin vector type: loads / stores through an
+typedef f32x4 __attribute__((address_space(1)))* gf4_t;            //  address-space pointer need no class copy constructor)
+__device__ __forceinline__ float4 gload4(gcptr_t p) {
+    const f32x4 v = *(gcf4_t)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void gstore4(gptr_t p, const float4& v) { *(gf4_t)p = (f32x4){v.x, v.y, v.z, v.w}; }
+
+// pixel strides (floats) of a view: pix_base(n, y, x) = n * nstride + y * sy + x * sx
+__device__ __forceinline__ void view_strides(const TView& v, size_t& sy, size_t& sx) {
+    const int r = v.d2s > 1 ? v.d2s : 1;
+    sx = (size_t)r * v.ld;
+    sy = (size_t)r * (size_t)(v.W * r) * v.ld;
+}
+
+template <int KS, int E, int NT, int MT>
+__global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamParams sp) {
+    typedef WsGeom<KS, E, NT, MT> GM;
+    const ConvParams& a = sp.c;
+    constexpr int G = GM::G, NGRP = E / G, CK = GM::CK, P = GM::P;
+    constexpr int TW = 16, TH = GM::TH, PAD = KS / 2, TWH = GM::TWH, THH = GM::THH, HPIX = GM::HPIX;
+    constexpr int KK = KS * KS, NGS = KK * NGRP, Q4 = CK / 4;
+    constexpr int HT = 256;                                       // helper threads
+    constexpr int CO = GM::CO, NQ = 4 * NT;
+    constexpr int WPD = 2;
+    static_assert(NGS % (WPD + 1) == 0 && NGS > WPD, "the filter ring runs across steps");
+    typedef typename WVec<NT>::T wvec_t;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const bufA = lds;
+    float* const bufB = lds + (GM::TOT - GM::TILE);
+    unsigned* const ctr = reinterpret_cast<unsigned*>(lds + GM::TOT);        // [0]: helpers' barrier, [1]: accumulators handed over
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave8 = tid >> 6;
+#ifdef WS_HELPERS_LAST
+    const bool helper = wave8 >= 4;
+#else
+    const bool helper = wave8 < 4;                                // (the OLDER waves of each SIMD: see below)
+#endif
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, SX = gridDim.x >> 3;
+    const int nchunks = a.Cin / CK;                               // (the launcher guarantees Cin % CK == 0)
+    const int tiles_here = min(sp.per_xcd, sp.ntiles - xcd * sp.per_xcd);
+    const int nvalid = max(tiles_here, 0) * sp.nblk;              // this XCD's items: (tile, n-block), n-blocks innermost
+    if (tid < 2) ctr[tid] = 0u;
+
+#ifdef STREAM_TRACE
+    // diagnostics build: per-workgroup sums of phase times (100 MHz ticks; word 0 in shader cycles), tools/ws_trace.py
+    unsigned long long tr_t = 0, tr_t0 = 0, tr_c = 0;
+    unsigned long long* const trw = sp.trace ? sp.trace + (size_t)blockIdx.x * 16 : nullptr;
+    const bool tr_on = trw && lane == 0 && (wave8 == 0 || wave8 == 4);      // (one MFMA wave, one helper wave)
+    if (trw && lane == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        atomicOr(trw + 13, (unsigned long long)((hw >> 4) & 3u) << (2 * wave8));
+        if (wave8 == 0) trw[6] = hw;
+    }
+    unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (sums stay in registers until the end)
+#define WS_T0() do { tr_t0 = wall_clock64(); } while (0)
+#define WS_TIC() do { tr_t = wall_clock64(); } while (0)
+#define WS_TOC(slot_) do { const unsigned long long n_ = wall_clock64(); tr_acc[slot_] += n_ - tr_t; tr_t = n_; } while (0)
+#define WS_END(slot_) do { tr_acc[slot_] = wall_clock64() - tr_t0; if (tr_on) { for (int q_ = 0; q_ < 16; ++q_) if (q_ != 6 && q_ != 13 && tr_acc[q_]) trw[q_] = tr_acc[q_]; } } while (0)
+#define WS_CYC0() do { tr_c = clock64(); } while (0)
+#define WS_CYC1() do { tr_acc[0] += clock64() - tr_c; } while (0)
+#else
+#define WS_T0()
+#define WS_TIC()
+#define WS_TOC(slot_)
+#define WS_END(slot_)
+#define WS_CYC0()
+#define WS_CYC1()
+#endif
+    struct Item { int n, y0, x0, n0; };
+    auto decode = [&](int li) {
+        const int tl = fast_div(li, sp.m_nblk);
+        const int nb = li - tl * sp.nblk;
+        const int t = xcd * sp.per_xcd + tl;
+        const int q = fast_div(t, a.m_txy[0]);
+        const int bx = t - q * a.tiles_x;
+        const int n = fast_div(q, a.m_txy[1]);
+        const int by = q - n * a.tiles_y;
+        Item it;
+        it.n = n; it.y0 = by * TH; it.x0 = bx * TW; it.n0 = nb * 16 * NT;
+        return it;
+    };
+
+    if (helper) {
+        // A helper wave gets an instruction issued only every ~80 cycles while the wave it shares its SIMD with streams MFMAs
+        // (measured, tools/ws_trace.py) -- of ANY kind, not only VALU.  So per element there is one memory instruction and
+        // nothing else: the offsets of a thread's elements relative to the tile origin are computed once per kernel, the
+        // origin is a wave-uniform buffer descriptor (scalar unit), and whatever lies outside the image or the tensor gets
+        // an out-of-range offset instead of a branch or a select: the buffer unit returns zeros for such loads -- exactly the
+        // convolution's zero padding -- and drops such stores.
+        const int htid = tid & 255;
+        constexpr int OOB = (int)0xffffff00u;
+        constexpr int RSRC3 = 0x00020000;                         // gfx9 raw buffer, 32-bit data
+        // ---- staging: thread = (channel quad c4, pixel p0 + PPASS * u)
+        constexpr int PPASS = HT / Q4, SIT = (HPIX + PPASS - 1) / PPASS;
+        const int c4 = htid % Q4, p0 = htid / Q4;
+        const bool st_active = p0 < PPASS;
+        size_t isy, isx;
+        view_strides(a.in, isy, isx);
+        int rel[SIT], soff[SIT], hyx[SIT];
+#pragma unroll
+        for (int u = 0; u < SIT; ++u) {
+            const int hp = p0 + PPASS * u;
+            const int hy = hp / TWH, hx = hp - hy * TWH;
+            const bool live = st_active && hp < HPIX;
+            hyx[u] = live ? ((hy << 8) | hx) : 0x7f7f;            // (0x7f: never inside the image window)
+            rel[u] = live ? (int)((hy * isy + hx * isx + (size_t)c4 * 4) * 4) : OOB;
+            soff[u] = rel[u];
+        }
+        int st_sig = (THH << 8) | TWH;                            // window signature of soff[]: (ylo, yhi, xlo, xhi) packed
+        st_sig |= 0 << 24;
+        const int st_dst = (p0 * P + c4 * 4);                     // floats; element u goes PPASS * P * u further
+        auto stage = [&](const Item& it, int c0, float* tile) __attribute__((always_inline)) {
+            // the part of the halo tile that lies inside the image: rows [ylo, yhi), columns [xlo, xhi)
+            const int ylo = max(0, PAD - it.y0), yhi = min(THH, a.H + PAD - it.y0);
+            const int xlo = max(0, PAD - it.x0), xhi = min(TWH, a.W + PAD - it.x0);
+            const int sig = (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
+            if (sig != st_sig) {                                  // (wave-uniform; n-blocks and chunks of one tile share it)
+                st_sig = sig;
+#pragma unroll
+                for (int u = 0; u < SIT; ++u) {
+                    const int hy = hyx[u] >> 8, hx = hyx[u] & 0xff;
+                    soff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? rel[u] : OOB;
+                }
+            }
+            // wave-uniform origin of the halo tile (outside the tensor for border tiles; never dereferenced there)
+            const long org = (long)((size_t)it.n * a.in.nstride) + (long)(it.y0 - PAD) * (long)isy + (long)(it.x0 - PAD) * (long)isx +
+                             (long)view_chan_off(a.in, c0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+            float* dst = tile + st_dst;
+            i32x4_t r[SIT];
+#pragma unroll
+            for (int u = 0; u < SIT; ++u) r[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[u], 0, 0);
+#ifdef STREAM_TRACE
+            WS_TOC(14);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WS_TOC(15);
+#endif
+#pragma unroll
+            for (int u = 0; u < SIT; ++u) {
+                if (u + 1 < SIT ? (PPASS * Q4 == HT || st_active) : (hyx[u] >> 8) < THH) {
+                    float* d = dst + u * (PPASS * P);
+                    if (G == 4) {
+                        *reinterpret_cast<i32x4_t*>(d) = r[u];
+                    } else {
+                        reinterpret_cast<int2*>(d)[0] = make_int2(r[u][0], r[u][1]);
+                        reinterpret_cast<int2*>(d)[1] = make_int2(r[u][2], r[u][3]);
+                    }
+                }
+            }
+        };
+        // ---- epilogue out of the hand-over area [pixel][CO] (linear): thread owns elements e = htid + 256 * u, element =
+        //      (pixel e / NQ, channel quad e % NQ) -> a wave stores whole 16*NQ-byte pixel segments
+        constexpr int ND = MT * NT;                               // elements per thread
+        size_t osy, osx;
+        view_strides(a.out, osy, osx);                            // (add / mask views have the same strides: launcher)
+        int dvo[ND];
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int e = htid + HT * u;
+            const int pix = e / NQ, quad = e - pix * NQ;
+            dvo[u] = (int)(((pix >> 4) * osy + (pix & 15) * osx + (size_t)quad * 4) * 4);
+        }
+        int dr_sig = (NQ << 16) | (TH << 8) | TW;                 // signature of dvo[]: (quads, rows, columns) that exist
+        auto drain = [&](const Item& it, const float* dump) __attribute__((always_inline)) {
+            const int nq = min(NQ, (a.Cout - it.n0) >> 2);        // channel quads of this n-block that exist
+            const int ymax = min(TH, a.H - it.y0), xmax = min(TW, a.W - it.x0);
+            const int sig = (nq << 16) | (ymax << 8) | xmax;
+            if (sig != dr_sig) {                                  // (wave-uniform: ragged image edges, last n-block of a ragged Cout)
+                dr_sig = sig;
+#pragma unroll
+                for (int u = 0; u < ND; ++u) {
+                    const int e = htid + HT * u;
+                    const int pix = e / NQ, quad = e - pix * NQ;
+                    const int o = (int)(((pix >> 4) * osy + (pix & 15) * osx + (size_t)quad * 4) * 4);
+                    dvo[u] = ((pix >> 4) < ymax && (pix & 15) < xmax && quad < nq) ? o : OOB;
+                }
+            }
+            const size_t ooff = (size_t)it.n * a.out.nstride + it.y0 * osy + it.x0 * osx + view_chan_off(a.out, it.n0);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out.p) + ooff * 4, 0, 0x7fffff00, RSRC3);
+            const size_t aoff = a.add.p ? (size_t)it.n * a.add.nstride + it.y0 * osy + it.x0 * osx + view_chan_off(a.add, it.n0) : 0;
+            const size_t moff = a.mask.p ? (size_t)it.n * a.mask.nstride + it.y0 * osy + it.x0 * osx + view_chan_off(a.mask, it.n0) : 0;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.add.p) + aoff * 4, 0, 0x7fffff00, RSRC3);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.mask.p) + moff * 4, 0, 0x7fffff00, RSRC3);
+            const float* src = dump + htid * 4;
+            // every combination of the epilogue switches gets its own straight-line code, in groups of GQ elements: all loads
+            // of a group are issued before the first value is used
+            auto body = [&](auto mode_tag) __attribute__((always_inline)) {
+                constexpr int M = decltype(mode_tag)::value;
+                constexpr bool ADD = (M & 1) != 0, RELU = (M & 2) != 0, MASK = (M & 4) != 0, ACC = (M & 8) != 0;
+                constexpr int NSTREAM = 1 + (ADD ? 1 : 0) + (MASK ? 1 : 0) + (ACC ? 1 : 0);
+                constexpr int GQ = NSTREAM <= 2 ? (ND % 6 == 0 ? 6 : ND) : (ND % 4 == 0 ? 4 : ND);
+#pragma unroll
+                for (int g0 = 0; g0 < ND; g0 += GQ) {
+                    f32x4 v[GQ];
+                    i32x4_t ad[ADD ? GQ : 1], mk[MASK ? GQ : 1], old[ACC ? GQ : 1];
+#pragma unroll
+                    for (int i = 0; i < GQ; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (g0 + i) * (HT * 4));
+                    if (ADD) {
+#pragma unroll
+                        for (int i = 0; i < GQ; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, dvo[g0 + i], 0, 0);
+                    }
+                    if (MASK) {
+#pragma unroll
+                        for (int i = 0; i < GQ; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, dvo[g0 + i], 0, 0);
+                    }
+                    if (ACC) {
+#pragma unroll
+                        for (int i = 0; i < GQ; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, dvo[g0 + i], 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < GQ; ++i) {
+                        f32x4 r4 = v[i];
+                        if (ADD) r4 += __builtin_bit_cast(f32x4, ad[i]);
+                        if (RELU) { r4[0] = fmaxf(r4[0], 0.f); r4[1] = fmaxf(r4[1], 0.f); r4[2] = fmaxf(r4[2], 0.f); r4[3] = fmaxf(r4[3], 0.f); }
+                        if (MASK) {
+                            const f32x4 m = __builtin_bit_cast(f32x4, mk[i]);
+                            r4[0] = m[0] > 0.f ? r4[0] : 0.f; r4[1] = m[1] > 0.f ? r4[1] : 0.f;
+                            r4[2] = m[2] > 0.f ? r4[2] : 0.f; r4[3] = m[3] > 0.f ? r4[3] : 0.f;
+                        }
+                        if (ACC) r4 += __builtin_bit_cast(f32x4, old[i]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, r4), ro, dvo[g0 + i], 0, 0);
+                    }
+                }
+            };
+            const int mode = (a.add.p ? 1 : 0) | (a.relu ? 2 : 0) | (a.mask.p ? 4 : 0) | (a.accumulate ? 8 : 0);
+            if (mode == 0) body(std::integral_constant<int, 0>{});
+            else if (mode == 1) body(std::integral_constant<int, 1>{});
+            else if (mode == 2) body(std::integral_constant<int, 2>{});
+            else if (mode == 3) body(std::integral_constant<int, 3>{});
+            else if (mode == 4) body(std::integral_constant<int, 4>{});
+            else if (mode == 5) body(std::integral_constant<int, 5>{});
+            else if (mode == 6) body(std::integral_constant<int, 6>{});
+            else if (mode == 7) body(std::integral_constant<int, 7>{});
+            else if (mode == 8) body(std::integral_constant<int, 8>{});
+            else if (mode == 9) body(std::integral_constant<int, 9>{});
+            else if (mode == 10) body(std::integral_constant<int, 10>{});
+            else if (mode == 11) body(std::integral_constant<int, 11>{});
+            else if (mode == 12) body(std::integral_constant<int, 12>{});
+            else if (mode == 13) body(std::integral_constant<int, 13>{});
+            else if (mode == 14) body(std::integral_constant<int, 14>{});
+            else body(std::integral_constant<int, 15>{});
+        };
+
+        unsigned epoch = 0, handed = 0;
+        auto helper_sync = [&]() {                                // the four helper waves only; the MFMA waves are in their K loop
+            ++epoch;
+            if (lane == 0) {
+                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * epoch)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto wait_handed = [&]() {                                // all four MFMA waves have written their accumulators
+            ++handed;
+            if (lane == 0) {
+                while (__hip_atomic_load(ctr + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * handed)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        // one loop over "steps" (item, chunk); iteration k runs beside the MFMA waves' K loop of step k and prepares step k+1
+        // (iteration -1 = the prologue: stage step 0)
+        bool pending = false;
+        Item pend_it = {0, 0, 0, 0}, cur = {0, 0, 0, 0};
+        const float* pend_dump = nullptr;
+        int li = slot, c = -1;                                    // step k = (li, c)
+        WS_T0();
+        for (int k = -1;; ++k) {
+            if (pending) {
+                WS_TIC();
+                wait_handed();
+                drain(pend_it, pend_dump);
+                WS_TOC(8);
+                helper_sync();
+                WS_TOC(9);
+                pending = false;
+            }
+            WS_TIC();
+            int nli = li, nc = c + 1;
+            if (k >= 0 && nc == nchunks) { nli = li + SX; nc = 0; }
+            const bool has_next = nli < nvalid;
+            Item nxt = cur;
+            if (has_next) {
+                if (nc == 0) nxt = decode(nli);
+                stage(nxt, nc * CK, ((k + 1) & 1) ? bufB : bufA);
+            }
+            WS_TOC(10);
+            __syncthreads();                                      // S0 (k = -1) / X: tile k consumed, tile k+1 staged
+            if (k >= 0 && c + 1 == nchunks) {
+                pending = true;
+                pend_it = cur;
+                pend_dump = (k & 1) ? lds + (GM::TOT - GM::DUMP) : lds;
+            }
+            WS_TOC(11);
+            if (!has_next) break;
+            cur = nxt; li = nli; c = nc;
+        }
+        if (pending) { wait_handed(); drain(pend_it, pend_dump); }
+        WS_END(12);
+        return;
+    }
+
+    // ---------------- MFMA waves
+    const int wave = wave8 & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int rd_off = ((wave * MT) * TWH + l15) * P + E * lq;
+    const unsigned row_bytes = (unsigned)sp.cw * 4u;
+    const unsigned tap_bytes = (unsigned)a.Cin * row_bytes;
+    const unsigned tap_step = tap_bytes - (unsigned)(E - 1) * row_bytes;
+    typedef const wvec_t __attribute__((address_space(1)))* gvec_t;
+    // filter: lane (row l15, k-slot lq) reads floats [co, co+NT) of row tap*Cin + c*CK + E*lq + e; the lane part of the address
+    // is one 32-bit offset, the (tap, e) part a wave-uniform base pointer that walks the rows in load order (made opaque at
+    // every load so that it stays ONE SGPR pair advanced by s_add instead of 54 precomputed 64-bit vector addresses)
+    auto lane_off = [&](int li_, int c_) {
+        const int tl = fast_div(li_, sp.m_nblk);
+        const int n0 = (li_ - tl * sp.nblk) * 16 * NT;
+        const int co_lane = min(n0 + NT * l15, sp.cw - NT);
+        return (unsigned)co_lane * 4u + (unsigned)(c_ * CK + E * lq) * row_bytes;
+    };
+    // the accumulators start at the bias: lane (pixel column l15, k-slot lq) owns couts n0 + 4*NT*lq + [0, 4*NT)
+    auto load_bias = [&](int li_, float4 (&bv)[NT]) {
+        const int tl = fast_div(li_, sp.m_nblk);
+        const int cb = (li_ - tl * sp.nblk) * 16 * NT + 4 * NT * lq;
+#pragma unroll
+        for (int v = 0; v < NT; ++v)
+            bv[v] = (a.bias && cb + 4 * v < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + cb + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    f32x4 acc[MT][NT];
+    auto init_acc = [&](const float4 (&bv)[NT]) {
+#pragma unroll
+        for (int v = 0; v < NT; ++v) {
+            const float o[4] = {bv[v].x, bv[v].y, bv[v].z, bv[v].w};
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][(4 * v + cc) % NT][(4 * v + cc) / NT] = o[cc];
+        }
+    };
+    gcptr_t wp = (gcptr_t)(reinterpret_cast<const char*>(a.w));
+    unsigned voff = 0;
+    auto load_w = [&](int e, wvec_t (&dst)[G]) {                  // e = first k-slot row of the group within its tap
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            asm volatile("" : "+s"(wp));
+            dst[s] = *(gvec_t)(wp + (size_t)voff);
+            wp += (e + s == E - 1) ? tap_step : row_bytes;
+        }
+    };
+    wvec_t wv[WPD + 1][G];
+    float4 bnext[NT];
+    if (slot < nvalid) {
+        load_bias(slot, bnext);
+        voff = lane_off(slot, 0);
+#pragma unroll
+        for (int d = 0; d < WPD; ++d) load_w((d % NGRP) * G, wv[d]);
+    } else {
+#pragma unroll
+        for (int v = 0; v < NT; ++v) bnext[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    init_acc(bnext);
+
+    __syncthreads();                                              // S0
+    int k = 0;
+    WS_T0();
+    for (int li = slot; li < nvalid; li += SX) {
+        for (int c = 0; c < nchunks; ++c) {
+            const float* rd = ((k & 1) ? bufB : bufA) + rd_off;
+            const bool last = c + 1 == nchunks;
+            // the step after this one (its first filter fragments are requested at the tail of this K loop)
+            const int nli = last ? li + SX : li, nc = last ? 0 : c + 1;
+            const unsigned voff_next = nli < nvalid ? lane_off(nli, nc) : voff;
+            if (last && nli < nvalid) load_bias(nli, bnext);
+            auto load_a = [&](int gs, float (&dst)[MT][G]) {
+                const int tap = gs / NGRP, g = gs - tap * NGRP;
+                const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float* src = rd + ((i + ky) * TWH + kx) * P + g * G;
+                    if (G == 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(src);
+                        dst[i][0] = v.x; dst[i][1] = v.y; dst[i][2 % G] = v.z; dst[i][3 % G] = v.w;
+                    } else {
+                        const float2 v = *reinterpret_cast<const float2*>(src);
+                        dst[i][0] = v.x; dst[i][1] = v.y;
+                    }
+                }
+            };
+            float av[2][MT][G];
+            WS_TIC();
+            WS_CYC0();
+            load_a(0, av[0]);
+#pragma unroll
+            for (int gs = 0; gs < NGS; ++gs) {
+                if (gs + WPD == NGS) {                            // from here on: the next step's rows
+                    wp = (gcptr_t)(reinterpret_cast<const char*>(a.w));
+                    voff = voff_next;
+                }
+                load_w(((gs + WPD) % NGRP) * G, wv[(gs + WPD) % (WPD + 1)]);
+                if (gs + 1 < NGS) load_a(gs + 1, av[(gs + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < G; ++s)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wget<NT>(wv[gs % (WPD + 1)][s], j), av[gs & 1][i][s],
+                                                                              acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            WS_CYC1();
+            WS_TOC(1);
+            __syncthreads();                                      // X
+            WS_TOC(2);
+#ifdef STREAM_TRACE
+            tr_acc[5] += 1;
+#endif
+            if (last) {
+                // hand the accumulators over: lane (pixel column l15, k-slot lq) owns couts 4*NT*lq + [0, 4*NT) of rows wave*MT + i
+                float* dump = ((k & 1) ? lds + (GM::TOT - GM::DUMP) : lds) + (wave * MT * 16 + l15) * CO + 4 * NT * lq;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int v = 0; v < NT; ++v) {
+                        float4 o;
+                        o.x = acc[i][(4 * v + 0) % NT][(4 * v + 0) / NT];
+                        o.y = acc[i][(4 * v + 1) % NT][(4 * v + 1) / NT];
+                        o.z = acc[i][(4 * v + 2) % NT][(4 * v + 2) / NT];
+                        o.w = acc[i][(4 * v + 3) % NT][(4 * v + 3) / NT];
+                        *reinterpret_cast<float4*>(dump + i * 16 * CO + 4 * v) = o;
+                    }
+                init_acc(bnext);
+                if (lane == 0) __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                WS_TOC(3);
+            }
+            ++k;
+        }
+    }
+    WS_END(4);
+}
+
 // Output-channel counts that no NT divides (40 = RB5 of the headline backbone) used to fall back to NT = 1: 16 couts per
 // block, one dword of filter per lane and k-step, 65 TFLOP/s.  They now run with the widest NT that pads Cout no further
 // than NT = 1 would (40 -> 48 with NT = 3) on a zero-padded copy of the filter ([rows][cw], cw = whole blocks), so
@@ -366,6 +839,92 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
 #endif
 }
 
+int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        return v;
+    }();
+    return n;
+}
+
+// producer / consumer form (conv_stream_ws_kernel): one persistent workgroup per CU
+template <int KS, int E, int NT, int MT>
+bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
+    typedef WsGeom<KS, E, NT, MT> GM;
+    if constexpr (!GM::fits) {
+        return false;
+    } else {
+        ConvParams& p = sp.c;
+        if (p.Cin % GM::CK) return false;
+        // the helpers address a whole chunk / n-block with ONE origin plus per-thread offsets: channel offsets must be linear
+        // inside a chunk (input) and an n-block (output), i.e. depth_to_space groups may not be straddled, and the add / mask
+        // operands must be laid out like the output
+        auto linear = [](const TView& v, int span) { return v.d2s <= 1 || (span <= v.cp && v.cp % span == 0); };
+        auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
+        if (!linear(p.in, GM::CK) || !linear(p.out, GM::CO)) return false;
+        if (p.add.p && !same_layout(p.add, p.out)) return false;
+        if (p.mask.p && !same_layout(p.mask, p.out)) return false;
+        if ((size_t)(4 * MT + 2) * p.out.W * std::max(p.out.d2s, 1) * std::max(p.out.d2s, 1) * p.out.ld * 4 >= (1ull << 31)) return false;
+        if ((size_t)(4 * MT + 2) * p.in.W * std::max(p.in.d2s, 1) * std::max(p.in.d2s, 1) * p.in.ld * 4 >= (1ull << 31)) return false;
+        p.tiles_x = cdiv(p.W, 16);
+        p.tiles_y = cdiv(p.H, 4 * MT);
+        p.m_txy[0] = div_magic(p.tiles_x);
+        p.m_txy[1] = div_magic(p.tiles_y);
+        sp.ntiles = p.tiles_x * p.tiles_y * N;
+        sp.nblk = cdiv(p.Cout, 16 * NT);
+        sp.m_nblk = div_magic(sp.nblk);
+        sp.per_xcd = cdiv(sp.ntiles, 8);
+        const char* force = getenv("DL4DS_STREAM_FORCE_WS");       // (tests: "<workgroups per XCD>", small grids too)
+        const int SX = force ? std::max(atoi(force), 1) : std::max(cu_count() / 8, 1);
+        if (!force && (long)sp.per_xcd * sp.nblk < 2l * SX) return false;          // fewer than two items per workgroup: nothing to overlap
+        sp.cw = p.Cout;
+        if (p.Cout % NT) {
+            sp.cw = sp.nblk * 16 * NT;
+            const int rows = KS * KS * p.Cin;
+            float* wp = pad_scratch(s, (size_t)rows * sp.cw);
+            ProfScope pp(s, "pad_filter", 0.0, 4.0 * rows * (p.Cout + sp.cw));
+            hipLaunchKernelGGL(pad_filter_kernel, dim3(std::min(cdiv(rows * sp.cw, 256), 1024)), dim3(256), 0, s, p.w, wp, rows, p.Cout, sp.cw);
+            HIP_CHECK(hipGetLastError());
+            p.w = wp;
+        }
+        auto kern = conv_stream_ws_kernel<KS, E, NT, MT>;
+        static std::once_flag once;
+        std::call_once(once, [&]() {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)GM::LDS_BYTES));
+        });
+        const double px = (double)N * p.H * p.W;
+        ProfScope ps(s, "conv_stream_ws<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + "," +
+                            std::to_string(MT) + ">",
+                     2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+#ifdef STREAM_TRACE
+        static unsigned long long* trace_buf = nullptr;
+        static int trace_n = 0;
+        sp.trace = nullptr;
+        if (trace_n < 6) {
+            if (!trace_buf) HIP_CHECK(hipMalloc((void**)&trace_buf, (size_t)4096 * 16 * 8));
+            HIP_CHECK(hipMemsetAsync(trace_buf, 0, (size_t)4096 * 16 * 8, s));
+            sp.trace = trace_buf;
+        }
+#endif
+        hipLaunchKernelGGL(kern, dim3(8 * SX), dim3(512), GM::LDS_BYTES, s, sp);
+        HIP_CHECK(hipGetLastError());
+#ifdef STREAM_TRACE
+        if (sp.trace) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h((size_t)8 * SX * 16);
+            HIP_CHECK(hipMemcpy(h.data(), trace_buf, h.size() * 8, hipMemcpyDeviceToHost));
+            char name[128];
+            std::snprintf(name, sizeof name, "gpurun_out/ws_trace_%d.bin", trace_n++);
+            if (FILE* f = std::fopen(name, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+        }
+#endif
+        return true;
+    }
+}
+
 template <int KS, int E>
 void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
     switch (NT) {
@@ -429,7 +988,8 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
             if (bk < 0 || padded < bk || (padded == bk && e > E8)) { bk = padded; E8 = e; }
         }
         const long ntiles8 = (long)cdiv(in.W, 16) * cdiv(in.H, 32) * in.N;
-        const bool big = ntiles8 * cdiv(out.C, 16 * NT8) >= 1024 || getenv("DL4DS_STREAM_FORCE_TALL") != nullptr;   // (tests)
+        const bool big = ntiles8 * cdiv(out.C, 16 * NT8) >= 1024 || getenv("DL4DS_STREAM_FORCE_TALL") != nullptr ||
+                         getenv("DL4DS_STREAM_FORCE_WS") != nullptr;   // (tests)
         tall = NT8 == 3 && E8 == 6 && bp <= best && bk <= bestk && big;     // (NT 2 / 16-channel chunks measured slower)
         if (getenv("DL4DS_STREAM_TALL_ANY")) tall = NT8 >= 2 && bp <= best && bk <= bestk && big;     // (experiments)
     }
@@ -440,6 +1000,12 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.CK = 4 * E; p.TPS = 0;
+    static const bool use_ws = getenv("DL4DS_STREAM_NO_WS") == nullptr;
+    if (tall && use_ws && E8 == 6 && NT8 == 3) {
+        p.CK = 24;
+        if (launch_stream_ws<3, 6, 3, 8>(s, sp, in.N)) return true;
+        p.w = w;                                               // (not eligible: fall through to the two-workgroup kernel)
+    }
     if (tall) {
         p.CK = 4 * E8;
         if (E8 == 4) {

@@ -104,6 +104,38 @@ def test_conv2d_stream_tall_tiles_depth_to_space(ops, monkeypatch):
     close(ops.conv2d_dgrad(dz, wt, d2s=r), gx)
 
 
+@pytest.mark.parametrize('sx', ['1', '3', '32'])
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 40, 33, 48, 48), (3, 64, 48, 48, 192), (1, 33, 17, 192, 48), (2, 70, 16, 24, 48),
+                                        (1, 35, 20, 48, 96), (2, 32, 32, 48, 40), (5, 32, 16, 24, 24)])
+def test_conv2d_stream_producer_consumer(ops, monkeypatch, sx, n, h, w, ci, co):
+    """conv_stream_ws_kernel (one persistent 8-wave workgroup per CU: MFMA waves + staging / epilogue waves) is only
+    picked for large grids; DL4DS_STREAM_FORCE_WS=<workgroups per XCD> makes it take these small ones with 8, 24 and 256
+    workgroups, i.e. with many, a few and at most one item per workgroup: forward with fused epilogues, dgrad with
+    accumulate, ReLU mask."""
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', sx)
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    close(ops.conv2d(x, wt, b), ref)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    close(ops.conv2d_dgrad(dz, wt), gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+
+
+def test_conv2d_stream_producer_consumer_depth_to_space(ops, monkeypatch):
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', '2')
+    n, h, w, ci, co, r = 2, 34, 20, 48, 192, 2
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
+    close(ops.conv2d(x, wt, b, d2s=r), ref)
+    dz = R(n, h * r, w * r, co // (r * r))
+    gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
+    close(ops.conv2d_dgrad(dz, wt, d2s=r), gx)
+
+
 @pytest.mark.parametrize('ci,co', [(8, 8), (4, 8), (8, 4), (6, 8)])
 def test_conv2d_fused_epilogues_pair_path(ops, ci, co):
     n, h, w = 2, 19, 45
