@@ -493,7 +493,8 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
                 constexpr int M = decltype(mode_tag)::value;
                 constexpr bool ADD = (M & 1) != 0, RELU = (M & 2) != 0, MASK = (M & 4) != 0, ACC = (M & 8) != 0;
                 constexpr int NSTREAM = 1 + (ADD ? 1 : 0) + (MASK ? 1 : 0) + (ACC ? 1 : 0);
-                constexpr int GQ = NSTREAM <= 2 ? (ND % 6 == 0 ? 6 : ND) : (ND % 4 == 0 ? 4 : ND);
+                constexpr int GQ = (NSTREAM <= 2 && ND % 6 == 0) ? 6 : 4;
+                static_assert(ND % GQ == 0, "elements per thread");
 #pragma unroll
                 for (int g0 = 0; g0 < ND; g0 += GQ) {
                     f32x4 v[GQ];
@@ -927,6 +928,18 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
 
 template <int KS, int E>
 void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
+    if constexpr (KS == 3 && E >= 6) {
+        static const bool use_ws = getenv("DL4DS_STREAM_NO_WS") == nullptr;
+        if (use_ws && NT >= 2) {
+            const float* w0 = sp.c.w;
+            bool done = false;
+            if (NT == 2) done = launch_stream_ws<3, E, 2, 4>(s, sp, N);
+            else if (NT == 3) done = launch_stream_ws<3, E, 3, 4>(s, sp, N);
+            else done = launch_stream_ws<3, E, 4, 4>(s, sp, N);
+            if (done) return;
+            sp.c.w = w0;
+        }
+    }
     switch (NT) {
         case 1: launch_stream<KS, E, 1, 4>(s, sp, N); break;
         case 2: launch_stream<KS, E, 2, 4>(s, sp, N); break;

@@ -106,7 +106,10 @@ def test_conv2d_stream_tall_tiles_depth_to_space(ops, monkeypatch):
 
 @pytest.mark.parametrize('sx', ['1', '3', '32'])
 @pytest.mark.parametrize('n,h,w,ci,co', [(2, 40, 33, 48, 48), (3, 64, 48, 48, 192), (1, 33, 17, 192, 48), (2, 70, 16, 24, 48),
-                                        (1, 35, 20, 48, 96), (2, 32, 32, 48, 40), (5, 32, 16, 24, 24)])
+                                        (1, 35, 20, 48, 96), (2, 32, 32, 48, 40), (5, 32, 16, 24, 24),
+                                        # 16x16-pixel tiles (MT = 4): 32/40/48/24-channel chunks, 2-4 cout tiles, ragged Cout (40, 44)
+                                        (2, 33, 40, 32, 32), (1, 48, 32, 40, 40), (3, 32, 32, 48, 64), (2, 20, 50, 64, 48),
+                                        (1, 64, 16, 24, 32), (2, 17, 33, 80, 96), (1, 32, 32, 96, 44), (4, 16, 16, 32, 128)])
 def test_conv2d_stream_producer_consumer(ops, monkeypatch, sx, n, h, w, ci, co):
     """conv_stream_ws_kernel (one persistent 8-wave workgroup per CU: MFMA waves + staging / epilogue waves) is only
     picked for large grids; DL4DS_STREAM_FORCE_WS=<workgroups per XCD> makes it take these small ones with 8, 24 and 256
