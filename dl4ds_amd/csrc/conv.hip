@@ -663,6 +663,7 @@ struct WgradParams {
     float* partial;     // [S*WK][KK*Cin*Cout + Cout]  (weight slab followed by the bias-gradient slab)
     int Cin, Cout, H, W;
     int tiles_x, tiles_y, ntiles, S;
+    unsigned m_tx, m_ty;        // div_magic(tiles_x / tiles_y): tile -> (n, ty, tx) on the scalar unit (ntiles < 2^20)
 };
 
 // block = 4 waves arranged WCO (cout tiles) x WK (pixel/K split).  A wave owns cout tiles
@@ -1156,82 +1157,78 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
     const float* xf0 = smem + ((wk * RW) * TWH + lq * 4) * PX + l15;
     const float* zf0 = smem + HPIX * PX + ((wk * RW) * TW + lq * 4) * PZ + wco * 16 + l15;
 
-    // staging (waves 4-7): the whole tile is requested at once (the staging waves hold no accumulators, so its 17 float4
-    // registers are free) and a full tile period ahead of its use
-    constexpr int XR = (HPIX * (CIB / 4) + 255) / 256, ZR = (NPIX * (COB / 4) + 255) / 256;
-    float4 xr[XR], zq[ZR];                          // (live in the staging waves only)
-    auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
-        int t = tile;
-        const int tx = t % a.tiles_x;
-        t /= a.tiles_x;
-        const int ty = t % a.tiles_y;
-        n = t / a.tiles_y;
-        x0 = tx * TW;
-        y0 = ty * TH;
-    };
-    auto stage_load = [&](int tile) {
-        int n, y0, x0;
-        tile_origin(tile, n, y0, x0);
-#pragma unroll
-        for (int u = 0; u < XR; ++u) {
-            const int idx0 = stid + u * 256;
-            const bool ok = idx0 < HPIX * (CIB / 4);
-            const int idx = ok ? idx0 : 0;
-            const int pix = idx / (CIB / 4), q = idx - pix * (CIB / 4);
-            const int r = pix / TWH, c = pix - r * TWH;
-            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-            xr[u] = view_load4_vec(a.x, n, gy, gx, ci0 + q * 4,
-                                   ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci0 + q * 4 < a.Cin);
-        }
-#pragma unroll
-        for (int u = 0; u < ZR; ++u) {
-            const int idx0 = stid + u * 256;
-            const bool ok = idx0 < NPIX * (COB / 4);
-            const int idx = ok ? idx0 : 0;
-            const int pix = idx / (COB / 4), q = idx - pix * (COB / 4);
-            const int r = pix / TW, c = pix - r * TW;
-            const int gy = y0 + r, gx = x0 + c;
-            zq[u] = view_load4_vec(a.dz, n, gy, gx, co0 + q * 4, ok && gy < a.H && gx < a.W && co0 + q * 4 < a.Cout);
-        }
-    };
-    auto stage_store = [&](int tile, int buf) {
-        float* x_tile = smem + buf * TILE_FLOATS;
-        float* z_tile = x_tile + HPIX * PX;
-        int n, y0, x0;
-        tile_origin(tile, n, y0, x0);
-#pragma unroll
-        for (int u = 0; u < XR; ++u) {
-            const int idx = stid + u * 256;
-            if (idx < HPIX * (CIB / 4)) {
-                const int pix = idx / (CIB / 4), q = idx - pix * (CIB / 4);
-                const int r = pix / TWH, c = pix - r * TWH;
-                const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-                *reinterpret_cast<float4*>(x_tile + pix * PX + q * 4) =
-                    mask4(xr[u], valid4(ci0 + q * 4, a.Cin, gy >= 0 && gy < a.H && gx >= 0 && gx < a.W));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < ZR; ++u) {
-            const int idx = stid + u * 256;
-            if (idx < NPIX * (COB / 4)) {
-                const int pix = idx / (COB / 4), q = idx - pix * (COB / 4);
-                const int r = pix / TW, c = pix - r * TW;
-                *reinterpret_cast<float4*>(z_tile + pix * PZ + q * 4) =
-                    mask4(zq[u], valid4(co0 + q * 4, a.Cout, y0 + r < a.H && x0 + c < a.W));
-            }
-        }
-    };
     if (producer) {
-#ifdef WGRAD_PRODUCER_PRIO
-        __builtin_amdgcn_s_setprio(WGRAD_PRODUCER_PRIO);
-#endif
-        // staging waves: own code path, so that their load registers never coexist with the 108 accumulator registers
-        // (issuing the loads a further tile ahead, across the barrier, measured 3 % slower than load + store per iteration)
-        if ((int)blockIdx.x < a.ntiles) { stage_load(blockIdx.x); stage_store(blockIdx.x, 0); }
+        // Staging waves.  A wave that shares its SIMD with an MFMA wave gets an instruction issued only every ~100 cycles
+        // (tools/ws_trace.py on conv_stream_ws), so a tile costs ONE memory instruction per element and a handful of others:
+        //   * thread = (tile column, channel quad), element u = tile row u, so a wave's load covers one row: whether that
+        //     row lies inside the image is wave-uniform and goes into the buffer descriptor (0 records = every lane out
+        //     of range), whether the thread's column does is one compare per tile and goes into its offset;
+        //   * out-of-range buffer loads return zeros: exactly the zero padding the halo needs;
+        //   * LDS addresses are thread base + immediate.
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
+        constexpr int QX = CIB / 4, QZ = COB / 4;
+        static_assert(TWH * QX <= 256 && TW * QZ <= 256 && 256 % (TW * QZ) == 0, "one (column, quad) pair per staging thread");
+        constexpr int RP = 256 / (TW * QZ), ZR = TH / RP;          // dz: tile rows per pass, passes
+        const TView& vx = a.x;
+        const TView& vz = a.dz;
+        const int rx = vx.d2s > 1 ? vx.d2s : 1, rz = vz.d2s > 1 ? vz.d2s : 1;
+        const size_t xsx = (size_t)rx * vx.ld, xsy = (size_t)rx * (size_t)(vx.W * rx) * vx.ld;
+        const size_t zsx = (size_t)rz * vz.ld, zsy = (size_t)rz * (size_t)(vz.W * rz) * vz.ld;
+        const int xc = stid / QX, xq = stid - xc * QX;
+        const bool x_act = stid < TWH * QX;
+        const int xv0 = (x_act && ci0 + 4 * xq < a.Cin) ? (int)((xc * xsx + view_chan_off(vx, min(ci0 + 4 * xq, a.Cin - 4))) * 4) : OOB;
+        const int zp = stid % (TW * QZ);
+        const int zr0 = __builtin_amdgcn_readfirstlane(stid / (TW * QZ));          // (wave-uniform: TW * QZ is a multiple of 64)
+        const int zc = zp / QZ, zq = zp - zc * QZ;
+        const int zv0 = (co0 + 4 * zq < a.Cout) ? (int)((zc * zsx + view_chan_off(vz, min(co0 + 4 * zq, a.Cout - 4))) * 4) : OOB;
+        const int x_dst = xc * PX + xq * 4, z_dst = (zr0 * TW + zc) * PZ + zq * 4;
+        auto stage = [&](int tile, int buf) __attribute__((always_inline)) {
+            const int tq = fast_div(tile, a.m_tx);
+            const int tx = tile - tq * a.tiles_x;
+            const int n = fast_div(tq, a.m_ty);
+            const int ty = tq - n * a.tiles_y;
+            const int x0 = tx * TW, y0 = ty * TH;
+            char* xb = reinterpret_cast<char*>(vx.p) + ((long)((size_t)n * vx.nstride) + (long)(y0 - PAD) * (long)xsy + (long)(x0 - PAD) * (long)xsx) * 4;
+            char* zb = reinterpret_cast<char*>(vz.p) + ((size_t)n * vz.nstride + y0 * zsy + x0 * zsx) * 4;
+            const int xv = (x0 - PAD + xc >= 0 && x0 - PAD + xc < a.W) ? xv0 : OOB;
+            const int zv = (x0 + zc < a.W) ? zv0 : OOB;
+            i32x4_t xr[THH], zq4[ZR];
+            if (y0 >= PAD && y0 + TH + PAD <= a.H) {              // every row of the halo inside the image: one descriptor each
+                const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 0x7fffff00, RSRC3);
+                const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(zb, 0, 0x7fffff00, RSRC3);
+#pragma unroll
+                for (int u = 0; u < THH; ++u) xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, xv, (int)(u * xsy * 4), 0);
+#pragma unroll
+                for (int u = 0; u < ZR; ++u) zq4[u] = __builtin_amdgcn_raw_buffer_load_b128(rsz, zv, (int)((u * RP + zr0) * zsy * 4), 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < THH; ++u) {
+                    const bool row_ok = y0 - PAD + u >= 0 && y0 - PAD + u < a.H;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, row_ok ? 0x7fffff00 : 0, RSRC3);
+                    xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, xv, (int)(u * xsy * 4), 0);
+                }
+#pragma unroll
+                for (int u = 0; u < ZR; ++u) {
+                    const int row = u * RP + zr0;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(zb, 0, (y0 + row < a.H) ? 0x7fffff00 : 0, RSRC3);
+                    zq4[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, zv, (int)(row * zsy * 4), 0);
+                }
+            }
+            float* x_tile = smem + buf * TILE_FLOATS;
+            float* z_tile = x_tile + HPIX * PX;
+            if (x_act) {
+#pragma unroll
+                for (int u = 0; u < THH; ++u) *reinterpret_cast<i32x4_t*>(x_tile + x_dst + u * (TWH * PX)) = xr[u];
+            }
+#pragma unroll
+            for (int u = 0; u < ZR; ++u) *reinterpret_cast<i32x4_t*>(z_tile + z_dst + u * (RP * TW * PZ)) = zq4[u];
+        };
+        if ((int)blockIdx.x < a.ntiles) stage(blockIdx.x, 0);
         __syncthreads();
         int itp = 0;
         for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S, ++itp) {
-            if (tile + a.S < a.ntiles) { stage_load(tile + a.S); stage_store(tile + a.S, (itp & 1) ^ 1); }
+            if (tile + a.S < a.ntiles) stage(tile + a.S, (itp & 1) ^ 1);
             __syncthreads();
         }
         return;                                        // (finished waves no longer take part in barriers)
@@ -1388,7 +1385,8 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     // every block does the same amount of work, so the grid should be exactly one residency round:
     // 256 CUs x 2 workgroups (LDS / VGPR limited) = 512 blocks.  768 blocks ran as 1.5 rounds (+33 % time).
     // (the producer/consumer rows kernel runs ONE 8-wave workgroup per CU)
-    p.ws = KS == 3 && !(p.CIT == 1 && p.WCO == 1) && x.vec && dz.vec && !getenv("DL4DS_NO_WGRAD_ROWS") && !getenv("DL4DS_NO_WGRAD_WS");
+    p.ws = KS == 3 && !(p.CIT == 1 && p.WCO == 1) && x.vec && dz.vec && p.ntiles < (1 << 20) && !getenv("DL4DS_NO_WGRAD_ROWS") &&
+           !getenv("DL4DS_NO_WGRAD_WS");
     int target = std::max(1, (p.ws ? 256 : 512) / (cob * cib));
     const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
     const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (slab * sizeof(float)));
@@ -1577,6 +1575,7 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     p.x = x; p.dz = dz; p.partial = workspace;
     p.Cin = x.C; p.Cout = dz.C; p.H = x.H; p.W = x.W;
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S;
+    p.m_tx = div_magic(p.tiles_x); p.m_ty = div_magic(p.tiles_y);
     if (direct_slabs) {
         nslabs = conv2d_direct_wgrad(s, x, dz, KS, workspace, direct_slabs);
     } else if (narrow_slabs) {

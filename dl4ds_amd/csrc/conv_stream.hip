@@ -400,6 +400,11 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
         const bool st_active = p0 < PPASS;
         size_t isy, isx;
         view_strides(a.in, isy, isx);
+        // channel offset of the thread's quad inside a chunk: linear views -> 4*c4 on top of the chunk's own offset (part of the
+        // origin); a view whose depth_to_space groups are narrower than a chunk is taken only with ONE chunk (launcher), whose
+        // per-quad offsets are static too
+        const bool in_lin = a.in.d2s <= 1 || (CK <= a.in.cp && a.in.cp % CK == 0);
+        const size_t in_c4 = in_lin ? (size_t)c4 * 4 : view_chan_off(a.in, min(c4 * 4, a.Cin - 4));
         int rel[SIT], soff[SIT], hyx[SIT];
 #pragma unroll
         for (int u = 0; u < SIT; ++u) {
@@ -407,7 +412,7 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
             const int hy = hp / TWH, hx = hp - hy * TWH;
             const bool live = st_active && hp < HPIX;
             hyx[u] = live ? ((hy << 8) | hx) : 0x7f7f;            // (0x7f: never inside the image window)
-            rel[u] = live ? (int)((hy * isy + hx * isx + (size_t)c4 * 4) * 4) : OOB;
+            rel[u] = live ? (int)((hy * isy + hx * isx + in_c4) * 4) : OOB;
             soff[u] = rel[u];
         }
         int st_sig = (THH << 8) | TWH;                            // window signature of soff[]: (ylo, yhi, xlo, xhi) packed
@@ -428,7 +433,7 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
             }
             // wave-uniform origin of the halo tile (outside the tensor for border tiles; never dereferenced there)
             const long org = (long)((size_t)it.n * a.in.nstride) + (long)(it.y0 - PAD) * (long)isy + (long)(it.x0 - PAD) * (long)isx +
-                             (long)view_chan_off(a.in, c0);
+                             (in_lin ? (long)view_chan_off(a.in, c0) : 0l);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
             float* dst = tile + st_dst;
@@ -458,32 +463,35 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
         constexpr int ND = MT * NT;                               // elements per thread
         size_t osy, osx;
         view_strides(a.out, osy, osx);                            // (add / mask views have the same strides: launcher)
+        // (the same for the output's channel quads inside an n-block; otherwise they go through the view per n-block)
+        const bool out_lin = a.out.d2s <= 1 || (CO <= a.out.cp && a.out.cp % CO == 0);
         int dvo[ND];
 #pragma unroll
         for (int u = 0; u < ND; ++u) {
             const int e = htid + HT * u;
             const int pix = e / NQ, quad = e - pix * NQ;
-            dvo[u] = (int)(((pix >> 4) * osy + (pix & 15) * osx + (size_t)quad * 4) * 4);
+            dvo[u] = (int)(((pix >> 4) * osy + (pix & 15) * osx + (out_lin ? (size_t)quad * 4 : view_chan_off(a.out, min(4 * quad, a.Cout - 4)))) * 4);
         }
-        int dr_sig = (NQ << 16) | (TH << 8) | TW;                 // signature of dvo[]: (quads, rows, columns) that exist
+        int dr_sig = (NQ << 16) | (TH << 8) | TW;                 // signature of dvo[]: (n-block,) quads, rows, columns that exist
         auto drain = [&](const Item& it, const float* dump) __attribute__((always_inline)) {
             const int nq = min(NQ, (a.Cout - it.n0) >> 2);        // channel quads of this n-block that exist
             const int ymax = min(TH, a.H - it.y0), xmax = min(TW, a.W - it.x0);
-            const int sig = (nq << 16) | (ymax << 8) | xmax;
+            const int sig = (out_lin ? 0 : it.n0 << 24) | (nq << 16) | (ymax << 8) | xmax;
             if (sig != dr_sig) {                                  // (wave-uniform: ragged image edges, last n-block of a ragged Cout)
                 dr_sig = sig;
 #pragma unroll
                 for (int u = 0; u < ND; ++u) {
                     const int e = htid + HT * u;
                     const int pix = e / NQ, quad = e - pix * NQ;
-                    const int o = (int)(((pix >> 4) * osy + (pix & 15) * osx + (size_t)quad * 4) * 4);
+                    const size_t ch = out_lin ? (size_t)quad * 4 : view_chan_off(a.out, min(it.n0 + 4 * quad, a.Cout - 4));
+                    const int o = (int)(((pix >> 4) * osy + (pix & 15) * osx + ch) * 4);
                     dvo[u] = ((pix >> 4) < ymax && (pix & 15) < xmax && quad < nq) ? o : OOB;
                 }
             }
-            const size_t ooff = (size_t)it.n * a.out.nstride + it.y0 * osy + it.x0 * osx + view_chan_off(a.out, it.n0);
+            const size_t ooff = (size_t)it.n * a.out.nstride + it.y0 * osy + it.x0 * osx + (out_lin ? view_chan_off(a.out, it.n0) : 0);
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out.p) + ooff * 4, 0, 0x7fffff00, RSRC3);
-            const size_t aoff = a.add.p ? (size_t)it.n * a.add.nstride + it.y0 * osy + it.x0 * osx + view_chan_off(a.add, it.n0) : 0;
-            const size_t moff = a.mask.p ? (size_t)it.n * a.mask.nstride + it.y0 * osy + it.x0 * osx + view_chan_off(a.mask, it.n0) : 0;
+            const size_t aoff = a.add.p ? (size_t)it.n * a.add.nstride + it.y0 * osy + it.x0 * osx + (out_lin ? view_chan_off(a.add, it.n0) : 0) : 0;
+            const size_t moff = a.mask.p ? (size_t)it.n * a.mask.nstride + it.y0 * osy + it.x0 * osx + (out_lin ? view_chan_off(a.mask, it.n0) : 0) : 0;
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.add.p) + aoff * 4, 0, 0x7fffff00, RSRC3);
             const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.mask.p) + moff * 4, 0, 0x7fffff00, RSRC3);
             const float* src = dump + htid * 4;
@@ -864,7 +872,8 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
         // operands must be laid out like the output
         auto linear = [](const TView& v, int span) { return v.d2s <= 1 || (span <= v.cp && v.cp % span == 0); };
         auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
-        if (!linear(p.in, GM::CK) || !linear(p.out, GM::CO)) return false;
+        if (!linear(p.in, GM::CK) && p.Cin != GM::CK) return false;        // (narrower groups: one chunk only)
+        if (!linear(p.out, GM::CO) && p.Cout >= 128) return false;         // (n0 must fit the 8 bits it gets in the drain signature)
         if (p.add.p && !same_layout(p.add, p.out)) return false;
         if (p.mask.p && !same_layout(p.mask, p.out)) return false;
         if ((size_t)(4 * MT + 2) * p.out.W * std::max(p.out.d2s, 1) * std::max(p.out.d2s, 1) * p.out.ld * 4 >= (1ull << 31)) return false;

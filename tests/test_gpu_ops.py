@@ -128,9 +128,12 @@ def test_conv2d_stream_producer_consumer(ops, monkeypatch, sx, n, h, w, ci, co):
     close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
 
 
-def test_conv2d_stream_producer_consumer_depth_to_space(ops, monkeypatch):
+@pytest.mark.parametrize('ci,co', [(48, 192), (48, 32), (24, 32), (48, 96)])
+def test_conv2d_stream_producer_consumer_depth_to_space(ops, monkeypatch, ci, co):
+    """... through depth_to_space views on the output (forward) and the input (dgrad), also with groups narrower than an
+    n-block / a channel chunk (32 couts = 4 groups of 8: the composed upsampling tail of the headline model)."""
     monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', '2')
-    n, h, w, ci, co, r = 2, 34, 20, 48, 192, 2
+    n, h, w, r = 2, 34, 20, 2
     x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
     ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
     close(ops.conv2d(x, wt, b, d2s=r), ref)
