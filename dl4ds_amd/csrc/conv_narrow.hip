@@ -193,59 +193,72 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
     const size_t q_mask = a.mask.p ? view_chan_off(a.mask, c_ok ? ec : 0) : 0;
     const float4 bias_v = (a.bias && c_ok) ? *reinterpret_cast<const float4*>(a.bias + ec) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int t = blockIdx.x; t < a.tiles_x * a.tiles_y * a.in.N; t += gridDim.x) {
+    // The halo tile of the NEXT tile is requested while this one is computed and stored: the kernel is HBM-bound, and with
+    // load -> LDS -> MFMA -> store phases per tile only a third of the resident workgroups had loads in flight at any time
+    // (3.0-3.4 TB/s).  The five float4 staging registers and the packed validity bits stay live across the MFMA phase.
+    const int ntiles_all = a.tiles_x * a.tiles_y * a.in.N;
+    float4 r[ITERS];
+    unsigned mbits = 0;
+    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const int q = fast_div(t, a.m_txy[0]);
+        const int bx = t - q * a.tiles_x;
+        const int n = fast_div(q, a.m_txy[1]);
+        const int by = q - n * a.tiles_y;
+        const int x0 = bx * PTW, y0 = by * PTH;
+        mbits = 0;
+        // the vec / scalar choice is made OUTSIDE the unrolled load loops: a (uniform) branch per load keeps the
+        // loads in separate basic blocks and cost 13 % on the aligned case
+        if (vec_in) {
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                const int e = tid + u * 256;
+                const int pix = e >> 1, c4 = e & 1;
+                const int hy = pix / TWH, hx = pix - hy * TWH;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool cok = ok && c4 * 4 < a.Cin;
+                const size_t off = (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld +
+                                   (cok ? c4 * 4 : 0);
+                r[u] = *reinterpret_cast<const float4*>(a.in.p + off);
+                mbits |= valid4(c4 * 4, a.Cin, ok) << (4 * u);
+            }
+            // channel affine of the view (ChannelAttention2D's scale / its backward, see TView): the thread's channel quad
+            // is fixed (e & 1 == tid & 1), the image is fixed for the tile; applied when the tile is written to LDS
+            if (a.in.sc) view_affine4(a.in, n, (tid & 1) * 4, s4, h4);
+        } else {
+            // Cin not a multiple of 4 (e.g. the 5 + 1 input channels of the U-Net): four clamped scalar loads
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                const int e = tid + u * 256;
+                const int pix = e >> 1, c4 = e & 1;
+                const int hy = pix / TWH, hx = pix - hy * TWH;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const float* px = a.in.p + (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld;
+                const int cm = a.Cin - 1;
+                r[u] = make_float4(px[min(c4 * 4, cm)], px[min(c4 * 4 + 1, cm)], px[min(c4 * 4 + 2, cm)], px[min(c4 * 4 + 3, cm)]);
+                mbits |= valid4(c4 * 4, a.Cin, ok) << (4 * u);
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles_all) issue(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles_all; t += gridDim.x) {
         const int q = fast_div(t, a.m_txy[0]);
         const int bx = t - q * a.tiles_x;
         const int n = fast_div(q, a.m_txy[1]);
         const int by = q - n * a.tiles_y;
         const int x0 = bx * PTW, y0 = by * PTH;
         {
-            float4 r[ITERS];
-            unsigned m[ITERS];
-            // the vec / scalar choice is made OUTSIDE the unrolled load loops: a (uniform) branch per load keeps the
-            // loads in separate basic blocks and cost 13 % on the aligned case
-            if (vec_in) {
+            if (vec_in && a.in.sc) {
 #pragma unroll
-                for (int u = 0; u < ITERS; ++u) {
-                    const int e = tid + u * 256;
-                    const int pix = e >> 1, c4 = e & 1;
-                    const int hy = pix / TWH, hx = pix - hy * TWH;
-                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                    const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                    const bool cok = ok && c4 * 4 < a.Cin;
-                    const size_t off = (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld +
-                                       (cok ? c4 * 4 : 0);
-                    r[u] = *reinterpret_cast<const float4*>(a.in.p + off);
-                    m[u] = valid4(c4 * 4, a.Cin, ok);
-                }
-                if (a.in.sc) {
-                    // channel affine of the view (ChannelAttention2D's scale / its backward, see TView): the thread's
-                    // channel quad is fixed (e & 1 == tid & 1), the image is fixed for the tile
-                    float4 s4, h4;
-                    view_affine4(a.in, n, (tid & 1) * 4, s4, h4);
-#pragma unroll
-                    for (int u = 0; u < ITERS; ++u) r[u] = affine4(r[u], s4, h4);
-                }
-            } else {
-                // Cin not a multiple of 4 (e.g. the 5 + 1 input channels of the U-Net): four clamped scalar loads
-#pragma unroll
-                for (int u = 0; u < ITERS; ++u) {
-                    const int e = tid + u * 256;
-                    const int pix = e >> 1, c4 = e & 1;
-                    const int hy = pix / TWH, hx = pix - hy * TWH;
-                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                    const bool ok = e < TOTAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                    const float* px = a.in.p + (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld;
-                    const int cm = a.Cin - 1;
-                    r[u] = make_float4(px[min(c4 * 4, cm)], px[min(c4 * 4 + 1, cm)], px[min(c4 * 4 + 2, cm)], px[min(c4 * 4 + 3, cm)]);
-                    m[u] = valid4(c4 * 4, a.Cin, ok);
-                }
+                for (int u = 0; u < ITERS; ++u) r[u] = affine4(r[u], s4, h4);
             }
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) {
                 const int e = tid + u * 256;
                 if (e < TOTAL) {
-                    const float4 v = mask4(r[u], m[u]);
+                    const float4 v = mask4(r[u], (mbits >> (4 * u)) & 15u);
                     float2* d = reinterpret_cast<float2*>(tile + (size_t)(e >> 1) * P + (e & 1) * 4);
                     d[0] = make_float2(v.x, v.y);
                     d[1] = make_float2(v.z, v.w);
@@ -253,6 +266,7 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
             }
         }
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles_all) issue(t + gridDim.x);
 
         f32x4 acc[NR];
 #pragma unroll
