@@ -1378,7 +1378,14 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     p.ntiles = p.tiles_x * p.tiles_y * x.N;
     p.CIT = (x.C > 32) ? 3 : (x.C > 16 ? 2 : 1);
     if (KS >= 5) p.CIT = 1;
-    p.WCO = (dz.C <= 16) ? 1 : (dz.C <= 32 ? 2 : 4);
+    // cout tiles per block (16 * WCO couts; the other 4 / WCO waves split the tile's rows): the least padded one.  48 and 40
+    // couts used to run as one 64-cout block with a quarter of the MFMAs on zero columns (93 TFLOP/s); as three 16-cout
+    // blocks whose four waves split the rows they reach 110
+    p.WCO = 4;
+    for (int wco = 4; wco >= 1; wco >>= 1)
+        if (cdiv(dz.C, 16 * wco) * 16 * wco < cdiv(dz.C, 16 * p.WCO) * 16 * p.WCO) p.WCO = wco;
+    if (dz.C <= 16) p.WCO = 1;
+    else if (dz.C <= 32 && p.WCO == 4) p.WCO = 2;
     if (const char* e = getenv("DL4DS_WGRAD_WCO")) p.WCO = atoi(e);      // (experiments)
     p.WK = 4 / p.WCO;
     const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
