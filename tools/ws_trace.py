@@ -11,7 +11,7 @@ ok = steps > 0
 a, steps = a[ok], steps[ok]
 us = lambda col: a[:, col] / 100.0
 print(f'{len(a)} workgroups with work, {steps.mean():.1f} steps each; per workgroup, mean (us):')
-print(f'  MFMA waves : lifetime {us(4).mean():8.1f} | K loops {us(1).mean():8.1f} | waiting at X {us(2).mean():7.1f} | hand-over + Y {us(3).mean():7.1f}')
+print(f'  MFMA waves : lifetime {us(4).mean():8.1f} | K loops {us(1).mean():8.1f} | waiting at X {us(2).mean():7.1f} | hand-over {us(3).mean():7.1f}')
 print(f'  helpers    : lifetime {us(12).mean():8.1f} | drain {us(8).mean():8.1f} | helper barrier {us(9).mean():6.1f} | stage {us(10).mean():7.1f} | waiting at X/Y {us(11).mean():7.1f}')
 print(f'  stage split: address + issue of the loads {us(14).mean():7.1f} | waiting for the data {us(15).mean():7.1f} | LDS writes (rest) {us(10).mean():7.1f}')
 cyc = a[:, 0] / steps
