@@ -153,7 +153,10 @@ void launch_narrow(hipStream_t s, ConvParams& p, int N) {
 // now covers 32 pixels: 24 MFMAs per 32 pixels instead of 36, and after the MFMA every lane holds four couts of one
 // pixel, so all 64 lanes store (the 16-pixel variant idles half of them).
 template <int NR>
-__global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvParams a) {
+#ifndef NARROW_PAIR_LB
+#define NARROW_PAIR_LB 3
+#endif
+__global__ void __launch_bounds__(256, NARROW_PAIR_LB) conv_narrow_pair_kernel(const ConvParams a) {
     constexpr int PTW = 32, PTH = 4 * NR;            // tile: 32 x (4 waves x NR rows)
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
     constexpr int P = 10;                            // LDS pixel pitch (floats): lanes 2 pixels apart -> all 32 banks
@@ -242,8 +245,13 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
             }
         }
     };
+#ifndef NARROW_PAIR_NOPF
     if ((int)blockIdx.x < ntiles_all) issue(blockIdx.x);
+#endif
     for (int t = blockIdx.x; t < ntiles_all; t += gridDim.x) {
+#ifdef NARROW_PAIR_NOPF
+        issue(t);
+#endif
         const int q = fast_div(t, a.m_txy[0]);
         const int bx = t - q * a.tiles_x;
         const int n = fast_div(q, a.m_txy[1]);
@@ -266,7 +274,9 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
             }
         }
         __syncthreads();
+#ifndef NARROW_PAIR_NOPF
         if (t + (int)gridDim.x < ntiles_all) issue(t + gridDim.x);
+#endif
 
         f32x4 acc[NR];
 #pragma unroll
@@ -336,6 +346,225 @@ __global__ void __launch_bounds__(256, 3) conv_narrow_pair_kernel(const ConvPara
     }
 }
 
+// Producer / consumer form of the pair kernel (float4-loadable plain inputs, no pooling partials): 8-wave workgroups, two per
+// CU.  Waves 4-7 do nothing but move halo tiles: buffer loads three tiles ahead (three register sets; out-of-range offsets
+// return the zero padding), LDS writes one tile ahead into the other of two buffers.  Waves 0-3 run the 96 MFMAs of a tile
+// (accumulators start at the bias through the C operand of each row's first MFMA) and store their four float4 per lane
+// through precomputed offsets.  One barrier per tile.  With load -> LDS -> MFMA -> store phases inside every wave the
+// kernel kept neither the matrix pipe (55 % busy) nor HBM (3.2 TB/s) occupied.
+template <int NR>
+__global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvParams a) {
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int PTW = 32, PTH = 4 * NR;
+    constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
+    constexpr int P = 10;
+    constexpr int TOTAL = HPIX * 2, ITERS = (TOTAL + 255) / 256;
+    constexpr int TILE = HPIX * P;
+    constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave8 = tid >> 6;
+    const int ntiles = a.tiles_x * a.tiles_y * a.in.N;
+    const int G = gridDim.x;
+    auto origin = [&](int t, int& n, int& y0, int& x0) {
+        const int q = fast_div(t, a.m_txy[0]);
+        const int bx = t - q * a.tiles_x;
+        n = fast_div(q, a.m_txy[1]);
+        const int by = q - n * a.tiles_y;
+        x0 = bx * PTW; y0 = by * PTH;
+    };
+
+    if (wave8 >= 4) {
+        // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 1) + 128 u, channel quad htid & 1)
+        const int htid = tid & 255;
+        const int c4 = htid & 1, p0 = htid >> 1;
+        const size_t isx = a.in.ld, isy = (size_t)a.W * a.in.ld;
+        int rel[ITERS], soff[ITERS], hyx[ITERS];
+#pragma unroll
+        for (int u = 0; u < ITERS; ++u) {
+            const int pix = p0 + 128 * u;
+            const int hy = pix / TWH, hx = pix - hy * TWH;
+            const bool live = pix < HPIX && c4 * 4 < a.Cin;
+            hyx[u] = pix < HPIX ? ((hy << 8) | hx) : 0x7f7f;
+            rel[u] = live ? (int)((hy * isy + hx * isx + (size_t)c4 * 4) * 4) : OOB;
+            soff[u] = rel[u];
+        }
+        int sig_cur = (THH << 8) | TWH;
+        i32x4_t r[3][ITERS];
+        auto issue = [&](int t, i32x4_t (&dst)[ITERS]) __attribute__((always_inline)) {
+            int n, y0, x0;
+            origin(t, n, y0, x0);
+            const int ylo = max(0, 1 - y0), yhi = min(THH, a.H + 1 - y0);
+            const int xlo = max(0, 1 - x0), xhi = min(TWH, a.W + 1 - x0);
+            const int sig = (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
+            if (sig != sig_cur) {
+                sig_cur = sig;
+#pragma unroll
+                for (int u = 0; u < ITERS; ++u) {
+                    const int hy = hyx[u] >> 8, hx = hyx[u] & 0xff;
+                    soff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? rel[u] : OOB;
+                }
+            }
+            const long org = (long)((size_t)n * a.in.nstride) + (long)(y0 - 1) * (long)isy + (long)(x0 - 1) * (long)isx;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[u], 0, 0);
+        };
+        auto put = [&](const i32x4_t (&src)[ITERS], float* tile) __attribute__((always_inline)) {
+            float* d0 = tile + p0 * P + c4 * 4;
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                if (u + 1 < ITERS || (hyx[u] >> 8) < THH) {
+                    int2* d = reinterpret_cast<int2*>(d0 + u * (128 * P));
+                    d[0] = make_int2(src[u][0], src[u][1]);
+                    d[1] = make_int2(src[u][2], src[u][3]);
+                }
+            }
+        };
+        const int t0 = blockIdx.x;
+        if (t0 < ntiles) issue(t0, r[0]);
+        if (t0 + G < ntiles) issue(t0 + G, r[1]);
+        if (t0 < ntiles) put(r[0], lds);
+        if (t0 + 2 * G < ntiles) issue(t0 + 2 * G, r[2]);
+        __syncthreads();                                          // S0: tile 0 staged
+        // iteration k (beside the MFMAs of tile k): write tile k+1, request tile k+3 into the set tile k used
+        int k = 0;
+        for (int t = t0; t < ntiles; t += 3 * G) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int tk = t + j * G;
+                if (tk < ntiles) {
+                    if (tk + G < ntiles) put(r[(j + 1) % 3], lds + ((k + 1) & 1) * TILE);
+                    if (tk + 3 * G < ntiles) issue(tk + 3 * G, r[j]);
+                    __syncthreads();                              // X: tile k consumed, tile k+1 staged
+                    ++k;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- MFMA waves
+    const int wave = wave8 & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    float wr[3][4][2];
+    {
+        const int h = l15 >> 3, co = l15 & 7;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ux = 0; ux < 4; ++ux)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kx = ux - h, ci = 2 * lq + e;
+                    const bool ok = kx >= 0 && kx <= 2 && ci < a.Cin && co < a.Cout;
+                    const float v = a.w[((size_t)(dy * 3 + (ok ? kx : 0)) * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? co : 0)];
+                    wr[dy][ux][e] = ok ? v : 0.f;
+                }
+    }
+    const int rd_off = ((wave * NR) * TWH + 2 * l15) * P + 2 * lq;
+    // lane (pair column l15, k-slot lq) holds rows 4*lq + r = (h = lq >> 1, couts 4*(lq & 1) + r)
+    const int eh = lq >> 1, ec = 4 * (lq & 1);
+    const bool c_ok = ec < a.Cout;
+    const float4 bias_v = (a.bias && c_ok) ? *reinterpret_cast<const float4*>(a.bias + ec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const f32x4 bias_c = {bias_v.x, bias_v.y, bias_v.z, bias_v.w};
+    size_t osx, osy;
+    {
+        const int r = a.out.d2s > 1 ? a.out.d2s : 1;
+        osx = (size_t)r * a.out.ld;
+        osy = (size_t)r * (size_t)(a.out.W * r) * a.out.ld;
+    }
+    int eo[NR], eoff[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        eo[i] = c_ok ? (int)(((wave * NR + i) * osy + (2 * l15 + eh) * osx + view_chan_off(a.out, c_ok ? ec : 0)) * 4) : OOB;
+        eoff[i] = eo[i];
+    }
+    int esig = (PTH << 8) | PTW;
+
+    __syncthreads();                                              // S0
+    int k = 0;
+    for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
+        const float* rd = lds + (k & 1) * TILE + rd_off;
+        f32x4 acc[NR];
+        // (reading the pixel fragments two halo rows ahead of their MFMAs costs 32 registers and the second workgroup per
+        //  CU: 78 -> 87 us for 16 x 512^2)
+#pragma unroll
+        for (int rho = 0; rho < NR + 2; ++rho) {
+            if (rho % 2 == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ux = 0; ux < 4; ++ux) {
+                const float2 v = *reinterpret_cast<const float2*>(rd + (rho * TWH + ux) * P);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = rho - dy;
+                    if (r >= 0 && r < NR) {
+                        const bool first = dy == 0 && ux == 0;    // this row's first MFMA: C = bias
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][0], v.x, first ? bias_c : acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][1], v.y, acc[r], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                          // X
+        int n, y0, x0;
+        origin(t, n, y0, x0);
+        const int ymax = min(PTH, a.H - y0), xmax = min(PTW, a.W - x0);
+        const int sig = (ymax << 8) | xmax;
+        if (sig != esig) {
+            esig = sig;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && 2 * l15 + eh < xmax) ? eo[i] : OOB;
+        }
+        const size_t pb = (size_t)y0 * osy + (size_t)x0 * osx;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(a.out.p) + ((size_t)n * a.out.nstride + pb) * 4, 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(a.add.p) + (a.add.p ? ((size_t)n * a.add.nstride + pb) * 4 : 0), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(a.mask.p) + (a.mask.p ? ((size_t)n * a.mask.nstride + pb) * 4 : 0), 0, 0x7fffff00, RSRC3);
+        i32x4_t ad[NR], mk[NR], old[NR];
+        if (a.add.p) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+        }
+        if (a.mask.p) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+        }
+        if (a.accumulate) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            f32x4 v = acc[i];
+            if (a.add.p) v += __builtin_bit_cast(f32x4, ad[i]);
+            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (a.mask.p) {
+                const f32x4 m = __builtin_bit_cast(f32x4, mk[i]);
+                v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f;
+                v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
+            }
+            if (a.accumulate) v += __builtin_bit_cast(f32x4, old[i]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
+        }
+    }
+}
+
+bool narrow_pair_ws_ok(const ConvParams& p) {
+    static const bool off = getenv("DL4DS_NO_PAIR_WS") != nullptr;
+    auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
+    if (off || p.pool || p.in.sc || !p.in.vec || (p.Cin & 3) || p.in.d2s > 1) return false;
+    if (p.add.p && !same_layout(p.add, p.out)) return false;
+    if (p.mask.p && !same_layout(p.mask, p.out)) return false;
+    const size_t r = p.out.d2s > 1 ? p.out.d2s : 1;
+    if ((size_t)20 * p.out.W * r * r * p.out.ld * 4 >= (1ull << 31) || (size_t)20 * p.W * p.in.ld * 4 >= (1ull << 31)) return false;
+    return true;
+}
+
 template <int NR>
 void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
     p.tiles_x = cdiv(p.W, 32);
@@ -344,8 +573,16 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
     p.m_txy[1] = div_magic(p.tiles_y);
     const int ntiles = p.tiles_x * p.tiles_y * N;
     if (ntiles == 0) return;
-    const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_kernel<NR>>(256));
     const double px = (double)N * p.H * p.W;
+    if (narrow_pair_ws_ok(p)) {
+        const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_ws_kernel<NR>>(512));
+        ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
+                     4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+        hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR>), dim3(blocks), dim3(512), 0, s, p);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_kernel<NR>>(256));
     ProfScope ps(s, "conv_narrow_pair<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
     hipLaunchKernelGGL((conv_narrow_pair_kernel<NR>), dim3(blocks), dim3(256), 0, s, p);
