@@ -822,7 +822,9 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_stream<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + "," +
                         std::to_string(MT) + ">",
-                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+                 2.0 * px * KS * KS * p.Cin * p.Cout,
+                 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) +
+                        (double)KS * KS * p.Cin * p.Cout));
 #ifdef STREAM_TRACE
     // -DSTREAM_TRACE build (tools/variant_build.sh): the first launches of the tall NT = 3 variant dump their timeline
     static unsigned long long* trace_buf = nullptr;
@@ -908,7 +910,10 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
         const double px = (double)N * p.H * p.W;
         ProfScope ps(s, "conv_stream_ws<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + "," +
                             std::to_string(MT) + ">",
-                     2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+                     2.0 * px * KS * KS * p.Cin * p.Cout,
+                     // (the fused epilogue's operands are part of the layer's algorithmic traffic: residual / ReLU-mask / old value)
+                     4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) +
+                            (double)KS * KS * p.Cin * p.Cout));
 #ifdef STREAM_TRACE
         static unsigned long long* trace_buf = nullptr;
         static int trace_n = 0;
