@@ -158,6 +158,18 @@ def test_supervised_forward_grads_and_adam_step(kind, cfg, xs, ss, loss):
                                           T.asarray(y.astype(np.float64)), loss=loss, opt=opt)
         l_hip = eng.step(inputs, y)
         assert l_hip == pytest.approx(lv, rel=2e-3), it
+        if it == 0:
+            # The first update must be Keras-Adam applied to the gradients the HIP path itself reported, to fp32 rounding
+            # (2e-6 = 0.2 % of one step) for EVERY entry: m = (1-b1) g, v = (1-b2) g^2, lr_t = lr sqrt(1-b2)/(1-b1).
+            # (The comparison with the oracle's trajectory below has to be loose: Adam divides by |g|, so an entry whose
+            # gradient differs in the last bits of a near-zero value may legitimately move by a whole step.)
+            w1 = model.get_weights()
+            b1, b2, eps, lr = 0.9, 0.999, 1e-7, 1e-3
+            for kk in w1:
+                g64 = g_hip[kk].astype(np.float64)
+                m1, v1 = (1 - b1) * g64, (1 - b2) * g64 * g64
+                ref1 = w0[kk].astype(np.float64) - lr * np.sqrt(1 - b2) / (1 - b1) * m1 / (np.sqrt(v1) + eps)
+                assert np.abs(w1[kk] - ref1).max() < 2e-6, kk
     w = model.get_weights()
     for k in w:
         upd_ref = PT[k].detach().numpy() - w0[k]
@@ -168,6 +180,31 @@ def test_supervised_forward_grads_and_adam_step(kind, cfg, xs, ss, loss):
         assert dev.max() < 3.3e-3, k              # never more than the three steps themselves
     m, v, step = eng.optimizer_state()
     assert step == 3
+
+
+def test_headline_model_through_producer_consumer_kernels(monkeypatch):
+    """The headline configuration's layers take conv_stream_ws_kernel / conv_narrow_pair_ws_kernel only on grids large
+    enough to give every workgroup two items (bench sizes); DL4DS_STREAM_FORCE_WS makes this reduced model take them too:
+    forward, loss, all gradients against the oracle."""
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', '2')
+    from dl4ds_amd.training import SupervisedEngine
+    kind, cfg, xs, ss = SUP_CASES[0]
+    model, P, ocfg = build_pair(kind, cfg, xs, ss)
+    rng, x, s, ref = tie_free_inputs(kind, P, ocfg, xs, ss)
+    inputs = [x] if s is None else [x, s]
+    out = model(inputs)
+    assert rel(out, ref) < 1e-3
+    y = rng.standard_normal(ref.shape).astype(np.float32)
+    PT = M.convert(P, T, requires_grad=True)
+    lv, grads, _ = TR.supervised_step(kind, ocfg, PT, T.asarray(x.astype(np.float64)),
+                                      None if s is None else T.asarray(s.astype(np.float64)),
+                                      T.asarray(y.astype(np.float64)), loss='mae', opt=None)
+    eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
+    l_hip, g_hip = eng.loss_and_grads(inputs, y)
+    assert l_hip == pytest.approx(lv, rel=1e-4)
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    for k in grads:
+        assert np.abs(g_hip[k] - grads[k].numpy()).max() / gscale < 1e-3, k
 
 
 @pytest.mark.parametrize('ups,scale', [('spc', 4), ('spc', 2), ('rc', 2), ('spc', 5)])
