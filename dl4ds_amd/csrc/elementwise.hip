@@ -603,3 +603,42 @@ void localconv_backward(hipStream_t s, const TView& x, const float* w, const TVi
                        accumulate_dw);
     HIP_CHECK(hipGetLastError());
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// tf.repeat(tf.expand_dims(s, 1), T, axis=1) and its gradient (spt_postups.py:139-140) as ONE launch each: the op used to
+// issue B*T copies forward and B*T dependent accumulations backward (128 + 128 launches of a few microseconds in cfg4).
+__global__ void repeat_time_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, size_t ps, int T, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / ps, r = e - b * ps;
+        const float v = in[e];
+        float* o = out + b * T * ps + r;
+        for (int t = 0; t < T; ++t) o[(size_t)t * ps] = v;
+    }
+}
+__global__ void repeat_time_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, size_t ps, int T, size_t total,
+                                       int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / ps, r = e - b * ps;
+        const float* o = dout + b * T * ps + r;
+        float s = accumulate ? din[e] : 0.f;
+        for (int t = 0; t < T; ++t) s += o[(size_t)t * ps];      // (same order as the T accumulating copies it replaces)
+        din[e] = s;
+    }
+}
+void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int T, size_t ps) {
+    const size_t total = (size_t)B * ps;
+    if (total == 0) return;
+    ProfScope pp(s, "repeat_time_fwd", 0.0, 4.0 * (double)total * (1 + T));
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(repeat_time_fwd_kernel, dim3(blocks), dim3(256), 0, s, in, out, ps, T, total);
+    HIP_CHECK(hipGetLastError());
+}
+void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, int T, size_t ps, int accumulate) {
+    const size_t total = (size_t)B * ps;
+    if (total == 0) return;
+    ProfScope pp(s, "repeat_time_bwd", 0.0, 4.0 * (double)total * (1 + T + (accumulate ? 1 : 0)));
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(repeat_time_bwd_kernel, dim3(blocks), dim3(256), 0, s, dout, din, ps, T, total, accumulate);
+    HIP_CHECK(hipGetLastError());
+}

@@ -24,6 +24,12 @@ struct GTensor {
     int n_conv_in = 0, n_other = 0;
     int n_add_in = 0;          // ... as an operand of an Add (which can apply the ReLU mask while copying its gradient)
     int n_masking = 0;         // ... as an input of a Concatenate / MaxPooling2D (their backward applies the mask, too)
+    int n_concat_in = 0;       // ... of which Concatenates
+    // Concatenate without the forward copy: the activation lives INSIDE the concatenation's buffer (channel offset
+    // alias_coff of tensor alias_of, pixel pitch alias_ld = that buffer's channel count); decided at finalize for tensors
+    // written by a Conv2D / Concatenate and read only by Conv2Ds and ONE Concatenate.  Gradients stay dense.
+    int alias_of = -1, alias_coff = 0, alias_ld = 0;
+    int alias_parent = -1;     // the Concatenate output it is a direct input slice of (alias_of = the root of a chain of them)
     // ReLU backward fused into the writers: every consumer is a Conv2D (or an Add), whose dgrad epilogue zeroes the gradient
     // where this activation is <= 0 (the mask is linear, so each accumulating writer applies it independently)
     bool grad_masked = false;

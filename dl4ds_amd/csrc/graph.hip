@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cstring>
 
+static void plan_concat_aliases(Graph& g);
+
 // ============================================================================================ Graph
 Graph::~Graph() {
     for (float* p : allocations) (void)hipFree(p);
@@ -71,6 +73,7 @@ void Graph::finalize() {
         HIP_CHECK(hipMemset(G, 0, bytes));
     }
     for (auto& op : ops) op->on_finalize(*this);
+    plan_concat_aliases(*this);
     if (wt_floats) HIP_CHECK(hipMalloc((void**)&Wt, wt_floats * sizeof(float)));
     finalized = true;
     // the headline model's arena is 0.82 MB (latency-bound collective): a few buckets; U-Net (54 MB): ~4 MB each
@@ -117,7 +120,7 @@ void Graph::prepare(int B) {
     auto bump = [&](size_t floats) { size_t o = total; total += (floats + 63) & ~(size_t)63; return o; };
     std::vector<size_t> doff(tensors.size()), goff(tensors.size()), soff(ops.size());
     for (size_t i = 0; i < tensors.size(); ++i) {
-        doff[i] = bump(tensors[i].per_sample() * B);
+        doff[i] = tensors[i].alias_of >= 0 ? (size_t)-1 : bump(tensors[i].per_sample() * B);     // (aliased: inside another buffer)
         goff[i] = (tensors[i].requires_grad) ? bump(tensors[i].per_sample() * B) : (size_t)-1;
     }
     for (size_t i = 0; i < ops.size(); ++i) soff[i] = bump(ops[i]->saved_floats_per_sample(*this) * B + 64);
@@ -125,8 +128,12 @@ void Graph::prepare(int B) {
     HIP_CHECK(hipMalloc((void**)&slab, total * sizeof(float)));
     allocations.push_back(slab);
     for (size_t i = 0; i < tensors.size(); ++i) {
-        tensors[i].data = slab + doff[i];
+        tensors[i].data = (doff[i] == (size_t)-1) ? nullptr : slab + doff[i];
         tensors[i].grad = (goff[i] == (size_t)-1) ? nullptr : slab + goff[i];
+    }
+    for (size_t i = tensors.size(); i-- > 0;) {               // a concatenation is created after its inputs: resolved first
+        GTensor& t = tensors[i];
+        if (t.alias_of >= 0) t.data = tensors[t.alias_of].data + t.alias_coff;
     }
     for (size_t i = 0; i < ops.size(); ++i) ops[i]->saved = slab + soff[i];
     size_t ws = 1 << 20;
@@ -143,6 +150,14 @@ TView Graph::view(int tid, int B, bool grad, int b_off, int b_cnt) const {
     float* base = grad ? t.grad : t.data;
     DL4DS_REQUIRE(base != nullptr, "tensor buffer missing (no grad buffer / graph not prepared)");
     const int cnt = (b_cnt < 0) ? B : b_cnt;
+    if (!grad && t.alias_of >= 0) {
+        const size_t img = (size_t)t.H * t.W * t.alias_ld;
+        TView v = make_view(base + (size_t)b_off * t.nmul * img, cnt * t.nmul, t.H, t.W, t.C);
+        v.ld = t.alias_ld;
+        v.nstride = img;
+        v.vec = v.vec && (t.alias_ld & 3) == 0;
+        return v;
+    }
     return make_view(base + (size_t)b_off * t.per_sample(), cnt * t.nmul, t.H, t.W, t.C);
 }
 
@@ -292,6 +307,7 @@ struct ConvOp : GOp {
         float* base = (grad ? to.grad : to.data) + (size_t)bo * to.per_sample();
         const int N = (bc < 0 ? B : bc) * to.nmul;
         if (d2s > 1) return make_view_d2s(base, N, ti.H, ti.W, Cout, d2s);
+        if (!grad && to.alias_of >= 0) return g.view(out, B, false, bo, bc);       // written straight into a Concatenate's buffer
         return make_view(base, N, ti.H, ti.W, Cout);
     }
     void forward(Graph& g, int B, bool) override {
@@ -501,8 +517,10 @@ struct ConcatOp : GOp {
         return v;
     }
     void forward(Graph& g, int B, bool) override {
-        for (size_t k = 0; k < ins.size(); ++k)
+        for (size_t k = 0; k < ins.size(); ++k) {
+            if (g.tensors[ins[k]].alias_parent == out) continue;     // its producer wrote it here already
             view_axpy(g.stream, g.view(ins[k], B, false), slice(g, B, false, (int)k, 0, -1), 1.f, 0);
+        }
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
@@ -635,23 +653,15 @@ struct RepeatTimeOp : GOp {
     int in, out, T;
     RepeatTimeOp() { kind = "repeat_time"; }
     void forward(Graph& g, int B, bool) override {
-        const size_t ps = g.tensors[in].per_sample();
-        for (int b = 0; b < B; ++b)
-            for (int t = 0; t < T; ++t)
-                HIP_CHECK(hipMemcpyAsync(g.tensors[out].data + ((size_t)b * T + t) * ps, g.tensors[in].data + (size_t)b * ps,
-                                         ps * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+        repeat_time_forward(g.stream, g.tensors[in].data, g.tensors[out].data, B, T, g.tensors[in].per_sample());
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
         const GTensor& ti = g.tensors[in];
         const size_t ps = ti.per_sample();
-        const int b1 = c.b_off + (c.b_cnt < 0 ? c.B : c.b_cnt);
-        for (int b = c.b_off; b < b1; ++b)
-            for (int t = 0; t < T; ++t) {
-                TView src = make_view(g.tensors[out].grad + ((size_t)b * T + t) * ps, 1, ti.H, ti.W, ti.C);
-                TView dst = make_view(ti.grad + (size_t)b * ps, 1, ti.H, ti.W, ti.C);
-                view_axpy(g.stream, src, dst, 1.f, (t > 0) || ti.grad_written);
-            }
+        const int cnt = c.b_cnt < 0 ? c.B : c.b_cnt;
+        repeat_time_backward(g.stream, g.tensors[out].grad + (size_t)c.b_off * T * ps, ti.grad + (size_t)c.b_off * ps, cnt, T, ps,
+                             ti.grad_written);
         g.tensors[in].grad_written = true;
     }
 };
@@ -719,7 +729,7 @@ int g_concat(Graph& g, const int* ins, int n) {
     ConcatOp* op = push<ConcatOp>(g);
     op->ins.assign(ins, ins + n);
     op->out = out;
-    for (int i = 0; i < n; ++i) g.tensors[ins[i]].n_masking++;
+    for (int i = 0; i < n; ++i) { g.tensors[ins[i]].n_masking++; g.tensors[ins[i]].n_concat_in++; }
     return out;
 }
 
@@ -782,4 +792,46 @@ int g_repeat_time(Graph& g, int in, int T) {
     op->in = in; op->out = out; op->T = T;
     g.tensors[in].n_other++;
     return out;
+}
+
+
+// Concatenate without the forward copy (GTensor::alias_of): see graph.h.  Eligible input of a Concatenate: produced by a
+// plain Conv2D (no depth_to_space store, no fused attention) or by another Concatenate, read by nothing but plain Conv2Ds
+// (as their convolved input) and this one Concatenate, not a model input / output.  DenseBlock chains resolve to ONE buffer:
+// x_{k+1} = concat(x_k, f(x_k)) makes x_k a channel prefix of x_{k+1}.  DL4DS_NO_CONCAT_ALIAS=1 keeps the copies (A/B, tests).
+static void plan_concat_aliases(Graph& g) {
+    if (getenv("DL4DS_NO_CONCAT_ALIAS")) return;
+    const int nt = (int)g.tensors.size();
+    std::vector<int> conv_readers(nt, 0), producer_ok(nt, 0);
+    for (auto& up : g.ops) {
+        if (ConvOp* c = dynamic_cast<ConvOp*>(up.get())) {
+            conv_readers[c->in]++;
+            if (c->d2s <= 1 && !c->att_after && !c->att_before) producer_ok[c->out] = 1;
+        } else if (ConcatOp* k = dynamic_cast<ConcatOp*>(up.get())) {
+            producer_ok[k->out] = 1;
+        }
+    }
+    auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
+    // in creation order, so that a concatenation that is itself aliased later already knows its own inputs
+    for (auto& up : g.ops) {
+        ConcatOp* k = dynamic_cast<ConcatOp*>(up.get());
+        if (!k) continue;
+        int off = 0;
+        for (int t : k->ins) {
+            GTensor& ti = g.tensors[t];
+            const bool ok = producer_ok[t] && !ti.is_input && !is_output(t) && ti.alias_of < 0 && ti.n_add_in == 0 &&
+                            ti.n_other == 0 && ti.n_concat_in == 1 && ti.n_masking == 1 && ti.n_conv_in == conv_readers[t] &&
+                            (off & 3) == 0 && (ti.C & 3) == 0;
+            if (ok) { ti.alias_of = k->out; ti.alias_parent = k->out; ti.alias_coff = off; }
+            off += ti.C;
+        }
+    }
+    // resolve chains to their root buffer (an aliased concatenation output forwards its inputs)
+    for (int t = 0; t < nt; ++t) {
+        GTensor& ti = g.tensors[t];
+        if (ti.alias_of < 0) continue;
+        int root = ti.alias_of, coff = ti.alias_coff;
+        while (g.tensors[root].alias_of >= 0) { coff += g.tensors[root].alias_coff; root = g.tensors[root].alias_of; }
+        ti.alias_of = root; ti.alias_coff = coff; ti.alias_ld = g.tensors[root].C;
+    }
 }

@@ -163,3 +163,5 @@ void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, si
 void batch_prepare(hipStream_t s, const float* hr, const float* pred, const float* stat, const int* idx, const int* cy,
                    const int* cx, float* out_lr, float* out_hr, float* out_stat, int H, int W, int C, int P, int S, int T,
                    int B, int scale, int psy, int psx, int pin, int static_in_lr);
+void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int T, size_t ps);
+void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, int T, size_t ps, int accumulate);
