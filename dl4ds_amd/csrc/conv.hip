@@ -1131,14 +1131,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradPara
 // per tile.  With two independent 4-wave workgroups per CU the staging phases were NOT hidden (measured: 1.72 ms as is,
 // 1.26 ms with the loads removed, and no re-ordering of the loads changed the sum) -- here the overlap is by
 // construction and the MFMA waves never issue a global load.
-template <int CIT, int WCO>
+template <int CIT, int WCO, int KS = 3>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradParams a) {
-    constexpr int KS = 3, COT = 1;
+    constexpr int COT = 1;
     constexpr int TW = 16, TH = 8;
     constexpr int WK = 4 / WCO, RW = TH / WK;            // output rows per wave
-    constexpr int PAD = 1;
-    constexpr int TWH = TW + 2, THH = TH + 2, HPIX = TWH * THH;
-    constexpr int KK = 9;
+    constexpr int PAD = KS / 2;
+    constexpr int TWH = TW + KS - 1, THH = TH + KS - 1, HPIX = TWH * THH;
+    constexpr int KK = KS * KS;
     constexpr int CIB = 16 * CIT, COB = 16 * WCO;
     constexpr int PX = CIB + 4, PZ = COB + 4;
     constexpr int NPIX = TW * TH;
@@ -1247,35 +1247,35 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
         const int buf = it & 1;
         const float* xf = xf0 + buf * TILE_FLOATS;
         const float* zf = zf0 + buf * TILE_FLOATS;
-        float zr[3][4];                 // dz fragments of the last three output rows (ring)
+        float zr[KS][4];                // dz fragments of the last KS output rows (ring)
 #pragma unroll
-        for (int rr = 0; rr < RW + 2; ++rr) {          // input row wk*RW + rr of the halo tile
-            float fx[6][CIT];
+        for (int rr = 0; rr < RW + KS - 1; ++rr) {     // input row wk*RW + rr of the halo tile
+            float fx[4 + KS - 1][CIT];
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
+            for (int c = 0; c < 4 + KS - 1; ++c)
 #pragma unroll
                 for (int i = 0; i < CIT; ++i) fx[c][i] = xf[(rr * TWH + c) * PX + i * 16];
             if (rr < RW) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) zr[rr % 3][q] = zf[(rr * TW + q) * PZ];
+                for (int q = 0; q < 4; ++q) zr[rr % KS][q] = zf[(rr * TW + q) * PZ];
             }
             __builtin_amdgcn_sched_barrier(0);
             if (rr < RW) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bsum[0] += zr[rr % 3][q];
+                for (int q = 0; q < 4; ++q) bsum[0] += zr[rr % KS][q];
             }
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < KS; ++ky) {
                 const int r = rr - ky;                  // output row fed through taps (ky, *)
                 if (r >= 0 && r < RW) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx)
+                        for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
                             for (int i = 0; i < CIT; ++i)
-                                acc[ky * 3 + kx][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q + kx][i], zr[r % 3][q],
-                                                                                              acc[ky * 3 + kx][i][0], 0, 0, 0);
+                                acc[ky * KS + kx][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q + kx][i], zr[r % KS][q],
+                                                                                               acc[ky * KS + kx][i][0], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1386,14 +1386,17 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
         if (cdiv(dz.C, 16 * wco) * 16 * wco < cdiv(dz.C, 16 * p.WCO) * 16 * p.WCO) p.WCO = wco;
     if (dz.C <= 16) p.WCO = 1;
     else if (dz.C <= 32 && p.WCO == 4) p.WCO = 2;
+    // 1x1 layers are HBM-bound: every cout block re-reads the x tile, so the fewest blocks win there (padded MFMAs are free)
+    if (KS == 1) p.WCO = (dz.C <= 16) ? 1 : (dz.C <= 32 ? 2 : 4);
     if (const char* e = getenv("DL4DS_WGRAD_WCO")) p.WCO = atoi(e);      // (experiments)
     p.WK = 4 / p.WCO;
     const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
     // every block does the same amount of work, so the grid should be exactly one residency round:
     // 256 CUs x 2 workgroups (LDS / VGPR limited) = 512 blocks.  768 blocks ran as 1.5 rounds (+33 % time).
     // (the producer/consumer rows kernel runs ONE 8-wave workgroup per CU)
-    p.ws = KS == 3 && !(p.CIT == 1 && p.WCO == 1) && x.vec && dz.vec && p.ntiles < (1 << 20) && !getenv("DL4DS_NO_WGRAD_ROWS") &&
-           !getenv("DL4DS_NO_WGRAD_WS");
+    // (1x1 layers are HBM streaming: the same producer / consumer kernel with one tap)
+    p.ws = (KS == 3 || (KS == 1 && !getenv("DL4DS_NO_WGRAD_WS1"))) && !(p.CIT == 1 && p.WCO == 1) && x.vec && dz.vec &&
+           p.ntiles < (1 << 20) && !getenv("DL4DS_NO_WGRAD_ROWS") && !getenv("DL4DS_NO_WGRAD_WS");
     int target = std::max(1, (p.ws ? 256 : 512) / (cob * cib));
     const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
     const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (slab * sizeof(float)));
@@ -1413,14 +1416,18 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     constexpr size_t red_bytes = (size_t)(WK / 2) * WCO * (KS * KS * CIT * COT * 4 + COT) * 64 * sizeof(float);
     // 3x3 layers beyond the small-channel prefetch variants: row-walking kernel (MFMA bound instead of LDS-read bound)
     static const bool no_rows = getenv("DL4DS_NO_WGRAD_ROWS") != nullptr;
-    constexpr bool ROWS_OK = (KS == 3) && !PF && COT == 1;
-    const bool rows = ROWS_OK && !no_rows;
+    constexpr bool ROWS_OK = (KS == 3 || KS == 1) && !PF && COT == 1;     // (KS == 1: only the producer / consumer form)
+    const bool rows = ROWS_OK && !no_rows && (KS == 3 || pl.ws);
     const bool ws = rows && pl.ws;            // producer/consumer form: float4-loadable views, one workgroup per CU
     const size_t lds = rows ? std::max((size_t)(ws ? 2 : 1) * (HPIX * (CIB + 4) + 128 * (COB + 4)) * sizeof(float), red_bytes)
                             : std::max((size_t)(PF ? 2 : 1) * (HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
     void (*kern)(const WgradParams) = conv_wgrad_kernel<KS, CIT, COT, WCO, PF>;
     if constexpr (ROWS_OK) {
-        if (rows) kern = ws ? conv_wgrad_rows_ws_kernel<CIT, WCO> : conv_wgrad_rows_kernel<CIT, WCO>;
+        if constexpr (KS == 3) {
+            if (rows) kern = ws ? conv_wgrad_rows_ws_kernel<CIT, WCO, 3> : conv_wgrad_rows_kernel<CIT, WCO>;
+        } else {
+            if (rows) kern = conv_wgrad_rows_ws_kernel<CIT, WCO, 1>;
+        }
     }
     static std::once_flag once;
     std::call_once(once, [&]() {
@@ -1428,10 +1435,11 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, CIT, COT, WCO, PF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, KS >= 7 ? kLdsMax : kLdsBudget));
         if constexpr (ROWS_OK) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_ws_kernel<CIT, WCO>),
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_ws_kernel<CIT, WCO, KS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax));
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<CIT, WCO>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+            if constexpr (KS == 3)
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<CIT, WCO>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
         }
     });
     DL4DS_REQUIRE(lds <= (size_t)((ws || KS >= 7) ? kLdsMax : kLdsBudget), "wgrad tile does not fit in LDS");
