@@ -633,13 +633,101 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
     const float* xa = xt + ((wave * NROWS) * TWH + lq) * 8 + l15;                        // halves one pixel apart
     const float* xb = xt + ((wave * NROWS) * TWH + lq) * 8 + (l15 & 7) + (l15 >> 3) * TWH * 8;   // one row apart
 
+    // float4-loadable x: ONE buffer load per element and nothing else per element.  The generic staging code spent ~35 VALU
+    // instructions per element on index arithmetic -- ~300 per tile and thread next to 160 MFMAs per wave, on the same issue
+    // port.  Offsets relative to the tile origin are per-thread constants; whatever lies outside the image (or the channel
+    // count) gets an out-of-range offset, for which the buffer unit returns the zero padding; they are recomputed only when
+    // the tile's border signature changes.
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
+    int xoff[XVEC ? XIT : 1], xhyx[XVEC ? XIT : 1], zoff[XVEC ? ZIT : 1], zyx[XVEC ? ZIT : 1];
+    int xsig = 0, zsig = 0;
+    if constexpr (XVEC) {
+#pragma unroll
+        for (int u = 0; u < XIT; ++u) {
+            const int e = tid + u * 256;
+            const int pix = e >> 1, c4 = e & 1;
+            const int hy = pix / TWH, hx = pix - hy * TWH;
+            const bool live = e < XQ && c4 * 4 < a.Cin;
+            xhyx[u] = live ? ((hy << 8) | hx) : 0x7f7f;
+            xoff[u] = live ? (int)((((size_t)hy * a.W + hx) * a.x.ld + c4 * 4) * 4) : OOB;
+        }
+#pragma unroll
+        for (int u = 0; u < ZIT; ++u) {
+            const int e = tid + u * 256;
+            const int pix = e / ZQ4, c4 = e - pix * ZQ4;
+            const int ry = pix / NTW, rx = pix - ry * NTW;
+            const bool live = e < ZQ && c4 * 4 < a.Cout;
+            zyx[u] = live ? ((ry << 8) | rx) : 0x7f7f;
+            zoff[u] = live ? (int)((((size_t)ry * a.W + rx) * a.dz.ld + c4 * 4) * 4) : OOB;
+        }
+        xsig = (THH << 8) | TWH;                        // rows [0, THH) x columns [0, TWH) of the halo inside the image
+        zsig = (NTH << 8) | NTW;
+    }
+
     for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         const int q0 = fast_div(t, a.m_tx);
         const int bx = t - q0 * a.tiles_x;
         const int n = fast_div(q0, a.m_ty);
         const int by = q0 - n * a.tiles_y;
         const int x0 = bx * NTW, y0 = by * NTH;
-        {
+        if constexpr (XVEC) {
+            const int ylo = max(0, 1 - y0), yhi = min(THH, a.H + 1 - y0), xlo = max(0, 1 - x0), xhi = min(TWH, a.W + 1 - x0);
+            const int sx = (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
+            if (sx != xsig) {
+                xsig = sx;
+#pragma unroll
+                for (int u = 0; u < XIT; ++u) {
+                    const int hy = xhyx[u] >> 8, hx = xhyx[u] & 0xff, c4 = (tid + u * 256) & 1;
+                    xoff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? (int)((((size_t)hy * a.W + hx) * a.x.ld + c4 * 4) * 4) : OOB;
+                }
+            }
+            const int ymax = min(NTH, a.H - y0), xmax = min(NTW, a.W - x0);
+            const int sz = (ymax << 8) | xmax;
+            if (sz != zsig) {
+                zsig = sz;
+#pragma unroll
+                for (int u = 0; u < ZIT; ++u) {
+                    const int ry = zyx[u] >> 8, rx = zyx[u] & 0xff, c4 = (tid + u * 256) % ZQ4;
+                    zoff[u] = (ry < ymax && rx < xmax) ? (int)((((size_t)ry * a.W + rx) * a.dz.ld + c4 * 4) * 4) : OOB;
+                }
+            }
+            const long xorg = (long)((size_t)n * a.x.nstride) + ((long)(y0 - 1) * a.W + (x0 - 1)) * (long)a.x.ld;
+            const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.x.p)) + xorg * 4, 0, 0x7fffff00, RSRC3);
+            const size_t zorg = (size_t)n * a.dz.nstride + ((size_t)y0 * a.W + x0) * a.dz.ld;
+            const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.dz.p)) + zorg * 4, 0, 0x7fffff00, RSRC3);
+            i32x4_t xr[XIT], zr[ZIT];
+#pragma unroll
+            for (int u = 0; u < XIT; ++u) xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[u], 0, 0);
+#pragma unroll
+            for (int u = 0; u < ZIT; ++u) zr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsz, zoff[u], 0, 0);
+            if (a.dz.sc) {
+                // dz carries a channel affine (ChannelAttention2D backward: dX = dY * scale + dmean): ZQ4 divides 256, so
+                // the thread's channel quad is fixed; the image is fixed for the tile.  Only INSIDE the tile: padding stays 0
+                float4 s4, h4;
+                view_affine4(a.dz, n, (tid % ZQ4) * 4, s4, h4);
+#pragma unroll
+                for (int u = 0; u < ZIT; ++u) {
+                    if (zoff[u] != OOB) {
+                        const float4 v = affine4(make_float4(__int_as_float(zr[u][0]), __int_as_float(zr[u][1]), __int_as_float(zr[u][2]),
+                                                             __int_as_float(zr[u][3])), s4, h4);
+                        zr[u] = (i32x4_t){__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < XIT; ++u) {
+                const int e = tid + u * 256;
+                if (e < XQ) *reinterpret_cast<i32x4_t*>(xt + (size_t)e * 4) = xr[u];
+            }
+#pragma unroll
+            for (int u = 0; u < ZIT; ++u) {
+                const int e = tid + u * 256;
+                if (e < ZQ) *reinterpret_cast<i32x4_t*>(zt + (size_t)e * 4) = zr[u];
+            }
+        } else {
             float4 xr[XIT], zr[ZIT];
             unsigned xm[XIT], zm[ZIT];
             if constexpr (XVEC) {
