@@ -315,7 +315,8 @@ __device__ __forceinline__ void view_strides(const TView& v, size_t& sy, size_t&
     sy = (size_t)r * (size_t)(v.W * r) * v.ld;
 }
 
-template <int KS, int E, int NT, int MT>
+// NL: views whose depth_to_space groups are narrower than a chunk / an n-block (per-quad channel offsets through the view)
+template <int KS, int E, int NT, int MT, bool NL>
 __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamParams sp) {
     typedef WsGeom<KS, E, NT, MT> GM;
     const ConvParams& a = sp.c;
@@ -403,17 +404,17 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
         // channel offset of the thread's quad inside a chunk: linear views -> 4*c4 on top of the chunk's own offset (part of the
         // origin); a view whose depth_to_space groups are narrower than a chunk is taken only with ONE chunk (launcher), whose
         // per-quad offsets are static too
-        const bool in_lin = a.in.d2s <= 1 || (CK <= a.in.cp && a.in.cp % CK == 0);
+        const bool in_lin = !NL || a.in.d2s <= 1 || (CK <= a.in.cp && a.in.cp % CK == 0);
         const size_t in_c4 = in_lin ? (size_t)c4 * 4 : view_chan_off(a.in, min(c4 * 4, a.Cin - 4));
-        int rel[SIT], soff[SIT], hyx[SIT];
+        int soff[SIT], hyx[SIT];
+        auto rel_of = [&](int hy, int hx) { return (int)((hy * isy + hx * isx + in_c4) * 4); };
 #pragma unroll
         for (int u = 0; u < SIT; ++u) {
             const int hp = p0 + PPASS * u;
             const int hy = hp / TWH, hx = hp - hy * TWH;
             const bool live = st_active && hp < HPIX;
             hyx[u] = live ? ((hy << 8) | hx) : 0x7f7f;            // (0x7f: never inside the image window)
-            rel[u] = live ? (int)((hy * isy + hx * isx + in_c4) * 4) : OOB;
-            soff[u] = rel[u];
+            soff[u] = live ? rel_of(hy, hx) : OOB;
         }
         int st_sig = (THH << 8) | TWH;                            // window signature of soff[]: (ylo, yhi, xlo, xhi) packed
         st_sig |= 0 << 24;
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
 #pragma unroll
                 for (int u = 0; u < SIT; ++u) {
                     const int hy = hyx[u] >> 8, hx = hyx[u] & 0xff;
-                    soff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? rel[u] : OOB;
+                    soff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? rel_of(hy, hx) : OOB;
                 }
             }
             // wave-uniform origin of the halo tile (outside the tensor for border tiles; never dereferenced there)
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
         size_t osy, osx;
         view_strides(a.out, osy, osx);                            // (add / mask views have the same strides: launcher)
         // (the same for the output's channel quads inside an n-block; otherwise they go through the view per n-block)
-        const bool out_lin = a.out.d2s <= 1 || (CO <= a.out.cp && a.out.cp % CO == 0);
+        const bool out_lin = !NL || a.out.d2s <= 1 || (CO <= a.out.cp && a.out.cp % CO == 0);
         int dvo[ND];
 #pragma unroll
         for (int u = 0; u < ND; ++u) {
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
                 constexpr int M = decltype(mode_tag)::value;
                 constexpr bool ADD = (M & 1) != 0, RELU = (M & 2) != 0, MASK = (M & 4) != 0, ACC = (M & 8) != 0;
                 constexpr int NSTREAM = 1 + (ADD ? 1 : 0) + (MASK ? 1 : 0) + (ACC ? 1 : 0);
-                constexpr int GQ = (NSTREAM <= 2 && ND % 6 == 0) ? 6 : 4;
+                constexpr int GQ = (NSTREAM <= 1 && ND % 6 == 0) ? 6 : 4;
                 static_assert(ND % GQ == 0, "elements per thread");
 #pragma unroll
                 for (int g0 = 0; g0 < ND; g0 += GQ) {
@@ -874,6 +875,8 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
         // operands must be laid out like the output
         auto linear = [](const TView& v, int span) { return v.d2s <= 1 || (span <= v.cp && v.cp % span == 0); };
         auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
+        const bool nl = !linear(p.in, GM::CK) || !linear(p.out, GM::CO);
+        if (nl && MT != 4) return false;                                   // (only the 16x16-tile variants are built for them)
         if (!linear(p.in, GM::CK) && p.Cin != GM::CK) return false;        // (narrower groups: one chunk only)
         if (!linear(p.out, GM::CO) && p.Cout >= 128) return false;         // (n0 must fit the 8 bits it gets in the drain signature)
         if (p.add.p && !same_layout(p.add, p.out)) return false;
@@ -901,11 +904,17 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
             HIP_CHECK(hipGetLastError());
             p.w = wp;
         }
-        auto kern = conv_stream_ws_kernel<KS, E, NT, MT>;
+        void (*kern)(const StreamParams) = conv_stream_ws_kernel<KS, E, NT, MT, false>;
+        if constexpr (MT == 4) {
+            if (nl) kern = conv_stream_ws_kernel<KS, E, NT, MT, true>;
+        }
         static std::once_flag once;
         std::call_once(once, [&]() {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)GM::LDS_BYTES));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stream_ws_kernel<KS, E, NT, MT, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES));
+            if constexpr (MT == 4)
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stream_ws_kernel<KS, E, NT, MT, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES));
         });
         const double px = (double)N * p.H * p.W;
         ProfScope ps(s, "conv_stream_ws<" + std::to_string(KS) + "," + std::to_string(E) + "," + std::to_string(NT) + "," +
