@@ -525,6 +525,12 @@ int dl4ds_graph_conv2d_folded(dl4ds_graph* g, int in, int w1, int b1, int w2, in
     *out = g_conv2d_folded(g->g, in, w1, b1, w2, b2, KS, Cmid, Cout, relu, d2s);
     API_END
 }
+int dl4ds_graph_conv2d_folded_aux(dl4ds_graph* g, int in, int aux, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout,
+                                  int relu, int d2s, int* out) {
+    API_BEGIN
+    *out = g_conv2d_folded(g->g, in, w1, b1, w2, b2, KS, Cmid, Cout, relu, d2s, aux);
+    API_END
+}
 int dl4ds_graph_pad(dl4ds_graph* g, int in, int Ho, int Wo, int* out) {
     API_BEGIN
     *out = g_pad(g->g, in, Ho, Wo);

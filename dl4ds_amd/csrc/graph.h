@@ -144,7 +144,7 @@ int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, in
 int g_gap(Graph& g, int in, int T);
 int g_dense(Graph& g, int in, int w, int b, int F, int act);
 int g_dropout(Graph& g, int in, float rate, int variant = 0, int mc = 0, int spatial_dim = 2);
-int g_conv2d_folded(Graph& g, int in, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout, int relu, int d2s);
+int g_conv2d_folded(Graph& g, int in, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout, int relu, int d2s, int aux = -1);
 int g_pad(Graph& g, int in, int Ho, int Wo);
 int g_dwconv(Graph& g, int in, int w, int b, int KS);
 int g_slice(Graph& g, int in, int oy, int ox, int step, int Ho, int Wo);

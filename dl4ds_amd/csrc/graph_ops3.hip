@@ -133,10 +133,29 @@ __global__ void __launch_bounds__(256) unfold_w2_kernel(const float* __restrict_
     }
 }
 
+// Auxiliary-input form (sp_postups.py:184-203 with HR static variables): TransitionLast reads Concatenate([x_up, s]), and a 1x1
+// convolution of a concatenation is the sum of two 1x1 convolutions, W2 = [W2x (Cm rows); W2s (Cs rows)]:
+//   out = act( conv_eff(x)  +  conv1x1(s; W2s)  + b_eff ).
+// The second term is an ordinary 1x1 convolution of the HR auxiliary tensor s into a private buffer, which the composed
+// convolution adds in its epilogue (read through the same depth_to_space view it stores through); backward: d(s) and dW2s are
+// the 1x1 dgrad / wgrad of the (masked) output gradient, dW2x / db2 / dW1 / db1 unfold as before.  Same variables as the
+// unfolded graph: 'TransitionLast/conv/kernel' has Cm + Cs rows.
 struct FoldedConvOp : GOp {
     int in, out, w1, b1, w2, b2, KS, r, Cm, Co, relu;
-    size_t weff_off = 0, beff_off = 0, dweff_off = 0, wt_off = 0;
+    int aux = -1, Cs = 0;          // HR auxiliary tensor and its channel count (rows Cm .. Cm+Cs of w2)
+    size_t weff_off = 0, beff_off = 0, dweff_off = 0, wt_off = 0, wt_aux_off = 0;
     FoldedConvOp() { kind = "conv2d_folded"; }
+    size_t saved_floats_per_sample(Graph& g) override { return aux >= 0 ? g.tensors[out].per_sample() : 0; }
+    float* w2s(Graph& g) const { return g.wp(w2) + (size_t)Cm * Co; }
+    float* gw2s(Graph& g) const { return g.gp(w2) + (size_t)Cm * Co; }
+    TView ts_view(Graph& g, int B, int bo, int bc, bool through_d2s) {     // conv1x1(s; W2s): plain HR tensor / as the d2s operand
+        const GTensor& ti = g.tensors[in];
+        const GTensor& to = g.tensors[out];
+        float* base = saved + (size_t)bo * to.per_sample();
+        const int N = (bc < 0 ? B : bc) * to.nmul;
+        if (through_d2s && r > 1) return make_view_d2s(base, N, ti.H, ti.W, ncol(), r);
+        return make_view(base, N, to.H, to.W, Co);
+    }
     int ncol() const { return r * r * Co; }
     int krows(Graph& g) const { return KS * KS * g.tensors[in].C; }
     void on_finalize(Graph& g) override {
@@ -146,6 +165,10 @@ struct FoldedConvOp : GOp {
         dweff_off = g.reserve_wt(n + ncol());          // [dW_eff | db_eff]
         wt_off = g.reserve_wt(n);                      // dgrad arrangement of W_eff (W_eff itself is rebuilt in forward)
         g.add_wt_job(weff_off, true, wt_off, KS * KS, g.tensors[in].C, ncol());
+        if (aux >= 0) {
+            wt_aux_off = g.reserve_wt((size_t)Cs * Co);
+            g.add_wt_job(g.params[w2].offset + (size_t)Cm * Co, false, wt_aux_off, 1, Cs, Co);
+        }
         GTensor& t = g.tensors[out];
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
@@ -163,7 +186,12 @@ struct FoldedConvOp : GOp {
     size_t workspace_bytes(Graph& g, int B) override {
         TView x = g.view(in, B, false);
         TView dz = make_view(nullptr, x.N, x.H, x.W, ncol());
-        return std::max(conv2d_wgrad_workspace_bytes(x, dz, KS), bias_grad_workspace_bytes(dz));
+        size_t ws = std::max(conv2d_wgrad_workspace_bytes(x, dz, KS), bias_grad_workspace_bytes(dz));
+        if (aux >= 0) {
+            TView s = g.view(aux, B, false);
+            ws = std::max(ws, conv2d_wgrad_workspace_bytes(s, make_view(nullptr, s.N, s.H, s.W, Co), 1));
+        }
+        return ws;
     }
     void forward(Graph& g, int B, bool) override {
         const int K = krows(g);
@@ -179,6 +207,11 @@ struct FoldedConvOp : GOp {
         ConvEpilogue ep;
         ep.bias = (b1 >= 0 || b2 >= 0) ? beff : nullptr;
         ep.relu = relu;
+        if (aux >= 0) {
+            ConvEpilogue none;
+            conv2d_forward(g.stream, g.view(aux, B, false), w2s(g), 1, ts_view(g, B, 0, -1, false), none);
+            ep.add = ts_view(g, B, 0, -1, true);
+        }
         conv2d_forward(g.stream, g.view(in, B, false), weff, KS, out_view(g, false, B, 0, -1), ep);
     }
     void backward(Graph& g, const BwdCtx& c) override {
@@ -188,6 +221,23 @@ struct FoldedConvOp : GOp {
         if (relu && !g.tensors[out].grad_masked)
             bias_act_backward(g.stream, dY, out_view(g, false, c.B, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace, g.workspace_bytes);
         float* weff = g.Wt + weff_off;
+        if (aux >= 0) {
+            // the 1x1 convolution of the auxiliary tensor: its input and weight gradients from the same (masked) dZ, read as
+            // the plain HR tensor it is
+            const GTensor& to = g.tensors[out];
+            const int cnt = c.b_cnt < 0 ? c.B : c.b_cnt;
+            TView dZ = make_view(to.grad + (size_t)c.b_off * to.per_sample(), cnt * to.nmul, to.H, to.W, Co);
+            if (c.param_grads)
+                conv2d_wgrad(g.stream, g.view(aux, c.B, false, c.b_off, c.b_cnt), dZ, 1, gw2s(g), g.params[w2].grad_written, nullptr, 0,
+                             g.workspace, g.workspace_bytes);
+            if (wants_grad(g, aux, c)) {
+                ConvEpilogue ep;
+                ep.accumulate = g.tensors[aux].grad_written;
+                if (g.tensors[aux].grad_masked) ep.mask = g.view(aux, c.B, false, c.b_off, c.b_cnt);
+                conv2d_forward(g.stream, dZ, g.Wt + wt_aux_off, 1, g.view(aux, c.B, true, c.b_off, c.b_cnt), ep);
+                g.tensors[aux].grad_written = true;
+            }
+        }
         if (c.param_grads) {
             float* dweff = g.Wt + dweff_off;
             float* dbeff = dweff + (size_t)K * ncol();
@@ -349,21 +399,28 @@ struct DwConvOp : GOp {
 
 }  // namespace
 
-int g_conv2d_folded(Graph& g, int in, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout, int relu, int d2s) {
+int g_conv2d_folded(Graph& g, int in, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout, int relu, int d2s, int aux) {
     const GTensor ti = g.tensors.at(in);
     const int r = d2s > 1 ? d2s : 1;
+    const int Cs = aux >= 0 ? g.tensors.at(aux).C : 0;
     DL4DS_REQUIRE(KS == 1 || KS == 3 || KS == 5 || KS == 7, "conv2d_folded: kernel size must be 1, 3, 5 or 7");
     DL4DS_REQUIRE(g.params.at(w1).n == (size_t)KS * KS * ti.C * r * r * Cmid, "conv2d_folded: first kernel size mismatch");
-    DL4DS_REQUIRE(g.params.at(w2).n == (size_t)Cmid * Cout, "conv2d_folded: 1x1 kernel size mismatch");
+    DL4DS_REQUIRE(g.params.at(w2).n == (size_t)(Cmid + Cs) * Cout, "conv2d_folded: 1x1 kernel size mismatch");
     if (b1 >= 0) DL4DS_REQUIRE(g.params.at(b1).n == (size_t)r * r * Cmid, "conv2d_folded: first bias size mismatch");
     if (b2 >= 0) DL4DS_REQUIRE(g.params.at(b2).n == (size_t)Cout, "conv2d_folded: 1x1 bias size mismatch");
+    if (aux >= 0) {
+        const GTensor ta = g.tensors.at(aux);
+        DL4DS_REQUIRE(ta.H == ti.H * r && ta.W == ti.W * r && ta.nmul == ti.nmul, "conv2d_folded: the auxiliary tensor must live on the output grid");
+        DL4DS_REQUIRE((Cout & 3) == 0, "conv2d_folded: the auxiliary form needs Cout % 4 == 0");
+    }
     const int out = g.add_tensor(ti.H * r, ti.W * r, Cout, ti.nmul, true, false);
     FoldedConvOp* op = new FoldedConvOp();
     g.ops.emplace_back(op);
     op->in = in; op->out = out; op->w1 = w1; op->b1 = b1; op->w2 = w2; op->b2 = b2; op->KS = KS; op->r = r; op->Cm = Cmid;
-    op->Co = Cout; op->relu = relu;
+    op->Co = Cout; op->relu = relu; op->aux = aux; op->Cs = Cs;
     op->pids = {w1, b1, w2, b2};
     g.tensors[in].n_conv_in++;
+    if (aux >= 0) g.tensors[aux].n_other++;
     return out;
 }
 

@@ -97,18 +97,26 @@ class GraphBuilder:
             y = self.act(y, activation, name + '/act')
         return y
 
-    def conv2d_folded(self, x, name, filters, ks, d2s, name2, filters2, activation=None):
+    def conv2d_folded(self, x, name, filters, ks, d2s, name2, filters2, activation=None, aux=None):
         """Conv2D(ks, d2s^2 * filters) [+ depth_to_space(d2s)] directly followed by Conv2D(1x1, filters2) + activation,
-        evaluated with the composed filter (csrc/graph_ops3.hip).  Variables are those of the two Keras layers."""
+        evaluated with the composed filter (csrc/graph_ops3.hip).  Variables are those of the two Keras layers.
+        ``aux``: an HR tensor that the reference concatenates to the first convolution's output before the 1x1 layer
+        (Concatenate([x, s]) -> TransitionLast, sp_postups.py:184-203): the 1x1 kernel then has filters + aux.C input
+        channels and the auxiliary part is added as a separate 1x1 convolution."""
         activation = _check_activation(activation)
         r2 = d2s * d2s if d2s and d2s > 1 else 1
         w1 = self.param(name + '/kernel', (ks, ks, x.C, r2 * filters))
         b1 = self.param(name + '/bias', (r2 * filters,), 'zeros')
-        w2 = self.param(name2 + '/kernel', (1, 1, filters, filters2))
+        w2 = self.param(name2 + '/kernel', (1, 1, filters + (aux.C if aux is not None else 0), filters2))
         b2 = self.param(name2 + '/bias', (filters2,), 'zeros')
         out = ctypes.c_int()
-        _lib.check(self._l.dl4ds_graph_conv2d_folded(self.h, x.id, w1, b1, w2, b2, int(ks), int(filters), int(filters2),
-                                                     int(activation == 'relu'), int(d2s or 0), ctypes.byref(out)))
+        if aux is not None:
+            _lib.check(self._l.dl4ds_graph_conv2d_folded_aux(self.h, x.id, aux.id, w1, b1, w2, b2, int(ks), int(filters),
+                                                             int(filters2), int(activation == 'relu'), int(d2s or 0),
+                                                             ctypes.byref(out)))
+        else:
+            _lib.check(self._l.dl4ds_graph_conv2d_folded(self.h, x.id, w1, b1, w2, b2, int(ks), int(filters), int(filters2),
+                                                         int(activation == 'relu'), int(d2s or 0), ctypes.byref(out)))
         y = self._out(out.value, 'conv2d+conv1x1 (folded)', name + ' -> ' + name2)
         if activation not in (None, 'relu'):
             y = self.act(y, activation, name2 + '/act')

@@ -134,7 +134,7 @@ def recurrent_conv_block(g, name, x, filters, time_window, activation='relu', no
                   activation=activation)
 
 
-def subpixel_block(g, name, x, scale, n_filters, fold_into=None):
+def subpixel_block(g, name, x, scale, n_filters, fold_into=None, fold_aux=None):
     """SubpixelConvolutionBlock.call -- blocks.py:433-454.  ``conv2x`` is ONE weight set applied at
     every x2 stage; depth_to_space is fused into the conv store.  ``fold_into=(name, filters, activation)``: the 1x1
     TransitionBlock that consumes the block's output directly is composed with the last stage's filter
@@ -143,17 +143,19 @@ def subpixel_block(g, name, x, scale, n_filters, fold_into=None):
     for i, f in enumerate(seq):
         sub = {2: 'conv2x', 5: 'conv5x'}.get(f, 'conv')
         if fold_into is not None and i == len(seq) - 1:
-            x = g.conv2d_folded(x, f'{name}/{sub}', n_filters, 3, f, fold_into[0] + '/conv', fold_into[1], fold_into[2])
+            x = g.conv2d_folded(x, f'{name}/{sub}', n_filters, 3, f, fold_into[0] + '/conv', fold_into[1], fold_into[2],
+                                aux=fold_aux)
         else:
             x = g.conv2d(x, f'{name}/{sub}', n_filters * f * f, 3, d2s=f)
     return x
 
 
-def resize_conv_block(g, name, x, scale, n_filters, interpolation='bilinear', fold_into=None):
+def resize_conv_block(g, name, x, scale, n_filters, interpolation='bilinear', fold_into=None, fold_aux=None):
     """ResizeConvolutionBlock.call -- blocks.py:485-491 (``fold_into``: see subpixel_block)."""
     y = g.resize(x, int(x.H * scale), int(x.W * scale), name + '/resize', interpolation)
     if fold_into is not None:
-        return g.conv2d_folded(y, name + '/conv', n_filters, 3, 0, fold_into[0] + '/conv', fold_into[1], fold_into[2])
+        return g.conv2d_folded(y, name + '/conv', n_filters, 3, 0, fold_into[0] + '/conv', fold_into[1], fold_into[2],
+                               aux=fold_aux)
     return g.conv2d(y, name + '/conv', n_filters, 3)
 
 

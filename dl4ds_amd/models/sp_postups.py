@@ -51,21 +51,26 @@ def backbone_section(g, x_in, backbone_block, n_filters, n_blocks, activation, n
     return x, n_filters
 
 
+def aux_branch(g, s_in, n_filters_aux, activation, normalization, convnext=False):
+    """The HR auxiliary channels' own block -- sp_postups.py:186-198."""
+    if convnext:
+        return convnext_block(g, 'ConvNextBlock_aux', s_in, n_filters_aux, use_1x1conv=True, activation=activation,
+                              normalization=normalization)
+    return conv_block(g, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation, normalization=normalization,
+                      attention=False)
+
+
 def tail_section(g, x, s_in, init_n_filters, n_filters_aux, n_channels_out, activation, output_activation,
                  normalization, dropout_rate, localcon_layer, convnext=False, transition_done=False):
     """sp_postups.py:184-212 / sp_preups.py:155-183 / :289-309.  ``convnext``: the auxiliary branch is a ConvNextBlock
-    and the two closing ConvBlocks use 7x7 kernels (`ks`, sp_postups.py:121,193-210)."""
+    and the two closing ConvBlocks use 7x7 kernels (`ks`, sp_postups.py:121,193-210).  ``transition_done``: the
+    auxiliary branch, the concatenation and TransitionLast are already part of `x` (composed upsampling tail)."""
     ks = 7 if convnext else 3
     if localcon_layer:
         lws = localized_conv_block(g, 'LocalizedConvBlock', x)
         x = g.concat([x, lws], 'lcb_concat')
-    if s_in is not None:
-        if convnext:
-            s = convnext_block(g, 'ConvNextBlock_aux', s_in, n_filters_aux, use_1x1conv=True, activation=activation,
-                               normalization=normalization)
-        else:
-            s = conv_block(g, 'ConvBlock_aux', s_in, n_filters_aux, activation=activation,
-                           normalization=normalization, attention=False)
+    if s_in is not None and not transition_done:
+        s = aux_branch(g, s_in, n_filters_aux, activation, normalization, convnext)
         x = g.concat([x, s], 'aux_concat')
     if not transition_done:          # else: composed with the upsampling block's last convolution (see net_postupsampling)
         x = transition_block(g, 'TransitionLast', x, init_n_filters)
@@ -95,12 +100,19 @@ def net_postupsampling(backbone_block, upsampling, scale, n_channels, n_aux_chan
     # Without auxiliary / localized branches 'TransitionLast' (1x1, nf -> n_filters, ReLU) reads the upsampling block's
     # output directly and nothing else does: the two linear layers are evaluated as one convolution with the composed
     # filter (same variables, same gradients; csrc/graph_ops3.hip).  DL4DS_NO_FOLD=1 keeps them separate.
-    fold = (s_in is None and not localcon_layer and upsampling in ('spc', 'rc') and not os.environ.get('DL4DS_NO_FOLD'))
+    # With HR auxiliary channels TransitionLast reads Concatenate([x, s]); a 1x1 convolution of a concatenation is the sum of
+    # two, so the x part still composes and the s part is added by the composed convolution's epilogue (FoldedConvOp's
+    # auxiliary form; needs n_filters % 4 == 0).  DL4DS_NO_FOLD_AUX=1 keeps that case unfolded.
+    fold = (not localcon_layer and upsampling in ('spc', 'rc') and not os.environ.get('DL4DS_NO_FOLD') and
+            (s_in is None or (n_filters % 4 == 0 and not os.environ.get('DL4DS_NO_FOLD_AUX'))))
     fold_into = ('TransitionLast', n_filters, 'relu') if fold else None
+    fold_aux = None
+    if fold and s_in is not None:
+        fold_aux = aux_branch(g, s_in, nf, activation, normalization, convnext=(backbone_block == 'convnext'))
     if upsampling == 'spc':
-        x = subpixel_block(g, 'SubpixelConvolution', x, scale, nf, fold_into=fold_into)
+        x = subpixel_block(g, 'SubpixelConvolution', x, scale, nf, fold_into=fold_into, fold_aux=fold_aux)
     elif upsampling == 'rc':
-        x = resize_conv_block(g, 'ResizeConvolution', x, scale, nf, rc_interpolation, fold_into=fold_into)
+        x = resize_conv_block(g, 'ResizeConvolution', x, scale, nf, rc_interpolation, fold_into=fold_into, fold_aux=fold_aux)
     elif upsampling == 'dc':
         x = transition_block(g, 'TransitionDC', x, n_filters, activation)
         x = deconv_block(g, 'Deconvolution', x, scale, nf, activation)

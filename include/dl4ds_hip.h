@@ -171,6 +171,10 @@ int dl4ds_graph_slice(dl4ds_graph* g, int in, int oy, int ox, int step, int Ho, 
  * + TransitionBlock 'TransitionLast' -- sp_postups.py:172-177,203. */
 int dl4ds_graph_conv2d_folded(dl4ds_graph* g, int in, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout, int relu,
                               int d2s, int* out);
+/* ... with the HR auxiliary branch of the model: TransitionLast reads Concatenate([upsampled x, s]) (sp_postups.py:184-203), i.e.
+ * w2 has Cmid + C(aux) rows; out = act(composed conv(x) + conv1x1(aux; rows Cmid..) + bias).  `aux` lives on the output grid. */
+int dl4ds_graph_conv2d_folded_aux(dl4ds_graph* g, int in, int aux, int w1, int b1, int w2, int b2, int KS, int Cmid, int Cout,
+                                  int relu, int d2s, int* out);
 /* ZeroPadding2D(((0, Ho - H), (0, Wo - W))) -- PadConcat, blocks.py:639-647 */
 int dl4ds_graph_pad(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
 int dl4ds_graph_dense(dl4ds_graph* g, int in, int w, int b, int F, int act, int* out);

@@ -207,15 +207,18 @@ def test_headline_model_through_producer_consumer_kernels(monkeypatch):
         assert np.abs(g_hip[k] - grads[k].numpy()).max() / gscale < 1e-3, k
 
 
+@pytest.mark.parametrize('n_aux', [0, 2])
 @pytest.mark.parametrize('ups,scale', [('spc', 4), ('spc', 2), ('rc', 2), ('spc', 5)])
-def test_folded_upsampling_tail_equals_unfolded(monkeypatch, ups, scale):
+def test_folded_upsampling_tail_equals_unfolded(monkeypatch, ups, scale, n_aux):
     """The last convolution of the upsampling block composed with TransitionLast (csrc/graph_ops3.hip, FoldedConvOp)
     against the same model built with DL4DS_NO_FOLD=1 (two separate layers, the reference's evaluation order): same
     variables, and forward output, loss, every gradient (conv2x is shared with the first x2 stage, so its gradient is
-    accumulated from both) and the weights after three Adam steps agree to fp32 rounding."""
+    accumulated from both) and the weights after three Adam steps agree to fp32 rounding.  ``n_aux`` > 0: the model has
+    HR auxiliary channels, TransitionLast reads Concatenate([x, ConvBlock_aux(s)]) and the composed layer takes the
+    auxiliary part as a separate 1x1 convolution added in its epilogue (FoldedConvOp's auxiliary form)."""
     import dl4ds_amd.models as PM
     from dl4ds_amd.training import SupervisedEngine
-    cfg = dict(backbone_block='resnet', upsampling=ups, scale=scale, n_channels=2, n_aux_channels=0, lr_size=(12, 10),
+    cfg = dict(backbone_block='resnet', upsampling=ups, scale=scale, n_channels=2, n_aux_channels=n_aux, lr_size=(12, 10),
                n_blocks=2, n_filters=8, seed=5)
     monkeypatch.delenv('DL4DS_NO_FOLD', raising=False)
     folded = PM.net_postupsampling(**cfg)
@@ -224,26 +227,28 @@ def test_folded_upsampling_tail_equals_unfolded(monkeypatch, ups, scale):
     monkeypatch.delenv('DL4DS_NO_FOLD')
     kinds = [k for k, _, _ in folded.graph.layers]
     assert any('folded' in k for k in kinds) and not any('folded' in k for k, _, _ in plain.graph.layers)
-    assert len(plain.graph.layers) == len(folded.graph.layers) + 1
+    assert len(plain.graph.layers) == len(folded.graph.layers) + (1 if n_aux == 0 else 2)      # (+ the Concatenate)
     rng = np.random.default_rng(3)
     w = plain.get_weights()
-    assert list(w) == list(folded.get_weights())
+    assert sorted(w) == sorted(folded.get_weights())          # (same variables; the auxiliary block is created earlier)
     for k in w:
         if k.endswith('bias'):
             w[k] = (rng.standard_normal(w[k].shape) * 0.1).astype(np.float32)
     plain.set_weights(w); folded.set_weights(w)
     x = rng.standard_normal((3, 12, 10, 2)).astype(np.float32)
     y = rng.standard_normal((3, 12 * scale, 10 * scale, 1)).astype(np.float32)
+    ins = [x] if n_aux == 0 else [x, rng.standard_normal((3, 12 * scale, 10 * scale, n_aux)).astype(np.float32)]
+    x = ins if n_aux else x
     assert rel(folded(x), plain(x)) < 2e-5
     e1, e2 = SupervisedEngine(folded, loss='mse', learning_rate=1e-3), SupervisedEngine(plain, loss='mse', learning_rate=1e-3)
-    l1, g1 = e1.loss_and_grads([x], y)
-    l2, g2 = e2.loss_and_grads([x], y)
+    l1, g1 = e1.loss_and_grads(ins, y)
+    l2, g2 = e2.loss_and_grads(ins, y)
     assert l1 == pytest.approx(l2, rel=1e-5)
     gs = max(np.abs(v).max() for v in g2.values())
     for k in g2:
         assert np.abs(g1[k] - g2[k]).max() / gs < 1e-4, k
     for _ in range(3):
-        a, b = e1.step([x], y), e2.step([x], y)
+        a, b = e1.step(ins, y), e2.step(ins, y)
         assert a == pytest.approx(b, rel=1e-4)
     w1, w2 = folded.get_weights(), plain.get_weights()
     for k in w1:
