@@ -132,11 +132,50 @@ def resize_array(array, newsize, interpolation='inter_area', squeezed=True, keep
     return out
 
 
+SEASONS = ('winter', 'spring', 'summer', 'autumn')
+
+
+def get_season(time_metadata, time_window=None):
+    """dataloader.py:508-525 (`_get_season_`).  ``time_metadata``: the sample's time stamp(s) -- numpy datetime64 /
+    pandas / xarray time values, or plain month numbers.  With a time window the reference takes
+    ``int(scipy.stats.mode(months).count)``, i.e. the NUMBER of occurrences of the most frequent month, not that month
+    (dataloader.py:514-515); that is what a model trained with the reference has seen, so it is kept."""
+    t = getattr(time_metadata, 'values', time_metadata)
+    t = np.atleast_1d(np.asarray(getattr(t, 'time', t)))
+    if np.issubdtype(t.dtype, np.datetime64):
+        months = t.astype('datetime64[M]').astype(int) % 12 + 1
+    else:
+        months = t.astype(int)
+    if time_window is None:
+        month = int(months.ravel()[0])
+    else:
+        _, counts = np.unique(months, return_counts=True)
+        month = int(counts.max())
+    if month in (12, 1, 2):
+        return 'winter'
+    if month in (3, 4, 5):
+        return 'spring'
+    if month in (6, 7, 8):
+        return 'summer'
+    if month in (9, 10, 11):
+        return 'autumn'
+    raise ValueError(f'no season for month {month}')       # (the reference leaves `season` unbound here)
+
+
+def get_season_array(season, sizey, sizex):
+    """dataloader.py:528-542: four one-hot channels (winter, spring, summer, autumn)."""
+    if season not in SEASONS:
+        raise ValueError('``season`` not recognized')
+    a = np.zeros((sizey, sizex, 4))
+    a[:, :, SEASONS.index(season)] += 1
+    return a
+
+
 def create_pair_hr_lr(array, array_lr, upsampling, scale, patch_size, static_vars=None, predictors=None,
                       season=None, debug=False, interpolation='inter_area', rng=None):
-    """dataloader.py:11-294 without the season channels.  Returns (hr, lr[, static_hr])."""
-    if season is not None:
-        raise NotImplementedError('season channels are not implemented')
+    """dataloader.py:11-294.  Returns (hr, lr[, static_hr]).  ``season``: four one-hot channels appended to the auxiliary
+    HR array and (spatial samples) to the LR array (dataloader.py:224-245); like the reference this needs ``static_vars``
+    (its `np.concatenate([[], season_array])` fails without them) and, with ``patch_size``, spatial samples."""
     hr = np.asarray(array)
     spt = hr.ndim == 4
     hr_y, hr_x = (hr.shape[1], hr.shape[2]) if spt else (hr.shape[0], hr.shape[1])
@@ -213,6 +252,20 @@ def create_pair_hr_lr(array, array_lr, upsampling, scale, patch_size, static_var
                     v_lr = v
                 lr = np.concatenate([lr, v_lr], axis=-1)
         static_hr = np.concatenate(stat, axis=-1).astype('float32')
+    if season is not None:
+        if static_hr is None:
+            raise ValueError('season channels need `static_vars` (dataloader.py:224-235 concatenates them to the static array)')
+        if patch_size is not None:
+            sy = sx = patch_size
+            ly = lx = int(patch_size / scale) if upsampling in POSTUPSAMPLING_METHODS else patch_size
+            to_lr = True                                   # (dataloader.py:232: also for spatio-temporal samples, where it fails)
+        else:
+            sy, sx = hr_y, hr_x
+            ly, lx = (int(hr_y / scale), int(hr_x / scale)) if upsampling in POSTUPSAMPLING_METHODS else (hr_y, hr_x)
+            to_lr = not spt
+        static_hr = np.concatenate([static_hr, get_season_array(season, sy, sx)], axis=-1).astype('float32')
+        if to_lr:
+            lr = np.concatenate([lr, get_season_array(season, ly, lx)], axis=-1)
     hr = np.asarray(hr, 'float32')
     lr = np.asarray(lr, 'float32')
     if static_hr is not None:
@@ -233,8 +286,11 @@ def create_batch_hr_lr(all_indices, index, array, array_lr, upsampling, scale=4,
         else:
             d, dl = array[i:i + time_window], (None if array_lr is None else array_lr[i:i + time_window])
             p = None if predictors is None else predictors[i:i + time_window]
+        season = None
+        if time_metadata is not None:                       # dataloader.py:327,334
+            season = get_season(time_metadata[i] if time_window is None else time_metadata[i:i + time_window], time_window)
         res = create_pair_hr_lr(d, dl, upsampling, scale, patch_size, static_vars=static_vars, predictors=p,
-                                interpolation=interpolation, rng=rng)
+                                season=season, interpolation=interpolation, rng=rng)
         if static_vars is not None:
             b_aux.append(res[2])
         b_hr.append(res[0])
@@ -249,7 +305,11 @@ class DataGenerator:
 
     def __init__(self, array, array_lr, backbone, upsampling, scale, batch_size=32, patch_size=None, time_window=None,
                  static_vars=None, predictors=None, interpolation='inter_area', repeat=None, seed=None, rank=0,
-                 world=1):
+                 world=1, time_metadata=None):
+        # time_metadata: per-time-step stamps; switches the four season channels on.  The reference's generator always
+        # passes None (`self.time_metadata = array.time.copy()` is commented out, dataloader.py:428-433), so the season
+        # channels are only reachable through create_pair_hr_lr / create_batch_hr_lr there; here it is an explicit option.
+        self.time_metadata = None if time_metadata is None else np.asarray(getattr(time_metadata, 'values', time_metadata))
         self.array = np.asarray(getattr(array, 'values', array))
         self.array_lr = None if array_lr is None else np.asarray(getattr(array_lr, 'values', array_lr))
         self.batch_size, self.scale, self.upsampling, self.backbone = batch_size, scale, upsampling, backbone
@@ -276,7 +336,8 @@ class DataGenerator:
         return create_batch_hr_lr(self.indices, index, self.array, self.array_lr, upsampling=self.upsampling,
                                   scale=self.scale, batch_size=self.batch_size, patch_size=self.patch_size,
                                   time_window=self.time_window, static_vars=self.static_vars,
-                                  predictors=self.predictors, interpolation=self.interpolation, rng=self.rng)
+                                  predictors=self.predictors, interpolation=self.interpolation,
+                                  time_metadata=self.time_metadata, rng=self.rng)
 
 
 class DeviceDataGenerator:

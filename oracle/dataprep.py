@@ -162,9 +162,36 @@ def crop(array, size, y, x):
 
 
 # ----------------------------------------------------------------------------------------------- create_pair_hr_lr
+def get_season(months, time_window=None):
+    """dataloader.py:508-525 on month numbers: the month itself, or -- with a time window -- the COUNT of the most frequent
+    month (`int(scipy.stats.mode(months).count)`, dataloader.py:514-515: the reference's own reading)."""
+    months = np.atleast_1d(np.asarray(months)).astype(int)
+    if time_window is None:
+        m = int(months.ravel()[0])
+    else:
+        best = 0
+        for v in set(months.tolist()):
+            best = max(best, int((months == v).sum()))
+        m = best
+    for name, ms in (('winter', (12, 1, 2)), ('spring', (3, 4, 5)), ('summer', (6, 7, 8)), ('autumn', (9, 10, 11))):
+        if m in ms:
+            return name
+    raise ValueError(f'no season for month {m}')
+
+
+def season_array(season, sizey, sizex):
+    """dataloader.py:528-542."""
+    order = ['winter', 'spring', 'summer', 'autumn']
+    if season not in order:
+        raise ValueError('``season`` not recognized')
+    a = np.zeros((sizey, sizex, 4))
+    a[:, :, order.index(season)] += 1
+    return a
+
+
 def create_pair_hr_lr(array, array_lr, upsampling, scale, patch_size, static_vars=None, predictors=None,
-                      interpolation='inter_area', randint=None):
-    """dataloader.py:11-294 without the season channels.  ``randint(lo, hi)`` replaces np.random.randint (hi exclusive).
+                      interpolation='inter_area', randint=None, season=None):
+    """dataloader.py:11-294.  ``randint(lo, hi)`` replaces np.random.randint (hi exclusive).
     Returns (hr, lr[, static_hr], (crop_y, crop_x) in HR pixels or None)."""
     hr = np.asarray(array)
     spt = hr.ndim == 4
@@ -254,6 +281,21 @@ def create_pair_hr_lr(array, array_lr, upsampling, scale, patch_size, static_var
             if not spt:
                 lr = np.concatenate([lr, v_lr], axis=-1)
         static_hr = np.concatenate(stat, axis=-1).astype('float32')
+    if season is not None:                                                      # :224-245
+        if static_hr is None:
+            raise ValueError('season channels need static_vars (np.concatenate([[], season_array]) fails in the reference)')
+        post = upsampling in POST
+        if patch_size is not None:
+            hr_sz = (patch_size, patch_size)
+            lr_sz = (int(patch_size / scale),) * 2 if post else hr_sz
+            to_lr = True
+        else:
+            hr_sz = (hr_y, hr_x)
+            lr_sz = (int(hr_y / scale), int(hr_x / scale)) if post else hr_sz
+            to_lr = not spt
+        static_hr = np.concatenate([static_hr, season_array(season, *hr_sz)], axis=-1).astype('float32')
+        if to_lr:
+            lr = np.concatenate([lr, season_array(season, *lr_sz)], axis=-1)
     out = [np.asarray(hr_out, 'float32'), np.asarray(lr, 'float32')]
     if static_hr is not None:
         out.append(static_hr)

@@ -110,3 +110,51 @@ def test_crop_corner_distribution_matches_np_random_randint():
     ys = {D.random_corner(10, 10, 6, rng)[0] for _ in range(400)}
     assert ys == {0, 1, 2, 3}
     assert D.random_corner(8, 8, 8, rng) == (0, 0)
+
+
+def test_season_channels():
+    """dataloader.py:224-245,508-542: four one-hot season channels appended to the auxiliary HR array and, for spatial
+    samples, to the LR array; the month of a time window is the reference's `int(scipy.stats.mode(months).count)`."""
+    assert [D.get_season(np.datetime64(f'2001-{m:02d}-15')) for m in (1, 4, 7, 10, 12)] == \
+        ['winter', 'spring', 'summer', 'autumn', 'winter']
+    assert D.get_season(np.array([7])) == O.get_season([7]) == 'summer'
+    # a window of eight July days: mode count = 8 -> 'summer' by accident; five -> 'spring' (the reference's reading)
+    july = np.array(['2001-07-%02d' % d for d in range(1, 9)], dtype='datetime64[D]')
+    assert D.get_season(july, 8) == O.get_season([7] * 8, 8) == 'summer'
+    assert D.get_season(july[:5], 5) == O.get_season([7] * 5, 5) == 'spring'
+    np.testing.assert_array_equal(D.get_season_array('autumn', 2, 3)[..., 3], np.ones((2, 3)))
+    assert D.get_season_array('autumn', 2, 3)[..., :3].sum() == 0
+    with pytest.raises(ValueError):
+        D.get_season_array('monsoon', 2, 2)
+
+    rng = np.random.default_rng(0)
+    hr = rng.random((16, 24, 1))
+    topo = rng.random((16, 24))
+    for ups in ('spc', 'pin'):
+        got = D.create_pair_hr_lr(hr, None, ups, 4, None, static_vars=[topo], season='spring')
+        ref = O.create_pair_hr_lr(hr, None, ups, 4, None, static_vars=[topo], season='spring')
+        for a, b in zip(got, ref[:3]):
+            np.testing.assert_allclose(a, b, rtol=1e-6)
+        lr_hw = (4, 6) if ups == 'spc' else (16, 24)
+        assert got[1].shape == lr_hw + (1 + 1 + 4,) and got[2].shape == (16, 24, 1 + 4)
+        np.testing.assert_array_equal(got[1][..., 2:], D.get_season_array('spring', *lr_hw))
+        np.testing.assert_array_equal(got[2][..., 1:], D.get_season_array('spring', 16, 24))
+    # patches
+    got = D.create_pair_hr_lr(hr, None, 'spc', 4, 8, static_vars=[topo], season='winter', rng=np.random.default_rng(1))
+    assert got[0].shape == (8, 8, 1) and got[1].shape == (2, 2, 6) and got[2].shape == (8, 8, 5)
+    # spatio-temporal samples without patches: auxiliary array only
+    hr4 = rng.random((3, 16, 24, 1))
+    got = D.create_pair_hr_lr(hr4, None, 'spc', 4, None, static_vars=[topo], season='summer')
+    assert got[1].shape == (3, 4, 6, 1) and got[2].shape == (16, 24, 5)
+    # like the reference: no season without static variables
+    with pytest.raises(ValueError):
+        D.create_pair_hr_lr(hr, None, 'spc', 4, None, season='summer')
+    # through the generator (explicit option here; the reference's generator never passes time stamps)
+    data = rng.random((6, 16, 24, 1)).astype('float32')
+    stamps = np.array(['2001-01-01', '2001-04-01', '2001-07-01', '2001-10-01', '2001-12-01', '2001-02-01'], dtype='datetime64[D]')
+    gen = D.DataGenerator(data, None, 'resnet', 'spc', 4, batch_size=3, static_vars=[topo], seed=3, time_metadata=stamps)
+    (lr, aux), (hrb,) = gen[0]
+    assert lr.shape == (3, 4, 6, 6) and aux.shape == (3, 16, 24, 5)
+    for k, i in enumerate(gen.indices[:3]):
+        want = D.SEASONS.index(D.get_season(stamps[i]))
+        assert aux[k, 0, 0, 1 + want] == 1 and aux[k, ..., 1:].sum() == 16 * 24
