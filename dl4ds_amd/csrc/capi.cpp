@@ -489,6 +489,11 @@ int dl4ds_graph_resize_nearest(dl4ds_graph* g, int in, int Ho, int Wo, int* out)
     *out = g_resize(g->g, in, Ho, Wo, 1);
     API_END
 }
+int dl4ds_graph_resize_bicubic(dl4ds_graph* g, int in, int Ho, int Wo, int* out) {
+    API_BEGIN
+    *out = g_resize(g->g, in, Ho, Wo, 2);
+    API_END
+}
 int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out) {
     API_BEGIN
     *out = g_localconv(g->g, in, w, b, F);

@@ -642,3 +642,62 @@ void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, i
     hipLaunchKernelGGL(repeat_time_bwd_kernel, dim3(blocks), dim3(256), 0, s, dout, din, ps, T, total, accumulate);
     HIP_CHECK(hipGetLastError());
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Resizing(..., interpolation='bicubic') = tf.image.resize(method='bicubic') = the ResizeBicubic op with half-pixel centres
+// (blocks.py:473-489): Keys cubic, A = -0.5, weights taken from a 1024-step table at lrintf(frac * 1024), taps outside the
+// image dropped and the rest renormalised.  Both passes are table driven and deterministic: forward gathers 4 x 4 taps per
+// output element; backward gathers, per INPUT element, the (output index, weight) pairs that reference it (CSR built on the
+// host once per op) -- the exact transpose, no atomics.
+__global__ void resize_table_fwd_kernel(TView x, TView y, const int* __restrict__ iy, const float* __restrict__ wy,
+                                        const int* __restrict__ ix, const float* __restrict__ wx, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % y.C);
+        size_t r = e / y.C;
+        const int xo = (int)(r % y.W); r /= y.W;
+        const int yo = (int)(r % y.H);
+        const int n = (int)(r / y.H);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) row += wx[xo * 4 + b] * x.p[view_off(x, n, iy[yo * 4 + a], ix[xo * 4 + b], c)];
+            acc += wy[yo * 4 + a] * row;
+        }
+        y.p[view_off(y, n, yo, xo, c)] = acc;
+    }
+}
+__global__ void resize_table_bwd_kernel(TView dy, TView dx, const int* __restrict__ py, const int* __restrict__ oy,
+                                        const float* __restrict__ vy, const int* __restrict__ px, const int* __restrict__ ox,
+                                        const float* __restrict__ vx, int accumulate, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % dx.C);
+        size_t r = e / dx.C;
+        const int xi = (int)(r % dx.W); r /= dx.W;
+        const int yi = (int)(r % dx.H);
+        const int n = (int)(r / dx.H);
+        float acc = 0.f;
+        for (int a = py[yi]; a < py[yi + 1]; ++a) {
+            float row = 0.f;
+            for (int b = px[xi]; b < px[xi + 1]; ++b) row += vx[b] * dy.p[view_off(dy, n, oy[a], ox[b], c)];
+            acc += vy[a] * row;
+        }
+        const size_t o = view_off(dx, n, yi, xi, c);
+        dx.p[o] = accumulate ? dx.p[o] + acc : acc;
+    }
+}
+void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx) {
+    const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    ProfScope ps(s, "resize_bicubic_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
+    hipLaunchKernelGGL(resize_table_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, iy, wy, ix, wx, total);
+    HIP_CHECK(hipGetLastError());
+}
+void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
+                           const int* px, const int* ox, const float* vx, int accumulate) {
+    const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
+    ProfScope ps(s, "resize_bicubic_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
+    hipLaunchKernelGGL(resize_table_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate, total);
+    HIP_CHECK(hipGetLastError());
+}

@@ -4,6 +4,8 @@
 #include "prof.h"
 #include <algorithm>
 #include <cstring>
+#include <cmath>
+#include <limits>
 
 static void plan_concat_aliases(Graph& g);
 
@@ -609,18 +611,93 @@ struct MaxPoolOp : GOp {
 };
 
 // ============================================================================================ Bilinear resize
+// Index / weight tables of tf.image.resize(method='bicubic') along one axis (ResizeBicubic, half_pixel_centers=True), in the
+// op's own float arithmetic: scale = in / out; src = (o + 0.5f) * scale - 0.5f; i0 = floor(src); the Keys (A = -0.5) weights
+// come from a 1024-step table at offset = lrintf((src - i0) * 1024); a tap whose index had to be clamped into the image gets
+// weight 0 and the remaining weights are renormalised to sum 1.
+static void bicubic_axis_tables(int in_size, int out_size, std::vector<int>& idx, std::vector<float>& w) {
+    const int T = 1024;
+    std::vector<float> lut((T + 1) * 2);
+    const float A = -0.5f;
+    for (int i = 0; i <= T; ++i) {
+        float x = i * 1.0f / T;
+        lut[i * 2] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        x += 1.0f;
+        lut[i * 2 + 1] = ((A * x - 5 * A) * x + 8 * A) * x - 4 * A;
+    }
+    const float scale = (float)in_size / (float)out_size;
+    idx.assign((size_t)out_size * 4, 0);
+    w.assign((size_t)out_size * 4, 0.f);
+    for (int o = 0; o < out_size; ++o) {
+        const float src = ((float)o + 0.5f) * scale - 0.5f;
+        const long i0 = (long)std::floor(src);
+        const float delta = src - (float)i0;
+        const long off = lrintf(delta * T);
+        const float wt[4] = {lut[off * 2 + 1], lut[off * 2], lut[(T - off) * 2], lut[(T - off) * 2 + 1]};
+        float sum = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const long want = i0 - 1 + k;
+            const long got = std::min<long>(std::max<long>(want, 0), in_size - 1);
+            idx[(size_t)o * 4 + k] = (int)got;
+            w[(size_t)o * 4 + k] = (got == want) ? wt[k] : 0.f;
+            sum += w[(size_t)o * 4 + k];
+        }
+        if (std::fabs(sum) >= 1000.f * std::numeric_limits<float>::min())
+            for (int k = 0; k < 4; ++k) w[(size_t)o * 4 + k] *= 1.0f / sum;
+    }
+}
+
 struct ResizeOp : GOp {
     int in, out;
-    bool nearest = false;
+    bool nearest = false, bicubic = false;
+    // bicubic: forward tables [out][4] and their transpose as CSR over the input index, on the device
+    int *d_iy = nullptr, *d_ix = nullptr, *d_py = nullptr, *d_oy = nullptr, *d_px = nullptr, *d_ox = nullptr;
+    float *d_wy = nullptr, *d_wx = nullptr, *d_vy = nullptr, *d_vx = nullptr;
     ResizeOp() { kind = "resize"; }
+    ~ResizeOp() override {
+        for (void* p : {(void*)d_iy, (void*)d_ix, (void*)d_py, (void*)d_oy, (void*)d_px, (void*)d_ox, (void*)d_wy, (void*)d_wx,
+                        (void*)d_vy, (void*)d_vx})
+            if (p) (void)hipFree(p);
+    }
+    template <class T>
+    static T* upload(const std::vector<T>& v) {
+        T* d = nullptr;
+        HIP_CHECK(hipMalloc((void**)&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+        if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return d;
+    }
+    static void axis(int in_size, int out_size, int*& d_i, float*& d_w, int*& d_p, int*& d_o, float*& d_v) {
+        std::vector<int> idx;
+        std::vector<float> w;
+        bicubic_axis_tables(in_size, out_size, idx, w);
+        std::vector<int> ptr(in_size + 1, 0), oo;
+        std::vector<float> vv;
+        for (int i = 0; i < in_size; ++i) {                       // (output index ascending, tap ascending: fixed summation order)
+            for (int o = 0; o < out_size; ++o)
+                for (int k = 0; k < 4; ++k)
+                    if (idx[(size_t)o * 4 + k] == i && w[(size_t)o * 4 + k] != 0.f) { oo.push_back(o); vv.push_back(w[(size_t)o * 4 + k]); }
+            ptr[i + 1] = (int)oo.size();
+        }
+        d_i = upload(idx); d_w = upload(w); d_p = upload(ptr); d_o = upload(oo); d_v = upload(vv);
+    }
+    void on_finalize(Graph& g) override {
+        if (!bicubic) return;
+        axis(g.tensors[in].H, g.tensors[out].H, d_iy, d_wy, d_py, d_oy, d_vy);
+        axis(g.tensors[in].W, g.tensors[out].W, d_ix, d_wx, d_px, d_ox, d_vx);
+    }
     void forward(Graph& g, int B, bool) override {
-        if (nearest) resize_nearest_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
+        if (bicubic) resize_table_forward(g.stream, g.view(in, B, false), g.view(out, B, false), d_iy, d_wy, d_ix, d_wx);
+        else if (nearest) resize_nearest_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
         else resize_bilinear_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
-        (nearest ? resize_nearest_backward : resize_bilinear_backward)(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt),
-                                 g.view(in, c.B, true, c.b_off, c.b_cnt), g.tensors[in].grad_written);
+        if (bicubic)
+            resize_table_backward(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt), g.view(in, c.B, true, c.b_off, c.b_cnt), d_py, d_oy,
+                                  d_vy, d_px, d_ox, d_vx, g.tensors[in].grad_written);
+        else
+            (nearest ? resize_nearest_backward : resize_bilinear_backward)(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt),
+                                     g.view(in, c.B, true, c.b_off, c.b_cnt), g.tensors[in].grad_written);
         g.tensors[in].grad_written = true;
     }
 };
@@ -767,7 +844,7 @@ int g_resize(Graph& g, int in, int Ho, int Wo, int nearest) {
     const GTensor ti = g.tensors.at(in);
     const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
     ResizeOp* op = push<ResizeOp>(g);
-    op->in = in; op->out = out; op->nearest = nearest != 0;
+    op->in = in; op->out = out; op->nearest = nearest == 1; op->bicubic = nearest == 2;      // (0 bilinear, 1 nearest, 2 bicubic)
     g.tensors[in].n_other++;
     return out;
 }

@@ -165,3 +165,6 @@ void batch_prepare(hipStream_t s, const float* hr, const float* pred, const floa
                    int B, int scale, int psy, int psx, int pin, int static_in_lr);
 void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int T, size_t ps);
 void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, int T, size_t ps, int accumulate);
+void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx);
+void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
+                           const int* px, const int* ox, const float* vx, int accumulate);

@@ -178,10 +178,13 @@ class GraphBuilder:
         return self._out(out.value, 'maxpool2', name)
 
     def resize(self, x, ho, wo, name='resize', interpolation='bilinear'):
-        if interpolation not in ('bilinear', 'nearest'):
-            raise NotImplementedError(f"Resizing(interpolation={interpolation!r}): only 'bilinear' and 'nearest' are implemented")
+        fns = {'bilinear': self._l.dl4ds_graph_resize, 'nearest': self._l.dl4ds_graph_resize_nearest,
+               'bicubic': self._l.dl4ds_graph_resize_bicubic}
+        if interpolation not in fns:
+            raise NotImplementedError(f"Resizing(interpolation={interpolation!r}): only 'bilinear', 'nearest' and 'bicubic' are "
+                                      "implemented ('area', 'lanczos3/5', 'gaussian', 'mitchellcubic' are not)")
         out = ctypes.c_int()
-        fn = self._l.dl4ds_graph_resize if interpolation == 'bilinear' else self._l.dl4ds_graph_resize_nearest
+        fn = fns[interpolation]
         _lib.check(fn(self.h, x.id, int(ho), int(wo), ctypes.byref(out)))
         return self._out(out.value, 'resize_' + interpolation, name)
 

@@ -154,6 +154,9 @@ int dl4ds_graph_maxpool2(dl4ds_graph* g, int in, int* out);
 int dl4ds_graph_resize(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
 /* Resizing(Ho, Wo, interpolation='nearest') (half-pixel centres) -- ResizeConvolutionBlock(interpolation='nearest'), blocks.py:473-489 */
 int dl4ds_graph_resize_nearest(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
+/* Resizing(interpolation='bicubic') = tf.image.resize(method='bicubic'): ResizeBicubic with half-pixel centres (Keys cubic,
+ * A = -0.5, 1024-step weight table, out-of-image taps dropped and the rest renormalised) -- blocks.py:473-489 */
+int dl4ds_graph_resize_bicubic(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
 int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out);
 int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out);
 int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out);

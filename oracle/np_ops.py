@@ -131,6 +131,44 @@ def resize_bilinear(x, ho, wo):
     return top * (1 - fy)[None, :, None, None] + bot * fy[None, :, None, None]
 
 
+def bicubic_axis_matrix(inn, out):
+    """Dense (out, inn) interpolation matrix of tf.image.resize(method='bicubic') along one axis -- the ResizeBicubic op
+    with half_pixel_centers=True (TensorFlow core/kernels/image/resize_bicubic_op.cc; TF is absent from this image, the
+    op's published algorithm is restated): float32 arithmetic throughout; scale = in / out; src = (o + 0.5) * scale - 0.5;
+    i0 = floor(src); Keys cubic with A = -0.5 read from a table of 1024 steps at offset = rint((src - i0) * 1024):
+    w(i0) = lut0[off], w(i0-1) = lut1[off], w(i0+1) = lut0[1024-off], w(i0+2) = lut1[1024-off]; a tap whose index has to
+    be clamped into the image gets weight 0 and the rest is renormalised to sum 1."""
+    f32 = np.float32
+    A = f32(-0.5)
+    t = np.arange(1025, dtype=np.float32) / f32(1024)
+    lut0 = ((A + f32(2)) * t - (A + f32(3))) * t * t + f32(1)
+    t1 = t + f32(1)
+    lut1 = ((A * t1 - f32(5) * A) * t1 + f32(8) * A) * t1 - f32(4) * A
+    scale = f32(inn) / f32(out)
+    M = np.zeros((out, inn), np.float64)
+    for o in range(out):
+        src = (f32(o) + f32(0.5)) * scale - f32(0.5)
+        i0 = int(np.floor(src))
+        off = int(np.rint((src - f32(i0)) * f32(1024)))
+        taps = [(i0 - 1, lut1[off]), (i0, lut0[off]), (i0 + 1, lut0[1024 - off]), (i0 + 2, lut1[1024 - off])]
+        ws = [f32(w) if 0 <= i < inn else f32(0) for i, w in taps]
+        tot = f32(0)
+        for w in ws:
+            tot = f32(tot + w)
+        if abs(tot) >= 1000 * np.finfo(np.float32).tiny:
+            ws = [f32(w * (f32(1) / tot)) for w in ws]
+        for (i, _), w in zip(taps, ws):
+            M[o, min(max(i, 0), inn - 1)] += float(w)
+    return M
+
+
+def resize_bicubic(x, ho, wo):
+    """tf.keras.layers.Resizing(..., 'bicubic') (dl4ds/models/blocks.py:473-489): separable, see bicubic_axis_matrix."""
+    My = bicubic_axis_matrix(x.shape[1], ho)
+    Mx = bicubic_axis_matrix(x.shape[2], wo)
+    return np.einsum('oh,nhwc,pw->nopc', My, x, Mx)
+
+
 def max_pool2(x):
     """MaxPooling2D((2,2)) VALID stride 2.  dl4ds/models/blocks.py:613."""
     n, h, w, c = x.shape

@@ -93,6 +93,13 @@ def resize_nearest(x, ho, wo):
     return x[:, iy][:, :, ix]
 
 
+def resize_bicubic(x, ho, wo):
+    from . import np_ops
+    My = torch.as_tensor(np_ops.bicubic_axis_matrix(x.shape[1], ho), dtype=x.dtype)
+    Mx = torch.as_tensor(np_ops.bicubic_axis_matrix(x.shape[2], wo), dtype=x.dtype)
+    return torch.einsum('oh,nhwc,pw->nopc', My, x, Mx)
+
+
 def resize_bilinear(x, ho, wo):
     n, h, w, c = x.shape
 

@@ -79,6 +79,9 @@ SUP_CASES = [
     ('net_postupsampling', dict(backbone_block='resnet', upsampling='rc', scale=3, n_blocks=1, n_filters=4,
                                 rc_interpolation='nearest'), (2, 7, 9, 2), (2, 21, 27, 1)),
     ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='rc', rc_interpolation='nearest'), (1, 16, 20, 2), None),
+    # Resizing(interpolation='bicubic')
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='rc', scale=2, n_blocks=1, n_filters=4,
+                                rc_interpolation='bicubic'), (2, 9, 7, 2), (2, 18, 14, 1)),
     # odd grids: MaxPooling2D drops a row / column, PadConcat zero-pads the decoder side back (blocks.py:629-656)
     ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='rc'), (2, 25, 30, 2), None),
     ('unet_pin', dict(n_filters=4, n_blocks=3, decoder_upsampling='spc'), (1, 37, 23, 1), (1, 37, 23, 1)),

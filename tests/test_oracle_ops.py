@@ -190,3 +190,33 @@ def test_msdssim_numpy_matches_torch_and_known_answers():
     assert d.shape == (2, 3)
     assert d[1, 2] == pytest.approx(x[0, 2, 4, 0])          # corner: the edge pixel repeated four times
     assert d[0, 2] == pytest.approx((x[0, 0, 4, 0] + x[0, 1, 4, 0]) / 2)
+
+
+def test_resize_bicubic_known_properties():
+    """tf.image.resize(method='bicubic') restated (oracle/np_ops.py: Keys cubic A = -0.5, 1024-step weight table,
+    out-of-image taps dropped and renormalised): identity at equal sizes, rows sum to 1, linear precision in the interior,
+    hand-computed weights at the quarter positions of a x2 up-sampling, numpy and torch versions agree."""
+    import torch
+    from oracle import np_ops as N, torch_ops as T
+    np.testing.assert_allclose(N.bicubic_axis_matrix(7, 7), np.eye(7), atol=1e-7)
+    for inn, out in ((5, 10), (8, 20), (9, 27), (12, 5), (6, 15)):
+        M = N.bicubic_axis_matrix(inn, out)
+        np.testing.assert_allclose(M.sum(axis=1), 1.0, atol=1e-6)
+    # x2: src = o/2 - 0.25 -> fractions 0.75 (even o) and 0.25 (odd o); Keys A = -0.5 weights at t = 0.25:
+    A, t = -0.5, 0.25
+    w = [((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A, ((A + 2) * t - (A + 3)) * t * t + 1,
+         ((A + 2) * (1 - t) - (A + 3)) * (1 - t) ** 2 + 1, ((A * (2 - t) - 5 * A) * (2 - t) + 8 * A) * (2 - t) - 4 * A]
+    np.testing.assert_allclose(w, [-0.0703125, 0.8671875, 0.2265625, -0.0234375])
+    M = N.bicubic_axis_matrix(8, 16)
+    np.testing.assert_allclose(M[7, 2:6], w, atol=1e-7)              # output 7: src = 3.25 -> taps 2..5
+    np.testing.assert_allclose(M[6, 1:5], w[::-1], atol=1e-7)        # output 6: src = 2.75 -> taps 1..4, mirrored weights
+    # first output: src = -0.25 -> i0 = -1, taps -2..1: only 0 and 1 are inside; renormalised
+    first = np.array([w[::-1][2], w[::-1][3]])
+    np.testing.assert_allclose(M[0, :2], first / first.sum(), atol=1e-6)
+    # A = -0.5 reproduces linear ramps away from the border
+    ramp = np.arange(12, dtype=np.float64)[None, :, None, None] * np.ones((1, 1, 3, 1))
+    up = N.resize_bicubic(ramp, 24, 3)[0, :, 0, 0]
+    np.testing.assert_allclose(up[4:20], (np.arange(24) + 0.5)[4:20] / 2 - 0.5, atol=1e-5)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 6, 5, 3))
+    np.testing.assert_allclose(T.resize_bicubic(torch.tensor(x), 15, 8).numpy(), N.resize_bicubic(x, 15, 8), atol=1e-12)
