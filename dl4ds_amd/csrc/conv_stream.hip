@@ -325,7 +325,9 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
     constexpr int KK = KS * KS, NGS = KK * NGRP, Q4 = CK / 4;
     constexpr int HT = 256;                                       // helper threads
     constexpr int CO = GM::CO, NQ = 4 * NT;
-    constexpr int WPD = 2;
+    // filter prefetch distance in group-steps; the ring of WPD + 1 fragment sets keeps turning across steps, so its size must
+    // divide the group-steps of a step (27 for 3x3; 75 or 50 for 5x5 with 24- / 32-channel chunks)
+    constexpr int WPD = (NGS % 3 == 0) ? 2 : 1;
     static_assert(NGS % (WPD + 1) == 0 && NGS > WPD, "the filter ring runs across steps");
     typedef typename WVec<NT>::T wvec_t;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -402,10 +404,10 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
         size_t isy, isx;
         view_strides(a.in, isy, isx);
         // channel offset of the thread's quad inside a chunk: linear views -> 4*c4 on top of the chunk's own offset (part of the
-        // origin); a view whose depth_to_space groups are narrower than a chunk is taken only with ONE chunk (launcher), whose
-        // per-quad offsets are static too
+        // origin); through a view whose depth_to_space groups are narrower than a chunk the per-quad offsets go through the
+        // view and depend on the chunk, which then is part of the signature below (recomputed per chunk)
         const bool in_lin = !NL || a.in.d2s <= 1 || (CK <= a.in.cp && a.in.cp % CK == 0);
-        const size_t in_c4 = in_lin ? (size_t)c4 * 4 : view_chan_off(a.in, min(c4 * 4, a.Cin - 4));
+        size_t in_c4 = in_lin ? (size_t)c4 * 4 : view_chan_off(a.in, min(c4 * 4, a.Cin - 4));
         int soff[SIT], hyx[SIT];
         auto rel_of = [&](int hy, int hx) { return (int)((hy * isy + hx * isx + in_c4) * 4); };
 #pragma unroll
@@ -423,9 +425,10 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
             // the part of the halo tile that lies inside the image: rows [ylo, yhi), columns [xlo, xhi)
             const int ylo = max(0, PAD - it.y0), yhi = min(THH, a.H + PAD - it.y0);
             const int xlo = max(0, PAD - it.x0), xhi = min(TWH, a.W + PAD - it.x0);
-            const int sig = (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
+            const int sig = ((in_lin ? 0 : c0 / CK) << 26) | (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
             if (sig != st_sig) {                                  // (wave-uniform; n-blocks and chunks of one tile share it)
                 st_sig = sig;
+                if (!in_lin) in_c4 = view_chan_off(a.in, min(c0 + c4 * 4, a.Cin - 4));
 #pragma unroll
                 for (int u = 0; u < SIT; ++u) {
                     const int hy = hyx[u] >> 8, hx = hyx[u] & 0xff;
@@ -877,7 +880,7 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
         auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
         const bool nl = !linear(p.in, GM::CK) || !linear(p.out, GM::CO);
         if (nl && MT != 4) return false;                                   // (only the 16x16-tile variants are built for them)
-        if (!linear(p.in, GM::CK) && p.Cin != GM::CK) return false;        // (narrower groups: one chunk only)
+        if (!linear(p.in, GM::CK) && p.Cin / GM::CK > 31) return false;    // (the chunk index is part of the staging signature: 5 bits)
         if (!linear(p.out, GM::CO) && p.Cout >= 128) return false;         // (n0 must fit the 8 bits it gets in the drain signature)
         if (p.add.p && !same_layout(p.add, p.out)) return false;
         if (p.mask.p && !same_layout(p.mask, p.out)) return false;
@@ -973,8 +976,49 @@ void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
 
 }  // namespace
 
+// 5x5 layers (the 9x9 stride-2 transposed convolutions of DeconvolutionBlock as 5x5 convolutions + depth_to_space, deconv.hip):
+// only the producer / consumer kernel, 24- or 32-channel chunks
+static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep) {
+    static const bool off = getenv("DL4DS_STREAM_NO_WS") != nullptr || getenv("DL4DS_STREAM_NO_WS5") != nullptr;
+    if (getenv("DL4DS_STREAM_DEBUG"))
+        fprintf(stderr, "stream5: N=%d H=%d W=%d Cin=%d (d2s %d cp %d vec %d) Cout=%d (d2s %d cp %d vec %d) add=%d mask=%d acc=%d\n", in.N, in.H,
+                in.W, in.C, in.d2s, in.cp, in.vec, out.C, out.d2s, out.cp, out.vec, ep.add.p != nullptr, ep.mask.p != nullptr, ep.accumulate);
+    if (off || in.C < 24 || (long)in.H * in.W < 256) return false;
+    if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
+    if ((((uintptr_t)ep.bias) & 15) != 0) return false;
+    if ((long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N >= (1l << 20)) return false;
+    const int E = (in.C % 32 == 0) ? 8 : ((in.C % 24 == 0) ? 6 : 0);
+    if (!E) return false;
+    int NT = 0;
+    long best = -1;
+    for (int pass = 0; pass < 2 && !NT; ++pass)
+        for (int nt = 2; nt <= 4; ++nt) {
+            // through a depth_to_space store an n-block should not straddle a group (cp channels each); where every choice
+            // does (groups of 8 or 16 channels) the kernel's narrow-group form takes the least padded one
+            if (pass == 0 && out.d2s > 1 && (16 * nt > out.cp || out.cp % (16 * nt))) continue;
+            const long padded = (long)cdiv(out.C, 16 * nt) * 16 * nt;
+            if (best < 0 || padded < best || (padded == best && nt > NT)) { best = padded; NT = nt; }
+        }
+    StreamParams sp;
+    ConvParams& p = sp.c;
+    p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
+    p.w = w; p.bias = ep.bias;
+    p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
+    p.relu = ep.relu; p.accumulate = ep.accumulate;
+    p.wvec = 0; p.CK = 4 * E; p.TPS = 0;
+    if (E == 8) {
+        if (NT == 2) return launch_stream_ws<5, 8, 2, 4>(s, sp, in.N);
+        if (NT == 3) return launch_stream_ws<5, 8, 3, 4>(s, sp, in.N);
+        return launch_stream_ws<5, 8, 4, 4>(s, sp, in.N);
+    }
+    if (NT == 2) return launch_stream_ws<5, 6, 2, 4>(s, sp, in.N);
+    if (NT == 3) return launch_stream_ws<5, 6, 3, 4>(s, sp, in.N);
+    return launch_stream_ws<5, 6, 4, 4>(s, sp, in.N);
+}
+
 bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep) {
+    if (KS == 5) return conv2d_stream5_forward(s, in, w, out, ep);
     if (KS != 3 && KS != 1) return false;
     if (in.C < 16 || (long)in.H * in.W < 256) return false;
     if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;

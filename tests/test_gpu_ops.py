@@ -128,6 +128,40 @@ def test_conv2d_stream_producer_consumer(ops, monkeypatch, sx, n, h, w, ci, co):
     close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
 
 
+@pytest.mark.parametrize('sx', ['1', '32'])
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 33, 20, 32, 64), (1, 40, 40, 64, 128), (3, 16, 16, 24, 48), (2, 20, 36, 48, 32),
+                                        (1, 32, 32, 128, 96), (2, 17, 17, 32, 40)])
+def test_conv2d_stream_producer_consumer_5x5(ops, monkeypatch, sx, n, h, w, ci, co):
+    """... and the 5x5 layers (DeconvolutionBlock's 9x9 stride-2 transposed convolutions run as 5x5 convolutions): 32-channel
+    chunks (filter ring of 2 fragment sets, 50 group-steps) and 24-channel chunks (ring of 3, 75 group-steps); forward with
+    fused epilogues, dgrad with accumulate."""
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', sx)
+    x, wt, b, add = R(n, h, w, ci), R(5, 5, ci, co) * 0.1, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    close(ops.conv2d(x, wt, b), ref)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    close(ops.conv2d_dgrad(dz, wt), gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+
+
+@pytest.mark.parametrize('ci,co', [(64, 128), (32, 64), (32, 32), (128, 256), (48, 64)])
+def test_conv2d_stream_producer_consumer_5x5_depth_to_space(ops, monkeypatch, ci, co):
+    """The DeconvolutionBlock layers themselves: 5x5 convolution storing through depth_to_space(2) (forward) and reading its
+    input through it (dgrad), with groups of 32 / 64 channels (whole n-blocks) and of 16 / 8 channels (narrower than an
+    n-block and than a 32-channel chunk: per-quad offsets through the view, several chunks)."""
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', '2')
+    n, h, w, r = 2, 20, 33, 2
+    x, wt, b = R(n, h, w, ci), R(5, 5, ci, co) * 0.1, R(co)
+    ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
+    close(ops.conv2d(x, wt, b, d2s=r), ref)
+    dz = R(n, h * r, w * r, co // (r * r))
+    gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
+    close(ops.conv2d_dgrad(dz, wt, d2s=r), gx)
+
+
 @pytest.mark.parametrize('ci,co', [(48, 192), (48, 32), (24, 32), (48, 96)])
 def test_conv2d_stream_producer_consumer_depth_to_space(ops, monkeypatch, ci, co):
     """... through depth_to_space views on the output (forward) and the input (dgrad), also with groups narrower than an
