@@ -328,7 +328,9 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
     // filter prefetch distance in group-steps; the ring of WPD + 1 fragment sets keeps turning across steps, so its size must
     // divide the group-steps of a step (27 for 3x3; 75 or 50 for 5x5 with 24- / 32-channel chunks)
     constexpr int WPD = (NGS % 3 == 0) ? 2 : 1;
-    static_assert(NGS % (WPD + 1) == 0 && NGS > WPD, "the filter ring runs across steps");
+    // (an odd count that is no multiple of 3 -- 25 for 5x5 with 16-channel chunks -- is padded with one idle group-step)
+    constexpr int NGSP = (NGS + WPD) / (WPD + 1) * (WPD + 1);
+    static_assert(NGSP % (WPD + 1) == 0 && NGS > WPD && NGSP - NGS <= 1, "the filter ring runs across steps");
     typedef typename WVec<NT>::T wvec_t;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const bufA = lds;
@@ -710,22 +712,24 @@ __global__ void __launch_bounds__(512, 1) conv_stream_ws_kernel(const StreamPara
             WS_CYC0();
             load_a(0, av[0]);
 #pragma unroll
-            for (int gs = 0; gs < NGS; ++gs) {
-                if (gs + WPD == NGS) {                            // from here on: the next step's rows
+            for (int gs = 0; gs < NGSP; ++gs) {
+                if (gs + WPD == NGSP) {                           // from here on: the next step's rows
                     wp = (gcptr_t)(reinterpret_cast<const char*>(a.w));
                     voff = voff_next;
                 }
-                load_w(((gs + WPD) % NGRP) * G, wv[(gs + WPD) % (WPD + 1)]);
+                if ((gs + WPD) % NGSP < NGS) load_w((((gs + WPD) % NGSP) % NGRP) * G, wv[(gs + WPD) % (WPD + 1)]);
                 if (gs + 1 < NGS) load_a(gs + 1, av[(gs + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (gs < NGS) {
 #pragma unroll
-                for (int s = 0; s < G; ++s)
+                    for (int s = 0; s < G; ++s)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
+                        for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wget<NT>(wv[gs % (WPD + 1)][s], j), av[gs & 1][i][s],
-                                                                              acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wget<NT>(wv[gs % (WPD + 1)][s], j), av[gs & 1][i][s],
+                                                                                  acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             WS_CYC1();
@@ -983,11 +987,11 @@ static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* 
     if (getenv("DL4DS_STREAM_DEBUG"))
         fprintf(stderr, "stream5: N=%d H=%d W=%d Cin=%d (d2s %d cp %d vec %d) Cout=%d (d2s %d cp %d vec %d) add=%d mask=%d acc=%d\n", in.N, in.H,
                 in.W, in.C, in.d2s, in.cp, in.vec, out.C, out.d2s, out.cp, out.vec, ep.add.p != nullptr, ep.mask.p != nullptr, ep.accumulate);
-    if (off || in.C < 24 || (long)in.H * in.W < 256) return false;
+    if (off || in.C < 16 || (long)in.H * in.W < 256) return false;
     if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
     if ((((uintptr_t)ep.bias) & 15) != 0) return false;
     if ((long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N >= (1l << 20)) return false;
-    const int E = (in.C % 32 == 0) ? 8 : ((in.C % 24 == 0) ? 6 : 0);
+    const int E = (in.C % 32 == 0) ? 8 : ((in.C % 24 == 0) ? 6 : ((in.C % 16 == 0) ? 4 : 0));
     if (!E) return false;
     int NT = 0;
     long best = -1;
@@ -1011,9 +1015,14 @@ static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* 
         if (NT == 3) return launch_stream_ws<5, 8, 3, 4>(s, sp, in.N);
         return launch_stream_ws<5, 8, 4, 4>(s, sp, in.N);
     }
-    if (NT == 2) return launch_stream_ws<5, 6, 2, 4>(s, sp, in.N);
-    if (NT == 3) return launch_stream_ws<5, 6, 3, 4>(s, sp, in.N);
-    return launch_stream_ws<5, 6, 4, 4>(s, sp, in.N);
+    if (E == 6) {
+        if (NT == 2) return launch_stream_ws<5, 6, 2, 4>(s, sp, in.N);
+        if (NT == 3) return launch_stream_ws<5, 6, 3, 4>(s, sp, in.N);
+        return launch_stream_ws<5, 6, 4, 4>(s, sp, in.N);
+    }
+    if (NT == 2) return launch_stream_ws<5, 4, 2, 4>(s, sp, in.N);
+    if (NT == 3) return launch_stream_ws<5, 4, 3, 4>(s, sp, in.N);
+    return launch_stream_ws<5, 4, 4, 4>(s, sp, in.N);
 }
 
 bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,

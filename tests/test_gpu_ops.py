@@ -130,10 +130,11 @@ def test_conv2d_stream_producer_consumer(ops, monkeypatch, sx, n, h, w, ci, co):
 
 @pytest.mark.parametrize('sx', ['1', '32'])
 @pytest.mark.parametrize('n,h,w,ci,co', [(2, 33, 20, 32, 64), (1, 40, 40, 64, 128), (3, 16, 16, 24, 48), (2, 20, 36, 48, 32),
-                                        (1, 32, 32, 128, 96), (2, 17, 17, 32, 40)])
+                                        (1, 32, 32, 128, 96), (2, 17, 17, 32, 40), (2, 24, 33, 16, 32), (1, 16, 16, 80, 48)])
 def test_conv2d_stream_producer_consumer_5x5(ops, monkeypatch, sx, n, h, w, ci, co):
     """... and the 5x5 layers (DeconvolutionBlock's 9x9 stride-2 transposed convolutions run as 5x5 convolutions): 32-channel
-    chunks (filter ring of 2 fragment sets, 50 group-steps) and 24-channel chunks (ring of 3, 75 group-steps); forward with
+    chunks (filter ring of 2 fragment sets, 50 group-steps), 24-channel chunks (ring of 3, 75 group-steps) and 16-channel chunks
+    (25 group-steps + one idle one); forward with
     fused epilogues, dgrad with accumulate."""
     monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', sx)
     x, wt, b, add = R(n, h, w, ci), R(5, 5, ci, co) * 0.1, R(co), R(n, h, w, co)
@@ -147,7 +148,7 @@ def test_conv2d_stream_producer_consumer_5x5(ops, monkeypatch, sx, n, h, w, ci, 
     close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
 
 
-@pytest.mark.parametrize('ci,co', [(64, 128), (32, 64), (32, 32), (128, 256), (48, 64)])
+@pytest.mark.parametrize('ci,co', [(64, 128), (32, 64), (32, 32), (128, 256), (48, 64), (16, 32)])
 def test_conv2d_stream_producer_consumer_5x5_depth_to_space(ops, monkeypatch, ci, co):
     """The DeconvolutionBlock layers themselves: 5x5 convolution storing through depth_to_space(2) (forward) and reading its
     input through it (dgrad), with groups of 32 / 64 channels (whole n-blocks) and of 16 / 8 channels (narrower than an
