@@ -15,19 +15,32 @@ def collect(root, counter):
 
 fetch = collect(sys.argv[1], 'FETCH_SIZE')
 write = collect(sys.argv[2], 'WRITE_SIZE')
-out = {}
-for k in fetch:
+def tag_of(k):
     m = re.search(r'(conv_\w+)<([^>]*)>', k)
-    args = m.group(2).replace(' ', '').split(',') if m else []
-    if m and 'igemm_db' in m.group(1):
+    if not m:
+        return k[:60]
+    args = m.group(2).replace(' ', '').split(',')
+    name = m.group(1)
+    if 'igemm_db' in name:
         args = args[:5]                      # bench.py's tag carries <KS,MT,NT,WM,WN> only
-    if m and m.group(1).startswith('conv_wgrad_rows'):
-        args = ['3', args[0], '1', args[1]]  # kernel <CIT,WCO> -> bench.py's tag <KS,CIT,COT,WCO>
-    elif m and m.group(1).startswith('conv_wgrad_kernel'):
+    if name.startswith('conv_wgrad_rows'):
+        args = [args[2] if len(args) > 2 else '3', args[0], '1', args[1]]   # kernel <CIT,WCO,KS> -> bench.py's tag <KS,CIT,COT,WCO>
+    elif name.startswith('conv_wgrad_kernel'):
         args = args[:4]                      # ... and <KS,CIT,COT,WCO> for wgrad (drop the prefetch flag)
-    tag = (m.group(1).replace('_kernel', '').replace('rows_ws', 'rows') + '<' + ','.join(args) + '>') if m else k[:60]
-    f = sum(fetch[k]) / len(fetch[k])
-    w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
-    out[tag] = {'launches': len(fetch[k]), 'fetch_kib_raw': f, 'write_kib_raw': w,
+    elif name.startswith('conv_stream_ws'):
+        args = args[:4]                      # <KS,E,NT,MT> (drop the narrow-group flag: both forms share bench.py's tag)
+    return name.replace('_kernel', '').replace('rows_ws', 'rows') + '<' + ','.join(args) + '>'
+
+
+merged = {}
+for k in fetch:
+    t = merged.setdefault(tag_of(k), [[], []])
+    t[0] += list(fetch[k])
+    t[1] += list(write.get(k, []))
+out = {}
+for tag, (fl, wl) in merged.items():
+    f = sum(fl) / len(fl)
+    w = sum(wl) / max(len(wl), 1)
+    out[tag] = {'launches': len(fl), 'fetch_kib_raw': f, 'write_kib_raw': w,
                 'hbm_bytes_per_launch': (2.0 * f + w) * 1024.0}
 print(json.dumps(out, indent=1))
