@@ -107,7 +107,7 @@ void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, in
 }
 
 void conv2d_transpose_dgrad(hipStream_t s, const TView& dz, const float* w, int KS, int stride, const TView& dx,
-                            int accumulate, float* workspace, size_t workspace_bytes) {
+                            int accumulate, float* workspace, size_t workspace_bytes, const TView* relu_mask) {
     DeconvGeom g = make_geom(KS, stride, dx.C, dz.C);
     Carve c = carve(g, workspace, workspace_bytes);
     const int CoutP = stride * stride * dz.C;
@@ -119,6 +119,7 @@ void conv2d_transpose_dgrad(hipStream_t s, const TView& dz, const float* w, int 
     dzv.nstride = dz.nstride;
     ConvEpilogue ep;
     ep.accumulate = accumulate;
+    if (relu_mask && relu_mask->p) ep.mask = *relu_mask;
     conv2d_forward(s, dzv, c.wpt, g.KV, dx, ep);
 }
 

@@ -3,6 +3,7 @@
 #include "graph.h"
 #include "head.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -27,6 +28,15 @@ struct ConvTOp : GOp {
         TView y = g.view(out, B, false);
         return conv2d_transpose_workspace_bytes(x, y, KS, stride);
     }
+    void on_finalize(Graph& g) override {
+        // ReLU backward of this layer's output folded into its consumers' gradient stores when all of them can (Conv2D dgrad,
+        // Add / Concatenate / MaxPooling2D backward, another Conv2DTranspose): same rule as ConvOp
+        GTensor& t = g.tensors[out];
+        bool is_output = false;
+        for (int o : g.outputs) is_output |= (o == out);
+        t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_add_in + t.n_masking) >= 1 && t.n_other == 0 &&
+                        !getenv("DL4DS_NO_MASK_FUSION");
+    }
     void forward(Graph& g, int B, bool) override {
         conv2d_transpose_forward(g.stream, g.view(in, B, false), g.wp(w), KS, stride, g.view(out, B, false), relu,
                                  g.workspace, g.workspace_bytes);
@@ -34,7 +44,7 @@ struct ConvTOp : GOp {
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
         TView dY = g.view(out, c.B, true, c.b_off, c.b_cnt);
-        if (relu)
+        if (relu && !g.tensors[out].grad_masked)
             bias_act_backward(g.stream, dY, g.view(out, c.B, false, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace,
                               g.workspace_bytes);
         if (c.param_grads) {
@@ -43,8 +53,10 @@ struct ConvTOp : GOp {
             g.params[w].grad_written = true;
         }
         if (wants_grad(g, in, c)) {
+            TView mask = kNone;
+            if (g.tensors[in].grad_masked) mask = g.view(in, c.B, false, c.b_off, c.b_cnt);
             conv2d_transpose_dgrad(g.stream, dY, g.wp(w), KS, stride, g.view(in, c.B, true, c.b_off, c.b_cnt),
-                                   g.tensors[in].grad_written, g.workspace, g.workspace_bytes);
+                                   g.tensors[in].grad_written, g.workspace, g.workspace_bytes, &mask);
             g.tensors[in].grad_written = true;
         }
     }
@@ -262,7 +274,7 @@ int g_conv2d_transpose(Graph& g, int in, int w, int KS, int stride, int Cout, in
     const int out = g.add_tensor(ti.H * stride, ti.W * stride, Cout, ti.nmul, true, false);
     ConvTOp* op = push<ConvTOp>(g);
     op->in = in; op->w = w; op->out = out; op->KS = KS; op->stride = stride; op->Cout = Cout; op->relu = relu;
-    g.tensors[in].n_other++;
+    g.tensors[in].n_masking++;              // (its dgrad store applies the producer's ReLU mask, like a Conv2D consumer)
     op->pids = {w};
     return out;
 }

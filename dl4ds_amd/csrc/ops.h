@@ -54,8 +54,11 @@ int conv2d_direct_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
 // Conv2DTranspose(k, stride s, 'same', no bias), kernel HWOI [k*k][Cout][Cin] (blocks.py:508-516)
 void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, int KS, int stride,
                               const TView& out, int relu, float* workspace, size_t workspace_bytes);
+// `relu_mask` (may be null): the layer's INPUT activation; its gradient is zeroed where that activation is <= 0 (the ReLU
+// backward of the producing layer folded into this store)
 void conv2d_transpose_dgrad(hipStream_t s, const TView& dz, const float* w, int KS, int stride,
-                            const TView& dx, int accumulate, float* workspace, size_t workspace_bytes);
+                            const TView& dx, int accumulate, float* workspace, size_t workspace_bytes,
+                            const TView* relu_mask = nullptr);
 void conv2d_transpose_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, int stride,
                             float* dw, int accumulate, float* workspace, size_t workspace_bytes);
 size_t conv2d_transpose_workspace_bytes(const TView& in, const TView& out, int KS, int stride);
