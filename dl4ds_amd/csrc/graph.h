@@ -25,6 +25,8 @@ struct GTensor {
     int n_add_in = 0;          // ... as an operand of an Add (which can apply the ReLU mask while copying its gradient)
     int n_masking = 0;         // ... as an input of a Concatenate / MaxPooling2D (their backward applies the mask, too)
     int n_concat_in = 0;       // ... of which Concatenates
+    int n_fused_add = 0;       // ... (counted in n_other) as the residual operand fused into a Conv2D's epilogue
+    bool relu_out = false;     // written by a layer whose fused activation is ReLU
     // Concatenate without the forward copy: the activation lives INSIDE the concatenation's buffer (channel offset
     // alias_coff of tensor alias_of, pixel pitch alias_ld = that buffer's channel count); decided at finalize for tensors
     // written by a Conv2D / Concatenate and read only by Conv2Ds and ONE Concatenate.  Gradients stay dense.

@@ -293,6 +293,15 @@ struct ConvOp : GOp {
             add_grad_shared = !r.is_input && !is_output && r.requires_grad && r.n_conv_in == 0 && r.n_add_in == 0 &&
                               r.n_masking == 0 && r.n_other == 1 && r.per_sample() == g.tensors[out].per_sample();
         }
+        // ... and where it cannot be shared, the copy of dZ into r's gradient can apply r's own ReLU mask (r = ReLU output of a
+        // Conv2D: the input of a residual block that also feeds the block's first convolution), which lets r's producer drop
+        // its separate ReLU-backward pass as it does when all consumers are convolutions
+        if (add >= 0 && !add_grad_shared && !getenv("DL4DS_NO_MASK_FUSION")) {
+            GTensor& r = g.tensors[add];
+            bool is_output = false;
+            for (int o : g.outputs) is_output |= (o == add);
+            if (r.relu_out && !r.is_input && !is_output && r.n_other == r.n_fused_add) r.grad_masked = true;
+        }
         wt_off = g.reserve_wt(g.params[w].n);
         g.add_wt_job(g.params[w].offset, false, wt_off, KS * KS, g.tensors[in].C, Cout);
         // ReLU backward fused into the consumers' dgrad stores when every consumer is a Conv2D reading this tensor
@@ -335,8 +344,13 @@ struct ConvOp : GOp {
                               g.workspace_bytes);
         }
         if (add >= 0 && wants_grad(g, add, c)) {
-            if (!add_grad_shared)
-                view_axpy(g.stream, dY, g.view(add, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[add].grad_written);
+            if (!add_grad_shared) {
+                if (g.tensors[add].grad_masked)
+                    view_axpy_masked(g.stream, dY, g.view(add, c.B, false, c.b_off, c.b_cnt), g.view(add, c.B, true, c.b_off, c.b_cnt),
+                                     g.tensors[add].grad_written);
+                else
+                    view_axpy(g.stream, dY, g.view(add, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[add].grad_written);
+            }
             g.tensors[add].grad_written = true;
         }
         if (c.param_grads) {     // weight gradient; the bias gradient (column sums of dZ) rides along
@@ -774,8 +788,9 @@ int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu
     op->in = in; op->w = w; op->b = b; op->add = add; op->out = out; op->KS = KS; op->Cout = Cout; op->relu = relu;
     op->pids = {w, b};
     g.tensors[in].n_conv_in++;
-    if (add >= 0) g.tensors[add].n_other++;
+    if (add >= 0) { g.tensors[add].n_other++; g.tensors[add].n_fused_add++; }
     op->d2s = d2s;
+    g.tensors[out].relu_out = relu != 0;
     return out;
 }
 
