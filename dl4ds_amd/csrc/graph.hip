@@ -198,7 +198,7 @@ void Graph::zero_grad_flags() {
 
 void Graph::backward(const BwdCtx& c) {
     refresh_dgrad_weights();
-    for (auto& t : tensors) t.grad_written = false;
+    for (auto& t : tensors) { t.grad_written = false; t.pending_add = nullptr; }
     for (int o : outputs) tensors[o].grad_written = true;      // seeded by the loss
     const bool bucketed = c.param_grads && grad_ready != nullptr && !buckets.empty();
     std::vector<char> sent(bucketed ? buckets.size() : 0, 0);
@@ -249,6 +249,8 @@ struct AttFusion {
     bool ds_ready = false;      // ... when it ran before this attention's backward (then no pass over dy, x is needed)
     int att_in = -1, att_out = -1;
 };
+
+static bool defer_ok(Graph& g, int tid);        // (defined after ConvOp: the tensor's one convolution consumer is a plain Conv2D)
 
 // ============================================================================================ Conv2D
 struct ConvOp : GOp {
@@ -344,14 +346,22 @@ struct ConvOp : GOp {
                               g.workspace_bytes);
         }
         if (add >= 0 && wants_grad(g, add, c)) {
-            if (!add_grad_shared) {
+            GTensor& ra = g.tensors[add];
+            // r feeds exactly this add and ONE convolution (a residual block's input) and nothing has written its gradient yet:
+            // leave dZ where it is; that convolution's dgrad store adds it (ConvOp::backward below), no copy
+            const bool defer = !add_grad_shared && !ra.grad_written && ra.n_conv_in == 1 && ra.n_add_in == 0 && ra.n_masking == 0 &&
+                               ra.n_other == 1 && ra.n_fused_add == 1 && d2s <= 1 && !dY.sc && defer_ok(g, add) &&
+                               !getenv("DL4DS_NO_DEFERRED_ADD");
+            if (defer) {
+                ra.pending_add = dY.p;
+            } else if (!add_grad_shared) {
                 if (g.tensors[add].grad_masked)
                     view_axpy_masked(g.stream, dY, g.view(add, c.B, false, c.b_off, c.b_cnt), g.view(add, c.B, true, c.b_off, c.b_cnt),
                                      g.tensors[add].grad_written);
                 else
                     view_axpy(g.stream, dY, g.view(add, c.B, true, c.b_off, c.b_cnt), 1.f, g.tensors[add].grad_written);
             }
-            g.tensors[add].grad_written = true;
+            if (!defer) g.tensors[add].grad_written = true;
         }
         if (c.param_grads) {     // weight gradient; the bias gradient (column sums of dZ) rides along
             const bool need_db = b >= 0;
@@ -385,11 +395,26 @@ struct ConvOp : GOp {
             ep.accumulate = g.tensors[in].grad_written;
             // the producer's ReLU backward rides on this store (saves a read-modify-write pass over the gradient)
             if (g.tensors[in].grad_masked) ep.mask = g.view(in, c.B, false, c.b_off, c.b_cnt);
+            if (g.tensors[in].pending_add) {
+                // the gradient that reached this tensor through the residual add of its block: dx = dgrad + dZ_add (then masked)
+                TView pv = g.view(in, c.B, true, c.b_off, c.b_cnt);
+                pv.p = const_cast<float*>(g.tensors[in].pending_add);
+                ep.add = pv;
+                g.tensors[in].pending_add = nullptr;
+            }
             conv2d_forward(g.stream, dY, wt, KS, g.view(in, c.B, true, c.b_off, c.b_cnt), ep);
             g.tensors[in].grad_written = true;
         }
     }
 };
+
+static bool defer_ok(Graph& g, int tid) {
+    // cached per tensor would be nicer; graphs have a few hundred ops and this runs once per residual block and step
+    for (auto& up : g.ops)
+        if (ConvOp* c = dynamic_cast<ConvOp*>(up.get()))
+            if (c->in == tid) return !c->att_before && !c->att_after;
+    return false;                                     // (the consumer is a folded / transposed / other convolution)
+}
 
 // ============================================================================================ ChannelAttention
 struct ChAttOp : GOp {
