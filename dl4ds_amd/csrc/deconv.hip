@@ -101,6 +101,8 @@ void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, in
     HIP_CHECK(hipGetLastError());
     TView outv = make_view_d2s(out.p, in.N, in.H, in.W, stride * stride * out.C, stride);
     outv.nstride = out.nstride;
+    outv.ld = out.ld;                 // (the output may be a channel slice of a Concatenate's buffer: pixel pitch > its channels)
+    outv.vec = outv.vec && out.vec && (out.ld & 3) == 0;
     ConvEpilogue ep;
     ep.relu = relu;
     conv2d_forward(s, in, c.wp, g.KV, outv, ep);

@@ -26,6 +26,7 @@ struct GTensor {
     int n_masking = 0;         // ... as an input of a Concatenate / MaxPooling2D (their backward applies the mask, too)
     int n_concat_in = 0;       // ... of which Concatenates
     int n_fused_add = 0;       // ... (counted in n_other) as the residual operand fused into a Conv2D's epilogue
+    int n_pool_in = 0, n_convt_in = 0;   // ... (counted in n_masking) as the input of a MaxPooling2D / Conv2DTranspose
     bool relu_out = false;     // written by a layer whose fused activation is ReLU
     // residual-block input during a backward pass: the gradient arriving through the block's fused add (the add's dZ) that
     // the block's first convolution will fold into its dgrad store instead of a copy + an accumulating store (null: none)
@@ -67,7 +68,9 @@ struct GOp {
     virtual bool set_mask(Graph& g, const float* host, size_t n) { return false; }   // dropout keep-mask injection
     virtual size_t mask_floats(Graph& g, int B) { return 0; }                         // size of the mask of the last forward
     const char* kind = "op";
-    virtual std::string describe_fusion(Graph& g) { return ""; }    // non-empty: JSON object describing what this op handed to its neighbours
+    virtual std::string describe_fusion(Graph& g) { return ""; }
+    // >= 0: the tensor this op writes THROUGH A VIEW (so it may live inside a Concatenate's buffer, GTensor::alias_of)
+    virtual int alias_output() const { return -1; }    // non-empty: JSON object describing what this op handed to its neighbours
 };
 
 struct Graph {

@@ -877,6 +877,7 @@ int g_maxpool2(Graph& g, int in) {
     MaxPoolOp* op = push<MaxPoolOp>(g);
     op->in = in; op->out = out;
     g.tensors[in].n_masking++;
+    g.tensors[in].n_pool_in++;
     return out;
 }
 
@@ -913,8 +914,9 @@ int g_repeat_time(Graph& g, int in, int T) {
 
 
 // Concatenate without the forward copy (GTensor::alias_of): see graph.h.  Eligible input of a Concatenate: produced by a
-// plain Conv2D (no depth_to_space store, no fused attention) or by another Concatenate, read by nothing but plain Conv2Ds
-// (as their convolved input) and this one Concatenate, not a model input / output.  DenseBlock chains resolve to ONE buffer:
+// plain Conv2D (no depth_to_space store, no fused attention), a Conv2DTranspose or another Concatenate, read by nothing but
+// plain Conv2Ds (as their convolved input), MaxPooling2D / Conv2DTranspose (which read through views) and this one Concatenate,
+// not a model input / output.  DenseBlock chains resolve to ONE buffer:
 // x_{k+1} = concat(x_k, f(x_k)) makes x_k a channel prefix of x_{k+1}.  DL4DS_NO_CONCAT_ALIAS=1 keeps the copies (A/B, tests).
 static void plan_concat_aliases(Graph& g) {
     if (getenv("DL4DS_NO_CONCAT_ALIAS")) return;
@@ -926,6 +928,8 @@ static void plan_concat_aliases(Graph& g) {
             if (c->d2s <= 1 && !c->att_after && !c->att_before) producer_ok[c->out] = 1;
         } else if (ConcatOp* k = dynamic_cast<ConcatOp*>(up.get())) {
             producer_ok[k->out] = 1;
+        } else if (up->alias_output() >= 0) {
+            producer_ok[up->alias_output()] = 1;                  // (Conv2DTranspose: stores through a depth_to_space view)
         }
     }
     auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
@@ -937,7 +941,8 @@ static void plan_concat_aliases(Graph& g) {
         for (int t : k->ins) {
             GTensor& ti = g.tensors[t];
             const bool ok = producer_ok[t] && !ti.is_input && !is_output(t) && ti.alias_of < 0 && ti.n_add_in == 0 &&
-                            ti.n_other == 0 && ti.n_concat_in == 1 && ti.n_masking == 1 && ti.n_conv_in == conv_readers[t] &&
+                            ti.n_other == 0 && ti.n_concat_in == 1 && ti.n_masking == 1 + ti.n_pool_in + ti.n_convt_in &&
+                            ti.n_conv_in == conv_readers[t] &&
                             (off & 3) == 0 && (ti.C & 3) == 0;
             if (ok) { ti.alias_of = k->out; ti.alias_parent = k->out; ti.alias_coff = off; }
             off += ti.C;
