@@ -410,7 +410,13 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
 #pragma unroll
-            for (int u = 0; u < ITERS; ++u) dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[u], 0, 0);
+            for (int u = 0; u < ITERS; ++u) {
+#if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 3
+                dst[u] = (i32x4_t){0, 0, 0, 0};
+#else
+                dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[u], 0, 0);
+#endif
+            }
         };
         auto put = [&](const i32x4_t (&src)[ITERS], float* tile) __attribute__((always_inline)) {
             float* d0 = tile + p0 * P + c4 * 4;
@@ -489,24 +495,41 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
     for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
         const float* rd = lds + (k & 1) * TILE + rd_off;
         f32x4 acc[NR];
-        // (reading the pixel fragments two halo rows ahead of their MFMAs costs 32 registers and the second workgroup per
-        //  CU: 78 -> 87 us for 16 x 512^2)
+        // pixel fragments ONE halo row ahead of the MFMAs that use them: without it every pair of rows waited for its eight LDS
+        // reads (ablation: no loads / no stores change nothing, no MFMAs -> 26 us of 79; the K loop itself ran at 65 %).  Two rows
+        // ahead costs 16 more registers and with them the second workgroup per CU (78 -> 87 us).
+        float2 pv[2][4];
+#if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 1
+        for (int i_ = 0; i_ < NR; ++i_) acc[i_] = bias_c;
+        for (int rho = 0; rho < 0; ++rho) {
+#else
+#pragma unroll
+        for (int ux = 0; ux < 4; ++ux) pv[0][ux] = *reinterpret_cast<const float2*>(rd + ux * P);
 #pragma unroll
         for (int rho = 0; rho < NR + 2; ++rho) {
-            if (rho % 2 == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (rho + 1 < NR + 2) {
+#pragma unroll
+                for (int ux = 0; ux < 4; ++ux) pv[(rho + 1) & 1][ux] = *reinterpret_cast<const float2*>(rd + ((rho + 1) * TWH + ux) * P);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (consecutive MFMAs go to different accumulators wherever a halo row feeds more than one output row)
 #pragma unroll
             for (int ux = 0; ux < 4; ++ux) {
-                const float2 v = *reinterpret_cast<const float2*>(rd + (rho * TWH + ux) * P);
+                const float2 v = pv[rho & 1][ux];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int r = rho - dy;
-                    if (r >= 0 && r < NR) {
-                        const bool first = dy == 0 && ux == 0;    // this row's first MFMA: C = bias
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][0], v.x, first ? bias_c : acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][1], v.y, acc[r], 0, 0, 0);
+                for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = rho - dy;
+                        if (r >= 0 && r < NR) {
+                            const bool first = dy == 0 && ux == 0 && e == 0;    // this row's first MFMA: C = bias
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][e], e ? v.y : v.x, first ? bias_c : acc[r], 0, 0, 0);
+                        }
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                          // X
         int n, y0, x0;
@@ -549,6 +572,9 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
                 v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
             }
             if (a.accumulate) v += __builtin_bit_cast(f32x4, old[i]);
+#if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 2
+            if (v[0] == 12345.678f)
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
         }
     }
