@@ -20,6 +20,7 @@
 #include "conv_kernels.h"
 #include "launch.h"
 #include <algorithm>
+#include <vector>
 #include <cstdlib>
 
 namespace {
@@ -352,6 +353,14 @@ __global__ void __launch_bounds__(256, NARROW_PAIR_LB) conv_narrow_pair_kernel(c
 // (accumulators start at the bias through the C operand of each row's first MFMA) and store their four float4 per lane
 // through precomputed offsets.  One barrier per tile.  With load -> LDS -> MFMA -> store phases inside every wave the
 // kernel kept neither the matrix pipe (55 % busy) nor HBM (3.2 TB/s) occupied.
+#ifdef PAIR_WS_TRACE
+__device__ unsigned long long pair_ws_trace[4096 * 8];      // diagnostics build: per-workgroup phase sums (tools/variant_build.sh)
+#define PT_TIC() do { pt_t = wall_clock64(); } while (0)
+#define PT_TOC(slot_) do { const unsigned long long n_ = wall_clock64(); pt_acc[slot_] += n_ - pt_t; pt_t = n_; } while (0)
+#else
+#define PT_TIC()
+#define PT_TOC(slot_)
+#endif
 template <int NR>
 __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvParams a) {
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -362,11 +371,18 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
     constexpr int TILE = HPIX * P;
     constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    // per tile, written by the loaders one tile ahead: byte addresses of the tile's origin in out / add / mask + the (rows, columns)
+    // of the tile that exist -- the MFMA waves' epilogue used to spend 40 % of their time on this arithmetic, starved by the other
+    // workgroup's MFMAs, while the loader waves idle 80 % of theirs (PAIR_WS_TRACE build)
+    __shared__ __attribute__((aligned(16))) unsigned dsc[2][8];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave8 = tid >> 6;
     const int ntiles = a.tiles_x * a.tiles_y * a.in.N;
     const int G = gridDim.x;
+#ifdef PAIR_WS_TRACE
+    unsigned long long pt_t = 0, pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto origin = [&](int t, int& n, int& y0, int& x0) {
         const int q = fast_div(t, a.m_txy[0]);
         const int bx = t - q * a.tiles_x;
@@ -429,7 +445,27 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
                 }
             }
         };
+        size_t hosx, hosy;
+        {
+            const int rr = a.out.d2s > 1 ? a.out.d2s : 1;
+            hosx = (size_t)rr * a.out.ld;
+            hosy = (size_t)rr * (size_t)(a.out.W * rr) * a.out.ld;
+        }
+        auto describe = [&](int t, unsigned* d) __attribute__((always_inline)) {
+            int n, y0, x0;
+            origin(t, n, y0, x0);
+            const size_t pb = (size_t)y0 * hosy + (size_t)x0 * hosx;
+            const unsigned long long ob = (unsigned long long)(uintptr_t)a.out.p + ((size_t)n * a.out.nstride + pb) * 4;
+            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (a.add.p ? ((size_t)n * a.add.nstride + pb) * 4 : 0);
+            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (a.mask.p ? ((size_t)n * a.mask.nstride + pb) * 4 : 0);
+            const int ymax = min(PTH, a.H - y0), xmax = min(PTW, a.W - x0);
+            if (tid == 256) {
+                *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)ob, (unsigned)(ob >> 32), (unsigned)ab, (unsigned)(ab >> 32));
+                *reinterpret_cast<uint4*>(d + 4) = make_uint4((unsigned)mb, (unsigned)(mb >> 32), (unsigned)((ymax << 8) | xmax), 0u);
+            }
+        };
         const int t0 = blockIdx.x;
+        if (t0 < ntiles) describe(t0, dsc[0]);
         if (t0 < ntiles) issue(t0, r[0]);
         if (t0 + G < ntiles) issue(t0 + G, r[1]);
         if (t0 < ntiles) put(r[0], lds);
@@ -442,13 +478,20 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
             for (int j = 0; j < 3; ++j) {
                 const int tk = t + j * G;
                 if (tk < ntiles) {
-                    if (tk + G < ntiles) put(r[(j + 1) % 3], lds + ((k + 1) & 1) * TILE);
+                    PT_TIC();
+                    if (tk + G < ntiles) { put(r[(j + 1) % 3], lds + ((k + 1) & 1) * TILE); describe(tk + G, dsc[(k + 1) & 1]); }
+                    PT_TOC(4);
                     if (tk + 3 * G < ntiles) issue(tk + 3 * G, r[j]);
+                    PT_TOC(5);
                     __syncthreads();                              // X: tile k consumed, tile k+1 staged
+                    PT_TOC(6);
                     ++k;
                 }
             }
         }
+#ifdef PAIR_WS_TRACE
+        if (tid == 256) for (int q_ = 4; q_ < 8; ++q_) pair_ws_trace[(size_t)blockIdx.x * 8 + q_] = pt_acc[q_];
+#endif
         return;
     }
 
@@ -494,6 +537,7 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
     int k = 0;
     for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
         const float* rd = lds + (k & 1) * TILE + rd_off;
+        PT_TIC();
         f32x4 acc[NR];
         // pixel fragments ONE halo row ahead of the MFMAs that use them: without it every pair of rows waited for its eight LDS
         // reads (ablation: no loads / no stores change nothing, no MFMAs -> 26 us of 79; the K loop itself ran at 65 %).  Two rows
@@ -531,23 +575,27 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the tile's descriptors come from the loaders (dsc[k & 1]: written during the previous step, overwritten for tile k + 2
+        // during the NEXT one -- so they are taken into scalar registers before this step's barrier)
+        const uint4 d0 = *reinterpret_cast<const uint4*>(dsc[k & 1]);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(dsc[k & 1] + 4);
+        auto sg = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        const unsigned long long ob = ((unsigned long long)sg(d0.y) << 32) | sg(d0.x);
+        const unsigned long long ab = ((unsigned long long)sg(d0.w) << 32) | sg(d0.z);
+        const unsigned long long mb = ((unsigned long long)sg(d1.y) << 32) | sg(d1.x);
+        const int sig = (int)sg(d1.z);
+        PT_TOC(0);
         __syncthreads();                                          // X
-        int n, y0, x0;
-        origin(t, n, y0, x0);
-        const int ymax = min(PTH, a.H - y0), xmax = min(PTW, a.W - x0);
-        const int sig = (ymax << 8) | xmax;
+        PT_TOC(1);
         if (sig != esig) {
             esig = sig;
+            const int ymax = sig >> 8, xmax = sig & 0xff;
 #pragma unroll
             for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && 2 * l15 + eh < xmax) ? eo[i] : OOB;
         }
-        const size_t pb = (size_t)y0 * osy + (size_t)x0 * osx;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<char*>(a.out.p) + ((size_t)n * a.out.nstride + pb) * 4, 0, 0x7fffff00, RSRC3);
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<char*>(a.add.p) + (a.add.p ? ((size_t)n * a.add.nstride + pb) * 4 : 0), 0, 0x7fffff00, RSRC3);
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<char*>(a.mask.p) + (a.mask.p ? ((size_t)n * a.mask.nstride + pb) * 4 : 0), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ob), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)mb), 0, 0x7fffff00, RSRC3);
         i32x4_t ad[NR], mk[NR], old[NR];
         if (a.add.p) {
 #pragma unroll
@@ -577,7 +625,14 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
 #endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
         }
+        PT_TOC(2);
+#ifdef PAIR_WS_TRACE
+        pt_acc[3] += 1;
+#endif
     }
+#ifdef PAIR_WS_TRACE
+    if (tid == 0) for (int q_ = 0; q_ < 4; ++q_) pair_ws_trace[(size_t)blockIdx.x * 8 + q_] = pt_acc[q_];
+#endif
 }
 
 bool narrow_pair_ws_ok(const ConvParams& p) {
@@ -606,6 +661,18 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
                      4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
         hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR>), dim3(blocks), dim3(512), 0, s, p);
         HIP_CHECK(hipGetLastError());
+#ifdef PAIR_WS_TRACE
+        {
+            HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h((size_t)blocks * 8);
+            HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(pair_ws_trace), h.size() * 8));
+            double a_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b_ = 0; b_ < blocks; ++b_) for (int q_ = 0; q_ < 8; ++q_) a_[q_] += (double)h[(size_t)b_ * 8 + q_];
+            fprintf(stderr, "pair_ws trace (%d workgroups, %.1f tiles each; us per workgroup): MFMA waves K loop %.1f | barrier %.1f | epilogue %.1f"
+                            " || loaders LDS writes %.1f | issue loads %.1f | barrier %.1f\n", blocks, a_[3] / blocks, a_[0] / blocks / 100,
+                    a_[1] / blocks / 100, a_[2] / blocks / 100, a_[4] / blocks / 100, a_[5] / blocks / 100, a_[6] / blocks / 100);
+        }
+#endif
         return;
     }
     const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_kernel<NR>>(256));
