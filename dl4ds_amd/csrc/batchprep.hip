@@ -100,7 +100,166 @@ __global__ void prep_hr_kernel(const PrepParams a) {
     }
 }
 
+// ---- every other interpolation of resize_array (utils.py:330-401: cv2 nearest / bilinear / bicubic / Lanczos-4, and
+// inter_area again): cv2.resize is separable, so one axis of it is a table of K (source index, weight) taps per output
+// row / column (built once on the host by the cv2 restatement, resident in HBM).  A "gather" pass evaluates
+//     out[b,t,oy,ox,c] = sum_ky sum_kx wy[ry,ky] wx[rx,kx] src_c[y0 + iy[ry,ky], x0 + ix[rx,kx]]
+// for up to three channel groups with their own source, table and origin rule (see batch_prepare_taps below).
+struct TapTable {
+    const int* iy; const float* wy; int ky;
+    const int* ix; const float* wx; int kx;
+};
+struct TapGroup {
+    const float* src;
+    int Cn;                 // channels of the source image
+    int frames;             // 0: dataset frame idx[b]+t   1: batch-local frame b*T+t   2: one static image
+    int sh, sw;             // source image size
+    int raw;                // 1: copy the source pixel at (cy+oy, cx+ox), no taps
+    int origin_from_crop;   // 1: tap indices are relative to the crop corner (the PATCH was resized)
+    int row_div;            // >0: table row = oy + cy/row_div (the whole FIELD was resized, then cropped)
+    TapTable tab;
+};
+struct TapParams {
+    TapGroup g[3];
+    int cend[3];            // exclusive channel end of each group in the output
+    int ng;
+    const int* idx; const int* cy; const int* cx;   // cy/cx null: no crop (origin 0)
+    float* out;
+    int oy_n, ox_n, CL, T, B;
+};
+
+__global__ void prep_taps_kernel(const TapParams a) {
+    const size_t total = (size_t)a.B * a.T * a.oy_n * a.ox_n * a.CL;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % a.CL);
+        size_t r = e / a.CL;
+        const int ox = (int)(r % a.ox_n); r /= a.ox_n;
+        const int oy = (int)(r % a.oy_n); r /= a.oy_n;
+        const int t = (int)(r % a.T);
+        const int b = (int)(r / a.T);
+        int gi = 0;
+        while (gi + 1 < a.ng && c >= a.cend[gi]) ++gi;
+        const TapGroup& g = a.g[gi];
+        const int cc = c - (gi ? a.cend[gi - 1] : 0);
+        const int cy = a.cy ? a.cy[b] : 0, cx = a.cx ? a.cx[b] : 0;
+        const size_t frame = g.frames == 0 ? (size_t)(a.idx[b] + t) : g.frames == 1 ? (size_t)b * a.T + t : 0;
+        const float* img = g.src + frame * g.sh * g.sw * g.Cn + cc;
+        float v;
+        if (g.raw) {
+            v = img[((size_t)(cy + oy) * g.sw + cx + ox) * g.Cn];
+        } else {
+            const int ry = g.row_div ? oy + cy / g.row_div : oy, rx = g.row_div ? ox + cx / g.row_div : ox;
+            const int y0 = g.origin_from_crop ? cy : 0, x0 = g.origin_from_crop ? cx : 0;
+            const int* iy = g.tab.iy + (size_t)ry * g.tab.ky;
+            const float* wy = g.tab.wy + (size_t)ry * g.tab.ky;
+            const int* ix = g.tab.ix + (size_t)rx * g.tab.kx;
+            const float* wx = g.tab.wx + (size_t)rx * g.tab.kx;
+            v = 0.f;
+            for (int ky = 0; ky < g.tab.ky; ++ky) {
+                const float* row = img + (size_t)(y0 + iy[ky]) * g.sw * g.Cn;
+                float acc = 0.f;
+                for (int kx = 0; kx < g.tab.kx; ++kx) acc += wx[kx] * row[(size_t)(x0 + ix[kx]) * g.Cn];
+                v += wy[ky] * acc;
+            }
+        }
+        a.out[e] = v;
+    }
+}
+
+void launch_taps(hipStream_t s, const TapParams& a, const char* name, double src_bytes) {
+    const size_t n = (size_t)a.B * a.T * a.oy_n * a.ox_n * a.CL;
+    ProfScope ps(s, name, 0.0, src_bytes + 4.0 * n);
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 16384));
+    hipLaunchKernelGGL(prep_taps_kernel, dim3(blocks), dim3(256), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace
+
+// Batch preparation for any separable interpolation.  Tables (device, built by the caller from cv2's coefficients):
+//   dn_patch : [psy/scale][ky] / [psx/scale][kx]  resize of a psy x psx PATCH to the LR grid (indices relative to the patch)
+//   dn_field : [H/scale] / [W/scale]               resize of the whole field to the LR grid
+//   up_field : [H] / [W]                           resize of the LR field back to H x W ('pin')
+// post-upsampling (dataloader.py:141-205): the HR crop is resized (dn_patch); predictors are resized as whole fields and
+// cropped on the LR grid (dn_field, corner / scale); static variables are cropped, then resized (dn_patch).
+// 'pin' (dataloader.py:94-112): HR and predictor fields are resized to the LR grid (dn_field, into `scratch`
+// [B][T][H/scale][W/scale][C+P]) and back (up_field), then cropped; static variables are cropped only.
+void batch_prepare_taps(hipStream_t s, const float* hr, const float* pred, const float* stat, const int* idx, const int* cy,
+                        const int* cx, float* out_lr, float* out_hr, float* out_stat, float* scratch, int H, int W, int C,
+                        int P, int S, int T, int B, int scale, int psy, int psx, int pin, int static_in_lr,
+                        const TapAxis* dn_patch, const TapAxis* dn_field, const TapAxis* up_field) {
+    DL4DS_REQUIRE(B > 0 && T > 0 && C > 0 && scale >= 1, "batch_prepare_taps: bad sizes");
+    DL4DS_REQUIRE(psy <= H && psx <= W, "batch_prepare_taps: patch larger than the field");
+    DL4DS_REQUIRE((P == 0) == (pred == nullptr) && (S == 0) == (stat == nullptr), "batch_prepare_taps: predictor/static pointers");
+    auto table = [](const TapAxis* t) {
+        TapTable r;
+        r.iy = t[0].idx; r.wy = t[0].wt; r.ky = t[0].k; r.ix = t[1].idx; r.wx = t[1].wt; r.kx = t[1].k;
+        return r;
+    };
+    auto ok = [](const TapAxis* t) { return t && t[0].idx && t[0].wt && t[0].k > 0 && t[1].idx && t[1].wt && t[1].k > 0; };
+    const int hl = H / scale, wl = W / scale;
+    const bool with_stat = static_in_lr && S;
+    TapParams a{};
+    a.idx = idx; a.T = T; a.B = B;
+    if (pin) {
+        DL4DS_REQUIRE(ok(dn_field) && ok(up_field) && scratch, "batch_prepare_taps: 'pin' needs dn_field, up_field and scratch");
+        // pass 1: whole fields -> LR grid
+        a.cy = a.cx = nullptr;
+        a.out = scratch; a.oy_n = hl; a.ox_n = wl; a.CL = C + P; a.ng = 0;
+        auto field = [&](const float* src, int Cn) {
+            TapGroup& g = a.g[a.ng];
+            g = TapGroup{};
+            g.src = src; g.Cn = Cn; g.frames = 0; g.sh = H; g.sw = W; g.tab = table(dn_field);
+            a.cend[a.ng] = (a.ng ? a.cend[a.ng - 1] : 0) + Cn;
+            ++a.ng;
+        };
+        field(hr, C);
+        if (P) field(pred, P);
+        launch_taps(s, a, "batch_prepare_taps_down", 4.0 * B * T * (double)H * W * (C + P));
+        // pass 2: LR fields -> HR grid, cropped; static variables copied
+        a.cy = cy; a.cx = cx;
+        a.out = out_lr; a.oy_n = psy; a.ox_n = psx; a.CL = C + P + (with_stat ? S : 0); a.ng = 1;
+        a.g[0] = TapGroup{};
+        a.g[0].src = scratch; a.g[0].Cn = C + P; a.g[0].frames = 1; a.g[0].sh = hl; a.g[0].sw = wl; a.g[0].row_div = 1;
+        a.g[0].tab = table(up_field);
+        a.cend[0] = C + P;
+        if (with_stat) {
+            a.g[1] = TapGroup{};
+            a.g[1].src = stat; a.g[1].Cn = S; a.g[1].frames = 2; a.g[1].sh = H; a.g[1].sw = W; a.g[1].raw = 1;
+            a.cend[1] = C + P + S;
+            a.ng = 2;
+        }
+        launch_taps(s, a, "batch_prepare_taps_up", 4.0 * B * T * (double)hl * wl * (C + P));
+    } else {
+        DL4DS_REQUIRE(psy % scale == 0 && psx % scale == 0, "batch_prepare_taps: patch size must be divisible by scale");
+        DL4DS_REQUIRE(ok(dn_patch) && (!P || ok(dn_field)), "batch_prepare_taps: tables missing");
+        a.cy = cy; a.cx = cx;
+        a.out = out_lr; a.oy_n = psy / scale; a.ox_n = psx / scale; a.CL = C + P + (with_stat ? S : 0); a.ng = 0;
+        int cend = 0;
+        auto add = [&](const float* src, int Cn, int frames, bool whole_field) {
+            TapGroup& g = a.g[a.ng];
+            g = TapGroup{};
+            g.src = src; g.Cn = Cn; g.frames = frames; g.sh = H; g.sw = W;
+            if (whole_field) { g.row_div = scale; g.tab = table(dn_field); }
+            else { g.origin_from_crop = 1; g.tab = table(dn_patch); }
+            cend += Cn;
+            a.cend[a.ng++] = cend;
+        };
+        add(hr, C, 0, false);
+        if (P) add(pred, P, 0, true);
+        if (with_stat) add(stat, S, 2, false);
+        launch_taps(s, a, "batch_prepare_taps_down", 4.0 * B * T * (double)psy * psx * (C + P));
+    }
+    // the HR crop and the static-variable crop are the copies of the default path
+    PrepParams h{};
+    h.hr = hr; h.stat = stat; h.idx = idx; h.cy = cy; h.cx = cx; h.out_hr = out_hr; h.out_stat = S ? out_stat : nullptr;
+    h.H = H; h.W = W; h.C = C; h.S = S; h.T = T; h.B = B; h.psy = psy; h.psx = psx;
+    const size_t n_hr = (size_t)B * T * psy * psx * C + (S ? (size_t)B * psy * psx * S : 0);
+    ProfScope ps(s, "batch_prepare_hr", 0.0, 8.0 * n_hr);
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n_hr, 256), 16384));
+    hipLaunchKernelGGL(prep_hr_kernel, dim3(blocks), dim3(256), 0, s, h);
+    HIP_CHECK(hipGetLastError());
+}
 
 void batch_prepare(hipStream_t s, const float* hr, const float* pred, const float* stat, const int* idx, const int* cy,
                    const int* cx, float* out_lr, float* out_hr, float* out_stat, int H, int W, int C, int P, int S, int T,

@@ -271,6 +271,33 @@ int dl4ds_batch_prepare(const float* hr, const float* pred, const float* stat, c
                   psy, psx, pin, static_in_lr);
     API_END
 }
+int dl4ds_batch_prepare_taps(const float* hr, const float* pred, const float* stat, const int* idx_host, const int* cy_host,
+                             const int* cx_host, float* out_lr, float* out_hr, float* out_stat, float* scratch_dev, int H, int W,
+                             int C, int P, int S_, int T, int B, int scale, int psy, int psx, int pin, int static_in_lr,
+                             const dl4ds_tap_axis* dn_patch, const dl4ds_tap_axis* dn_field, const dl4ds_tap_axis* up_field) {
+    API_BEGIN
+    DL4DS_REQUIRE(B > 0 && idx_host && cy_host && cx_host, "batch_prepare_taps: index lists missing");
+    static int* d_idx = nullptr;
+    static int cap = 0;
+    static std::vector<int> h_idx;
+    if (3 * B > cap) {
+        if (d_idx) HIP_CHECK(hipFree(d_idx));
+        cap = std::max(3 * B, 3 * 256);
+        HIP_CHECK(hipMalloc((void**)&d_idx, (size_t)cap * sizeof(int)));
+    }
+    h_idx.resize(3 * (size_t)B);
+    for (int b = 0; b < B; ++b) { h_idx[b] = idx_host[b]; h_idx[B + b] = cy_host[b]; h_idx[2 * B + b] = cx_host[b]; }
+    HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), 3 * (size_t)B * sizeof(int), hipMemcpyHostToDevice, S()));
+    auto axes = [](const dl4ds_tap_axis* t, TapAxis* o) -> const TapAxis* {
+        if (!t) return nullptr;
+        for (int i = 0; i < 2; ++i) { o[i].idx = t[i].idx; o[i].wt = t[i].wt; o[i].k = t[i].k; }
+        return o;
+    };
+    TapAxis a0[2], a1[2], a2[2];
+    batch_prepare_taps(S(), hr, pred, stat, d_idx, d_idx + B, d_idx + 2 * B, out_lr, out_hr, out_stat, scratch_dev, H, W, C, P,
+                       S_, T, B, scale, psy, psx, pin, static_in_lr, axes(dn_patch, a0), axes(dn_field, a1), axes(up_field, a2));
+    API_END
+}
 int dl4ds_op_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r) {
     API_BEGIN
     depth_to_space(S(), x, y, N, H, W, C, r);
@@ -492,6 +519,11 @@ int dl4ds_graph_resize_nearest(dl4ds_graph* g, int in, int Ho, int Wo, int* out)
 int dl4ds_graph_resize_bicubic(dl4ds_graph* g, int in, int Ho, int Wo, int* out) {
     API_BEGIN
     *out = g_resize(g->g, in, Ho, Wo, 2);
+    API_END
+}
+int dl4ds_graph_resize_method(dl4ds_graph* g, int in, int Ho, int Wo, int method, int* out) {
+    API_BEGIN
+    *out = g_resize(g->g, in, Ho, Wo, method);
     API_END
 }
 int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out) {

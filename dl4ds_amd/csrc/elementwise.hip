@@ -651,7 +651,7 @@ void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, i
 // output element; backward gathers, per INPUT element, the (output index, weight) pairs that reference it (CSR built on the
 // host once per op) -- the exact transpose, no atomics.
 __global__ void resize_table_fwd_kernel(TView x, TView y, const int* __restrict__ iy, const float* __restrict__ wy,
-                                        const int* __restrict__ ix, const float* __restrict__ wx, size_t total) {
+                                        const int* __restrict__ ix, const float* __restrict__ wx, int ky, int kx, size_t total) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % y.C);
         size_t r = e / y.C;
@@ -659,12 +659,10 @@ __global__ void resize_table_fwd_kernel(TView x, TView y, const int* __restrict_
         const int yo = (int)(r % y.H);
         const int n = (int)(r / y.H);
         float acc = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < ky; ++a) {
             float row = 0.f;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) row += wx[xo * 4 + b] * x.p[view_off(x, n, iy[yo * 4 + a], ix[xo * 4 + b], c)];
-            acc += wy[yo * 4 + a] * row;
+            for (int b = 0; b < kx; ++b) row += wx[xo * kx + b] * x.p[view_off(x, n, iy[yo * ky + a], ix[xo * kx + b], c)];
+            acc += wy[yo * ky + a] * row;
         }
         y.p[view_off(y, n, yo, xo, c)] = acc;
     }
@@ -688,16 +686,17 @@ __global__ void resize_table_bwd_kernel(TView dy, TView dx, const int* __restric
         dx.p[o] = accumulate ? dx.p[o] + acc : acc;
     }
 }
-void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx) {
+void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx,
+                          int ky, int kx) {
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
-    ProfScope ps(s, "resize_bicubic_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
-    hipLaunchKernelGGL(resize_table_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, iy, wy, ix, wx, total);
+    ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
+    hipLaunchKernelGGL(resize_table_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, iy, wy, ix, wx, ky, kx, total);
     HIP_CHECK(hipGetLastError());
 }
 void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
                            const int* px, const int* ox, const float* vx, int accumulate) {
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
-    ProfScope ps(s, "resize_bicubic_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
+    ProfScope ps(s, "resize_table_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
     hipLaunchKernelGGL(resize_table_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate, total);
     HIP_CHECK(hipGetLastError());
 }

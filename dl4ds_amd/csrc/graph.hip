@@ -686,10 +686,64 @@ static void bicubic_axis_tables(int in_size, int out_size, std::vector<int>& idx
     }
 }
 
+// The same for tf.image.resize(method = 'lanczos3' | 'lanczos5' | 'gaussian' | 'mitchellcubic', antialias=False), i.e.
+// ScaleAndTranslate with scale = out / in, translation 0 and kernel scale 1 (its ComputeSpans, in the op's float arithmetic):
+// sample = (o + 0.5f) / scale; taps ceil(sample - R - 0.5) .. floor(sample + R - 0.5) clamped into the image, weight
+// kernel(|i + 0.5 - sample|), normalised to sum 1.  Kernels (sampling_kernels.h): Lanczos radius R: 0 beyond R, 1 within 1e-3,
+// else R sin(pi x) sin(pi x / R) / (pi x)^2; Gaussian: radius 1.5, sigma 0.5; Mitchell-Netravali cubic (B = C = 1/3), radius 2.
+// Returns the number of taps per output (the widest span); narrower spans are padded with weight 0.
+static int scale_translate_axis_tables(int method, int in_size, int out_size, std::vector<int>& idx, std::vector<float>& w) {
+    const float R = method == 3 ? 3.f : method == 4 ? 5.f : method == 5 ? 1.5f : 2.f;
+    auto kernel = [&](float x) -> float {
+        x = std::fabs(x);
+        if (method == 3 || method == 4) {
+            const float kPI = 3.14159265359f;
+            if (x > R) return 0.f;
+            if (x <= 1e-3f) return 1.f;
+            return R * std::sin(kPI * x) * std::sin(kPI * x / R) / (kPI * kPI * x * x);
+        }
+        if (method == 5) {
+            const float sigma = R / 3.f;
+            if (x >= R) return 0.f;
+            return std::exp(-x * x / (2.0f * sigma * sigma));
+        }
+        if (x >= 2.f) return 0.f;
+        if (x >= 1.f) return (((-7.0f / 18.0f) * x + 2.0f) * x - 10.0f / 3.0f) * x + 16.0f / 9.0f;
+        return (((7.0f / 6.0f) * x - 2.0f) * x) * x + 8.0f / 9.0f;
+    };
+    const float inv_scale = 1.0f / ((float)out_size / (float)in_size);
+    std::vector<int> start(out_size, 0);
+    std::vector<std::vector<float>> ws(out_size);
+    int K = 1;
+    for (int o = 0; o < out_size; ++o) {
+        const float sample = ((float)o + 0.5f) * inv_scale;
+        if (sample < 0 || sample > (float)in_size) continue;
+        long s0 = (long)std::ceil(sample - R - 0.5f), s1 = (long)std::floor(sample + R - 0.5f);
+        s0 = std::min<long>(std::max<long>(s0, 0), in_size - 1);
+        s1 = std::min<long>(std::max<long>(s1, 0), in_size - 1) + 1;
+        float tot = 0.f;
+        for (long i = s0; i < s1; ++i) {
+            const float wt = kernel((float)i + 0.5f - sample);
+            tot += wt;
+            ws[o].push_back(wt);
+        }
+        if (std::fabs(tot) >= 1000.f * std::numeric_limits<float>::min())
+            for (float& v : ws[o]) v *= 1.0f / tot;
+        start[o] = (int)s0;
+        K = std::max<int>(K, (int)ws[o].size());
+    }
+    idx.assign((size_t)out_size * K, 0);
+    w.assign((size_t)out_size * K, 0.f);
+    for (int o = 0; o < out_size; ++o)
+        for (size_t k = 0; k < ws[o].size(); ++k) { idx[(size_t)o * K + k] = start[o] + (int)k; w[(size_t)o * K + k] = ws[o][k]; }
+    return K;
+}
+
 struct ResizeOp : GOp {
     int in, out;
-    bool nearest = false, bicubic = false;
-    // bicubic: forward tables [out][4] and their transpose as CSR over the input index, on the device
+    bool nearest = false, bicubic = false;      // `bicubic`: any table-driven method
+    int method = 0, ky = 4, kx = 4;             // 0 bilinear 1 nearest 2 bicubic 3 lanczos3 4 lanczos5 5 gaussian 6 mitchellcubic
+    // table-driven: forward tables [out][k] and their transpose as CSR over the input index, on the device
     int *d_iy = nullptr, *d_ix = nullptr, *d_py = nullptr, *d_oy = nullptr, *d_px = nullptr, *d_ox = nullptr;
     float *d_wy = nullptr, *d_wx = nullptr, *d_vy = nullptr, *d_vx = nullptr;
     ResizeOp() { kind = "resize"; }
@@ -705,27 +759,33 @@ struct ResizeOp : GOp {
         if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
         return d;
     }
-    static void axis(int in_size, int out_size, int*& d_i, float*& d_w, int*& d_p, int*& d_o, float*& d_v) {
+    int axis(int in_size, int out_size, int*& d_i, float*& d_w, int*& d_p, int*& d_o, float*& d_v) const {
         std::vector<int> idx;
         std::vector<float> w;
-        bicubic_axis_tables(in_size, out_size, idx, w);
+        int K = 4;
+        if (method == 2) bicubic_axis_tables(in_size, out_size, idx, w);
+        else K = scale_translate_axis_tables(method, in_size, out_size, idx, w);
+        // transpose: per input index the (output, weight) pairs, output index ascending, tap ascending (fixed summation order)
+        std::vector<std::vector<std::pair<int, float>>> cols(in_size);
+        for (int o = 0; o < out_size; ++o)
+            for (int k = 0; k < K; ++k)
+                if (w[(size_t)o * K + k] != 0.f) cols[idx[(size_t)o * K + k]].push_back({o, w[(size_t)o * K + k]});
         std::vector<int> ptr(in_size + 1, 0), oo;
         std::vector<float> vv;
-        for (int i = 0; i < in_size; ++i) {                       // (output index ascending, tap ascending: fixed summation order)
-            for (int o = 0; o < out_size; ++o)
-                for (int k = 0; k < 4; ++k)
-                    if (idx[(size_t)o * 4 + k] == i && w[(size_t)o * 4 + k] != 0.f) { oo.push_back(o); vv.push_back(w[(size_t)o * 4 + k]); }
+        for (int i = 0; i < in_size; ++i) {
+            for (auto& pr : cols[i]) { oo.push_back(pr.first); vv.push_back(pr.second); }
             ptr[i + 1] = (int)oo.size();
         }
         d_i = upload(idx); d_w = upload(w); d_p = upload(ptr); d_o = upload(oo); d_v = upload(vv);
+        return K;
     }
     void on_finalize(Graph& g) override {
         if (!bicubic) return;
-        axis(g.tensors[in].H, g.tensors[out].H, d_iy, d_wy, d_py, d_oy, d_vy);
-        axis(g.tensors[in].W, g.tensors[out].W, d_ix, d_wx, d_px, d_ox, d_vx);
+        ky = axis(g.tensors[in].H, g.tensors[out].H, d_iy, d_wy, d_py, d_oy, d_vy);
+        kx = axis(g.tensors[in].W, g.tensors[out].W, d_ix, d_wx, d_px, d_ox, d_vx);
     }
     void forward(Graph& g, int B, bool) override {
-        if (bicubic) resize_table_forward(g.stream, g.view(in, B, false), g.view(out, B, false), d_iy, d_wy, d_ix, d_wx);
+        if (bicubic) resize_table_forward(g.stream, g.view(in, B, false), g.view(out, B, false), d_iy, d_wy, d_ix, d_wx, ky, kx);
         else if (nearest) resize_nearest_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
         else resize_bilinear_forward(g.stream, g.view(in, B, false), g.view(out, B, false));
     }
@@ -885,7 +945,8 @@ int g_resize(Graph& g, int in, int Ho, int Wo, int nearest) {
     const GTensor ti = g.tensors.at(in);
     const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
     ResizeOp* op = push<ResizeOp>(g);
-    op->in = in; op->out = out; op->nearest = nearest == 1; op->bicubic = nearest == 2;      // (0 bilinear, 1 nearest, 2 bicubic)
+    DL4DS_REQUIRE(nearest >= 0 && nearest <= 6, "resize: unknown method");
+    op->in = in; op->out = out; op->method = nearest; op->nearest = nearest == 1; op->bicubic = nearest >= 2;
     g.tensors[in].n_other++;
     return out;
 }

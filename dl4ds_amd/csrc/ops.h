@@ -166,8 +166,16 @@ void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, si
 void batch_prepare(hipStream_t s, const float* hr, const float* pred, const float* stat, const int* idx, const int* cy,
                    const int* cx, float* out_lr, float* out_hr, float* out_stat, int H, int W, int C, int P, int S, int T,
                    int B, int scale, int psy, int psx, int pin, int static_in_lr);
+// One axis of a separable cv2.resize: k (source index, weight) taps per output row / column, device arrays [n_out][k].
+struct TapAxis { const int* idx; const float* wt; int k; };
+// The same for any interpolation (see batchprep.hip): each table argument is {y axis, x axis}.
+void batch_prepare_taps(hipStream_t s, const float* hr, const float* pred, const float* stat, const int* idx, const int* cy,
+                        const int* cx, float* out_lr, float* out_hr, float* out_stat, float* scratch, int H, int W, int C,
+                        int P, int S, int T, int B, int scale, int psy, int psx, int pin, int static_in_lr,
+                        const TapAxis* dn_patch, const TapAxis* dn_field, const TapAxis* up_field);
 void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int T, size_t ps);
 void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, int T, size_t ps, int accumulate);
-void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx);
+void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx,
+                          int ky, int kx);   // [out][k] taps per axis
 void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
                            const int* px, const int* ox, const float* vx, int accumulate);

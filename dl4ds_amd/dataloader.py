@@ -96,7 +96,24 @@ def _axis_taps(n_src, n_dst, interpolation):
         w2 = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
         idx = np.clip(sx[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
         return idx, np.stack([w0, w1, w2, 1.0 - w0 - w1 - w2], 1)
-    raise NotImplementedError(f"interpolation '{interpolation}' (cv2.INTER_LANCZOS4) is not implemented")
+    if interpolation == 'lanczos':               # cv2.INTER_LANCZOS4 (interpolateLanczos4: one sin/cos pair, rotated by 45 degrees per tap)
+        c = (d + 0.5) * scale - 0.5
+        sx = np.floor(c).astype(int)
+        t = c - sx
+        s45 = 0.70710678118654752440084436210485
+        rot = np.array([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45], [0, -1], [-s45, s45]])
+        y0 = -(t + 3) * np.pi * 0.25
+        k = np.arange(8)
+        y = -(t[:, None] + 3 - k[None, :]) * np.pi * 0.25
+        with np.errstate(divide='ignore', invalid='ignore'):
+            w = (rot[None, :, 0] * np.sin(y0)[:, None] + rot[None, :, 1] * np.cos(y0)[:, None]) / (y * y)
+            w = w / w.sum(1, keepdims=True)
+        centre = np.zeros(8)
+        centre[3] = 1.0
+        w = np.where((t < np.finfo(np.float32).eps)[:, None], centre[None, :], w)
+        idx = np.clip(sx[:, None] + np.arange(-3, 5)[None, :], 0, n_src - 1)
+        return idx, w
+    raise ValueError(f"unknown interpolation '{interpolation}'")
 
 
 def _resize2d(a, size_y, size_x, interpolation):
@@ -344,8 +361,10 @@ class DeviceDataGenerator:
     """DataGenerator whose dataset lives in HBM and whose batches are gathered by `dl4ds_batch_prepare`
     (csrc/batchprep.hip) -- SURVEY section 8 "next" row f1.  Same constructor, same seeded permutation and the same
     per-sample RNG calls as DataGenerator, so `gen[i]` holds exactly the batch `DataGenerator(...)[i]` would build
-    (block means agree to fp32 rounding).  Supported: interpolation='inter_area', no external LR array, field sizes
-    divisible by `scale`; anything else raises (use DataGenerator).
+    (to fp32 rounding).  'inter_area' (the default) runs the block-mean / replication kernels; every other interpolation
+    of `resize_array` (nearest, bilinear, bicubic, lanczos -- and inter_area again with ``taps=True``) runs
+    `dl4ds_batch_prepare_taps` on per-axis tap tables built once from cv2's coefficients (`_axis_taps`).  Not supported:
+    an external LR array, field sizes not divisible by `scale` (use DataGenerator).
 
     `gen[i]` returns ([lr(, static_hr)], [hr]) as DeviceArray objects that stay valid until the next `gen[...]` call
     (two rotating output buffers, so the previous batch can still be in flight); `.numpy()` them for inspection.
@@ -353,12 +372,14 @@ class DeviceDataGenerator:
 
     def __init__(self, array, array_lr, backbone, upsampling, scale, batch_size=32, patch_size=None, time_window=None,
                  static_vars=None, predictors=None, interpolation='inter_area', repeat=None, seed=None, rank=0,
-                 world=1):
+                 world=1, taps=None):
         from .device import DeviceArray
         if array_lr is not None:
             raise NotImplementedError('DeviceDataGenerator: an external LR array is not supported (use DataGenerator)')
-        if interpolation != 'inter_area':
-            raise NotImplementedError("DeviceDataGenerator: only interpolation='inter_area' is implemented on the device")
+        if interpolation not in INTERPOLATION_METHODS:
+            raise ValueError(f'`interpolation` must be one of {INTERPOLATION_METHODS}. Received {interpolation}')
+        self.interpolation = interpolation
+        self.taps = (interpolation != 'inter_area') if taps is None else bool(taps)
         a = np.asarray(getattr(array, 'values', array), np.float32)
         if a.ndim == 3:
             a = a[..., None]
@@ -405,6 +426,41 @@ class DeviceDataGenerator:
             st = DeviceArray((B, self.psy, self.psx, self.S)) if self.S else None
             self._bufs.append((lr, hr, st))
         self._turn = 0
+        if self.taps:
+            self._build_tap_tables()
+
+    def _build_tap_tables(self):
+        """Per-axis (index, weight) tables of cv2.resize for the three resizes of create_pair_hr_lr, resident in HBM."""
+        import ctypes
+        from .device import DeviceArray
+
+        class TapAxis(ctypes.Structure):
+            _fields_ = [('idx', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('k', ctypes.c_int)]
+        self._tap_keep = []
+
+        def pair(src_yx, dst_yx):
+            arr = (TapAxis * 2)()
+            for i, (n_src, n_dst) in enumerate(zip(src_yx, dst_yx)):
+                if n_src == n_dst:
+                    idx, wt = np.arange(n_dst)[:, None], np.ones((n_dst, 1))
+                else:
+                    idx, wt = _axis_taps(n_src, n_dst, self.interpolation)
+                d_idx = DeviceArray.from_numpy(np.ascontiguousarray(idx, np.int32))
+                d_wt = DeviceArray.from_numpy(np.ascontiguousarray(wt, np.float32))
+                self._tap_keep += [d_idx, d_wt]
+                arr[i].idx, arr[i].wt, arr[i].k = d_idx.ptr, d_wt.ptr, idx.shape[1]
+            return arr
+        s = self.scale
+        hl, wl = self.H // s, self.W // s
+        self._dn_patch = self._dn_field = self._up_field = self._scratch = None
+        if self.pin:
+            self._dn_field = pair((self.H, self.W), (hl, wl))
+            self._up_field = pair((hl, wl), (self.H, self.W))
+            self._scratch = DeviceArray((self.batch_size, self.T, hl, wl, self.C + self.P))
+        else:
+            self._dn_patch = pair((self.psy, self.psx), (self.psy // s, self.psx // s))
+            if self.P:
+                self._dn_field = pair((self.H, self.W), (hl, wl))
 
     def __len__(self):
         return len(self.indices) // self.batch_size
@@ -441,6 +497,16 @@ class DeviceDataGenerator:
         lr, hr, st = self._bufs[self._turn]
         self._turn ^= 1
         ip = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data
+        if self.taps:
+            import ctypes
+            ap = lambda t: None if t is None else ctypes.addressof(t)
+            _lib.check(_lib.lib().dl4ds_batch_prepare_taps(
+                self._hr.ptr, None if self._pred is None else self._pred.ptr, None if self._stat is None else self._stat.ptr,
+                ip(idx), ip(cy), ip(cx), lr.ptr, hr.ptr, None if st is None else st.ptr,
+                None if self._scratch is None else self._scratch.ptr, self.H, self.W, self.C, self.P, self.S, self.T,
+                self.batch_size, self.scale, self.psy, self.psx, int(self.pin), int(self.static_in_lr), ap(self._dn_patch),
+                ap(self._dn_field), ap(self._up_field)))
+            return ([lr, st], [hr]) if st is not None else ([lr], [hr])
         _lib.check(_lib.lib().dl4ds_batch_prepare(
             self._hr.ptr, None if self._pred is None else self._pred.ptr, None if self._stat is None else self._stat.ptr,
             ip(idx), ip(cy), ip(cx), lr.ptr, hr.ptr, None if st is None else st.ptr, self.H, self.W, self.C, self.P, self.S,

@@ -178,14 +178,14 @@ class GraphBuilder:
         return self._out(out.value, 'maxpool2', name)
 
     def resize(self, x, ho, wo, name='resize', interpolation='bilinear'):
-        fns = {'bilinear': self._l.dl4ds_graph_resize, 'nearest': self._l.dl4ds_graph_resize_nearest,
-               'bicubic': self._l.dl4ds_graph_resize_bicubic}
-        if interpolation not in fns:
-            raise NotImplementedError(f"Resizing(interpolation={interpolation!r}): only 'bilinear', 'nearest' and 'bicubic' are "
-                                      "implemented ('area', 'lanczos3/5', 'gaussian', 'mitchellcubic' are not)")
+        methods = {'bilinear': 0, 'nearest': 1, 'bicubic': 2, 'lanczos3': 3, 'lanczos5': 4, 'gaussian': 5, 'mitchellcubic': 6}
+        if interpolation == 'area':
+            raise NotImplementedError("Resizing(interpolation='area'): TensorFlow's ResizeArea op has no gradient, the reference "
+                                      "cannot train a model built with it either")
+        if interpolation not in methods:
+            raise ValueError(f'unknown Resizing interpolation {interpolation!r}; one of {sorted(methods)}')
         out = ctypes.c_int()
-        fn = fns[interpolation]
-        _lib.check(fn(self.h, x.id, int(ho), int(wo), ctypes.byref(out)))
+        _lib.check(self._l.dl4ds_graph_resize_method(self.h, x.id, int(ho), int(wo), methods[interpolation], ctypes.byref(out)))
         return self._out(out.value, 'resize_' + interpolation, name)
 
     def localconv(self, x, name, filters=2, use_bias=True):

@@ -84,10 +84,10 @@ class CGANTrainer(Trainer):
             self.steps_per_epoch = n_samples // self.batch_size
         rng = np.random.default_rng(17)
         preds = None if self.predictors_train is None else np.concatenate(self.predictors_train, axis=-1)
-        # dataset in HBM, batches gathered by csrc/batchprep.hip for the default 'inter_area' pipeline (same crops as
-        # the numpy loop: it draws them from the same generator); otherwise the host loop below
+        # dataset in HBM, batches gathered by csrc/batchprep.hip (same crops as the numpy loop: it draws them from the
+        # same generator); the host loop below remains for external LR arrays
         dev = None
-        if self.data_train_lr is None and self.interpolation == 'inter_area' and self.static_vars is not None:
+        if self.data_train_lr is None and self.static_vars is not None:
             try:
                 dev = DeviceDataGenerator(self.data_train, None, self.backbone, self.upsampling, self.scale,
                                           batch_size=self.batch_size, patch_size=self.patch_size,

@@ -50,9 +50,9 @@ class SupervisedTrainer(Trainer):
                   batch_size=self.global_batch_size, static_vars=self.static_vars, patch_size=self.patch_size,
                   interpolation=self.interpolation, time_window=self.time_window, rank=self.rank, world=self.world)
         def make(data, data_lr, predictors, seed):
-            # datasets live in HBM and batches are gathered on the device (csrc/batchprep.hip) whenever the request is
-            # the default 'inter_area' pipeline; the numpy loop remains for external LR arrays / other interpolations
-            if getattr(self, 'device_data', True) and data_lr is None and self.interpolation == 'inter_area':
+            # datasets live in HBM and batches are gathered on the device (csrc/batchprep.hip: block means for the default
+            # 'inter_area', cv2 tap tables for the other interpolations); the numpy loop remains for external LR arrays
+            if getattr(self, 'device_data', True) and data_lr is None:
                 try:
                     return DeviceDataGenerator(data, None, predictors=predictors, seed=seed, **kw)
                 except (NotImplementedError, ValueError):

@@ -157,6 +157,11 @@ int dl4ds_graph_resize_nearest(dl4ds_graph* g, int in, int Ho, int Wo, int* out)
 /* Resizing(interpolation='bicubic') = tf.image.resize(method='bicubic'): ResizeBicubic with half-pixel centres (Keys cubic,
  * A = -0.5, 1024-step weight table, out-of-image taps dropped and the rest renormalised) -- blocks.py:473-489 */
 int dl4ds_graph_resize_bicubic(dl4ds_graph* g, int in, int Ho, int Wo, int* out);
+/* Resizing(interpolation=...) by number: 0 bilinear, 1 nearest, 2 bicubic, and tf.image.resize's ScaleAndTranslate family
+ * (antialias=False: scale = out / in, kernel scale 1, spans clamped into the image and normalised): 3 lanczos3, 4 lanczos5,
+ * 5 gaussian (radius 1.5, sigma 0.5), 6 mitchellcubic -- blocks.py:473-489.  ('area' has no gradient in TensorFlow, so a
+ * ResizeConvolutionBlock built with it cannot be trained by the reference either; it is rejected.) */
+int dl4ds_graph_resize_method(dl4ds_graph* g, int in, int Ho, int Wo, int method, int* out);
 int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out);
 int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out);
 int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out);
@@ -273,6 +278,22 @@ int dl4ds_batch_prepare(const float* hr_dev, const float* pred_dev, const float*
                         const int* cy_host, const int* cx_host, float* out_lr_dev, float* out_hr_dev,
                         float* out_static_dev, int H, int W, int C, int P, int S, int T, int B, int scale, int psy,
                         int psx, int pin, int static_in_lr);
+
+/* The same for every interpolation of resize_array (utils.py:369-381: cv2 INTER_NEAREST / INTER_CUBIC / INTER_LINEAR /
+ * INTER_AREA / INTER_LANCZOS4).  cv2.resize is separable; one axis of it is a device table of k (source index, weight)
+ * taps per output row / column, [n_out][k], built once by the caller from cv2's coefficients.  Each table argument points
+ * at two axes {y, x}:
+ *   dn_patch : resize of a psy x psx PATCH to (psy/scale) x (psx/scale), indices relative to the patch  (post-upsampling:
+ *              the HR crop and the cropped static variables, dataloader.py:141-205,261-289)
+ *   dn_field : resize of the whole H x W field to (H/scale) x (W/scale)  (predictors, dataloader.py:150-160; 'pin')
+ *   up_field : resize of the (H/scale) x (W/scale) field back to H x W   ('pin', dataloader.py:94-112)
+ * scratch_dev: 'pin' only, [B][T][H/scale][W/scale][C+P] floats.  Unused tables may be NULL. */
+typedef struct dl4ds_tap_axis { const int* idx; const float* wt; int k; } dl4ds_tap_axis;
+int dl4ds_batch_prepare_taps(const float* hr_dev, const float* pred_dev, const float* static_dev, const int* idx_host,
+                             const int* cy_host, const int* cx_host, float* out_lr_dev, float* out_hr_dev,
+                             float* out_static_dev, float* scratch_dev, int H, int W, int C, int P, int S, int T, int B,
+                             int scale, int psy, int psx, int pin, int static_in_lr, const dl4ds_tap_axis* dn_patch,
+                             const dl4ds_tap_axis* dn_field, const dl4ds_tap_axis* up_field);
 
 /* ---------------------------------------------------------------- data parallelism (RCCL over xGMI)
  * replaces Horovod: hvd.init/rank/size (base.py:97-107), DistributedOptimizer / DistributedGradientTape

@@ -15,7 +15,9 @@ scale_x = src_w / dst_w (the same along y), for floating-point images:
 * INTER_LINEAR: fx = (dx + 0.5) * scale_x - 0.5; sx = floor(fx); fx -= sx; sx < 0 -> (0, 0); sx >= src_w - 1 -> (src_w - 1, 0).
 * INTER_CUBIC: same centre, taps sx - 1 .. sx + 2 (indices clamped = BORDER_REPLICATE), Keys weights with A = -0.75:
   w0 = ((A (t+1) - 5A)(t+1) + 8A)(t+1) - 4A, w1 = ((A+2) t - (A+3)) t^2 + 1, w2 = ((A+2)(1-t) - (A+3))(1-t)^2 + 1, w3 = 1 - w0 - w1 - w2.
-* INTER_LANCZOS4 is not restated (raises).
+* INTER_LANCZOS4: same centre, taps sx - 3 .. sx + 4 (indices clamped), the a = 4 Lanczos window
+  L(t) = sinc(t) sinc(t / 4) evaluated at t = (f + 3 - k), k = 0..7, and normalised to sum 1 (OpenCV's interpolateLanczos4 obtains the
+  same eight values from one sin/cos pair and a table of 45-degree rotations; f < FLT_EPSILON -> the centre tap alone).
 
 Parity status: "unpinned" -- nothing here was compared with cv2 output (none is available); the known-answer tests in
 tests/test_oracle_dataprep.py pin the formulas to hand-computed values.
@@ -94,6 +96,25 @@ def _axis_cubic(n_src, n_dst):
     return W
 
 
+def _axis_lanczos4(n_src, n_dst):
+    scale = n_src / n_dst
+    W = np.zeros((n_dst, n_src))
+    for d in range(n_dst):
+        f = (d + 0.5) * scale - 0.5
+        sx = int(np.floor(f))
+        f -= sx
+        if f < np.finfo(np.float32).eps:
+            w = [0.0] * 8
+            w[3] = 1.0
+        else:
+            w = [float(np.sinc(f + 3 - k) * np.sinc((f + 3 - k) / 4.0)) for k in range(8)]
+            tot = sum(w)
+            w = [v / tot for v in w]
+        for k in range(8):
+            W[d, min(max(sx - 3 + k, 0), n_src - 1)] += w[k]
+    return W
+
+
 def cv2_resize(img, size_xy, interpolation):
     """cv2.resize(img, (size_x, size_y), interpolation=...) for a float [y, x(, c)] image."""
     a = np.asarray(img, np.float64)
@@ -114,6 +135,8 @@ def cv2_resize(img, size_xy, interpolation):
             return _axis_linear(n_src, n_dst)
         if interpolation == 'bicubic':
             return _axis_cubic(n_src, n_dst)
+        if interpolation == 'lanczos':
+            return _axis_lanczos4(n_src, n_dst)
         raise NotImplementedError(f'cv2 interpolation {interpolation!r} is not restated')
     if interpolation == 'inter_area' and ((size_y < h) != (size_x < w)) and size_y != h and size_x != w:
         raise NotImplementedError('INTER_AREA with one axis shrinking and the other growing is not restated')

@@ -287,7 +287,10 @@ def subpixel_block(ops, P, name, x, scale, n_filters):
 def resize_conv_block(ops, P, name, x, scale, n_filters, interpolation='bilinear'):
     """ResizeConvolutionBlock.call -- blocks.py:485-491 (Resizing with 'bilinear' or 'nearest')."""
     h, w = x.shape[1], x.shape[2]
-    rs = {'bilinear': ops.resize_bilinear, 'nearest': ops.resize_nearest, 'bicubic': ops.resize_bicubic}[interpolation]
+    if interpolation in ('lanczos3', 'lanczos5', 'gaussian', 'mitchellcubic'):
+        rs = lambda t, ho, wo: ops.resize_scale_translate(t, ho, wo, interpolation)
+    else:
+        rs = {'bilinear': ops.resize_bilinear, 'nearest': ops.resize_nearest, 'bicubic': ops.resize_bicubic}[interpolation]
     y = rs(x, int(h * scale), int(w * scale))
     return _conv(ops, P, name + '/conv', y, n_filters, 3)
 

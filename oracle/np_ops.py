@@ -169,6 +169,62 @@ def resize_bicubic(x, ho, wo):
     return np.einsum('oh,nhwc,pw->nopc', My, x, Mx)
 
 
+def scale_translate_axis_matrix(inn, out, method):
+    """Dense (out, inn) matrix of tf.image.resize(method in {'lanczos3', 'lanczos5', 'gaussian', 'mitchellcubic'},
+    antialias=False) along one axis: the ScaleAndTranslate op with scale = out / in, translation 0 and kernel scale 1
+    (TensorFlow core/kernels/image/scale_and_translate_op.cc ComputeSpans + sampling_kernels.h; TF is absent from this image,
+    the op's published algorithm is restated, float32 like the op): sample = (o + 0.5) / scale; source pixels
+    ceil(sample - R - 0.5) .. floor(sample + R - 0.5), clamped into the image; weight kernel(|i + 0.5 - sample|), the span
+    normalised to sum 1.  Kernels: Lanczos (R = 3 / 5): 0 beyond R, 1 within 1e-3, else R sin(pi x) sin(pi x / R) / (pi x)^2;
+    Gaussian: R = 1.5, sigma = R / 3; Mitchell-Netravali cubic (B = C = 1/3), R = 2."""
+    f32 = np.float32
+    R = {'lanczos3': 3.0, 'lanczos5': 5.0, 'gaussian': 1.5, 'mitchellcubic': 2.0}[method]
+
+    def kernel(x):
+        x = f32(abs(x))
+        if method.startswith('lanczos'):
+            pi = f32(3.14159265359)
+            if x > R:
+                return f32(0)
+            if x <= f32(1e-3):
+                return f32(1)
+            return f32(f32(R) * np.sin(pi * x) * np.sin(pi * x / f32(R)) / (pi * pi * x * x))
+        if method == 'gaussian':
+            sigma = f32(R) / f32(3)
+            return f32(0) if x >= R else f32(np.exp(-x * x / (f32(2) * sigma * sigma)))
+        if x >= 2:
+            return f32(0)
+        if x >= 1:
+            return f32(((f32(-7 / 18) * x + f32(2)) * x - f32(10 / 3)) * x + f32(16 / 9))
+        return f32(((f32(7 / 6) * x - f32(2)) * x) * x + f32(8 / 9))
+    inv_scale = f32(1) / (f32(out) / f32(inn))
+    M = np.zeros((out, inn), np.float64)
+    for o in range(out):
+        sample = (f32(o) + f32(0.5)) * inv_scale
+        if sample < 0 or sample > inn:
+            continue
+        s0 = int(np.ceil(sample - f32(R) - f32(0.5)))
+        s1 = int(np.floor(sample + f32(R) - f32(0.5)))
+        s0 = min(max(s0, 0), inn - 1)
+        s1 = min(max(s1, 0), inn - 1) + 1
+        ws = [kernel(f32(i) + f32(0.5) - sample) for i in range(s0, s1)]
+        tot = f32(0)
+        for w in ws:
+            tot = f32(tot + w)
+        if abs(tot) >= 1000 * np.finfo(np.float32).tiny:
+            ws = [f32(w * (f32(1) / tot)) for w in ws]
+        for i, w in zip(range(s0, s1), ws):
+            M[o, i] += float(w)
+    return M
+
+
+def resize_scale_translate(x, ho, wo, method):
+    """tf.keras.layers.Resizing(..., interpolation=method) for the ScaleAndTranslate family (blocks.py:473-489)."""
+    My = scale_translate_axis_matrix(x.shape[1], ho, method)
+    Mx = scale_translate_axis_matrix(x.shape[2], wo, method)
+    return np.einsum('oh,nhwc,pw->nopc', My, x, Mx)
+
+
 def max_pool2(x):
     """MaxPooling2D((2,2)) VALID stride 2.  dl4ds/models/blocks.py:613."""
     n, h, w, c = x.shape

@@ -100,6 +100,14 @@ def resize_bicubic(x, ho, wo):
     return torch.einsum('oh,nhwc,pw->nopc', My, x, Mx)
 
 
+def resize_scale_translate(x, ho, wo, method):
+    """ScaleAndTranslate family ('lanczos3', 'lanczos5', 'gaussian', 'mitchellcubic'): np_ops.scale_translate_axis_matrix."""
+    from . import np_ops
+    My = torch.as_tensor(np_ops.scale_translate_axis_matrix(x.shape[1], ho, method), dtype=x.dtype)
+    Mx = torch.as_tensor(np_ops.scale_translate_axis_matrix(x.shape[2], wo, method), dtype=x.dtype)
+    return torch.einsum('oh,nhwc,pw->nopc', My, x, Mx)
+
+
 def resize_bilinear(x, ho, wo):
     n, h, w, c = x.shape
 

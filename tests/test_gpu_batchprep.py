@@ -114,3 +114,44 @@ def test_device_batches_equal_the_oracle(ups, scale, H, W, C, P, S, patch, tw, B
         saw_unaligned |= any(c is not None and (c[0] % scale or c[1] % scale) for c in crops)
     if patch is not None and (ups == 'pin' or P == 0):
         assert saw_unaligned        # these paths crop at arbitrary pixels: the case the block alignment matters for
+
+
+TAP_CASES = [
+    # upsampling, scale, H, W, C, n_pred, n_static, patch, time_window, batch
+    ('spc', 4, 32, 32, 1, 0, 0, None, None, 4),
+    ('spc', 2, 48, 64, 2, 0, 2, 16, None, 3),          # scale 2: the cubic / Lanczos taps reach over the PATCH border (clamped there)
+    ('rc', 2, 40, 40, 1, 2, 1, 20, None, 5),           # predictors: whole field resized, cropped on the LR grid (clamped at the FIELD border)
+    ('pin', 4, 32, 48, 1, 2, 1, 20, None, 4),          # whole field down and up again, then cropped anywhere
+    ('pin', 2, 24, 24, 3, 0, 0, None, None, 2),
+    ('spc', 4, 32, 32, 1, 1, 1, None, 3, 2),
+    ('pin', 2, 20, 20, 2, 0, 1, 12, 4, 3),
+]
+
+
+@pytest.mark.parametrize('interpolation', ['nearest', 'bilinear', 'bicubic', 'lanczos', 'inter_area'])
+@pytest.mark.parametrize('ups,scale,H,W,C,P,S,patch,tw,B', TAP_CASES)
+def test_device_batches_any_interpolation_equal_the_oracle(ups, scale, H, W, C, P, S, patch, tw, B, interpolation):
+    """dl4ds_batch_prepare_taps (per-axis cv2 tap tables, csrc/batchprep.hip) against oracle/dataprep.py's per-pixel
+    restatement of cv2.resize for every interpolation `resize_array` offers (utils.py:369-381)."""
+    from dl4ds_amd.dataloader import DeviceDataGenerator
+    from oracle import dataprep as O
+    n = 9
+    hr = _fields(n, H, W, C, 1)
+    preds = None if P == 0 else _fields(n, H, W, P, 2)
+    stat = None if S == 0 else [np.random.default_rng(3 + i).standard_normal((H, W)).astype(np.float32) for i in range(S)]
+    dev = DeviceDataGenerator(hr, None, backbone='resnet', upsampling=ups, scale=scale, batch_size=B, patch_size=patch,
+                              time_window=tw, static_vars=stat, predictors=None if preds is None else [preds],
+                              interpolation=interpolation, seed=11, taps=True)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(n - (tw or 0))
+    for i in range(len(dev)):
+        xo, yo, _ = O.create_batch_hr_lr(perm, i, hr, None, ups, scale=scale, batch_size=B, patch_size=patch,
+                                         time_window=tw, static_vars=stat, predictors=preds,
+                                         interpolation=interpolation, randint=lambda lo, hi: rng.integers(lo, hi))
+        xd, yd = dev[i]
+        lr_d = xd[0].numpy()
+        assert lr_d.shape == xo[0].shape
+        np.testing.assert_allclose(lr_d, xo[0], rtol=0, atol=1e-5 * max(np.abs(xo[0]).max(), 1.0))
+        np.testing.assert_array_equal(yd[0].numpy(), yo[0])
+        if len(xo) == 2:
+            np.testing.assert_array_equal(xd[1].numpy(), xo[1])

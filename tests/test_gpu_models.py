@@ -82,6 +82,9 @@ SUP_CASES = [
     # Resizing(interpolation='bicubic')
     ('net_postupsampling', dict(backbone_block='resnet', upsampling='rc', scale=2, n_blocks=1, n_filters=4,
                                 rc_interpolation='bicubic'), (2, 9, 7, 2), (2, 18, 14, 1)),
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='rc', scale=4, n_blocks=1, n_filters=4,
+                                rc_interpolation='lanczos3'), (2, 6, 5, 2), (2, 24, 20, 1)),
+    ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='rc', rc_interpolation='mitchellcubic'), (1, 16, 20, 2), None),
     # odd grids: MaxPooling2D drops a row / column, PadConcat zero-pads the decoder side back (blocks.py:629-656)
     ('unet_pin', dict(n_filters=4, n_blocks=2, decoder_upsampling='rc'), (2, 25, 30, 2), None),
     ('unet_pin', dict(n_filters=4, n_blocks=3, decoder_upsampling='spc'), (1, 37, 23, 1), (1, 37, 23, 1)),

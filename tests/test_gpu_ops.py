@@ -572,8 +572,10 @@ def test_resize_nearest_in_graph(shape, out):
 
 @pytest.mark.parametrize('shape,out', [((2, 5, 7, 3), (10, 14)), ((1, 8, 6, 4), (32, 24)), ((2, 9, 9, 1), (27, 27)), ((1, 12, 10, 2), (5, 4)),
                                        ((1, 6, 5, 2), (15, 8))])
-def test_resize_bicubic_in_graph(shape, out):
-    """Resizing(interpolation='bicubic') (tf.image.resize bicubic: Keys A = -0.5 from a 1024-step table, out-of-image taps
+@pytest.mark.parametrize('method', ['bicubic', 'lanczos3', 'lanczos5', 'gaussian', 'mitchellcubic'])
+def test_resize_bicubic_in_graph(shape, out, method):
+    """Resizing(interpolation='lanczos3' | 'lanczos5' | 'gaussian' | 'mitchellcubic') (tf.image.resize's ScaleAndTranslate
+    family: spans clamped into the image, normalised) and Resizing(interpolation='bicubic') (tf.image.resize bicubic: Keys A = -0.5 from a 1024-step table, out-of-image taps
     dropped and renormalised): forward, and the gradient THROUGH the resize (the table-driven transpose kernel) via the
     kernel of a 1x1 convolution in front of it -- integer and fractional ratios, down-sampling included."""
     import dl4ds_amd.graph as G
@@ -582,7 +584,7 @@ def test_resize_bicubic_in_graph(shape, out):
     g = G.GraphBuilder()
     x_in = g.input(h, w, c)
     z = g.conv2d(x_in, 'pre', c, 1, use_bias=False)
-    y = g.conv2d(g.resize(z, out[0], out[1], interpolation='bicubic'), 'post', c, 1, use_bias=False)
+    y = g.conv2d(g.resize(z, out[0], out[1], interpolation=method), 'post', c, 1, use_bias=False)
     g.finalize(y, seed=0)
     m = G.Model(g, 'resize', [(h, w, c)])
     k1, k2 = (R(1, 1, c, c) * 0.5 + np.eye(c, dtype=np.float32)), (R(1, 1, c, c) * 0.5 + np.eye(c, dtype=np.float32))
@@ -591,7 +593,7 @@ def test_resize_bicubic_in_graph(shape, out):
     xt = torch.tensor(x, dtype=torch.float64)
     t1 = torch.tensor(k1.reshape(c, c), dtype=torch.float64, requires_grad=True)
     t2 = torch.tensor(k2.reshape(c, c), dtype=torch.float64, requires_grad=True)
-    ref = T.resize_bicubic(xt @ t1, *out) @ t2
+    ref = (T.resize_bicubic(xt @ t1, *out) if method == 'bicubic' else T.resize_scale_translate(xt @ t1, *out, method)) @ t2
     close(m([x]), ref.detach().numpy(), 1e-5)
     yt = R(n, out[0], out[1], c)
     ((ref - torch.tensor(yt, dtype=torch.float64)) ** 2).mean().backward()

@@ -41,11 +41,36 @@ def test_nearest_bilinear_bicubic_known_answers():
     np.testing.assert_allclose(O.cv2_resize(x, (12, 1), 'bicubic')[0, 5], np.dot(w, x[0, 1:5]))     # dx = 5: centre 2.25
     # left border: taps sx - 1 = -1 is clamped to pixel 0 (BORDER_REPLICATE): dx = 1, centre 0.25
     np.testing.assert_allclose(O.cv2_resize(x, (12, 1), 'bicubic')[0, 1], np.dot(w, x[0, [0, 0, 1, 2]]))
-    with pytest.raises(NotImplementedError):
-        O.cv2_resize(x, (12, 1), 'lanczos')
 
 
-@pytest.mark.parametrize('interp', ['inter_area', 'nearest', 'bilinear', 'bicubic'])
+def test_lanczos4_known_answers():
+    """INTER_LANCZOS4: eight taps sx-3..sx+4 of L(t) = sinc(t) sinc(t/4), normalised; centre tap alone when the fraction is 0."""
+    x = np.array([[3.0, -1.0, 4.0, 1.0, -5.0, 9.0, 2.0, 6.0, -3.0, 5.0]])
+    np.testing.assert_allclose(O.cv2_resize(np.full((1, 8), 2.5), (16, 1), 'lanczos'), np.full((1, 16), 2.5), atol=1e-14)
+    # x2 up-scaling, dx = 9: centre 4.25 -> sx = 4, t = 0.25; weights by hand from the closed form
+    t = 0.25
+    arg = np.array([t + 3 - k for k in range(8)])
+    w = np.sin(np.pi * arg) * np.sin(np.pi * arg / 4) / (np.pi ** 2 * arg ** 2 / 4)
+    w /= w.sum()
+    assert abs(w.sum() - 1) < 1e-15 and w[3] == w.max() and w[3] > 0.87 and w[2] < 0 and w[5] < 0
+    np.testing.assert_allclose(O.cv2_resize(x, (20, 1), 'lanczos')[0, 9], np.dot(w, x[0, 1:9]), rtol=1e-13)
+    # OpenCV's form: sin(y0 + 5 pi k / 4) / y_k^2 with y_k = -(t + 3 - k) pi / 4 -- the same eight values after normalisation
+    yk = -(t + 3 - np.arange(8)) * np.pi / 4
+    w_cv = np.sin(yk[0] + 5 * np.pi * np.arange(8) / 4) / yk ** 2
+    np.testing.assert_allclose(w_cv / w_cv.sum(), w, rtol=1e-12)
+    # borders: tap indices are clamped (dx = 1: centre 0.25, taps -3..4 -> 0,0,0,0,1,2,3,4)
+    np.testing.assert_allclose(O.cv2_resize(x, (20, 1), 'lanczos')[0, 1], np.dot(w, x[0, [0, 0, 0, 0, 1, 2, 3, 4]]), rtol=1e-13)
+    # an integer down-scaling by 2 samples at fraction 0.5: symmetric weights
+    arg = np.array([0.5 + 3 - k for k in range(8)])
+    w2 = np.sinc(arg) * np.sinc(arg / 4)
+    w2 /= w2.sum()
+    np.testing.assert_allclose(w2, w2[::-1], rtol=1e-13)
+    np.testing.assert_allclose(O.cv2_resize(x, (5, 1), 'lanczos')[0, 2], np.dot(w2, x[0, 1:9]), rtol=1e-13)   # centre 4.5
+    # same size: identity
+    np.testing.assert_array_equal(O.cv2_resize(x, (10, 1), 'lanczos'), x)
+
+
+@pytest.mark.parametrize('interp', ['inter_area', 'nearest', 'bilinear', 'bicubic', 'lanczos'])
 @pytest.mark.parametrize('shape,new', [((12, 8, 3), (4, 6)), ((6, 9, 1), (27, 12)), ((10, 10, 2), (10, 5)), ((4, 6), (18, 8))])
 def test_product_resize_equals_oracle(interp, shape, new):
     a = np.random.default_rng(1).standard_normal(shape)
@@ -72,6 +97,10 @@ CASES = [
     ('pin', 2, 16, 16, 1, 0, 0, 8, None, True, 'nearest'),
     ('spc', 4, 32, 32, 1, 1, 1, None, 3, False, 'inter_area'),
     ('pin', 2, 20, 20, 2, 0, 1, 12, 4, False, 'inter_area'),
+    ('pin', 4, 32, 48, 1, 2, 1, 20, None, False, 'lanczos'),
+    ('rc', 2, 40, 40, 1, 2, 1, 20, None, False, 'lanczos'),            # patch border vs field border clamping differ
+    ('spc', 2, 48, 64, 2, 0, 2, 16, None, False, 'bicubic'),
+    ('rc', 2, 40, 40, 1, 2, 1, 20, None, False, 'bilinear'),
 ]
 
 

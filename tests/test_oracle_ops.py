@@ -220,3 +220,46 @@ def test_resize_bicubic_known_properties():
     rng = np.random.default_rng(0)
     x = rng.standard_normal((2, 6, 5, 3))
     np.testing.assert_allclose(T.resize_bicubic(torch.tensor(x), 15, 8).numpy(), N.resize_bicubic(x, 15, 8), atol=1e-12)
+
+
+def test_resize_scale_translate_known_properties():
+    """tf.image.resize(method = lanczos3 / lanczos5 / gaussian / mitchellcubic, antialias=False) restated
+    (oracle/np_ops.py::scale_translate_axis_matrix): identity at equal sizes, rows sum to 1, spans no wider than 2R + 1 and
+    clamped into the image, hand-computed kernel values, mirror symmetry, numpy and torch versions agree."""
+    import torch
+    from oracle import np_ops as N, torch_ops as T
+    radius = {'lanczos3': 3.0, 'lanczos5': 5.0, 'gaussian': 1.5, 'mitchellcubic': 2.0}
+    for m, R in radius.items():
+        # equal sizes: sample = o + 0.5, the centre tap has |x| = 0; the Lanczos / Mitchell / Gaussian neighbours at |x| = 1, 2, ..
+        M = N.scale_translate_axis_matrix(7, 7, m)
+        if m.startswith('lanczos'):
+            np.testing.assert_allclose(M, np.eye(7), atol=2e-7)     # sin(pi k) = 0 at the integer offsets (to float32 of pi)
+        for inn, out in ((5, 10), (8, 32), (9, 27), (12, 5), (6, 15)):
+            M = N.scale_translate_axis_matrix(inn, out, m)
+            np.testing.assert_allclose(M.sum(axis=1), 1.0, atol=1e-6)
+            assert (M != 0).sum(axis=1).max() <= 2 * R + 1
+            np.testing.assert_allclose(M, M[::-1, ::-1], atol=1e-6)                      # the sampling grid is symmetric
+    # x2 up-sampling, output 7: sample = 3.75; mitchellcubic taps 2..5 at |x| = 1.25, 0.25, 0.75, 1.75
+    def mitchell(x):
+        return ((-7 / 18 * x + 2) * x - 10 / 3) * x + 16 / 9 if x >= 1 else ((7 / 6 * x - 2) * x) * x + 8 / 9
+    w = np.array([mitchell(1.25), mitchell(0.25), mitchell(0.75), mitchell(1.75)])
+    np.testing.assert_allclose(w.sum(), 1.0, atol=1e-12)            # the Mitchell-Netravali filter is a partition of unity
+    np.testing.assert_allclose(N.scale_translate_axis_matrix(8, 16, 'mitchellcubic')[7, 2:6], w, atol=1e-6)
+    # gaussian: sigma = 0.5, radius 1.5 -> taps with |x| < 1.5: 2, 3, 4 at |x| = 1.25, 0.25, 0.75
+    g = np.exp(-np.array([1.25, 0.25, 0.75]) ** 2 / (2 * 0.25))
+    np.testing.assert_allclose(N.scale_translate_axis_matrix(8, 16, 'gaussian')[7, 2:5], g / g.sum(), atol=1e-6)
+    # lanczos3: taps 1..6 (|x| = 2.25, 1.25, 0.25, 0.75, 1.75, 2.75), closed form, normalised
+    xs = np.array([2.25, 1.25, 0.25, 0.75, 1.75, 2.75])
+    l3 = np.sinc(xs) * np.sinc(xs / 3)
+    np.testing.assert_allclose(N.scale_translate_axis_matrix(8, 16, 'lanczos3')[7, 1:7], l3 / l3.sum(), atol=1e-6)
+    # the first output (sample 0.25): the span ceil(0.25 - 3.5) .. floor(0.25 + 2.5) = -3 .. 2 is CLAMPED to 0 .. 2 (not replicated)
+    xs = np.array([0.25, 1.25, 2.25])
+    l3 = np.sinc(xs) * np.sinc(xs / 3)
+    M = N.scale_translate_axis_matrix(8, 16, 'lanczos3')
+    np.testing.assert_allclose(M[0, :3], l3 / l3.sum(), atol=1e-6)
+    assert not M[0, 3:].any()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 6, 5, 3))
+    for m in radius:
+        np.testing.assert_allclose(T.resize_scale_translate(torch.tensor(x), 15, 8, m).numpy(),
+                                   N.resize_scale_translate(x, 15, 8, m), atol=1e-12)
