@@ -691,6 +691,13 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
 // general kernel issues (one 16-cin tile per tap, half of it padding).  All LDS reads use immediate offsets from
 // two per-lane bases; the dz fragment of a quad is read once and reused by the five MFMAs; the bias gradient is the
 // running sum of those dz fragments.  Persistent blocks, one partial slab per block, fixed reduction order.
+// Cout <= 8 (PZ == 8) leaves half of the MFMA's 16 ROWS empty as well; they take the dz of the pixel ONE ROW BELOW:
+//   D[(s, co)][(j, ci)] += dz[p + s * (1,0)][co] * x[p + o_j][ci]   ==   dW[o_j - s * (1,0)][ci][co],
+// four taps per MFMA.  Column pairs o = (1,0)|(1,1), (2,1)|(2,2), (2,0)|(1,2) give, with s = 0 / 1, the taps
+// {(1,0),(1,1),(0,0),(0,1)}, {(2,1),(2,2),(1,1)*,(1,2)}, {(2,0),(1,2)*,(1,0)*,(0,2)} (* = duplicate, discarded): all nine taps
+// in THREE MFMAs per pixel quad, all three with the same dz fragment.  The shifted half sees every image row but the
+// first (tile row 32 = the next tile's first row is staged as well); tiles on the top edge take one extra row step
+// (r = -1) with the unshifted half zeroed.
 struct NarrowWgradParams {
     TView x, dz;
     float* partial;
@@ -703,12 +710,18 @@ template <int PZ, bool XVEC>     // PZ: dz channels per pixel in LDS: 8 (Cout <=
 __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowWgradParams a) {
     constexpr int TWH = NTW + 2, THH = NTH + 2, HPIX = TWH * THH;
     constexpr int XQ = HPIX * 2;                        // float4s in the x halo tile (8 channels per pixel)
-    constexpr int ZQ4 = PZ / 4, ZQ = NTW * NTH * ZQ4;   // float4s in the dz tile
+#ifdef NARROW_WGRAD_NO_P3                               // (variant builds: the five-MFMA form for A/B runs)
+    constexpr bool P3 = false;
+#else
+    constexpr bool P3 = (PZ == 8);                      // three-MFMA form: dz rows of two vertically adjacent pixels per MFMA
+#endif
+    constexpr int ZROWS = P3 ? NTH + 1 : NTH;           // (the shifted half needs the row below the tile)
+    constexpr int ZQ4 = PZ / 4, ZQ = NTW * ZROWS * ZQ4; // float4s in the dz tile
     constexpr int XIT = (XQ + 255) / 256, ZIT = (ZQ + 255) / 256;
     constexpr int XF = HPIX * 8 + 32;                   // + slack: the unused half of the lone tap reads one pixel on
-    constexpr int NG = 5, NV = NG * 4 + 1;              // accumulator groups; values per lane in the final reduction
-    __shared__ __attribute__((aligned(16))) float smem[XF + NTW * NTH * PZ];
-    static_assert(XF + NTW * NTH * PZ >= NV * 256, "reduction buffer does not fit");
+    constexpr int NG = P3 ? 3 : 5, NV = NG * 4 + 1;     // accumulator groups; values per lane in the final reduction
+    __shared__ __attribute__((aligned(16))) float smem[XF + NTW * ZROWS * PZ];
+    static_assert(XF + NTW * ZROWS * PZ >= NV * 256, "reduction buffer does not fit");
     float* xt = smem;
     float* zt = smem + XF;
 
@@ -721,10 +734,12 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    const bool zlane = (PZ == 16) || l15 < 8;           // PZ == 8: lanes 8..15 would read the next pixel's channels
-    const float* zrd = zt + ((wave * NROWS) * NTW + lq) * PZ + (zlane ? l15 : 0);
+    const bool zlane = (PZ == 16) || l15 < 8;           // PZ == 8: lanes 8..15 hold the pixel one row below
+    const float* zrd = P3 ? zt + ((wave * NROWS + (l15 >> 3)) * NTW + lq) * PZ + (l15 & 7)
+                          : zt + ((wave * NROWS) * NTW + lq) * PZ + (zlane ? l15 : 0);
     const float* xa = xt + ((wave * NROWS) * TWH + lq) * 8 + l15;                        // halves one pixel apart
-    const float* xb = xt + ((wave * NROWS) * TWH + lq) * 8 + (l15 & 7) + (l15 >> 3) * TWH * 8;   // one row apart
+    // second half one row apart (five-MFMA form: taps (0,2)|(1,2)) / one row up and two pixels on (three-MFMA form: (2,0)|(1,2))
+    const float* xb = xt + ((wave * NROWS) * TWH + lq) * 8 + (l15 & 7) + (l15 >> 3) * (P3 ? (2 - TWH) * 8 : TWH * 8);
 
     // float4-loadable x: ONE buffer load per element and nothing else per element.  The generic staging code spent ~35 VALU
     // instructions per element on index arithmetic -- ~300 per tile and thread next to 160 MFMAs per wave, on the same issue
@@ -755,7 +770,7 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
             zoff[u] = live ? (int)((((size_t)ry * a.W + rx) * a.dz.ld + c4 * 4) * 4) : OOB;
         }
         xsig = (THH << 8) | TWH;                        // rows [0, THH) x columns [0, TWH) of the halo inside the image
-        zsig = (NTH << 8) | NTW;
+        zsig = (ZROWS << 8) | NTW;
     }
 
     for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
@@ -775,7 +790,7 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
                     xoff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? (int)((((size_t)hy * a.W + hx) * a.x.ld + c4 * 4) * 4) : OOB;
                 }
             }
-            const int ymax = min(NTH, a.H - y0), xmax = min(NTW, a.W - x0);
+            const int ymax = min(ZROWS, a.H - y0), xmax = min(NTW, a.W - x0);
             const int sz = (ymax << 8) | xmax;
             if (sz != zsig) {
                 zsig = sz;
@@ -897,6 +912,37 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
             }
         }
         __syncthreads();
+        if constexpr (P3) {
+            if (y0 == 0 && wave == 0) {
+                // top edge: the shifted half has no tile above that covers image row 0 -- one extra step at r = -1
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float dzv = zrd[(-1 * NTW + q * 4) * PZ];                  // (lanes >= 8: tile row 0; lanes < 8: out of the tile)
+                    dzv = zlane ? 0.f : dzv;
+                    const float x0v = xa[((-1 + 1) * TWH + q * 4 + 0) * 8];
+                    const float x1v = xa[((-1 + 2) * TWH + q * 4 + 1) * 8];
+                    const float x2v = xb[((-1 + 2) * TWH + q * 4 + 0) * 8];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x0v, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x1v, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x2v, acc[2], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NROWS; ++r) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dzv = zrd[(r * NTW + q * 4) * PZ];             // rows 0-7: dz[r], rows 8-15: dz[r + 1]
+                    bsum += dzv;                                               // (only lanes < 8 are kept)
+                    const float x0v = xa[((r + 1) * TWH + q * 4 + 0) * 8];     // (1,0) | (1,1)   -> shifted: (0,0) | (0,1)
+                    const float x1v = xa[((r + 2) * TWH + q * 4 + 1) * 8];     // (2,1) | (2,2)   -> shifted: (1,1)* | (1,2)
+                    const float x2v = xb[((r + 2) * TWH + q * 4 + 0) * 8];     // (2,0) | (1,2)*  -> shifted: (1,0)* | (0,2)
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x0v, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x1v, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x2v, acc[2], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < NROWS; ++r) {
             __builtin_amdgcn_sched_barrier(0);          // one row's fragments in flight at a time (VGPR bound)
@@ -913,9 +959,10 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x0v, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x1v, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x2v, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x3v, acc[3], 0, 0, 0);
-                acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x4v, acc[4], 0, 0, 0);
+                acc[NG - 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x3v, acc[NG - 2], 0, 0, 0);
+                acc[NG - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x4v, acc[NG - 1], 0, 0, 0);
             }
+        }
         }
         __syncthreads();
     }
@@ -933,7 +980,23 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
     const size_t nw = (size_t)9 * a.Cin * a.Cout;
     float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
     const int half = l15 >> 3, ci = l15 & 7;
-    const int tap_a[NG] = {0, 3, 6, 2, 8}, tap_b[NG] = {1, 4, 7, 5, -1};
+    if constexpr (P3) {
+        // rows (s, co) = (lq >> 1, (lq & 1) * 4 + rg), columns (j, ci) = (half, ci); tap[g][s][j], -1 = duplicate
+        const int s1 = lq >> 1;
+        const int tap3[3] = {s1 ? (half ? 1 : 0) : (half ? 4 : 3), s1 ? (half ? 5 : -1) : (half ? 8 : 7),
+                             s1 ? (half ? 2 : -1) : (half ? -1 : 6)};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float* src = smem + (g * 4 + rg) * 256 + lane;
+                const float v = (src[0] + src[64]) + (src[128] + src[192]);
+                const int co = (lq & 1) * 4 + rg;
+                if (tap3[g] >= 0 && ci < a.Cin && co < a.Cout) slab[((size_t)tap3[g] * a.Cin + ci) * a.Cout + co] = v;
+            }
+        }
+    } else {
+    const int tap_a[5] = {0, 3, 6, 2, 8}, tap_b[5] = {1, 4, 7, 5, -1};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int tap = half ? tap_b[g] : tap_a[g];
@@ -944,6 +1007,7 @@ __global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowW
             const int co = lq * 4 + rg;
             if (tap >= 0 && ci < a.Cin && co < a.Cout) slab[((size_t)tap * a.Cin + ci) * a.Cout + co] = v;
         }
+    }
     }
     {
         const float* src = smem + (NG * 4) * 256 + lane;
