@@ -1396,7 +1396,7 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     // (the producer/consumer rows kernel runs ONE 8-wave workgroup per CU)
     // (1x1 layers are HBM streaming: the same producer / consumer kernel with one tap)
     // (<= 16 x <= 16 channels used to keep the register-prefetch kernel: 373 us vs 196 us for 16 -> 16 at 16 x 512^2)
-    p.ws = (KS == 3 || (KS == 1 && !getenv("DL4DS_NO_WGRAD_WS1"))) && (!(p.CIT == 1 && p.WCO == 1) || !getenv("DL4DS_NO_WGRAD_WS11")) && x.vec && dz.vec &&
+    p.ws = (KS == 3 || (KS == 1 && !getenv("DL4DS_NO_WGRAD_WS1")) || (KS == 5 && !getenv("DL4DS_NO_WGRAD_WS5"))) && (!(p.CIT == 1 && p.WCO == 1) || !getenv("DL4DS_NO_WGRAD_WS11")) && x.vec && dz.vec &&
            p.ntiles < (1 << 20) && !getenv("DL4DS_NO_WGRAD_ROWS") && !getenv("DL4DS_NO_WGRAD_WS");
     int target = std::max(1, (p.ws ? 256 : 512) / (cob * cib));
     const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
@@ -1417,7 +1417,8 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     constexpr size_t red_bytes = (size_t)(WK / 2) * WCO * (KS * KS * CIT * COT * 4 + COT) * 64 * sizeof(float);
     // 3x3 layers beyond the small-channel prefetch variants: row-walking kernel (MFMA bound instead of LDS-read bound)
     static const bool no_rows = getenv("DL4DS_NO_WGRAD_ROWS") != nullptr;
-    constexpr bool ROWS_OK = (KS == 3 || KS == 1) && COT == 1;     // (KS == 1 and the small-channel variants: only the producer / consumer form)
+    // (KS == 1, KS == 5 and the small-channel variants: only the producer / consumer form; 5x5 plans always have CIT == 1)
+    constexpr bool ROWS_OK = (KS == 3 || KS == 1 || (KS == 5 && CIT == 1)) && COT == 1;
     const bool rows = ROWS_OK && !no_rows && ((KS == 3 && !PF) || pl.ws);
     const bool ws = rows && pl.ws;            // producer/consumer form: float4-loadable views, one workgroup per CU
     const size_t lds = rows ? std::max((size_t)(ws ? 2 : 1) * (HPIX * (CIB + 4) + 128 * (COB + 4)) * sizeof(float), red_bytes)
@@ -1428,7 +1429,7 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
             if constexpr (PF) { if (rows) kern = conv_wgrad_rows_ws_kernel<CIT, WCO, 3>; }
             else if (rows) kern = ws ? conv_wgrad_rows_ws_kernel<CIT, WCO, 3> : conv_wgrad_rows_kernel<CIT, WCO>;
         } else {
-            if (rows) kern = conv_wgrad_rows_ws_kernel<CIT, WCO, 1>;
+            if (rows) kern = conv_wgrad_rows_ws_kernel<CIT, WCO, KS>;
         }
     }
     static std::once_flag once;
