@@ -133,6 +133,33 @@ __global__ void strided_axpy4_kernel(const float* __restrict__ src, int ld_s, fl
     }
 }
 
+// the same for slices whose channel counts / pixel pitches are not multiples of four (a 26-channel concatenation of 16 + 8 + 2):
+// V = 2 (everything even) or 1 floats per thread; no per-element divisions (the generic view kernel spends ~40 instructions per
+// element on them)
+template <int V>
+__global__ void strided_axpy_small_kernel(const float* __restrict__ src, int ld_s, float* __restrict__ dst, int ld_d, int cvn,
+                                          size_t step_pix, int step_cv, float alpha, int accumulate, size_t totalv) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t pix = e / (size_t)cvn;
+    int cv = (int)(e - pix * (size_t)cvn);
+    for (; e < totalv; e += (size_t)gridDim.x * blockDim.x) {
+        const float* sp = src + pix * (size_t)ld_s + (size_t)cv * V;
+        float* dp = dst + pix * (size_t)ld_d + (size_t)cv * V;
+        if constexpr (V == 2) {
+            float2 v = *reinterpret_cast<const float2*>(sp);
+            v.x *= alpha; v.y *= alpha;
+            if (accumulate) { const float2 o = *reinterpret_cast<const float2*>(dp); v.x += o.x; v.y += o.y; }
+            *reinterpret_cast<float2*>(dp) = v;
+        } else {
+            float v = alpha * sp[0];
+            if (accumulate) v += dp[0];
+            dp[0] = v;
+        }
+        pix += step_pix; cv += step_cv;
+        if (cv >= cvn) { cv -= cvn; ++pix; }
+    }
+}
+
 // dst (+)= src * [mask > 0]: float4, strided pixels on all three sides (see strided_axpy4_kernel)
 __global__ void strided_masked_axpy4_kernel(const float* __restrict__ src, int ld_s, const float* __restrict__ mask, int ld_m,
                                             float* __restrict__ dst, int ld_d, int c4n, size_t step_pix, int step_c4,
@@ -467,6 +494,18 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
         const size_t stride = (size_t)blocks * 256;
         hipLaunchKernelGGL(strided_axpy4_kernel, dim3(blocks), dim3(256), 0, s, src.p, src.ld, dst.p, dst.ld, c4n,
                            stride / (size_t)c4n, (int)(stride % (size_t)c4n), alpha, accumulate, total / 4);
+    } else if (src.d2s <= 1 && dst.d2s <= 1 && !src.sc && !dst.sc && src.nstride == (size_t)src.H * src.W * src.ld &&
+               dst.nstride == (size_t)dst.H * dst.W * dst.ld) {
+        // channel counts / pitches that are not multiples of four: float2 when everything is even, else one float per thread
+        const bool v2 = ((src.C | src.ld | dst.ld) & 1) == 0 && ((((uintptr_t)src.p) | ((uintptr_t)dst.p)) & 7) == 0;
+        const int V = v2 ? 2 : 1;
+        const int cvn = src.C / V;
+        const size_t totalv = total / V;
+        const int blocks = ew_blocks(totalv);
+        const size_t stride = (size_t)blocks * 256;
+        auto kern = v2 ? strided_axpy_small_kernel<2> : strided_axpy_small_kernel<1>;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, src.p, src.ld, dst.p, dst.ld, cvn, stride / (size_t)cvn,
+                           (int)(stride % (size_t)cvn), alpha, accumulate, totalv);
     } else {
         hipLaunchKernelGGL(view_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, dst, alpha, accumulate, total);
     }
