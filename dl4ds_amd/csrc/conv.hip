@@ -1177,12 +1177,18 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
         const size_t zsx = (size_t)rz * vz.ld, zsy = (size_t)rz * (size_t)(vz.W * rz) * vz.ld;
         const int xc = stid / QX, xq = stid - xc * QX;
         const bool x_act = stid < TWH * QX;
-        const int xv0 = (x_act && ci0 + 4 * xq < a.Cin) ? (int)((xc * xsx + view_chan_off(vx, min(ci0 + 4 * xq, a.Cin - 4))) * 4) : OOB;
+        const int xv0 = (x_act && ci0 + 4 * xq < a.Cin) ? (int)((xc * xsx + view_chan_off(vx, ci0 + 4 * xq)) * 4) : OOB;
         const int zp = stid % (TW * QZ);
         const int zr0 = __builtin_amdgcn_readfirstlane(stid / (TW * QZ));          // (wave-uniform: TW * QZ is a multiple of 64)
         const int zc = zp / QZ, zq = zp - zc * QZ;
-        const int zv0 = (co0 + 4 * zq < a.Cout) ? (int)((zc * zsx + view_chan_off(vz, min(co0 + 4 * zq, a.Cout - 4))) * 4) : OOB;
+        const int zv0 = (co0 + 4 * zq < a.Cout) ? (int)((zc * zsx + view_chan_off(vz, co0 + 4 * zq)) * 4) : OOB;
         const int x_dst = xc * PX + xq * 4, z_dst = (zr0 * TW + zc) * PZ + zq * 4;
+        // views that are not float4-loadable (channel count / pitch not a multiple of four): the last quad of a pixel reaches into
+        // the next pixel (harmless, see plan_wgrad) and, for the very last pixel, past the tensor -- there the descriptor carries
+        // the exact number of bytes left, and the buffer unit zero-fills dword by dword (measured on gfx950)
+        const bool x_exact = !vx.vec, z_exact = !vz.vec;
+        const char* x_end = reinterpret_cast<const char*>(vx.p) + ((size_t)(vx.N - 1) * vx.nstride + (size_t)vx.H * vx.W * vx.ld) * 4;
+        const char* z_end = reinterpret_cast<const char*>(vz.p) + ((size_t)(vz.N - 1) * vz.nstride + (size_t)vz.H * vz.W * vz.ld) * 4;
         auto stage = [&](int tile, int buf) __attribute__((always_inline)) {
             const int tq = fast_div(tile, a.m_tx);
             const int tx = tile - tq * a.tiles_x;
@@ -1194,9 +1200,12 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
             const int xv = (x0 - PAD + xc >= 0 && x0 - PAD + xc < a.W) ? xv0 : OOB;
             const int zv = (x0 + zc < a.W) ? zv0 : OOB;
             i32x4_t xr[THH], zq4[ZR];
+            int nrx = 0x7fffff00, nrz = 0x7fffff00;
+            if (x_exact) { const long rem = x_end - xb; nrx = rem < 0x7fffff00l ? (int)rem : 0x7fffff00; }
+            if (z_exact) { const long rem = z_end - zb; nrz = rem < 0x7fffff00l ? (int)rem : 0x7fffff00; }
             if (y0 >= PAD && y0 + TH + PAD <= a.H) {              // every row of the halo inside the image: one descriptor each
-                const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 0x7fffff00, RSRC3);
-                const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(zb, 0, 0x7fffff00, RSRC3);
+                const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(xb, 0, nrx, RSRC3);
+                const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(zb, 0, nrz, RSRC3);
 #pragma unroll
                 for (int u = 0; u < THH; ++u) xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, xv, (int)(u * xsy * 4), 0);
 #pragma unroll
@@ -1205,13 +1214,13 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
 #pragma unroll
                 for (int u = 0; u < THH; ++u) {
                     const bool row_ok = y0 - PAD + u >= 0 && y0 - PAD + u < a.H;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, row_ok ? 0x7fffff00 : 0, RSRC3);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, row_ok ? nrx : 0, RSRC3);
                     xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, xv, (int)(u * xsy * 4), 0);
                 }
 #pragma unroll
                 for (int u = 0; u < ZR; ++u) {
                     const int row = u * RP + zr0;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(zb, 0, (y0 + row < a.H) ? 0x7fffff00 : 0, RSRC3);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(zb, 0, (y0 + row < a.H) ? nrz : 0, RSRC3);
                     zq4[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, zv, (int)(row * zsy * 4), 0);
                 }
             }
@@ -1373,6 +1382,12 @@ struct WgradPlan { int S, CIT, WCO, WK, tiles_x, tiles_y, ntiles; bool ws; };
 
 WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     WgradPlan p;
+    // The producer / consumer kernel stages with 16-byte buffer loads.  Plain views whose channel count or pixel pitch is not a
+    // multiple of four are fine too: the loads only need dword alignment, and what the last quad of a pixel picks up beyond
+    // its channels (the next pixel's first channels) lands in rows / columns of the MFMA tile that are never written out
+    // (ci >= Cin, co >= Cout) -- 13-, 26- and 2-channel layers (densenet transitions, LocalizedConvBlock) used to fall back to
+    // the scalar-staged kernel at 1.5 TB/s
+    auto ws_ok = [](const TView& v) { return v.vec || (v.d2s <= 1 && !getenv("DL4DS_NO_WGRAD_WS_UNALIGNED")); };
     p.tiles_x = cdiv(x.W, 16);
     p.tiles_y = cdiv(x.H, 8);
     p.ntiles = p.tiles_x * p.tiles_y * x.N;
@@ -1396,7 +1411,7 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     // (the producer/consumer rows kernel runs ONE 8-wave workgroup per CU)
     // (1x1 layers are HBM streaming: the same producer / consumer kernel with one tap)
     // (<= 16 x <= 16 channels used to keep the register-prefetch kernel: 373 us vs 196 us for 16 -> 16 at 16 x 512^2)
-    p.ws = (KS == 3 || (KS == 1 && !getenv("DL4DS_NO_WGRAD_WS1")) || (KS == 5 && !getenv("DL4DS_NO_WGRAD_WS5"))) && (!(p.CIT == 1 && p.WCO == 1) || !getenv("DL4DS_NO_WGRAD_WS11")) && x.vec && dz.vec &&
+    p.ws = (KS == 3 || (KS == 1 && !getenv("DL4DS_NO_WGRAD_WS1")) || (KS == 5 && !getenv("DL4DS_NO_WGRAD_WS5"))) && (!(p.CIT == 1 && p.WCO == 1) || !getenv("DL4DS_NO_WGRAD_WS11")) && ws_ok(x) && ws_ok(dz) &&
            p.ntiles < (1 << 20) && !getenv("DL4DS_NO_WGRAD_ROWS") && !getenv("DL4DS_NO_WGRAD_WS");
     int target = std::max(1, (p.ws ? 256 : 512) / (cob * cib));
     const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
