@@ -34,6 +34,8 @@ bool conv2d_direct_forward(hipStream_t s, const TView& in, const float* w, int K
 // 3x3, Cin <= 16, Cout <= 16: register-resident filter, persistent MFMA kernel (conv_narrow.hip)
 bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep);
+// 1x1 layers whose channel counts are not multiples of four (conv_point.hip): contiguous staging + MFMA + contiguous store
+bool conv2d_point_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out, const ConvEpilogue& ep);
 bool conv2d_narrow_pair_ok(const TView& in, const TView& out, int KS, const ConvEpilogue& ep);
 int conv2d_narrow_pair_tiles_per_image(int H, int W);
 bool conv2d_direct_eligible(const TView& in, const TView& out, int KS);

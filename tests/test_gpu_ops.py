@@ -666,6 +666,24 @@ def test_conv2d_random_shapes(ops, i):
     close(ops.conv2d_wgrad(x, dz, ks, d2s=d2s), gw, 5e-4)
 
 
+@pytest.mark.parametrize('n,h,w,ci,co', [(3, 40, 36, 26, 13), (2, 33, 17, 13, 26), (2, 64, 64, 24, 2), (1, 19, 23, 2, 24),
+                                        (2, 21, 30, 50, 25), (1, 5, 7, 7, 3), (1, 16, 16, 61, 64), (4, 32, 32, 10, 6)])
+def test_pointwise_conv_odd_channels(ops, n, h, w, ci, co):
+    """1x1 layers whose channel counts are not multiples of four (densenet transitions, TransitionLast 26 -> 13,
+    LocalizedConvBlock's 24 -> 2; csrc/conv_point.hip: contiguous staging, MFMA, contiguous store): forward with bias +
+    residual add + ReLU, forward without an epilogue, dgrad with accumulation (tile tails of 1..255 pixels included)."""
+    x, wt, b = R(n, h, w, ci), R(1, 1, ci, co) * 0.3, R(co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    add = R(n, h, w, co)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None), ref - b.astype(np.float64))
+    dz = R(n, h, w, co)
+    gx, gw = _torch_conv_grads(x, wt, dz, d2s=0)
+    base = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base), gx + base)
+    close(ops.conv2d_wgrad(x, dz, 1), gw, 5e-4)
+
+
 @pytest.mark.parametrize('shape', [(5, 40, 36, 1), (3, 24, 50, 2), (4, 9, 8, 1)])
 def test_image_metrics(shape):
     """compute_metrics' reductions (metrics.py:166-262) on the device vs the numpy restatement: PSNR / SSIM / MAE / RMSE /
