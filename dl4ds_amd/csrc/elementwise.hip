@@ -725,9 +725,72 @@ __global__ void resize_table_bwd_kernel(TView dy, TView dx, const int* __restric
         dx.p[o] = accumulate ? dx.p[o] + acc : acc;
     }
 }
+// float4 over the channels (both views float4-loadable): the index / weight lookups are shared by four channels
+__global__ void resize_table_fwd4_kernel(TView x, TView y, const int* __restrict__ iy, const float* __restrict__ wy,
+                                         const int* __restrict__ ix, const float* __restrict__ wx, int ky, int kx, size_t total4) {
+    const int C4 = y.C >> 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        // (32-bit index arithmetic: the launcher checks total4 < 2^32; 64-bit divisions cost ~40 instructions each)
+        const unsigned e32 = (unsigned)e;
+        unsigned r = e32 / (unsigned)C4;
+        const int c = (int)(e32 - r * (unsigned)C4) * 4;
+        const unsigned r1 = r / (unsigned)y.W;
+        const int xo = (int)(r - r1 * (unsigned)y.W);
+        const int n = (int)(r1 / (unsigned)y.H);
+        const int yo = (int)(r1 - (unsigned)n * (unsigned)y.H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < ky; ++a) {
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int sy = iy[yo * ky + a];
+            for (int b = 0; b < kx; ++b) {
+                const float w = wx[xo * kx + b];
+                const float4 v = *reinterpret_cast<const float4*>(x.p + view_off(x, n, sy, ix[xo * kx + b], c));
+                row.x += w * v.x; row.y += w * v.y; row.z += w * v.z; row.w += w * v.w;
+            }
+            const float w = wy[yo * ky + a];
+            acc.x += w * row.x; acc.y += w * row.y; acc.z += w * row.z; acc.w += w * row.w;
+        }
+        *reinterpret_cast<float4*>(y.p + view_off(y, n, yo, xo, c)) = acc;
+    }
+}
+__global__ void resize_table_bwd4_kernel(TView dy, TView dx, const int* __restrict__ py, const int* __restrict__ oy,
+                                         const float* __restrict__ vy, const int* __restrict__ px, const int* __restrict__ ox,
+                                         const float* __restrict__ vx, int accumulate, size_t total4) {
+    const int C4 = dx.C >> 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        const unsigned e32 = (unsigned)e;
+        unsigned r = e32 / (unsigned)C4;
+        const int c = (int)(e32 - r * (unsigned)C4) * 4;
+        const unsigned r1 = r / (unsigned)dx.W;
+        const int xi = (int)(r - r1 * (unsigned)dx.W);
+        const int n = (int)(r1 / (unsigned)dx.H);
+        const int yi = (int)(r1 - (unsigned)n * (unsigned)dx.H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = py[yi]; a < py[yi + 1]; ++a) {
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int sy = oy[a];
+            for (int b = px[xi]; b < px[xi + 1]; ++b) {
+                const float w = vx[b];
+                const float4 v = *reinterpret_cast<const float4*>(dy.p + view_off(dy, n, sy, ox[b], c));
+                row.x += w * v.x; row.y += w * v.y; row.z += w * v.z; row.w += w * v.w;
+            }
+            const float w = vy[a];
+            acc.x += w * row.x; acc.y += w * row.y; acc.z += w * row.z; acc.w += w * row.w;
+        }
+        float4* d = reinterpret_cast<float4*>(dx.p + view_off(dx, n, yi, xi, c));
+        if (accumulate) { const float4 o = *d; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        *d = acc;
+    }
+}
 void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx,
                           int ky, int kx) {
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
+    if (x.vec && y.vec && x.d2s <= 1 && y.d2s <= 1 && !x.sc && total / 4 < (1ull << 32)) {
+        ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
+        hipLaunchKernelGGL(resize_table_fwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x, y, iy, wy, ix, wx, ky, kx, total / 4);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
     hipLaunchKernelGGL(resize_table_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, iy, wy, ix, wx, ky, kx, total);
     HIP_CHECK(hipGetLastError());
@@ -735,6 +798,13 @@ void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const i
 void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
                            const int* px, const int* ox, const float* vx, int accumulate) {
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
+    if (dy.vec && dx.vec && dy.d2s <= 1 && dx.d2s <= 1 && !dy.sc && total / 4 < (1ull << 32)) {
+        ProfScope ps(s, "resize_table_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
+        hipLaunchKernelGGL(resize_table_bwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate,
+                           total / 4);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     ProfScope ps(s, "resize_table_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
     hipLaunchKernelGGL(resize_table_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate, total);
     HIP_CHECK(hipGetLastError());

@@ -654,6 +654,25 @@ struct MaxPoolOp : GOp {
 // op's own float arithmetic: scale = in / out; src = (o + 0.5f) * scale - 0.5f; i0 = floor(src); the Keys (A = -0.5) weights
 // come from a 1024-step table at offset = lrintf((src - i0) * 1024); a tap whose index had to be clamped into the image gets
 // weight 0 and the remaining weights are renormalised to sum 1.
+// ... and of tf.image.resize(method='bilinear') (half-pixel centres), the arithmetic of elementwise.hip's bilinear_src: two taps
+// lo = max(floor(src), 0), hi = min(ceil(src), in - 1) with weights 1 - f, f (f = src - floor(src)).  The table kernels evaluate
+// them with four channels per thread and, in the backward pass, as the exact transpose (CSR gather) -- the direct kernels spent
+// ~3 600 instructions per input element on re-deriving the taps of the ~120 candidate outputs of a x4 up-sampling.
+static void bilinear_axis_tables(int in_size, int out_size, std::vector<int>& idx, std::vector<float>& w) {
+    const float scale = (float)in_size / (float)out_size;
+    idx.assign((size_t)out_size * 2, 0);
+    w.assign((size_t)out_size * 2, 0.f);
+    for (int o = 0; o < out_size; ++o) {
+        const float src = ((float)o + 0.5f) * scale - 0.5f;
+        const float fl = std::floor(src);
+        const float f = src - fl;
+        idx[(size_t)o * 2] = std::max((int)fl, 0);
+        idx[(size_t)o * 2 + 1] = std::min((int)std::ceil(src), in_size - 1);
+        w[(size_t)o * 2] = 1.f - f;
+        w[(size_t)o * 2 + 1] = f;
+    }
+}
+
 static void bicubic_axis_tables(int in_size, int out_size, std::vector<int>& idx, std::vector<float>& w) {
     const int T = 1024;
     std::vector<float> lut((T + 1) * 2);
@@ -764,6 +783,7 @@ struct ResizeOp : GOp {
         std::vector<float> w;
         int K = 4;
         if (method == 2) bicubic_axis_tables(in_size, out_size, idx, w);
+        else if (method == 0) { bilinear_axis_tables(in_size, out_size, idx, w); K = 2; }
         else K = scale_translate_axis_tables(method, in_size, out_size, idx, w);
         // transpose: per input index the (output, weight) pairs, output index ascending, tap ascending (fixed summation order)
         std::vector<std::vector<std::pair<int, float>>> cols(in_size);
@@ -946,7 +966,8 @@ int g_resize(Graph& g, int in, int Ho, int Wo, int nearest) {
     const int out = g.add_tensor(Ho, Wo, ti.C, ti.nmul, true, false);
     ResizeOp* op = push<ResizeOp>(g);
     DL4DS_REQUIRE(nearest >= 0 && nearest <= 6, "resize: unknown method");
-    op->in = in; op->out = out; op->method = nearest; op->nearest = nearest == 1; op->bicubic = nearest >= 2;
+    op->in = in; op->out = out; op->method = nearest; op->nearest = nearest == 1;
+    op->bicubic = nearest >= 2 || (nearest == 0 && !getenv("DL4DS_RESIZE_BILINEAR_DIRECT"));     // table-driven
     g.tensors[in].n_other++;
     return out;
 }
