@@ -559,7 +559,8 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
     const long blocks = (long)grid.x * grid.y;
     const int nchunks = cdiv(p.Cin, CK);
     int S = 1;
-    if (!no_splitk && blocks < 256 && nchunks >= 2) S = (int)std::min<long>(nchunks, std::max<long>(2, 512 / blocks));
+    static const long sk_target = getenv("DL4DS_SPLITK_TARGET") ? atol(getenv("DL4DS_SPLITK_TARGET")) : 768;
+    if (!no_splitk && blocks < 256 && nchunks >= 2) S = (int)std::min<long>(nchunks, std::max<long>(2, sk_target / blocks));
     ProfScope ps(s, "conv_igemm<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
                         std::to_string(WM) + "," + std::to_string(WN) + (S > 1 ? ",splitk>" : ">"),
                  2.0 * px * KK * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KK * p.Cin * p.Cout));
@@ -603,7 +604,11 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
             const int th = (bn >= 96) ? 8 : 16;
             return (long)cdiv(p.W, 16) * cdiv(p.H, th) * N * cdiv(p.Cout, bn);
         };
-        if (blocks_for(best) < 256) {
+        // ... unless the reduction is long enough for split-K (launch_fwd) to supply the blocks: a wide cout tile reads 0.5 LDS
+        // fragments per MFMA where the 16-cout tile reads 1.25, and the slabs of these layers are a few MB
+        const long kparts = std::max(1, cdiv(p.Cin, 64));
+        const bool wide_splitk = kparts >= 2 && blocks_for(best) * kparts >= (getenv("DL4DS_WIDE_SPLITK_MIN") ? atol(getenv("DL4DS_WIDE_SPLITK_MIN")) : 128) && !getenv("DL4DS_NO_WIDE_SPLITK");
+        if (blocks_for(best) < 256 && !wide_splitk) {
             int pick = best;
             for (int bn : bns) {
                 if (bn >= pick) continue;
