@@ -637,9 +637,9 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
         case 128: launch_fwd<KS, 4, 4, 2, 2>(s, p, N); break;   // 8x16 x 128
         case 96:  launch_fwd<KS, 4, 3, 2, 2>(s, p, N); break;   // 8x16 x 96
         case 48:  launch_fwd<KS, 4, 3, 4, 1>(s, p, N); break;   // 16x16 x 48
-        case 32:  launch_fwd<KS, 4, 2, 4, 1>(s, p, N); break;   // 16x16 x 32
+        case 32:  launch_fwd<KS, 4, 2, 4, 1>(s, p, N); break;   // 16x16 x 32 (a second wave set measured no better here)
         default:                                                // 16x16 x 16; under-filled multi-tap launches: 2 waves/SIMD
-            if (KS > 1 && (long)cdiv(p.W, 16) * cdiv(p.H, 16) * N * cdiv(p.Cout, 16) < 256 && !getenv("DL4DS_NO_KSP"))
+            if (KS > 1 && (long)cdiv(p.W, 16) * cdiv(p.H, 16) * N * cdiv(p.Cout, 16) <= (getenv("DL4DS_KSP_MAX") ? atol(getenv("DL4DS_KSP_MAX")) : 256) && !getenv("DL4DS_NO_KSP"))
                 launch_fwd<KS, 4, 1, 4, 1, 2>(s, p, N);       // (four wave sets measured no better than two)
             else
                 launch_fwd<KS, 4, 1, 4, 1>(s, p, N);
