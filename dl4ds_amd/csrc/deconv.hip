@@ -119,6 +119,8 @@ void conv2d_transpose_dgrad(hipStream_t s, const TView& dz, const float* w, int 
     conv2d_dgrad_weights(s, c.wp, c.wpt, g.KV, g.Cin, CoutP);
     TView dzv = make_view_d2s(dz.p, dx.N, dx.H, dx.W, CoutP, stride);
     dzv.nstride = dz.nstride;
+    dzv.ld = dz.ld;                   // (dz may be a channel slice of a Concatenate's gradient: pixel pitch > its channels)
+    dzv.vec = dzv.vec && dz.vec && (dz.ld & 3) == 0;
     ConvEpilogue ep;
     ep.accumulate = accumulate;
     if (relu_mask && relu_mask->p) ep.mask = *relu_mask;
@@ -132,6 +134,8 @@ void conv2d_transpose_wgrad(hipStream_t s, const TView& x, const TView& dz, int 
     const int CoutP = stride * stride * dz.C;
     TView dzv = make_view_d2s(dz.p, x.N, x.H, x.W, CoutP, stride);
     dzv.nstride = dz.nstride;
+    dzv.ld = dz.ld;
+    dzv.vec = dzv.vec && dz.vec && (dz.ld & 3) == 0;
     conv2d_wgrad(s, x, dzv, g.KV, c.dwp, 0, nullptr, 0, c.rest, c.rest_bytes);
     const size_t total = (size_t)KS * KS * dz.C * x.C;
     hipLaunchKernelGGL(deconv_unpack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, c.dwp, dw, g, accumulate);

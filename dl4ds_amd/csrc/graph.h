@@ -36,6 +36,10 @@ struct GTensor {
     // written by a Conv2D / Concatenate and read only by Conv2Ds and ONE Concatenate.  Gradients stay dense.
     int alias_of = -1, alias_coff = 0, alias_ld = 0;
     int alias_parent = -1;     // the Concatenate output it is a direct input slice of (alias_of = the root of a chain of them)
+    // ... and the gradient too (round 2): d(loss)/d(this tensor) is the same channel slice of the concatenation's gradient
+    // buffer, so Concatenate's backward copies nothing for it; its other consumers accumulate into the slice, its producer
+    // reads its dZ from it (plan_grad_aliases in graph.hip lists the conditions)
+    bool galias = false;
     // ReLU backward fused into the writers: every consumer is a Conv2D (or an Add), whose dgrad epilogue zeroes the gradient
     // where this activation is <= 0 (the mask is linear, so each accumulating writer applies it independently)
     bool grad_masked = false;
@@ -70,7 +74,9 @@ struct GOp {
     const char* kind = "op";
     virtual std::string describe_fusion(Graph& g) { return ""; }
     // >= 0: the tensor this op writes THROUGH A VIEW (so it may live inside a Concatenate's buffer, GTensor::alias_of)
-    virtual int alias_output() const { return -1; }    // non-empty: JSON object describing what this op handed to its neighbours
+    virtual int alias_output() const { return -1; }
+    // does this op read tensor t as an input?  (only the op kinds that may read an aliased tensor have to answer: plan_grad_aliases)
+    virtual bool reads_tensor(int t) const { return false; }    // non-empty: JSON object describing what this op handed to its neighbours
 };
 
 struct Graph {

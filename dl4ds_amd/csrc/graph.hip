@@ -8,6 +8,7 @@
 #include <limits>
 
 static void plan_concat_aliases(Graph& g);
+static void plan_grad_aliases(Graph& g);
 
 // ============================================================================================ Graph
 Graph::~Graph() {
@@ -76,6 +77,7 @@ void Graph::finalize() {
     }
     for (auto& op : ops) op->on_finalize(*this);
     plan_concat_aliases(*this);
+    plan_grad_aliases(*this);
     if (wt_floats) HIP_CHECK(hipMalloc((void**)&Wt, wt_floats * sizeof(float)));
     finalized = true;
     // the headline model's arena is 0.82 MB (latency-bound collective): a few buckets; U-Net (54 MB): ~4 MB each
@@ -123,7 +125,7 @@ void Graph::prepare(int B) {
     std::vector<size_t> doff(tensors.size()), goff(tensors.size()), soff(ops.size());
     for (size_t i = 0; i < tensors.size(); ++i) {
         doff[i] = tensors[i].alias_of >= 0 ? (size_t)-1 : bump(tensors[i].per_sample() * B);     // (aliased: inside another buffer)
-        goff[i] = (tensors[i].requires_grad) ? bump(tensors[i].per_sample() * B) : (size_t)-1;
+        goff[i] = (tensors[i].requires_grad && !tensors[i].galias) ? bump(tensors[i].per_sample() * B) : (size_t)-1;
     }
     for (size_t i = 0; i < ops.size(); ++i) soff[i] = bump(ops[i]->saved_floats_per_sample(*this) * B + 64);
     float* slab = nullptr;
@@ -136,6 +138,7 @@ void Graph::prepare(int B) {
     for (size_t i = tensors.size(); i-- > 0;) {               // a concatenation is created after its inputs: resolved first
         GTensor& t = tensors[i];
         if (t.alias_of >= 0) t.data = tensors[t.alias_of].data + t.alias_coff;
+        if (t.galias) t.grad = tensors[t.alias_of].grad + t.alias_coff;
     }
     for (size_t i = 0; i < ops.size(); ++i) ops[i]->saved = slab + soff[i];
     size_t ws = 1 << 20;
@@ -152,7 +155,7 @@ TView Graph::view(int tid, int B, bool grad, int b_off, int b_cnt) const {
     float* base = grad ? t.grad : t.data;
     DL4DS_REQUIRE(base != nullptr, "tensor buffer missing (no grad buffer / graph not prepared)");
     const int cnt = (b_cnt < 0) ? B : b_cnt;
-    if (!grad && t.alias_of >= 0) {
+    if ((!grad || t.galias) && t.alias_of >= 0) {
         const size_t img = (size_t)t.H * t.W * t.alias_ld;
         TView v = make_view(base + (size_t)b_off * t.nmul * img, cnt * t.nmul, t.H, t.W, t.C);
         v.ld = t.alias_ld;
@@ -320,7 +323,7 @@ struct ConvOp : GOp {
         float* base = (grad ? to.grad : to.data) + (size_t)bo * to.per_sample();
         const int N = (bc < 0 ? B : bc) * to.nmul;
         if (d2s > 1) return make_view_d2s(base, N, ti.H, ti.W, Cout, d2s);
-        if (!grad && to.alias_of >= 0) return g.view(out, B, false, bo, bc);       // written straight into a Concatenate's buffer
+        if ((!grad || to.galias) && to.alias_of >= 0) return g.view(out, B, grad, bo, bc);       // straight into / out of a Concatenate's buffer
         return make_view(base, N, ti.H, ti.W, Cout);
     }
     void forward(Graph& g, int B, bool) override {
@@ -567,6 +570,7 @@ struct ConcatOp : GOp {
         if (!g.tensors[out].grad_written) return;
         for (size_t k = 0; k < ins.size(); ++k) {
             if (!wants_grad(g, ins[k], c)) continue;
+            if (g.tensors[ins[k]].galias) { g.tensors[ins[k]].grad_written = true; continue; }     // its gradient IS this slice
             // a ReLU output whose consumers apply the mask: this copy zeroes the gradient where the activation is <= 0
             TView mask{nullptr, 0, 0, 0, 0, 0, 0, 0};
             if (g.tensors[ins[k]].grad_masked) mask = g.view(ins[k], c.B, false, c.b_off, c.b_cnt);
@@ -1037,5 +1041,53 @@ static void plan_concat_aliases(Graph& g) {
         int root = ti.alias_of, coff = ti.alias_coff;
         while (g.tensors[root].alias_of >= 0) { coff += g.tensors[root].alias_coff; root = g.tensors[root].alias_of; }
         ti.alias_of = root; ti.alias_coff = coff; ti.alias_ld = g.tensors[root].C;
+    }
+}
+
+
+// Concatenate without the backward copies (GTensor::galias).  For a Concatenate K with output R:
+//   * every input lives in R's buffer as a direct slice (forward alias, not nested) and R is not itself aliased or a model output;
+//   * the inputs' other consumers were created BEFORE K, so in the backward pass K comes first: R's own consumers have written
+//     all of dR by then (the first of them without accumulation), the inputs' other consumers accumulate into their slices after;
+//   * ReLU masks: an input whose consumers apply its mask (grad_masked) expected K's copy to do so.  Without the copy the mask
+//     has to be on dR already -- so if any input is grad_masked, ALL inputs must be ReLU outputs and R becomes grad_masked itself:
+//     R's consumers (Conv2D dgrad stores, MaxPooling2D / Conv2DTranspose backward, ...) zero dR where R <= 0, which is each
+//     input's own mask on its slice.  (An input that applies its mask itself does it a second time: idempotent.)
+// The U-Net decoder levels (PadConcat of the transposed convolution's output and the encoder skip) qualify.
+// DL4DS_NO_GRAD_ALIAS=1 keeps the copies (A/B, tests).
+static void plan_grad_aliases(Graph& g) {
+    if (getenv("DL4DS_NO_GRAD_ALIAS") || getenv("DL4DS_NO_CONCAT_ALIAS")) return;
+    auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
+    const int nops = (int)g.ops.size();
+    for (int ik = 0; ik < nops; ++ik) {
+        ConcatOp* k = dynamic_cast<ConcatOp*>(g.ops[ik].get());
+        if (!k) continue;
+        GTensor& tr = g.tensors[k->out];
+        if (tr.alias_of >= 0 || !tr.requires_grad || is_output(k->out)) continue;
+        bool ok = true, any_masked = false, all_relu = true;
+        for (int t : k->ins) {
+            const GTensor& ti = g.tensors[t];
+            ok = ok && ti.alias_parent == k->out && ti.alias_of == k->out && ti.requires_grad && !ti.is_input;
+            any_masked |= ti.grad_masked;
+            all_relu = all_relu && ti.relu_out;
+        }
+        if (!ok) continue;
+        auto reads = [&](GOp* op, int t) {
+            if (ConvOp* c = dynamic_cast<ConvOp*>(op)) return c->in == t || c->add == t;
+            if (MaxPoolOp* m = dynamic_cast<MaxPoolOp*>(op)) return m->in == t;
+            if (ConcatOp* c2 = dynamic_cast<ConcatOp*>(op)) { for (int u : c2->ins) if (u == t) return true; return false; }
+            return op->reads_tensor(t);
+        };
+        for (int j = ik + 1; j < nops && ok; ++j)
+            for (int t : k->ins)
+                if (reads(g.ops[j].get(), t)) ok = false;
+        if (!ok) continue;
+        if (any_masked) {
+            const bool r_maskable = (tr.n_conv_in + tr.n_add_in + tr.n_masking) >= 1 && tr.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
+            if (!all_relu || !r_maskable) continue;
+            tr.grad_masked = true;
+            tr.relu_out = true;                      // (every channel of R is a ReLU output)
+        }
+        for (int t : k->ins) g.tensors[t].galias = true;
     }
 }

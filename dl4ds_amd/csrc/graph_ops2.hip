@@ -24,6 +24,7 @@ struct ConvTOp : GOp {
     int in, w, out, KS, stride, Cout, relu;
     ConvTOp() { kind = "conv2d_transpose"; }
     int alias_output() const override { return out; }
+    bool reads_tensor(int t) const override { return t == in; }
     size_t workspace_bytes(Graph& g, int B) override {
         TView x = g.view(in, B, false);
         TView y = g.view(out, B, false);
@@ -277,6 +278,7 @@ int g_conv2d_transpose(Graph& g, int in, int w, int KS, int stride, int Cout, in
     op->in = in; op->w = w; op->out = out; op->KS = KS; op->stride = stride; op->Cout = Cout; op->relu = relu;
     g.tensors[in].n_masking++;              // (its dgrad store applies the producer's ReLU mask, like a Conv2D consumer)
     g.tensors[in].n_convt_in++;
+    g.tensors[out].relu_out = relu != 0;
     op->pids = {w};
     return out;
 }

@@ -667,3 +667,45 @@ def test_attention_handed_to_neighbouring_convolutions_equals_separate_passes(mo
     wf, wp = fused.get_weights(), plain.get_weights()
     for k in wf:
         assert np.abs(wf[k] - wp[k]).max() < 2e-4, k          # three Adam steps of 1e-3 each; sign flips of ~0 gradients aside
+
+
+@pytest.mark.parametrize('kind,kw,ins', [
+    ('unet_pin', dict(backbone_block='unet', n_channels=3, n_aux_channels=1, n_filters=8, n_blocks=3, hr_size=(32, 48), decoder_upsampling='dc'), 2),
+    ('unet_pin', dict(backbone_block='unet', n_channels=2, n_aux_channels=0, n_filters=8, n_blocks=2, hr_size=(32, 32), decoder_upsampling='spc'), 1),
+    ('net_postupsampling', dict(backbone_block='densenet', upsampling='spc', scale=2, n_channels=2, n_aux_channels=0, lr_size=(16, 12),
+                                n_filters=8, n_blocks=2), 1),
+])
+def test_concatenate_without_copies_equals_concatenate_with_copies(monkeypatch, kind, kw, ins):
+    """Concatenate inputs that live inside the concatenation's buffer -- activations (forward) and gradients (backward: the
+    decoder levels of the U-Net, whose Concatenate then copies nothing) -- against the same model with DL4DS_NO_CONCAT_ALIAS=1
+    (dense tensors, forward and backward copies): same forward, loss, gradients and three Adam steps to fp32 rounding."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import SupervisedEngine
+    build = getattr(PM, kind)
+    monkeypatch.delenv('DL4DS_NO_CONCAT_ALIAS', raising=False)
+    monkeypatch.delenv('DL4DS_NO_GRAD_ALIAS', raising=False)
+    aliased = build(seed=5, **kw)
+    monkeypatch.setenv('DL4DS_NO_CONCAT_ALIAS', '1')
+    dense = build(seed=5, **kw)
+    monkeypatch.delenv('DL4DS_NO_CONCAT_ALIAS')
+    rng = np.random.default_rng(3)
+    w = dense.get_weights()
+    for k in w:
+        if k.endswith('bias'):
+            w[k] = (rng.standard_normal(w[k].shape) * 0.1).astype(np.float32)
+    dense.set_weights(w); aliased.set_weights(w)
+    B = 3
+    xs = [rng.standard_normal((B,) + s).astype(np.float32) for s in aliased.input_shapes[:ins]]
+    y = rng.standard_normal((B,) + aliased.output_shape).astype(np.float32)
+    assert rel(aliased(xs), dense(xs)) < 2e-6
+    ea = SupervisedEngine(aliased, loss='mse', learning_rate=1e-3)
+    ed = SupervisedEngine(dense, loss='mse', learning_rate=1e-3)
+    la, ga = ea.loss_and_grads(xs, y)
+    ld, gd = ed.loss_and_grads(xs, y)
+    assert la == pytest.approx(ld, rel=1e-6)
+    gs = max(np.abs(v).max() for v in gd.values())
+    for k in gd:
+        assert np.abs(ga[k] - gd[k]).max() / gs < 2e-5, k
+    for _ in range(3):
+        la, ld = ea.step(xs, y), ed.step(xs, y)
+        assert la == pytest.approx(ld, rel=2e-5)
