@@ -1352,30 +1352,32 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
 // out0[e] (+)= sum_k partial[k*n + e] for e < n0 ; out1[e-n0] likewise for e >= n0.
 // One block reduces 16 consecutive elements: thread = (slab sub-index 0..15, element 0..15) -> 64-byte row
 // segments per slab, 16 slabs in flight per block, fixed summation order (deterministic).
+template <int EL>      // elements per block: 16 (64-byte row segments per slab, 16 slabs in flight) or 4 (small filters: 64 slabs in flight)
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out0,
                                                            float* __restrict__ out1, size_t n0, size_t n, int S,
                                                            int acc0, int acc1) {
-    __shared__ float red[16][17];
-    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const size_t ngroups = (n + 15) >> 4;
+    constexpr int SL = 256 / EL;
+    __shared__ float red[SL][EL + 1];
+    const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+    const size_t ngroups = (n + EL - 1) / EL;
     for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const size_t e = grp * 16 + el;
+        const size_t e = grp * EL + el;
         float s = 0.f;
         if (e < n) {
             int k = sl;
-            for (; k + 48 < S; k += 64) {       // 4 independent loads in flight
-                const float a0 = partial[(size_t)k * n + e], a1 = partial[(size_t)(k + 16) * n + e];
-                const float a2 = partial[(size_t)(k + 32) * n + e], a3 = partial[(size_t)(k + 48) * n + e];
+            for (; k + 3 * SL < S; k += 4 * SL) {       // 4 independent loads in flight
+                const float a0 = partial[(size_t)k * n + e], a1 = partial[(size_t)(k + SL) * n + e];
+                const float a2 = partial[(size_t)(k + 2 * SL) * n + e], a3 = partial[(size_t)(k + 3 * SL) * n + e];
                 s += (a0 + a1) + (a2 + a3);
             }
-            for (; k < S; k += 16) s += partial[(size_t)k * n + e];
+            for (; k < S; k += SL) s += partial[(size_t)k * n + e];
         }
         red[sl][el] = s;
         __syncthreads();
         if (sl == 0 && e < n) {
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t += red[k][el];
+            for (int k = 0; k < SL; ++k) t += red[k][el];
             if (e < n0) out0[e] = acc0 ? out0[e] + t : t;
             else if (out1) out1[e - n0] = acc1 ? out1[e - n0] + t : t;
         }
@@ -1628,9 +1630,17 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
             default: throw Dl4dsError("wgrad: kernel size not supported (1,3,5,7)");
         }
     }
-    const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 16), 8192));
     ProfScope ps(s, "wgrad_reduce_slabs", 0.0, 4.0 * (double)n * (nslabs + 1));
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
-                       accumulate_db);
+    // small filters (a 3x3 8 -> 8 layer has 584 values in up to 1024 slabs): 16 elements per block would leave 37 blocks walking
+    // 64 slabs per thread one latency after the other (13 us); 4 elements per block put 64 slabs in flight per block
+    if (n < 4096 && nslabs >= 128 && !getenv("DL4DS_REDUCE16")) {
+        const int blocks = (int)std::max<size_t>(1, cdivz(n, 4));
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
+                           accumulate_db);
+    } else {
+        const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 16), 8192));
+        hipLaunchKernelGGL(reduce_slabs_kernel<16>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
+                           accumulate_db);
+    }
     HIP_CHECK(hipGetLastError());
 }
