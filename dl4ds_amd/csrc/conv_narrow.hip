@@ -56,6 +56,8 @@ __global__ void __launch_bounds__(256, CI == 8 ? 4 : 2) conv_narrow_kernel(const
         }
 
     const float* rd = tile + ((wave * NROWS) * TWH + l15) * CI + E * lq;
+    const size_t in_total = (size_t)(a.in.N - 1) * a.in.nstride + (size_t)a.H * a.W * a.in.ld;      // floats in the input view
+    const bool ragged = (a.Cin & 3) != 0;           // channel quads that reach into the next pixel (and, at the very end, beyond the view)
 
     for (int t = blockIdx.x; t < a.tiles_x * a.tiles_y * a.in.N; t += gridDim.x) {
         const int q = fast_div(t, a.m_txy[0]);
@@ -79,7 +81,13 @@ __global__ void __launch_bounds__(256, CI == 8 ? 4 : 2) conv_narrow_kernel(const
                 const bool cok = ok && c4 * 4 < a.Cin;
                 const size_t off = (size_t)n * a.in.nstride + ((size_t)(ok ? gy : 0) * a.W + (ok ? gx : 0)) * a.in.ld +
                                    (cok ? c4 * 4 : 0);
-                r[u] = *reinterpret_cast<const float4*>(a.in.p + off);
+                if (!ragged || off + 4 <= in_total) {
+                    r[u] = *reinterpret_cast<const float4*>(a.in.p + off);      // (dword-aligned when the channel count is not a multiple of 4)
+                } else {
+                    // the last quad of the tensor's last pixel when Cin % 4 != 0: nothing may be read beyond the buffer
+                    const float* q = a.in.p + off;
+                    r[u] = make_float4(q[0], off + 1 < in_total ? q[1] : 0.f, off + 2 < in_total ? q[2] : 0.f, 0.f);
+                }
                 m[u] = valid4(c4 * 4, a.Cin, ok);
             }
 #pragma unroll
@@ -1069,7 +1077,10 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
                            const ConvEpilogue& ep) {
     if (KS != 3 || in.C > 16 || out.C > 16 || in.d2s > 1) return false;
     const bool pair_ok = conv2d_narrow_pair_ok(in, out, KS, ep);
-    if (!in.vec && !pair_ok) return false;
+    // 9..16 input channels that are not a multiple of four (the 13-channel ConvBlock behind TransitionLast 26 -> 13): the halo
+    // staging's float4 loads only need dword alignment; channels beyond Cin are masked when the tile is written to LDS
+    const bool unaligned_ok = in.C > 8 && in.d2s <= 1 && !in.sc && !ep.pool && !getenv("DL4DS_NO_NARROW_UNALIGNED");
+    if (!in.vec && !pair_ok && !unaligned_ok) return false;
     if ((long)cdiv(in.W, NTW) * cdiv(in.H, NTH) * in.N >= (1l << 20)) return false;    // fast_div range
     DL4DS_REQUIRE(pair_ok || (!in.sc && !ep.pool), "conv_narrow: channel-affine input / pooling partials need the pair kernel");
     ConvParams p;
