@@ -402,30 +402,62 @@ __global__ void localconv_fwd_kernel(TView x, const float* __restrict__ w, const
     }
 }
 // one thread per (h,w): loops the batch, so dW / db need no atomics
-__global__ void localconv_bwd_kernel(TView x, const float* __restrict__ w, TView dy, TView dx, int acc_dx,
-                                     float* __restrict__ dw, float* __restrict__ db, int acc_dw) {
-    const int C = x.C, F = dy.C;
+// One thread per (grid point, quarter of the batch): the weight gradient of a grid point is a sum over the batch, and one thread
+// walking all N images of its point (128 dependent load round trips, 4 waves per CU) was latency-bound at 0.6 TB/s.  A wave
+// holds 16 points x 4 batch lanes; the four partial sums meet through two shuffles.  CT / FT > 0: compile-time channel counts
+// (registers instead of dynamically indexed scratch arrays); 0: run-time counts up to kLcMax.
+template <int CT, int FT>
+__global__ void __launch_bounds__(256) localconv_bwd_kernel(TView x, const float* __restrict__ w, TView dy, TView dx, int acc_dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, int acc_dw) {
+    constexpr int CM = CT ? CT : kLcMax, FM = FT ? FT : kLcMax;
+    const int C = CT ? CT : x.C, F = FT ? FT : dy.C;
     const size_t nhw = (size_t)x.H * x.W;
-    for (size_t hw = (size_t)blockIdx.x * blockDim.x + threadIdx.x; hw < nhw; hw += (size_t)gridDim.x * blockDim.x) {
-        const int yy = (int)(hw / x.W), xx = (int)(hw % x.W);
-        float wl[kLcMax * kLcMax], gw[kLcMax * kLcMax], gb[kLcMax];
-        for (int i = 0; i < C * F; ++i) { wl[i] = w[hw * C * F + i]; gw[i] = 0.f; }
-        for (int f = 0; f < F; ++f) gb[f] = 0.f;
-        for (int n = 0; n < x.N; ++n) {
-            float xv[kLcMax], gy[kLcMax];
-            for (int c = 0; c < C; ++c) xv[c] = x.p[view_off(x, n, yy, xx, c)];
-            for (int f = 0; f < F; ++f) { gy[f] = dy.p[view_off(dy, n, yy, xx, f)]; gb[f] += gy[f]; }
-            for (int c = 0; c < C; ++c) {
-                float s = 0.f;
-                for (int f = 0; f < F; ++f) { s += gy[f] * wl[c * F + f]; gw[c * F + f] += xv[c] * gy[f]; }
-                if (dx.p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 15, nl = lane >> 4;
+    const size_t hw = ((size_t)blockIdx.x * 4 + wave) * 16 + pl;
+    const bool live = hw < nhw;
+    const size_t hwc = live ? hw : 0;
+    const int yy = (int)(hwc / x.W), xx = (int)(hwc % x.W);
+    float wl[CM * FM], gw[CM * FM], gb[FM];
+#pragma unroll
+    for (int i = 0; i < CM * FM; ++i) { wl[i] = (i < C * F) ? w[hwc * C * F + i] : 0.f; gw[i] = 0.f; }
+#pragma unroll
+    for (int f = 0; f < FM; ++f) gb[f] = 0.f;
+    for (int n = nl; n < x.N; n += 4) {
+        float xv[CM], gy[FM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) xv[c] = (c < C) ? x.p[view_off(x, n, yy, xx, c)] : 0.f;
+#pragma unroll
+        for (int f = 0; f < FM; ++f) { gy[f] = (f < F) ? dy.p[view_off(dy, n, yy, xx, f)] : 0.f; gb[f] += gy[f]; }
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < C) {
+                float sdx = 0.f;
+#pragma unroll
+                for (int f = 0; f < FM; ++f)
+                    if (f < F) { sdx += gy[f] * wl[c * F + f]; gw[c * F + f] += xv[c] * gy[f]; }
+                if (dx.p && live) {
                     const size_t o = view_off(dx, n, yy, xx, c);
-                    dx.p[o] = acc_dx ? dx.p[o] + s : s;
+                    dx.p[o] = acc_dx ? dx.p[o] + sdx : sdx;
                 }
             }
         }
-        for (int i = 0; i < C * F; ++i) dw[hw * C * F + i] = acc_dw ? dw[hw * C * F + i] + gw[i] : gw[i];
-        if (db) for (int f = 0; f < F; ++f) db[hw * F + f] = acc_dw ? db[hw * F + f] + gb[f] : gb[f];
+    }
+#pragma unroll
+    for (int i = 0; i < CM * FM; ++i) {
+        float v = gw[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (nl == 0 && live && i < C * F) dw[hw * C * F + i] = acc_dw ? dw[hw * C * F + i] + v : v;
+    }
+    if (db) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+            float v = gb[f];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (nl == 0 && live && f < F) db[hw * F + f] = acc_dw ? db[hw * F + f] + v : v;
+        }
     }
 }
 
@@ -638,8 +670,11 @@ void localconv_backward(hipStream_t s, const TView& x, const float* w, const TVi
     const size_t nhw = (size_t)x.H * x.W;
     ProfScope ps(s, "localconv_bwd", 4.0 * nhw * x.N * x.C * dy.C,
                  4.0 * ((double)nhw * x.N * (2 * x.C + dy.C) + 2.0 * (double)nhw * (x.C + 1) * dy.C));
-    hipLaunchKernelGGL(localconv_bwd_kernel, dim3(ew_blocks(nhw)), dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db,
-                       accumulate_dw);
+    const dim3 grid((unsigned)cdivz(nhw, 64));
+    if (x.C == 2 && dy.C == 2)      // LocalizedConvBlock (blocks.py:312-336): TransitionBlock(2) -> LocallyConnected2D(2)
+        hipLaunchKernelGGL((localconv_bwd_kernel<2, 2>), grid, dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db, accumulate_dw);
+    else
+        hipLaunchKernelGGL((localconv_bwd_kernel<0, 0>), grid, dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db, accumulate_dw);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -298,10 +298,13 @@ def test_resize_bilinear(ops, h, w, ho, wo):
     close(ops.resize_bilinear_bwd(dy, h, w), xt.grad.numpy())
 
 
-def test_localconv(ops):
-    x, w, b = R(3, 9, 11, 2), R(9, 11, 2, 2), R(9, 11, 2)
+@pytest.mark.parametrize('n,h,w_,c,f', [(3, 9, 11, 2, 2), (13, 20, 17, 2, 2), (5, 8, 8, 3, 2), (2, 6, 7, 4, 5)])
+def test_localconv(ops, n, h, w_, c, f):
+    """LocallyConnected2D 1x1 (blocks.py:322-328): forward, and the backward kernel whose batch sum is split over four lanes
+    of a wave (2 -> 2 channels compiled in, other counts at run time; batch sizes that do not divide by four)."""
+    x, w, b = R(n, h, w_, c), R(h, w_, c, f), R(h, w_, f)
     close(ops.localconv(x, w, b), N.locally_connected_1x1(x.astype(np.float64), w, b))
-    dy = R(3, 9, 11, 2)
+    dy = R(n, h, w_, f)
     xt, wt, bt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, w, b))
     (T.locally_connected_1x1(xt, wt, bt) * torch.tensor(dy, dtype=torch.float64)).sum().backward()
     dx, dw, db = ops.localconv_bwd(x, w, dy)
