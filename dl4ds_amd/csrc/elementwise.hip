@@ -566,6 +566,72 @@ void view_axpy_masked(hipStream_t s, const TView& src, const TView& mask, const 
     HIP_CHECK(hipGetLastError());
 }
 
+// Concatenate backward in ONE pass: the wide gradient [npx][ld] is read once, contiguously, and every element goes to the dense
+// gradient of the input whose channel range holds it (with that input's ReLU mask / accumulation).  Copying slice by slice touches
+// every cache line of the wide tensor once per slice (a 2-channel slice of 26 channels reads all of it for 8 % of its bytes).
+struct SplitSlice { float* dst; const float* mask; int off, C, acc; };
+struct SplitParams { const float* src; int ld, n; SplitSlice sl[4]; };
+template <int V>
+__global__ void concat_split_kernel(const SplitParams a, int cvn, size_t step_pix, int step_cv, size_t totalv) {
+    // (four grid strides per iteration with all loads first measured 7 % slower)
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t pix = e / (size_t)cvn;
+    int cv = (int)(e - pix * (size_t)cvn);
+    for (; e < totalv; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = cv * V;
+        float v[V];
+        if constexpr (V == 2) { const float2 t = *reinterpret_cast<const float2*>(a.src + pix * (size_t)a.ld + c); v[0] = t.x; v[1] = t.y; }
+        else v[0] = a.src[pix * (size_t)a.ld + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < a.n && c >= a.sl[k].off && c < a.sl[k].off + a.sl[k].C) {
+                const SplitSlice& sl = a.sl[k];
+                const size_t o = pix * (size_t)sl.C + (size_t)(c - sl.off);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float r = v[j];
+                    if (sl.mask) r = sl.mask[o + j] > 0.f ? r : 0.f;
+                    if (sl.acc) r += sl.dst[o + j];
+                    v[j] = r;
+                }
+                if constexpr (V == 2) *reinterpret_cast<float2*>(sl.dst + o) = make_float2(v[0], v[1]);
+                else sl.dst[o] = v[0];
+            }
+        }
+        pix += step_pix; cv += step_cv;
+        if (cv >= cvn) { cv -= cvn; ++pix; }
+    }
+}
+
+// src: plain [npx][ld]; slices: up to four channel ranges with dense destinations [npx][C_k] (mask likewise, or null).
+// Channels of src that belong to no slice are skipped.
+void concat_split(hipStream_t s, const float* src, int ld, size_t npx, const ConcatSlice* slices, int n) {
+    DL4DS_REQUIRE(n >= 1 && n <= 4, "concat_split: 1..4 slices");
+    SplitParams a;
+    a.src = src; a.ld = ld; a.n = n;
+    bool even = (ld & 1) == 0 && ((uintptr_t)src & 7) == 0;
+    double bytes = 4.0 * (double)npx * ld;
+    for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+            a.sl[k] = SplitSlice{slices[k].dst, slices[k].mask, slices[k].off, slices[k].C, slices[k].accumulate};
+            even = even && ((slices[k].off | slices[k].C) & 1) == 0 && ((uintptr_t)slices[k].dst & 7) == 0;
+            bytes += 4.0 * (double)npx * slices[k].C * (1 + (slices[k].mask ? 1 : 0) + (slices[k].accumulate ? 1 : 0));
+        } else {
+            a.sl[k] = SplitSlice{nullptr, nullptr, 0, 0, 0};
+        }
+    }
+    const int V = even ? 2 : 1;
+    const int cvn = ld / V;
+    const size_t totalv = npx * (size_t)cvn;
+    if (totalv == 0) return;
+    ProfScope ps(s, "concat_split", 0.0, bytes);
+    const int blocks = ew_blocks(totalv);
+    const size_t stride = (size_t)blocks * 256;
+    auto kern = even ? concat_split_kernel<2> : concat_split_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, a, cvn, stride / (size_t)cvn, (int)(stride % (size_t)cvn), totalv);
+    HIP_CHECK(hipGetLastError());
+}
+
 void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate) {
     if (n == 0) return;
     ProfScope ps(s, "masked_axpy", 0.0, 4.0 * (double)n * (3 + (accumulate ? 1 : 0)));

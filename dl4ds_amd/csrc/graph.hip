@@ -568,6 +568,35 @@ struct ConcatOp : GOp {
     }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
+        // two or more inputs that need a copy, everything dense: one pass over the wide gradient (concat_split)
+        {
+            const TView wide = g.view(out, c.B, true, c.b_off, c.b_cnt);
+            const bool wide_plain = wide.d2s <= 1 && wide.ld == wide.C && wide.nstride == (size_t)wide.H * wide.W * wide.C;
+            ConcatSlice sl[4];
+            int n = 0, off = 0;
+            bool ok = wide_plain && !getenv("DL4DS_NO_CONCAT_SPLIT");
+            for (size_t k = 0; k < ins.size() && ok; ++k) {
+                const GTensor& ti = g.tensors[ins[k]];
+                if (wants_grad(g, ins[k], c) && !ti.galias) {
+                    const TView d = g.view(ins[k], c.B, true, c.b_off, c.b_cnt);
+                    ok = n < 4 && d.d2s <= 1 && d.ld == d.C && d.nstride == (size_t)d.H * d.W * d.C;
+                    const float* mk = nullptr;
+                    if (ok && ti.grad_masked) {
+                        const TView m = g.view(ins[k], c.B, false, c.b_off, c.b_cnt);
+                        ok = m.d2s <= 1 && m.ld == m.C && m.nstride == (size_t)m.H * m.W * m.C && !m.sc;
+                        mk = m.p;
+                    }
+                    if (ok) sl[n++] = ConcatSlice{d.p, mk, off, ti.C, ti.grad_written ? 1 : 0};
+                }
+                off += ti.C;
+            }
+            if (ok && n >= 2) {
+                concat_split(g.stream, wide.p, wide.ld, (size_t)wide.N * wide.H * wide.W, sl, n);
+                for (size_t k = 0; k < ins.size(); ++k)
+                    if (wants_grad(g, ins[k], c)) g.tensors[ins[k]].grad_written = true;
+                return;
+            }
+        }
         for (size_t k = 0; k < ins.size(); ++k) {
             if (!wants_grad(g, ins[k], c)) continue;
             if (g.tensors[ins[k]].galias) { g.tensors[ins[k]].grad_written = true; continue; }     // its gradient IS this slice

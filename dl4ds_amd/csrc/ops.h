@@ -74,6 +74,9 @@ void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TVi
 void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, int accumulate);
 // dst (+)= src * [mask > 0] (mask.p == nullptr: plain copy): Concatenate backward of a ReLU output whose mask the consumers apply
 void view_axpy_masked(hipStream_t s, const TView& src, const TView& mask, const TView& dst, int accumulate);
+// Concatenate backward in one pass over the wide gradient (elementwise.hip): slice k = channels [off, off + C) -> dense dst (+ mask)
+struct ConcatSlice { float* dst; const float* mask; int off, C, accumulate; };
+void concat_split(hipStream_t s, const float* src, int ld, size_t npx, const ConcatSlice* slices, int n);
 // dst (+)= dy * [y > 0]  (flat, contiguous)
 void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate);
 // out = act(a + b)
