@@ -404,6 +404,8 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
         const int htid = tid & 255;
         const int c4 = htid & 1, p0 = htid >> 1;
         const size_t isx = a.in.ld, isy = (size_t)a.W * a.in.ld;
+        const bool ragged = (a.Cin & 3) != 0 || (a.in.ld & 3) != 0;     // quads may reach beyond the end of the view
+        const long in_total = (long)((size_t)(a.in.N - 1) * a.in.nstride + (size_t)a.H * a.W * a.in.ld);
         int rel[ITERS], soff[ITERS], hyx[ITERS];
 #pragma unroll
         for (int u = 0; u < ITERS; ++u) {
@@ -431,8 +433,10 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
                 }
             }
             const long org = (long)((size_t)n * a.in.nstride) + (long)(y0 - 1) * (long)isy + (long)(x0 - 1) * (long)isx;
+            int nrec = 0x7fffff00;
+            if (ragged) { const long rem = (in_total - org) * 4; nrec = rem < 0x7fffff00l ? (int)rem : 0x7fffff00; }
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+                const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, nrec, RSRC3);
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) {
 #if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 3
@@ -646,7 +650,12 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
 bool narrow_pair_ws_ok(const ConvParams& p) {
     static const bool off = getenv("DL4DS_NO_PAIR_WS") != nullptr;
     auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
-    if (off || p.pool || p.in.sc || !p.in.vec || (p.Cin & 3) || p.in.d2s > 1) return false;
+    // inputs whose channel count / pixel pitch is not a multiple of four (the discriminator's 5-channel first layer): the loaders'
+    // 16-byte buffer loads only need dword alignment, what a quad picks up beyond Cin meets zero filter entries, and the
+    // descriptor's exact size makes the buffer unit zero-fill at the very end of the view
+    static const bool no_ragged = getenv("DL4DS_NO_PAIR_WS_RAGGED") != nullptr;
+    if (off || p.pool || p.in.sc || p.in.d2s > 1) return false;
+    if ((!p.in.vec || (p.Cin & 3)) && no_ragged) return false;
     if (p.add.p && !same_layout(p.add, p.out)) return false;
     if (p.mask.p && !same_layout(p.mask, p.out)) return false;
     const size_t r = p.out.d2s > 1 ? p.out.d2s : 1;

@@ -687,6 +687,19 @@ def test_pointwise_conv_odd_channels(ops, n, h, w, ci, co):
     close(ops.conv2d_wgrad(x, dz, 1), gw, 5e-4)
 
 
+@pytest.mark.parametrize('n,h,w,ci,co', [(3, 45, 70, 5, 8), (2, 33, 31, 3, 4), (2, 64, 64, 6, 8), (1, 16, 16, 7, 8), (2, 40, 36, 13, 13),
+                                        (1, 37, 29, 10, 6)])
+def test_narrow_kernels_ragged_input_channels(ops, n, h, w, ci, co):
+    """3x3 layers whose input channel count is not a multiple of four through the float4-staged narrow kernels (the
+    discriminator's 5 -> 8 first layer in the producer / consumer pair kernel, 13 -> 13 in conv_narrow<16>): dword-aligned
+    16-byte loads, the quad that reaches beyond the last pixel of the tensor included."""
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    add = R(n, h, w, co)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, b), ref)
+
+
 @pytest.mark.parametrize('shape', [(5, 40, 36, 1), (3, 24, 50, 2), (4, 9, 8, 1)])
 def test_image_metrics(shape):
     """compute_metrics' reductions (metrics.py:166-262) on the device vs the numpy restatement: PSNR / SSIM / MAE / RMSE /
