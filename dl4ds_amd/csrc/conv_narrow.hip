@@ -724,7 +724,7 @@ struct NarrowWgradParams {
 };
 
 template <int PZ, bool XVEC>     // PZ: dz channels per pixel in LDS: 8 (Cout <= 8) or 16; XVEC: x is float4-loadable
-__global__ void __launch_bounds__(256, 4) conv_narrow_wgrad_kernel(const NarrowWgradParams a) {
+__global__ void __launch_bounds__(256, PZ == 8 ? 4 : 2) conv_narrow_wgrad_kernel(const NarrowWgradParams a) {
     constexpr int TWH = NTW + 2, THH = NTH + 2, HPIX = TWH * THH;
     constexpr int XQ = HPIX * 2;                        // float4s in the x halo tile (8 channels per pixel)
 #ifdef NARROW_WGRAD_NO_P3                               // (variant builds: the five-MFMA form for A/B runs)
