@@ -1,5 +1,6 @@
 """Batch preparation for the headline workload (HR 512^2 fields -> LR 128^2 block means + HR targets, batch 64):
-the reference-style host loop (numpy port) vs the device gather kernels.   python tools/bench_batchprep.py"""
+the reference-style host loop (numpy port) vs the device gather kernels.
+   python tools/bench_batchprep.py [interpolation] [upsampling]      e.g.  bicubic pin"""
 import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +10,10 @@ from dl4ds_amd.dataloader import DataGenerator, DeviceDataGenerator
 lib = L.lib()
 N, H, B, S = 256, 512, 64, 4
 hr = np.random.default_rng(0).random((N, H, H, 1)).astype(np.float32)
-kw = dict(backbone='resnet', upsampling='spc', scale=S, batch_size=B, seed=1)
+INTERP = sys.argv[1] if len(sys.argv) > 1 else 'inter_area'
+UPS = sys.argv[2] if len(sys.argv) > 2 else 'spc'
+kw = dict(backbone='resnet', upsampling=UPS, scale=S, batch_size=B, seed=1, interpolation=INTERP)
+print('interpolation', INTERP, 'upsampling', UPS)
 host, dev = DataGenerator(hr, None, **kw), DeviceDataGenerator(hr, None, **kw)
 t0 = time.perf_counter()
 for i in range(len(host)):
