@@ -28,6 +28,7 @@ struct PointParams {
     const float* w; const float* bias;
     size_t npx;
     int Cin, Cout, relu, accumulate;
+    int ldx;                     // pixel pitch of x in floats (> Cin: x is a channel slice of a wider buffer, e.g. a Concatenate's)
     int SX;                      // floats in the x tile (with slack, multiple of four)
     unsigned m_cin, m_cout;      // magic dividers
 };
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(256) conv_point_kernel(const PointParams a) {
     float* sy = sm + a.SX;                       // [PT][Cout]: the memory layout again
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int Cin = a.Cin, Cout = a.Cout, SY = a.Cout;
+    const int Cin = a.Cin, Cout = a.Cout, SY = a.Cout, LDX = a.ldx;
 
     // filter fragments: first MFMA operand = W^T[cout = 16 t + l15][k = 4 s + lq], zero beyond Cin / Cout
     float wr[NT][KT];
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256) conv_point_kernel(const PointParams a) {
     // LDS tiles keep the memory layout (pitch = channel count): staging and store are straight float4 copies.  The last k-step
     // of a pixel reads up to three floats beyond its channels -- the next pixel's first channels, times ZERO filter entries; the
     // floats behind the last staged pixel are zeroed so that nothing non-finite can be picked up there
-    if (tid < 4 * KT) sx[PT * Cin + tid] = 0.f;
+    if (tid < 4 * KT) sx[PT * LDX + tid] = 0.f;
     // the bias comes from LDS in the epilogue: a global load there would wait for the prefetched loads of the next tile first
     // (vector memory loads return in order), which would expose their whole latency once per tile
     float* sb = sy + PT * SY;
@@ -67,14 +68,15 @@ __global__ void __launch_bounds__(256) conv_point_kernel(const PointParams a) {
     const size_t ntiles = (a.npx + PT - 1) / PT;
     // the tile's float4s go through registers: all of a thread's loads are issued back to back, and the NEXT tile's loads are in
     // flight while this one is multiplied and stored (a full tile is 64 Cin float4s: at most KT per thread)
-    float4 rg[KT];
+    constexpr int RG = KT + 2;       // a full tile is 64 * ldx float4s; the launcher keeps ldx <= 4 KT + 8
+    float4 rg[RG];
     auto issue = [&](size_t tile) __attribute__((always_inline)) {
         const size_t p0 = tile * PT;
         const int np = (a.npx - p0 < (size_t)PT) ? (int)(a.npx - p0) : PT;
-        const float4* src = reinterpret_cast<const float4*>(a.x + p0 * Cin);
-        const int n4 = (np * Cin) >> 2;
+        const float4* src = reinterpret_cast<const float4*>(a.x + p0 * LDX);
+        const int n4 = ((np - 1) * LDX + Cin) >> 2;        // (the last pixel ends with its own channels: nothing is read beyond the view)
 #pragma unroll
-        for (int u = 0; u < KT; ++u) {
+        for (int u = 0; u < RG; ++u) {
             const int i = tid + u * 256;
             rg[u] = (i < n4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -85,15 +87,15 @@ __global__ void __launch_bounds__(256) conv_point_kernel(const PointParams a) {
         const int np = (a.npx - p0 < (size_t)PT) ? (int)(a.npx - p0) : PT;
         // ---- the staged registers -> LDS (same layout as memory); a ragged end element by element
         {
-            const int n = np * Cin, n4 = n >> 2;
+            const int n = (np - 1) * LDX + Cin, n4 = n >> 2;
 #pragma unroll
-            for (int u = 0; u < KT; ++u) {
+            for (int u = 0; u < RG; ++u) {
                 const int i = tid + u * 256;
                 if (i < n4) reinterpret_cast<float4*>(sx)[i] = rg[u];
             }
-            const float* src = a.x + p0 * Cin;
+            const float* src = a.x + p0 * LDX;
             for (int e = 4 * n4 + tid; e < n; e += 256) sx[e] = src[e];
-            if (np < PT && tid < 4 * KT) sx[n + tid] = 0.f;          // (rows beyond np: stale but finite, their results are not stored)
+            if (tid < 4 * KT) sx[n + tid] = 0.f;          // what the last pixel's last k-step reads beyond its channels
         }
         __syncthreads();
         if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256) conv_point_kernel(const PointParams a) {
             f32x4 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float* bp = sx + (wave * 64 + g * 16 + l15) * Cin + lq;
+            const float* bp = sx + (wave * 64 + g * 16 + l15) * LDX + lq;
 #pragma unroll
             for (int s = 0; s < KT; ++s) {
                 const float b = (4 * s < Cin) ? bp[4 * s] : 0.f;                 // (k-steps entirely beyond Cin: uniform skip)
@@ -201,7 +203,11 @@ void dispatch_nt(hipStream_t s, const PointParams& p, size_t lds) {
 bool conv2d_point_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out, const ConvEpilogue& ep) {
     if (KS != 1 || getenv("DL4DS_NO_POINT")) return false;
     if (((in.C & 3) == 0 && (out.C & 3) == 0) || in.C > 64 || out.C > 64 || ep.pool) return false;
-    if (!plain(in) || !plain(out) || (ep.add.p && (!plain(ep.add) || ep.add.C != out.C)) ||
+    // the input may be a channel slice of a wider buffer (pixel pitch ld > C: a Concatenate's buffer): whole pixels of the wide
+    // buffer are staged, the channels outside the slice meet zero filter entries
+    const bool in_ok = in.p && in.d2s <= 1 && !in.sc && in.ld >= in.C && in.nstride == (size_t)in.H * in.W * in.ld &&
+                       ((((uintptr_t)in.p) & 15) == 0) && in.ld <= 4 * (4 * ((((in.C + 3) / 4) + 3) / 4)) + 8;
+    if (!in_ok || !plain(out) || (ep.add.p && (!plain(ep.add) || ep.add.C != out.C)) ||
         (ep.mask.p && (!plain(ep.mask) || ep.mask.C != out.C)))
         return false;
     PointParams p;
@@ -209,13 +215,14 @@ bool conv2d_point_forward(hipStream_t s, const TView& in, const float* w, int KS
     p.npx = (size_t)in.N * in.H * in.W;
     p.Cin = in.C; p.Cout = out.C; p.relu = ep.relu; p.accumulate = ep.accumulate;
     const int kt = (in.C + 3) / 4;
-    p.SX = (PT * in.C + 16 * ((kt + 3) / 4) + 3) & ~3;          // the kernel's k-steps come in groups of four (template KT)
+    p.ldx = in.ld;
+    p.SX = (PT * in.ld + 16 * ((kt + 3) / 4) + 3) & ~3;          // the kernel's k-steps come in groups of four (template KT)
     p.m_cin = div_magic(in.C);
     p.m_cout = div_magic(out.C);
     const size_t lds = ((size_t)p.SX + (size_t)PT * (out.C | 1) + 64) * sizeof(float);
     const double px = (double)p.npx;
     ProfScope ps(s, "conv_point", 2.0 * px * in.C * out.C,
-                 4.0 * px * (in.C + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))));
+                 4.0 * px * (in.ld + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))));
     switch ((kt + 3) / 4) {          // k-steps in groups of four: 16 / 32 / 48 / 64 input channels
         case 1: dispatch_nt<4>(s, p, lds); break;
         case 2: dispatch_nt<8>(s, p, lds); break;
