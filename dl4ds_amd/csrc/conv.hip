@@ -961,7 +961,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams a)
 // (4 pixels apart) fall on two disjoint bank halves.
 template <int CIT, int WCO>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradParams a) {
-    constexpr int KS = 3, COT = 1;
+    [[maybe_unused]] constexpr int KS = 3;
+    constexpr int COT = 1;
     constexpr int TW = 16, TH = 8;
     constexpr int WK = 4 / WCO, RW = TH / WK;            // output rows per wave
     constexpr int PAD = 1;
