@@ -960,10 +960,11 @@ template <int KS, int E>
 void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
     if constexpr (KS == 3 && E >= 6) {
         static const bool use_ws = getenv("DL4DS_STREAM_NO_WS") == nullptr;
-        if (use_ws && NT >= 2) {
+        if (use_ws && (NT >= 2 || (NT == 1 && E == 8 && !getenv("DL4DS_STREAM_NO_WS_NT1")))) {
             const float* w0 = sp.c.w;
             bool done = false;
-            if (NT == 2) done = launch_stream_ws<3, E, 2, 4>(s, sp, N);
+            if (NT == 1) { if constexpr (E == 8) done = launch_stream_ws<3, 8, 1, 4>(s, sp, N); }
+            else if (NT == 2) done = launch_stream_ws<3, E, 2, 4>(s, sp, N);
             else if (NT == 3) done = launch_stream_ws<3, E, 3, 4>(s, sp, N);
             else done = launch_stream_ws<3, E, 4, 4>(s, sp, N);
             if (done) return;
