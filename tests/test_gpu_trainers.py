@@ -401,3 +401,25 @@ def test_predict_on_a_grid_other_than_the_one_the_model_was_built_for():
     lcb = PM.net_postupsampling('resnet', 'spc', 2, 1, 0, (16, 16), n_blocks=1, localcon_layer=True, seed=1)
     with pytest.raises(ValueError, match='localcon_layer'):
         lcb.predict(rng.standard_normal((1, 20, 20, 1)).astype(np.float32))
+
+
+@pytest.mark.parametrize('ups,interp', [('spc', 'bicubic'), ('pin', 'bilinear'), ('rc', 'lanczos')])
+def test_supervised_trainer_other_interpolations_prepare_batches_on_the_device(ups, interp):
+    """`interpolation` other than the default: the trainers still gather their batches on the device (cv2 tap tables,
+    `dl4ds_batch_prepare_taps`), the batches equal the host loader's, and training runs."""
+    from dl4ds_amd.training import SupervisedTrainer
+    from dl4ds_amd.dataloader import DataGenerator, DeviceDataGenerator
+    tr, va, te = _fields(16, 32, 0), _fields(8, 32, 1), _fields(8, 32, 2)
+    t = SupervisedTrainer('resnet', ups, tr, va, te, scale=2, interpolation=interp, batch_size=4, epochs=3, patch_size=16,
+                          learning_rate=2e-3, verbose=False, n_blocks=1, n_filters=4, save=False)
+    t.run()
+    assert isinstance(t.ds_train, DeviceDataGenerator) and t.ds_train.taps
+    assert np.isfinite(t.fithist['loss']).all() and t.fithist['loss'][-1] < t.fithist['loss'][0]
+    host = DataGenerator(tr, None, backbone='resnet', upsampling=ups, scale=2, batch_size=4, patch_size=16,
+                         interpolation=interp, seed=5)
+    dev = DeviceDataGenerator(tr, None, backbone='resnet', upsampling=ups, scale=2, batch_size=4, patch_size=16,
+                              interpolation=interp, seed=5)
+    (xh,), (yh,) = host[0]
+    (xd,), (yd,) = dev[0]
+    np.testing.assert_allclose(xd.numpy(), xh, rtol=0, atol=1e-5 * max(np.abs(xh).max(), 1.0))
+    np.testing.assert_array_equal(yd.numpy(), yh)
