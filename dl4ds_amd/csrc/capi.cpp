@@ -4,6 +4,7 @@
 #include "runtime.h"
 #include "dist.h"
 #include "prof.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -144,7 +145,7 @@ int dl4ds_memset(void* p, int value, size_t bytes) {
 }
 int dl4ds_sync(void) {
     API_BEGIN
-    HIP_CHECK(hipStreamSynchronize(S()));
+    dist_stream_sync(S(), "dl4ds_sync");          // (plain hipStreamSynchronize unless several ranks take part)
     API_END
 }
 int dl4ds_event_timer_start(void) {
@@ -716,6 +717,26 @@ int dl4ds_graph_fusion_report(dl4ds_graph* g, int B, char* json_buf, size_t bufl
     std::memcpy(json_buf, out.c_str(), out.size() + 1);
     API_END
 }
+int dl4ds_graph_bucket_plan(dl4ds_graph* g, char* buf, size_t buflen) {
+    API_BEGIN
+    DL4DS_REQUIRE(g && g->g.finalized, "graph not finalized");
+    // launch order = the order in which the backward pass completes the buckets (largest ready_op first)
+    std::vector<int> order(g->g.buckets.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return g->g.buckets[a].ready_op > g->g.buckets[b].ready_op; });
+    std::string r = "[";
+    for (size_t i = 0; i < order.size(); ++i) {
+        const auto& b = g->g.buckets[order[i]];
+        if (i) r += ",";
+        r += "{\"bytes\":" + std::to_string(b.n * sizeof(float)) + ",\"offset\":" + std::to_string(b.off * sizeof(float)) +
+             ",\"params\":" + std::to_string(b.p_hi - b.p_lo) + ",\"final_after_backward_of_op\":" + std::to_string(b.ready_op) +
+             ",\"of_ops\":" + std::to_string(g->g.ops.size()) + "}";
+    }
+    r += "]";
+    DL4DS_REQUIRE(r.size() + 1 <= buflen, "bucket plan buffer too small");
+    std::memcpy(buf, r.c_str(), r.size() + 1);
+    API_END
+}
 int dl4ds_graph_tensor_ptr(dl4ds_graph* g, int tid, int grad, float** p) {
     API_BEGIN
     const GTensor& t = g->g.tensors.at(tid);
@@ -769,7 +790,7 @@ int dl4ds_trainer_evaluate(dl4ds_trainer* tr, const float* const* inputs, int n_
     DL4DS_REQUIRE(loss_host, "evaluate: loss_host is required");
     trainer_evaluate(*tr->t, inputs, n_inputs, y_true, B, is_host != 0);
     HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
-    HIP_CHECK(hipStreamSynchronize(S()));
+    dist_stream_sync(S(), "dl4ds_trainer_last_loss");
     API_END
 }
 int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, long* step) {
@@ -825,7 +846,7 @@ int dl4ds_trainer_last_loss(dl4ds_trainer* tr, float* loss_host) {
     API_BEGIN
     DL4DS_REQUIRE(tr && tr->t, "not a supervised trainer");
     HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
-    HIP_CHECK(hipStreamSynchronize(S()));
+    dist_stream_sync(S(), "dl4ds_trainer_last_loss");
     API_END
 }
 

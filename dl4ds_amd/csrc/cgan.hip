@@ -42,6 +42,9 @@ CganTrainer* cgan_create(Graph* gen, Graph* disc, int px_loss_kind, float lr, fl
     t->D = trainer_create(disc, LOSS_MAE, c);
     t->px_kind = px_loss_kind;
     t->lam = lam;
+    // BatchNormalization inside the discriminator (discriminator.py:38,50,70): the merged [real ; fake] batch keeps the
+    // statistics of the reference's two calls apart
+    for (auto& op : disc->ops) op->set_batch_groups(2);
     HIP_CHECK(hipMalloc((void**)&t->d_losses, 8 * sizeof(float)));
     HIP_CHECK(hipMemset(t->d_losses, 0, 8 * sizeof(float)));
     return t;
@@ -163,7 +166,7 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
     if (losses_host) {
         float h[4];
         HIP_CHECK(hipMemcpyAsync(h, t.d_losses, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        dist_stream_sync(s, "dl4ds_cgan_step (loss read-back)");
         const float px = h[1] / t.lam;               // loss kernel was scaled by lambda
         losses_host[0] = h[0] + t.lam * px;          // gen_total
         losses_host[1] = h[0];                       // gen_gan

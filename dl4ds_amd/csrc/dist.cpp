@@ -12,13 +12,28 @@
 #include "dist.h"
 #include "runtime.h"
 #include <rccl/rccl.h>
+#include <chrono>
 #include <cstring>
+#include <strings.h>
 #include <cstdlib>
+#include <thread>
 
 namespace {
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_world = 1;
-hipEvent_t g_ev_ready = nullptr, g_ev_ready_aux = nullptr, g_ev_done = nullptr;
+// one "bucket is final" event per bucket launch (a ring, far longer than the number of buckets in flight): a wait captures
+// the record it follows, so a single re-recorded event would be correct too -- separate events keep that from being a
+// property every future edit has to preserve
+constexpr int kEvRing = 128;
+hipEvent_t g_ev_ring[kEvRing] = {};
+int g_ev_next = 0;
+hipEvent_t g_ev_done = nullptr;
+hipEvent_t next_ready_event() {
+    hipEvent_t& e = g_ev_ring[g_ev_next];
+    g_ev_next = (g_ev_next + 1) % kEvRing;
+    if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return e;
+}
 float* g_small = nullptr;            // device scratch of the host-side reductions
 constexpr int kSmallFloats = 1024;
 
@@ -46,9 +61,7 @@ void dist_init(int rank, int world, const char id128[128]) {
     NCCL_CHECK(ncclCommInitRank(&g_comm, world, id, rank));
     g_rank = rank;
     g_world = world;
-    HIP_CHECK(hipEventCreateWithFlags(&g_ev_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&g_ev_ready_aux, hipEventDisableTiming));
 }
 
 void dist_world(int& rank, int& world) {
@@ -59,8 +72,9 @@ void dist_world(int& rank, int& world) {
 void dist_allreduce_grads(float* buf, size_t n, hipStream_t stream) {
     if (g_comm == nullptr || n == 0) return;      // (a 1-rank communicator still runs the collective: smoke-tests the path)
     hipStream_t cs = rt().comm_stream;
-    HIP_CHECK(hipEventRecord(g_ev_ready, stream));
-    HIP_CHECK(hipStreamWaitEvent(cs, g_ev_ready, 0));
+    hipEvent_t ready = next_ready_event();
+    HIP_CHECK(hipEventRecord(ready, stream));
+    HIP_CHECK(hipStreamWaitEvent(cs, ready, 0));
     NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, cs));
     HIP_CHECK(hipEventRecord(g_ev_done, cs));
     HIP_CHECK(hipStreamWaitEvent(stream, g_ev_done, 0));
@@ -71,13 +85,50 @@ bool dist_active() { return g_comm != nullptr; }
 void dist_allreduce_bucket_async(float* buf, size_t n, hipStream_t stream, hipStream_t aux) {
     if (g_comm == nullptr || n == 0) return;
     hipStream_t cs = rt().comm_stream;
-    HIP_CHECK(hipEventRecord(g_ev_ready, stream));
-    HIP_CHECK(hipStreamWaitEvent(cs, g_ev_ready, 0));
+    hipEvent_t ready = next_ready_event();
+    HIP_CHECK(hipEventRecord(ready, stream));
+    HIP_CHECK(hipStreamWaitEvent(cs, ready, 0));
     if (aux) {
-        HIP_CHECK(hipEventRecord(g_ev_ready_aux, aux));
-        HIP_CHECK(hipStreamWaitEvent(cs, g_ev_ready_aux, 0));
+        hipEvent_t ready_aux = next_ready_event();
+        HIP_CHECK(hipEventRecord(ready_aux, aux));
+        HIP_CHECK(hipStreamWaitEvent(cs, ready_aux, 0));
     }
     NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, cs));
+}
+
+// Host-side wait for `stream` with a watchdog.  With more than one rank, work queued behind a collective only completes
+// when EVERY rank has entered that collective: a rank that crashed, skipped a step or called the collectives in another
+// order would leave the others in hipStreamSynchronize for ever.  Poll instead, surface RCCL's asynchronous errors and
+// give up after DL4DS_COLLECTIVE_TIMEOUT_S (default 1800 s) with a message that names the call.
+void dist_stream_sync(hipStream_t stream, const char* what) {
+    if (g_comm == nullptr || g_world <= 1) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
+    static const double limit = [] {
+        const char* e = std::getenv("DL4DS_COLLECTIVE_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 0.0;
+        return v > 0.0 ? v : 1800.0;
+    }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIP_CHECK(e);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > 2e-3) {                                   // short waits stay a pure spin
+            ncclResult_t async = ncclSuccess;
+            if (ncclCommGetAsyncError(g_comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress)
+                throw Dl4dsError(std::string(what) + ": RCCL reported an asynchronous error on rank " + std::to_string(g_rank) +
+                                 " of " + std::to_string(g_world) + ": " + ncclGetErrorString(async));
+            if (waited > limit)
+                throw Dl4dsError(std::string(what) + ": rank " + std::to_string(g_rank) + " of " + std::to_string(g_world) +
+                                 " waited " + std::to_string((long)waited) + " s for work queued behind an RCCL collective -- "
+                                 "another rank has died, skipped a step or entered the collectives in a different order "
+                                 "(DL4DS_COLLECTIVE_TIMEOUT_S sets this limit)");
+            std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.05 ? 20 : 200));
+        }
+    }
 }
 
 void dist_allreduce_wait(hipStream_t stream) {
@@ -92,8 +143,11 @@ void dist_broadcast(float* buf, size_t n, int root, hipStream_t stream) {
 }
 
 int dist_expected_world() {
+    // (same reading as dl4ds_amd.parallel.allow_unsynced: unset, empty, "0", "false", "no", "off" mean NO)
     const char* allow = std::getenv("DL4DS_ALLOW_UNSYNCED");
-    if (allow && allow[0] && allow[0] != '0') return 1;
+    if (allow && allow[0] && std::strcmp(allow, "0") != 0 && strcasecmp(allow, "false") != 0 && strcasecmp(allow, "no") != 0 &&
+        strcasecmp(allow, "off") != 0)
+        return 1;
     const char* w = std::getenv("WORLD_SIZE");
     const int n = w ? std::atoi(w) : 1;
     return n > 1 ? n : 1;
@@ -125,11 +179,11 @@ void dist_allreduce_host(float* host, int n, int op) {
     const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
     NCCL_CHECK(ncclAllReduce(g_small, g_small, n, ncclFloat32, ops[op], g_comm, s));
     HIP_CHECK(hipMemcpyAsync(host, g_small, n * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    dist_stream_sync(s, "dl4ds_dist_allreduce_host");
 }
 
 void dist_barrier() {
-    HIP_CHECK(hipStreamSynchronize(rt().stream));
+    dist_stream_sync(rt().stream, "dl4ds_dist_barrier");
     float one = 1.f;
     dist_allreduce_host(&one, 1, 0);
 }
@@ -150,7 +204,7 @@ void dist_broadcast_i64(long* host_value, int root) {
     HIP_CHECK(hipMemcpyAsync(g_small, host_value, 8, hipMemcpyHostToDevice, s));
     NCCL_CHECK(ncclBroadcast(g_small, g_small, 1, ncclInt64, root, g_comm, s));
     HIP_CHECK(hipMemcpyAsync(host_value, g_small, 8, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    dist_stream_sync(s, "dl4ds_dist_broadcast (optimizer.iterations)");
 }
 
 void dist_finalize() {

@@ -12,6 +12,8 @@ void dist_allreduce_grads(float* buf, size_t n, hipStream_t stream);
 void dist_allreduce_bucket_async(float* buf, size_t n, hipStream_t stream, hipStream_t aux = nullptr);
 void dist_allreduce_wait(hipStream_t stream);
 bool dist_active();
+// hipStreamSynchronize with a watchdog when more than one rank takes part (a stranded peer must fail loudly, not hang)
+void dist_stream_sync(hipStream_t stream, const char* what);
 void dist_broadcast(float* buf, size_t n, int root, hipStream_t stream);
 void dist_finalize();
 // --- fail-safe bring-up (the reference calls hvd.init() itself, training/base.py:97-107): the launcher's WORLD_SIZE is

@@ -69,6 +69,9 @@ struct GOp {
     virtual void on_finalize(Graph& g) {}
     virtual void on_prepare(Graph& g) {}      // after (re)allocation of the activation / gradient buffers
     virtual bool partial_batch_ok() const { return true; }   // backward over a sample sub-range (BwdCtx::b_off / b_cnt)
+    // ops with batch statistics: the forward batch is `groups` independent sub-batches (CGAN: [real ; fake] = the reference's
+    // two discriminator calls), each normalised by its own statistics, moving averages updated group after group
+    virtual void set_batch_groups(int groups) {}
     virtual bool set_mask(Graph& g, const float* host, size_t n) { return false; }   // dropout keep-mask injection
     virtual size_t mask_floats(Graph& g, int B) { return 0; }                         // size of the mask of the last forward
     const char* kind = "op";

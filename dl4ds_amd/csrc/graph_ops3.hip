@@ -18,20 +18,33 @@ struct NormOp : GOp {
     bool batch = false;
     float eps = 1e-3f;
     int relu = 0;
+    int groups = 1;          // BatchNormalization: independent sub-batches of one forward batch (set_batch_groups)
+    int fwd_groups = 1;      // ... as used by the last training-mode forward
     NormOp() { kind = "norm"; }
     size_t npix(Graph& g, int B) const { const GTensor& t = g.tensors[in]; return (size_t)B * t.nmul * t.H * t.W; }
     size_t workspace_bytes(Graph& g, int) override { return norm_workspace_bytes(g.tensors[in].C); }
-    // batch statistics (mean, 1/std) of the last training forward; 2*C floats in total, independent of B
+    // batch statistics (mean, 1/std) of the last training forward; 2*C floats per group (a group holds >= 1 sample, so
+    // 2*C per sample is always enough room)
     size_t saved_floats_per_sample(Graph& g) override { return batch ? 2 * (size_t)g.tensors[in].C : 0; }
+    void set_batch_groups(int n) override { groups = std::max(n, 1); }
     void forward(Graph& g, int B, bool training) override {
         const GTensor& t = g.tensors[in];
-        if (batch)
-            batchnorm_forward(g.stream, t.data, g.wp(gamma), g.wp(beta), g.wp(mov_mean), g.wp(mov_var), g.tensors[out].data,
-                              saved, npix(g, B), t.C, eps, 0.99f, training, relu, g.workspace, g.workspace_bytes);
-        else
+        if (batch) {
+            // one call per group: the reference's discriminator sees the real and the generated batch in two calls
+            // (cgan.py:599-600), each with its own batch statistics and its own moving-average update, real first
+            const int ng = (training && groups > 1 && B % groups == 0) ? groups : 1;
+            if (training) fwd_groups = ng;
+            const size_t gs = (size_t)(B / ng) * t.per_sample();
+            for (int k = 0; k < ng; ++k)
+                batchnorm_forward(g.stream, t.data + k * gs, g.wp(gamma), g.wp(beta), g.wp(mov_mean), g.wp(mov_var),
+                                  g.tensors[out].data + k * gs, saved + (size_t)k * 2 * t.C, npix(g, B / ng), t.C, eps, 0.99f, training,
+                                  relu, g.workspace, g.workspace_bytes);
+        } else {
             layernorm_forward(g.stream, t.data, g.wp(gamma), g.wp(beta), g.tensors[out].data, npix(g, B), t.C, eps, relu);
+        }
     }
-    bool partial_batch_ok() const override { return !batch; }
+    // a partial backward pass is defined for whole groups only (checked in backward)
+    bool partial_batch_ok() const override { return !batch || groups > 1; }
     void backward(Graph& g, const BwdCtx& c) override {
         if (!g.tensors[out].grad_written) return;
         const GTensor& t = g.tensors[in];
@@ -43,10 +56,15 @@ struct NormOp : GOp {
         float* db = c.param_grads ? g.gp(beta) : nullptr;
         const int accw = g.params[gamma].grad_written;
         if (batch) {
-            // the statistics couple every sample of the forward batch: a partial back-propagation has no meaning
-            DL4DS_REQUIRE(c.b_off == 0 && cnt == c.B, "batchnorm: backward over part of the batch is not defined");
-            batchnorm_backward(g.stream, t.data, g.tensors[out].data, g.tensors[out].grad, g.wp(gamma), saved, dxp,
-                               t.grad_written, dg, db, accw, n, t.C, relu, g.workspace, g.workspace_bytes);
+            // the statistics couple every sample of a group: back-propagation runs over whole groups
+            const int ng = fwd_groups, per = c.B / ng;
+            DL4DS_REQUIRE(c.B % ng == 0 && c.b_off % per == 0 && cnt % per == 0,
+                          "batchnorm: backward over part of a statistics group is not defined");
+            const size_t gs = (size_t)per * t.per_sample();
+            for (int k = c.b_off / per, first = 1; k < (c.b_off + cnt) / per; ++k, first = 0)
+                batchnorm_backward(g.stream, t.data + k * gs, g.tensors[out].data + k * gs, g.tensors[out].grad + k * gs, g.wp(gamma),
+                                   saved + (size_t)k * 2 * t.C, dx ? t.grad + k * gs : nullptr, t.grad_written, dg, db,
+                                   first ? accw : 1, (size_t)per * t.nmul * t.H * t.W, t.C, relu, g.workspace, g.workspace_bytes);
         } else {
             layernorm_backward(g.stream, t.data + off, g.tensors[out].data + off, g.tensors[out].grad + off, g.wp(gamma), dxp,
                                t.grad_written, dg, db, accw, n, t.C, eps, relu, g.workspace, g.workspace_bytes);

@@ -79,7 +79,10 @@ void trainer_loss_and_grads(Trainer& t, const float* const* inputs, int n_inputs
     g.zero_grad_flags();
     loss_forward_backward(g.stream, t.loss_kind, yt, o.data, o.grad, B * o.nmul, o.H, o.W, o.C, 1.f, t.d_loss, 0,
                           t.loss_ws, t.loss_ws_bytes);
-    BwdCtx c{B, 0, B, true, false};
+    // (inputs created with dl4ds_graph_input_requires_grad get their gradient too: dl4ds_graph_tensor_ptr(id, grad = 1))
+    bool input_grads = false;
+    for (int i : g.inputs) input_grads = input_grads || g.tensors[i].requires_grad;
+    BwdCtx c{B, 0, B, true, input_grads};
     // data parallel: buckets of the gradient arena are all-reduced on the communication stream as the backward pass
     // finishes them; trainer_step waits for the last one before Adam
     if (reduce_across_ranks && dist_active()) {
@@ -137,6 +140,6 @@ void trainer_step(Trainer& t, const float* const* inputs, int n_inputs, const fl
     trainer_apply_adam(t);
     if (loss_host) {
         HIP_CHECK(hipMemcpyAsync(loss_host, t.d_loss, sizeof(float), hipMemcpyDeviceToHost, g.stream));
-        HIP_CHECK(hipStreamSynchronize(g.stream));
+        dist_stream_sync(g.stream, "dl4ds_trainer_step (loss read-back)");
     }
 }

@@ -12,15 +12,14 @@ def residual_discriminator(n_channels, upsampling, is_spatiotemporal, scale, lr_
     grid by two stride-2 convolutions (scale 4: 'same'; scale 5: 'valid' + a one-pixel crop) or, for any other scale,
     by bilinear resizing (discriminator.py:52-63).  Spatio-temporal: ConvLSTM stem with LayerNormalization on the
     conditioning branch, time-distributed residual blocks, 3-D global pooling (:31-33, :73-74); ``time_window`` sizes
-    the static graph (the reference leaves the axis dynamic)."""
+    the static graph (the reference leaves the axis dynamic).  ``normalization='bn'``: the CGAN step evaluates the real and
+    the generated batch in ONE pass over [real ; fake]; BatchNormalization then normalises the two halves separately and
+    updates its moving averages half after half, which is what the reference's two calls do (csrc/graph_ops3.hip, NormOp)."""
     T = 1
     if is_spatiotemporal:
         if not time_window:
             raise ValueError('the spatio-temporal discriminator needs time_window')
         T = int(time_window)
-    if normalization == 'bn':
-        raise NotImplementedError("discriminator with normalization='bn': the CGAN step evaluates real and fake batches "
-                                  "in one pass, which would merge their batch statistics; use 'ln' or None")
     post = upsampling in POSTUPSAMPLING_METHODS
     if hr_size is None:
         hr_size = (int(lr_size[0] * scale), int(lr_size[1] * scale))

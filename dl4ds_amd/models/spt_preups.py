@@ -6,7 +6,7 @@ from .spt_postups import rec_backbone, rec_tail
 
 @resizable('hr_size')
 def recnet_pin(backbone_block, n_channels, n_aux_channels, hr_size, time_window, n_channels_out=1, n_filters=8,
-               n_blocks=6, dropout_rate=0, dropout_variant=None, normalization=None, attention=False,
+               n_blocks=6, normalization=None, dropout_rate=0, dropout_variant=None, attention=False,
                activation='relu', output_activation=None, localcon_layer=False, seed=None):
     backbone_block = checkarg_backbone(backbone_block)
     dropout_variant = checkarg_dropout_variant(dropout_variant)

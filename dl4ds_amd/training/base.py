@@ -97,15 +97,20 @@ class Trainer(ABC):
             lr = (int(self.patch_size / self.scale),) * 2
         return lr, hr
 
-    def save_results(self, model, folder_prefix=None):
-        """base.py:162-187 -- weights as a named .npz (TF SavedModel is not reproducible without TF), running time,
-        test loss."""
-        if not (self.save and self.running_on_first_worker):
+    def save_results(self, model_to_save=None, folder_prefix=None):
+        """base.py:162-187 -- same signature and file layout: the model goes to
+        ``save_path + [folder_prefix] + <backbone>_<upsampling>/`` (as named weights, ``model_weights.npz``: TF SavedModel is not
+        reproducible without TF), running time and test loss next to it in ``save_path``; first worker only."""
+        if not self.save:
             return
-        prefix = folder_prefix or ''
-        os.makedirs(self.save_path, exist_ok=True)
-        np.savez(os.path.join(self.save_path, prefix + 'model_weights.npz'), **model.get_weights())
+        if model_to_save is None:
+            model_to_save = self.model
+        self.model_save_path = self.save_path + (folder_prefix or '') + self.backbone + '_' + self.upsampling + '/'
+        if not self.running_on_first_worker:
+            return
+        os.makedirs(self.model_save_path, exist_ok=True)
+        np.savez(os.path.join(self.model_save_path, 'model_weights.npz'), **model_to_save.get_weights())
         if hasattr(self, 'running_time'):
-            np.savetxt(os.path.join(self.save_path, prefix + 'running_time.txt'), [self.running_time], fmt='%s')
+            np.savetxt(os.path.join(self.save_path, 'running_time.txt'), [self.running_time], fmt='%s')
         if hasattr(self, 'test_loss'):
-            np.savetxt(os.path.join(self.save_path, prefix + 'test_loss.txt'), [self.test_loss], fmt='%0.6f')
+            np.savetxt(os.path.join(self.save_path, 'test_loss.txt'), [self.test_loss], fmt='%0.6f')

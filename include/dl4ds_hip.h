@@ -221,6 +221,11 @@ int dl4ds_graph_tensor_ptr(dl4ds_graph* g, int tensor_id, int grad, float** p_de
  * (pooling from the producer's epilogue, scale in the consumer's loads, dX in the producer's backward loads): a JSON list,
  * one object per attention layer.  Diagnostics / tests; DL4DS_NO_TAIL_FUSION=1 turns the hand-over off. */
 int dl4ds_graph_fusion_report(dl4ds_graph* g, int B, char* json_buf, size_t buflen);
+/* the gradient buckets of the data-parallel all-reduce (hvd.DistributedOptimizer's fusion buffer, supervised.py:363-365;
+ * hvd.DistributedGradientTape, cgan.py:608-611) in LAUNCH order: a JSON list of {bytes, offset, params,
+ * final_after_backward_of_op, of_ops} -- bucket k's ncclAllReduce is queued on the communication stream as soon as the
+ * backward pass has run forward op number `final_after_backward_of_op` (the tail of the network goes first). */
+int dl4ds_graph_bucket_plan(dl4ds_graph* g, char* json_buf, size_t buflen);
 
 /* ---------------------------------------------------------------- training
  * replaces the Keras fit inner step configured by SupervisedTrainer.run (supervised.py:336-353,396-406):

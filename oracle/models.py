@@ -543,11 +543,13 @@ def recnet_pin(ops, P, x_in, s_in=None, *, backbone_block, time_window, n_channe
 # discriminator  (dl4ds/models/discriminator.py:25-80), spatial 'pin' + scale-4 'same' branches
 def residual_discriminator(ops, P, x_in, x_ref, dropout_mask=None, *, upsampling, scale,
                            lr_size=None, n_filters=8, n_res_blocks=4, activation='relu',
-                           attention=False, normalization=None):
+                           attention=False, normalization=None, ctx=None):
     """discriminator.py:25-80.  5-D inputs (B,T,H,W,C) select the spatio-temporal form: RecurrentConvBlock with
     LayerNormalization on the conditioning branch (:31-33), Conv2D / ResidualBlock applied frame-wise (Keras Conv2D
-    treats the leading axes as batch), GlobalAveragePooling3D (:73-74)."""
-    rb = dict(attention=attention, normalization=normalization)
+    treats the leading axes as batch), GlobalAveragePooling3D (:73-74).  ``ctx``: call mode for BatchNormalization in the
+    residual blocks (:38,50,70) -- ``Ctx(training=True)`` normalises with the statistics of THIS call's batch and records
+    the moving-average updates."""
+    rb = dict(attention=attention, normalization=normalization, ctx=ctx)
     if len(x_in.shape) == 5:
         x1 = b = recurrent_conv_block(ops, P, 'RecurrentConvBlock', x_in, n_filters, activation, normalization='ln')
     else:

@@ -17,6 +17,39 @@ import torch.nn.functional as F
 
 name = 'torch'
 
+# ---- derivative discontinuities (used by tests/parity.py only) -------------------------------------------------------
+# The gradient of a ReLU network is a DISCONTINUOUS function of its inputs: a pre-activation within rounding distance
+# of zero takes either branch depending on summation order, which moves every upstream gradient by that unit's whole
+# contribution (observed between two fp32 evaluations of the same graph: 1e-3 ... 5e-3 of a gradient tensor's size at
+# 128 x 128, where all forward values agree to 4e-7).  With KINK = +d / -d every derivative discontinuity of the graph
+# is displaced by d times the magnitude of its argument -- ReLU / leaky-ReLU / SELU thresholds, the hard-sigmoid clip
+# points, the sign of the MAE residual, max-pooling ties -- which changes forward values by at most that much and
+# decides every near-tie one way (+d) or the other (-d).  The two gradients bracket what any evaluation whose forward
+# rounding error is below d can produce; they coincide when nothing lies within d of a discontinuity.
+KINK = 0.0
+
+
+class kink_shift:
+    def __init__(self, rel):
+        self.rel = float(rel)
+
+    def __enter__(self):
+        global KINK
+        self.prev, KINK = KINK, self.rel
+        return self
+
+    def __exit__(self, *exc):
+        global KINK
+        KINK = self.prev
+        return False
+
+
+def _shifted(x):
+    """x minus KINK * max|x| (x itself when KINK == 0)."""
+    if KINK == 0.0:
+        return x
+    return x - KINK * float(x.detach().abs().max())
+
 
 def asarray(x, dtype=None):
     if isinstance(x, torch.Tensor):
@@ -131,6 +164,11 @@ def resize_bilinear(x, ho, wo):
 
 
 def max_pool2(x):
+    if KINK != 0.0:
+        # near-ties inside a 2 x 2 window: bias the candidates by their position, one way or the other
+        h, w = x.shape[-3], x.shape[-2]
+        pos = (torch.arange(h, dtype=x.dtype).view(-1, 1) % 2) * 2 + (torch.arange(w, dtype=x.dtype).view(1, -1) % 2)
+        x = x + (KINK * float(x.detach().abs().max()) / 3.0) * pos.unsqueeze(-1)
     return _nhwc(F.max_pool2d(_nchw(x), 2))
 
 
@@ -139,7 +177,7 @@ def locally_connected_1x1(x, w, b):
 
 
 def relu(x):
-    return torch.relu(x)
+    return torch.relu(_shifted(x))
 
 
 def sigmoid(x):
@@ -151,14 +189,14 @@ def tanh(x):
 
 
 def hard_sigmoid(x):
-    return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
+    return torch.clamp(0.2 * _shifted(x) + 0.5, 0.0, 1.0)
 
 
 def activation(x, kind):
     if kind is None or kind == 'linear':
         return x
     if kind == 'relu':
-        return torch.relu(x)
+        return torch.relu(_shifted(x))
     if kind == 'sigmoid':
         return torch.sigmoid(x)
     if kind == 'tanh':
@@ -166,9 +204,9 @@ def activation(x, kind):
     if kind == 'elu':
         return F.elu(x)
     if kind == 'leaky_relu':
-        return F.leaky_relu(x, 0.2)
+        return F.leaky_relu(_shifted(x), 0.2)
     if kind == 'selu':
-        return F.selu(x)
+        return F.selu(_shifted(x))
     if kind == 'gelu':
         return F.gelu(x)
     raise ValueError(kind)
@@ -209,7 +247,7 @@ def expand_repeat_time(s, t):
 def channel_attention(x, w1, b1, w2, b2):
     y = mean_hw(x, keepdims=True)
     c = w1.shape[2]
-    y = torch.relu(y @ w1.reshape(c, -1) + b1)
+    y = relu(y @ w1.reshape(c, -1) + b1)
     y = torch.sigmoid(y @ w2.reshape(-1, c) + b2)
     return x * y
 
@@ -273,7 +311,7 @@ def batch_norm(x, gamma, beta, mean, var, eps=1e-3):
 
 # ----------------------------------------------------------------------------
 def mae(y_true, y_pred):
-    return (y_pred - y_true).abs().mean()
+    return _shifted(y_pred - y_true).abs().mean()
 
 
 def mse(y_true, y_pred):

@@ -72,8 +72,22 @@ def cgan_step(gen_model, gen_cfg, PG, disc_cfg, PD, lr_array, hr_array, static_a
     discriminator's Dropout(0.4) (None -> no dropout).  Returns dict of losses/grads."""
     gen = forward(gen_model, gen_cfg, PG, lr_array, static_array)
     mr, mf = (None, None) if dropout_masks is None else dropout_masks
-    d_real = M.residual_discriminator(T, PD, lr_array, hr_array, mr, **disc_cfg)
-    d_fake = M.residual_discriminator(T, PD, lr_array, gen, mf, **disc_cfg)
+    bn_updates = None
+    if disc_cfg.get('normalization') == 'bn':
+        # two training-mode calls (cgan.py:599-600): each normalises with its own batch statistics; the second call
+        # starts from the moving averages the first one left (they do not enter the training-mode output)
+        c_real, c_fake = M.Ctx(training=True), M.Ctx(training=True)
+        d_real = M.residual_discriminator(T, PD, lr_array, hr_array, mr, ctx=c_real, **disc_cfg)
+        PD2 = M.Params()
+        for k, v in PD.items():
+            PD2[k] = v
+        for name, (mm, mv) in c_real.bn_updates.items():
+            PD2[name + '/moving_mean'], PD2[name + '/moving_variance'] = mm.detach(), mv.detach()
+        d_fake = M.residual_discriminator(T, PD2, lr_array, gen, mf, ctx=c_fake, **disc_cfg)
+        bn_updates = {k: (a.detach(), b.detach()) for k, (a, b) in c_fake.bn_updates.items()}
+    else:
+        d_real = M.residual_discriminator(T, PD, lr_array, hr_array, mr, **disc_cfg)
+        d_fake = M.residual_discriminator(T, PD, lr_array, gen, mf, **disc_cfg)
     gan_loss = T.bce(torch.ones_like(d_fake), d_fake)
     px = LOSSES[px_loss](hr_array, gen)
     g_total = gan_loss + lam * px
@@ -89,7 +103,7 @@ def cgan_step(gen_model, gen_cfg, PG, disc_cfg, PD, lr_array, hr_array, static_a
     return dict(gen_total=float(g_total.detach()), gen_gan=float(gan_loss.detach()),
                 gen_px=float(px.detach()), disc=float(d_loss.detach()),
                 gradsG=gG, gradsD=gD, gen=gen.detach(),
-                d_real=d_real.detach(), d_fake=d_fake.detach())
+                d_real=d_real.detach(), d_fake=d_fake.detach(), bn_updates=bn_updates)
 
 
 def synthetic_batch(seed, batch, hr, scale, n_pred=0, dtype=np.float32):

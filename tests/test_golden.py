@@ -70,9 +70,12 @@ def test_hip_reproduces_golden(case):
     assert sorted(grads.keys()) == names
     gmax = g['grad_norms'].max()
     for i, k in enumerate(names):
-        assert abs(np.linalg.norm(grads[k].astype(np.float64)) - g['grad_norms'][i]) < 1e-3 * gmax + 1e-3 * g['grad_norms'][i], k
+        # every tensor at its own scale (the fixture holds each gradient's l2 norm and first four entries)
+        ref_n = g['grad_norms'][i]
+        assert abs(np.linalg.norm(grads[k].astype(np.float64)) - ref_n) <= 1e-3 * max(ref_n, 1e-6 * gmax), k
         head = grads[k].ravel()[:4]
-        assert np.abs(head - g['grad_heads'][i][:head.size]).max() < 1e-3 * max(np.abs(g['grad_heads'][i]).max(), gmax * 1e-2), k
+        rms = ref_n / np.sqrt(grads[k].size)
+        assert np.abs(head - g['grad_heads'][i][:head.size]).max() <= 1e-3 * max(np.abs(g['grad_heads'][i]).max(), rms, 1e-6 * gmax), k
 
 
 @pytest.mark.gpu
@@ -91,4 +94,4 @@ def test_hip_cgan_step_reproduces_golden():
     gg, gd = gen.get_gradients(), disc.get_gradients()
     for names, norms, got in ((g['g_names'], g['g_norms'], gg), (g['d_names'], g['d_norms'], gd)):
         for k, ref in zip(names, norms):
-            assert abs(np.linalg.norm(got[str(k)].astype(np.float64)) - ref) < 1e-3 * norms.max() + 1e-3 * ref, k
+            assert abs(np.linalg.norm(got[str(k)].astype(np.float64)) - ref) <= 1e-3 * max(ref, 1e-6 * norms.max()), k

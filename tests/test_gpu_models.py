@@ -9,6 +9,7 @@ from oracle import np_ops as N
 from oracle import torch_ops as T
 from oracle import models as M
 from oracle import train as TR
+from tests.parity import assert_grads_close, assert_matches_reference, banded_reference, oracle_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -142,12 +143,12 @@ def test_supervised_forward_grads_and_adam_step(kind, cfg, xs, ss, loss):
     eng = SupervisedEngine(model, loss=loss, learning_rate=1e-3)
     l_hip, g_hip = eng.loss_and_grads(inputs, y)
     assert l_hip == pytest.approx(lv, rel=1e-4)
-    gscale = max(float(g.abs().max()) for g in grads.values())
+    # every tensor at its own scale, with the oracle's discontinuity band and fp32 noise floor (tests/parity.py)
+    ref = oracle_reference('supervised', kind, ocfg, model.get_weights(), x, s, y, loss=loss)
+    assert_matches_reference(g_hip, ref, what=(kind, loss))
     steady = {}
     for k in grads:
         gr = grads[k].numpy()
-        err = np.abs(g_hip[k] - gr).max() / gscale
-        assert err < 1e-3, (k, err)
         # Elements whose gradient already differs by > 1 % of its own size: a pre-activation within fp32 rounding of 0
         # takes the other ReLU branch in the fp64 oracle (seen: |pre| = 5e-8 at scale 0.7), which moves a handful of
         # small gradient entries.  Adam divides by |g|, so those entries may move by a whole step; they are excluded
@@ -208,9 +209,8 @@ def test_headline_model_through_producer_consumer_kernels(monkeypatch):
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     l_hip, g_hip = eng.loss_and_grads(inputs, y)
     assert l_hip == pytest.approx(lv, rel=1e-4)
-    gscale = max(float(g.abs().max()) for g in grads.values())
-    for k in grads:
-        assert np.abs(g_hip[k] - grads[k].numpy()).max() / gscale < 1e-3, k
+    ref = oracle_reference('supervised', kind, ocfg, model.get_weights(), x, s, y, loss='mae')
+    assert_matches_reference(g_hip, ref, what='producer / consumer kernels')
 
 
 @pytest.mark.parametrize('n_aux', [0, 2])
@@ -250,9 +250,7 @@ def test_folded_upsampling_tail_equals_unfolded(monkeypatch, ups, scale, n_aux):
     l1, g1 = e1.loss_and_grads(ins, y)
     l2, g2 = e2.loss_and_grads(ins, y)
     assert l1 == pytest.approx(l2, rel=1e-5)
-    gs = max(np.abs(v).max() for v in g2.values())
-    for k in g2:
-        assert np.abs(g1[k] - g2[k]).max() / gs < 1e-4, k
+    assert_grads_close(g1, g2, tol=1e-4, floor=1e-5, what='folded vs unfolded')
     for _ in range(3):
         a, b = e1.step(ins, y), e2.step(ins, y)
         assert a == pytest.approx(b, rel=1e-4)
@@ -270,6 +268,26 @@ def test_cfg2_parameter_count_and_name():
     assert m.output_shape == (64, 64, 1)
     m = PM.net_pin('resnet', 2, 0, (16, 16))
     assert m.count_params() == 121341 and m.name == 'resnet_pin'
+
+
+def _cgan_banded(gkind, gcfg, gw, dcfg, dw, lr, hr, st, mask):
+    """tests/parity.py's reference of one whole-batch CGAN step: generator gradients under 'G:<name>', discriminator
+    gradients under 'D:<name>' (BatchNormalization moving statistics carry no gradient and are left out)."""
+    B = lr.shape[0]
+
+    def call(dt):
+        PG, PD = M.Params(), M.Params()
+        for k, v in gw.items():
+            PG[k] = np.asarray(v, dt)
+        for k, v in dw.items():
+            PD[k] = np.asarray(v, dt)
+        t = lambda a: T.asarray(a.astype(dt))
+        r = TR.cgan_step(gkind, gcfg, M.convert(PG, T, requires_grad=True), dcfg, M.convert(PD, T, requires_grad=True), t(lr), t(hr),
+                         t(st), dropout_masks=(t(mask[:B]), t(mask[B:])))
+        g = {'G:' + k: v for k, v in r['gradsG'].items()}
+        g.update({'D:' + k: v for k, v in r['gradsD'].items()})
+        return [r['gen_total'], r['gen_gan'], r['gen_px'], r['disc']], g, None
+    return banded_reference(call)
 
 
 def test_cgan_step_matches_oracle():
@@ -312,12 +330,8 @@ def test_cgan_step_matches_oracle():
     assert out[2] == pytest.approx(ref['gen_px'], rel=1e-4)
     assert out[3] == pytest.approx(ref['disc'], rel=1e-4)
     gg, gd = gen.get_gradients(), disc.get_gradients()
-    sg = max(float(v.abs().max()) for v in ref['gradsG'].values())
-    sd = max(float(v.abs().max()) for v in ref['gradsD'].values())
-    for k, v in ref['gradsG'].items():
-        assert np.abs(gg[k] - v.numpy()).max() / sg < 1e-3, k
-    for k, v in ref['gradsD'].items():
-        assert np.abs(gd[k] - v.numpy()).max() / sd < 1e-3, k
+    bref = _cgan_banded('unet_pin', gcfg, g0, dcfg, d0, lr, hr, st, mask)
+    assert_matches_reference({'G:' + k: v for k, v in gg.items()} | {'D:' + k: v for k, v in gd.items()}, bref, what='cgan')
     # first Adam step = -lr * sign(g) (to eps): compare against the oracle's updated weights
     for m, P0, Pt in ((gen, g0, PGt), (disc, d0, PDt)):
         w = m.get_weights()
@@ -337,6 +351,12 @@ CGAN_CASES = [
      dict(upsampling='pin', scale=2, n_filters=4, n_res_blocks=1), (8, 8), 1, 2),
     ('recnet_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4, time_window=3, n_filters=4,
                                    n_blocks=1), dict(upsampling='spc', scale=4, n_filters=4, n_res_blocks=1), (4, 6), 4, 3),
+    # BatchNormalization in the discriminator's residual blocks (discriminator.py:38,50,70): the real and the generated
+    # batch are normalised separately (two calls in the reference, two statistics groups of one pass here)
+    ('net_pin', dict(backbone_block='convnet', n_blocks=1, n_filters=4),
+     dict(upsampling='pin', scale=2, n_filters=4, n_res_blocks=1, normalization='bn'), (8, 10), 1, None),
+    ('net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4, n_blocks=1, n_filters=4),
+     dict(upsampling='spc', scale=4, n_filters=4, n_res_blocks=2, normalization='bn', attention=True), (6, 8), 4, None),
 ]
 
 
@@ -354,6 +374,8 @@ def test_cgan_step_discriminator_variants(gkind, gcfg, dcfg, lr_hw, scale, tw):
     n_ch = 2
     if gkind == 'net_postupsampling':
         gen = PM.net_postupsampling(n_channels=n_ch, n_aux_channels=1, lr_size=(h, w), seed=3, **gcfg)
+    elif gkind == 'net_pin':
+        gen = PM.net_pin(n_channels=n_ch, n_aux_channels=1, hr_size=(H, W), seed=3, **gcfg)
     elif gkind == 'recnet_pin':
         gen = PM.recnet_pin(n_channels=n_ch, n_aux_channels=1, hr_size=(H, W), seed=3, **gcfg)
     else:
@@ -367,6 +389,10 @@ def test_cgan_step_discriminator_variants(gkind, gcfg, dcfg, lr_hw, scale, tw):
         for k in wts:
             if k.endswith('bias') or k.endswith('beta'):
                 wts[k] = (rng.standard_normal(wts[k].shape) * 0.05).astype(np.float32)
+            elif k.endswith('gamma'):
+                wts[k] = (1 + 0.1 * rng.standard_normal(wts[k].shape)).astype(np.float32)
+            elif k.endswith('moving_variance'):
+                wts[k] = (0.5 + rng.random(wts[k].shape)).astype(np.float32)
         m.set_weights(wts)
     PG = M.Params(); PD = M.Params()
     for k, v in gen.get_weights().items():
@@ -389,26 +415,37 @@ def test_cgan_step_discriminator_variants(gkind, gcfg, dcfg, lr_hw, scale, tw):
     for i, k in enumerate(('gen_total', 'gen_gan', 'gen_px', 'disc')):
         assert out[i] == pytest.approx(ref[k], rel=1e-4), k
     gg, gd = gen.get_gradients(), disc.get_gradients()
-    sg = max(float(v.abs().max()) for v in ref['gradsG'].values())
-    sd = max(float(v.abs().max()) for v in ref['gradsD'].values())
-    for k, v in ref['gradsG'].items():
-        assert np.abs(gg[k] - v.numpy()).max() / sg < 1e-3, k
-    for k, v in ref['gradsD'].items():
-        assert np.abs(gd[k] - v.numpy()).max() / sd < 1e-3, k
+    bref = _cgan_banded(gkind, gcfg, gen.get_weights(), ocfg, disc.get_weights(), lr, hr, st, mask)
+    assert_matches_reference({'G:' + k: v for k, v in gg.items()} | {'D:' + k: v for k, v in gd.items()}, bref,
+                             what=(gkind, dcfg))
+    if dcfg.get('normalization') == 'bn':
+        # moving averages after the step: updated by the real batch, then by the generated one (cgan.py:599-600)
+        wd = disc.get_weights()
+        assert ref['bn_updates']
+        for name, (mm, mv) in ref['bn_updates'].items():
+            np.testing.assert_allclose(wd[name + '/moving_mean'], mm.numpy(), rtol=2e-4, atol=2e-6, err_msg=name)
+            np.testing.assert_allclose(wd[name + '/moving_variance'], mv.numpy(), rtol=2e-4, atol=2e-6, err_msg=name)
+            assert np.abs(gd[name + '/moving_mean']).max() == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ block variants (f2)
-def _oracle_pass(kind, ocfg, P, x, s, y, loss, ctx_kw, noises, training=True):
-    """Training-mode oracle pass (torch fp64) with the dropout noise the device drew: loss, grads, prediction, ctx."""
-    ctx = M.Ctx(training=training, noises=None if noises is None else [n.astype(np.float64) for n in noises], **ctx_kw)
-    PT = M.convert(P, T, requires_grad=True)
-    pred = M.MODELS[kind](T, PT, T.asarray(x.astype(np.float64)), None if s is None else T.asarray(s.astype(np.float64)),
+def _oracle_pass(kind, ocfg, P, x, s, y, loss, ctx_kw, noises, training=True, dtype=np.float64):
+    """Training-mode oracle pass (torch, fp64 unless told otherwise) with the dropout noise the device drew: loss, grads,
+    prediction, ctx."""
+    ctx = M.Ctx(training=training, noises=None if noises is None else [n.astype(dtype) for n in noises], **ctx_kw)
+    PT = M.convert(P, T, dtype=dtype, requires_grad=True)
+    pred = M.MODELS[kind](T, PT, T.asarray(x.astype(dtype)), None if s is None else T.asarray(s.astype(dtype)),
                           ctx=ctx, **ocfg)
-    lv = TR.LOSSES[loss](T.asarray(y.astype(np.float64)), pred)
+    lv = TR.LOSSES[loss](T.asarray(y.astype(dtype)), pred)
     keys = [k for k in PT if not k.endswith(('moving_mean', 'moving_variance'))]
     gs = torch.autograd.grad(lv, [PT[k] for k in keys], allow_unused=True)
     grads = {k: (np.zeros(PT[k].shape) if g is None else g.numpy()) for k, g in zip(keys, gs)}
     return float(lv.detach()), grads, pred.detach().numpy(), ctx
+
+
+def _banded_pass(kind, ocfg, P, x, s, y, loss, ctx_kw, noises):
+    """tests/parity.py's reference (mid-point of the +/- band evaluations, band, fp32 noise floor) of _oracle_pass."""
+    return banded_reference(lambda dt: _oracle_pass(kind, ocfg, P, x, s, y, loss, ctx_kw, noises, dtype=dt)[:3])
 
 
 VARIANT_CASES = [
@@ -478,9 +515,7 @@ def test_normalization_and_dropout_variants(kind, cfg, var, xs, ss):
                 assert abs(nz.mean() - 1) < 0.05 and abs(nz.std() - np.sqrt(rate / (1 - rate))) < 0.05
     lv, grads, pred, ctx = _oracle_pass(kind, ocfg, P, x, s, y, 'mae', var, noises)
     assert l_hip == pytest.approx(lv, rel=1e-4)
-    gscale = max(np.abs(v).max() for v in grads.values())
-    for k, gr in grads.items():
-        assert np.abs(g_hip[k] - gr).max() / gscale < 1e-3, k
+    assert_matches_reference(g_hip, _banded_pass(kind, ocfg, P, x, s, y, 'mae', var, noises), what=(kind, var))
     w_after = model.get_weights()
     for k in w_after:
         if k.endswith(('moving_mean', 'moving_variance')):
@@ -602,9 +637,7 @@ def test_random_builder_combinations(i):
     noises = [g.dropout_mask(k, xs[0]).reshape(shp) for k, shp in enumerate(probe.noise_shapes)]
     lv, grads, pred, ctx = _oracle_pass(kind, ocfg, P, x, s, y, 'mse', var, noises)
     assert l_hip == pytest.approx(lv, rel=2e-4), (kind, cfg, var)
-    gscale = max(np.abs(v).max() for v in grads.values())
-    for k, gr in grads.items():
-        assert np.abs(g_hip[k] - gr).max() / gscale < 2e-3, (k, kind, cfg, var)
+    assert_matches_reference(g_hip, _banded_pass(kind, ocfg, P, x, s, y, 'mse', var, noises), what=(kind, cfg, var))
 
 
 def _fusion_report(model, B):
@@ -656,9 +689,7 @@ def test_attention_handed_to_neighbouring_convolutions_equals_separate_passes(mo
     lf, gf = ef.loss_and_grads([x], y)
     lp, gp = ep.loss_and_grads([x], y)
     assert lf == pytest.approx(lp, rel=1e-6)
-    gs = max(np.abs(v).max() for v in gp.values())
-    for k in gp:
-        assert np.abs(gf[k] - gp[k]).max() / gs < 2e-5, k
+    assert_grads_close(gf, gp, tol=1e-4, floor=1e-5, what='handed vs separate')
     # a smaller batch after a larger one re-uses the buffers laid out for the larger (fusion addresses must stay valid)
     assert rel(fused(x[:1]), plain(x[:1])) < 2e-6
     for _ in range(3):
@@ -703,9 +734,7 @@ def test_concatenate_without_copies_equals_concatenate_with_copies(monkeypatch, 
     la, ga = ea.loss_and_grads(xs, y)
     ld, gd = ed.loss_and_grads(xs, y)
     assert la == pytest.approx(ld, rel=1e-6)
-    gs = max(np.abs(v).max() for v in gd.values())
-    for k in gd:
-        assert np.abs(ga[k] - gd[k]).max() / gs < 2e-5, k
+    assert_grads_close(ga, gd, tol=1e-4, floor=1e-5, what='aliased vs copied')
     for _ in range(3):
         la, ld = ea.step(xs, y), ed.step(xs, y)
         assert la == pytest.approx(ld, rel=2e-5)

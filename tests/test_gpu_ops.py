@@ -724,3 +724,58 @@ def test_image_metrics(shape):
     rmse_map, corr_map, nmb, full = compute_metrics(y, p, verbose=False)
     assert rmse_map.shape == shape[1:] and full['summary']['PSNR'][0] == pytest.approx(ref['psnr'].mean(), rel=1e-5)
     np.testing.assert_allclose(nmb, ref['bias_map'] / (y.mean() * 100), rtol=2e-4, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ ConvLSTM2D (a6)
+CONVLSTM_CASES = [
+    # B, T, H, W, Cin, F, KS, relu -- the cfg4 shapes (T = 8, 64^2: 5x5 1 -> 8 and 3x3 8 -> 8), wider filters, ragged grids
+    (2, 8, 64, 64, 1, 8, 5, True), (2, 8, 64, 64, 8, 8, 3, True), (1, 8, 64, 64, 2, 4, 5, False),
+    (1, 8, 64, 64, 4, 16, 3, True), (2, 8, 64, 64, 3, 16, 5, False), (1, 8, 64, 64, 8, 4, 3, False),
+    (2, 8, 37, 23, 2, 8, 5, True), (1, 8, 19, 50, 5, 4, 3, True), (3, 3, 9, 7, 1, 16, 3, False),
+]
+
+
+@pytest.mark.parametrize('B,Tn,H,W,C,F,KS,relu', CONVLSTM_CASES)
+def test_conv_lstm2d(B, Tn, H, W, C, F, KS, relu):
+    """ConvLSTM2D(F, k, 'same', return_sequences=True) [+ ReLU] as ONE op (blocks.py:350-355; gates i, f, c, o,
+    hard-sigmoid recurrent activation, h0 = c0 = 0): output and -- through an MSE loss -- dX, dK (input kernel), dU
+    (recurrent kernel) and db against the fp64 torch oracle, every gradient at its own scale."""
+    import ctypes
+    from dl4ds_amd import _lib
+    from dl4ds_amd.graph import GraphBuilder, Model
+    from dl4ds_amd.training import SupervisedEngine
+    from tests.parity import assert_matches_reference, banded_reference
+    r = np.random.default_rng(1000 * KS + 10 * F + C + H)
+    gb = GraphBuilder()
+    xin = gb.input(H, W, C, nmul=Tn, requires_grad=True)
+    out = gb.convlstm(xin, 'lstm', F, KS, Tn, activation='relu' if relu else None)
+    gb.finalize(out, seed=1)
+    model = Model(gb, 'convlstm_only', [(Tn, H, W, C)])
+    w = model.get_weights()
+    w['lstm/bias'] = (w['lstm/bias'] + 0.1 * r.standard_normal(4 * F)).astype(np.float32)
+    # inputs large enough that the hard sigmoids saturate in places (both clip branches of the backward pass run)
+    w['lstm/kernel'] = (w['lstm/kernel'] * 2.0).astype(np.float32)
+    model.set_weights(w)
+    x = (1.5 * r.standard_normal((B, Tn, H, W, C))).astype(np.float32)
+    y = r.standard_normal((B, Tn, H, W, F)).astype(np.float32)
+    def call(dt):
+        t = lambda a: torch.tensor(np.asarray(a, dt), requires_grad=True)
+        xt, kt, ut, bt = t(x), t(w['lstm/kernel']), t(w['lstm/recurrent_kernel']), t(w['lstm/bias'])
+        out = T.conv_lstm2d(xt, kt, ut, bt)
+        if relu:
+            out = T.relu(out)
+        loss = ((out - torch.tensor(y.astype(dt))) ** 2).mean()
+        gx, gk, gu, gb_ = torch.autograd.grad(loss, [xt, kt, ut, bt])
+        return float(loss), {'x': gx, 'lstm/kernel': gk, 'lstm/recurrent_kernel': gu, 'lstm/bias': gb_}, out.detach()
+    # reference = mid-point of the evaluations with the hard-sigmoid / ReLU kinks displaced by +/- 4e-6, tests/parity.py
+    ref = banded_reference(call)
+    got = model([x])
+    close(got, ref['pred'])
+    eng = SupervisedEngine(model, loss='mse', learning_rate=1e-3)
+    l_hip, g_hip = eng.loss_and_grads([x], y)
+    assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
+    p = ctypes.c_void_p()
+    _lib.check(_lib.lib().dl4ds_graph_tensor_ptr(gb.h, xin.id, 1, ctypes.byref(p)))
+    dx = np.empty(x.shape, np.float32)
+    _lib.check(_lib.lib().dl4ds_memcpy_d2h(dx.ctypes.data, p, dx.nbytes))
+    assert_matches_reference(dict(g_hip, x=dx), ref, what=(B, Tn, H, W, C, F, KS, relu))
