@@ -62,9 +62,12 @@ def synthetic_batch(seed, batch, hr=512, scale=4):
     return block_mean(y, scale).astype(np.float32), y.astype(np.float32)
 
 
-def cpu_baseline(weights, budget_s=25.0):
-    """The oracle (torch-CPU restatement of the identical graph, fp32) timed on a bounded sample of the same workload:
-    B=4 at 128->512, thread count = fastest of 16/32/64, median of 3 steps after warm-up."""
+def cpu_baseline(weights, budget_s=30.0):
+    """The oracle (torch-CPU restatement of the identical graph, fp32, oneDNN convolutions) timed on a bounded sample of the
+    same workload: B = 16 at 128 -> 512, the thread count swept over 16 / 32 / 64 / 128 (one thread per physical core on
+    the 2 x 64-core host) / all hardware threads, best of two steps after a warm-up step per count; the best count is
+    reported with the whole sweep.  (numactl is not in the image, so memory placement is the kernel's first-touch
+    default; SURVEY.md section 8d asks for all physical cores, printed -- `cores`, `cores_total`, `sweep`.)"""
     import torch
     from oracle import torch_ops as T  # noqa: F401
     from oracle import models as M
@@ -75,7 +78,7 @@ def cpu_baseline(weights, budget_s=25.0):
     for k, v in weights.items():
         P[k] = torch.from_numpy(np.array(v, np.float32)).requires_grad_(True)
     opt = TR.Adam(P, lr=1e-3)
-    b = 4
+    b = 16
     x, y = synthetic_batch(4242, b)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
 
@@ -84,28 +87,29 @@ def cpu_baseline(weights, budget_s=25.0):
         TR.supervised_step('net_postupsampling', cfg, P, xt, None, yt, loss='mae', opt=opt)
         return time.perf_counter() - t0
 
-    # oneDNN does not scale to every hardware thread on this graph (2x64-core host: 256 threads are ~100x
-    # slower than 32): probe a few thread counts for a couple of seconds each and keep the fastest.
     t_all = time.perf_counter()
-    best = None
-    for threads in sorted({min(ncpu, t) for t in (16, 32, 64)}):
+    sweep, best = {}, None
+    for threads in sorted({min(ncpu, t) for t in (16, 32, 64, 128, ncpu)}):
+        if time.perf_counter() - t_all > budget_s:
+            sweep[str(threads)] = 'skipped (time budget)'
+            continue
         torch.set_num_threads(threads)
         first = step()                                     # warm-up for this thread count
-        if first > 8.0 or time.perf_counter() - t_all > budget_s:
+        if first > 10.0:                                   # (oneDNN collapses when oversubscribed: do not spend the budget there)
+            sweep[str(threads)] = round(b / first, 2)
+            if best is None:
+                best = (threads, first)
             continue
         dt = min(step(), step())
+        sweep[str(threads)] = round(b / dt, 2)
         if best is None or dt < best[1]:
             best = (threads, dt)
-    if best is None:
-        best = (torch.get_num_threads(), first)
-    threads, _ = best
-    torch.set_num_threads(threads)
-    times = [step() for _ in range(3)]
-    dt = float(np.median(times))
+    threads, dt = best
     return {'value': b / dt, 'unit': 'HR samples/s', 'cores': threads, 'cores_total': ncpu, 'kind': 'port',
-            'sample': f'oracle torch-CPU (oneDNN) fp32 train step (fwd+MAE+bwd+Adam), B={b} at 128->512, median of '
-                      f'3 steps after warm-up; {threads} threads = fastest of 16/32/64 on a host with {ncpu} hardware '
-                      'threads (oneDNN gets slower beyond that on this graph)'}
+            'sweep_samples_per_s_by_threads': sweep,
+            'sample': f'oracle torch-CPU (oneDNN) fp32 train step (fwd+MAE+bwd+Adam), B={b} at 128->512, best of 2 steps after '
+                      f'a warm-up step per thread count; {threads} threads = fastest of the sweep on a host with {ncpu} '
+                      'hardware threads'}
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -206,6 +210,16 @@ def spawn_ranks(n, argv):
         for q in procs:
             q.kill()
     return rc
+
+
+def bucket_plan(model):
+    """The gradient buckets of the model's arena in launch order (dl4ds_graph_bucket_plan)."""
+    import dl4ds_amd._lib as L
+    buf = ctypes.create_string_buffer(1 << 16)
+    L.check(L.lib().dl4ds_graph_bucket_plan(model.graph.h, buf, len(buf)))
+    plan = json.loads(buf.value.decode())
+    return {'buckets': len(plan), 'bytes': [b['bytes'] for b in plan],
+            'final_after_backward_of_op': [b['final_after_backward_of_op'] for b in plan], 'forward_ops': plan[0]['of_ops'] if plan else 0}
 
 
 def main():
@@ -323,11 +337,13 @@ def main():
             if os.path.exists(tfile):
                 try:
                     tj = json.load(open(tfile))
-                    traffic = tj.get(dom)
+                    # keyed by config, then by kernel tag: PMC bytes of ANOTHER config's launch of a same-named kernel
+                    # (another shape) are not this kernel's traffic -- no entry, no number
+                    traffic = (tj.get(args.config) or {}).get(dom)
                     if traffic is not None:
                         traffic_source = ('profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
-                                          'command on an earlier run (' + str(tj.get('_round', 'r01')) + '), not measured in '
-                                          'this run')
+                                          'command (--config ' + args.config + ') on an earlier run (' + str(tj.get('_round', 'r01')) +
+                                          '), not measured in this run')
                 except Exception:
                     traffic = None
             roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
@@ -349,7 +365,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': wl['describe'], 'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}', 'loss_after_run': loss},
-            'rccl': {'nranks': comm['nranks'], 'launcher_world': world} if dist_on else None,
+            'rccl': {'nranks': comm['nranks'], 'launcher_world': world, 'bucket_plan': bucket_plan(model)} if dist_on else None,
             # executed FLOPs (library profiler, rank 0) over the measured step time
             'step_tflops_per_gpu': (executed_gflop_per_step / ms_step) if executed_gflop_per_step else None,
             'mfma_conv_frac_of_peak': (mfma_gflop_per_step / ms_step / PEAK_FP32_MFMA_TFLOPS) if mfma_gflop_per_step else None,

@@ -12,6 +12,7 @@
 #include "dist.h"
 #include "runtime.h"
 #include <rccl/rccl.h>
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <strings.h>
@@ -28,6 +29,25 @@ constexpr int kEvRing = 128;
 hipEvent_t g_ev_ring[kEvRing] = {};
 int g_ev_next = 0;
 hipEvent_t g_ev_done = nullptr;
+// DL4DS_DIST_STANDIN=1 (profiling aid, profiles/rccl_overlap_*.txt): a 1-rank communicator's in-place all-reduce launches
+// NO device kernel (RCCL returns early), and RCCL refuses two ranks on one GPU, so a single-GPU trace cannot show where the
+// collectives sit.  With this switch every bucket launch is followed, on the communication stream, by a stand-in kernel
+// that reads and rewrites the bucket (values unchanged): the trace then shows the stream / event topology -- what runs
+// concurrently with the backward pass and what Adam waits for.  It is NOT a collective and says so in its name.
+__global__ void standin_for_rccl_allreduce_kernel(float* buf, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = buf[i];
+        asm volatile("" : "+v"(v));
+        buf[i] = v;
+    }
+}
+void launch_standin(float* buf, size_t n, hipStream_t cs) {
+    static const bool on = std::getenv("DL4DS_DIST_STANDIN") != nullptr;
+    if (!on || g_world != 1) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 64);      // few workgroups: a collective occupies few CUs
+    hipLaunchKernelGGL(standin_for_rccl_allreduce_kernel, dim3(blocks), dim3(256), 0, cs, buf, n);
+    HIP_CHECK(hipGetLastError());
+}
 hipEvent_t next_ready_event() {
     hipEvent_t& e = g_ev_ring[g_ev_next];
     g_ev_next = (g_ev_next + 1) % kEvRing;
@@ -94,6 +114,7 @@ void dist_allreduce_bucket_async(float* buf, size_t n, hipStream_t stream, hipSt
         HIP_CHECK(hipStreamWaitEvent(cs, ready_aux, 0));
     }
     NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, cs));
+    launch_standin(buf, n, cs);
 }
 
 // Host-side wait for `stream` with a watchdog.  With more than one rank, work queued behind a collective only completes

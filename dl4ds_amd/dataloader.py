@@ -5,8 +5,8 @@ square crops, coarsening by `scale` (cv2.INTER_AREA at an integer ratio == block
 'pin' models, predictor / static-variable channel stacking, spatio-temporal windows.  OpenCV is not a
 dependency here: ``cv2.resize`` is evaluated from OpenCV's published formulas (resize.cpp) as separable
 gathers -- INTER_AREA (integer-ratio block mean; up-scaling through OpenCV's own bilinear-path coefficients,
-which replicate pixels at integer factors), INTER_NEAREST, INTER_LINEAR (half-pixel centres, edge clamp) and
-INTER_CUBIC (A = -0.75, replicated border); INTER_LANCZOS4 is refused.  oracle/dataprep.py restates the same
+which replicate pixels at integer factors), INTER_NEAREST, INTER_LINEAR (half-pixel centres, edge clamp),
+INTER_CUBIC (A = -0.75, replicated border) and INTER_LANCZOS4 (8 taps, replicated border).  oracle/dataprep.py restates the same
 formulas independently (dense per-pixel form) and tests/test_oracle_dataprep.py compares the two.
 Season/time-metadata channels are not implemented.
 """
@@ -399,13 +399,16 @@ class DeviceDataGenerator:
         self._pred, self.P = None, 0
         if predictors is not None:
             p = np.concatenate([np.asarray(q, np.float32) for q in predictors], axis=-1)
-            assert p.shape[:3] == a.shape[:3], 'predictors must share the HR grid'
+            if p.shape[:3] != a.shape[:3]:
+                # predictors already on the LR / an intermediate grid (dataloader.py:158-163): the host generator's case
+                raise NotImplementedError('DeviceDataGenerator: predictors must share the HR grid')
             self._pred, self.P = DeviceArray.from_numpy(p), p.shape[-1]
         self._stat, self.S = None, 0
         if static_vars is not None:
             sv = [checkarray_ndim(np.squeeze(np.asarray(getattr(v, 'values', v), np.float32)), 3) for v in static_vars]
             st = np.concatenate(sv, axis=-1)
-            assert st.shape[:2] == (self.H, self.W), 'static variables must share the HR grid'
+            if st.shape[:2] != (self.H, self.W):
+                raise NotImplementedError('DeviceDataGenerator: static variables must share the HR grid')
             self._stat, self.S = DeviceArray.from_numpy(st), st.shape[-1]
         self.n = self.N - self.T if self.spt else self.N
         self.rng = np.random.default_rng(seed)

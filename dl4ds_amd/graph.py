@@ -467,14 +467,40 @@ class Model:
         if kwargs.get('localcon_layer'):
             # LocallyConnected2D weights are per grid point: the reference fixes the Input shape too (sp_postups.py:106-115)
             raise ValueError('a model with localcon_layer=True is tied to the grid it was built for')
-        cache = self.__dict__.setdefault('_resized_cache', {})
+        cache = self.__dict__.setdefault('_resized_cache', OrderedDict())
         grid = (int(grid[0]), int(grid[1]))
         m = cache.get(grid)
         if m is None:
             m = fn(**dict(kwargs, **{size_key: grid}))
             cache[grid] = m
-        m.set_weights(self.get_weights())
+            while len(cache) > self.RESIZED_CACHE_GRIDS:       # least recently used grid goes (its graph frees its HBM)
+                cache.popitem(last=False)
+        else:
+            cache.move_to_end(grid)
+        self._copy_weights_to(m)
         return m
+
+    RESIZED_CACHE_GRIDS = 4
+
+    def _arena(self):
+        w, g = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(self.graph._l.dl4ds_graph_arena_ptrs(self.graph.h, ctypes.byref(w), ctypes.byref(g)))
+        n, k = ctypes.c_size_t(), ctypes.c_int()
+        _lib.check(self.graph._l.dl4ds_graph_param_count(self.graph.h, ctypes.byref(n), ctypes.byref(k)))
+        return w, n.value
+
+    def _copy_weights_to(self, other):
+        """Current weights -> a sibling graph of the same architecture: the parameter arenas have the same layout (no
+        parameter of a resizable model depends on the grid), so ONE device-to-device copy replaces the per-variable
+        download + upload (13.6 M parameters for the U-Net)."""
+        (src, n), (dst, m) = self._arena(), other._arena()
+        same = n == m and [(k, p['shape']) for k, p in self.graph.params.items()] == \
+            [(k, p['shape']) for k, p in other.graph.params.items()]
+        if same and n:
+            _lib.check(self.graph._l.dl4ds_memcpy_d2d(dst, src, n * 4))
+            _lib.check(self.graph._l.dl4ds_sync())
+        else:
+            other.set_weights(self.get_weights())
 
     def summary(self, line_length=100, print_fn=print):
         print_fn(f'Model: "{self.name}"')

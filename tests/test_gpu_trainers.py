@@ -395,6 +395,15 @@ def test_predict_on_a_grid_other_than_the_one_the_model_was_built_for():
     w2 = {k: (v * np.float32(0.5)).astype(np.float32) for k, v in w.items()}
     m.set_weights(w2); direct.set_weights(w2)
     np.testing.assert_array_equal(m.predict(x), direct.predict(x))                        # cached sibling follows the weights
+    # ... also when the weights change on the DEVICE (an optimiser step), and the cache of re-planned graphs stays bounded
+    from dl4ds_amd.training import SupervisedEngine
+    SupervisedEngine(m, loss='mae', learning_rate=1e-2).step([rng.standard_normal((2, 16, 16, 1)).astype(np.float32)],
+                                                             rng.standard_normal((2, 64, 64, 1)).astype(np.float32))
+    direct.set_weights(m.get_weights())
+    np.testing.assert_array_equal(m.predict(x), direct.predict(x))
+    for g in ((8, 8), (9, 12), (12, 9), (10, 10), (11, 8)):
+        assert m.predict(rng.standard_normal((1,) + g + (1,)).astype(np.float32)).shape == (1, 4 * g[0], 4 * g[1], 1)
+    assert len(m._resized_cache) == m.RESIZED_CACHE_GRIDS == 4 and (24, 20) not in m._resized_cache
     pin = PM.unet_pin('unet', 2, 1, hr_size=(32, 32), n_filters=4, n_blocks=2, seed=3)
     xs = [rng.standard_normal((2, 48, 40, 2)).astype(np.float32), rng.standard_normal((2, 48, 40, 1)).astype(np.float32)]
     assert pin.predict(xs).shape == (2, 48, 40, 1)

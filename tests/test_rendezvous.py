@@ -121,3 +121,75 @@ def test_bench_port_pair_is_free():
         s = socket.socket()
         s.bind(('127.0.0.1', port))
         s.close()
+
+
+def test_bad_peers_do_not_take_rank_zero_down(monkeypatch):
+    """A stale client of another job (wrong world size), a peer that hangs up in the middle of the hello and a port scanner
+    reach rank 0 before the real rank 1 does: rank 0 rejects them, keeps serving and completes the exchange."""
+    import struct
+    import threading
+    import time
+    from dl4ds_amd import parallel
+    port = _free_port()
+    ep = ('127.0.0.1', port)
+    out = {}
+    t = threading.Thread(target=lambda: out.setdefault('root', parallel.exchange_bytes(b'I' * 128, 0, 2, timeout=30.0, endpoint=ep)))
+    t.start()
+
+    def connect():
+        for _ in range(200):
+            try:
+                return socket.create_connection(ep, timeout=2.0)
+            except OSError:
+                time.sleep(0.02)
+        raise AssertionError('rank 0 never listened')
+    with connect() as c:                                     # another job's rank: "rank 1 of 4"
+        c.sendall(parallel._MAGIC + struct.pack('<ii', 1, 4))
+        assert struct.unpack('<i', parallel._recv_exact(c, 4))[0] == -1
+    with connect() as c:                                     # dies half-way through the hello
+        c.sendall(parallel._MAGIC[:4])
+    with connect() as c:                                     # not this protocol at all
+        c.sendall(b'GET / HTTP/1.0\r\n\r\n' + b' ' * 16)
+    got = parallel.exchange_bytes(b'', 1, 2, timeout=30.0, endpoint=ep)
+    t.join(timeout=30)
+    assert got == b'I' * 128 and out['root'] == b'I' * 128
+
+
+def test_rendezvous_token_must_match(monkeypatch):
+    import threading
+    from dl4ds_amd import parallel
+    port = _free_port()
+    ep = ('127.0.0.1', port)
+    monkeypatch.setenv('DL4DS_RDZV_TOKEN', 'job-1234')
+    err = {}
+
+    def root():
+        try:
+            parallel.exchange_bytes(b'I' * 128, 0, 2, timeout=3.0, endpoint=ep)
+        except TimeoutError as e:
+            err['root'] = str(e)
+    t = threading.Thread(target=root)
+    t.start()
+    import struct, time
+    for _ in range(200):
+        try:
+            c = socket.create_connection(ep, timeout=2.0)
+            break
+        except OSError:
+            time.sleep(0.02)
+    with c:                                                  # right rank and world, wrong secret: no id for this peer
+        c.sendall(parallel._MAGIC + struct.pack('<ii', 1, 2) + b'job-9999')
+        assert struct.unpack('<i', parallel._recv_exact(c, 4))[0] == -1
+    t.join(timeout=30)
+    assert 'wrong token' in err['root']
+
+
+@pytest.mark.parametrize('value,expect', [(None, False), ('', False), ('0', False), ('false', False), ('No', False), ('off', False),
+                                          ('1', True), ('yes', True), ('true', True)])
+def test_allow_unsynced_reads_the_variable_like_the_library(monkeypatch, value, expect):
+    from dl4ds_amd import parallel
+    if value is None:
+        monkeypatch.delenv('DL4DS_ALLOW_UNSYNCED', raising=False)
+    else:
+        monkeypatch.setenv('DL4DS_ALLOW_UNSYNCED', value)
+    assert parallel.allow_unsynced() is expect
