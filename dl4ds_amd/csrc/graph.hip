@@ -101,7 +101,10 @@ void Graph::plan_buckets(size_t target_bytes) {
         cur.p_hi = pid + 1;
         cur.n = end - cur.off;
         end_prev = end;
-        if (cur.n * sizeof(float) >= target_bytes || pid + 1 == (int)params.size()) {
+        // the bucket that holds the FIRST parameters of the arena is the last one to become final (its collective has only
+        // the optimiser behind it to hide under): keep it small -- 256 KB is still latency-bound on xGMI
+        const size_t want = buckets.empty() ? std::min<size_t>(target_bytes, 256 << 10) : target_bytes;
+        if (cur.n * sizeof(float) >= want || pid + 1 == (int)params.size()) {
             buckets.push_back(cur);
             cur = GradBucket();
             cur.p_lo = pid + 1; cur.off = end; cur.ready_op = (int)ops.size();
