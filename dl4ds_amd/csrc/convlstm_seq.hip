@@ -1,0 +1,466 @@
+// ConvLSTM2D as ONE launch per layer and direction -- dl4ds/models/blocks.py:339-398 (RecurrentConvBlock: ConvLSTM2D 5x5
+// then 3x3, return_sequences=True, tf.keras-2 defaults: tanh / hard_sigmoid, gate order i, f, c, o, zero initial state).
+//
+// The input convolution of all T frames is one batched launch of the ordinary convolution kernels (graph_ops2.hip).  What
+// is left is the recurrence: for every time step a convolution of h_{t-1} with the recurrent kernel, the gate arithmetic,
+// and -- backwards -- the same in reverse time.  Run step by step that is 2 T small launches per layer and direction (64^2
+// frames x 16 samples = 256 tiles: every launch under-fills the chip, starts cold and pays a kernel boundary).  Here the
+// whole sequence runs inside ONE persistent kernel:
+//   * a workgroup owns 16 x 16-pixel tiles for all T steps; the recurrent filter sits in LDS, already in MFMA A-fragment
+//     order, for the whole launch;
+//   * per step: stage the tile + halo of h_{t-1} (backward: of dZ_{t+1}) into LDS, implicit GEMM on v_mfma_f32_16x16x4_f32
+//     with the GATE dimension on the MFMA rows, and the gate arithmetic straight on the accumulators: the gate channels are
+//     kept interleaved (channel 4 f + gate) in every internal buffer, so the four rows a lane holds are the i, f, g, o
+//     pre-activations of ONE (pixel, filter) and z / dz move as float4;
+//   * steps are ordered by a flag per tile, not by a grid barrier: tile X may start step t once its 3 x 3 tile
+//     neighbourhood has published step t-1 (agent-scope release -> relaxed flag -> relaxed poll by one lane -> ONE
+//     agent-scope acquire -> __syncthreads: MI355X_MICROARCH.md "inter-workgroup visibility" -- per-XCD L2s are not
+//     coherent, a CU's L1 is never refreshed by other CUs' stores).  Tiles of one image are dealt to one XCD (blockIdx % 8)
+//     so that halo exchange stays inside an L2 -- speed only, never correctness.
+// Every block of the grid must be resident (a tile waits for its neighbours): grid <= CUs (one 256-thread block per CU,
+// LDS-bound), flags zeroed by a memset node ahead of every launch, every spin bounded.
+#include "ops.h"
+#include "prof.h"
+#include "head.h"
+#include <algorithm>
+
+namespace {
+
+int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        return v;
+    }();
+    return n;
+}
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+using gu32 = __attribute__((address_space(1))) unsigned;
+
+__device__ __forceinline__ float hsig(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
+__device__ __forceinline__ float dhsig(float z) { return (z >= -2.5f && z <= 2.5f) ? 0.2f : 0.f; }
+
+constexpr unsigned SPIN_LIMIT = 1u << 22;       // ~seconds: a lost neighbour yields wrong numbers, never a hung GPU
+
+template <int KS, int F, bool BWD>
+struct Geom {
+    static constexpr int TS = 16;
+    static constexpr int TW = TS + KS - 1;
+    static constexpr int CIN = BWD ? 4 * F : F;             // channels of the staged tensor (dZ' : h)
+    static constexpr int NQ = CIN / 4;                      // ... in quads
+    static constexpr int RT = BWD ? 1 : F / 4;              // MFMA row tiles: 4F gate rows forward, F (<= 16) rows backward
+    static constexpr int KSTEPS = KS * KS * NQ;
+    static constexpr int W_FLOATS = KSTEPS * RT * 64;
+    static constexpr int TILE_FLOATS = TW * TW * CIN;
+    static constexpr int XCH_FLOATS = BWD ? 0 : 3 * 256 * F;   // forward: h, c, out of a tile on their way to 16-byte stores
+    static constexpr size_t LDS_BYTES = (size_t)(W_FLOATS + TILE_FLOATS + XCH_FLOATS) * sizeof(float);
+};
+
+struct SeqParams {
+    const float* U;        // (KS*KS, F, 4F) recurrent kernel, gate-interleaved columns
+    float* Z;              // (B,T,H,W,4F) interleaved: forward in = x-part + bias, out = z; backward in
+    float* C;              // (B,T,H,W,F) cell states
+    float* Hrec;           // (B,T,H,W,F): frame t = h_{t-1} (frame 0 = 0), written by the forward kernel
+    float* out;            // (B,T,H,W,F) layer output ([relu](h_t)); backward: read for the ReLU mask
+    const float* dout;     // backward: gradient of out
+    float* dZ;             // backward out: (B,T,H,W,4F) interleaved
+    float* dc;             // backward scratch: (B,H,W,F) running dL/dc
+    unsigned* flags;       // [tiles]: steps completed by each tile (zeroed before the launch)
+    int B, T, H, W, tiles_x, tiles_y, ntiles, relu;
+};
+
+// tile index of this block's i-th tile: consecutive tiles (= the tiles of one image) go to blocks of ONE XCD
+__device__ __forceinline__ int my_tile(int i, int grid) {
+    const int b = blockIdx.x;
+    const int per = grid >> 3;
+    const int lin = (grid & 7) ? b : (b & 7) * per + (b >> 3);
+    return i * grid + lin;
+}
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+constexpr int RSRC3 = 0x00020000;
+constexpr int AUX_SC1 = 16;                     // buffer_load / buffer_store ... sc1: bypass L1 / write through (agent-visible)
+constexpr int OOB = (int)0x7ffffff0;            // beyond every descriptor's record count: loads return 0, stores are dropped
+
+// Hand-off between workgroups inside the launch (cdna_hip_programming.md, Guideline 16, form R1): the payload another
+// workgroup will read -- h_t forward, dZ_t backward -- is stored WRITE-THROUGH (16-byte sc1 stores), every storing wave
+// drains its stores, ONE lane then stores the tile's step counter (relaxed, agent scope).  The consumer polls the counters
+// of its 3 x 3 tile neighbourhood (nine lanes, one word each, relaxed) and stages the halo with sc1 LOADS (L2-served, the
+// CU's L1 is bypassed): no release / acquire fence on either side, nothing depends on where a workgroup runs.
+__device__ __forceinline__ void wait_neighbours(const SeqParams& p, int tile, unsigned need) {
+    if (threadIdx.x < 9) {
+        const int tpi = p.tiles_x * p.tiles_y;
+        const int img = tile / tpi, loc = tile - img * tpi;
+        const int ty = loc / p.tiles_x, tx = loc - ty * p.tiles_x;
+        const int yy = ty + (int)threadIdx.x / 3 - 1, xx = tx + (int)threadIdx.x % 3 - 1;
+        if (threadIdx.x != 4 && yy >= 0 && xx >= 0 && yy < p.tiles_y && xx < p.tiles_x) {
+            gu32* f = (gu32*)(p.flags + img * tpi + yy * p.tiles_x + xx);
+            unsigned spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void publish(const SeqParams& p, int tile, unsigned done) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains its (sc1) stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store((gu32*)(p.flags + tile), done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// stage the (TW x TW) halo tile of a frame (pixel pitch CIN floats, zero outside the image) as [y][cq][x][4], sc1 loads
+template <int TW, int CIN>
+__device__ __forceinline__ void stage_tile(float* tile, const float* frame, int y0, int x0, int H, int W, int half) {
+    constexpr int NQ = CIN / 4;
+    constexpr int N = TW * TW * NQ, ITERS = (N + 255) / 256;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(frame), 0, H * W * CIN * 4, RSRC3);
+    i32x4_t v[ITERS];
+#pragma unroll
+    for (int u = 0; u < ITERS; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int cq = e % NQ, pix = e / NQ;
+        const int xx = pix % TW, yy = pix / TW;
+        const int y = y0 + yy - half, x = x0 + xx - half;
+        const bool ok = e < N && y >= 0 && y < H && x >= 0 && x < W;
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? ((y * W + x) * CIN + 4 * cq) * 4 : OOB, 0, AUX_SC1);
+    }
+#pragma unroll
+    for (int u = 0; u < ITERS; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int cq = e % NQ, pix = e / NQ;
+        const int xx = pix % TW, yy = pix / TW;
+        if (e < N) *reinterpret_cast<i32x4_t*>(tile + ((size_t)(yy * NQ + cq) * TW + xx) * 4) = v[u];
+    }
+}
+
+// ================================================================================================ forward
+template <int KS, int F>
+__global__ __launch_bounds__(256, 1) void convlstm_seq_fwd_kernel(const SeqParams p) {
+    using G = Geom<KS, F, false>;
+    constexpr int RT = G::RT, NQ = G::NQ, TW = G::TW, C4 = 4 * F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wA = smem;                              // [kstep][lane][RT]
+    float* tile = smem + G::W_FLOATS;
+    float* xch = tile + G::TILE_FLOATS;            // [3][256 pixels][F]: h, c, out of the tile on their way to 16-byte stores
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, q = lane >> 4;
+    // recurrent filter -> A fragments: row m of row tile a is gate channel 16 a + m (= filter 4 a + m / 4, gate m % 4)
+    for (int e = tid; e < G::W_FLOATS; e += 256) {
+        const int a = e % RT, l = (e / RT) & 63, s = e / (RT * 64);
+        const int cq = s % NQ, tap = s / NQ;
+        wA[e] = p.U[((size_t)tap * F + 4 * cq + (l >> 4)) * C4 + 16 * a + (l & 15)];
+    }
+    __syncthreads();
+    const int grid = gridDim.x;
+    const bool single = p.ntiles <= grid;          // one tile per workgroup: the cell state never leaves the registers
+    const int tpi = p.tiles_x * p.tiles_y;
+    const size_t hw = (size_t)p.H * p.W;
+    float cstate[RT][4];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cstate[a][r] = 0.f;
+    for (int t = 0; t < p.T; ++t) {
+        for (int it = 0;; ++it) {
+            const int tl = my_tile(it, grid);
+            if (tl >= p.ntiles) { if (it * grid >= p.ntiles) break; else continue; }
+            const int img = tl / tpi, loc = tl - img * tpi;
+            const int ty = loc / p.tiles_x, tx = loc - ty * p.tiles_x;
+            const int y0 = ty * 16, x0 = tx * 16;
+            const size_t fr = ((size_t)img * p.T + t) * hw;               // pixel index of frame (img, t)
+            const int x = x0 + n16;
+            // accumulators start at the input part (+ bias) of z; requested before the wait for the neighbours
+            f32x4_t acc[RT][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 + 4 * wave + r;
+                const bool ok = y < p.H && x < p.W;
+                const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
+#pragma unroll
+                for (int a = 0; a < RT; ++a) {
+                    acc[a][r] = *reinterpret_cast<const f32x4_t*>(p.Z + pix * C4 + 16 * a + 4 * q);
+                    if (!single) cstate[a][r] = (t > 0) ? __builtin_nontemporal_load(p.C + (pix - hw) * F + 4 * a + q) : 0.f;
+                }
+            }
+            if (t > 0) {
+                wait_neighbours(p, tl, (unsigned)t);
+                stage_tile<TW, F>(tile, p.Hrec + fr * F, y0, x0, p.H, p.W, KS / 2);
+                __syncthreads();
+#pragma unroll 1
+                for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                        for (int cq = 0; cq < NQ; ++cq) {
+                            const int s = (ky * KS + kx) * NQ + cq;
+                            float af[RT];
+                            const float* wp = wA + ((size_t)s * 64 + lane) * RT;
+#pragma unroll
+                            for (int a = 0; a < RT; ++a) af[a] = wp[a];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float bf = tile[((size_t)((4 * wave + r + ky) * NQ + cq) * TW + n16 + kx) * 4 + q];
+#pragma unroll
+                                for (int a = 0; a < RT; ++a)
+                                    acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf, acc[a][r], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            // gates on the accumulators: (i, f, g, o) of filter 4 a + q at pixel (y, x); z goes out as float4, h / c / out
+            // cross the LDS so that they leave as 16-byte stores too (h write-through: the neighbours read it next step)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 + 4 * wave + r;
+                const bool ok = y < p.H && x < p.W;
+                const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
+                const int pl = (4 * wave + r) * 16 + n16;
+#pragma unroll
+                for (int a = 0; a < RT; ++a) {
+                    const f32x4_t z = acc[a][r];
+                    const float gi = hsig(z[0]), gf = hsig(z[1]), gg = tanhf(z[2]), go = hsig(z[3]);
+                    const float c = gf * cstate[a][r] + gi * gg;
+                    const float h = go * tanhf(c);
+                    cstate[a][r] = c;
+                    const int f = 4 * a + q;
+                    if (ok) *reinterpret_cast<f32x4_t*>(p.Z + pix * C4 + 16 * a + 4 * q) = z;
+                    xch[pl * F + f] = h;
+                    xch[(256 + pl) * F + f] = c;
+                    xch[(512 + pl) * F + f] = p.relu ? fmaxf(h, 0.f) : h;
+                }
+            }
+            __syncthreads();
+            {
+                const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(p.Hrec + (fr + hw) * F, 0, (int)(hw * F * 4), RSRC3);
+                for (int e = tid; e < 256 * NQ; e += 256) {
+                    const int cq = e % NQ, pl = e / NQ;
+                    const int y = y0 + (pl >> 4), xx = x0 + (pl & 15);
+                    if (y < p.H && xx < p.W) {
+                        const size_t pix = fr + (size_t)y * p.W + xx;
+                        const i32x4_t hv = *reinterpret_cast<const i32x4_t*>(xch + pl * F + 4 * cq);
+                        if (t + 1 < p.T) __builtin_amdgcn_raw_buffer_store_b128(hv, rh, ((y * p.W + xx) * F + 4 * cq) * 4, 0, AUX_SC1);
+                        *reinterpret_cast<f32x4_t*>(p.C + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (256 + pl) * F + 4 * cq);
+                        *reinterpret_cast<f32x4_t*>(p.out + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (512 + pl) * F + 4 * cq);
+                    }
+                }
+            }
+            if (t + 1 < p.T) publish(p, tl, (unsigned)(t + 1));
+            else __syncthreads();
+        }
+    }
+}
+
+// ================================================================================================ backward
+// dh_{t}[p, ci] (recurrent part) = sum_{tap, c'} dZ'_{t+1}[p - tap + half, c'] U'[tap][ci][c']: a convolution of dZ'_{t+1}
+// with the flipped, transposed filter; MFMA rows = the F hidden channels (rows F..15 idle for F < 16), K = taps x 4F.
+template <int KS, int F>
+__global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParams p) {
+    using G = Geom<KS, F, true>;
+    constexpr int NQ = G::NQ, TW = G::TW, C4 = 4 * F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wA = smem;                              // [kstep][lane]
+    float* tile = smem + G::W_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, q = lane >> 4;
+    for (int e = tid; e < G::W_FLOATS; e += 256) {
+        const int l = e & 63, s = e >> 6;
+        const int cq = s % NQ, tap = s / NQ;
+        const int ci = l & 15, cc = 4 * cq + (l >> 4);
+        const int ftap = KS * KS - 1 - tap;                              // flipped tap
+        wA[e] = (ci < F) ? p.U[((size_t)ftap * F + ci) * C4 + cc] : 0.f;
+    }
+    __syncthreads();
+    const int grid = gridDim.x;
+    const int tpi = p.tiles_x * p.tiles_y;
+    const size_t hw = (size_t)p.H * p.W;
+    const bool active = 4 * q < F;                 // this lane's four rows are hidden channels 4 q .. 4 q + 3
+    for (int t = p.T - 1; t >= 0; --t) {
+        const unsigned step = (unsigned)(p.T - 1 - t);                   // steps completed before this one
+        for (int it = 0;; ++it) {
+            const int tl = my_tile(it, grid);
+            if (tl >= p.ntiles) { if (it * grid >= p.ntiles) break; else continue; }
+            const int img = tl / tpi, loc = tl - img * tpi;
+            const int ty = loc / p.tiles_x, tx = loc - ty * p.tiles_x;
+            const int y0 = ty * 16, x0 = tx * 16;
+            const size_t fr = ((size_t)img * p.T + t) * hw;
+            const int x = x0 + n16;
+            f32x4_t acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            // everything the gate arithmetic reads is requested BEFORE the wait for the neighbours (none of it depends on them)
+            f32x4_t dO[4], oo[4], cc[4], cp[4], dcn[4], zz[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 + 4 * wave + r;
+                const bool ok = active && y < p.H && x < p.W;
+                const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
+                const size_t sp = ((size_t)img * hw + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * F + (ok ? 4 * q : 0);
+                const int q4 = ok ? 4 * q : 0;
+                dO[r] = *reinterpret_cast<const f32x4_t*>(p.dout + pix * F + q4);
+                oo[r] = *reinterpret_cast<const f32x4_t*>(p.out + pix * F + q4);
+                cc[r] = *reinterpret_cast<const f32x4_t*>(p.C + pix * F + q4);
+                cp[r] = (t > 0) ? *reinterpret_cast<const f32x4_t*>(p.C + (pix - hw) * F + q4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                dcn[r] = (t + 1 < p.T) ? *reinterpret_cast<const f32x4_t*>(p.dc + sp) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zz[r][j] = *reinterpret_cast<const f32x4_t*>(p.Z + pix * C4 + 4 * (q4 + j));
+            }
+            if (t + 1 < p.T) {
+                wait_neighbours(p, tl, step);
+                stage_tile<TW, C4>(tile, p.dZ + (fr + hw) * C4, y0, x0, p.H, p.W, KS / 2);
+                __syncthreads();
+#pragma unroll 1
+                for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll 1
+                    for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                        for (int cq = 0; cq < NQ; ++cq) {
+                            const int s = (ky * KS + kx) * NQ + cq;
+                            const float af = wA[(size_t)s * 64 + lane];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float bf = tile[((size_t)((4 * wave + r + ky) * NQ + cq) * TW + n16 + kx) * 4 + q];
+                                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[r], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            // gate backward for (pixel, filters 4 q .. 4 q + 3); lanes whose rows are padding idle.  dZ_t is what the
+            // neighbours stage next step: write-through 16-byte stores
+            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(p.dZ + fr * C4, 0, (int)(hw * C4 * 4), RSRC3);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 + 4 * wave + r;
+                if (active && y < p.H && x < p.W) {
+                    const size_t sp = ((size_t)img * hw + (size_t)y * p.W + x) * F + 4 * q;      // per-sample state (dc)
+                    f32x4_t dcout;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4_t z = zz[r][j];
+                        const float gi = hsig(z[0]), gf = hsig(z[1]), gg = tanhf(z[2]), go = hsig(z[3]);
+                        float dh = dO[r][j];
+                        if (p.relu) dh = (oo[r][j] > 0.f) ? dh : 0.f;
+                        dh += acc[r][j];
+                        const float tc = tanhf(cc[r][j]);
+                        const float dc = dh * go * (1.f - tc * tc) + dcn[r][j];
+                        f32x4_t dz;
+                        dz[0] = dc * gg * dhsig(z[0]);
+                        dz[1] = dc * cp[r][j] * dhsig(z[1]);
+                        dz[2] = dc * gi * (1.f - gg * gg);
+                        dz[3] = dh * tc * dhsig(z[3]);
+                        i32x4_t dzi;
+                        __builtin_memcpy(&dzi, &dz, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(dzi, rz, (((y * p.W + x) * C4) + 4 * (4 * q + j)) * 4, 0, AUX_SC1);
+                        dcout[j] = dc * gf;
+                    }
+                    if (t > 0) *reinterpret_cast<f32x4_t*>(p.dc + sp) = dcout;
+                }
+            }
+            if (t > 0) publish(p, tl, step + 1);
+            else __syncthreads();
+        }
+    }
+}
+
+// column permutation between the Keras gate-major layout (column = gate * F + f) and the interleaved one (4 f + gate)
+__global__ void gate_interleave_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int F, int to_interleaved,
+                                       int accumulate) {
+    const int C4 = 4 * F;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * C4; e += gridDim.x * blockDim.x) {
+        const int row = e / C4, c = e - row * C4;
+        // e indexes the DESTINATION; c is its column
+        int sc;
+        if (to_interleaved) { const int f = c >> 2, gate = c & 3; sc = gate * F + f; }
+        else { const int gate = c / F, f = c - gate * F; sc = 4 * f + gate; }
+        const float v = src[(size_t)row * C4 + sc];
+        dst[e] = accumulate ? dst[e] + v : v;
+    }
+}
+
+template <int KS, int F>
+void launch_fwd(hipStream_t s, const SeqParams& p, int grid) {
+    using G = Geom<KS, F, false>;
+    static bool once = false;
+    if (!once) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_seq_fwd_kernel<KS, F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        once = true;
+    }
+    hipLaunchKernelGGL((convlstm_seq_fwd_kernel<KS, F>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+template <int KS, int F>
+void launch_bwd(hipStream_t s, const SeqParams& p, int grid) {
+    using G = Geom<KS, F, true>;
+    static bool once = false;
+    if (!once) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_seq_bwd_kernel<KS, F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        once = true;
+    }
+    hipLaunchKernelGGL((convlstm_seq_bwd_kernel<KS, F>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+bool convlstm_seq_supported(int KS, int F, int H, int W, int B) {
+    if (getenv("DL4DS_NO_CONVLSTM_SEQ")) return false;
+    if (!(KS == 3 || KS == 5) || !(F == 4 || F == 8 || F == 16)) return false;
+    if (F == 16 && KS == 5) return false;                  // backward: filter fragments + the dZ halo tile exceed the LDS
+    const long tiles = (long)cdiv(H, 16) * cdiv(W, 16) * B;
+    return tiles >= 1 && tiles < (1l << 24);
+}
+
+void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int rows, int F, bool to_interleaved, bool accumulate) {
+    const int n = rows * 4 * F;
+    hipLaunchKernelGGL(gate_interleave_kernel, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, s, src, dst, rows, F,
+                       to_interleaved ? 1 : 0, accumulate ? 1 : 0);
+    HIP_CHECK(hipGetLastError());
+}
+
+static int seq_grid(const SeqParams& p) { return std::min(p.ntiles, std::max(cu_count(), 8)); }
+
+static SeqParams seq_params(const float* U, float* Z, float* C, float* Hrec, float* out, const float* dout, float* dZ, float* dc,
+                            unsigned* flags, int B, int T, int H, int W, int relu) {
+    SeqParams p;
+    p.U = U; p.Z = Z; p.C = C; p.Hrec = Hrec; p.out = out; p.dout = dout; p.dZ = dZ; p.dc = dc; p.flags = flags;
+    p.B = B; p.T = T; p.H = H; p.W = W; p.relu = relu;
+    p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); p.ntiles = p.tiles_x * p.tiles_y * B;
+    return p;
+}
+
+size_t convlstm_seq_flag_bytes(int H, int W, int B) { return (size_t)cdiv(H, 16) * cdiv(W, 16) * B * sizeof(unsigned); }
+
+void convlstm_seq_forward(hipStream_t s, const float* U_il, float* Z_il, float* C, float* Hrec, float* out, unsigned* flags,
+                          int B, int T, int H, int W, int KS, int F, int relu) {
+    SeqParams p = seq_params(U_il, Z_il, C, Hrec, out, nullptr, nullptr, nullptr, flags, B, T, H, W, relu);
+    HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)p.ntiles * sizeof(unsigned), s));
+    const double px = (double)B * T * H * W;
+    ProfScope ps(s, "convlstm_seq_fwd<" + std::to_string(KS) + "," + std::to_string(F) + ">",
+                 2.0 * (double)B * (T - 1) * H * W * KS * KS * F * 4 * F, 4.0 * px * (4 * F * 2 + F * 4));
+    const int grid = seq_grid(p);
+#define DL4DS_SEQ_CASE(K_, F_) if (KS == K_ && F == F_) { launch_fwd<K_, F_>(s, p, grid); return; }
+    DL4DS_SEQ_CASE(3, 4) DL4DS_SEQ_CASE(3, 8) DL4DS_SEQ_CASE(3, 16) DL4DS_SEQ_CASE(5, 4) DL4DS_SEQ_CASE(5, 8)
+#undef DL4DS_SEQ_CASE
+    DL4DS_REQUIRE(false, "convlstm_seq_forward: unsupported (KS, F)");
+}
+
+void convlstm_seq_backward(hipStream_t s, const float* U_il, const float* Z_il, const float* C, const float* out, const float* dout,
+                           float* dZ_il, float* dc, unsigned* flags, int B, int T, int H, int W, int KS, int F, int relu) {
+    SeqParams p = seq_params(U_il, const_cast<float*>(Z_il), const_cast<float*>(C), nullptr, const_cast<float*>(out), dout, dZ_il, dc,
+                             flags, B, T, H, W, relu);
+    HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)p.ntiles * sizeof(unsigned), s));
+    const double px = (double)B * T * H * W;
+    ProfScope ps(s, "convlstm_seq_bwd<" + std::to_string(KS) + "," + std::to_string(F) + ">",
+                 2.0 * (double)B * (T - 1) * H * W * KS * KS * F * 4 * F, 4.0 * px * (4 * F * 2 + F * 6));
+    const int grid = seq_grid(p);
+#define DL4DS_SEQ_CASE(K_, F_) if (KS == K_ && F == F_) { launch_bwd<K_, F_>(s, p, grid); return; }
+    DL4DS_SEQ_CASE(3, 4) DL4DS_SEQ_CASE(3, 8) DL4DS_SEQ_CASE(3, 16) DL4DS_SEQ_CASE(5, 4) DL4DS_SEQ_CASE(5, 8)
+#undef DL4DS_SEQ_CASE
+    DL4DS_REQUIRE(false, "convlstm_seq_backward: unsupported (KS, F)");
+}

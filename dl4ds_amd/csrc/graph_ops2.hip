@@ -68,16 +68,35 @@ struct ConvTOp : GOp {
 struct ConvLSTMOp : GOp {
     int in, out, wk, wr, b, KS, F, T, relu;
     size_t wt_k = 0, wt_r = 0;
+    // persistent form (convlstm_seq.hip): one launch per direction for the whole sequence; Z / dZ and the filters it uses
+    // keep the gate channels interleaved (column 4 f + gate instead of Keras' gate * F + f)
+    bool seq = false;
+    size_t wt_kp = 0, wt_up = 0, wt_bp = 0;       // interleaved copies of kernel / recurrent kernel / bias in the Wt scratch
     ConvLSTMOp() { kind = "convlstm2d"; }
+    int cin(Graph& g) const { return g.tensors[in].C; }
     void on_finalize(Graph& g) override {
+        const GTensor& ti = g.tensors[in];
+        seq = convlstm_seq_supported(KS, F, ti.H, ti.W, 1);
+        if (seq) {
+            wt_kp = g.reserve_wt(g.params[wk].n);
+            wt_up = g.reserve_wt(g.params[wr].n);
+            wt_bp = g.reserve_wt(g.params[b].n);
+            wt_k = g.reserve_wt(g.params[wk].n);
+            // dgrad filter of the INTERLEAVED kernel copy (written by every forward pass, read at the start of the backward pass)
+            g.add_wt_job(wt_kp, true, wt_k, KS * KS, ti.C, 4 * F);
+            return;
+        }
         wt_k = g.reserve_wt(g.params[wk].n);
         wt_r = g.reserve_wt(g.params[wr].n);
         g.add_wt_job(g.params[wk].offset, false, wt_k, KS * KS, g.tensors[in].C, 4 * F);     // Graph::refresh_dgrad_weights
         g.add_wt_job(g.params[wr].offset, false, wt_r, KS * KS, F, 4 * F);
     }
     size_t hw(Graph& g) { return (size_t)g.tensors[in].H * g.tensors[in].W; }
+    size_t scratch_floats(Graph& g) {       // dK', dU', db' (interleaved weight gradients) + the tile flags of one launch
+        return (size_t)KS * KS * (cin(g) + F) * 4 * F + 4 * F + 64 + hw(g) / 64 + 64;
+    }
     size_t saved_floats_per_sample(Graph& g) override {
-        return (size_t)T * hw(g) * (4 * F + F + F + 4 * F) + 2 * hw(g) * F;
+        return (size_t)T * hw(g) * (4 * F + F + F + 4 * F) + 2 * hw(g) * F + (seq ? scratch_floats(g) : 0);
     }
     size_t workspace_bytes(Graph& g, int B) override {
         const GTensor& ti = g.tensors[in];
@@ -87,12 +106,16 @@ struct ConvLSTMOp : GOp {
         return std::max(conv2d_wgrad_workspace_bytes(xa, za, KS),
                         std::max(conv2d_wgrad_workspace_bytes(hf, zf, KS), conv2d_wgrad_workspace_bytes(ha, za, KS)));
     }
-    struct Bufs { float *Z, *C, *H, *dZ, *dh, *dc; };
+    struct Bufs { float *Z, *C, *H, *dZ, *dh, *dc, *dKp, *dUp, *dbp; unsigned* flags; };
     Bufs bufs(Graph& g, int B) {
         const size_t n = (size_t)B * T * hw(g);
         Bufs r;
         r.Z = saved; r.C = r.Z + n * 4 * F; r.H = r.C + n * F; r.dZ = r.H + n * F;
         r.dh = r.dZ + n * 4 * F; r.dc = r.dh + (size_t)B * hw(g) * F;
+        r.dKp = r.dc + (size_t)B * hw(g) * F;
+        r.dUp = r.dKp + (size_t)KS * KS * cin(g) * 4 * F;
+        r.dbp = r.dUp + (size_t)KS * KS * F * 4 * F;
+        r.flags = reinterpret_cast<unsigned*>(r.dbp + 4 * F + 60);
         return r;
     }
     TView frame(Graph& g, float* base, int B, int t, int ch) {      // frame t of every sample of a (B,T,H,W,ch) buffer
@@ -104,13 +127,25 @@ struct ConvLSTMOp : GOp {
     void forward(Graph& g, int B, bool) override {
         const GTensor& ti = g.tensors[in];
         Bufs bf = bufs(g, B);
-        ConvEpilogue ep;
-        ep.bias = g.wp(b);
-        conv2d_forward(g.stream, g.view(in, B, false), g.wp(wk), KS, make_view(bf.Z, B * T, ti.H, ti.W, 4 * F), ep);
         // H holds the RECURRENT INPUT of every step: H[b, t] = h_{t-1}, H[b, 0] = 0 (zero initial state).  Stored that way
         // the recurrent kernel's weight gradient sum_{b,t} wgrad(h_{t-1}, dZ_t) is ONE convolution-wgrad over the B*T frame
         // pairs (H, dZ) -- frame 0 of every sample contributes nothing -- instead of T-1 launches of ~60 us.
         HIP_CHECK(hipMemset2DAsync(bf.H, (size_t)T * hw(g) * F * sizeof(float), 0, hw(g) * F * sizeof(float), (size_t)B, g.stream));
+        if (seq) {
+            DL4DS_REQUIRE(convlstm_seq_flag_bytes(ti.H, ti.W, B) <= (hw(g) / 64 + 64) * sizeof(float) * (size_t)B, "convlstm: flag area");
+            float *Kp = g.Wt + wt_kp, *Up = g.Wt + wt_up, *bp = g.Wt + wt_bp;
+            convlstm_gate_interleave(g.stream, g.wp(wk), Kp, KS * KS * ti.C, F, true, false);
+            convlstm_gate_interleave(g.stream, g.wp(wr), Up, KS * KS * F, F, true, false);
+            convlstm_gate_interleave(g.stream, g.wp(b), bp, 1, F, true, false);
+            ConvEpilogue ep;
+            ep.bias = bp;
+            conv2d_forward(g.stream, g.view(in, B, false), Kp, KS, make_view(bf.Z, B * T, ti.H, ti.W, 4 * F), ep);
+            convlstm_seq_forward(g.stream, Up, bf.Z, bf.C, bf.H, g.tensors[out].data, bf.flags, B, T, ti.H, ti.W, KS, F, relu);
+            return;
+        }
+        ConvEpilogue ep;
+        ep.bias = g.wp(b);
+        conv2d_forward(g.stream, g.view(in, B, false), g.wp(wk), KS, make_view(bf.Z, B * T, ti.H, ti.W, 4 * F), ep);
         for (int t = 0; t < T; ++t) {
             TView zt = frame(g, bf.Z, B, t, 4 * F);
             if (t > 0) {
@@ -131,6 +166,32 @@ struct ConvLSTMOp : GOp {
         const int B = c.B;
         const GTensor& ti = g.tensors[in];
         Bufs bf = bufs(g, B);
+        TView dZall = make_view(bf.dZ, B * T, ti.H, ti.W, 4 * F);
+        if (seq) {
+            convlstm_seq_backward(g.stream, g.Wt + wt_up, bf.Z, bf.C, g.tensors[out].data, g.tensors[out].grad, bf.dZ, bf.dc, bf.flags,
+                                  B, T, ti.H, ti.W, KS, F, relu);
+            if (c.param_grads) {
+                // weight gradients against the interleaved dZ come out with interleaved columns: back to Keras' order on the
+                // way into the gradient arena
+                conv2d_wgrad(g.stream, g.view(in, B, false), dZall, KS, bf.dKp, 0, bf.dbp, 0, g.workspace, g.workspace_bytes);
+                convlstm_gate_interleave(g.stream, bf.dKp, g.gp(wk), KS * KS * ti.C, F, false, g.params[wk].grad_written);
+                convlstm_gate_interleave(g.stream, bf.dbp, g.gp(b), 1, F, false, g.params[b].grad_written);
+                g.params[wk].grad_written = g.params[b].grad_written = true;
+                if (T > 1) {
+                    conv2d_wgrad(g.stream, make_view(bf.H, B * T, ti.H, ti.W, F), dZall, KS, bf.dUp, 0, nullptr, 0, g.workspace,
+                                 g.workspace_bytes);
+                    convlstm_gate_interleave(g.stream, bf.dUp, g.gp(wr), KS * KS * F, F, false, g.params[wr].grad_written);
+                    g.params[wr].grad_written = true;
+                }
+            }
+            if (wants_grad(g, in, c)) {
+                ConvEpilogue ep;
+                ep.accumulate = g.tensors[in].grad_written;
+                conv2d_forward(g.stream, dZall, g.Wt + wt_k, KS, g.view(in, B, true), ep);
+                g.tensors[in].grad_written = true;
+            }
+            return;
+        }
         float* Ut = g.Wt + wt_r;
         TView dh = make_view(bf.dh, B, ti.H, ti.W, F), dc = make_view(bf.dc, B, ti.H, ti.W, F);
         for (int t = T - 1; t >= 0; --t) {
@@ -143,7 +204,6 @@ struct ConvLSTMOp : GOp {
                 conv2d_forward(g.stream, dzt, Ut, KS, dh, ep);
             }
         }
-        TView dZall = make_view(bf.dZ, B * T, ti.H, ti.W, 4 * F);
         if (c.param_grads) {
             conv2d_wgrad(g.stream, g.view(in, B, false), dZall, KS, g.gp(wk), g.params[wk].grad_written, g.gp(b),
                          g.params[b].grad_written, g.workspace, g.workspace_bytes);

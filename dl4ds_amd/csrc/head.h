@@ -17,3 +17,12 @@ void convlstm_gates_forward(hipStream_t s, const TView& z, const TView& c_prev, 
 void convlstm_gates_backward(hipStream_t s, const TView& z, const TView& c_prev, const TView& c, const TView& out,
                              const TView& dout, const TView& dh_rec, const TView& dc_next, const TView& dz, int relu,
                              int first, int last);
+// ConvLSTM2D recurrence as one persistent launch per layer and direction (convlstm_seq.hip); internal buffers keep the gate
+// channels interleaved (4 f + gate)
+bool convlstm_seq_supported(int KS, int F, int H, int W, int B);
+size_t convlstm_seq_flag_bytes(int H, int W, int B);
+void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int rows, int F, bool to_interleaved, bool accumulate);
+void convlstm_seq_forward(hipStream_t s, const float* U_il, float* Z_il, float* C, float* Hrec, float* out, unsigned* flags,
+                          int B, int T, int H, int W, int KS, int F, int relu);
+void convlstm_seq_backward(hipStream_t s, const float* U_il, const float* Z_il, const float* C, const float* out, const float* dout,
+                           float* dZ_il, float* dc, unsigned* flags, int B, int T, int H, int W, int KS, int F, int relu);
