@@ -23,6 +23,7 @@
 #include "prof.h"
 #include "head.h"
 #include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -41,20 +42,29 @@ using gu32 = __attribute__((address_space(1))) unsigned;
 
 __device__ __forceinline__ float hsig(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float dhsig(float z) { return (z >= -2.5f && z <= 2.5f) ? 0.2f : 0.f; }
+// tanh through one v_exp_f32 and one v_rcp_f32: 1 - 2 / (e^{2x} + 1); absolute error ~1e-7 (a few ulps of 1), saturates
+// cleanly.  The gate arithmetic is VALU work squeezed between the MFMA phases of a step: libm's tanhf was ~40 % of it.
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - __fdividef(2.f, __expf(2.f * x) + 1.f); }
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;       // ~seconds: a lost neighbour yields wrong numbers, never a hung GPU
 
-template <int KS, int F, bool BWD>
+// TR = pixel rows per wave: the tile is 16 wide and 4 TR high.  TR = 2 (8 x 16 tiles) doubles the number of tiles: with two
+// tiles per workgroup the hand-off latency of one (drain -> flag -> poll -> stage) passes under the other's arithmetic.
+template <int KS, int F, bool BWD, int TR>
 struct Geom {
-    static constexpr int TS = 16;
-    static constexpr int TW = TS + KS - 1;
+    static constexpr int TH = 4 * TR;
+    static constexpr int TW = 16 + KS - 1;                  // staged tile: TW wide, TY high
+    static constexpr int TY = TH + KS - 1;
+    static constexpr int PX = 64 * TR;                      // pixels per tile
     static constexpr int CIN = BWD ? 4 * F : F;             // channels of the staged tensor (dZ' : h)
     static constexpr int NQ = CIN / 4;                      // ... in quads
     static constexpr int RT = BWD ? 1 : F / 4;              // MFMA row tiles: 4F gate rows forward, F (<= 16) rows backward
     static constexpr int KSTEPS = KS * KS * NQ;
     static constexpr int W_FLOATS = KSTEPS * RT * 64;
-    static constexpr int TILE_FLOATS = TW * TW * CIN;
-    static constexpr int XCH_FLOATS = BWD ? 0 : 3 * 256 * F;   // forward: h, c, out of a tile on their way to 16-byte stores
+    static constexpr int E = CIN / 4;                       // channels per MFMA k-slot and tap: k-slot kk owns channels E kk .. E kk + E - 1
+    static constexpr int PITCH = CIN + 4;                   // floats per staged pixel (odd number of 16-byte slots: conflict-free wide reads)
+    static constexpr int TILE_FLOATS = TY * TW * PITCH;
+    static constexpr int XCH_FLOATS = BWD ? 0 : 3 * PX * F;   // forward: h, c, out of a tile on their way to 16-byte stores
     static constexpr size_t LDS_BYTES = (size_t)(W_FLOATS + TILE_FLOATS + XCH_FLOATS) * sizeof(float);
 };
 
@@ -68,8 +78,11 @@ struct SeqParams {
     float* dZ;             // backward out: (B,T,H,W,4F) interleaved
     float* dc;             // backward scratch: (B,H,W,F) running dL/dc
     unsigned* flags;       // [tiles]: steps completed by each tile (zeroed before the launch)
-    int B, T, H, W, tiles_x, tiles_y, ntiles, relu;
+    int B, T, H, W, tiles_x, tiles_y, ntiles, relu, tr;
+    unsigned long long* trace;   // DL4DS_SEQ_TRACE: [block][8] phase times (100 MHz wall clock), null otherwise
 };
+
+#define SEQ_MARK(ph) do { if (p.trace && threadIdx.x == 0) { const unsigned long long _n = wall_clock64(); p.trace[blockIdx.x * 8 + (ph)] += _n - _t0; _t0 = _n; } } while (0)
 
 // tile index of this block's i-th tile: consecutive tiles (= the tiles of one image) go to blocks of ONE XCD
 __device__ __forceinline__ int my_tile(int i, int grid) {
@@ -111,11 +124,11 @@ __device__ __forceinline__ void publish(const SeqParams& p, int tile, unsigned d
     if (threadIdx.x == 0) __hip_atomic_store((gu32*)(p.flags + tile), done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// stage the (TW x TW) halo tile of a frame (pixel pitch CIN floats, zero outside the image) as [y][cq][x][4], sc1 loads
-template <int TW, int CIN>
+// stage the (TY x TW) halo tile of a frame (pixel pitch CIN floats, zero outside the image) as [y][x][CIN + 4], sc1 loads
+template <int TW, int TY, int CIN>
 __device__ __forceinline__ void stage_tile(float* tile, const float* frame, int y0, int x0, int H, int W, int half) {
     constexpr int NQ = CIN / 4;
-    constexpr int N = TW * TW * NQ, ITERS = (N + 255) / 256;
+    constexpr int N = TY * TW * NQ, ITERS = (N + 255) / 256;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(frame), 0, H * W * CIN * 4, RSRC3);
     i32x4_t v[ITERS];
 #pragma unroll
@@ -132,124 +145,185 @@ __device__ __forceinline__ void stage_tile(float* tile, const float* frame, int 
         const int e = threadIdx.x + 256 * u;
         const int cq = e % NQ, pix = e / NQ;
         const int xx = pix % TW, yy = pix / TW;
-        if (e < N) *reinterpret_cast<i32x4_t*>(tile + ((size_t)(yy * NQ + cq) * TW + xx) * 4) = v[u];
+        if (e < N) *reinterpret_cast<i32x4_t*>(tile + (size_t)(yy * TW + xx) * (CIN + 4) + 4 * cq) = v[u];
     }
 }
 
+// The K loop of both directions.  K is ordered (tap, e) with MFMA k-slot kk owning channels E kk + e, e = 0 .. E - 1, of the
+// staged tensor (E = channels / 4): a lane then needs E CONSECUTIVE channels of one pixel per tap -- one or two ds_read_b128
+// (ds_read_b64 / b32 for 8 / 4 channels) feed E k-steps, and the filter fragments, stored [tap][row tile][lane][E], come the
+// same way: 0.3 LDS reads per MFMA instead of 1.25 (which cost the single wave of a SIMD ~10 issue cycles each).  Software-
+// pipelined by hand: the fragments of tap k + 1 are requested before the MFMAs of tap k are issued (two register sets, the
+// tap loop unrolled by two) -- fully unrolled the compiler hoists every read and spills at 5 x 5, rolled it waits per tap.
+// E consecutive floats from LDS as the widest reads their alignment allows (E * 4 bytes, at most 16)
+template <int E>
+__device__ __forceinline__ void lds_vec(const float* p, float (&d)[E]) {
+    if constexpr (E == 1) {
+        d[0] = p[0];
+    } else if constexpr (E == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        d[0] = v.x; d[1] = v.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(p + 4 * i);
+            d[4 * i] = v[0]; d[4 * i + 1] = v[1]; d[4 * i + 2] = v[2]; d[4 * i + 3] = v[3];
+        }
+    }
+}
+
+template <int KS, int CIN, int RT, int TR, int TW>
+__device__ __forceinline__ void seq_kloop(const float* wA, const float* tile, int lane, int wave, int n16, int q,
+                                          f32x4_t (&acc)[RT][TR]) {
+    constexpr int E = CIN / 4, P = CIN + 4;
+    const float* bbase = tile + ((size_t)(TR * wave) * TW + n16) * P + E * q;
+    const float* abase = wA + (size_t)lane * E;
+    float afA[RT][E], bfA[TR][E], afB[RT][E], bfB[TR][E];
+    auto load = [&](int tap, int ky, int kx, float (&af)[RT][E], float (&bf)[TR][E]) __attribute__((always_inline)) {
+        const float* ap = abase + (size_t)tap * RT * 64 * E;
+        const float* bp = bbase + ((size_t)ky * TW + kx) * P;
+#pragma unroll
+        for (int a = 0; a < RT; ++a) lds_vec<E>(ap + a * 64 * E, af[a]);
+#pragma unroll
+        for (int r = 0; r < TR; ++r) lds_vec<E>(bp + (size_t)r * TW * P, bf[r]);
+    };
+    auto mma = [&](const float (&af)[RT][E], const float (&bf)[TR][E]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int a = 0; a < RT; ++a) acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][e], bf[r][e], acc[a][r], 0, 0, 0);
+    };
+    constexpr int NT = KS * KS;                  // odd: (NT - 1) / 2 pairs of taps, then the last tap -- no conditional inside the loop
+    static_assert(NT % 2 == 1, "tap count must be odd");
+    int ky = 0, kx = 0;
+    auto next = [&]() __attribute__((always_inline)) { if (++kx == KS) { kx = 0; ++ky; } };
+    load(0, 0, 0, afA, bfA);
+#pragma unroll 1
+    for (int tap = 0; tap < NT - 1; tap += 2) {
+        next();
+        load(tap + 1, ky, kx, afB, bfB);
+        mma(afA, bfA);
+        next();
+        load(tap + 2, ky, kx, afA, bfA);
+        mma(afB, bfB);
+    }
+    mma(afA, bfA);
+}
+
 // ================================================================================================ forward
-template <int KS, int F>
+template <int KS, int F, int TR>
 __global__ __launch_bounds__(256, 1) void convlstm_seq_fwd_kernel(const SeqParams p) {
-    using G = Geom<KS, F, false>;
-    constexpr int RT = G::RT, NQ = G::NQ, TW = G::TW, C4 = 4 * F;
+    using G = Geom<KS, F, false, TR>;
+    constexpr int RT = G::RT, NQ = G::NQ, TW = G::TW, C4 = 4 * F, PX = G::PX;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wA = smem;                              // [kstep][lane][RT]
+    float* wA = smem;                              // [tap][row tile][lane][E]
     float* tile = smem + G::W_FLOATS;
-    float* xch = tile + G::TILE_FLOATS;            // [3][256 pixels][F]: h, c, out of the tile on their way to 16-byte stores
+    float* xch = tile + G::TILE_FLOATS;            // [3][PX pixels][F]: h, c, out of the tile on their way to 16-byte stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, q = lane >> 4;
     // recurrent filter -> A fragments: row m of row tile a is gate channel 16 a + m (= filter 4 a + m / 4, gate m % 4)
-    for (int e = tid; e < G::W_FLOATS; e += 256) {
-        const int a = e % RT, l = (e / RT) & 63, s = e / (RT * 64);
-        const int cq = s % NQ, tap = s / NQ;
-        wA[e] = p.U[((size_t)tap * F + 4 * cq + (l >> 4)) * C4 + 16 * a + (l & 15)];
+    for (int i = tid; i < G::W_FLOATS; i += 256) {                 // [tap][row tile][lane][E]
+        constexpr int E = G::E;
+        const int e = i % E, l = (i / E) & 63, a = (i / (E * 64)) % RT, tap = i / (E * 64 * RT);
+        wA[i] = p.U[((size_t)tap * F + E * (l >> 4) + e) * C4 + 16 * a + (l & 15)];
     }
     __syncthreads();
     const int grid = gridDim.x;
     const bool single = p.ntiles <= grid;          // one tile per workgroup: the cell state never leaves the registers
     const int tpi = p.tiles_x * p.tiles_y;
     const size_t hw = (size_t)p.H * p.W;
-    float cstate[RT][4];
+    unsigned long long _t0 = p.trace ? wall_clock64() : 0ull;
+    float cstate[RT][TR];
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cstate[a][r] = 0.f;
+        for (int r = 0; r < TR; ++r) cstate[a][r] = 0.f;
     for (int t = 0; t < p.T; ++t) {
         for (int it = 0;; ++it) {
             const int tl = my_tile(it, grid);
             if (tl >= p.ntiles) { if (it * grid >= p.ntiles) break; else continue; }
             const int img = tl / tpi, loc = tl - img * tpi;
             const int ty = loc / p.tiles_x, tx = loc - ty * p.tiles_x;
-            const int y0 = ty * 16, x0 = tx * 16;
+            const int y0 = ty * (4 * TR), x0 = tx * 16;
             const size_t fr = ((size_t)img * p.T + t) * hw;               // pixel index of frame (img, t)
             const int x = x0 + n16;
-            // accumulators start at the input part (+ bias) of z; requested before the wait for the neighbours
-            f32x4_t acc[RT][4];
+            f32x4_t acc[RT][TR], zx[RT][TR];
+            // the input part (+ bias) of z and the previous cell state are requested AFTER the halo has been staged, so that
+            // they arrive under the K loop (vector memory returns in order: requested earlier they would stand between the
+            // staging loads and their LDS writes)
+            auto request = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = y0 + 4 * wave + r;
-                const bool ok = y < p.H && x < p.W;
-                const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
+                for (int r = 0; r < TR; ++r) {
+                    const int y = y0 + TR * wave + r;
+                    const bool ok = y < p.H && x < p.W;
+                    const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
 #pragma unroll
-                for (int a = 0; a < RT; ++a) {
-                    acc[a][r] = *reinterpret_cast<const f32x4_t*>(p.Z + pix * C4 + 16 * a + 4 * q);
-                    if (!single) cstate[a][r] = (t > 0) ? __builtin_nontemporal_load(p.C + (pix - hw) * F + 4 * a + q) : 0.f;
-                }
-            }
-            if (t > 0) {
-                wait_neighbours(p, tl, (unsigned)t);
-                stage_tile<TW, F>(tile, p.Hrec + fr * F, y0, x0, p.H, p.W, KS / 2);
-                __syncthreads();
-#pragma unroll 1
-                for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) {
-#pragma unroll
-                        for (int cq = 0; cq < NQ; ++cq) {
-                            const int s = (ky * KS + kx) * NQ + cq;
-                            float af[RT];
-                            const float* wp = wA + ((size_t)s * 64 + lane) * RT;
-#pragma unroll
-                            for (int a = 0; a < RT; ++a) af[a] = wp[a];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float bf = tile[((size_t)((4 * wave + r + ky) * NQ + cq) * TW + n16 + kx) * 4 + q];
-#pragma unroll
-                                for (int a = 0; a < RT; ++a)
-                                    acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf, acc[a][r], 0, 0, 0);
-                            }
-                        }
+                    for (int a = 0; a < RT; ++a) {
+                        zx[a][r] = *reinterpret_cast<const f32x4_t*>(p.Z + pix * C4 + 16 * a + 4 * q);
+                        if (!single) cstate[a][r] = (t > 0) ? __builtin_nontemporal_load(p.C + (pix - hw) * F + 4 * a + q) : 0.f;
                     }
                 }
+            };
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int a = 0; a < RT; ++a) acc[a][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            SEQ_MARK(0);
+            if (t > 0) {
+                wait_neighbours(p, tl, (unsigned)t);
+                SEQ_MARK(1);
+                stage_tile<TW, G::TY, F>(tile, p.Hrec + fr * F, y0, x0, p.H, p.W, KS / 2);
+                __syncthreads();
+                SEQ_MARK(2);
+                request();
+                seq_kloop<KS, F, RT, TR, TW>(wA, tile, lane, wave, n16, q, acc);
+            } else {
+                request();
             }
+            SEQ_MARK(3);
             // gates on the accumulators: (i, f, g, o) of filter 4 a + q at pixel (y, x); z goes out as float4, h / c / out
             // cross the LDS so that they leave as 16-byte stores too (h write-through: the neighbours read it next step)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = y0 + 4 * wave + r;
+            for (int r = 0; r < TR; ++r) {
+                const int y = y0 + TR * wave + r;
                 const bool ok = y < p.H && x < p.W;
                 const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
-                const int pl = (4 * wave + r) * 16 + n16;
+                const int pl = (TR * wave + r) * 16 + n16;
 #pragma unroll
                 for (int a = 0; a < RT; ++a) {
-                    const f32x4_t z = acc[a][r];
-                    const float gi = hsig(z[0]), gf = hsig(z[1]), gg = tanhf(z[2]), go = hsig(z[3]);
+                    const f32x4_t z = acc[a][r] + zx[a][r];
+                    const float gi = hsig(z[0]), gf = hsig(z[1]), gg = tanh_fast(z[2]), go = hsig(z[3]);
                     const float c = gf * cstate[a][r] + gi * gg;
-                    const float h = go * tanhf(c);
+                    const float h = go * tanh_fast(c);
                     cstate[a][r] = c;
                     const int f = 4 * a + q;
                     if (ok) *reinterpret_cast<f32x4_t*>(p.Z + pix * C4 + 16 * a + 4 * q) = z;
                     xch[pl * F + f] = h;
-                    xch[(256 + pl) * F + f] = c;
-                    xch[(512 + pl) * F + f] = p.relu ? fmaxf(h, 0.f) : h;
+                    xch[(PX + pl) * F + f] = c;
+                    xch[(2 * PX + pl) * F + f] = p.relu ? fmaxf(h, 0.f) : h;
                 }
             }
             __syncthreads();
             {
                 const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(p.Hrec + (fr + hw) * F, 0, (int)(hw * F * 4), RSRC3);
-                for (int e = tid; e < 256 * NQ; e += 256) {
+                for (int e = tid; e < PX * NQ; e += 256) {
                     const int cq = e % NQ, pl = e / NQ;
                     const int y = y0 + (pl >> 4), xx = x0 + (pl & 15);
                     if (y < p.H && xx < p.W) {
                         const size_t pix = fr + (size_t)y * p.W + xx;
                         const i32x4_t hv = *reinterpret_cast<const i32x4_t*>(xch + pl * F + 4 * cq);
                         if (t + 1 < p.T) __builtin_amdgcn_raw_buffer_store_b128(hv, rh, ((y * p.W + xx) * F + 4 * cq) * 4, 0, AUX_SC1);
-                        *reinterpret_cast<f32x4_t*>(p.C + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (256 + pl) * F + 4 * cq);
-                        *reinterpret_cast<f32x4_t*>(p.out + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (512 + pl) * F + 4 * cq);
+                        *reinterpret_cast<f32x4_t*>(p.C + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (PX + pl) * F + 4 * cq);
+                        *reinterpret_cast<f32x4_t*>(p.out + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (2 * PX + pl) * F + 4 * cq);
                     }
                 }
             }
+            SEQ_MARK(4);
             if (t + 1 < p.T) publish(p, tl, (unsigned)(t + 1));
             else __syncthreads();
+            SEQ_MARK(5);
         }
     }
 }
@@ -257,27 +331,27 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_fwd_kernel(const SeqParam
 // ================================================================================================ backward
 // dh_{t}[p, ci] (recurrent part) = sum_{tap, c'} dZ'_{t+1}[p - tap + half, c'] U'[tap][ci][c']: a convolution of dZ'_{t+1}
 // with the flipped, transposed filter; MFMA rows = the F hidden channels (rows F..15 idle for F < 16), K = taps x 4F.
-template <int KS, int F>
+template <int KS, int F, int TR>
 __global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParams p) {
-    using G = Geom<KS, F, true>;
+    using G = Geom<KS, F, true, TR>;
     constexpr int NQ = G::NQ, TW = G::TW, C4 = 4 * F;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wA = smem;                              // [kstep][lane]
+    float* wA = smem;                              // [tap][lane][E]
     float* tile = smem + G::W_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, q = lane >> 4;
-    for (int e = tid; e < G::W_FLOATS; e += 256) {
-        const int l = e & 63, s = e >> 6;
-        const int cq = s % NQ, tap = s / NQ;
-        const int ci = l & 15, cc = 4 * cq + (l >> 4);
+    for (int i = tid; i < G::W_FLOATS; i += 256) {                 // [tap][lane][E]
+        constexpr int E = G::E;
+        const int e = i % E, l = (i / E) & 63, tap = i / (E * 64);
+        const int ci = l & 15, cc = E * (l >> 4) + e;
         const int ftap = KS * KS - 1 - tap;                              // flipped tap
-        wA[e] = (ci < F) ? p.U[((size_t)ftap * F + ci) * C4 + cc] : 0.f;
+        wA[i] = (ci < F) ? p.U[((size_t)ftap * F + ci) * C4 + cc] : 0.f;
     }
     __syncthreads();
     const int grid = gridDim.x;
     const int tpi = p.tiles_x * p.tiles_y;
     const size_t hw = (size_t)p.H * p.W;
-    const bool active = 4 * q < F;                 // this lane's four rows are hidden channels 4 q .. 4 q + 3
+    unsigned long long _t0 = p.trace ? wall_clock64() : 0ull;
     for (int t = p.T - 1; t >= 0; --t) {
         const unsigned step = (unsigned)(p.T - 1 - t);                   // steps completed before this one
         for (int it = 0;; ++it) {
@@ -285,83 +359,92 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParam
             if (tl >= p.ntiles) { if (it * grid >= p.ntiles) break; else continue; }
             const int img = tl / tpi, loc = tl - img * tpi;
             const int ty = loc / p.tiles_x, tx = loc - ty * p.tiles_x;
-            const int y0 = ty * 16, x0 = tx * 16;
+            const int y0 = ty * (4 * TR), x0 = tx * 16;
             const size_t fr = ((size_t)img * p.T + t) * hw;
             const int x = x0 + n16;
-            f32x4_t acc[4];
+            f32x4_t acc[1][TR];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            // everything the gate arithmetic reads is requested BEFORE the wait for the neighbours (none of it depends on them)
-            f32x4_t dO[4], oo[4], cc[4], cp[4], dcn[4], zz[4][4];
+            for (int r = 0; r < TR; ++r) acc[0][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            // everything the gate arithmetic reads is requested right AFTER the halo has been staged, so that it arrives under
+            // the K loop (vector memory returns in order: requested before the staging loads it would delay them).  The gate
+            // work is spread over ALL lanes: lane (pixel n16, q) takes filters FPL q .. FPL q + FPL - 1 (FPL = F / 4), although
+            // the MFMA leaves the recurrent part of dh for filters 4 q' .. 4 q' + 3 in lanes q' < F / 4
+            constexpr int FPL = F / 4;
+            float dO[TR][FPL], oo[TR][FPL], cc[TR][FPL], cp[TR][FPL], dcn[TR][FPL];
+            f32x4_t zz[TR][FPL];
+            auto request = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = y0 + 4 * wave + r;
-                const bool ok = active && y < p.H && x < p.W;
-                const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
-                const size_t sp = ((size_t)img * hw + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * F + (ok ? 4 * q : 0);
-                const int q4 = ok ? 4 * q : 0;
-                dO[r] = *reinterpret_cast<const f32x4_t*>(p.dout + pix * F + q4);
-                oo[r] = *reinterpret_cast<const f32x4_t*>(p.out + pix * F + q4);
-                cc[r] = *reinterpret_cast<const f32x4_t*>(p.C + pix * F + q4);
-                cp[r] = (t > 0) ? *reinterpret_cast<const f32x4_t*>(p.C + (pix - hw) * F + q4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                dcn[r] = (t + 1 < p.T) ? *reinterpret_cast<const f32x4_t*>(p.dc + sp) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < TR; ++r) {
+                    const int y = y0 + TR * wave + r;
+                    const bool ok = y < p.H && x < p.W;
+                    const size_t pix = fr + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0);
+                    const size_t sp = ((size_t)img * hw + (size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * F + FPL * q;
+                    __builtin_memcpy(dO[r], p.dout + pix * F + FPL * q, FPL * 4);
+                    __builtin_memcpy(oo[r], p.out + pix * F + FPL * q, FPL * 4);
+                    __builtin_memcpy(cc[r], p.C + pix * F + FPL * q, FPL * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) zz[r][j] = *reinterpret_cast<const f32x4_t*>(p.Z + pix * C4 + 4 * (q4 + j));
-            }
+                    for (int i = 0; i < FPL; ++i) { cp[r][i] = 0.f; dcn[r][i] = 0.f; }
+                    if (t > 0) __builtin_memcpy(cp[r], p.C + (pix - hw) * F + FPL * q, FPL * 4);
+                    if (t + 1 < p.T) __builtin_memcpy(dcn[r], p.dc + sp, FPL * 4);
+#pragma unroll
+                    for (int i = 0; i < FPL; ++i) zz[r][i] = *reinterpret_cast<const f32x4_t*>(p.Z + pix * C4 + 4 * (FPL * q + i));
+                }
+            };
+            SEQ_MARK(0);
             if (t + 1 < p.T) {
                 wait_neighbours(p, tl, step);
-                stage_tile<TW, C4>(tile, p.dZ + (fr + hw) * C4, y0, x0, p.H, p.W, KS / 2);
+                SEQ_MARK(1);
+                stage_tile<TW, G::TY, C4>(tile, p.dZ + (fr + hw) * C4, y0, x0, p.H, p.W, KS / 2);
                 __syncthreads();
-#pragma unroll 1
-                for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll 1
-                    for (int kx = 0; kx < KS; ++kx) {
-#pragma unroll
-                        for (int cq = 0; cq < NQ; ++cq) {
-                            const int s = (ky * KS + kx) * NQ + cq;
-                            const float af = wA[(size_t)s * 64 + lane];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float bf = tile[((size_t)((4 * wave + r + ky) * NQ + cq) * TW + n16 + kx) * 4 + q];
-                                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[r], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
+                SEQ_MARK(2);
+                request();
+                seq_kloop<KS, C4, 1, TR, TW>(wA, tile, lane, wave, n16, q, acc);
+            } else {
+                request();
             }
-            // gate backward for (pixel, filters 4 q .. 4 q + 3); lanes whose rows are padding idle.  dZ_t is what the
-            // neighbours stage next step: write-through 16-byte stores
+            SEQ_MARK(3);
+            // gate backward; dZ_t is what the neighbours stage next step: write-through 16-byte stores
             const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(p.dZ + fr * C4, 0, (int)(hw * C4 * 4), RSRC3);
+            const int src_lane = n16 + 16 * ((FPL * q) >> 2), j0 = (FPL * q) & 3;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = y0 + 4 * wave + r;
-                if (active && y < p.H && x < p.W) {
-                    const size_t sp = ((size_t)img * hw + (size_t)y * p.W + x) * F + 4 * q;      // per-sample state (dc)
-                    f32x4_t dcout;
+            for (int r = 0; r < TR; ++r) {
+                const int y = y0 + TR * wave + r;
+                // the recurrent part of dh for this lane's filters sits in lane src_lane, accumulator rows j0 .. j0 + FPL - 1
+                float rec[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4_t z = zz[r][j];
-                        const float gi = hsig(z[0]), gf = hsig(z[1]), gg = tanhf(z[2]), go = hsig(z[3]);
-                        float dh = dO[r][j];
-                        if (p.relu) dh = (oo[r][j] > 0.f) ? dh : 0.f;
-                        dh += acc[r][j];
-                        const float tc = tanhf(cc[r][j]);
-                        const float dc = dh * go * (1.f - tc * tc) + dcn[r][j];
+                for (int j = 0; j < 4; ++j) rec[j] = (FPL == 4) ? acc[0][r][j] : __shfl(acc[0][r][j], src_lane, 64);
+                if (y < p.H && x < p.W) {
+                    const size_t sp = ((size_t)img * hw + (size_t)y * p.W + x) * F + FPL * q;      // per-sample state (dc)
+                    float dcout[FPL];
+#pragma unroll
+                    for (int i = 0; i < FPL; ++i) {
+                        const f32x4_t z = zz[r][i];
+                        const float gi = hsig(z[0]), gf = hsig(z[1]), gg = tanh_fast(z[2]), go = hsig(z[3]);
+                        float dh = dO[r][i];
+                        if (p.relu) dh = (oo[r][i] > 0.f) ? dh : 0.f;
+                        float rc = rec[i];
+                        if (FPL == 2) rc = j0 ? rec[2 + i] : rec[i];
+                        if (FPL == 1) rc = j0 == 0 ? rec[0] : (j0 == 1 ? rec[1] : (j0 == 2 ? rec[2] : rec[3]));
+                        dh += rc;
+                        const float tc = tanh_fast(cc[r][i]);
+                        const float dc = dh * go * (1.f - tc * tc) + dcn[r][i];
                         f32x4_t dz;
                         dz[0] = dc * gg * dhsig(z[0]);
-                        dz[1] = dc * cp[r][j] * dhsig(z[1]);
+                        dz[1] = dc * cp[r][i] * dhsig(z[1]);
                         dz[2] = dc * gi * (1.f - gg * gg);
                         dz[3] = dh * tc * dhsig(z[3]);
                         i32x4_t dzi;
                         __builtin_memcpy(&dzi, &dz, 16);
-                        __builtin_amdgcn_raw_buffer_store_b128(dzi, rz, (((y * p.W + x) * C4) + 4 * (4 * q + j)) * 4, 0, AUX_SC1);
-                        dcout[j] = dc * gf;
+                        __builtin_amdgcn_raw_buffer_store_b128(dzi, rz, (((y * p.W + x) * C4) + 4 * (FPL * q + i)) * 4, 0, AUX_SC1);
+                        dcout[i] = dc * gf;
                     }
-                    if (t > 0) *reinterpret_cast<f32x4_t*>(p.dc + sp) = dcout;
+                    if (t > 0) __builtin_memcpy(p.dc + sp, dcout, FPL * 4);
                 }
             }
+            SEQ_MARK(4);
             if (t > 0) publish(p, tl, step + 1);
             else __syncthreads();
+            SEQ_MARK(5);
         }
     }
 }
@@ -381,28 +464,28 @@ __global__ void gate_interleave_kernel(const float* __restrict__ src, float* __r
     }
 }
 
-template <int KS, int F>
+template <int KS, int F, int TR>
 void launch_fwd(hipStream_t s, const SeqParams& p, int grid) {
-    using G = Geom<KS, F, false>;
+    using G = Geom<KS, F, false, TR>;
     static bool once = false;
     if (!once) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_seq_fwd_kernel<KS, F>),
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_seq_fwd_kernel<KS, F, TR>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         once = true;
     }
-    hipLaunchKernelGGL((convlstm_seq_fwd_kernel<KS, F>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((convlstm_seq_fwd_kernel<KS, F, TR>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     HIP_CHECK(hipGetLastError());
 }
-template <int KS, int F>
+template <int KS, int F, int TR>
 void launch_bwd(hipStream_t s, const SeqParams& p, int grid) {
-    using G = Geom<KS, F, true>;
+    using G = Geom<KS, F, true, TR>;
     static bool once = false;
     if (!once) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_seq_bwd_kernel<KS, F>),
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(convlstm_seq_bwd_kernel<KS, F, TR>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         once = true;
     }
-    hipLaunchKernelGGL((convlstm_seq_bwd_kernel<KS, F>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((convlstm_seq_bwd_kernel<KS, F, TR>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -423,28 +506,61 @@ void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int r
     HIP_CHECK(hipGetLastError());
 }
 
+// DL4DS_SEQ_TRACE=1 (development): per-phase times of every launch on stderr (synchronises)
+static unsigned long long* trace_begin(SeqParams& p, int grid, hipStream_t s) {
+    static const bool on = getenv("DL4DS_SEQ_TRACE") != nullptr;
+    if (!on) return nullptr;
+    static unsigned long long* buf = nullptr;
+    if (!buf) HIP_CHECK(hipMalloc((void**)&buf, 4096 * 8 * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemsetAsync(buf, 0, (size_t)grid * 8 * sizeof(unsigned long long), s));
+    p.trace = buf;
+    return buf;
+}
+static void trace_end(const char* what, const SeqParams& p, int grid, hipStream_t s) {
+    if (!p.trace) return;
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    HIP_CHECK(hipMemcpy(h.data(), p.trace, h.size() * 8, hipMemcpyDeviceToHost));
+    double ph[8] = {0};
+    for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) ph[k] += (double)h[(size_t)b * 8 + k] / grid * 0.01;      // us
+    fprintf(stderr, "%s T=%d tiles=%d grid=%d tr=%d: prefetch %.1f wait %.1f stage %.1f kloop %.1f gates+stores %.1f publish %.1f us (mean per block, whole launch)\n",
+            what, p.T, p.ntiles, grid, p.tr, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+}
 static int seq_grid(const SeqParams& p) { return std::min(p.ntiles, std::max(cu_count(), 8)); }
 
+// rows per wave.  Backward: 8 x 16 tiles while 16 x 16 tiles would give a workgroup fewer than two of them (see Geom; its
+// step ends with the drain of 32 KB of write-through dZ stores, which the second tile's arithmetic covers).  Forward: 16 x 16
+// (its hand-off is 8 KB and the smaller tiles' extra halo costs more than it hides).  Measured at 16 x 8 x 64^2, F = 8:
+// backward 5x5 184 -> 173 us, 3x3 123 -> 109 us per launch with two 8 x 16 tiles; forward 87 / 62 us with 16 x 16, 95 / 68 with 8 x 16.
+static int seq_tr(int H, int W, int B, bool backward) {
+    if (const char* e = getenv("DL4DS_CONVLSTM_SEQ_TR")) return atoi(e) == 2 ? 2 : 4;
+    const long t16 = (long)cdiv(H, 16) * cdiv(W, 16) * B;
+    return (backward && t16 < 2l * std::max(cu_count(), 8) && H > 8) ? 2 : 4;
+}
+
 static SeqParams seq_params(const float* U, float* Z, float* C, float* Hrec, float* out, const float* dout, float* dZ, float* dc,
-                            unsigned* flags, int B, int T, int H, int W, int relu) {
+                            unsigned* flags, int B, int T, int H, int W, int relu, bool backward) {
     SeqParams p;
     p.U = U; p.Z = Z; p.C = C; p.Hrec = Hrec; p.out = out; p.dout = dout; p.dZ = dZ; p.dc = dc; p.flags = flags;
     p.B = B; p.T = T; p.H = H; p.W = W; p.relu = relu;
-    p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); p.ntiles = p.tiles_x * p.tiles_y * B;
+    p.tr = seq_tr(H, W, B, backward);
+    p.trace = nullptr;
+    p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 4 * p.tr); p.ntiles = p.tiles_x * p.tiles_y * B;
     return p;
 }
 
-size_t convlstm_seq_flag_bytes(int H, int W, int B) { return (size_t)cdiv(H, 16) * cdiv(W, 16) * B * sizeof(unsigned); }
+size_t convlstm_seq_flag_bytes(int H, int W, int B) { return (size_t)cdiv(H, 8) * cdiv(W, 16) * B * sizeof(unsigned); }
 
 void convlstm_seq_forward(hipStream_t s, const float* U_il, float* Z_il, float* C, float* Hrec, float* out, unsigned* flags,
                           int B, int T, int H, int W, int KS, int F, int relu) {
-    SeqParams p = seq_params(U_il, Z_il, C, Hrec, out, nullptr, nullptr, nullptr, flags, B, T, H, W, relu);
+    SeqParams p = seq_params(U_il, Z_il, C, Hrec, out, nullptr, nullptr, nullptr, flags, B, T, H, W, relu, false);
     HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)p.ntiles * sizeof(unsigned), s));
     const double px = (double)B * T * H * W;
     ProfScope ps(s, "convlstm_seq_fwd<" + std::to_string(KS) + "," + std::to_string(F) + ">",
                  2.0 * (double)B * (T - 1) * H * W * KS * KS * F * 4 * F, 4.0 * px * (4 * F * 2 + F * 4));
     const int grid = seq_grid(p);
-#define DL4DS_SEQ_CASE(K_, F_) if (KS == K_ && F == F_) { launch_fwd<K_, F_>(s, p, grid); return; }
+    trace_begin(p, grid, s);
+#define DL4DS_SEQ_CASE(K_, F_) if (KS == K_ && F == F_) { if (p.tr == 2) launch_fwd<K_, F_, 2>(s, p, grid); else launch_fwd<K_, F_, 4>(s, p, grid); trace_end("convlstm_seq_fwd", p, grid, s); return; }
     DL4DS_SEQ_CASE(3, 4) DL4DS_SEQ_CASE(3, 8) DL4DS_SEQ_CASE(3, 16) DL4DS_SEQ_CASE(5, 4) DL4DS_SEQ_CASE(5, 8)
 #undef DL4DS_SEQ_CASE
     DL4DS_REQUIRE(false, "convlstm_seq_forward: unsupported (KS, F)");
@@ -453,13 +569,14 @@ void convlstm_seq_forward(hipStream_t s, const float* U_il, float* Z_il, float* 
 void convlstm_seq_backward(hipStream_t s, const float* U_il, const float* Z_il, const float* C, const float* out, const float* dout,
                            float* dZ_il, float* dc, unsigned* flags, int B, int T, int H, int W, int KS, int F, int relu) {
     SeqParams p = seq_params(U_il, const_cast<float*>(Z_il), const_cast<float*>(C), nullptr, const_cast<float*>(out), dout, dZ_il, dc,
-                             flags, B, T, H, W, relu);
+                             flags, B, T, H, W, relu, true);
     HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)p.ntiles * sizeof(unsigned), s));
     const double px = (double)B * T * H * W;
     ProfScope ps(s, "convlstm_seq_bwd<" + std::to_string(KS) + "," + std::to_string(F) + ">",
                  2.0 * (double)B * (T - 1) * H * W * KS * KS * F * 4 * F, 4.0 * px * (4 * F * 2 + F * 6));
     const int grid = seq_grid(p);
-#define DL4DS_SEQ_CASE(K_, F_) if (KS == K_ && F == F_) { launch_bwd<K_, F_>(s, p, grid); return; }
+    trace_begin(p, grid, s);
+#define DL4DS_SEQ_CASE(K_, F_) if (KS == K_ && F == F_) { if (p.tr == 2) launch_bwd<K_, F_, 2>(s, p, grid); else launch_bwd<K_, F_, 4>(s, p, grid); trace_end("convlstm_seq_bwd", p, grid, s); return; }
     DL4DS_SEQ_CASE(3, 4) DL4DS_SEQ_CASE(3, 8) DL4DS_SEQ_CASE(3, 16) DL4DS_SEQ_CASE(5, 4) DL4DS_SEQ_CASE(5, 8)
 #undef DL4DS_SEQ_CASE
     DL4DS_REQUIRE(false, "convlstm_seq_backward: unsupported (KS, F)");
