@@ -30,8 +30,11 @@ constexpr int NTW = 16, NTH = 32, NROWS = 8;      // tile width / height, rows p
 #define NARROW_PAIR_ROWS 4
 #endif
 
+#ifndef NARROW16_LB
+#define NARROW16_LB 2
+#endif
 template <int CI>
-__global__ void __launch_bounds__(256, CI == 8 ? 4 : 2) conv_narrow_kernel(const ConvParams a) {
+__global__ void __launch_bounds__(256, CI == 8 ? 4 : NARROW16_LB) conv_narrow_kernel(const ConvParams a) {
     constexpr int E = CI / 4;                      // cin values per lane and tap
     constexpr int TWH = NTW + 2, THH = NTH + 2, HPIX = TWH * THH;
     constexpr int Q4 = CI / 4;                     // float4s per pixel
@@ -647,6 +650,265 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
 #endif
 }
 
+// Producer / consumer form for 9..16 input channels (the 16-channel levels of the U-Net at 512^2 / 256^2, the recurrent nets'
+// 16-channel upsampling convolution): the same division of labour as conv_narrow_pair_ws_kernel -- waves 4-7 move halo tiles
+// (zero-filling buffer loads three tiles ahead, LDS writes one tile ahead into the other of two buffers) and prepare the tile's
+// store descriptors, waves 0-3 hold the 16 x 16 x 9 filter in 36 registers and issue nothing but the 36 MFMAs per halo row
+// (pixel fragments as one ds_read_b128 per tap column, one halo row ahead; accumulators start at the bias) plus one 16-byte
+// store per output row.  conv_narrow_kernel<16> -- load, LDS, MFMA and store phases inside every wave -- held the matrix
+// pipe 43 % busy (profiles/pmc_mfma_r02.txt) at 74 TFLOP/s stand-alone, 58-63 inside the models.
+template <int NR>
+__global__ void __launch_bounds__(512, NR <= 4 ? 2 : 1) conv_narrow16_ws_kernel(const ConvParams a) {
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int PTW = 16, PTH = 4 * NR;
+    constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
+    constexpr int P = 20;                                       // floats per staged pixel: 5 x 16 bytes (odd: conflict-free b128 reads)
+    constexpr int TOTAL = HPIX * 4, ITERS = (TOTAL + 255) / 256;
+    constexpr int TILE = HPIX * P;
+    constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    __shared__ __attribute__((aligned(16))) unsigned dsc[2][8];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave8 = tid >> 6;
+    const int ntiles = a.tiles_x * a.tiles_y * a.in.N;
+    const int G = gridDim.x;
+    auto origin = [&](int t, int& n, int& y0, int& x0) {
+        const int q = fast_div(t, a.m_txy[0]);
+        const int bx = t - q * a.tiles_x;
+        n = fast_div(q, a.m_txy[1]);
+        const int by = q - n * a.tiles_y;
+        x0 = bx * PTW; y0 = by * PTH;
+    };
+
+    if (wave8 >= 4) {
+        // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 2) + 64 u, channel quad htid & 3)
+        const int htid = tid & 255;
+        const int c4 = htid & 3, p0 = htid >> 2;
+        const size_t isx = a.in.ld, isy = (size_t)a.W * a.in.ld;
+        int rel[ITERS], soff[ITERS], hyx[ITERS];
+#pragma unroll
+        for (int u = 0; u < ITERS; ++u) {
+            const int pix = p0 + 64 * u;
+            const int hy = pix / TWH, hx = pix - hy * TWH;
+            const bool live = pix < HPIX && c4 * 4 < a.Cin;
+            hyx[u] = pix < HPIX ? ((hy << 8) | hx) : 0x7f7f;
+            rel[u] = live ? (int)((hy * isy + hx * isx + (size_t)c4 * 4) * 4) : OOB;
+            soff[u] = rel[u];
+        }
+        int sig_cur = (THH << 8) | TWH;
+        i32x4_t r[3][ITERS];
+        auto issue = [&](int t, i32x4_t (&dst)[ITERS]) __attribute__((always_inline)) {
+            int n, y0, x0;
+            origin(t, n, y0, x0);
+            const int ylo = max(0, 1 - y0), yhi = min(THH, a.H + 1 - y0);
+            const int xlo = max(0, 1 - x0), xhi = min(TWH, a.W + 1 - x0);
+            const int sig = (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
+            if (sig != sig_cur) {
+                sig_cur = sig;
+#pragma unroll
+                for (int u = 0; u < ITERS; ++u) {
+                    const int hy = hyx[u] >> 8, hx = hyx[u] & 0xff;
+                    soff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? rel[u] : OOB;
+                }
+            }
+            const long org = (long)((size_t)n * a.in.nstride) + (long)(y0 - 1) * (long)isy + (long)(x0 - 1) * (long)isx;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[u], 0, 0);
+        };
+        auto put = [&](const i32x4_t (&src)[ITERS], float* tile) __attribute__((always_inline)) {
+            float* d0 = tile + p0 * P + c4 * 4;
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u)
+                if (u + 1 < ITERS || (hyx[u] >> 8) < THH) *reinterpret_cast<i32x4_t*>(d0 + u * (64 * P)) = src[u];
+        };
+        size_t hosx, hosy;
+        {
+            const int rr = a.out.d2s > 1 ? a.out.d2s : 1;
+            hosx = (size_t)rr * a.out.ld;
+            hosy = (size_t)rr * (size_t)(a.out.W * rr) * a.out.ld;
+        }
+        auto describe = [&](int t, unsigned* d) __attribute__((always_inline)) {
+            int n, y0, x0;
+            origin(t, n, y0, x0);
+            const size_t pb = (size_t)y0 * hosy + (size_t)x0 * hosx;
+            const unsigned long long ob = (unsigned long long)(uintptr_t)a.out.p + ((size_t)n * a.out.nstride + pb) * 4;
+            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (a.add.p ? ((size_t)n * a.add.nstride + pb) * 4 : 0);
+            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (a.mask.p ? ((size_t)n * a.mask.nstride + pb) * 4 : 0);
+            const int ymax = min(PTH, a.H - y0), xmax = min(PTW, a.W - x0);
+            if (tid == 256) {
+                *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)ob, (unsigned)(ob >> 32), (unsigned)ab, (unsigned)(ab >> 32));
+                *reinterpret_cast<uint4*>(d + 4) = make_uint4((unsigned)mb, (unsigned)(mb >> 32), (unsigned)((ymax << 8) | xmax), 0u);
+            }
+        };
+        const int t0 = blockIdx.x;
+        if (t0 < ntiles) describe(t0, dsc[0]);
+        if (t0 < ntiles) issue(t0, r[0]);
+        if (t0 + G < ntiles) issue(t0 + G, r[1]);
+        if (t0 < ntiles) put(r[0], lds);
+        if (t0 + 2 * G < ntiles) issue(t0 + 2 * G, r[2]);
+        __syncthreads();                                          // S0: tile 0 staged
+        int k = 0;
+        for (int t = t0; t < ntiles; t += 3 * G) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int tk = t + j * G;
+                if (tk < ntiles) {
+                    if (tk + G < ntiles) { put(r[(j + 1) % 3], lds + ((k + 1) & 1) * TILE); describe(tk + G, dsc[(k + 1) & 1]); }
+                    if (tk + 3 * G < ntiles) issue(tk + 3 * G, r[j]);
+                    __syncthreads();                              // X: tile k consumed, tile k+1 staged
+                    ++k;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- MFMA waves: filter fragment (tap, e) = W[tap][cin = 4 lq + e][cout = l15]
+    const int wave = wave8 & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    float wr[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = 4 * lq + e;
+            const bool ok = ci < a.Cin && l15 < a.Cout;
+            const float v = a.w[((size_t)t * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? l15 : 0)];
+            wr[t][e] = ok ? v : 0.f;
+        }
+    const int rd_off = ((wave * NR) * TWH + l15) * P + 4 * lq;
+    // lane (pixel column l15, k-slot lq) ends with rows 4 lq + r = couts 4 lq .. 4 lq + 3 of its pixel
+    const int ec = 4 * lq;
+    const bool c_ok = ec < a.Cout;
+    const float4 bias_v = (a.bias && c_ok) ? *reinterpret_cast<const float4*>(a.bias + ec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const f32x4 bias_c = {bias_v.x, bias_v.y, bias_v.z, bias_v.w};
+    size_t osx, osy;
+    {
+        const int r = a.out.d2s > 1 ? a.out.d2s : 1;
+        osx = (size_t)r * a.out.ld;
+        osy = (size_t)r * (size_t)(a.out.W * r) * a.out.ld;
+    }
+    int eo[NR], eoff[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        eo[i] = c_ok ? (int)(((wave * NR + i) * osy + l15 * osx + view_chan_off(a.out, c_ok ? ec : 0)) * 4) : OOB;
+        eoff[i] = eo[i];
+    }
+    int esig = (PTH << 8) | PTW;
+
+    __syncthreads();                                              // S0
+    int k = 0;
+    for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
+        const float* rd = lds + (k & 1) * TILE + rd_off;
+        f32x4 acc[NR];
+        f32x4 pv[2][3];                                           // pixel fragments, ONE halo row ahead of the MFMAs that use them
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) pv[0][dx] = *reinterpret_cast<const f32x4*>(rd + dx * P);
+#pragma unroll
+        for (int rho = 0; rho < NR + 2; ++rho) {
+            if (rho + 1 < NR + 2) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) pv[(rho + 1) & 1][dx] = *reinterpret_cast<const f32x4*>(rd + ((rho + 1) * TWH + dx) * P);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f32x4 v = pv[rho & 1][dx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = rho - dy;
+                        if (r >= 0 && r < NR) {
+                            const bool first = dy == 0 && dx == 0 && e == 0;    // this row's first MFMA: C = bias
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy * 3 + dx][e], v[e], first ? bias_c : acc[r], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const uint4 d0 = *reinterpret_cast<const uint4*>(dsc[k & 1]);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(dsc[k & 1] + 4);
+        auto sg = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        const unsigned long long ob = ((unsigned long long)sg(d0.y) << 32) | sg(d0.x);
+        const unsigned long long ab = ((unsigned long long)sg(d0.w) << 32) | sg(d0.z);
+        const unsigned long long mb = ((unsigned long long)sg(d1.y) << 32) | sg(d1.x);
+        const int sig = (int)sg(d1.z);
+        __syncthreads();                                          // X
+        if (sig != esig) {
+            esig = sig;
+            const int ymax = sig >> 8, xmax = sig & 0xff;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && l15 < xmax) ? eo[i] : OOB;
+        }
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ob), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)mb), 0, 0x7fffff00, RSRC3);
+        i32x4_t ad[NR], mk[NR], old[NR];
+        if (a.add.p) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+        }
+        if (a.mask.p) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+        }
+        if (a.accumulate) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            f32x4 v = acc[i];
+            if (a.add.p) v += __builtin_bit_cast(f32x4, ad[i]);
+            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (a.mask.p) {
+                const f32x4 m = __builtin_bit_cast(f32x4, mk[i]);
+                v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f;
+                v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
+            }
+            if (a.accumulate) v += __builtin_bit_cast(f32x4, old[i]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
+        }
+    }
+}
+
+bool narrow16_ws_ok(const ConvParams& p) {
+    static const bool off = getenv("DL4DS_NO_NARROW16_WS") != nullptr;
+    auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
+    if (off || p.pool || p.in.sc || p.in.d2s > 1 || !p.in.vec || (p.Cin & 3) || p.Cin <= 8) return false;
+    if (!p.out.vec || (p.Cout & 3) || (p.add.p && !p.add.vec) || (p.mask.p && !p.mask.vec)) return false;
+    if ((((uintptr_t)p.bias) & 15) != 0) return false;
+    if (p.add.p && !same_layout(p.add, p.out)) return false;
+    if (p.mask.p && !same_layout(p.mask, p.out)) return false;
+    const size_t r = p.out.d2s > 1 ? p.out.d2s : 1;
+    if ((size_t)20 * p.out.W * r * r * p.out.ld * 4 >= (1ull << 31) || (size_t)20 * p.W * p.in.ld * 4 >= (1ull << 31)) return false;
+    return true;
+}
+
+template <int NR>
+bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
+    if (!narrow16_ws_ok(p)) return false;
+    p.tiles_x = cdiv(p.W, 16);
+    p.tiles_y = cdiv(p.H, 4 * NR);
+    p.m_txy[0] = div_magic(p.tiles_x);
+    p.m_txy[1] = div_magic(p.tiles_y);
+    const long nt = (long)p.tiles_x * p.tiles_y * N;
+    if (nt == 0 || nt >= (1l << 20)) return false;
+    const int ntiles = (int)nt;
+    const int blocks = std::min(ntiles, resident_blocks<conv_narrow16_ws_kernel<NR>>(512));
+    const double px = (double)N * p.H * p.W;
+    ProfScope ps(s, "conv_narrow16_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
+                 4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+    hipLaunchKernelGGL((conv_narrow16_ws_kernel<NR>), dim3(blocks), dim3(512), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+    return true;
+}
+
 bool narrow_pair_ws_ok(const ConvParams& p) {
     static const bool off = getenv("DL4DS_NO_PAIR_WS") != nullptr;
     auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
@@ -1104,6 +1366,10 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
         return true;
     }
     if (in.C <= 8) launch_narrow<8>(s, p, in.N);
-    else launch_narrow<16>(s, p, in.N);
+    else {
+        static const int nr = getenv("DL4DS_NARROW16_NR") ? atoi(getenv("DL4DS_NARROW16_NR")) : 4;       // (experiments)
+        const bool done = nr == 8 ? launch_narrow16_ws<8>(s, p, in.N) : (nr == 2 ? launch_narrow16_ws<2>(s, p, in.N) : launch_narrow16_ws<4>(s, p, in.N));
+        if (!done) launch_narrow<16>(s, p, in.N);
+    }
     return true;
 }

@@ -1,11 +1,12 @@
-"""8->8 3x3 conv at 512^2, batch 16 (the HBM-bound tail layers of cfg2): fwd / dgrad / wgrad in isolation."""
+"""8->8 3x3 conv at 512^2, batch 16 (the HBM-bound tail layers of cfg2): fwd / wgrad in isolation (MB_N / MB_H / MB_W / MB_CI / MB_CO
+override the shape: MB_CI=16 MB_CO=16 is the U-Net's 16-channel level)."""
 import ctypes, json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dl4ds_amd._lib as L
 from dl4ds_amd.device import DeviceArray
 lib = L.lib()
-N, H, W, CI, CO = 16, 512, 512, 8, 8
+N, H, W, CI, CO = (int(os.environ.get(k, d)) for k, d in (('MB_N', 16), ('MB_H', 512), ('MB_W', 512), ('MB_CI', 8), ('MB_CO', 8)))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.default_rng(0)
 x = DeviceArray.from_numpy(rng.standard_normal((N, H, W, CI)).astype(np.float32))
