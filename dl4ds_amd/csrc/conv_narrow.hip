@@ -373,7 +373,7 @@ __device__ unsigned long long pair_ws_trace[4096 * 8];      // diagnostics build
 #define PT_TOC(slot_)
 #endif
 template <int NR>
-__global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvParams a) {
+__global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvParams a) {      // (4 waves per SIMD = two workgroups per CU)
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int PTW = 32, PTH = 4 * NR;
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
@@ -386,6 +386,7 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
     // of the tile that exist -- the MFMA waves' epilogue used to spend 40 % of their time on this arithmetic, starved by the other
     // workgroup's MFMAs, while the loader waves idle 80 % of theirs (PAIR_WS_TRACE build)
     __shared__ __attribute__((aligned(16))) unsigned dsc[2][8];
+    __shared__ __attribute__((aligned(16))) float pool_red[2][32];     // a.pool: [parity][wave][channel]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave8 = tid >> 6;
@@ -421,7 +422,15 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
         }
         int sig_cur = (THH << 8) | TWH;
         i32x4_t r[3][ITERS];
-        auto issue = [&](int t, i32x4_t (&dst)[ITERS]) __attribute__((always_inline)) {
+        unsigned vm[3] = {0u, 0u, 0u};      // a.in.sc: which elements of a register set lie inside the image (the affine must not touch the padding)
+        // ... and the channel affine of the NEXT tile to be written to LDS for this thread's quad, requested right after the previous
+        // tile's LDS writes and BEFORE the next batch of tile loads (vector memory returns in order: requested at write time it
+        // would wait for the two tiles requested in between)
+        float4 as4 = make_float4(1.f, 1.f, 1.f, 1.f), ah4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto load_affine = [&](int t) __attribute__((always_inline)) {
+            if (a.in.sc && t < ntiles) { int n, y0, x0; origin(t, n, y0, x0); view_affine4(a.in, n, c4 * 4, as4, ah4); }
+        };
+        auto issue = [&](int t, i32x4_t (&dst)[ITERS], unsigned& vmask) __attribute__((always_inline)) {
             int n, y0, x0;
             origin(t, n, y0, x0);
             const int ylo = max(0, 1 - y0), yhi = min(THH, a.H + 1 - y0);
@@ -440,6 +449,11 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
             if (ragged) { const long rem = (in_total - org) * 4; nrec = rem < 0x7fffff00l ? (int)rem : 0x7fffff00; }
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, nrec, RSRC3);
+            if (a.in.sc) {
+                vmask = 0u;
+#pragma unroll
+                for (int u = 0; u < ITERS; ++u) vmask |= (soff[u] != OOB ? 1u : 0u) << u;
+            }
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) {
 #if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 3
@@ -449,14 +463,22 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
 #endif
             }
         };
-        auto put = [&](const i32x4_t (&src)[ITERS], float* tile) __attribute__((always_inline)) {
+        auto put = [&](const i32x4_t (&src)[ITERS], float* tile, unsigned vmask) __attribute__((always_inline)) {
+            const float4 s4 = as4, h4 = ah4;
             float* d0 = tile + p0 * P + c4 * 4;
+            // channel affine of the view (ChannelAttention2D's scale / its backward, see TView): this thread's channel quad is
+            // fixed, the image is the tile's; applied on the way into LDS, inside the image only
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) {
                 if (u + 1 < ITERS || (hyx[u] >> 8) < THH) {
+                    i32x4_t v = src[u];
+                    if (a.in.sc && ((vmask >> u) & 1u)) {
+                        const float4 f = affine4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])), s4, h4);
+                        v = (i32x4_t){__float_as_int(f.x), __float_as_int(f.y), __float_as_int(f.z), __float_as_int(f.w)};
+                    }
                     int2* d = reinterpret_cast<int2*>(d0 + u * (128 * P));
-                    d[0] = make_int2(src[u][0], src[u][1]);
-                    d[1] = make_int2(src[u][2], src[u][3]);
+                    d[0] = make_int2(v[0], v[1]);
+                    d[1] = make_int2(v[2], v[3]);
                 }
             }
         };
@@ -481,10 +503,12 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
         };
         const int t0 = blockIdx.x;
         if (t0 < ntiles) describe(t0, dsc[0]);
-        if (t0 < ntiles) issue(t0, r[0]);
-        if (t0 + G < ntiles) issue(t0 + G, r[1]);
-        if (t0 < ntiles) put(r[0], lds);
-        if (t0 + 2 * G < ntiles) issue(t0 + 2 * G, r[2]);
+        load_affine(t0);
+        if (t0 < ntiles) issue(t0, r[0], vm[0]);
+        if (t0 + G < ntiles) issue(t0 + G, r[1], vm[1]);
+        if (t0 < ntiles) put(r[0], lds, vm[0]);
+        load_affine(t0 + G);
+        if (t0 + 2 * G < ntiles) issue(t0 + 2 * G, r[2], vm[2]);
         __syncthreads();                                          // S0: tile 0 staged
         // iteration k (beside the MFMAs of tile k): write tile k+1, request tile k+3 into the set tile k used
         int k = 0;
@@ -494,9 +518,10 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
                 const int tk = t + j * G;
                 if (tk < ntiles) {
                     PT_TIC();
-                    if (tk + G < ntiles) { put(r[(j + 1) % 3], lds + ((k + 1) & 1) * TILE); describe(tk + G, dsc[(k + 1) & 1]); }
+                    if (tk + G < ntiles) { put(r[(j + 1) % 3], lds + ((k + 1) & 1) * TILE, vm[(j + 1) % 3]); describe(tk + G, dsc[(k + 1) & 1]); }
                     PT_TOC(4);
-                    if (tk + 3 * G < ntiles) issue(tk + 3 * G, r[j]);
+                    load_affine(tk + 2 * G);
+                    if (tk + 3 * G < ntiles) issue(tk + 3 * G, r[j], vm[j]);
                     PT_TOC(5);
                     __syncthreads();                              // X: tile k consumed, tile k+1 staged
                     PT_TOC(6);
@@ -507,6 +532,7 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
 #ifdef PAIR_WS_TRACE
         if (tid == 256) for (int q_ = 4; q_ < 8; ++q_) pair_ws_trace[(size_t)blockIdx.x * 8 + q_] = pt_acc[q_];
 #endif
+        if (a.pool) __syncthreads();                               // P: the MFMA waves' last pooling record (below)
         return;
     }
 
@@ -602,6 +628,11 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
         PT_TOC(0);
         __syncthreads();                                          // X
         PT_TOC(1);
+        // a.pool: the previous tile's per-wave channel sums are complete behind this barrier: one 8-float record per tile
+        if (a.pool && k > 0 && tid < 8) {
+            const float* red = pool_red[(k - 1) & 1];
+            a.pool[(size_t)(t - G) * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
+        }
         if (sig != esig) {
             esig = sig;
             const int ymax = sig >> 8, xmax = sig & 0xff;
@@ -612,6 +643,7 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)mb), 0, 0x7fffff00, RSRC3);
         i32x4_t ad[NR], mk[NR], old[NR];
+        f32x4 psum = {0.f, 0.f, 0.f, 0.f};          // a.pool: this lane's share of the tile's channel sums
         if (a.add.p) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
@@ -639,11 +671,32 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
             if (v[0] == 12345.678f)
 #endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
+            if (a.pool && eoff[i] != OOB) psum += v;
+        }
+        if (a.pool) {
+            // GlobalAveragePooling of ChannelAttention2D (blocks.py:585-588) from this epilogue: per-tile channel sums in the
+            // fixed order of conv_narrow_pair_kernel (16 pair columns, the two pixels of a pair, the four waves through LDS)
+#pragma unroll
+            for (int mk_ = 1; mk_ < 16; mk_ <<= 1) {
+                psum[0] += __shfl_xor(psum[0], mk_, 64); psum[1] += __shfl_xor(psum[1], mk_, 64);
+                psum[2] += __shfl_xor(psum[2], mk_, 64); psum[3] += __shfl_xor(psum[3], mk_, 64);
+            }
+            psum[0] += __shfl_xor(psum[0], 32, 64); psum[1] += __shfl_xor(psum[1], 32, 64);
+            psum[2] += __shfl_xor(psum[2], 32, 64); psum[3] += __shfl_xor(psum[3], 32, 64);
+            if (lane == 0 || lane == 16) *reinterpret_cast<f32x4*>(pool_red[k & 1] + wave * 8 + (lane >> 4) * 4) = psum;
         }
         PT_TOC(2);
 #ifdef PAIR_WS_TRACE
         pt_acc[3] += 1;
 #endif
+    }
+    if (a.pool) {
+        __syncthreads();                                          // P (the loaders arrive here too)
+        if (k > 0 && tid < 8) {
+            const float* red = pool_red[(k - 1) & 1];
+            const int tl = (int)blockIdx.x + (k - 1) * G;
+            a.pool[(size_t)tl * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
+        }
     }
 #ifdef PAIR_WS_TRACE
     if (tid == 0) for (int q_ = 0; q_ < 4; ++q_) pair_ws_trace[(size_t)blockIdx.x * 8 + q_] = pt_acc[q_];
@@ -658,7 +711,7 @@ __global__ void __launch_bounds__(512, 2) conv_narrow_pair_ws_kernel(const ConvP
 // store per output row.  conv_narrow_kernel<16> -- load, LDS, MFMA and store phases inside every wave -- held the matrix
 // pipe 43 % busy (profiles/pmc_mfma_r02.txt) at 74 TFLOP/s stand-alone, 58-63 inside the models.
 template <int NR>
-__global__ void __launch_bounds__(512, NR <= 4 ? 2 : 1) conv_narrow16_ws_kernel(const ConvParams a) {
+__global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvParams a) {    // (2 waves per SIMD: ONE workgroup per CU -- 144 registers; capped at 128 for two workgroups it spills and runs at half the rate)
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int PTW = 16, PTH = 4 * NR;
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
@@ -916,7 +969,9 @@ bool narrow_pair_ws_ok(const ConvParams& p) {
     // 16-byte buffer loads only need dword alignment, what a quad picks up beyond Cin meets zero filter entries, and the
     // descriptor's exact size makes the buffer unit zero-fill at the very end of the view
     static const bool no_ragged = getenv("DL4DS_NO_PAIR_WS_RAGGED") != nullptr;
-    if (off || p.pool || p.in.sc || p.in.d2s > 1) return false;
+    if (off || p.in.d2s > 1) return false;
+    if ((p.pool || p.in.sc) && getenv("DL4DS_NO_PAIR_WS_FUSED")) return false;      // (A/B: attention pieces through the older kernel)
+    if (p.in.sc && (!p.in.vec || (p.Cin & 3))) return false;
     if ((!p.in.vec || (p.Cin & 3)) && no_ragged) return false;
     if (p.add.p && !same_layout(p.add, p.out)) return false;
     if (p.mask.p && !same_layout(p.mask, p.out)) return false;
