@@ -56,8 +56,6 @@ def run_job(job, meta, mine):
                                                      loss=meta['loss'])
                     add(tag, g, 1.0 / B)
                     losses.setdefault(tag, [0.0])[0] += lv / B
-                    if tag == 'p':
-                        preds.append(pred.numpy())
                 else:
                     PG, PD = params('g', dt), params('d', dt)
                     v_shape.update({k: v.shape for k, v in PG.items()})
@@ -71,6 +69,15 @@ def run_job(job, meta, mine):
                     cur = losses.setdefault(tag, [0.0, 0.0, 0.0, 0.0])
                     for j, k in enumerate(('gen_total', 'gen_gan', 'gen_px', 'disc')):
                         cur[j] += r[k] / B
+    if meta['what'] == 'supervised':
+        # the reference PREDICTION is the plain fp64 forward pass (no displacement): the mid-point of the displaced passes
+        # is a reference for gradients, its forward values sit ~1e-5 off
+        import torch
+        with torch.no_grad():
+            P0 = params('w', np.float64)
+            for i in mine:
+                sl = slice(i, i + 1)
+                preds.append(TR.forward(meta['kind'], meta['cfg'], P0, arr('x', sl, np.float64), arr('s', sl, np.float64)).numpy())
     out = dict(acc)
     for tag, v in losses.items():
         out['loss/' + tag] = np.asarray(v, np.float64)

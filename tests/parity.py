@@ -192,7 +192,14 @@ def banded_reference(call, band=BAND):
                 noise={k: float(np.abs(res['f32'][1][k] - mid[k]).max()) if mid[k].size else 0.0 for k in names},
                 losses=0.5 * (res['p'][0] + res['m'][0]), loss=float(0.5 * (res['p'][0][0] + res['m'][0][0])),
                 loss_spread=float(np.abs(res['p'][0] - res['m'][0]).max()),
-                pred=None if res['p'][2] is None else 0.5 * (res['p'][2] + res['m'][2]))
+                pred=None if res['p'][2] is None else plain_forward(call))
+
+
+def plain_forward(call):
+    """Prediction of ``call`` in fp64 with NO displacement (the displaced passes' forward values sit ~1e-5 off)."""
+    from oracle import torch_ops as T
+    with T.kink_shift(0.0):
+        return _np(call(np.float64)[2]).astype(np.float64)
 
 
 def oracle_reference(what, kind, cfg, weights, x, s, y, loss='mae', dcfg=None, dweights=None, mask=None, band=BAND,

@@ -305,7 +305,10 @@ def test_cfg4_full_size_against_the_oracle():
     y = _targets_clear_of_the_kink(out, rng)
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x, aux], y))
-    assert any(t.startswith('conv_narrow<16>') for t in tags) and any(t.startswith('convlstm') for t in tags), sorted(tags)
+    # the bench's kernels: the persistent ConvLSTM recurrence (both directions, 5x5 and 3x3) and the 16-channel layer
+    for must in ('convlstm_seq_fwd<5,8>', 'convlstm_seq_fwd<3,8>', 'convlstm_seq_bwd<5,8>', 'convlstm_seq_bwd<3,8>', 'conv_narrow16_ws<4>'):
+        assert must in tags, (must, sorted(tags))
+    assert not any(t.startswith('convlstm_gates') for t in tags), sorted(tags)
     ref = oracle_reference('supervised', 'recnet_postupsampling', CFG4_OCFG, w, x, aux, y, loss='mae', workers=ORACLE_WORKERS)
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
@@ -343,7 +346,7 @@ def test_cfg5_generator_full_size_against_the_oracle():
     y = _targets_clear_of_the_kink(out, rng)
     eng = SupervisedEngine(gen, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([lr, st], y))
-    for must in ('conv_narrow_pair_ws<4>', 'conv_narrow<16>', 'conv_narrow_wgrad<8>'):
+    for must in ('conv_narrow_pair_ws<4>', 'conv_narrow16_ws<4>', 'conv_narrow_wgrad<8>'):
         assert must in tags, (must, sorted(tags))
     assert any(t.startswith('conv_stream_ws<5,') for t in tags), sorted(tags)
     ref = oracle_reference('supervised', 'unet_pin', CFG5_GCFG, w, lr, st, y, loss='mae', workers=ORACLE_WORKERS)

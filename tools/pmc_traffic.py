@@ -16,11 +16,13 @@ def collect(root, counter):
 fetch = collect(sys.argv[1], 'FETCH_SIZE')
 write = collect(sys.argv[2], 'WRITE_SIZE')
 def tag_of(k):
-    m = re.search(r'(conv_\w+)<([^>]*)>', k)
+    m = re.search(r'(conv\w+)<([^>]*)>', k)
     if not m:
         return k[:60]
     args = m.group(2).replace(' ', '').split(',')
     name = m.group(1)
+    if name.startswith('convlstm_seq'):
+        args = args[:2]                      # <KS,F> (the tile-rows parameter is not part of bench.py's tag)
     if 'igemm_db' in name:
         args = args[:5]                      # bench.py's tag carries <KS,MT,NT,WM,WN> only
     if name.startswith('conv_wgrad_rows'):
