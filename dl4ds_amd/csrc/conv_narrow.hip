@@ -745,6 +745,11 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
         const int htid = tid & 255;
         const int c4 = htid & 3, p0 = htid >> 2;
         const size_t isx = a.in.ld, isy = (size_t)a.W * a.in.ld;
+        // channel counts / pixel pitches that are not multiples of four (the 13-channel layer behind TransitionLast 26 -> 13,
+        // 16-channel slices of a 26-channel concatenation): the 16-byte buffer loads only need dword alignment, what a quad
+        // picks up beyond Cin meets zero filter entries, the descriptor's exact size zero-fills at the very end of the view
+        const bool ragged = (a.Cin & 3) != 0 || (a.in.ld & 3) != 0;
+        const long in_total = (long)((size_t)(a.in.N - 1) * a.in.nstride + (size_t)a.H * a.W * a.in.ld);
         int rel[ITERS], soff[ITERS], hyx[ITERS];
 #pragma unroll
         for (int u = 0; u < ITERS; ++u) {
@@ -772,8 +777,10 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
                 }
             }
             const long org = (long)((size_t)n * a.in.nstride) + (long)(y0 - 1) * (long)isy + (long)(x0 - 1) * (long)isx;
+            int nrec = 0x7fffff00;
+            if (ragged) { const long rem = (in_total - org) * 4; nrec = rem < 0x7fffff00l ? (int)rem : 0x7fffff00; }
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+                const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, nrec, RSRC3);
 #pragma unroll
             for (int u = 0; u < ITERS; ++u) dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[u], 0, 0);
         };
@@ -842,6 +849,7 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
     // lane (pixel column l15, k-slot lq) ends with rows 4 lq + r = couts 4 lq .. 4 lq + 3 of its pixel
     const int ec = 4 * lq;
     const bool c_ok = ec < a.Cout;
+    const int nvalid = min(max(a.Cout - ec, 0), 4);              // channels of this lane's quad that exist
     const float4 bias_v = (a.bias && c_ok) ? *reinterpret_cast<const float4*>(a.bias + ec) : make_float4(0.f, 0.f, 0.f, 0.f);
     const f32x4 bias_c = {bias_v.x, bias_v.y, bias_v.z, bias_v.w};
     size_t osx, osy;
@@ -931,7 +939,14 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
                 v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
             }
             if (a.accumulate) v += __builtin_bit_cast(f32x4, old[i]);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
+            if (nvalid == 4) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
+            } else {
+                // Cout % 4 != 0 (8 -> 13): the last quad of a pixel ends in the next pixel -- its valid channels go out one by one
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < nvalid) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[j]), ro, eoff[i] + 4 * j, 0, 0);
+            }
         }
     }
 }
@@ -939,8 +954,15 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
 bool narrow16_ws_ok(const ConvParams& p) {
     static const bool off = getenv("DL4DS_NO_NARROW16_WS") != nullptr;
     auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
-    if (off || p.pool || p.in.sc || p.in.d2s > 1 || !p.in.vec || (p.Cin & 3) || p.Cin <= 8) return false;
-    if (!p.out.vec || (p.Cout & 3) || (p.add.p && !p.add.vec) || (p.mask.p && !p.mask.vec)) return false;
+    static const bool no_ragged = getenv("DL4DS_NO_NARROW16_WS_RAGGED") != nullptr;      // (A/B)
+    if (off || p.pool || p.in.sc || p.in.d2s > 1) return false;
+    if (p.Cin <= 8) return false;          // (conv_narrow_kernel<8> issues half the MFMAs there; measured on 8 -> 13 at 128 x 256^2: 0.54 ms there, 0.59 here)
+    if ((!p.in.vec || (p.Cin & 3)) && no_ragged) return false;
+    if ((((uintptr_t)p.in.p) & 3) != 0) return false;
+    // outputs (and the epilogue's operands, which share the output's layout) in a channel slice of a wider buffer -- pixel pitch
+    // not a multiple of 16 bytes -- are fine: buffer_store / buffer_load_dwordx4 only need dword alignment
+    auto quad_ok = [&](const TView& v) { return v.vec || (!no_ragged && v.d2s <= 1 && ((((uintptr_t)v.p) & 3) == 0)); };
+    if (((p.Cout & 3) && (no_ragged || p.out.d2s > 1)) || !quad_ok(p.out) || (p.add.p && !quad_ok(p.add)) || (p.mask.p && !quad_ok(p.mask))) return false;
     if ((((uintptr_t)p.bias) & 15) != 0) return false;
     if (p.add.p && !same_layout(p.add, p.out)) return false;
     if (p.mask.p && !same_layout(p.mask, p.out)) return false;
@@ -951,7 +973,14 @@ bool narrow16_ws_ok(const ConvParams& p) {
 
 template <int NR>
 bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
-    if (!narrow16_ws_ok(p)) return false;
+    if (!narrow16_ws_ok(p)) {
+        if (getenv("DL4DS_NARROW_DEBUG"))
+            fprintf(stderr, "narrow16_ws declined: N=%d H=%d W=%d Cin=%d (ld %d vec %d d2s %d sc %d) Cout=%d (ld %d vec %d d2s %d) add=%d(ld %d vec %d) mask=%d(ld %d vec %d) "
+                            "acc=%d pool=%d bias&15=%d\n", N, p.H, p.W, p.Cin, p.in.ld, p.in.vec, p.in.d2s, p.in.sc != nullptr, p.Cout, p.out.ld, p.out.vec,
+                    p.out.d2s, p.add.p != nullptr, p.add.ld, p.add.vec, p.mask.p != nullptr, p.mask.ld, p.mask.vec, p.accumulate, p.pool != nullptr,
+                    (int)(((uintptr_t)p.bias) & 15));
+        return false;
+    }
     p.tiles_x = cdiv(p.W, 16);
     p.tiles_y = cdiv(p.H, 4 * NR);
     p.m_txy[0] = div_magic(p.tiles_x);
@@ -1426,11 +1455,10 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
         launch_narrow_pair<NARROW_PAIR_ROWS>(s, p, in.N);
         return true;
     }
-    if (in.C <= 8) launch_narrow<8>(s, p, in.N);
-    else {
+    {
         static const int nr = getenv("DL4DS_NARROW16_NR") ? atoi(getenv("DL4DS_NARROW16_NR")) : 4;       // (experiments)
         const bool done = nr == 8 ? launch_narrow16_ws<8>(s, p, in.N) : (nr == 2 ? launch_narrow16_ws<2>(s, p, in.N) : launch_narrow16_ws<4>(s, p, in.N));
-        if (!done) launch_narrow<16>(s, p, in.N);
+        if (!done) { if (in.C <= 8) launch_narrow<8>(s, p, in.N); else launch_narrow<16>(s, p, in.N); }
     }
     return true;
 }

@@ -133,6 +133,9 @@ void Graph::prepare(int B) {
     for (size_t i = 0; i < ops.size(); ++i) soff[i] = bump(ops[i]->saved_floats_per_sample(*this) * B + 64);
     float* slab = nullptr;
     HIP_CHECK(hipMalloc((void**)&slab, total * sizeof(float)));
+    // once per (re)allocation: kernels that load 16-byte quads at dword alignment read floats that belong to a neighbouring
+    // pixel / channel slice and multiply them by zero filter entries -- those floats must be finite from the first step on
+    HIP_CHECK(hipMemsetAsync(slab, 0, total * sizeof(float), stream));
     allocations.push_back(slab);
     for (size_t i = 0; i < tensors.size(); ++i) {
         tensors[i].data = (doff[i] == (size_t)-1) ? nullptr : slab + doff[i];

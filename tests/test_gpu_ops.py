@@ -56,6 +56,12 @@ CONV_CASES = [
     # streamed-filter MFMA path (conv_stream.hip): Cin >= 16, Cin % 4 == 0, Cout % 4 == 0, H*W >= 256
     (1, 16, 16, 48, 48, 3), (2, 20, 33, 48, 192, 3), (1, 16, 16, 192, 48, 3), (1, 17, 19, 24, 32, 3),
     (1, 18, 16, 32, 64, 3), (1, 16, 17, 64, 24, 3), (1, 16, 16, 96, 40, 3), (2, 32, 32, 40, 40, 3), (1, 16, 16, 20, 36, 3),
+    # producer / consumer kernel for 9..16 input channels (conv_narrow16_ws), incl. channel counts that are not multiples of
+    # four (16-byte loads at dword alignment, zero filter rows beyond Cin) and ragged / multi-tile grids
+    (2, 20, 33, 13, 8, 3), (1, 17, 16, 15, 16, 3), (1, 16, 18, 9, 12, 3), (3, 40, 35, 16, 16, 3), (2, 64, 64, 12, 4, 3),
+    (1, 5, 3, 13, 8, 3),
+    # ... and output channel counts that are not multiples of four (the last quad of a pixel stored channel by channel)
+    (2, 20, 33, 8, 13, 3), (1, 17, 16, 16, 10, 3), (1, 16, 18, 4, 15, 3), (2, 19, 21, 13, 13, 3),
 ]
 
 
