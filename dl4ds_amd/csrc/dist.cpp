@@ -122,7 +122,9 @@ void dist_allreduce_bucket_async(float* buf, size_t n, hipStream_t stream, hipSt
 // order would leave the others in hipStreamSynchronize for ever.  Poll instead, surface RCCL's asynchronous errors and
 // give up after DL4DS_COLLECTIVE_TIMEOUT_S (default 1800 s) with a message that names the call.
 void dist_stream_sync(hipStream_t stream, const char* what) {
-    if (g_comm == nullptr || g_world <= 1) {
+    // (DL4DS_FORCE_WATCHDOG=1: take the polling path with a 1-rank communicator too -- the only way to exercise it on one GPU)
+    static const bool force = std::getenv("DL4DS_FORCE_WATCHDOG") != nullptr;
+    if (g_comm == nullptr || (g_world <= 1 && !force)) {
         HIP_CHECK(hipStreamSynchronize(stream));
         return;
     }
@@ -134,6 +136,9 @@ void dist_stream_sync(hipStream_t stream, const char* what) {
     const auto t0 = std::chrono::steady_clock::now();
     for (long spin = 0;; ++spin) {
         const hipError_t e = hipStreamQuery(stream);
+        // hipErrorNotReady is a status, but HIP records it as the thread's sticky "last error": clear it, or the next
+        // HIP_CHECK(hipGetLastError()) after a kernel launch would report it
+        if (e == hipErrorNotReady) (void)hipGetLastError();
         if (e == hipSuccess) return;
         if (e != hipErrorNotReady) HIP_CHECK(e);
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -208,3 +208,29 @@ def test_two_real_ranks_average_gradients_and_stay_identical(tmp_path):
         lr_t = 1e-3 * np.sqrt(1 - b2) / (1 - b1)
         w1 = z[0]['w0/' + k] - lr_t * m_ / (np.sqrt(v_) + eps)
         np.testing.assert_allclose(z[0]['w1/' + k], w1, rtol=0, atol=2e-6, err_msg='Adam on the averaged gradient: ' + k)
+
+
+def test_watchdog_polling_path_on_a_one_rank_communicator():
+    """The host-side waits poll the stream (instead of blocking) when several ranks take part, so that a stranded peer fails
+    loudly.  DL4DS_FORCE_WATCHDOG=1 takes that path with a 1-rank communicator: train steps with loss read-back, host
+    reductions and dl4ds_sync must work through it -- in particular hipStreamQuery's hipErrorNotReady must not linger as the
+    thread's last error and surface at the next kernel launch."""
+    r = _run('''
+        import sys, numpy as np
+        sys.path.insert(0, %(root)r)
+        from dl4ds_amd import parallel
+        import dl4ds_amd.models as PM
+        from dl4ds_amd.training import SupervisedEngine
+        parallel.init_with_id(0, 1, parallel.unique_id())
+        m = PM.net_postupsampling('resnet', 'spc', 2, 1, 0, (16, 16), n_blocks=1, n_filters=4, seed=1)
+        eng = SupervisedEngine(m, loss='mae', learning_rate=1e-3)
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal((2, 16, 16, 1)).astype(np.float32); y = rng.standard_normal((2, 32, 32, 1)).astype(np.float32)
+        losses = [eng.step([x], y) for _ in range(5)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        assert parallel.allreduce_host([3.0], 'max') == [3.0]
+        parallel.barrier()
+        parallel.finalize()
+        print('WATCHDOG-OK')
+    ''', env={'DL4DS_FORCE_WATCHDOG': '1'})
+    assert r.returncode == 0 and 'WATCHDOG-OK' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
