@@ -183,6 +183,62 @@ def test_conv2d_stream_producer_consumer_depth_to_space(ops, monkeypatch, ci, co
     close(ops.conv2d_dgrad(dz, wt, d2s=r), gx)
 
 
+WINO_CASES = [
+    # one pass of 48 / 32 input channels, one .. four chunks of 48 / 32 couts, ragged grids (odd sizes: half tiles)
+    (2, 40, 33, 48, 48), (3, 64, 48, 48, 192), (2, 33, 40, 32, 32), (1, 48, 32, 40, 40), (2, 20, 50, 24, 48), (1, 35, 21, 48, 96),
+    (1, 17, 19, 24, 32), (5, 32, 16, 24, 24), (2, 32, 32, 48, 40), (1, 18, 16, 32, 64), (1, 16, 16, 28, 36),
+    # several passes over the input channels (192 -> 48 is the dgrad of SubpixelConvolution's conv2x)
+    (1, 33, 17, 192, 48), (2, 17, 33, 96, 96), (1, 16, 17, 64, 24), (1, 20, 20, 144, 40),
+]
+
+
+@pytest.mark.parametrize('sx', ['', '1'])
+@pytest.mark.parametrize('n,h,w,ci,co', WINO_CASES)
+def test_conv2d_winograd(ops, monkeypatch, sx, n, h, w, ci, co):
+    """conv_wino_kernel (Winograd F(2x2, 3x3), conv_wino.hip) is only picked for grids that give every workgroup several tile
+    groups; DL4DS_WINO_FORCE makes it take these small ones ('1': one workgroup per XCD and cout chunk, i.e. many iterations
+    of the persistent loop): forward with fused epilogues, dgrad with accumulate.  Same 2e-4 bar as the direct kernels."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_WINO_FORCE', sx or 'all')
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert any(t.startswith('conv_wino<') for t in tags), tags
+    close(got, ref)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt))
+    assert co < 24 or any(t.startswith('conv_wino<') for t in tags), tags
+    close(got, gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+    monkeypatch.setenv('DL4DS_NO_WINOGRAD', '1')
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert not any(t.startswith('conv_wino<') for t in tags), tags
+    close(got, ref)
+
+
+@pytest.mark.parametrize('ci,co', [(48, 192), (48, 32), (24, 32), (48, 96), (32, 128)])
+def test_conv2d_winograd_depth_to_space(ops, monkeypatch, ci, co):
+    """... through depth_to_space views on the output (forward) and the input (dgrad), also with groups narrower than a cout
+    chunk / a channel pass (32 couts = 4 groups of 8: the composed upsampling tail of the headline model)."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_WINO_FORCE', '1')
+    n, h, w, r = 2, 34, 20, 2
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b, d2s=r))
+    assert any(t.startswith('conv_wino<') for t in tags), tags
+    close(got, ref)
+    dz = R(n, h * r, w * r, co // (r * r))
+    gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt, d2s=r))
+    assert any(t.startswith('conv_wino<') for t in tags), tags
+    close(got, gx)
+
+
 @pytest.mark.parametrize('ci,co', [(8, 8), (4, 8), (8, 4), (6, 8)])
 def test_conv2d_fused_epilogues_pair_path(ops, ci, co):
     n, h, w = 2, 19, 45
