@@ -276,7 +276,8 @@ def main():
     for _ in range(max(args.warmup - nprof, 0)):
         step()
     breakdown, dom, dom_share = None, None, None
-    executed_gflop_per_step = mfma_gflop_per_step = None
+    executed_gflop_per_step = mfma_gflop_per_step = direct_gflop_per_step = None
+    winograd = False
     hbm_kernels = None
 
     def report():
@@ -296,9 +297,14 @@ def main():
                          'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else None,
                          'gbps': v['bytes'] / (v['ms'] * 1e-3) / 1e9}
                      for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms'])}
+        # (issued work: the Winograd launches count the multiply-adds they issue -- 4 per output and (cin, cout) pair on the
+        #  padded operands plus the transforms' additions -- not the 9 of the direct form; `direct_form_gflop_per_sample` is
+        #  the same step priced as the direct kernels would execute it)
         executed_gflop_per_step = sum(v['flops'] for v in rep.values()) / nprof / 1e9
+        direct_gflop_per_step = sum(v.get('direct_flops', v['flops']) for v in rep.values()) / nprof / 1e9
+        winograd = any(k.startswith('conv_wino') for k in rep)
         mfma_gflop_per_step = sum(v['flops'] for k, v in rep.items()
-                                  if k.startswith(('conv_stream', 'conv_wgrad', 'conv_igemm', 'conv_narrow', 'conv_pack'))
+                                  if k.startswith(('conv_stream', 'conv_wgrad', 'conv_igemm', 'conv_narrow', 'conv_pack', 'conv_wino'))
                                   ) / nprof / 1e9
         # memory-bound kernels (north_star: "achieved HBM GB/s for the memory-bound upsampling/attention kernels"):
         # algorithmic bytes (one read of each input + one write of each output) / HIP-event duration, vs the 8 TB/s spec
@@ -352,6 +358,12 @@ def main():
                         'algorithmic_bytes_per_launch': d['bytes'] / d['n'],
                         'launches': d['n'], 'avg_launch_ms': d['ms'] / d['n'],
                         'algorithmic_gflop_per_launch': d['flops'] / d['n'] / 1e9,
+                        **({'winograd': True,
+                            'note': 'achieved / frac price the multiply-adds this kernel ISSUES (F(2x2,3x3): 4 per output and '
+                                    '(cin, cout) pair + transforms); direct_form_* is the same layer at the 9 of the direct form',
+                            'direct_form_gflop_per_launch': d.get('direct_flops', d['flops']) / d['n'] / 1e9,
+                            'direct_form_tflops': d.get('direct_flops', d['flops']) / (d['ms'] * 1e-3) / 1e12}
+                           if dom.startswith('conv_wino') else {}),
                         'share_of_step_time': dom_share,
                         'measured': 'HIP events around every launch of this kernel inside the timed region'}
 
@@ -370,7 +382,9 @@ def main():
             'step_tflops_per_gpu': (executed_gflop_per_step / ms_step) if executed_gflop_per_step else None,
             'mfma_conv_frac_of_peak': (mfma_gflop_per_step / ms_step / PEAK_FP32_MFMA_TFLOPS) if mfma_gflop_per_step else None,
             'executed_gflop_per_sample': (executed_gflop_per_step / B) if executed_gflop_per_step else None,
+            'direct_form_gflop_per_sample': (direct_gflop_per_step / B) if direct_gflop_per_step else None,
             'conv_folding': not bool(os.environ.get('DL4DS_NO_FOLD')),
+            'winograd': winograd,
             'roofline': roofline,
             'hbm_kernels': hbm_kernels,
             'cpu_baseline': None,

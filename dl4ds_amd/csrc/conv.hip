@@ -1605,6 +1605,7 @@ size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS) {
 void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* dw, int accumulate, float* db,
                   int accumulate_db, float* workspace, size_t workspace_bytes) {
     DL4DS_REQUIRE(x.N == dz.N && x.H == dz.H && x.W == dz.W, "wgrad: shapes differ");
+    if (KS == 3 && conv2d_wino_wgrad(s, x, dz, dw, accumulate, db, accumulate_db)) return;     // MFMA-bound 3x3 layers: Winograd
     WgradPlan pl = plan_wgrad(x, dz, KS);
     const size_t nw = (size_t)KS * KS * x.C * dz.C;
     const size_t n = nw + dz.C;

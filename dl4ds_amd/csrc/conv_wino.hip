@@ -93,7 +93,8 @@ bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const T
     if (passes > 1 && ep.accumulate) return false;
     const int full_epi = (ep.add.p ? WINO_ADD : 0) | (ep.mask.p ? WINO_MASK : 0) | (ep.accumulate ? WINO_OLDA : 0);
     if (!wino_epi_built(full_epi) || (passes > 1 && !wino_epi_built(full_epi | WINO_OLDF))) return false;
-    const int NT = out.C <= 32 ? 2 : 3;
+    // cout chunks of 32 or 48: the least padding, then the wider chunk (the input transform is paid once per chunk)
+    const int NT = (cdiv(out.C, 32) * 32 < cdiv(out.C, 48) * 48) ? 2 : 3;
     WinoParams wp;
     ConvParams& p = wp.c;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
@@ -119,7 +120,8 @@ bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const T
     const double issued = 2.0 * (px / 4.0) * 16.0 * (16.0 * KQ * passes) * (16.0 * NT * wp.nchunk) +
                           (px / 4.0) * (32.0 * in.C * wp.nchunk + 24.0 * out.C * passes);
     ProfScope ps(s, "conv_wino<" + std::to_string(KQ) + "," + std::to_string(NT) + ">", issued,
-                 4.0 * (px * (in.C + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))) + 9.0 * in.C * out.C));
+                 4.0 * (px * (in.C + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))) + 9.0 * in.C * out.C),
+                 2.0 * px * 9.0 * in.C * out.C);
     const size_t per_pass = (size_t)wp.nchunk * 4 * (16 * KQ * NT) * 64;
     float* const u = wino_scratch(s, per_pass * passes);
     {

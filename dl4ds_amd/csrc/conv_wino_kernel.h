@@ -140,7 +140,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         const int hy = hp / HW, hx = hp - hy * HW;
         soff[u] = (q_ok && hp < HPIX) ? rel_of(hy, hx) : OOB;
     }
-    int st_sig = (HH << 8) | HW;
     const bool st_last = st_active && sp0 + PPASS * (SIT - 1) < HPIX;
     struct Item { int n, y0, x0; };
     auto decode = [&](int t) {
@@ -159,15 +158,16 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
     auto stage_issue = [&](const Item& it) __attribute__((always_inline)) {
         const int ylo = max(0, 1 - it.y0), yhi = min(HH, a.H + 1 - it.y0);
         const int xlo = max(0, 1 - it.x0), xhi = min(HW, a.W + 1 - it.x0);
-        const int sig = (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
-        if (sig != st_sig) {                                        // (border tile groups; the empty asm keeps it a branch)
+        int so[SIT];
+#pragma unroll
+        for (int u = 0; u < SIT; ++u) so[u] = soff[u];
+        if (ylo | xlo | (yhi - HH) | (xhi - HW)) {                  // border tile groups (the empty asm keeps it a branch)
             asm volatile("" ::: "memory");
-            st_sig = sig;
 #pragma unroll
             for (int u = 0; u < SIT; ++u) {
                 const int hp = sp0 + PPASS * u;
                 const int hy = hp / HW, hx = hp - hy * HW;
-                soff[u] = (q_ok && hp < HPIX && hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? rel_of(hy, hx) : OOB;
+                so[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? soff[u] : OOB;
             }
         }
         const long org = (long)((size_t)it.n * a.in.nstride) + (long)(it.y0 - 1) * (long)isy + (long)(it.x0 - 1) * (long)isx;
@@ -177,9 +177,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
 #pragma unroll
         for (int u = 0; u < SIT; ++u)
             if (u + 1 < SIT ? st_active : st_last)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(raw + st_wave + u * (PPASS * Q4 * 4)), 16, soff[u], 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(raw + st_wave + u * (PPASS * Q4 * 4)), 16, so[u], 0, 0, 0);
 #else
-        (void)rs; (void)st_wave; (void)st_last;
+        (void)rs; (void)st_wave; (void)st_last; (void)so;
 #endif
     };
     auto stage_landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -196,11 +196,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
     view_strides(a.out, osy, osx);
     int dvo[ND], prd[ND];
     const int nq = min(NQ, max(0, (a.Cout - n0) >> 2));
-    auto out_off = [&](int u, int ymax, int xmax) {
+    auto out_off = [&](int u) {
         const int e = tid + 256 * u;
         const int pix = e / NQ, quad = e - pix * NQ;
         const int py = pix >> 4, px = pix & 15;
-        if (py >= ymax || px >= xmax || quad >= nq) return OOB;
+        if (quad >= nq) return OOB;
         return (int)((py * osy + px * osx + view_chan_off(a.out, n0 + 4 * quad)) * 4);
     };
     // (256 % NQ == 4 % NQ and 16 NQ pixels per row pair: whether an element belongs to the upper or the lower row of its tile
@@ -212,11 +212,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         const int py = pix >> 4, px = pix & 15;
         const int t = (py >> 1) * 8 + (px >> 1), i = py & 1, j = px & 1;
         prd[u] = (((i * 2 + j) * 16 + t) * PP + 4 * quad) | (i << 30);        // (bit 30: lower row -> r0 - (r1 + r2))
-        dvo[u] = out_off(u, 4, 16);
+        dvo[u] = out_off(u);
     }
-    int dr_sig = (4 << 8) | 16;
     const float floor_v = a.relu ? 0.f : -3.0e38f;
     const bool want_bias = wp.first && a.bias != nullptr;
+    const int bias_max = max(a.Cout - 4, 0);                        // (couts beyond Cout are never stored: any finite value will do)
 
     // ---- the wave's row of the transformed filter, as MFMA first operands: lane (row l15, k-slot lq), k-step ks = 4 kq + s
     //      -> U[xi = wave][nu][cin = cin0 + 16 kq + 4 lq + s][cout = n0 + 16 cb + l15]; nu = 3 is stored NEGATED: its
@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
     WT(0);
     for (;;) {
         // ---- A: V = B^T d B (rows 1 and 2 of the halo feed all four xi)
+#ifndef WINO_NO_A
         if (a_on) {
             const float* rp = raw + a_rd;
             float* vp = Vb + a_wr;
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
             for (int c = 0; c < 4; ++c) T[c] = sub4(d1[c], *reinterpret_cast<const f32x4*>(rp + (3 * HW + c) * RP));
             emit(3, T);
         }
+#endif
         WT(1);
         __syncthreads();                                            // V complete, raw consumed
         WT(2);
@@ -291,12 +293,18 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         Item nxt = cur;
         if (has_next) {
             nxt = decode(ntg);
+#ifndef WINO_NO_LOAD
             stage_issue(nxt);
+#endif
         }
         WT(3);
         // ---- B: wave xi, M[nu] = U[xi][nu]^T V[xi][nu] over cin; R0 = M0 + M1 + M2, R1 = M1 - M2 - M3.  nu = 0 accumulates in
         //      R0 and nu = 3 (negated filter) in R1 directly; M1 and M2 are added / subtracted by the vector unit
         f32x4 R0[NT], R1[NT];
+#ifdef WINO_NO_B
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb) { R0[cb] = (f32x4){U[0][0][cb], 0.f, 0.f, 0.f}; R1[cb] = R0[cb]; }
+#else
         {
             constexpr int AVB = (16 * KQ * NT > 128) ? 1 : 2;          // (register budget of two workgroups per CU: 256)
             f32x4 av[AVB][KQ];
@@ -337,8 +345,18 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
             }
             kloop(3, 1 % AVB, R1);
         }
+#endif
         WT(4);
         __syncthreads();                                            // every wave has read its rows of V: the products take its place
+        if (want_bias && wave == 1) {
+            // rows 0 and 1 of A^T both carry xi = 1 with coefficient +1: the bias added to R[1][j] reaches all four outputs
+#pragma unroll
+            for (int cb = 0; cb < NT; ++cb) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + min(n0 + 16 * cb + 4 * lq, bias_max));
+                R0[cb] += b4;
+                R1[cb] += b4;
+            }
+        }
 #pragma unroll
         for (int cb = 0; cb < NT; ++cb) {
             *reinterpret_cast<f32x4*>(pwr + 16 * cb) = R0[cb];
@@ -349,14 +367,19 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         __syncthreads();                                            // products complete, next halo staged
         WT(6);
         // ---- C: Y = A^T (M A), epilogue, store
+#ifndef WINO_NO_C
         {
             const int ymax = min(4, a.H - cur.y0), xmax = min(16, a.W - cur.x0);
-            const int sig = (ymax << 8) | xmax;
-            if (sig != dr_sig) {
-                asm volatile("" ::: "memory");
-                dr_sig = sig;
+            int dv[ND];
 #pragma unroll
-                for (int u = 0; u < ND; ++u) dvo[u] = out_off(u, ymax, xmax);
+            for (int u = 0; u < ND; ++u) dv[u] = dvo[u];
+            if ((ymax - 4) | (xmax - 16)) {                          // ragged right / bottom edge
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < ND; ++u) {
+                    const int pix = (tid + 256 * u) / NQ;
+                    dv[u] = ((pix >> 4) < ymax && (pix & 15) < xmax) ? dvo[u] : OOB;
+                }
             }
             const size_t pb = cur.y0 * osy + cur.x0 * osx;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
@@ -364,19 +387,19 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
             i32x4_t e_old[(OLDF || OLDA) ? ND : 1], e_add[ADD ? ND : 1], e_mask[MASK ? ND : 1];
             if (OLDF || OLDA) {
 #pragma unroll
-                for (int u = 0; u < ND; ++u) e_old[u] = __builtin_amdgcn_raw_buffer_load_b128(ro, dvo[u], 0, 0);
+                for (int u = 0; u < ND; ++u) e_old[u] = __builtin_amdgcn_raw_buffer_load_b128(ro, dv[u], 0, 0);
             }
             if (ADD) {
                 const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
                     reinterpret_cast<char*>(a.add.p) + ((size_t)cur.n * a.add.nstride + pb) * 4, 0, 0x7fffff00, RSRC3);
 #pragma unroll
-                for (int u = 0; u < ND; ++u) e_add[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, dvo[u], 0, 0);
+                for (int u = 0; u < ND; ++u) e_add[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, dv[u], 0, 0);
             }
             if (MASK) {
                 const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
                     reinterpret_cast<char*>(a.mask.p) + ((size_t)cur.n * a.mask.nstride + pb) * 4, 0, 0x7fffff00, RSRC3);
 #pragma unroll
-                for (int u = 0; u < ND; ++u) e_mask[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, dvo[u], 0, 0);
+                for (int u = 0; u < ND; ++u) e_mask[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, dv[u], 0, 0);
             }
             f32x4 v[ND];
 #pragma unroll
@@ -387,13 +410,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
                 const f32x4 r2 = *reinterpret_cast<const f32x4*>(p + 4 * 16 * PP);
                 const f32x4 s12 = r1 + r2;
                 v[u] = (prd[u] >> 30) ? sub4(r0, s12) : r0 + s12;
-            }
-            if (want_bias) {
-#pragma unroll
-                for (int u = 0; u < ND; ++u) {
-                    const int quad = (tid + 256 * u) % NQ;
-                    v[u] += *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * min(quad, max(nq - 1, 0)));
-                }
             }
 #pragma unroll
             for (int u = 0; u < ND; ++u) {
@@ -407,9 +423,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
                     r[2] = m[2] > 0.f ? r[2] : 0.f; r[3] = m[3] > 0.f ? r[3] : 0.f;
                 }
                 if (OLDA) r += __builtin_bit_cast(f32x4, e_old[u]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, r), ro, dvo[u], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, r), ro, dv[u], 0, 0);
             }
         }
+#endif
         WT(7);
 #ifdef WINO_TRACE
         tr[0] += 1ull << 48;

@@ -50,6 +50,8 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
 // 3x3, Cin >= 16: filter streamed from L2 into the MFMA operands, no barriers in the K loop (conv_stream.hip)
 // Winograd F(2x2, 3x3) form of the MFMA-bound 3x3 layers (conv_wino.hip); false = not eligible
 bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep);
+// ... and of their weight gradient (conv_wino_wgrad.hip): dw [3][3][Cin][Cout], db [Cout] or null
+bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw, int accumulate, float* db, int accumulate_db);
 bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                            const ConvEpilogue& ep);
 int conv2d_direct_wgrad_slabs(const TView& x, const TView& dz, int KS);

@@ -19,13 +19,13 @@ void Profiler::reset() {
 
 std::string Profiler::report_json(hipStream_t s) {
     (void)hipStreamSynchronize(s);
-    struct Agg { int n = 0; double ms = 0, flops = 0, bytes = 0; };
+    struct Agg { int n = 0; double ms = 0, flops = 0, bytes = 0, direct = 0; };
     std::map<std::string, Agg> agg;
     for (auto& e : entries) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
         Agg& a = agg[e.tag];
-        a.n += 1; a.ms += ms; a.flops += e.flops; a.bytes += e.bytes;
+        a.n += 1; a.ms += ms; a.flops += e.flops; a.bytes += e.bytes; a.direct += e.direct_flops;
     }
     std::ostringstream o;
     o.precision(9);
@@ -35,7 +35,7 @@ std::string Profiler::report_json(hipStream_t s) {
         if (!first) o << ",";
         first = false;
         o << "\"" << kv.first << "\":{\"n\":" << kv.second.n << ",\"ms\":" << kv.second.ms << ",\"flops\":" << kv.second.flops
-          << ",\"bytes\":" << kv.second.bytes << "}";
+          << ",\"bytes\":" << kv.second.bytes << ",\"direct_flops\":" << kv.second.direct << "}";
     }
     o << "}";
     reset();

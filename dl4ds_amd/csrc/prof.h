@@ -8,6 +8,7 @@
 struct ProfEntry {
     std::string tag;
     double flops, bytes;
+    double direct_flops;      // launches that issue fewer multiply-adds than the layer's direct form (Winograd): the direct-form count
     hipEvent_t e0, e1;
 };
 
@@ -26,12 +27,12 @@ Profiler& prof();
 struct ProfScope {
     hipStream_t s;
     int idx = -1;
-    ProfScope(hipStream_t stream, const std::string& tag, double flops, double bytes) : s(stream) {
+    ProfScope(hipStream_t stream, const std::string& tag, double flops, double bytes, double direct_flops = 0.0) : s(stream) {
         Profiler& p = prof();
         if (!p.on) return;
         if (!p.filter.empty() && tag.compare(0, p.filter.size(), p.filter) != 0) return;
         ProfEntry e;
-        e.tag = tag; e.flops = flops; e.bytes = bytes;
+        e.tag = tag; e.flops = flops; e.bytes = bytes; e.direct_flops = direct_flops > 0.0 ? direct_flops : flops;
         e.e0 = p.get_event();
         e.e1 = p.get_event();
         (void)hipEventRecord(e.e0, s);

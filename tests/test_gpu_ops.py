@@ -239,6 +239,41 @@ def test_conv2d_winograd_depth_to_space(ops, monkeypatch, ci, co):
     close(got, gx)
 
 
+@pytest.mark.parametrize('sx', ['all', '1'])
+@pytest.mark.parametrize('n,h,w,ci,co', WINO_CASES)
+def test_conv2d_winograd_wgrad(ops, monkeypatch, sx, n, h, w, ci, co):
+    """conv_wino_wgrad_kernel (conv_wino_wgrad.hip): dW = G^T [sum over tiles (B^T d B) . (A dY A^T)] G, also accumulated into
+    an existing gradient; DL4DS_WINO_FORCE as above ('1': one workgroup per XCD and chunk pair)."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_WINO_FORCE', sx)
+    x, wt, dz = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(n, h, w, co)
+    _, gw = _torch_conv_grads(x, wt, dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_wgrad(x, dz, 3))
+    assert any(t.startswith('conv_wino_wgrad<') for t in tags), tags
+    close(got, gw)
+    np.testing.assert_array_equal(got, ops.conv2d_wgrad(x, dz, 3))          # bitwise reproducible
+    base_w = R(*gw.shape)
+    close(ops.conv2d_wgrad(x, dz, 3, accumulate_into=base_w), gw + base_w)
+    monkeypatch.setenv('DL4DS_NO_WINOGRAD_WGRAD', '1')
+    got, tags = kernel_tags(lambda: ops.conv2d_wgrad(x, dz, 3))
+    assert not any(t.startswith('conv_wino') for t in tags), tags
+    close(got, gw)
+
+
+@pytest.mark.parametrize('ci,co', [(48, 192), (48, 32), (24, 32), (48, 96), (32, 128)])
+def test_conv2d_winograd_wgrad_depth_to_space(ops, monkeypatch, ci, co):
+    """... with the output gradient read through a depth_to_space view (groups of 48, 8, 24 and 32 channels)."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_WINO_FORCE', '1')
+    n, h, w, r = 2, 34, 20, 2
+    x, wt = R(n, h, w, ci), R(3, 3, ci, co) * 0.2
+    dz = R(n, h * r, w * r, co // (r * r))
+    _, gw = _torch_conv_grads(x, wt, dz, d2s=r)
+    got, tags = kernel_tags(lambda: ops.conv2d_wgrad(x, dz, 3, d2s=r))
+    assert any(t.startswith('conv_wino_wgrad<') for t in tags), tags
+    close(got, gw)
+
+
 @pytest.mark.parametrize('ci,co', [(8, 8), (4, 8), (8, 4), (6, 8)])
 def test_conv2d_fused_epilogues_pair_path(ops, ci, co):
     n, h, w = 2, 19, 45

@@ -39,3 +39,28 @@ for H, CI, CO, r in CASES:
             direct_tf = 2.0 * B * H * H * 9 * CI * CO / (tot * 1e-3) / 1e12
             tags = ' + '.join(f"{k} x{v['n'] // reps}" for k, v in rep.items())
             print(f'{H:4d}^2 {CI:3d}->{CO:3d} d2s={r} {mode:6s} {what:5s} {tot:8.4f} ms  {direct_tf:6.1f} direct-equivalent TFLOP/s  [{tags}]', flush=True)
+
+# ---- weight gradients
+print('weight gradients', flush=True)
+for H, CI, CO, r in CASES:
+    x = DeviceArray.from_numpy(rng.standard_normal((B, H, H, CI)).astype(np.float32))
+    rr = max(r, 1)
+    dz = DeviceArray.from_numpy(rng.standard_normal((B, rr * H, rr * H, CO // (rr * rr))).astype(np.float32))
+    dw = DeviceArray.zeros((3, 3, CI, CO))
+    for mode in ('wino', 'direct'):
+        if mode == 'direct':
+            os.environ['DL4DS_NO_WINOGRAD'] = '1'
+        else:
+            os.environ.pop('DL4DS_NO_WINOGRAD', None)
+        for it in range(2):          # (the first round warms up: attributes, scratch)
+            L.check(lib.dl4ds_profile_enable(1))
+            for _ in range(reps):
+                L.check(lib.dl4ds_op_conv2d_wgrad(x.ptr, dz.ptr, dw.ptr, B, H, H, CI, CO, 3, r, 0))
+            buf = ctypes.create_string_buffer(1 << 16)
+            L.check(lib.dl4ds_profile_report(buf, len(buf)))
+            L.check(lib.dl4ds_profile_enable(0))
+        rep = json.loads(buf.value.decode())
+        tot = sum(v['ms'] for v in rep.values()) / reps
+        direct_tf = 2.0 * B * H * H * 9 * CI * CO / (tot * 1e-3) / 1e12
+        tags = ' + '.join(f"{k} x{v['n'] // reps} {v['ms'] / reps:.3f}" for k, v in rep.items())
+        print(f'{H:4d}^2 {CI:3d}->{CO:3d} d2s={r} {mode:6s} wgrad {tot:8.4f} ms  {direct_tf:6.1f} direct-equivalent TFLOP/s  [{tags}]', flush=True)
