@@ -349,7 +349,8 @@ def main():
                     if traffic is not None:
                         traffic_source = ('profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
                                           'command (--config ' + args.config + ') on an earlier run (' + str(tj.get('_round', 'r01')) +
-                                          '), not measured in this run')
+                                          '), not measured in this run; per call of the layer, like achieved (a Winograd '
+                                          'layer with more than 48 input channels is several kernel launches per call)')
                 except Exception:
                     traffic = None
             roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,

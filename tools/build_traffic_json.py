@@ -1,0 +1,35 @@
+"""profiles/traffic.json from the round's PMC passes: {config: {bench tag: HBM bytes per CALL}, '_round': tag}.
+
+    python tools/build_traffic_json.py r03 [dir = gpurun_out/prof_r03]
+
+bench.py's roofline block looks its dominant kernel up here (keyed by config, then by the library profiler's tag).  A tag of
+the library profiler is one CALL of a layer; the Winograd layers with more than 48 input channels run as several kernel
+launches per call (and one small filter-transform launch), so per-launch PMC averages are scaled by launches / calls, both
+counted per step (PMC pass: --steps 3 --warmup 2; calls: the bench line's breakdown is not needed -- the kernel-trace
+statistics of the same command give launches per step for the tag's kernels, the bench line its calls per step)."""
+import json, os, re, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'prof_' + tag) if len(sys.argv) < 3 else sys.argv[2]
+out = {'_round': tag, '_unit': 'HBM bytes per call of the tagged layer kernel(s): (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction'}
+PMC_STEPS = 5
+for cfg in ('cfg2', 'cfg4', 'cfg5'):
+    f = os.path.join(root, f'pmc_traffic_{cfg}_{tag}.json')
+    if not os.path.exists(f):
+        continue
+    t = json.load(open(f))
+    sfx = '' if cfg == 'cfg2' else '_' + cfg
+    line = json.loads(open(os.path.join(root, f'bench_line{sfx}_{tag}.json')).read().strip().splitlines()[-1])
+    dom = line['roofline']['kernel']
+    calls_per_step = line['roofline']['launches'] / line['steps']
+    d = {}
+    for k, v in t.items():
+        if not re.match(r'^[a-z_0-9]+(<[0-9,]*>)?$', k):
+            continue
+        per_call = v['hbm_bytes_per_launch']
+        if k == dom:
+            per_call *= (v['launches'] / PMC_STEPS) / calls_per_step
+        d[k] = per_call
+    out[cfg] = d
+json.dump(out, open(os.path.join(os.path.dirname(root.rstrip('/')), '..', 'profiles', 'traffic.json') if False else
+                    os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'traffic.json'), 'w'), indent=1)
+print({c: len(v) for c, v in out.items() if isinstance(v, dict)})

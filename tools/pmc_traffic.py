@@ -21,6 +21,8 @@ def tag_of(k):
         return k[:60]
     args = m.group(2).replace(' ', '').split(',')
     name = m.group(1)
+    if name.startswith('conv_wino_kernel'):
+        args = args[:2]                      # <KQ,NT> (the epilogue form is not part of bench.py's tag)
     if name.startswith('conv_point'):
         return 'conv_point'                  # bench.py's tag has no template arguments: both tile variants merge
     if name.startswith('convlstm_seq'):
