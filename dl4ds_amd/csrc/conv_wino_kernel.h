@@ -154,6 +154,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
     // the halo goes straight into LDS (buffer_load ... lds: wave-uniform base + 16 bytes per lane = the thread order above);
     // nothing is held in registers while the MFMAs run
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifdef WINO_REGSTAGE
+    constexpr bool REGSTAGE = 16 * KQ * NT <= 96;                  // (experiment: halo through registers where there is room)
+#else
+    constexpr bool REGSTAGE = false;
+#endif
+    i32x4_t sreg[REGSTAGE ? SIT : 1];
     const int st_wave = __builtin_amdgcn_readfirstlane(wave) * 256;            // floats
     auto stage_issue = [&](const Item& it) __attribute__((always_inline)) {
         const int ylo = max(0, 1 - it.y0), yhi = min(HH, a.H + 1 - it.y0);
@@ -173,6 +179,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         const long org = (long)((size_t)it.n * a.in.nstride) + (long)(it.y0 - 1) * (long)isy + (long)(it.x0 - 1) * (long)isx;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+        if (REGSTAGE) {
+#pragma unroll
+            for (int u = 0; u < SIT; ++u) sreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, so[u], 0, 0);
+            return;
+        }
 #if defined(__HIP_DEVICE_COMPILE__)                                   // (the host pass has no LDS address space to cast to)
 #pragma unroll
         for (int u = 0; u < SIT; ++u)
@@ -182,7 +193,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         (void)rs; (void)st_wave; (void)st_last; (void)so;
 #endif
     };
-    auto stage_landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto stage_landed = [&]() __attribute__((always_inline)) {
+        if (REGSTAGE) {
+#pragma unroll
+            for (int u = 0; u < SIT; ++u)
+                if (u + 1 < SIT ? st_active : st_last) *reinterpret_cast<i32x4_t*>(raw + tid * 4 + u * (PPASS * Q4 * 4)) = sreg[u];
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
 
     // ---- phase A: thread = (tile, channel quad)
     const bool a_on = tid < 16 * Q4;
@@ -306,44 +325,40 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         for (int cb = 0; cb < NT; ++cb) { R0[cb] = (f32x4){U[0][0][cb], 0.f, 0.f, 0.f}; R1[cb] = R0[cb]; }
 #else
         {
-            constexpr int AVB = (16 * KQ * NT > 128) ? 1 : 2;          // (register budget of two workgroups per CU: 256)
-            f32x4 av[AVB][KQ];
-            auto fetch = [&](int nu, int slot_) __attribute__((always_inline)) {
+            // the pixel operands of nu + 1 replace those of nu quad by quad, right after their last use: the LDS latency is
+            // hidden behind the remaining MFMAs of nu without a second register set (the budget is 256 with two workgroups per CU)
+            f32x4 av[KQ];
+            auto kloop = [&](int nu, f32x4 (&acc)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int kq = 0; kq < KQ; ++kq) av[slot_][kq] = *reinterpret_cast<const f32x4*>(vrd + nu * 16 * VP + 16 * kq);
-            };
-            auto kloop = [&](int nu, int slot_, f32x4 (&acc)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int kq = 0; kq < KQ; ++kq)
+                for (int kq = 0; kq < KQ; ++kq) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                         for (int cb = 0; cb < NT; ++cb)
-                            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[nu][4 * kq + s4][cb], av[slot_][kq][s4], acc[cb], 0, 0, 0);
+                            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[nu][4 * kq + s4][cb], av[kq][s4], acc[cb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nu < 3) av[kq] = *reinterpret_cast<const f32x4*>(vrd + (nu + 1) * 16 * VP + 16 * kq);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             };
             f32x4 M[NT];
-            fetch(0, 0);
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) av[kq] = *reinterpret_cast<const f32x4*>(vrd + 16 * kq);
 #pragma unroll
             for (int cb = 0; cb < NT; ++cb) R0[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (AVB == 2) fetch(1, 1);
-            kloop(0, 0, R0);
-            if (AVB == 1) fetch(1, 0);
+            kloop(0, R0);
 #pragma unroll
             for (int cb = 0; cb < NT; ++cb) R1[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (AVB == 2) fetch(2, 0);
-            kloop(1, 1 % AVB, R1);
-            if (AVB == 1) fetch(2, 0);
+            kloop(1, R1);
 #pragma unroll
             for (int cb = 0; cb < NT; ++cb) M[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (AVB == 2) fetch(3, 1);
-            kloop(2, 0, M);
-            if (AVB == 1) fetch(3, 0);
+            kloop(2, M);
 #pragma unroll
             for (int cb = 0; cb < NT; ++cb) {
                 R0[cb] += R1[cb] + M[cb];
                 R1[cb] = sub4(R1[cb], M[cb]);
             }
-            kloop(3, 1 % AVB, R1);
+            kloop(3, R1);
         }
 #endif
         WT(4);

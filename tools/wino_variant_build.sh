@@ -5,7 +5,7 @@ R=$(cd "$(dirname "$0")/.." && pwd); NAME=$1; shift
 mkdir -p $R/gpurun_variants/obj_$NAME
 OBJS=""
 for f in $R/dl4ds_amd/csrc/*.hip $R/dl4ds_amd/csrc/*.cpp; do b=$(basename $f); case $b in conv_wino*.hip) continue;; esac; OBJS="$OBJS $R/dl4ds_amd/csrc/_build/$b.o"; done
-for k in _22 _23 _32 _33 ""; do
+for k in _22 _23 _32 _33 _wgrad ""; do
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/opt/rocm/include -x hip "$@" -c $R/dl4ds_amd/csrc/conv_wino$k.hip -o $R/gpurun_variants/obj_$NAME/conv_wino$k.o &
 done
 wait
