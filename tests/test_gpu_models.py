@@ -213,6 +213,33 @@ def test_headline_model_through_producer_consumer_kernels(monkeypatch):
     assert_matches_reference(g_hip, ref, what='producer / consumer kernels')
 
 
+@pytest.mark.parametrize('sx', ['all', '1'])
+def test_wide_model_through_the_winograd_kernels(monkeypatch, sx):
+    """A residual net with 16 .. 64 filters takes the Winograd kernels (conv_wino.hip, conv_wino_wgrad.hip) only on bench-sized
+    grids; DL4DS_WINO_FORCE makes this 32 x 32 one take them: layers of 32, 48 and 64 channels, i.e. one and two passes over
+    the input channels, residual adds and ReLU masks in the last pass of two (epilogue forms that the headline model does not
+    reach), weight gradients with two input-channel chunks.  Forward, loss and every gradient against the oracle."""
+    monkeypatch.setenv('DL4DS_WINO_FORCE', sx)
+    from dl4ds_amd.training import SupervisedEngine
+    from tests.parity import kernel_tags
+    kind, cfg, xs, ss = 'net_pin', dict(backbone_block='resnet', n_filters=16, n_blocks=4), (2, 32, 32, 2), None
+    model, P, ocfg = build_pair(kind, cfg, xs, ss)
+    rng, x, s, ref = tie_free_inputs(kind, P, ocfg, xs, ss)
+    out, tags_f = kernel_tags(lambda: model([x]))
+    assert any(t.startswith('conv_wino<') for t in tags_f), sorted(tags_f)
+    assert rel(out, ref) < 1e-3
+    y = rng.standard_normal(ref.shape).astype(np.float32)
+    PT = M.convert(P, T, requires_grad=True)
+    lv, grads, _ = TR.supervised_step(kind, ocfg, PT, T.asarray(x.astype(np.float64)), None, T.asarray(y.astype(np.float64)),
+                                      loss='mae', opt=None)
+    eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
+    (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x], y))
+    assert any(t.startswith('conv_wino_wgrad<') for t in tags), sorted(tags)
+    assert l_hip == pytest.approx(lv, rel=1e-4)
+    ref = oracle_reference('supervised', kind, ocfg, model.get_weights(), x, s, y, loss='mae')
+    assert_matches_reference(g_hip, ref, what='Winograd kernels')
+
+
 @pytest.mark.parametrize('n_aux', [0, 2])
 @pytest.mark.parametrize('ups,scale', [('spc', 4), ('spc', 2), ('rc', 2), ('spc', 5)])
 def test_folded_upsampling_tail_equals_unfolded(monkeypatch, ups, scale, n_aux):
