@@ -372,8 +372,19 @@ __device__ unsigned long long pair_ws_trace[4096 * 8];      // diagnostics build
 #define PT_TIC()
 #define PT_TOC(slot_)
 #endif
-template <int NR>
+// EPI: the epilogue form as a compile-time bit set (PAIR_EPI_*), or -1 = decided at run time from the parameters.  Every
+// run-time switch costs the MFMA waves vector instructions (selects between the variants), and a vector instruction of one
+// wave is starved to ONE issue per MFMA of the other workgroup's wave on the same SIMD (profiles/mfma_ubench_r02.txt): the
+// generic epilogue's ~45 vector instructions per row were as long as the K loop itself (PAIR_WS_TRACE: K loop 150 us,
+// epilogue 133 us per workgroup at 64 x 512^2).
+enum : int { PAIR_EPI_ADD = 1, PAIR_EPI_RELU = 2, PAIR_EPI_MASK = 4, PAIR_EPI_ACC = 8, PAIR_EPI_POOL = 16 };
+template <int NR, int EPI>
 __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvParams a) {      // (4 waves per SIMD = two workgroups per CU)
+    const bool f_add = EPI < 0 ? a.add.p != nullptr : (EPI & PAIR_EPI_ADD) != 0;
+    const bool f_relu = EPI < 0 ? a.relu != 0 : (EPI & PAIR_EPI_RELU) != 0;
+    const bool f_mask = EPI < 0 ? a.mask.p != nullptr : (EPI & PAIR_EPI_MASK) != 0;
+    const bool f_acc = EPI < 0 ? a.accumulate != 0 : (EPI & PAIR_EPI_ACC) != 0;
+    const bool f_pool = EPI < 0 ? a.pool != nullptr : (EPI & PAIR_EPI_POOL) != 0;
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int PTW = 32, PTH = 4 * NR;
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
@@ -403,6 +414,14 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         x0 = bx * PTW; y0 = by * PTH;
     };
 
+#ifdef PAIR_WS_DESYNC
+    // (experiment: the two workgroups of a CU start in phase and stay in phase -- both in their K loops, then both in their
+    //  epilogues; delay one of them by part of a tile time.  1: odd workgroups, 2: the upper half of the grid)
+    if (PAIR_WS_DESYNC == 1 ? (blockIdx.x & 1) : ((int)blockIdx.x >= (G >> 1))) {
+#pragma unroll
+        for (int q_ = 0; q_ < PAIR_WS_DESYNC_N; ++q_) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     if (wave8 >= 4) {
         // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 1) + 128 u, channel quad htid & 1)
         const int htid = tid & 255;
@@ -493,8 +512,8 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
             origin(t, n, y0, x0);
             const size_t pb = (size_t)y0 * hosy + (size_t)x0 * hosx;
             const unsigned long long ob = (unsigned long long)(uintptr_t)a.out.p + ((size_t)n * a.out.nstride + pb) * 4;
-            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (a.add.p ? ((size_t)n * a.add.nstride + pb) * 4 : 0);
-            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (a.mask.p ? ((size_t)n * a.mask.nstride + pb) * 4 : 0);
+            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (f_add ? ((size_t)n * a.add.nstride + pb) * 4 : 0);
+            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (f_mask ? ((size_t)n * a.mask.nstride + pb) * 4 : 0);
             const int ymax = min(PTH, a.H - y0), xmax = min(PTW, a.W - x0);
             if (tid == 256) {
                 *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)ob, (unsigned)(ob >> 32), (unsigned)ab, (unsigned)(ab >> 32));
@@ -532,7 +551,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
 #ifdef PAIR_WS_TRACE
         if (tid == 256) for (int q_ = 4; q_ < 8; ++q_) pair_ws_trace[(size_t)blockIdx.x * 8 + q_] = pt_acc[q_];
 #endif
-        if (a.pool) __syncthreads();                               // P: the MFMA waves' last pooling record (below)
+        if (f_pool) __syncthreads();                               // P: the MFMA waves' last pooling record (below)
         return;
     }
 
@@ -579,6 +598,43 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
     for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
         const float* rd = lds + (k & 1) * TILE + rd_off;
         PT_TIC();
+        // the tile's descriptors come from the loaders (dsc[k & 1]: written during the previous step, overwritten for tile k + 2
+        // during the NEXT one -- so they are taken into scalar registers before this step's barrier)
+        const uint4 d0 = *reinterpret_cast<const uint4*>(dsc[k & 1]);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(dsc[k & 1] + 4);
+        auto sg = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        const unsigned long long ob = ((unsigned long long)sg(d0.y) << 32) | sg(d0.x);
+        const unsigned long long ab = ((unsigned long long)sg(d0.w) << 32) | sg(d0.z);
+        const unsigned long long mb = ((unsigned long long)sg(d1.y) << 32) | sg(d1.x);
+        const int sig = (int)sg(d1.z);
+        if (sig != esig) {
+            esig = sig;
+            const int ymax = sig >> 8, xmax = sig & 0xff;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && 2 * l15 + eh < xmax) ? eo[i] : OOB;
+        }
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ob), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)mb), 0, 0x7fffff00, RSRC3);
+        // the epilogue's operands are requested BEFORE the K loop (compiled forms): requested in the epilogue their latency was
+        // exposed once per tile (cfg5: the residual + ReLU form 155 us against 122 us for the plain ReLU form with 1.5 x the bytes).
+        // Two operands at once (32 registers) only where the budget of 128 holds them.
+        constexpr bool PRE = EPI >= 0;
+        i32x4_t ad[NR], mk[NR], old[NR];
+        if (PRE) {
+            if (f_add) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+            }
+            if (f_mask) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+            }
+            if (f_acc) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+            }
+        }
         f32x4 acc[NR];
         // pixel fragments ONE halo row ahead of the MFMAs that use them: without it every pair of rows waited for its eight LDS
         // reads (ablation: no loads / no stores change nothing, no MFMAs -> 26 us of 79; the K loop itself ran at 65 %).  Two rows
@@ -616,64 +672,47 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the tile's descriptors come from the loaders (dsc[k & 1]: written during the previous step, overwritten for tile k + 2
-        // during the NEXT one -- so they are taken into scalar registers before this step's barrier)
-        const uint4 d0 = *reinterpret_cast<const uint4*>(dsc[k & 1]);
-        const uint4 d1 = *reinterpret_cast<const uint4*>(dsc[k & 1] + 4);
-        auto sg = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-        const unsigned long long ob = ((unsigned long long)sg(d0.y) << 32) | sg(d0.x);
-        const unsigned long long ab = ((unsigned long long)sg(d0.w) << 32) | sg(d0.z);
-        const unsigned long long mb = ((unsigned long long)sg(d1.y) << 32) | sg(d1.x);
-        const int sig = (int)sg(d1.z);
         PT_TOC(0);
         __syncthreads();                                          // X
         PT_TOC(1);
         // a.pool: the previous tile's per-wave channel sums are complete behind this barrier: one 8-float record per tile
-        if (a.pool && k > 0 && tid < 8) {
+        if (f_pool && k > 0 && tid < 8) {
             const float* red = pool_red[(k - 1) & 1];
             a.pool[(size_t)(t - G) * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
         }
-        if (sig != esig) {
-            esig = sig;
-            const int ymax = sig >> 8, xmax = sig & 0xff;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && 2 * l15 + eh < xmax) ? eo[i] : OOB;
-        }
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ob), 0, 0x7fffff00, RSRC3);
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)mb), 0, 0x7fffff00, RSRC3);
-        i32x4_t ad[NR], mk[NR], old[NR];
         f32x4 psum = {0.f, 0.f, 0.f, 0.f};          // a.pool: this lane's share of the tile's channel sums
-        if (a.add.p) {
+        if (!PRE) {
+            if (f_add) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
-        }
-        if (a.mask.p) {
+                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+            }
+            if (f_mask) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
-        }
-        if (a.accumulate) {
+                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+            }
+            if (f_acc) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+                for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             f32x4 v = acc[i];
-            if (a.add.p) v += __builtin_bit_cast(f32x4, ad[i]);
-            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            if (a.mask.p) {
+            if (f_add) v += __builtin_bit_cast(f32x4, ad[i]);
+            if (f_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (f_mask) {
                 const f32x4 m = __builtin_bit_cast(f32x4, mk[i]);
                 v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f;
                 v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
             }
-            if (a.accumulate) v += __builtin_bit_cast(f32x4, old[i]);
+            if (f_acc) v += __builtin_bit_cast(f32x4, old[i]);
 #if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 2
             if (v[0] == 12345.678f)
 #endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
-            if (a.pool && eoff[i] != OOB) psum += v;
+            if (f_pool && eoff[i] != OOB) psum += v;
         }
-        if (a.pool) {
+        if (f_pool) {
             // GlobalAveragePooling of ChannelAttention2D (blocks.py:585-588) from this epilogue: per-tile channel sums in the
             // fixed order of conv_narrow_pair_kernel (16 pair columns, the two pixels of a pair, the four waves through LDS)
 #pragma unroll
@@ -690,7 +729,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         pt_acc[3] += 1;
 #endif
     }
-    if (a.pool) {
+    if (f_pool) {
         __syncthreads();                                          // P (the loaders arrive here too)
         if (k > 0 && tid < 8) {
             const float* red = pool_red[(k - 1) & 1];
@@ -710,8 +749,22 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
 // (pixel fragments as one ds_read_b128 per tap column, one halo row ahead; accumulators start at the bias) plus one 16-byte
 // store per output row.  conv_narrow_kernel<16> -- load, LDS, MFMA and store phases inside every wave -- held the matrix
 // pipe 43 % busy (profiles/pmc_mfma_r02.txt) at 74 TFLOP/s stand-alone, 58-63 inside the models.
-template <int NR>
-__global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvParams a) {    // (2 waves per SIMD: ONE workgroup per CU -- 144 registers; capped at 128 for two workgroups it spills and runs at half the rate)
+// Waves per SIMD: the compiled forms with at most two epilogue operands fit 128 registers = TWO workgroups per CU (62 KB of
+// LDS each), so that one workgroup's K loop runs beside the other's epilogue; the run-time form and the three-operand forms
+// need 144 and keep one workgroup per CU (capped at 128 they spill and run at half the rate).
+constexpr int narrow16_wps(int epi) {
+#ifdef NARROW16_WPS
+    return NARROW16_WPS;
+#else
+    return (epi >= 0 && ((epi & 1) + ((epi >> 2) & 1) + ((epi >> 3) & 1)) <= 2) ? 4 : 2;
+#endif
+}
+template <int NR, int EPI>      // EPI: compiled epilogue form (PAIR_EPI_* bits) or -1 = run-time, as in conv_narrow_pair_ws_kernel
+__global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kernel(const ConvParams a) {
+    const bool f_add = EPI < 0 ? a.add.p != nullptr : (EPI & PAIR_EPI_ADD) != 0;
+    const bool f_relu = EPI < 0 ? a.relu != 0 : (EPI & PAIR_EPI_RELU) != 0;
+    const bool f_mask = EPI < 0 ? a.mask.p != nullptr : (EPI & PAIR_EPI_MASK) != 0;
+    const bool f_acc = EPI < 0 ? a.accumulate != 0 : (EPI & PAIR_EPI_ACC) != 0;    // (2 waves per SIMD: ONE workgroup per CU -- 144 registers; capped at 128 for two workgroups it spills and runs at half the rate)
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int PTW = 16, PTH = 4 * NR;
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
@@ -801,8 +854,8 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
             origin(t, n, y0, x0);
             const size_t pb = (size_t)y0 * hosy + (size_t)x0 * hosx;
             const unsigned long long ob = (unsigned long long)(uintptr_t)a.out.p + ((size_t)n * a.out.nstride + pb) * 4;
-            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (a.add.p ? ((size_t)n * a.add.nstride + pb) * 4 : 0);
-            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (a.mask.p ? ((size_t)n * a.mask.nstride + pb) * 4 : 0);
+            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (f_add ? ((size_t)n * a.add.nstride + pb) * 4 : 0);
+            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (f_mask ? ((size_t)n * a.mask.nstride + pb) * 4 : 0);
             const int ymax = min(PTH, a.H - y0), xmax = min(PTW, a.W - x0);
             if (tid == 256) {
                 *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)ob, (unsigned)(ob >> 32), (unsigned)ab, (unsigned)(ab >> 32));
@@ -870,6 +923,39 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
     int k = 0;
     for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
         const float* rd = lds + (k & 1) * TILE + rd_off;
+        const uint4 d0 = *reinterpret_cast<const uint4*>(dsc[k & 1]);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(dsc[k & 1] + 4);
+        auto sg = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        const unsigned long long ob = ((unsigned long long)sg(d0.y) << 32) | sg(d0.x);
+        const unsigned long long ab = ((unsigned long long)sg(d0.w) << 32) | sg(d0.z);
+        const unsigned long long mb = ((unsigned long long)sg(d1.y) << 32) | sg(d1.x);
+        const int sig = (int)sg(d1.z);
+        if (sig != esig) {
+            esig = sig;
+            const int ymax = sig >> 8, xmax = sig & 0xff;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && l15 < xmax) ? eo[i] : OOB;
+        }
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ob), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)mb), 0, 0x7fffff00, RSRC3);
+        // compiled forms request the epilogue's operands before the K loop (see conv_narrow_pair_ws_kernel)
+        constexpr bool PRE = EPI >= 0;
+        i32x4_t ad[NR], mk[NR], old[NR];
+        if (PRE) {
+            if (f_add) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+            }
+            if (f_mask) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+            }
+            if (f_acc) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+            }
+        }
         f32x4 acc[NR];
         f32x4 pv[2][3];                                           // pixel fragments, ONE halo row ahead of the MFMAs that use them
 #pragma unroll
@@ -898,47 +984,32 @@ __global__ void __launch_bounds__(512, 2) conv_narrow16_ws_kernel(const ConvPara
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const uint4 d0 = *reinterpret_cast<const uint4*>(dsc[k & 1]);
-        const uint4 d1 = *reinterpret_cast<const uint4*>(dsc[k & 1] + 4);
-        auto sg = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-        const unsigned long long ob = ((unsigned long long)sg(d0.y) << 32) | sg(d0.x);
-        const unsigned long long ab = ((unsigned long long)sg(d0.w) << 32) | sg(d0.z);
-        const unsigned long long mb = ((unsigned long long)sg(d1.y) << 32) | sg(d1.x);
-        const int sig = (int)sg(d1.z);
         __syncthreads();                                          // X
-        if (sig != esig) {
-            esig = sig;
-            const int ymax = sig >> 8, xmax = sig & 0xff;
+        if (!PRE) {
+            if (f_add) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && l15 < xmax) ? eo[i] : OOB;
-        }
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ob), 0, 0x7fffff00, RSRC3);
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)mb), 0, 0x7fffff00, RSRC3);
-        i32x4_t ad[NR], mk[NR], old[NR];
-        if (a.add.p) {
+                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+            }
+            if (f_mask) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
-        }
-        if (a.mask.p) {
+                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+            }
+            if (f_acc) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
-        }
-        if (a.accumulate) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+                for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             f32x4 v = acc[i];
-            if (a.add.p) v += __builtin_bit_cast(f32x4, ad[i]);
-            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            if (a.mask.p) {
+            if (f_add) v += __builtin_bit_cast(f32x4, ad[i]);
+            if (f_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (f_mask) {
                 const f32x4 m = __builtin_bit_cast(f32x4, mk[i]);
                 v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f;
                 v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
             }
-            if (a.accumulate) v += __builtin_bit_cast(f32x4, old[i]);
+            if (f_acc) v += __builtin_bit_cast(f32x4, old[i]);
             if (nvalid == 4) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), ro, eoff[i], 0, 0);
             } else {
@@ -988,11 +1059,20 @@ bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
     const long nt = (long)p.tiles_x * p.tiles_y * N;
     if (nt == 0 || nt >= (1l << 20)) return false;
     const int ntiles = (int)nt;
-    const int blocks = std::min(ntiles, resident_blocks<conv_narrow16_ws_kernel<NR>>(512));
+    static const bool generic_only = getenv("DL4DS_NARROW16_WS_GENERIC") != nullptr;      // (A/B)
+    const int epi = generic_only ? -1 : ((p.add.p ? PAIR_EPI_ADD : 0) | (p.relu ? PAIR_EPI_RELU : 0) | (p.mask.p ? PAIR_EPI_MASK : 0) |
+                                         (p.accumulate ? PAIR_EPI_ACC : 0));
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_narrow16_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
-    hipLaunchKernelGGL((conv_narrow16_ws_kernel<NR>), dim3(blocks), dim3(512), 0, s, p);
+#define NARROW16_FORM(E_) case E_: hipLaunchKernelGGL((conv_narrow16_ws_kernel<NR, E_>), \
+        dim3(std::min(ntiles, resident_blocks<conv_narrow16_ws_kernel<NR, E_>>(512))), dim3(512), 0, s, p); break;
+    switch (epi) {
+        NARROW16_FORM(0) NARROW16_FORM(1) NARROW16_FORM(2) NARROW16_FORM(3) NARROW16_FORM(4) NARROW16_FORM(5) NARROW16_FORM(6) NARROW16_FORM(7)
+        NARROW16_FORM(8) NARROW16_FORM(9) NARROW16_FORM(10) NARROW16_FORM(11) NARROW16_FORM(12) NARROW16_FORM(13) NARROW16_FORM(14) NARROW16_FORM(15)
+        NARROW16_FORM(-1)
+    }
+#undef NARROW16_FORM
     HIP_CHECK(hipGetLastError());
     return true;
 }
@@ -1025,10 +1105,22 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
     if (ntiles == 0) return;
     const double px = (double)N * p.H * p.W;
     if (narrow_pair_ws_ok(p)) {
-        const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_ws_kernel<NR>>(512));
+        // the epilogue forms the models use are compiled in (see the kernel's comment); anything else takes the run-time form
+        static const bool generic_only = getenv("DL4DS_PAIR_WS_GENERIC") != nullptr;      // (A/B)
+        const int epi = (p.add.p ? PAIR_EPI_ADD : 0) | (p.relu ? PAIR_EPI_RELU : 0) | (p.mask.p ? PAIR_EPI_MASK : 0) |
+                        (p.accumulate ? PAIR_EPI_ACC : 0) | (p.pool ? PAIR_EPI_POOL : 0);
+        const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_ws_kernel<NR, -1>>(512));
         ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                      4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
-        hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR>), dim3(blocks), dim3(512), 0, s, p);
+#define PAIR_WS_FORM(E_) case E_: hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR, E_>), dim3(blocks), dim3(512), 0, s, p); break;
+        switch (generic_only ? -1 : epi) {
+            PAIR_WS_FORM(0) PAIR_WS_FORM(1) PAIR_WS_FORM(2) PAIR_WS_FORM(3) PAIR_WS_FORM(4) PAIR_WS_FORM(5) PAIR_WS_FORM(6) PAIR_WS_FORM(7)
+            PAIR_WS_FORM(8) PAIR_WS_FORM(9) PAIR_WS_FORM(10) PAIR_WS_FORM(11) PAIR_WS_FORM(12) PAIR_WS_FORM(13) PAIR_WS_FORM(14) PAIR_WS_FORM(15)
+            PAIR_WS_FORM(PAIR_EPI_POOL)
+            PAIR_WS_FORM(PAIR_EPI_POOL | PAIR_EPI_RELU)
+            default: hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR, -1>), dim3(blocks), dim3(512), 0, s, p); break;
+        }
+#undef PAIR_WS_FORM
         HIP_CHECK(hipGetLastError());
 #ifdef PAIR_WS_TRACE
         {
@@ -1456,8 +1548,7 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
         return true;
     }
     {
-        static const int nr = getenv("DL4DS_NARROW16_NR") ? atoi(getenv("DL4DS_NARROW16_NR")) : 4;       // (experiments)
-        const bool done = nr == 8 ? launch_narrow16_ws<8>(s, p, in.N) : (nr == 2 ? launch_narrow16_ws<2>(s, p, in.N) : launch_narrow16_ws<4>(s, p, in.N));
+        const bool done = launch_narrow16_ws<4>(s, p, in.N);
         if (!done) { if (in.C <= 8) launch_narrow<8>(s, p, in.N); else launch_narrow<16>(s, p, in.N); }
     }
     return true;

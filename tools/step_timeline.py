@@ -1,5 +1,6 @@
 """One train step as a launch-ordered timeline from a rocprofv3 --kernel-trace CSV: the launches between the last
-two adam kernels, with grid size and duration.  Usage: step_timeline.py <rocprof output dir>"""
+two adam kernels, with grid size and duration.  Usage: step_timeline.py <rocprof output dir> [adam launches per step]
+(cfg5's CGAN step has two: discriminator and generator)"""
 import csv, glob, sys, re
 rows = []
 for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
@@ -8,7 +9,8 @@ for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
                      int(r.get('Grid_Size_X', r.get('Grid_Size', 0)) or 0), int(r.get('Workgroup_Size_X', 0) or 0)))
 rows.sort()
 adam = [i for i, r in enumerate(rows) if 'adam' in r[2]]
-lo, hi = (adam[-2] + 1, adam[-1] + 1) if len(adam) >= 2 else (0, len(rows))
+aps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+lo, hi = (adam[-1 - aps] + 1, adam[-1] + 1) if len(adam) > aps else (0, len(rows))
 t0 = rows[lo][0]
 tot = 0
 for s, e, k, g, wg in rows[lo:hi]:
