@@ -377,7 +377,7 @@ __device__ unsigned long long pair_ws_trace[4096 * 8];      // diagnostics build
 // wave is starved to ONE issue per MFMA of the other workgroup's wave on the same SIMD (profiles/mfma_ubench_r02.txt): the
 // generic epilogue's ~45 vector instructions per row were as long as the K loop itself (PAIR_WS_TRACE: K loop 150 us,
 // epilogue 133 us per workgroup at 64 x 512^2).
-enum : int { PAIR_EPI_ADD = 1, PAIR_EPI_RELU = 2, PAIR_EPI_MASK = 4, PAIR_EPI_ACC = 8, PAIR_EPI_POOL = 16 };
+enum : int { PAIR_EPI_ADD = 1, PAIR_EPI_RELU = 2, PAIR_EPI_MASK = 4, PAIR_EPI_ACC = 8, PAIR_EPI_POOL = 16, PAIR_EPI_AFF = 32 };
 template <int NR, int EPI>
 __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvParams a) {      // (4 waves per SIMD = two workgroups per CU)
     const bool f_add = EPI < 0 ? a.add.p != nullptr : (EPI & PAIR_EPI_ADD) != 0;
@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
     const bool f_mask = EPI < 0 ? a.mask.p != nullptr : (EPI & PAIR_EPI_MASK) != 0;
     const bool f_acc = EPI < 0 ? a.accumulate != 0 : (EPI & PAIR_EPI_ACC) != 0;
     const bool f_pool = EPI < 0 ? a.pool != nullptr : (EPI & PAIR_EPI_POOL) != 0;
+    const bool f_aff = EPI < 0 ? a.in.sc != nullptr : (EPI & PAIR_EPI_AFF) != 0;       // channel affine of the input view (loaders)
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int PTW = 32, PTH = 4 * NR;
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
@@ -401,8 +402,17 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave8 = tid >> 6;
-    const int ntiles = a.tiles_x * a.tiles_y * a.in.N;
-    const int G = gridDim.x;
+    // XCD-aware walk (a.CK != 0, grid a multiple of 8): workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the tiles
+    // and its workgroups walk it with the XCD's stride, so the tiles in flight on an XCD are neighbours (consecutive tile rows of
+    // one image) and their halo rows meet in that XCD's L2 instead of being fetched once per XCD
+    const int ntiles_all = a.tiles_x * a.tiles_y * a.in.N;
+    int T0 = blockIdx.x, G = gridDim.x, ntiles = ntiles_all;
+    if (a.CK && (G & 7) == 0) {
+        const int per = (ntiles_all + 7) >> 3, xcd = blockIdx.x & 7;
+        T0 = xcd * per + (blockIdx.x >> 3);
+        G >>= 3;
+        ntiles = min(ntiles_all, (xcd + 1) * per);
+    }
 #ifdef PAIR_WS_TRACE
     unsigned long long pt_t = 0, pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -417,7 +427,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
 #ifdef PAIR_WS_DESYNC
     // (experiment: the two workgroups of a CU start in phase and stay in phase -- both in their K loops, then both in their
     //  epilogues; delay one of them by part of a tile time.  1: odd workgroups, 2: the upper half of the grid)
-    if (PAIR_WS_DESYNC == 1 ? (blockIdx.x & 1) : ((int)blockIdx.x >= (G >> 1))) {
+    if (PAIR_WS_DESYNC == 1 ? (blockIdx.x & 1) : ((int)blockIdx.x >= ((int)gridDim.x >> 1))) {
 #pragma unroll
         for (int q_ = 0; q_ < PAIR_WS_DESYNC_N; ++q_) __builtin_amdgcn_s_sleep(32);
     }
@@ -447,7 +457,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         // would wait for the two tiles requested in between)
         float4 as4 = make_float4(1.f, 1.f, 1.f, 1.f), ah4 = make_float4(0.f, 0.f, 0.f, 0.f);
         auto load_affine = [&](int t) __attribute__((always_inline)) {
-            if (a.in.sc && t < ntiles) { int n, y0, x0; origin(t, n, y0, x0); view_affine4(a.in, n, c4 * 4, as4, ah4); }
+            if (f_aff && t < ntiles) { int n, y0, x0; origin(t, n, y0, x0); view_affine4(a.in, n, c4 * 4, as4, ah4); }
         };
         auto issue = [&](int t, i32x4_t (&dst)[ITERS], unsigned& vmask) __attribute__((always_inline)) {
             int n, y0, x0;
@@ -468,7 +478,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
             if (ragged) { const long rem = (in_total - org) * 4; nrec = rem < 0x7fffff00l ? (int)rem : 0x7fffff00; }
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(reinterpret_cast<const char*>(a.in.p)) + org * 4, 0, nrec, RSRC3);
-            if (a.in.sc) {
+            if (f_aff) {
                 vmask = 0u;
 #pragma unroll
                 for (int u = 0; u < ITERS; ++u) vmask |= (soff[u] != OOB ? 1u : 0u) << u;
@@ -491,7 +501,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
             for (int u = 0; u < ITERS; ++u) {
                 if (u + 1 < ITERS || (hyx[u] >> 8) < THH) {
                     i32x4_t v = src[u];
-                    if (a.in.sc && ((vmask >> u) & 1u)) {
+                    if (f_aff && ((vmask >> u) & 1u)) {
                         const float4 f = affine4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])), s4, h4);
                         v = (i32x4_t){__float_as_int(f.x), __float_as_int(f.y), __float_as_int(f.z), __float_as_int(f.w)};
                     }
@@ -520,7 +530,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
                 *reinterpret_cast<uint4*>(d + 4) = make_uint4((unsigned)mb, (unsigned)(mb >> 32), (unsigned)((ymax << 8) | xmax), 0u);
             }
         };
-        const int t0 = blockIdx.x;
+        const int t0 = T0;
         if (t0 < ntiles) describe(t0, dsc[0]);
         load_affine(t0);
         if (t0 < ntiles) issue(t0, r[0], vm[0]);
@@ -595,7 +605,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
 
     __syncthreads();                                              // S0
     int k = 0;
-    for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
+    for (int t = T0; t < ntiles; t += G, ++k) {
         const float* rd = lds + (k & 1) * TILE + rd_off;
         PT_TIC();
         // the tile's descriptors come from the loaders (dsc[k & 1]: written during the previous step, overwritten for tile k + 2
@@ -733,7 +743,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         __syncthreads();                                          // P (the loaders arrive here too)
         if (k > 0 && tid < 8) {
             const float* red = pool_red[(k - 1) & 1];
-            const int tl = (int)blockIdx.x + (k - 1) * G;
+            const int tl = T0 + (k - 1) * G;
             a.pool[(size_t)tl * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
         }
     }
@@ -783,8 +793,17 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave8 = tid >> 6;
-    const int ntiles = a.tiles_x * a.tiles_y * a.in.N;
-    const int G = gridDim.x;
+    // XCD-aware walk (a.CK != 0, grid a multiple of 8): workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the tiles
+    // and its workgroups walk it with the XCD's stride, so the tiles in flight on an XCD are neighbours (consecutive tile rows of
+    // one image) and their halo rows meet in that XCD's L2 instead of being fetched once per XCD
+    const int ntiles_all = a.tiles_x * a.tiles_y * a.in.N;
+    int T0 = blockIdx.x, G = gridDim.x, ntiles = ntiles_all;
+    if (a.CK && (G & 7) == 0) {
+        const int per = (ntiles_all + 7) >> 3, xcd = blockIdx.x & 7;
+        T0 = xcd * per + (blockIdx.x >> 3);
+        G >>= 3;
+        ntiles = min(ntiles_all, (xcd + 1) * per);
+    }
     auto origin = [&](int t, int& n, int& y0, int& x0) {
         const int q = fast_div(t, a.m_txy[0]);
         const int bx = t - q * a.tiles_x;
@@ -862,7 +881,7 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
                 *reinterpret_cast<uint4*>(d + 4) = make_uint4((unsigned)mb, (unsigned)(mb >> 32), (unsigned)((ymax << 8) | xmax), 0u);
             }
         };
-        const int t0 = blockIdx.x;
+        const int t0 = T0;
         if (t0 < ntiles) describe(t0, dsc[0]);
         if (t0 < ntiles) issue(t0, r[0]);
         if (t0 + G < ntiles) issue(t0 + G, r[1]);
@@ -921,7 +940,7 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
 
     __syncthreads();                                              // S0
     int k = 0;
-    for (int t = blockIdx.x; t < ntiles; t += G, ++k) {
+    for (int t = T0; t < ntiles; t += G, ++k) {
         const float* rd = lds + (k & 1) * TILE + rd_off;
         const uint4 d0 = *reinterpret_cast<const uint4*>(dsc[k & 1]);
         const uint4 d1 = *reinterpret_cast<const uint4*>(dsc[k & 1] + 4);
@@ -1065,8 +1084,11 @@ bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_narrow16_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+    static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;                     // (A/B)
+    p.CK = no_xcd ? 0 : 1;
+    auto grid_of = [&](int resident) { const int b = std::min(ntiles, resident); return b >= 8 ? (b & ~7) : b; };
 #define NARROW16_FORM(E_) case E_: hipLaunchKernelGGL((conv_narrow16_ws_kernel<NR, E_>), \
-        dim3(std::min(ntiles, resident_blocks<conv_narrow16_ws_kernel<NR, E_>>(512))), dim3(512), 0, s, p); break;
+        dim3(grid_of(resident_blocks<conv_narrow16_ws_kernel<NR, E_>>(512))), dim3(512), 0, s, p); break;
     switch (epi) {
         NARROW16_FORM(0) NARROW16_FORM(1) NARROW16_FORM(2) NARROW16_FORM(3) NARROW16_FORM(4) NARROW16_FORM(5) NARROW16_FORM(6) NARROW16_FORM(7)
         NARROW16_FORM(8) NARROW16_FORM(9) NARROW16_FORM(10) NARROW16_FORM(11) NARROW16_FORM(12) NARROW16_FORM(13) NARROW16_FORM(14) NARROW16_FORM(15)
@@ -1108,8 +1130,11 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
         // the epilogue forms the models use are compiled in (see the kernel's comment); anything else takes the run-time form
         static const bool generic_only = getenv("DL4DS_PAIR_WS_GENERIC") != nullptr;      // (A/B)
         const int epi = (p.add.p ? PAIR_EPI_ADD : 0) | (p.relu ? PAIR_EPI_RELU : 0) | (p.mask.p ? PAIR_EPI_MASK : 0) |
-                        (p.accumulate ? PAIR_EPI_ACC : 0) | (p.pool ? PAIR_EPI_POOL : 0);
-        const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_ws_kernel<NR, -1>>(512));
+                        (p.accumulate ? PAIR_EPI_ACC : 0) | (p.pool ? PAIR_EPI_POOL : 0) | (p.in.sc ? PAIR_EPI_AFF : 0);
+        int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_ws_kernel<NR, -1>>(512));
+        static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;                 // (A/B)
+        if (blocks >= 8) blocks &= ~7;
+        p.CK = no_xcd ? 0 : 1;
         ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                      4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
 #define PAIR_WS_FORM(E_) case E_: hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR, E_>), dim3(blocks), dim3(512), 0, s, p); break;
@@ -1118,6 +1143,8 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
             PAIR_WS_FORM(8) PAIR_WS_FORM(9) PAIR_WS_FORM(10) PAIR_WS_FORM(11) PAIR_WS_FORM(12) PAIR_WS_FORM(13) PAIR_WS_FORM(14) PAIR_WS_FORM(15)
             PAIR_WS_FORM(PAIR_EPI_POOL)
             PAIR_WS_FORM(PAIR_EPI_POOL | PAIR_EPI_RELU)
+            PAIR_WS_FORM(PAIR_EPI_AFF) PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_MASK) PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_ACC)
+            PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_MASK | PAIR_EPI_ACC) PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_RELU)
             default: hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR, -1>), dim3(blocks), dim3(512), 0, s, p); break;
         }
 #undef PAIR_WS_FORM
