@@ -33,6 +33,7 @@ struct DirectParams {
     unsigned m_tx, m_ty;
     int relu, accumulate;
     int bpi = 0;                         // wgrad only: > 0 = per-image slabs, `bpi` blocks per image (slab = blockIdx.x = n*bpi + b)
+    int xcd = 0;                         // second generation: XCD-aware tile walk
 };
 
 // Stage the (DTY+KS-1) x (DTX+KS-1) halo tile of `v` (CI padded channels) around (n, y0, x0) into LDS planes.
@@ -383,6 +384,411 @@ __global__ void __launch_bounds__(256) conv_direct_wgrad_kernel(const DirectPara
     }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// Second generation (round 3) of the two kernels above, for plain (not depth_to_space) inputs:
+//   * 32 x 16 tile, every thread owns TWO vertically adjacent pixels: the halo shrinks from 1.33 to 1.19 x the tile and the four
+//     halo rows of a pixel pair are read from LDS once for both (24 instead of 36 reads per pair with 8 input channels);
+//   * the NEXT tile's buffer loads are issued right after this tile is in LDS and stay in flight during the 72+ FMAs per
+//     pixel (register staging: 5 x 16 bytes per thread) -- the first generation waited for its loads between two barriers;
+//   * the epilogue's operands (residual, ReLU mask, old value) are requested before the FMAs, too;
+//   * XCD-aware walk: workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the tiles, so vertically
+//     neighbouring tiles meet in one L2 (the halo rows and the partial 128-byte lines at the tile's left and right edge
+//     were fetched once per XCD before: 8 -> 1 at 64 x 512^2 read 1.3 x its input).
+// Same arithmetic per output, same epilogue semantics, same slab layout; DL4DS_NO_DIRECT2=1 restores the first generation.
+constexpr int D2Y = 16;
+
+template <int CI>
+struct Stager2 {
+    static constexpr int HWD = DTX + 2, HHT = D2Y + 2, HPIX = HWD * HHT;
+    static constexpr int VEC = CI < 4 ? CI : 4, NPL = CI / VEC;
+    static constexpr int TOTAL = HPIX * NPL, ITERS = (TOTAL + 255) / 256;
+    static constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    typedef int i32x2_t __attribute__((ext_vector_type(2)));
+    int soff[ITERS], hyx[ITERS], sig;
+    int r[ITERS][VEC];
+    unsigned inside;                     // (channel affine: which elements of `r` lie inside the image)
+    __device__ __forceinline__ int rel(const TView& v, int hy, int hx, int pl) const {
+        return (int)((((size_t)hy * v.W + hx) * v.ld + pl * 4) * 4);
+    }
+    __device__ __forceinline__ void init(const TView& v, int Cin, int tid) {
+        sig = (HHT << 8) | HWD;
+        inside = 0u;
+#pragma unroll
+        for (int u = 0; u < ITERS; ++u) {
+            const int e = tid + u * 256;
+            const int hp = e / NPL, pl = e - hp * NPL;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const bool live = e < TOTAL && pl * 4 < Cin;
+            hyx[u] = live ? ((hy << 8) | hx) : 0x7f7f;
+            soff[u] = live ? rel(v, hy, hx, pl) : OOB;
+        }
+    }
+    // request the halo of the tile at (n, y0, x0): zero padding = out-of-range offsets
+    __device__ __forceinline__ void issue(const TView& v, int H, int W, int n, int y0, int x0, int tid) {
+        const int ylo = max(0, 1 - y0), yhi = min(HHT, H + 1 - y0), xlo = max(0, 1 - x0), xhi = min(HWD, W + 1 - x0);
+        const int sg = (ylo << 24) | (xlo << 16) | (yhi << 8) | xhi;
+        if (sg != sig) {
+            sig = sg;
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) {
+                const int hy = hyx[u] >> 8, hx = hyx[u] & 0xff, pl = (tid + u * 256) % NPL;
+                soff[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? rel(v, hy, hx, pl) : OOB;
+            }
+        }
+        const long org = (long)((size_t)n * v.nstride) + ((long)(y0 - 1) * v.W + (x0 - 1)) * (long)v.ld;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(v.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+        if (v.sc) {
+            inside = 0u;
+#pragma unroll
+            for (int u = 0; u < ITERS; ++u) inside |= (soff[u] != OOB ? 1u : 0u) << u;
+        }
+#pragma unroll
+        for (int u = 0; u < ITERS; ++u) {
+            if constexpr (VEC == 4) {
+                const i32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[u], 0, 0);
+                r[u][0] = t[0]; r[u][1] = t[1]; r[u][2 % VEC] = t[2]; r[u][3 % VEC] = t[3];
+            } else if constexpr (VEC == 2) {
+                const i32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, soff[u], 0, 0);
+                r[u][0] = t[0]; r[u][1 % VEC] = t[1];
+            } else {
+                r[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, soff[u], 0, 0);
+            }
+        }
+    }
+    // the requested halo -> LDS planes [pl][halo pixel][VEC]; the channel affine of the view (image n_of_tile) on the way
+    __device__ __forceinline__ void put(const TView& v, int n_of_tile, int tid, float* __restrict__ tile) {
+        if constexpr (VEC == 4) {
+            if (v.sc) {
+                float4 s4, h4;
+                view_affine4(v, n_of_tile, (tid % NPL) * 4, s4, h4);
+#pragma unroll
+                for (int u = 0; u < ITERS; ++u) {
+                    if ((inside >> u) & 1u) {
+                        const float4 t4 = affine4(make_float4(__int_as_float(r[u][0]), __int_as_float(r[u][1]), __int_as_float(r[u][2 % VEC]),
+                                                              __int_as_float(r[u][3 % VEC])), s4, h4);
+                        r[u][0] = __float_as_int(t4.x); r[u][1] = __float_as_int(t4.y);
+                        r[u][2 % VEC] = __float_as_int(t4.z); r[u][3 % VEC] = __float_as_int(t4.w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ITERS; ++u) {
+            const int e = tid + u * 256;
+            if (e < TOTAL) {
+                const int hp = e / NPL, pl = e - hp * NPL;
+                float* d = tile + ((size_t)pl * HPIX + hp) * VEC;
+                if constexpr (VEC == 4) *reinterpret_cast<i32x4_t*>(d) = (i32x4_t){r[u][0], r[u][1], r[u][2 % VEC], r[u][3 % VEC]};
+                else if constexpr (VEC == 2) *reinterpret_cast<i32x2_t*>(d) = (i32x2_t){r[u][0], r[u][1 % VEC]};
+                else d[0] = __int_as_float(r[u][0]);
+            }
+        }
+    }
+};
+
+// which tiles a workgroup takes: first, end, stride (XCD-aware when the grid is a multiple of 8; per-image mode for the
+// attention weight gradient: block n * bpi + b walks tiles b, b + bpi, ... of image n only)
+struct Walk2 { int t0, t1, ts; };
+__device__ __forceinline__ Walk2 walk2(const DirectParams& a) {
+    Walk2 w;
+    const int G = gridDim.x;
+    if (a.bpi > 0) {
+        const int tpi = a.tiles_x * a.tiles_y, img = (int)blockIdx.x / a.bpi;
+        w.t0 = img * tpi + ((int)blockIdx.x - img * a.bpi); w.t1 = (img + 1) * tpi; w.ts = a.bpi;
+    } else if (a.xcd && (G & 7) == 0) {
+        const int per = (a.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        w.t0 = xcd * per + (int)(blockIdx.x >> 3); w.t1 = min(a.ntiles, (xcd + 1) * per); w.ts = G >> 3;
+    } else {
+        w.t0 = blockIdx.x; w.t1 = a.ntiles; w.ts = G;
+    }
+    return w;
+}
+
+template <int KS, int CI, int CO>
+__global__ void __launch_bounds__(256) conv_direct2_kernel(const DirectParams a) {
+    typedef Stager2<CI> ST;
+    constexpr int HWD = ST::HWD, HPIX = ST::HPIX, VEC = ST::VEC, NPL = ST::NPL;
+    constexpr int KK = KS * KS, NWT = KK * CI * CO;
+    __shared__ __attribute__((aligned(16))) float tile[NPL * HPIX * VEC];
+    __shared__ float wl[NWT];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NWT; e += 256) {
+        const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+        wl[e] = (ci < a.Cin && co < a.Cout) ? a.w[((size_t)tap * a.Cin + ci) * a.Cout + co] : 0.f;
+    }
+    __syncthreads();
+    float ws[NWT];
+#pragma unroll
+    for (int e = 0; e < NWT; ++e) ws[e] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wl[e])));
+    float bs[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) bs[co] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+
+    const int tx = tid & (DTX - 1), ty = tid / DTX;          // pixels (2 ty, tx) and (2 ty + 1, tx) of the tile
+    const bool vec_out = (CO % 4 == 0) && a.Cout == CO && a.out.vec && (!a.add.p || a.add.vec) && (!a.mask.p || a.mask.vec);
+    const Walk2 wk = walk2(a);
+    auto decode = [&](int t, int& n, int& y0, int& x0) {
+        const int q = fast_div(t, a.m_tx);
+        const int bx = t - q * a.tiles_x;
+        n = fast_div(q, a.m_ty);
+        const int by = q - n * a.tiles_y;
+        x0 = bx * DTX; y0 = by * D2Y;
+    };
+    ST st;
+    st.init(a.in, a.Cin, tid);
+    if (wk.t0 < wk.t1) { int n, y0, x0; decode(wk.t0, n, y0, x0); st.issue(a.in, a.H, a.W, n, y0, x0, tid); }
+    for (int t = wk.t0; t < wk.t1; t += wk.ts) {
+        int n, y0, x0;
+        decode(t, n, y0, x0);
+        st.put(a.in, n, tid, tile);
+        __syncthreads();
+        if (t + wk.ts < wk.t1) { int n2, y2, x2; decode(t + wk.ts, n2, y2, x2); st.issue(a.in, a.H, a.W, n2, y2, x2, tid); }
+        const int gx = x0 + tx;
+        // the epilogue's operands, requested before the arithmetic where that is cheap in registers (<= 2 outputs per pixel;
+        // with 8 the 48 registers cost a wave per SIMD and the 1 -> 8 layer ran 15 % slower than the first generation)
+        constexpr bool PRE = CO <= 2;
+        float e_add[2][CO], e_mask[2][CO], e_old[2][CO];
+        bool pok[2];
+        auto fetch_operands = [&](int i) __attribute__((always_inline)) {
+            const int gy = y0 + 2 * ty + i;
+            if (vec_out) {
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4) {
+                    if (a.add.p) {
+                        const float4 q = mask4(view_load4_raw(a.add, n, gy, gx, c4 * 4, pok[i]), pok[i] ? 0xfu : 0u);
+                        e_add[i][(c4 * 4) % CO] = q.x; e_add[i][(c4 * 4 + 1) % CO] = q.y; e_add[i][(c4 * 4 + 2) % CO] = q.z; e_add[i][(c4 * 4 + 3) % CO] = q.w;
+                    }
+                    if (a.mask.p) {
+                        const float4 q = mask4(view_load4_raw(a.mask, n, gy, gx, c4 * 4, pok[i]), pok[i] ? 0xfu : 0u);
+                        e_mask[i][(c4 * 4) % CO] = q.x; e_mask[i][(c4 * 4 + 1) % CO] = q.y; e_mask[i][(c4 * 4 + 2) % CO] = q.z; e_mask[i][(c4 * 4 + 3) % CO] = q.w;
+                    }
+                    if (a.accumulate) {
+                        const float4 q = mask4(view_load4_raw(a.out, n, gy, gx, c4 * 4, pok[i]), pok[i] ? 0xfu : 0u);
+                        e_old[i][(c4 * 4) % CO] = q.x; e_old[i][(c4 * 4 + 1) % CO] = q.y; e_old[i][(c4 * 4 + 2) % CO] = q.z; e_old[i][(c4 * 4 + 3) % CO] = q.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const bool ok = pok[i] && co < a.Cout;
+                    e_add[i][co] = (a.add.p && ok) ? a.add.p[view_off(a.add, n, gy, gx, co)] : 0.f;
+                    e_mask[i][co] = (a.mask.p && ok) ? a.mask.p[view_off(a.mask, n, gy, gx, co)] : 0.f;
+                    e_old[i][co] = (a.accumulate && ok) ? a.out.p[view_off(a.out, n, gy, gx, co)] : 0.f;
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pok[i] = (y0 + 2 * ty + i) < a.H && gx < a.W;
+            if (PRE) fetch_operands(i);
+        }
+        float acc[2][CO];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[i][co] = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < KS + 1; ++rr) {
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    float v[VEC];
+                    const float* src = tile + ((size_t)pl * HPIX + (2 * ty + rr) * HWD + tx + dx) * VEC;
+                    if (VEC == 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(src);
+                        v[0] = t4.x; v[1] = t4.y; v[2 % VEC] = t4.z; v[3 % VEC] = t4.w;
+                    } else if (VEC == 2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(src);
+                        v[0] = t2.x; v[1 % VEC] = t2.y;
+                    } else {
+                        v[0] = src[0];
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+#pragma unroll
+                        for (int co = 0; co < CO; ++co) {
+                            if (rr < KS) acc[0][co] = fmaf(v[k], ws[((rr * KS + dx) * CI + pl * VEC + k) * CO + co], acc[0][co]);
+                            if (rr >= 1) acc[1][co] = fmaf(v[k], ws[(((rr - 1) * KS + dx) * CI + pl * VEC + k) * CO + co], acc[1][co]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gy = y0 + 2 * ty + i;
+            if (!pok[i]) continue;
+            if (!PRE) fetch_operands(i);
+            float o[CO];
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                float tv = acc[i][co] + bs[co];
+                if (a.add.p) tv += e_add[i][co];
+                if (a.relu) tv = fmaxf(tv, 0.f);
+                if (a.mask.p) tv = e_mask[i][co] > 0.f ? tv : 0.f;
+                if (a.accumulate) tv += e_old[i][co];
+                o[co] = tv;
+            }
+            if (vec_out) {
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4)
+                    *reinterpret_cast<float4*>(a.out.p + view_off(a.out, n, gy, gx, c4 * 4)) =
+                        make_float4(o[(c4 * 4) % CO], o[(c4 * 4 + 1) % CO], o[(c4 * 4 + 2) % CO], o[(c4 * 4 + 3) % CO]);
+            } else {
+#pragma unroll
+                for (int co = 0; co < CO; ++co)
+                    if (co < a.Cout) a.out.p[view_off(a.out, n, gy, gx, co)] = o[co];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int KS, int CI, int CO>
+__global__ void __launch_bounds__(256) conv_direct2_wgrad_kernel(const DirectParams a) {
+    typedef Stager2<CI> ST;
+    constexpr int HWD = ST::HWD, HPIX = ST::HPIX, VEC = ST::VEC, NPL = ST::NPL;
+    constexpr int KK = KS * KS, NWT = KK * CI * CO, NACC = NWT + CO;
+    __shared__ __attribute__((aligned(16))) float tile[NPL * HPIX * VEC];
+    __shared__ float red[4][NACC];
+    const int tid = threadIdx.x;
+    const int tx = tid & (DTX - 1), ty = tid / DTX;
+    float acc[NACC];
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) acc[e] = 0.f;
+    const bool vec_dz = (CO % 4 == 0) && a.Cout == CO && a.out.vec;
+    const Walk2 wk = walk2(a);
+    auto decode = [&](int t, int& n, int& y0, int& x0) {
+        const int q = fast_div(t, a.m_tx);
+        const int bx = t - q * a.tiles_x;
+        n = fast_div(q, a.m_ty);
+        const int by = q - n * a.tiles_y;
+        x0 = bx * DTX; y0 = by * D2Y;
+    };
+    // dz of this thread's two pixels of the tile at (n, y0, x0) (zero outside the image)
+    auto load_dz = [&](int n, int y0, int x0, float (&dz)[2][CO]) __attribute__((always_inline)) {
+        const int gx = x0 + tx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gy = y0 + 2 * ty + i;
+            const bool pok = gy < a.H && gx < a.W;
+            if (vec_dz) {
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4) {
+                    const float4 r4 = mask4(view_load4_raw(a.out, n, gy, gx, c4 * 4, pok), valid4(c4 * 4, a.Cout, pok));
+                    dz[i][(c4 * 4) % CO] = r4.x; dz[i][(c4 * 4 + 1) % CO] = r4.y; dz[i][(c4 * 4 + 2) % CO] = r4.z; dz[i][(c4 * 4 + 3) % CO] = r4.w;
+                }
+            } else {
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const bool ok = pok && co < a.Cout;
+                    const float rv = a.out.p[view_off(a.out, n, ok ? gy : 0, ok ? gx : 0, ok ? co : 0)];
+                    unsigned mm = ok ? 0xffffffffu : 0u;
+                    asm volatile("" : "+v"(mm));
+                    dz[i][co] = __uint_as_float(__float_as_uint(rv) & mm);
+                }
+            }
+        }
+    };
+    ST st;
+    st.init(a.in, a.Cin, tid);
+    float dzn[2][CO];
+    if (wk.t0 < wk.t1) {
+        int n, y0, x0;
+        decode(wk.t0, n, y0, x0);
+        st.issue(a.in, a.H, a.W, n, y0, x0, tid);
+        load_dz(n, y0, x0, dzn);
+    }
+    for (int t = wk.t0; t < wk.t1; t += wk.ts) {
+        int n, y0, x0;
+        decode(t, n, y0, x0);
+        st.put(a.in, n, tid, tile);
+        float dz[2][CO];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) dz[i][co] = dzn[i][co];
+        __syncthreads();
+        if (t + wk.ts < wk.t1) {
+            int n2, y2, x2;
+            decode(t + wk.ts, n2, y2, x2);
+            st.issue(a.in, a.H, a.W, n2, y2, x2, tid);
+            load_dz(n2, y2, x2, dzn);
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[NWT + co] += dz[0][co] + dz[1][co];
+#pragma unroll
+        for (int rr = 0; rr < KS + 1; ++rr) {
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    float v[VEC];
+                    const float* src = tile + ((size_t)pl * HPIX + (2 * ty + rr) * HWD + tx + dx) * VEC;
+                    if (VEC == 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(src);
+                        v[0] = t4.x; v[1] = t4.y; v[2 % VEC] = t4.z; v[3 % VEC] = t4.w;
+                    } else if (VEC == 2) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(src);
+                        v[0] = t2.x; v[1 % VEC] = t2.y;
+                    } else {
+                        v[0] = src[0];
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+#pragma unroll
+                        for (int co = 0; co < CO; ++co) {
+                            if (rr < KS) {
+                                const int e = ((rr * KS + dx) * CI + pl * VEC + k) * CO + co;
+                                acc[e] = fmaf(v[k], dz[0][co], acc[e]);
+                            }
+                            if (rr >= 1) {
+                                const int e = (((rr - 1) * KS + dx) * CI + pl * VEC + k) * CO + co;
+                                acc[e] = fmaf(v[k], dz[1][co], acc[e]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // block reduction in a fixed order: lanes (butterfly) -> waves -> slab
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) {
+        const float sm = wave_sum(acc[e]);
+        if (lane == 0) red[wave][e] = sm;
+    }
+    __syncthreads();
+    const size_t nw = (size_t)KK * a.Cin * a.Cout;
+    float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
+    for (int e = tid; e < NACC; e += 256) {
+        const float sm = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < NWT) {
+            const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+            if (ci < a.Cin && co < a.Cout) slab[((size_t)tap * a.Cin + ci) * a.Cout + co] = sm;
+        } else if (e - NWT < a.Cout) {
+            slab[nw + (e - NWT)] = sm;
+        }
+    }
+}
+
+// the second generation takes plain inputs whose channels its loads cover exactly
+bool direct2_ok(const DirectParams& p, int ci) {
+    static const bool off = getenv("DL4DS_NO_DIRECT2") != nullptr;
+    if (off || p.in.d2s > 1) return false;
+    if ((((uintptr_t)p.in.p) & 3) != 0) return false;
+    if (ci >= 4 ? (!p.in.vec || (p.Cin & 3) != 0) : (p.Cin != ci)) return false;
+    if (ci < 4 && p.in.sc) return false;
+    if ((size_t)(D2Y + 3) * p.W * p.in.ld * 4 >= (1ull << 31)) return false;
+    return (long)cdiv(p.W, DTX) * cdiv(p.H, D2Y) * p.in.N < (1l << 20);
+}
+
 inline int pad_pow2(int c) { int p = 1; while (p < c) p <<= 1; return p; }
 
 bool eligible(const TView& in, const TView& out, int KS) {
@@ -402,17 +808,37 @@ void fill_tiles(DirectParams& p, int N) {
 }
 
 template <int KS, int CI, int CO>
-int launch_direct(hipStream_t s, const DirectParams& p, bool wgrad, int max_blocks, bool exact_grid = false) {
+int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blocks, bool exact_grid = false) {
+    DirectParams p = p0;
+    // forward with more than two outputs per pixel stays on the first generation (1 -> 8 at 64 x 512^2: 0.196 ms there, 0.229 here:
+    // 142 registers against 45 and the layer is bound by its stores); every weight gradient measured is faster here
+    const bool gen2 = direct2_ok(p, CI) && (wgrad || CO <= 2);
+    if (gen2) {
+        p.tiles_y = cdiv(p.H, D2Y);
+        p.ntiles = p.tiles_x * p.tiles_y * p.in.N;
+        p.m_ty = div_magic(p.tiles_y);
+        static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;
+        p.xcd = no_xcd ? 0 : 1;
+    }
     // persistent kernels: one residency round (blocks do equal work); exact_grid: per-image slabs need exactly that many blocks
-    const int blocks = exact_grid ? max_blocks
-                                  : std::min(max_blocks, wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256)
-                                                               : resident_blocks<conv_direct_kernel<KS, CI, CO>>(256));
+    int blocks = max_blocks;
+    if (!exact_grid) {
+        const int resident = gen2 ? (wgrad ? resident_blocks<conv_direct2_wgrad_kernel<KS, CI, CO>>(256) : resident_blocks<conv_direct2_kernel<KS, CI, CO>>(256))
+                                  : (wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256) : resident_blocks<conv_direct_kernel<KS, CI, CO>>(256));
+        blocks = std::max(1, std::min(std::min(max_blocks, resident), p.ntiles));
+        if (gen2 && blocks >= 8) blocks &= ~7;
+    }
     const double px = (double)p.in.N * p.H * p.W;
     const std::string tag = std::string(wgrad ? "conv_direct_wgrad<" : "conv_direct<") + std::to_string(KS) + "," +
                             std::to_string(CI) + "," + std::to_string(CO) + ">";
     ProfScope ps(s, tag, 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * px * (p.Cin + p.Cout));
-    if (wgrad) hipLaunchKernelGGL((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_direct_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+    if (gen2) {
+        if (wgrad) hipLaunchKernelGGL((conv_direct2_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_direct2_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+    } else {
+        if (wgrad) hipLaunchKernelGGL((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_direct_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+    }
     HIP_CHECK(hipGetLastError());
     return blocks;
 }

@@ -271,7 +271,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
     const float* const vrd = Vb + ((wave * 4) * 16 + l15) * VP + 4 * lq;
     float* const pwr = Pb + ((wave * 2) * 16 + l15) * PP + 4 * lq;
     WT(0);
+#ifndef WINO_PRIO
+#define WINO_PRIO 1
+#endif
     for (;;) {
+        // Vector-instruction issue on a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md, two waves per SIMD): at equal
+        // priority the transform phases of the younger workgroup's wave get ONE issue per MFMA of the older one's phase B (3 000 cycles
+        // for phase A's ~100 instructions).  Raised priority outside phase B lets them through at their own issue cost instead.
+        if (WINO_PRIO) __builtin_amdgcn_s_setprio(WINO_PRIO);
         // ---- A: V = B^T d B (rows 1 and 2 of the halo feed all four xi)
 #ifndef WINO_NO_A
         if (a_on) {
@@ -320,6 +327,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         // ---- B: wave xi, M[nu] = U[xi][nu]^T V[xi][nu] over cin; R0 = M0 + M1 + M2, R1 = M1 - M2 - M3.  nu = 0 accumulates in
         //      R0 and nu = 3 (negated filter) in R1 directly; M1 and M2 are added / subtracted by the vector unit
         f32x4 R0[NT], R1[NT];
+        if (WINO_PRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef WINO_NO_B
 #pragma unroll
         for (int cb = 0; cb < NT; ++cb) { R0[cb] = (f32x4){U[0][0][cb], 0.f, 0.f, 0.f}; R1[cb] = R0[cb]; }
@@ -362,6 +370,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
         }
 #endif
         WT(4);
+        if (WINO_PRIO) __builtin_amdgcn_s_setprio(WINO_PRIO);
         __syncthreads();                                            // every wave has read its rows of V: the products take its place
         if (want_bias && wave == 1) {
             // rows 0 and 1 of A^T both carry xi = 1 with coefficient +1: the bias added to R[1][j] reaches all four outputs
