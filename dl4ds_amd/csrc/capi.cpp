@@ -194,6 +194,18 @@ int dl4ds_op_conv2d_fwd(const float* x, const float* w, const float* b, const fl
     conv2d_forward(S(), in, w, KS, out, ep);
     API_END
 }
+int dl4ds_op_conv2d_epilogue(const float* x, const float* w, const float* b, const float* add, const float* mask, float* y, int N,
+                             int H, int W, int Cin, int Cout, int KS, int relu, int accumulate) {
+    API_BEGIN
+    ConvEpilogue ep;
+    ep.bias = b;
+    if (add) ep.add = make_view(nc(add), N, H, W, Cout);
+    if (mask) ep.mask = make_view(nc(mask), N, H, W, Cout);
+    ep.relu = relu;
+    ep.accumulate = accumulate;
+    conv2d_forward(S(), make_view(nc(x), N, H, W, Cin), w, KS, make_view(y, N, H, W, Cout), ep);
+    API_END
+}
 int dl4ds_op_conv2d_dgrad(const float* dz, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int KS,
                           int d2s_r, int accumulate) {
     API_BEGIN

@@ -433,6 +433,9 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
     }
 #endif
     if (wave8 >= 4) {
+#ifdef PAIR_WS_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(PAIR_WS_LOADER_PRIO);
+#endif
         // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 1) + 128 u, channel quad htid & 1)
         const int htid = tid & 255;
         const int c4 = htid & 1, p0 = htid >> 1;
@@ -813,6 +816,9 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
     };
 
     if (wave8 >= 4) {
+#ifdef PAIR_WS_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(PAIR_WS_LOADER_PRIO);
+#endif
         // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 2) + 64 u, channel quad htid & 3)
         const int htid = tid & 255;
         const int c4 = htid & 3, p0 = htid >> 2;

@@ -36,6 +36,18 @@ def conv2d(x, w, b=None, add=None, relu=False, d2s=0):
     return y.numpy()
 
 
+def conv2d_epilogue(x, w, b=None, add=None, mask=None, relu=False, accumulate_into=None):
+    """y = [y_old +] where(mask > 0, [relu](conv_same(x,w) + b + add), 0): every operand of the fused epilogue."""
+    n, h, wd, cin = x.shape
+    ks, _, ci, cout = w.shape
+    assert ci == cin
+    dx, dw, db, da, dm = _d(x), _d(w), _d(b), _d(add), _d(mask)
+    y = DeviceArray.zeros((n, h, wd, cout)) if accumulate_into is None else _d(accumulate_into)
+    _lib.check(_lib.lib().dl4ds_op_conv2d_epilogue(dx.ptr, dw.ptr, _p(db), _p(da), _p(dm), y.ptr, n, h, wd, cin, cout, ks,
+                                                   int(relu), int(accumulate_into is not None)))
+    return y.numpy()
+
+
 def conv2d_dgrad(dz, w, d2s=0, accumulate_into=None):
     """dx = dgrad(dz, w).  dz: gradient of the conv output (in d2s layout if d2s>1)."""
     ks, _, cin, cout = w.shape

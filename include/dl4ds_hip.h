@@ -57,6 +57,14 @@ int dl4ds_profile_report(char* json_buf, size_t buflen);
  * fused with Add (blocks.py:228), Activation (blocks.py:75) and tf.nn.depth_to_space (blocks.py:427). */
 int dl4ds_op_conv2d_fwd(const float* x_dev, const float* w_dev, const float* b_dev, const float* add_dev,
                         float* y_dev, int N, int H, int W, int Cin, int Cout, int KS, int relu, int d2s_r);
+/* The same convolution with EVERY operand of the fused epilogue, in the order the train step applies them:
+ * y = [y_old +] mask_gt0( [relu]( conv_same_s1(x,w) + b + add ), mask ) -- residual Add (blocks.py:228), Activation
+ * (blocks.py:75), the ReLU backward of the layer below riding on a dgrad store (mask = that layer's activation) and gradient
+ * accumulation.  The narrow kernels compile one form per operand combination (csrc/conv_narrow.hip); this entry point lets a
+ * test reach all of them.  b, add, mask may be NULL; accumulate != 0 adds the result to what y holds. */
+int dl4ds_op_conv2d_epilogue(const float* x_dev, const float* w_dev, const float* b_dev, const float* add_dev,
+                             const float* mask_dev, float* y_dev, int N, int H, int W, int Cin, int Cout, int KS, int relu,
+                             int accumulate);
 /* dx (+)= dgrad(dz, w); dz may be given in depth_to_space(d2s_r) layout (gradient of a fused-d2s conv) */
 int dl4ds_op_conv2d_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int N, int H, int W,
                           int Cin, int Cout, int KS, int d2s_r, int accumulate);

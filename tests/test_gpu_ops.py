@@ -288,6 +288,38 @@ def test_conv2d_fused_epilogues_pair_path(ops, ci, co):
     close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
 
 
+@pytest.mark.parametrize('form', range(16))
+@pytest.mark.parametrize('ci,co,h,w', [(8, 8, 37, 70), (5, 8, 19, 45), (16, 16, 37, 40), (13, 16, 20, 33), (8, 1, 35, 45), (1, 1, 19, 70),
+                                       (1, 8, 19, 45), (2, 2, 33, 33)])
+def test_conv2d_every_epilogue_form(ops, form, ci, co, h, w):
+    """The producer / consumer narrow kernels (8 -> 8: conv_narrow_pair_ws, 9..16 -> 16: conv_narrow16_ws) compile one epilogue
+    form per combination of residual, ReLU, ReLU mask and accumulation (16 forms each, operands requested before the K loop), and
+    the stencil kernels apply the same four switches at run time (second generation: operands fetched before the arithmetic):
+    every combination against y = [old +] where(mask > 0, [relu](conv + b + add), 0) on grids with ragged right / bottom tiles
+    (several tiles per workgroup, so the XCD-aware walk and the one-tile-ahead descriptors are exercised too)."""
+    n = 3
+    has_add, relu, has_mask, acc = bool(form & 1), bool(form & 2), bool(form & 4), bool(form & 8)
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    add = R(n, h, w, co) if has_add else None
+    mask = R(n, h, w, co) if has_mask else None
+    old = R(n, h, w, co) if acc else None
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    if has_add:
+        ref = ref + add
+    if relu:
+        ref = np.maximum(ref, 0)
+    if has_mask:
+        ref = np.where(mask > 0, ref, 0.0)
+    if acc:
+        ref = ref + old
+    from tests.parity import kernel_tags
+    got, tags = kernel_tags(lambda: ops.conv2d_epilogue(x, wt, b, add=add, mask=mask, relu=relu, accumulate_into=old))
+    want = {(8, 8): 'conv_narrow_pair_ws<', (5, 8): 'conv_narrow_pair_ws<', (16, 16): 'conv_narrow16_ws<', (13, 16): 'conv_narrow16_ws<'}.get(
+        (ci, co), 'conv_direct<')
+    assert any(t.startswith(want) for t in tags), tags
+    close(got, ref)
+
+
 @pytest.mark.parametrize('ci,co', [(8, 1), (1, 8), (1, 1), (3, 2)])
 def test_conv2d_fused_epilogues_stencil_path(ops, ci, co):
     n, h, w = 2, 19, 45
