@@ -61,20 +61,22 @@ __global__ void colsum_finish_kernel(const float* __restrict__ partial, float* _
 
 // mean[g*C + c] = scale * sum_k partial[(g*tiles + k)*8 + c]: the per-tile channel sums the narrow pair convolution
 // wrote from its epilogue (ConvEpilogue::pool), same eight-way fixed association order as colsum_finish_kernel
-__global__ void pool_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int tiles, int C, int GC,
-                                   float scale) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= GC) return;
-    const int g = e / C, c = e - g * C;
+// One wave per instance g: lane (u = lane >> 3, c = lane & 7) sums the tiles k = u (mod 8) -- the eight partial sums one thread
+// used to keep (512 dependent loads per thread, 32 us at 64 x 512^2) -- and three shuffles combine them in the same order.
+__global__ void __launch_bounds__(256) pool_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int tiles, int C,
+                                                          int G, float scale) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;                                   // (whole waves)
+    const int lane = threadIdx.x & 63, u = lane >> 3, c = lane & 7;
     const float* p = partial + (size_t)g * tiles * 8 + c;
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= tiles; k += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(k + u) * 8];
-    }
-    for (; k < tiles; ++k) s[0] += p[(size_t)k * 8];
-    out[e] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * scale;
+    const int full = tiles & ~7;
+    float s = 0.f;
+    for (int k = u; k < full; k += 8) s += p[(size_t)k * 8];
+    if (u == 0) for (int k = full; k < tiles; ++k) s += p[(size_t)k * 8];
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (u == 0 && c < C) out[(size_t)g * C + c] = s * scale;
 }
 
 // one thread per (instance, c)
@@ -241,8 +243,8 @@ void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, 
     ProfScope ps(s, "chatt_fwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * ((pool_partial ? 0 : 1) + (y ? 2 : 0)));
     if (pool_partial) {
         DL4DS_REQUIRE(sh.P == 1 && sh.C <= 8, "chatt: pooling partials come from the 8-channel pair convolution");
-        hipLaunchKernelGGL(pool_finish_kernel, dim3(cdiv(sh.G * sh.C, 256)), dim3(256), 0, s, pool_partial, mean, pool_tiles,
-                           sh.C, sh.G * sh.C, 1.f / (float)sh.R);
+        hipLaunchKernelGGL(pool_finish_kernel, dim3(cdiv(sh.G, 4)), dim3(256), 0, s, pool_partial, mean, pool_tiles,
+                           sh.C, sh.G, 1.f / (float)sh.R);
         HIP_CHECK(hipGetLastError());
     } else {
         colsum(s, x, nullptr, workspace, mean, sh.G, sh.R, Q, 1.f / (float)sh.R);
