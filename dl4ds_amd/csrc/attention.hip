@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(256) pool_finish_kernel(const float* __restric
     const float* p = partial + (size_t)g * tiles * 8 + c;
     const int full = tiles & ~7;
     float s = 0.f;
-    for (int k = u; k < full; k += 8) s += p[(size_t)k * 8];
+#pragma unroll 8
+    for (int k = u; k < full; k += 8) s += p[(size_t)k * 8];                // (unrolled: the loads of eight steps in flight, the additions in order)
     if (u == 0) for (int k = full; k < tiles; ++k) s += p[(size_t)k * 8];
     s += __shfl_xor(s, 8, 64);
     s += __shfl_xor(s, 16, 64);

@@ -1507,6 +1507,7 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     DL4DS_REQUIRE(!in.sc && !ep.pool, "conv2d: channel-affine input / pooling partials are only implemented by the direct "
                                      "and narrow-pair kernels (the caller must check conv2d_direct_eligible / conv2d_narrow_pair_ok)");
     if (KS == 3 && conv2d_wino_forward(s, in, w, out, ep)) return;  // MFMA-bound 3x3 layers: Winograd F(2x2, 3x3)
+    if (KS == 1 && getenv("DL4DS_POINT_FIRST") && conv2d_point_forward(s, in, w, KS, out, ep)) return;     // (experiment)
     if (!getenv("DL4DS_NO_STREAM") && conv2d_stream_forward(s, in, w, KS, out, ep)) return;
     if (conv2d_point_forward(s, in, w, KS, out, ep)) return;      // 1x1 with channel counts that are not multiples of four
     ConvParams p;
