@@ -150,61 +150,62 @@ void chatt_apply(hipStream_t s, const float* a, const float* scale, const float*
     HIP_CHECK(hipGetLastError());
 }
 
-// single block: phase A per instance, phase B deterministic parameter-gradient sums
-__global__ void __launch_bounds__(256) chatt_mlp_bwd_kernel(
-    const float* __restrict__ ds, const float* __restrict__ mean, const float* __restrict__ hidden,
-    const float* __restrict__ scale, const float* __restrict__ w1, const float* __restrict__ w2,
-    float* __restrict__ dpre1, float* __restrict__ dpre2, float* __restrict__ dmean, float* __restrict__ dw1,
-    float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2, int ninst, int C, int Cr,
-    float inv_r, int accumulate) {
-    for (int inst = threadIdx.x; inst < ninst; inst += blockDim.x) {
-        const float* s = scale + (size_t)inst * C;
-        const float* h = hidden + (size_t)inst * Cr;
-        float* p2 = dpre2 + (size_t)inst * C;
-        float* p1 = dpre1 + (size_t)inst * Cr;
-        for (int c = 0; c < C; ++c) p2[c] = ds[(size_t)inst * C + c] * s[c] * (1.f - s[c]);
-        for (int j = 0; j < Cr; ++j) {
-            float dh = 0.f;
-            for (int c = 0; c < C; ++c) dh += p2[c] * w2[j * C + c];
-            p1[j] = (h[j] > 0.f) ? dh : 0.f;
-        }
-        for (int c = 0; c < C; ++c) {
-            float dm = 0.f;
-            for (int j = 0; j < Cr; ++j) dm += p1[j] * w1[c * Cr + j];
-            dmean[(size_t)inst * C + c] = dm * inv_r;
-        }
+// phase A per instance (one thread each), phase B deterministic parameter-gradient sums (one wavefront per output element,
+// lanes stride the instances, fixed shuffle tree).  Two launches over as many blocks as there is work: as ONE block (round 2)
+// the 5-D form of cfg4 (4 096 instances) took 113 us per attention layer.
+__global__ void __launch_bounds__(256) chatt_mlp_bwd_inst_kernel(
+    const float* __restrict__ ds, const float* __restrict__ hidden, const float* __restrict__ scale, const float* __restrict__ w1,
+    const float* __restrict__ w2, float* __restrict__ dpre1, float* __restrict__ dpre2, float* __restrict__ dmean, int ninst, int C,
+    int Cr, float inv_r) {
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= ninst) return;
+    const float* s = scale + (size_t)inst * C;
+    const float* h = hidden + (size_t)inst * Cr;
+    float* p2 = dpre2 + (size_t)inst * C;
+    float* p1 = dpre1 + (size_t)inst * Cr;
+    for (int c = 0; c < C; ++c) p2[c] = ds[(size_t)inst * C + c] * s[c] * (1.f - s[c]);
+    for (int j = 0; j < Cr; ++j) {
+        float dh = 0.f;
+        for (int c = 0; c < C; ++c) dh += p2[c] * w2[j * C + c];
+        p1[j] = (h[j] > 0.f) ? dh : 0.f;
     }
-    __syncthreads();
-    if (dw1 == nullptr) return;        // input gradient only (CGAN generator pass through the discriminator)
-    // dW1[c][j] = sum_inst mean[c]*dpre1[j] ; dW2[j][c] = sum_inst h[j]*dpre2[c] ; db1 = sum dpre1 ; db2 = sum dpre2.
-    // One wavefront per output element, lanes stride the instances (1024 of them in the 5-D form: the former
-    // one-thread-per-output loops took 0.14 ms), fixed shuffle tree.
-    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int c = 0; c < C; ++c) {
+        float dm = 0.f;
+        for (int j = 0; j < Cr; ++j) dm += p1[j] * w1[c * Cr + j];
+        dmean[(size_t)inst * C + c] = dm * inv_r;
+    }
+}
+// dW1[c][j] = sum_inst mean[c]*dpre1[j] ; dW2[j][c] = sum_inst h[j]*dpre2[c] ; db1 = sum dpre1 ; db2 = sum dpre2
+__global__ void __launch_bounds__(256) chatt_mlp_bwd_param_kernel(
+    const float* __restrict__ mean, const float* __restrict__ hidden, const float* __restrict__ dpre1, const float* __restrict__ dpre2,
+    float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2, int ninst, int C, int Cr,
+    int accumulate) {
+    const int lane = threadIdx.x & 63;
     const int nout = 2 * C * Cr + Cr + C;
-    for (int o = threadIdx.x >> 6; o < nout; o += nw) {
-        float a = 0.f;
-        float* dst;
-        if (o < C * Cr) {
-            const int c = o / Cr, j = o - c * Cr;
-            for (int inst = lane; inst < ninst; inst += 64) a += mean[(size_t)inst * C + c] * dpre1[(size_t)inst * Cr + j];
-            dst = dw1 + c * Cr + j;
-        } else if (o < 2 * C * Cr) {
-            const int e = o - C * Cr, c = e / Cr, j = e - c * Cr;
-            for (int inst = lane; inst < ninst; inst += 64) a += hidden[(size_t)inst * Cr + j] * dpre2[(size_t)inst * C + c];
-            dst = dw2 + j * C + c;
-        } else if (o < 2 * C * Cr + Cr) {
-            const int j = o - 2 * C * Cr;
-            for (int inst = lane; inst < ninst; inst += 64) a += dpre1[(size_t)inst * Cr + j];
-            dst = db1 + j;
-        } else {
-            const int c = o - 2 * C * Cr - Cr;
-            for (int inst = lane; inst < ninst; inst += 64) a += dpre2[(size_t)inst * C + c];
-            dst = db2 + c;
-        }
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
-        if (lane == 0) *dst = accumulate ? *dst + a : a;
+    const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (o >= nout) return;                                  // (whole waves)
+    float a = 0.f;
+    float* dst;
+    if (o < C * Cr) {
+        const int c = o / Cr, j = o - c * Cr;
+        for (int inst = lane; inst < ninst; inst += 64) a += mean[(size_t)inst * C + c] * dpre1[(size_t)inst * Cr + j];
+        dst = dw1 + c * Cr + j;
+    } else if (o < 2 * C * Cr) {
+        const int e = o - C * Cr, c = e / Cr, j = e - c * Cr;
+        for (int inst = lane; inst < ninst; inst += 64) a += hidden[(size_t)inst * Cr + j] * dpre2[(size_t)inst * C + c];
+        dst = dw2 + j * C + c;
+    } else if (o < 2 * C * Cr + Cr) {
+        const int j = o - 2 * C * Cr;
+        for (int inst = lane; inst < ninst; inst += 64) a += dpre1[(size_t)inst * Cr + j];
+        dst = db1 + j;
+    } else {
+        const int c = o - 2 * C * Cr - Cr;
+        for (int inst = lane; inst < ninst; inst += 64) a += dpre2[(size_t)inst * C + c];
+        dst = db2 + c;
     }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) *dst = accumulate ? *dst + a : a;
 }
 
 int pick_tx(int Q) { return Q <= 8 ? 8 : (Q <= 16 ? 16 : (Q <= 32 ? 32 : 64)); }
@@ -271,9 +272,15 @@ void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, i
     if (dmean_out) dmean = dmean_out;           // kept by the caller: the producer reads dX = dY * scale + dmean lazily
     ProfScope ps(s, "chatt_bwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * ((ds_given ? 0 : 2) + (dx ? 2 + (accumulate_dx ? 1 : 0) : 0)));
     if (ds_given == nullptr) colsum(s, dy, x, partial, ds, sh.G, sh.R, Q, 1.f);
-    hipLaunchKernelGGL(chatt_mlp_bwd_kernel, dim3(1), dim3(256), 0, s, ds_given ? ds_given : ds, mean, hidden, scale, w1, w2, dpre1, dpre2,
-                       dmean, dw1, db1, dw2, db2, ninst, sh.C, sh.Cr, 1.f / (float)sh.R, accumulate_dw);
+    hipLaunchKernelGGL(chatt_mlp_bwd_inst_kernel, dim3(cdiv(ninst, 256)), dim3(256), 0, s, ds_given ? ds_given : ds, hidden, scale, w1, w2,
+                       dpre1, dpre2, dmean, ninst, sh.C, sh.Cr, 1.f / (float)sh.R);
     HIP_CHECK(hipGetLastError());
+    if (dw1) {              // (null: input gradient only -- the CGAN generator pass through the discriminator)
+        const int nout = 2 * sh.C * sh.Cr + sh.Cr + sh.C;
+        hipLaunchKernelGGL(chatt_mlp_bwd_param_kernel, dim3(cdiv(nout, 4)), dim3(256), 0, s, mean, hidden, dpre1, dpre2, dw1, db1, dw2, db2,
+                           ninst, sh.C, sh.Cr, accumulate_dw);
+        HIP_CHECK(hipGetLastError());
+    }
     if (dx == nullptr) return;                  // dX is not materialised (TView::sc / sh on the producer's dY view)
     chatt_apply<true>(s, dy, scale, dmean, dx, sh.G, sh.R, Q, accumulate_dx);
 }

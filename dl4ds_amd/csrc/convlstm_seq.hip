@@ -498,9 +498,14 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParam
     }
 }
 
-// column permutation between the Keras gate-major layout (column = gate * F + f) and the interleaved one (4 f + gate)
-__global__ void gate_interleave_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int F, int to_interleaved,
-                                       int accumulate) {
+// column permutation between the Keras gate-major layout (column = gate * F + f) and the interleaved one (4 f + gate); up to
+// three arrays per launch (kernel, recurrent kernel, bias of one layer: blockIdx.y picks the job)
+struct GateJobs { const float* src[3]; float* dst[3]; int rows[3]; int acc[3]; };
+__global__ void gate_interleave_kernel(const GateJobs jobs, int F, int to_interleaved) {
+    const int j = blockIdx.y;
+    const float* __restrict__ src = jobs.src[j];
+    float* __restrict__ dst = jobs.dst[j];
+    const int rows = jobs.rows[j], accumulate = jobs.acc[j];
     const int C4 = 4 * F;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * C4; e += gridDim.x * blockDim.x) {
         const int row = e / C4, c = e - row * C4;
@@ -548,11 +553,21 @@ bool convlstm_seq_supported(int KS, int F, int H, int W, int B) {
     return tiles >= 1 && tiles < (1l << 24);
 }
 
-void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int rows, int F, bool to_interleaved, bool accumulate) {
-    const int n = rows * 4 * F;
-    hipLaunchKernelGGL(gate_interleave_kernel, dim3(std::min(cdiv(n, 256), 512)), dim3(256), 0, s, src, dst, rows, F,
-                       to_interleaved ? 1 : 0, accumulate ? 1 : 0);
+void convlstm_gate_interleave_n(hipStream_t s, int njobs, const float* const* src, float* const* dst, const int* rows, const int* accumulate,
+                                int F, bool to_interleaved) {
+    GateJobs jobs{};
+    int nmax = 0;
+    for (int j = 0; j < njobs && j < 3; ++j) {
+        jobs.src[j] = src[j]; jobs.dst[j] = dst[j]; jobs.rows[j] = rows[j]; jobs.acc[j] = accumulate[j];
+        nmax = std::max(nmax, rows[j] * 4 * F);
+    }
+    if (njobs <= 0 || nmax == 0) return;
+    hipLaunchKernelGGL(gate_interleave_kernel, dim3(std::min(cdiv(nmax, 256), 512), njobs), dim3(256), 0, s, jobs, F, to_interleaved ? 1 : 0);
     HIP_CHECK(hipGetLastError());
+}
+void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int rows, int F, bool to_interleaved, bool accumulate) {
+    const int acc = accumulate ? 1 : 0;
+    convlstm_gate_interleave_n(s, 1, &src, &dst, &rows, &acc, F, to_interleaved);
 }
 
 // DL4DS_SEQ_TRACE=1 (development): per-phase times of every launch on stderr (synchronises)

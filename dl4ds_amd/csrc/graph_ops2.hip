@@ -134,9 +134,12 @@ struct ConvLSTMOp : GOp {
         if (seq) {
             DL4DS_REQUIRE(convlstm_seq_flag_bytes(ti.H, ti.W, B) <= (hw(g) / 64 + 64) * sizeof(float) * (size_t)B, "convlstm: flag area");
             float *Kp = g.Wt + wt_kp, *Up = g.Wt + wt_up, *bp = g.Wt + wt_bp;
-            convlstm_gate_interleave(g.stream, g.wp(wk), Kp, KS * KS * ti.C, F, true, false);
-            convlstm_gate_interleave(g.stream, g.wp(wr), Up, KS * KS * F, F, true, false);
-            convlstm_gate_interleave(g.stream, g.wp(b), bp, 1, F, true, false);
+            {   // kernel, recurrent kernel and bias into the interleaved gate order: one launch
+                const float* src[3] = {g.wp(wk), g.wp(wr), g.wp(b)};
+                float* dst[3] = {Kp, Up, bp};
+                const int rows[3] = {KS * KS * ti.C, KS * KS * F, 1}, acc[3] = {0, 0, 0};
+                convlstm_gate_interleave_n(g.stream, 3, src, dst, rows, acc, F, true);
+            }
             ConvEpilogue ep;
             ep.bias = bp;
             conv2d_forward(g.stream, g.view(in, B, false), Kp, KS, make_view(bf.Z, B * T, ti.H, ti.W, 4 * F), ep);
@@ -174,15 +177,18 @@ struct ConvLSTMOp : GOp {
                 // weight gradients against the interleaved dZ come out with interleaved columns: back to Keras' order on the
                 // way into the gradient arena
                 conv2d_wgrad(g.stream, g.view(in, B, false), dZall, KS, bf.dKp, 0, bf.dbp, 0, g.workspace, g.workspace_bytes);
-                convlstm_gate_interleave(g.stream, bf.dKp, g.gp(wk), KS * KS * ti.C, F, false, g.params[wk].grad_written);
-                convlstm_gate_interleave(g.stream, bf.dbp, g.gp(b), 1, F, false, g.params[b].grad_written);
-                g.params[wk].grad_written = g.params[b].grad_written = true;
-                if (T > 1) {
+                if (T > 1)
                     conv2d_wgrad(g.stream, make_view(bf.H, B * T, ti.H, ti.W, F), dZall, KS, bf.dUp, 0, nullptr, 0, g.workspace,
                                  g.workspace_bytes);
-                    convlstm_gate_interleave(g.stream, bf.dUp, g.gp(wr), KS * KS * F, F, false, g.params[wr].grad_written);
-                    g.params[wr].grad_written = true;
+                {   // (one launch for the two or three arrays)
+                    const float* src[3] = {bf.dKp, bf.dbp, bf.dUp};
+                    float* dst[3] = {g.gp(wk), g.gp(b), g.gp(wr)};
+                    const int rows[3] = {KS * KS * ti.C, 1, KS * KS * F};
+                    const int acc[3] = {(int)g.params[wk].grad_written, (int)g.params[b].grad_written, (int)g.params[wr].grad_written};
+                    convlstm_gate_interleave_n(g.stream, T > 1 ? 3 : 2, src, dst, rows, acc, F, false);
                 }
+                g.params[wk].grad_written = g.params[b].grad_written = true;
+                if (T > 1) g.params[wr].grad_written = true;
             }
             if (wants_grad(g, in, c)) {
                 ConvEpilogue ep;

@@ -22,6 +22,8 @@ void convlstm_gates_backward(hipStream_t s, const TView& z, const TView& c_prev,
 bool convlstm_seq_supported(int KS, int F, int H, int W, int B);
 size_t convlstm_seq_flag_bytes(int H, int W, int B);
 void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int rows, int F, bool to_interleaved, bool accumulate);
+void convlstm_gate_interleave_n(hipStream_t s, int njobs, const float* const* src, float* const* dst, const int* rows, const int* accumulate,
+                                int F, bool to_interleaved);      // up to three arrays in one launch
 void convlstm_seq_forward(hipStream_t s, const float* U_il, float* Z_il, float* C, float* Hrec, float* out, unsigned* flags,
                           int B, int T, int H, int W, int KS, int F, int relu);
 void convlstm_seq_backward(hipStream_t s, const float* U_il, const float* Z_il, const float* C, const float* out, const float* dout,
