@@ -632,6 +632,60 @@ void concat_split(hipStream_t s, const float* src, int ld, size_t npx, const Con
     HIP_CHECK(hipGetLastError());
 }
 
+// Concatenate forward in ONE pass (the mirror of concat_split): the wide tensor [npx][ld] is WRITTEN once, contiguously, every
+// element taken from the dense input whose channel range holds it.  Copying input by input writes every 32-byte sector of the
+// wide tensor in pieces (a 26-channel pixel is 104 bytes: no slice of it is sector-aligned): 2-channel and 8-channel slices of
+// cfg4's concatenation took 273 + 477 us for 335 MB.  Channels that belong to no slice (inputs that live in the buffer
+// already) are left alone.
+struct JoinSlice { const float* src; int off, C; };
+struct JoinParams { float* dst; int ld, n; JoinSlice sl[4]; };
+template <int V>
+__global__ void concat_join_kernel(const JoinParams a, int cvn, size_t step_pix, int step_cv, size_t totalv) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t pix = e / (size_t)cvn;
+    int cv = (int)(e - pix * (size_t)cvn);
+    for (; e < totalv; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = cv * V;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < a.n && c >= a.sl[k].off && c < a.sl[k].off + a.sl[k].C) {
+                const float* sp = a.sl[k].src + pix * (size_t)a.sl[k].C + (size_t)(c - a.sl[k].off);
+                float* dp = a.dst + pix * (size_t)a.ld + c;
+                if constexpr (V == 2) *reinterpret_cast<float2*>(dp) = *reinterpret_cast<const float2*>(sp);
+                else dp[0] = sp[0];
+            }
+        }
+        pix += step_pix; cv += step_cv;
+        if (cv >= cvn) { cv -= cvn; ++pix; }
+    }
+}
+void concat_join(hipStream_t s, float* dst, int ld, size_t npx, const ConcatSlice* slices, int n) {
+    DL4DS_REQUIRE(n >= 1 && n <= 4, "concat_join: 1..4 slices");
+    JoinParams a;
+    a.dst = dst; a.ld = ld; a.n = n;
+    bool even = (ld & 1) == 0 && ((uintptr_t)dst & 7) == 0;
+    double bytes = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+            a.sl[k] = JoinSlice{slices[k].dst, slices[k].off, slices[k].C};
+            even = even && ((slices[k].off | slices[k].C) & 1) == 0 && ((uintptr_t)slices[k].dst & 7) == 0;
+            bytes += 8.0 * (double)npx * slices[k].C;
+        } else {
+            a.sl[k] = JoinSlice{nullptr, 0, 0};
+        }
+    }
+    const int V = even ? 2 : 1;
+    const int cvn = ld / V;
+    const size_t totalv = npx * (size_t)cvn;
+    if (totalv == 0) return;
+    ProfScope ps(s, "concat_join", 0.0, bytes);
+    const int blocks = ew_blocks(totalv);
+    const size_t stride = (size_t)blocks * 256;
+    auto kern = even ? concat_join_kernel<2> : concat_join_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, a, cvn, stride / (size_t)cvn, (int)(stride % (size_t)cvn), totalv);
+    HIP_CHECK(hipGetLastError());
+}
+
 void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate) {
     if (n == 0) return;
     ProfScope ps(s, "masked_axpy", 0.0, 4.0 * (double)n * (3 + (accumulate ? 1 : 0)));
@@ -772,6 +826,67 @@ void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int 
     ProfScope pp(s, "repeat_time_fwd", 0.0, 4.0 * (double)total * (1 + T));
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(repeat_time_fwd_kernel, dim3(blocks), dim3(256), 0, s, in, out, ps, T, total);
+    HIP_CHECK(hipGetLastError());
+}
+// ... straight into a channel slice of a wider buffer (the Concatenate that follows, GTensor::alias_of): out is a view with pixel
+// pitch ld >= C; V floats per access (4 / 2 / 1: what the slice's offset and pitch allow)
+template <int V>
+__global__ void repeat_time_fwd_view_kernel(const float* __restrict__ in, float* __restrict__ out, int cvn, size_t hw, int C, int ld,
+                                            size_t nstride, int T, size_t totalv) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < totalv; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = e / (size_t)cvn;                    // pixel index over (b, y, x)
+        const int cv = (int)(e - px * (size_t)cvn);
+        const size_t b = px / hw, r = px - b * hw;
+        const float* ip = in + px * (size_t)C + (size_t)cv * V;
+        float* o = out + (b * T) * nstride + r * (size_t)ld + (size_t)cv * V;
+        if constexpr (V == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(ip);
+            for (int t = 0; t < T; ++t) *reinterpret_cast<float4*>(o + (size_t)t * nstride) = v;
+        } else if constexpr (V == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(ip);
+            for (int t = 0; t < T; ++t) *reinterpret_cast<float2*>(o + (size_t)t * nstride) = v;
+        } else {
+            const float v = ip[0];
+            for (int t = 0; t < T; ++t) o[(size_t)t * nstride] = v;
+        }
+    }
+}
+void repeat_time_forward_view(hipStream_t s, const float* in, const TView& out, int B, int T) {
+    DL4DS_REQUIRE(out.d2s <= 1 && out.N == B * T, "repeat_time: plain output view of B * T frames expected");
+    const size_t hw = (size_t)out.H * out.W, total = (size_t)B * hw * out.C;
+    if (total == 0) return;
+    ProfScope pp(s, "repeat_time_fwd", 0.0, 4.0 * (double)total * (1 + T));
+    const uintptr_t a = (uintptr_t)out.p | (uintptr_t)in;
+    const int V = ((out.C & 3) == 0 && (out.ld & 3) == 0 && (a & 15) == 0) ? 4 : (((out.C & 1) == 0 && (out.ld & 1) == 0 && (a & 7) == 0) ? 2 : 1);
+    const size_t totalv = total / V;
+    const int blocks = (int)std::min<size_t>((totalv + 255) / 256, 8192);
+    const int cvn = out.C / V;
+    if (V == 4) hipLaunchKernelGGL(repeat_time_fwd_view_kernel<4>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
+    else if (V == 2) hipLaunchKernelGGL(repeat_time_fwd_view_kernel<2>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
+    else hipLaunchKernelGGL(repeat_time_fwd_view_kernel<1>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
+    HIP_CHECK(hipGetLastError());
+}
+// ... and its gradient read from a channel slice of the Concatenate's gradient (GTensor::galias): same summation order
+__global__ void repeat_time_bwd_view_kernel(const float* __restrict__ dout, float* __restrict__ din, size_t hw, int C, int ld,
+                                            size_t nstride, int T, size_t total, int accumulate) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = e / (size_t)C;
+        const int c = (int)(e - px * (size_t)C);
+        const size_t b = px / hw, r = px - b * hw;
+        const float* o = dout + (b * T) * nstride + r * (size_t)ld + c;
+        float sm = accumulate ? din[e] : 0.f;
+        for (int t = 0; t < T; ++t) sm += o[(size_t)t * nstride];
+        din[e] = sm;
+    }
+}
+void repeat_time_backward_view(hipStream_t s, const TView& dout, float* din, int B, int T, int accumulate) {
+    DL4DS_REQUIRE(dout.d2s <= 1 && dout.N == B * T, "repeat_time: plain gradient view of B * T frames expected");
+    const size_t hw = (size_t)dout.H * dout.W, total = (size_t)B * hw * dout.C;
+    if (total == 0) return;
+    ProfScope pp(s, "repeat_time_bwd", 0.0, 4.0 * (double)total * (1 + T + (accumulate ? 1 : 0)));
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(repeat_time_bwd_view_kernel, dim3(blocks), dim3(256), 0, s, dout.p, din, hw, dout.C, dout.ld, dout.nstride, T, total,
+                       accumulate);
     HIP_CHECK(hipGetLastError());
 }
 void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, int T, size_t ps, int accumulate) {

@@ -567,6 +567,26 @@ struct ConcatOp : GOp {
         return v;
     }
     void forward(Graph& g, int B, bool) override {
+        // two or more dense inputs that need a copy into a dense output: one pass that writes the wide tensor contiguously
+        {
+            const TView wide = g.view(out, B, false);
+            ConcatSlice sl[4];
+            int n = 0, off = 0;
+            bool ok = wide.d2s <= 1 && wide.ld == wide.C && wide.nstride == (size_t)wide.H * wide.W * wide.C && !getenv("DL4DS_NO_CONCAT_JOIN");
+            for (size_t k = 0; k < ins.size() && ok; ++k) {
+                const GTensor& ti = g.tensors[ins[k]];
+                if (ti.alias_parent != out) {
+                    const TView d = g.view(ins[k], B, false);
+                    ok = n < 4 && d.d2s <= 1 && d.ld == d.C && d.nstride == (size_t)d.H * d.W * d.C && !d.sc;
+                    if (ok) sl[n++] = ConcatSlice{d.p, nullptr, off, ti.C, 0};
+                }
+                off += ti.C;
+            }
+            if (ok && n >= 2) {
+                concat_join(g.stream, wide.p, wide.ld, (size_t)wide.N * wide.H * wide.W, sl, n);
+                return;
+            }
+        }
         for (size_t k = 0; k < ins.size(); ++k) {
             if (g.tensors[ins[k]].alias_parent == out) continue;     // its producer wrote it here already
             view_axpy(g.stream, g.view(ins[k], B, false), slice(g, B, false, (int)k, 0, -1), 1.f, 0);
@@ -864,6 +884,7 @@ struct ResizeOp : GOp {
 struct LocalConvOp : GOp {
     int in, out, w, b;
     LocalConvOp() { kind = "localconv"; }
+    int alias_output() const override { return out; }      // stores through a view: may live inside the Concatenate that follows
     void forward(Graph& g, int B, bool) override {
         localconv_forward(g.stream, g.view(in, B, false), g.wp(w), b >= 0 ? g.wp(b) : nullptr, g.view(out, B, false));
     }
@@ -887,7 +908,13 @@ struct LocalConvOp : GOp {
 struct RepeatTimeOp : GOp {
     int in, out, T;
     RepeatTimeOp() { kind = "repeat_time"; }
+    int alias_output() const override { return out; }
     void forward(Graph& g, int B, bool) override {
+        if (g.tensors[out].alias_of >= 0) {                  // straight into the Concatenate's buffer
+            DL4DS_REQUIRE(g.tensors[in].alias_of < 0, "repeat_time: dense input expected");
+            repeat_time_forward_view(g.stream, g.tensors[in].data, g.view(out, B, false), B, T);
+            return;
+        }
         repeat_time_forward(g.stream, g.tensors[in].data, g.tensors[out].data, B, T, g.tensors[in].per_sample());
     }
     void backward(Graph& g, const BwdCtx& c) override {
@@ -895,8 +922,11 @@ struct RepeatTimeOp : GOp {
         const GTensor& ti = g.tensors[in];
         const size_t ps = ti.per_sample();
         const int cnt = c.b_cnt < 0 ? c.B : c.b_cnt;
-        repeat_time_backward(g.stream, g.tensors[out].grad + (size_t)c.b_off * T * ps, ti.grad + (size_t)c.b_off * ps, cnt, T, ps,
-                             ti.grad_written);
+        if (g.tensors[out].galias)           // the gradient is a channel slice of the Concatenate's
+            repeat_time_backward_view(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt), ti.grad + (size_t)c.b_off * ps, cnt, T, ti.grad_written);
+        else
+            repeat_time_backward(g.stream, g.tensors[out].grad + (size_t)c.b_off * T * ps, ti.grad + (size_t)c.b_off * ps, cnt, T, ps,
+                                 ti.grad_written);
         g.tensors[in].grad_written = true;
     }
 };
@@ -948,6 +978,10 @@ int g_chatt(Graph& g, int in, int w1, int b1, int w2, int b2, int Cr, int mode5d
     op->in = in; op->out = out; op->w1 = w1; op->b1 = b1; op->w2 = w2; op->b2 = b2; op->Cr = Cr; op->T5 = mode5d_T;
     op->pids = {w1, b1, w2, b2};
     g.tensors[in].n_other++;
+    // out = in * scale with scale = sigmoid(..) > 0: behind a ReLU the output is >= 0 and zero exactly where the ReLU's own
+    // backward mask is zero, and d(scale) = sum(dout * in) has no term there either -- so a consumer that zeroes d(out) where
+    // out <= 0 (a Concatenate's gradient alias, plan_grad_aliases) changes nothing.  The flag only says that much.
+    g.tensors[out].relu_out = ti.relu_out;
     return out;
 }
 
@@ -1030,6 +1064,7 @@ int g_repeat_time(Graph& g, int in, int T) {
     RepeatTimeOp* op = push<RepeatTimeOp>(g);
     op->in = in; op->out = out; op->T = T;
     g.tensors[in].n_other++;
+    g.tensors[out].relu_out = ti.relu_out;       // (T copies of a ReLU output; its gradient is their sum, masked by the producer)
     return out;
 }
 
@@ -1050,7 +1085,10 @@ static void plan_concat_aliases(Graph& g) {
         } else if (ConcatOp* k = dynamic_cast<ConcatOp*>(up.get())) {
             producer_ok[k->out] = 1;
         } else if (up->alias_output() >= 0) {
-            producer_ok[up->alias_output()] = 1;                  // (Conv2DTranspose: stores through a depth_to_space view)
+            // Conv2DTranspose stores through a depth_to_space view; LocalizedConvBlock and the time repeat store through plain
+            // views of any channel count / offset (2 = no alignment rule: cfg4's 16 + 8 + 2-channel concatenation)
+            const bool any_align = std::string(up->kind) == "localconv" || std::string(up->kind) == "repeat_time";
+            producer_ok[up->alias_output()] = (any_align && !getenv("DL4DS_NO_SLICE_WRITERS")) ? 2 : (any_align ? 0 : 1);
         }
     }
     auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
@@ -1059,12 +1097,17 @@ static void plan_concat_aliases(Graph& g) {
         ConcatOp* k = dynamic_cast<ConcatOp*>(up.get());
         if (!k) continue;
         int off = 0;
+        // a pixel of the concatenation should be whole 32-byte sectors: with 26 channels (104 bytes) no slice is sector-aligned
+        // and every producer that stores into it writes partial sectors (cfg4: the 16-channel convolution 519 instead of 302 us,
+        // the 8-channel time repeat 394 instead of 69, LocalizedConvBlock 319 instead of 72).  Such a concatenation keeps its own
+        // buffer and is written in one pass (concat_join); its inputs may still be concatenations with aligned pixels.
+        const bool pitch_ok = (g.tensors[k->out].C & 7) == 0 || getenv("DL4DS_ALIAS_ANY_PITCH") != nullptr;
         for (int t : k->ins) {
             GTensor& ti = g.tensors[t];
-            const bool ok = producer_ok[t] && !ti.is_input && !is_output(t) && ti.alias_of < 0 && ti.n_add_in == 0 &&
+            const bool ok = pitch_ok && producer_ok[t] && !ti.is_input && !is_output(t) && ti.alias_of < 0 && ti.n_add_in == 0 &&
                             ti.n_other == 0 && ti.n_concat_in == 1 && ti.n_masking == 1 + ti.n_pool_in + ti.n_convt_in &&
                             ti.n_conv_in == conv_readers[t] &&
-                            (off & 3) == 0 && (ti.C & 3) == 0;
+                            (producer_ok[t] == 2 || ((off & 3) == 0 && (ti.C & 3) == 0));
             if (ok) { ti.alias_of = k->out; ti.alias_parent = k->out; ti.alias_coff = off; }
             off += ti.C;
         }
@@ -1103,6 +1146,9 @@ static void plan_grad_aliases(Graph& g) {
         for (int t : k->ins) {
             const GTensor& ti = g.tensors[t];
             ok = ok && ti.alias_parent == k->out && ti.alias_of == k->out && ti.requires_grad && !ti.is_input;
+            // (slices that are not whole channel quads -- LocalizedConvBlock's two channels behind 24 -- keep their dense gradients:
+            //  with the 26-channel gradient aliased the 2 -> 24 1x1 dgrad into its 24-channel slice leaves conv_point, +0.64 ms)
+            ok = ok && (ti.C & 3) == 0 && (ti.alias_coff & 3) == 0;
             any_masked |= ti.grad_masked;
             all_relu = all_relu && ti.relu_out;
         }

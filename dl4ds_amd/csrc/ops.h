@@ -81,6 +81,8 @@ void view_axpy_masked(hipStream_t s, const TView& src, const TView& mask, const 
 // Concatenate backward in one pass over the wide gradient (elementwise.hip): slice k = channels [off, off + C) -> dense dst (+ mask)
 struct ConcatSlice { float* dst; const float* mask; int off, C, accumulate; };
 void concat_split(hipStream_t s, const float* src, int ld, size_t npx, const ConcatSlice* slices, int n);
+// the mirror, Concatenate forward in one pass: slices[k].dst is read as the dense input k (mask / accumulate unused)
+void concat_join(hipStream_t s, float* dst, int ld, size_t npx, const ConcatSlice* slices, int n);
 // dst (+)= dy * [y > 0]  (flat, contiguous)
 void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate);
 // out = act(a + b)
@@ -183,7 +185,9 @@ void batch_prepare_taps(hipStream_t s, const float* hr, const float* pred, const
                         int P, int S, int T, int B, int scale, int psy, int psx, int pin, int static_in_lr,
                         const TapAxis* dn_patch, const TapAxis* dn_field, const TapAxis* up_field);
 void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int T, size_t ps);
+void repeat_time_forward_view(hipStream_t s, const float* in, const TView& out, int B, int T);     // out: (B*T, H, W, C) view, any pixel pitch
 void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, int T, size_t ps, int accumulate);
+void repeat_time_backward_view(hipStream_t s, const TView& dout, float* din, int B, int T, int accumulate);   // dout: slice view
 void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx,
                           int ky, int kx);   // [out][k] taps per axis
 void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
