@@ -1052,7 +1052,11 @@ bool narrow16_ws_ok(const ConvParams& p) {
     auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
     static const bool no_ragged = getenv("DL4DS_NO_NARROW16_WS_RAGGED") != nullptr;      // (A/B)
     if (off || p.pool || p.in.sc || p.in.d2s > 1) return false;
-    if (p.Cin <= 8) return false;          // (conv_narrow_kernel<8> issues half the MFMAs there; measured on 8 -> 13 at 128 x 256^2: 0.54 ms there, 0.59 here)
+    // <= 8 input channels with 9..16 outputs (8 -> 13: the dgrad of ConvBlock_att's first layer in the recurrent nets) come here too
+    // since the epilogue forms are compiled in: conv_narrow_kernel<8> issues half the MFMAs but 0.53 ms at 128 x 256^2 against
+    // 0.35 here (first half of round 3, run-time epilogue: 0.54 there, 0.59 here).  DL4DS_NARROW16_NO_SMALL_CIN=1 for A/B.
+    static const bool no_small_cin = getenv("DL4DS_NARROW16_NO_SMALL_CIN") != nullptr;
+    if (p.Cin <= 8 && no_small_cin) return false;
     if ((!p.in.vec || (p.Cin & 3)) && no_ragged) return false;
     if ((((uintptr_t)p.in.p) & 3) != 0) return false;
     // outputs (and the epilogue's operands, which share the output's layout) in a channel slice of a wider buffer -- pixel pitch
