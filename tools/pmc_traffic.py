@@ -21,6 +21,9 @@ def tag_of(k):
         return k[:60]
     args = m.group(2).replace(' ', '').split(',')
     name = m.group(1)
+    if name.startswith('conv_narrow_pair_ws') or name.startswith('conv_narrow16_ws'):
+        args = args[:1]                      # <NR> (the compiled epilogue form is not part of bench.py's tag)
+    name = name.replace('conv_direct2', 'conv_direct')      # both generations of the stencil kernels share bench.py's tag
     if name.startswith('conv_wino_kernel'):
         args = args[:2]                      # <KQ,NT> (the epilogue form is not part of bench.py's tag)
     if name.startswith('conv_point'):
