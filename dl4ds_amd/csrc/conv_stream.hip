@@ -900,7 +900,10 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
         sp.per_xcd = cdiv(sp.ntiles, 8);
         const char* force = getenv("DL4DS_STREAM_FORCE_WS");       // (tests: "<workgroups per XCD>", small grids too)
         const int SX = force ? std::max(atoi(force), 1) : std::max(cu_count() / 8, 1);
-        if (!force && (long)sp.per_xcd * sp.nblk < 2l * SX) return false;          // fewer than two items per workgroup: nothing to overlap
+        // at least one item per workgroup (two until round 3: "nothing to overlap" -- but the LDS-staged kernel these layers fell back to
+        // is slower still: cfg5 568 -> 580 samples/s with 1, 581 with 0.5, 575 with 0.25; DL4DS_STREAM_MIN_ITEMS=<f> for A/B)
+        static const double min_items = getenv("DL4DS_STREAM_MIN_ITEMS") ? atof(getenv("DL4DS_STREAM_MIN_ITEMS")) : 1.0;
+        if (!force && (double)sp.per_xcd * sp.nblk < min_items * SX) return false;
         sp.cw = p.Cout;
         if (p.Cout % NT) {
             sp.cw = sp.nblk * 16 * NT;
