@@ -477,6 +477,7 @@ int dl4ds_graph_input_requires_grad(dl4ds_graph* g, int tid) {
     GTensor& t = g->g.tensors.at(tid);
     DL4DS_REQUIRE(t.is_input, "not an input tensor");
     t.requires_grad = true;
+    t.dep_grad_input = true;
     API_END
 }
 int dl4ds_graph_param(dl4ds_graph* g, size_t n, int* pid) {

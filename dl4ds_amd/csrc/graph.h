@@ -17,6 +17,7 @@ struct GTensor {
     int nmul = 1;              // batch multiplier: N = B * nmul (time_window for TimeDistributed tensors)
     bool requires_grad = true;
     bool is_input = false;
+    bool dep_grad_input = false;   // depends (transitively) on an input tensor that takes a gradient (set by the op constructors)
     float* data = nullptr;
     float* grad = nullptr;
     bool grad_written = false;

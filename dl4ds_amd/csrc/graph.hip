@@ -238,7 +238,9 @@ namespace {
 
 inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
     const GTensor& t = g.tensors[tid];
-    return t.requires_grad && (!t.is_input || c.input_grads);
+    // (a pass without parameter gradients -- the generator's adversarial gradient through the discriminator -- only needs the
+    //  tensors that depend on an input that takes a gradient: the conditioning branch of the discriminator is skipped)
+    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || getenv("DL4DS_NO_BWD_PRUNE") != nullptr);
 }
 
 // ChannelAttention2D between two convolutions (ConvBlock(attention=True) followed by another conv: blocks.py:87-103,
@@ -965,6 +967,7 @@ int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu
     if (add >= 0) { g.tensors[add].n_other++; g.tensors[add].n_fused_add++; }
     op->d2s = d2s;
     g.tensors[out].relu_out = relu != 0;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input || (add >= 0 && g.tensors[add].dep_grad_input);
     return out;
 }
 
@@ -982,6 +985,7 @@ int g_chatt(Graph& g, int in, int w1, int b1, int w2, int b2, int Cr, int mode5d
     // backward mask is zero, and d(scale) = sum(dout * in) has no term there either -- so a consumer that zeroes d(out) where
     // out <= 0 (a Concatenate's gradient alias, plan_grad_aliases) changes nothing.  The flag only says that much.
     g.tensors[out].relu_out = ti.relu_out;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -1000,6 +1004,7 @@ int g_concat(Graph& g, const int* ins, int n) {
     op->ins.assign(ins, ins + n);
     op->out = out;
     for (int i = 0; i < n; ++i) { g.tensors[ins[i]].n_masking++; g.tensors[ins[i]].n_concat_in++; }
+    for (int i = 0; i < n; ++i) g.tensors[out].dep_grad_input = g.tensors[out].dep_grad_input || g.tensors[ins[i]].dep_grad_input;
     return out;
 }
 
@@ -1011,6 +1016,7 @@ int g_add(Graph& g, int a, int b, int relu) {
     op->a = a; op->b = b; op->out = out; op->relu = relu;
     g.tensors[a].n_add_in++;
     g.tensors[b].n_add_in++;
+    g.tensors[out].dep_grad_input = g.tensors[a].dep_grad_input || g.tensors[b].dep_grad_input;
     return out;
 }
 
@@ -1020,6 +1026,7 @@ int g_act(Graph& g, int in, int kind) {
     ActOp* op = push<ActOp>(g);
     op->in = in; op->out = out; op->act = kind;
     g.tensors[in].n_other++;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -1031,6 +1038,7 @@ int g_maxpool2(Graph& g, int in) {
     op->in = in; op->out = out;
     g.tensors[in].n_masking++;
     g.tensors[in].n_pool_in++;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -1042,6 +1050,7 @@ int g_resize(Graph& g, int in, int Ho, int Wo, int nearest) {
     op->in = in; op->out = out; op->method = nearest; op->nearest = nearest == 1;
     op->bicubic = nearest >= 2 || (nearest == 0 && !getenv("DL4DS_RESIZE_BILINEAR_DIRECT"));     // table-driven
     g.tensors[in].n_other++;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -1054,6 +1063,7 @@ int g_localconv(Graph& g, int in, int w, int b, int F) {
     op->in = in; op->out = out; op->w = w; op->b = b;
     op->pids = {w, b};
     g.tensors[in].n_other++;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -1065,6 +1075,7 @@ int g_repeat_time(Graph& g, int in, int T) {
     op->in = in; op->out = out; op->T = T;
     g.tensors[in].n_other++;
     g.tensors[out].relu_out = ti.relu_out;       // (T copies of a ReLU output; its gradient is their sum, masked by the producer)
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 

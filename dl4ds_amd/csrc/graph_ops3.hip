@@ -9,7 +9,7 @@ namespace {
 
 inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
     const GTensor& t = g.tensors[tid];
-    return t.requires_grad && (!t.is_input || c.input_grads);
+    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || getenv("DL4DS_NO_BWD_PRUNE") != nullptr);
 }
 
 // ============================================================================================ LayerNorm / BatchNorm
@@ -439,6 +439,7 @@ int g_conv2d_folded(Graph& g, int in, int w1, int b1, int w2, int b2, int KS, in
     op->pids = {w1, b1, w2, b2};
     g.tensors[in].n_conv_in++;
     if (aux >= 0) g.tensors[aux].n_other++;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input || (aux >= 0 && g.tensors[aux].dep_grad_input);
     return out;
 }
 
@@ -450,6 +451,7 @@ int g_pad(Graph& g, int in, int Ho, int Wo) {
     g.ops.emplace_back(op);
     op->in = in; op->out = out;
     g.tensors[in].n_other++;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -464,6 +466,7 @@ int g_dwconv(Graph& g, int in, int w, int b, int KS) {
     op->in = in; op->out = out; op->w = w; op->b = b; op->KS = KS;
     g.tensors[in].n_other++;
     op->pids = b >= 0 ? std::vector<int>{w, b} : std::vector<int>{w};
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -476,6 +479,7 @@ int g_slice(Graph& g, int in, int oy, int ox, int step, int Ho, int Wo) {
     g.ops.emplace_back(op);
     op->in = in; op->out = out; op->oy = oy; op->ox = ox; op->step = step;
     g.tensors[in].n_other++;
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
 
@@ -493,5 +497,6 @@ int g_norm(Graph& g, int in, int gamma, int beta, int mov_mean, int mov_var, int
     if (batch) { op->mov_mean = mov_mean; op->mov_var = mov_var; }
     g.tensors[in].n_other++;
     op->pids = batch ? std::vector<int>{gamma, beta, mov_mean, mov_var} : std::vector<int>{gamma, beta};
+    g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
