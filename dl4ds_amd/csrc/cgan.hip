@@ -25,6 +25,7 @@ struct CganTrainer {
     size_t hr_floats = 0;
     float* loss_ws = nullptr;
     size_t loss_ws_bytes = 0;
+    int shared_plan = -1;          // discriminator: conditioning branch evaluated once for [real ; fake] (-1: not decided yet)
 };
 
 CganTrainer* cgan_create(Graph* gen, Graph* disc, int px_loss_kind, float lr, float beta1, float lam) {
@@ -111,6 +112,9 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
             if (D.ops[i].get() == dop) n = dop->saved_floats_per_sample(D) * 2 * B;
         dop->set_mask(D, dropout_keep_host, n);
     }
+    // the conditioning branch sees the same array in both halves: evaluated once (Graph::plan_shared; decided per graph, once)
+    if (t.shared_plan < 0) t.shared_plan = D.plan_shared({D.inputs[0]}) ? 1 : 0;
+    D.shared_groups = t.shared_plan == 1 ? 2 : 1;
     D.forward(2 * B, true);
     GTensor& dout = D.tensors[D.outputs[0]];
     DL4DS_REQUIRE(dout.per_sample() == 1, "discriminator must output one probability per sample");
@@ -140,6 +144,7 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
         BwdCtx c2{2 * B, 0, 2 * B, false, true};
         D.backward(c2);
     }
+    D.shared_groups = 1;
     // ---- generator backward: lambda * dpx/dgen + dgan/dgen
     G.zero_grad_flags();
     loss_forward_backward(s, t.px_kind, t.hr, go.data, go.grad, B * go.nmul, go.H, go.W, go.C, t.lam, t.d_losses + 1, 0,

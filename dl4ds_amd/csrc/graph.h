@@ -67,6 +67,8 @@ struct GOp {
     virtual size_t saved_floats_per_sample(Graph& g) { return 0; }   // op-private saved activations
     float* saved = nullptr;
     std::vector<int> pids;     // parameters this op reads (set by the op constructors; drives gradient bucketing)
+    std::vector<int> in_tids;  // tensors this op reads (negative entries: absent optional operands) and the one it writes
+    int out_tid = -1;
     virtual void on_finalize(Graph& g) {}
     virtual void on_prepare(Graph& g) {}      // after (re)allocation of the activation / gradient buffers
     virtual bool partial_batch_ok() const { return true; }   // backward over a sample sub-range (BwdCtx::b_off / b_cnt)
@@ -132,6 +134,16 @@ struct Graph {
     void (*grad_ready)(void* ctx, float* grads, size_t n, hipStream_t stream, hipStream_t aux) = nullptr;
     void* grad_ready_ctx = nullptr;
     void plan_buckets(size_t target_bytes);
+    // Shared sub-graph of a batch that is `groups` copies of the SAME samples on some inputs (CGAN: the discriminator sees
+    // [real ; fake], and its conditioning branch gets the same array in both halves -- the reference's two discriminator calls
+    // evaluate that branch twice on identical data, cgan.py:598-599).  Ops whose inputs all descend from such inputs run on the
+    // first B / groups samples only; a tensor they hand to the rest of the graph is copied to the other groups in forward, its
+    // gradient groups are summed into the first before the shared producer's backward (the branch is linear in its output
+    // gradient and its ReLU masks are the same in every group, so back-propagating the sum once is the sum of the groups'
+    // parameter gradients).  plan_shared() decides; shared_groups > 1 switches it on for the forward / backward calls that follow.
+    std::vector<char> op_shared, t_boundary;
+    int shared_groups = 1;
+    bool plan_shared(const std::vector<int>& dup_inputs);
 
     ~Graph();
     int add_tensor(int H, int W, int C, int nmul, bool requires_grad, bool is_input);

@@ -172,10 +172,68 @@ TView Graph::view(int tid, int B, bool grad, int b_off, int b_cnt) const {
     return make_view(base + (size_t)b_off * t.per_sample(), cnt * t.nmul, t.H, t.W, t.C);
 }
 
+bool Graph::plan_shared(const std::vector<int>& dup_inputs) {
+    op_shared.assign(ops.size(), 0);
+    t_boundary.assign(tensors.size(), 0);
+    auto fail = [&]() { op_shared.clear(); t_boundary.clear(); return false; };
+    if (getenv("DL4DS_NO_SHARED_BRANCH")) return fail();
+    std::vector<char> tdup(tensors.size(), 0);
+    for (int t : dup_inputs) {
+        if (tensors.at(t).requires_grad) return fail();
+        tdup[t] = 1;
+    }
+    bool any_shared = false;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        GOp* op = ops[i].get();
+        if (op->out_tid < 0) return fail();
+        bool all = true, any = false;
+        for (int t : op->in_tids) {
+            if (t < 0) continue;
+            any = true;
+            all = all && tdup[t];
+        }
+        if (!(all && any)) continue;
+        // per-sample ops without batch statistics, noise or cross-sample state only
+        const std::string k = op->kind;
+        const bool plain = k == "conv2d" || k == "add" || k == "act" || k == "concat" || k == "maxpool2" || k == "pad" || k == "slice";
+        if (!plain || !op->partial_batch_ok()) return fail();
+        op_shared[i] = 1;
+        tdup[op->out_tid] = 1;
+        any_shared = true;
+    }
+    if (!any_shared) return fail();
+    for (int o : outputs) if (tdup[o]) return fail();
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (op_shared[i]) continue;
+        for (int t : ops[i]->in_tids)
+            if (t >= 0 && tdup[t] && !tensors[t].is_input) t_boundary[t] = 1;
+    }
+    // a tensor handed over to the rest of the graph must not be read inside the shared part as well (its gradient groups are
+    // summed right before its producer's backward: a shared reader would have written one group only)
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (!op_shared[i]) continue;
+        for (int t : ops[i]->in_tids)
+            if (t >= 0 && t_boundary[t]) return fail();
+    }
+    return true;
+}
+
 void Graph::forward(int B, bool training) {
     prepare(B);
     wt_fresh = false;          // the filters may have been updated since the last backward pass
-    for (auto& op : ops) op->forward(*this, B, training);
+    const bool sh = shared_groups > 1 && !op_shared.empty() && B % shared_groups == 0;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        GOp* op = ops[i].get();
+        if (sh && op_shared[i]) {
+            const int Bh = B / shared_groups;
+            op->forward(*this, Bh, training);
+            if (t_boundary[op->out_tid])
+                for (int gi = 1; gi < shared_groups; ++gi)
+                    view_axpy(stream, view(op->out_tid, B, false, 0, Bh), view(op->out_tid, B, false, gi * Bh, Bh), 1.f, 0);
+        } else {
+            op->forward(*this, B, training);
+        }
+    }
 }
 
 void Graph::refresh_dgrad_weights() {
@@ -221,8 +279,23 @@ void Graph::backward(const BwdCtx& c) {
             sent[k] = 1;
         }
     };
+    const bool sh = shared_groups > 1 && !op_shared.empty() && c.B % shared_groups == 0;
+    const bool whole = c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B);
     for (int i = (int)ops.size() - 1; i >= 0; --i) {
-        ops[i]->backward(*this, c);
+        if (sh && op_shared[i]) {
+            // the shared part takes no input gradient (plan_shared): only a whole-batch pass with parameter gradients enters it
+            if (whole && c.param_grads) {
+                const int t = ops[i]->out_tid, Bh = c.B / shared_groups;
+                if (t_boundary[t] && tensors[t].grad_written)
+                    for (int gi = 1; gi < shared_groups; ++gi)
+                        view_axpy(stream, view(t, c.B, true, gi * Bh, Bh), view(t, c.B, true, 0, Bh), 1.f, 1);
+                BwdCtx ch = c;
+                ch.b_off = 0; ch.b_cnt = Bh;
+                ops[i]->backward(*this, ch);
+            }
+        } else {
+            ops[i]->backward(*this, c);
+        }
         if (bucketed) flush_ready(i);
     }
     join_aux();
@@ -967,6 +1040,7 @@ int g_conv2d(Graph& g, int in, int w, int b, int add, int KS, int Cout, int relu
     if (add >= 0) { g.tensors[add].n_other++; g.tensors[add].n_fused_add++; }
     op->d2s = d2s;
     g.tensors[out].relu_out = relu != 0;
+    op->out_tid = out; op->in_tids = {in, add};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input || (add >= 0 && g.tensors[add].dep_grad_input);
     return out;
 }
@@ -985,6 +1059,7 @@ int g_chatt(Graph& g, int in, int w1, int b1, int w2, int b2, int Cr, int mode5d
     // backward mask is zero, and d(scale) = sum(dout * in) has no term there either -- so a consumer that zeroes d(out) where
     // out <= 0 (a Concatenate's gradient alias, plan_grad_aliases) changes nothing.  The flag only says that much.
     g.tensors[out].relu_out = ti.relu_out;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -1004,6 +1079,7 @@ int g_concat(Graph& g, const int* ins, int n) {
     op->ins.assign(ins, ins + n);
     op->out = out;
     for (int i = 0; i < n; ++i) { g.tensors[ins[i]].n_masking++; g.tensors[ins[i]].n_concat_in++; }
+    op->out_tid = out; op->in_tids.assign(ins, ins + n);
     for (int i = 0; i < n; ++i) g.tensors[out].dep_grad_input = g.tensors[out].dep_grad_input || g.tensors[ins[i]].dep_grad_input;
     return out;
 }
@@ -1016,6 +1092,7 @@ int g_add(Graph& g, int a, int b, int relu) {
     op->a = a; op->b = b; op->out = out; op->relu = relu;
     g.tensors[a].n_add_in++;
     g.tensors[b].n_add_in++;
+    op->out_tid = out; op->in_tids = {a, b};
     g.tensors[out].dep_grad_input = g.tensors[a].dep_grad_input || g.tensors[b].dep_grad_input;
     return out;
 }
@@ -1026,6 +1103,7 @@ int g_act(Graph& g, int in, int kind) {
     ActOp* op = push<ActOp>(g);
     op->in = in; op->out = out; op->act = kind;
     g.tensors[in].n_other++;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -1038,6 +1116,7 @@ int g_maxpool2(Graph& g, int in) {
     op->in = in; op->out = out;
     g.tensors[in].n_masking++;
     g.tensors[in].n_pool_in++;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -1050,6 +1129,7 @@ int g_resize(Graph& g, int in, int Ho, int Wo, int nearest) {
     op->in = in; op->out = out; op->method = nearest; op->nearest = nearest == 1;
     op->bicubic = nearest >= 2 || (nearest == 0 && !getenv("DL4DS_RESIZE_BILINEAR_DIRECT"));     // table-driven
     g.tensors[in].n_other++;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -1063,6 +1143,7 @@ int g_localconv(Graph& g, int in, int w, int b, int F) {
     op->in = in; op->out = out; op->w = w; op->b = b;
     op->pids = {w, b};
     g.tensors[in].n_other++;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -1075,6 +1156,7 @@ int g_repeat_time(Graph& g, int in, int T) {
     op->in = in; op->out = out; op->T = T;
     g.tensors[in].n_other++;
     g.tensors[out].relu_out = ti.relu_out;       // (T copies of a ReLU output; its gradient is their sum, masked by the producer)
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }

@@ -346,6 +346,7 @@ int g_conv2d_transpose(Graph& g, int in, int w, int KS, int stride, int Cout, in
     g.tensors[in].n_convt_in++;
     g.tensors[out].relu_out = relu != 0;
     op->pids = {w};
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -362,6 +363,7 @@ int g_convlstm(Graph& g, int in, int wk, int wr, int b, int KS, int F, int T, in
     op->in = in; op->out = out; op->wk = wk; op->wr = wr; op->b = b; op->KS = KS; op->F = F; op->T = T; op->relu = relu;
     g.tensors[in].n_other++;
     op->pids = {wk, wr, b};
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -372,6 +374,7 @@ int g_gap(Graph& g, int in, int over_time) {
     GapOp* op = push<GapOp>(g);
     op->in = in; op->out = out; op->over_time = over_time != 0;
     g.tensors[in].n_other++;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -386,6 +389,7 @@ int g_dense(Graph& g, int in, int w, int b, int F, int act) {
     op->in = in; op->out = out; op->w = w; op->b = b; op->F = F; op->act = act;
     g.tensors[in].n_other++;
     op->pids = {w, b};
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -400,6 +404,7 @@ int g_dropout(Graph& g, int in, float rate, int variant, int mc, int spatial_dim
     op->seed += 0x9E3779B97F4A7C15ull * (g.dropout_ops.size() + 1);
     g.tensors[in].n_other++;
     g.dropout_ops.push_back(op);
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }

@@ -439,6 +439,7 @@ int g_conv2d_folded(Graph& g, int in, int w1, int b1, int w2, int b2, int KS, in
     op->pids = {w1, b1, w2, b2};
     g.tensors[in].n_conv_in++;
     if (aux >= 0) g.tensors[aux].n_other++;
+    op->out_tid = out; op->in_tids = {in, aux};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input || (aux >= 0 && g.tensors[aux].dep_grad_input);
     return out;
 }
@@ -451,6 +452,7 @@ int g_pad(Graph& g, int in, int Ho, int Wo) {
     g.ops.emplace_back(op);
     op->in = in; op->out = out;
     g.tensors[in].n_other++;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -466,6 +468,7 @@ int g_dwconv(Graph& g, int in, int w, int b, int KS) {
     op->in = in; op->out = out; op->w = w; op->b = b; op->KS = KS;
     g.tensors[in].n_other++;
     op->pids = b >= 0 ? std::vector<int>{w, b} : std::vector<int>{w};
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -479,6 +482,7 @@ int g_slice(Graph& g, int in, int oy, int ox, int step, int Ho, int Wo) {
     g.ops.emplace_back(op);
     op->in = in; op->out = out; op->oy = oy; op->ox = ox; op->step = step;
     g.tensors[in].n_other++;
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
@@ -497,6 +501,7 @@ int g_norm(Graph& g, int in, int gamma, int beta, int mov_mean, int mov_var, int
     if (batch) { op->mov_mean = mov_mean; op->mov_var = mov_var; }
     g.tensors[in].n_other++;
     op->pids = batch ? std::vector<int>{gamma, beta, mov_mean, mov_var} : std::vector<int>{gamma, beta};
+    op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;
 }
