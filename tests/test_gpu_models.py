@@ -366,6 +366,41 @@ def test_cgan_step_matches_oracle():
             assert np.abs((w[k] - P0[k]) - (Pt[k].detach().numpy() - P0[k])).max() < 0.2 * 2e-4 + 1e-7, k
 
 
+def test_cgan_shared_conditioning_branch_equals_two_evaluations(monkeypatch):
+    """The discriminator sees [real ; fake] with the SAME conditioning array in both halves; its conditioning branch is evaluated
+    once (Graph::plan_shared, csrc/graph.hip), the hand-over tensor copied to the second half and its gradient halves summed
+    before the branch's backward.  Against the same step with the branch evaluated on both halves (DL4DS_NO_SHARED_BRANCH=1:
+    what the reference's two discriminator calls do, cgan.py:598-599): losses and every gradient of both models."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import CGANEngine
+    B, H = 3, 24
+    rng = np.random.default_rng(21)
+    lr = rng.random((B, H, H, 3)).astype(np.float32)
+    st = rng.random((B, H, H, 1)).astype(np.float32)
+    hr = rng.random((B, H, H, 1)).astype(np.float32)
+    mask = (rng.random((2 * B, 8)) > 0.4).astype(np.float32)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('DL4DS_NO_SHARED_BRANCH', '1')
+        else:
+            monkeypatch.delenv('DL4DS_NO_SHARED_BRANCH', raising=False)
+        gen = PM.unet_pin('unet', 3, 1, hr_size=(H, H), seed=3, n_filters=4, n_blocks=2, decoder_upsampling='dc')
+        disc = PM.residual_discriminator(3, 'pin', False, 8, (H // 8, H // 8), n_filters=4, n_res_blocks=2, hr_size=(H, H), seed=4)
+        eng = CGANEngine(gen, disc, loss='mae', learning_rate=2e-4, beta_1=0.5)
+        out = eng.step([lr, st], hr, dropout_keep=mask)
+        res.append((out, gen.get_gradients(), disc.get_gradients()))
+    (o0, g0, d0), (o1, g1, d1) = res
+    for a, b in zip(o0, o1):
+        assert a == pytest.approx(b, rel=1e-5)
+    for name, (x, y) in [('G', (g0, g1)), ('D', (d0, d1))]:
+        for k in x:
+            scale = max(np.abs(y[k]).max(), 1e-12)
+            assert np.abs(x[k] - y[k]).max() <= 2e-5 * scale + 1e-9, (name, k)
+    # the branch's weight gradients are sums over a different association of the two halves: close, not identical
+    assert any(not np.array_equal(d0[k], d1[k]) for k in d0 if 'branch1' in k)
+
+
 CGAN_CASES = [
     # generator kind, generator cfg, discriminator cfg (oracle), LR grid, scale, time window
     ('net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4, n_blocks=1, n_filters=4),
