@@ -6,10 +6,41 @@
 //   pass 1: dL_D/dp on all 2B rows  -> D parameter gradients (no input gradients)
 //   pass 2: dL_G,gan/dp on the fake half only -> gradient w.r.t. D's HR input = dL/d(generated), no D parameter grads
 // and the generator back-propagates lambda * dpx/dgen + (pass-2 result).
+// Round 3: the conditioning branch is evaluated once for both halves (Graph::plan_shared) and pass 2 is replaced by a per-sample
+// rescaling of pass 1's gradients at D's HR input layer (cgan_ratio_kernel below) where D has no batch statistics.
 #include "graph.h"
 #include "runtime.h"
 #include "dist.h"
 #include <cmath>
+
+// Pass 2 without a second backward pass (round 3).  D is per-sample independent (no batch statistics), its output is one
+// probability p_i per sample, and back-propagation is linear in the output gradient: for a fake sample i every gradient pass 1
+// left inside D is u1_i * (dp_i / d.) with u1_i = dBCE(p_i, 0)/dp, and pass 2 wants u2_i * (dp_i / d.) with u2_i = dBCE(p_i, 1)/dp.
+// Both are zero exactly where Keras' clip(p, eps, 1 - eps) cuts the gradient, elsewhere u2_i / u1_i = -(1 - p_i) / p_i.  So the
+// output gradient of the op(s) that read D's HR input is scaled per sample by that ratio (0 on the real half) and ONLY those
+// ops back-propagate again (one 8 -> 1 dgrad in residual_discriminator) -- the rest of pass 2 (the HR branch's and the merge
+// block's dgrads for the fake half) is gone.
+__global__ void cgan_ratio_kernel(const float* __restrict__ p_fake, float* __restrict__ r, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * B) return;
+    float v = 0.f;
+    if (i >= B) {
+        const float eps = 1e-7f, pr = p_fake[i - B];
+        if (pr >= eps && pr <= 1.f - eps) { const float pc = fminf(fmaxf(pr, eps), 1.f - eps); v = -(1.f - pc) / pc; }
+    }
+    r[i] = v;
+}
+// v[image n, ...] *= r[n / nmul]  (the frames of one sample share its factor)
+__global__ void scale_samples_kernel(TView v, const float* __restrict__ r, size_t per_img, int nmul, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e / per_img);
+        size_t q = e - (size_t)n * per_img;
+        const int c = (int)(q % v.C); q /= v.C;
+        const int x = (int)(q % v.W);
+        const int y = (int)(q / v.W);
+        v.p[view_off(v, n, y, x, c)] *= r[n / nmul];
+    }
+}
 
 Trainer* trainer_create(Graph* g, int loss_kind, const AdamCfg& cfg);
 void graph_load_inputs(Graph& g, const float* const* inputs, int n_inputs, int B, bool is_host);
@@ -26,6 +57,10 @@ struct CganTrainer {
     float* loss_ws = nullptr;
     size_t loss_ws_bytes = 0;
     int shared_plan = -1;          // discriminator: conditioning branch evaluated once for [real ; fake] (-1: not decided yet)
+    int ratio_plan = -1;           // pass 2 by per-sample rescaling of pass 1's gradients (-1: not decided yet)
+    std::vector<int> ratio_ops;    // ops of D that read its gradient-taking input
+    float* ratio = nullptr;        // [2B] per-sample factors
+    int ratio_n = 0;
 };
 
 CganTrainer* cgan_create(Graph* gen, Graph* disc, int px_loss_kind, float lr, float beta1, float lam) {
@@ -58,6 +93,7 @@ void cgan_destroy(CganTrainer* t) {
     if (t->d_losses) (void)hipFree(t->d_losses);
     if (t->hr) (void)hipFree(t->hr);
     if (t->loss_ws) (void)hipFree(t->loss_ws);
+    if (t->ratio) (void)hipFree(t->ratio);
     delete t;
 }
 Trainer* cgan_disc_trainer(CganTrainer* t) { return t->D; }
@@ -132,9 +168,43 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
     if (apply_update) dist_allreduce_bucket_async(D.G, D.n_params, s, nullptr);
     // ---- pass 2: generator's adversarial loss through D (fake half, inputs only)
     bce_forward_backward(s, p_fake, 1.f, B, 1.f, t.d_losses + 0, dout.grad + B, 0);
+    if (t.ratio_plan < 0) {
+        // eligible: no normalisation ops (BatchNormalization couples the samples of a group), every reader of the HR input known
+        bool ok = getenv("DL4DS_NO_CGAN_RATIO") == nullptr;
+        t.ratio_ops.clear();
+        for (size_t i = 0; i < D.ops.size() && ok; ++i) {
+            GOp* op = D.ops[i].get();
+            if (std::string(op->kind) == "norm") ok = false;
+            bool reads = false;
+            for (int tid : op->in_tids) reads = reads || (tid >= 0 && D.tensors[tid].is_input && D.tensors[tid].requires_grad);
+            if (reads) { ok = ok && op->out_tid >= 0; t.ratio_ops.push_back((int)i); }
+        }
+        t.ratio_plan = (ok && !t.ratio_ops.empty()) ? 1 : 0;
+    }
     bool partial = true;
     for (auto& op : D.ops) partial = partial && op->partial_batch_ok();
-    if (partial) {
+    if (t.ratio_plan == 1) {
+        if (t.ratio_n < 2 * B) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (t.ratio) HIP_CHECK(hipFree(t.ratio));
+            HIP_CHECK(hipMalloc((void**)&t.ratio, (size_t)2 * B * sizeof(float)));
+            t.ratio_n = 2 * B;
+        }
+        hipLaunchKernelGGL(cgan_ratio_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, p_fake, t.ratio, B);
+        HIP_CHECK(hipGetLastError());
+        BwdCtx cr{2 * B, 0, 2 * B, false, true};
+        for (int k = (int)t.ratio_ops.size() - 1; k >= 0; --k) {
+            GOp* op = D.ops[t.ratio_ops[k]].get();
+            const GTensor& to = D.tensors[op->out_tid];
+            if (!to.grad_written) continue;
+            TView gv = D.view(op->out_tid, 2 * B, true);
+            const size_t per_img = (size_t)gv.H * gv.W * gv.C, total = per_img * gv.N;
+            hipLaunchKernelGGL(scale_samples_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, gv, t.ratio,
+                               per_img, to.nmul, total);
+            HIP_CHECK(hipGetLastError());
+            op->backward(D, cr);
+        }
+    } else if (partial) {
         BwdCtx c2{2 * B, B, B, false, true};
         D.backward(c2);
     } else {

@@ -366,11 +366,14 @@ def test_cgan_step_matches_oracle():
             assert np.abs((w[k] - P0[k]) - (Pt[k].detach().numpy() - P0[k])).max() < 0.2 * 2e-4 + 1e-7, k
 
 
-def test_cgan_shared_conditioning_branch_equals_two_evaluations(monkeypatch):
+@pytest.mark.parametrize('switch', ['DL4DS_NO_SHARED_BRANCH', 'DL4DS_NO_CGAN_RATIO'])
+def test_cgan_shared_conditioning_branch_equals_two_evaluations(monkeypatch, switch):
     """The discriminator sees [real ; fake] with the SAME conditioning array in both halves; its conditioning branch is evaluated
     once (Graph::plan_shared, csrc/graph.hip), the hand-over tensor copied to the second half and its gradient halves summed
     before the branch's backward.  Against the same step with the branch evaluated on both halves (DL4DS_NO_SHARED_BRANCH=1:
-    what the reference's two discriminator calls do, cgan.py:598-599): losses and every gradient of both models."""
+    what the reference's two discriminator calls do, cgan.py:598-599): losses and every gradient of both models.
+    DL4DS_NO_CGAN_RATIO: the generator's adversarial gradient by per-sample rescaling of the discriminator-loss pass
+    (csrc/cgan.hip, cgan_ratio_kernel) against the second backward pass through the discriminator it replaces."""
     import dl4ds_amd.models as PM
     from dl4ds_amd.training import CGANEngine
     B, H = 3, 24
@@ -382,9 +385,9 @@ def test_cgan_shared_conditioning_branch_equals_two_evaluations(monkeypatch):
     res = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv('DL4DS_NO_SHARED_BRANCH', '1')
+            monkeypatch.setenv(switch, '1')
         else:
-            monkeypatch.delenv('DL4DS_NO_SHARED_BRANCH', raising=False)
+            monkeypatch.delenv(switch, raising=False)
         gen = PM.unet_pin('unet', 3, 1, hr_size=(H, H), seed=3, n_filters=4, n_blocks=2, decoder_upsampling='dc')
         disc = PM.residual_discriminator(3, 'pin', False, 8, (H // 8, H // 8), n_filters=4, n_res_blocks=2, hr_size=(H, H), seed=4)
         eng = CGANEngine(gen, disc, loss='mae', learning_rate=2e-4, beta_1=0.5)
@@ -398,7 +401,9 @@ def test_cgan_shared_conditioning_branch_equals_two_evaluations(monkeypatch):
             scale = max(np.abs(y[k]).max(), 1e-12)
             assert np.abs(x[k] - y[k]).max() <= 2e-5 * scale + 1e-9, (name, k)
     # the branch's weight gradients are sums over a different association of the two halves: close, not identical
-    assert any(not np.array_equal(d0[k], d1[k]) for k in d0 if 'branch1' in k)
+    changed = d0 if switch == 'DL4DS_NO_SHARED_BRANCH' else g0
+    other = d1 if switch == 'DL4DS_NO_SHARED_BRANCH' else g1
+    assert any(not np.array_equal(changed[k], other[k]) for k in changed)     # (the switch did select another evaluation)
 
 
 CGAN_CASES = [
