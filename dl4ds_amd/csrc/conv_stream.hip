@@ -999,8 +999,11 @@ static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* 
     if (!E) return false;
     int NT = 0;
     long best = -1;
+    // (<= 16 outputs -- the dgrad of a ConvLSTM's 5x5 input kernel, 32 gate channels -> 8: one 16-cout block instead of two,
+    //  half the MFMAs; DL4DS_STREAM5_NO_NT1=1 for A/B)
+    const int nt_lo = (out.C <= 16 && !getenv("DL4DS_STREAM5_NO_NT1")) ? 1 : 2;
     for (int pass = 0; pass < 2 && !NT; ++pass)
-        for (int nt = 2; nt <= 4; ++nt) {
+        for (int nt = nt_lo; nt <= 4; ++nt) {
             // through a depth_to_space store an n-block should not straddle a group (cp channels each); where every choice
             // does (groups of 8 or 16 channels) the kernel's narrow-group form takes the least padded one
             if (pass == 0 && out.d2s > 1 && (16 * nt > out.cp || out.cp % (16 * nt))) continue;
@@ -1015,15 +1018,18 @@ static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* 
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.CK = 4 * E; p.TPS = 0;
     if (E == 8) {
+        if (NT == 1) return launch_stream_ws<5, 8, 1, 4>(s, sp, in.N);
         if (NT == 2) return launch_stream_ws<5, 8, 2, 4>(s, sp, in.N);
         if (NT == 3) return launch_stream_ws<5, 8, 3, 4>(s, sp, in.N);
         return launch_stream_ws<5, 8, 4, 4>(s, sp, in.N);
     }
     if (E == 6) {
+        if (NT == 1) NT = 2;
         if (NT == 2) return launch_stream_ws<5, 6, 2, 4>(s, sp, in.N);
         if (NT == 3) return launch_stream_ws<5, 6, 3, 4>(s, sp, in.N);
         return launch_stream_ws<5, 6, 4, 4>(s, sp, in.N);
     }
+    if (NT == 1) return launch_stream_ws<5, 4, 1, 4>(s, sp, in.N);
     if (NT == 2) return launch_stream_ws<5, 4, 2, 4>(s, sp, in.N);
     if (NT == 3) return launch_stream_ws<5, 4, 3, 4>(s, sp, in.N);
     return launch_stream_ws<5, 4, 4, 4>(s, sp, in.N);

@@ -135,7 +135,7 @@ def test_conv2d_stream_producer_consumer(ops, monkeypatch, sx, n, h, w, ci, co):
 
 
 @pytest.mark.parametrize('sx', ['1', '32'])
-@pytest.mark.parametrize('n,h,w,ci,co', [(2, 33, 20, 32, 64), (1, 40, 40, 64, 128), (3, 16, 16, 24, 48), (2, 20, 36, 48, 32),
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 33, 20, 32, 64), (1, 40, 40, 64, 128), (3, 16, 16, 24, 48), (2, 20, 36, 48, 32), (2, 33, 20, 32, 8), (2, 20, 36, 16, 12),
                                         (1, 32, 32, 128, 96), (2, 17, 17, 32, 40), (2, 24, 33, 16, 32), (1, 16, 16, 80, 48)])
 def test_conv2d_stream_producer_consumer_5x5(ops, monkeypatch, sx, n, h, w, ci, co):
     """... and the 5x5 layers (DeconvolutionBlock's 9x9 stride-2 transposed convolutions run as 5x5 convolutions): 32-channel
