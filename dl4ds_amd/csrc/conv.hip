@@ -1137,8 +1137,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradPara
 // per tile.  With two independent 4-wave workgroups per CU the staging phases were NOT hidden (measured: 1.72 ms as is,
 // 1.26 ms with the loads removed, and no re-ordering of the loads changed the sum) -- here the overlap is by
 // construction and the MFMA waves never issue a global load.
-template <int CIT, int WCO, int KS = 3>
+// PACK (CIT == 1, Cin <= 8: the ConvLSTM kernels of the recurrent nets, 8 -> 32 gate channels): rows 8..15 of the MFMA's first
+// operand would be zero padding; they take the SAME eight input channels one pixel to the right instead, so one MFMA accumulates
+// the taps (ky, kx) and (ky, kx + 1): 3 instead of 5 MFMAs per tap row for 5x5, 2 instead of 3 for 3x3.
+template <int CIT, int WCO, int KS = 3, bool PACK = false>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradParams a) {
+    static_assert(!PACK || CIT == 1, "tap packing: one 16-row block of which eight are channels");
+    constexpr int KXS = PACK ? 2 : 1, NKX = (KS + KXS - 1) / KXS, NACC = KS * NKX;     // tap columns per MFMA, MFMAs per tap row
     constexpr int COT = 1;
     constexpr int TW = 16, TH = 8;
     constexpr int WK = 4 / WCO, RW = TH / WK;            // output rows per wave
@@ -1160,7 +1165,8 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
     const int ci0 = blockIdx.z * CIB;
     const int co0 = blockIdx.y * COB;
 
-    const float* xf0 = smem + ((wk * RW) * TWH + lq * 4) * PX + l15;
+    const float* xf0 = PACK ? smem + ((wk * RW) * TWH + lq * 4 + (l15 >> 3)) * PX + (l15 & 7)
+                            : smem + ((wk * RW) * TWH + lq * 4) * PX + l15;
     const float* zf0 = smem + HPIX * PX + ((wk * RW) * TW + lq * 4) * PZ + wco * 16 + l15;
 
     if (producer) {
@@ -1248,10 +1254,10 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
         }
         return;                                        // (finished waves no longer take part in barriers)
     }
-    f32x4 acc[KK][CIT][COT];
+    f32x4 acc[NACC][CIT][COT];
     float bsum[COT];
 #pragma unroll
-    for (int t = 0; t < KK; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int i = 0; i < CIT; ++i) acc[t][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bsum[0] = 0.f;
@@ -1265,7 +1271,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
         float zr[KS][4];                // dz fragments of the last KS output rows (ring)
 #pragma unroll
         for (int rr = 0; rr < RW + KS - 1; ++rr) {     // input row wk*RW + rr of the halo tile
-            float fx[4 + KS - 1][CIT];
+            float fx[4 + KS - 1][CIT];             // (PACK: the upper half-rows read one pixel further: column c + 1)
 #pragma unroll
             for (int c = 0; c < 4 + KS - 1; ++c)
 #pragma unroll
@@ -1286,11 +1292,11 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int kx = 0; kx < KS; ++kx)
+                        for (int kx = 0; kx < KS; kx += KXS)
 #pragma unroll
                             for (int i = 0; i < CIT; ++i)
-                                acc[ky * KS + kx][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q + kx][i], zr[r % KS][q],
-                                                                                               acc[ky * KS + kx][i][0], 0, 0, 0);
+                                acc[ky * NKX + kx / KXS][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q + kx][i], zr[r % KS][q],
+                                                                                                      acc[ky * NKX + kx / KXS][i][0], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1299,14 +1305,14 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
     }
     // K-split waves: pairwise tree reduction through LDS so the block emits ONE slab
     if (WK > 1) {
-        constexpr int SLOTF = (KK * CIT * COT * 4 + COT) * 64;      // floats per wave image
+        constexpr int SLOTF = (NACC * CIT * COT * 4 + COT) * 64;      // floats per wave image
         for (int half = WK / 2; half >= 1; half >>= 1) {
             __syncthreads();
             if (wk >= half && wk < 2 * half) {
                 float* dst = smem + (size_t)((wk - half) * WCO + wco) * SLOTF + lane;
                 int o = 0;
 #pragma unroll
-                for (int tp = 0; tp < KK; ++tp)
+                for (int tp = 0; tp < NACC; ++tp)
 #pragma unroll
                     for (int i = 0; i < CIT; ++i)
 #pragma unroll
@@ -1318,7 +1324,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
                 const float* src = smem + (size_t)(wk * WCO + wco) * SLOTF + lane;
                 int o = 0;
 #pragma unroll
-                for (int tp = 0; tp < KK; ++tp)
+                for (int tp = 0; tp < NACC; ++tp)
 #pragma unroll
                     for (int i = 0; i < CIT; ++i)
 #pragma unroll
@@ -1332,6 +1338,17 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
     const size_t nw = (size_t)KK * a.Cin * a.Cout;
     float* slab = a.partial + (size_t)blockIdx.x * (nw + a.Cout);
     const int co = co0 + wco * 16 + l15;
+    if constexpr (PACK) {
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kp = 0; kp < NKX; ++kp)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int row = lq * 4 + rg, ci = ci0 + (row & 7), kx = kp * 2 + (row >> 3);
+                    if (co < a.Cout && ci < a.Cin && kx < KS) slab[((size_t)(ky * KS + kx) * a.Cin + ci) * a.Cout + co] = acc[ky * NKX + kp][0][0][rg];
+                }
+    } else {
 #pragma unroll
     for (int tp = 0; tp < KK; ++tp)
 #pragma unroll
@@ -1342,6 +1359,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
                 if (co < a.Cout && ci < a.Cin) slab[((size_t)tp * a.Cin + ci) * a.Cout + co] = acc[tp][i][0][rg];
             }
         }
+    }
     if (blockIdx.z == 0) {
         float v = bsum[0];
         v += __shfl_xor(v, 16, 64);
@@ -1447,6 +1465,10 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     const size_t lds = rows ? std::max((size_t)(ws ? 2 : 1) * (HPIX * (CIB + 4) + 128 * (COB + 4)) * sizeof(float), red_bytes)
                             : std::max((size_t)(PF ? 2 : 1) * (HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
     void (*kern)(const WgradParams) = conv_wgrad_kernel<KS, CIT, COT, WCO, PF>;
+    // <= 8 input channels on the producer / consumer kernel: two taps per MFMA (see the kernel's PACK comment); DL4DS_NO_WGRAD_PACK=1 for A/B
+    static const bool no_pack = getenv("DL4DS_NO_WGRAD_PACK") != nullptr;
+    constexpr bool PACK_OK = ROWS_OK && CIT == 1 && (KS == 3 || KS == 5);
+    const bool pack = PACK_OK && ws && p.Cin <= 8 && !no_pack;
     if constexpr (ROWS_OK) {
         if constexpr (KS == 3) {
             if constexpr (PF) { if (rows) kern = conv_wgrad_rows_ws_kernel<CIT, WCO, 3>; }
@@ -1455,11 +1477,17 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
             if (rows) kern = conv_wgrad_rows_ws_kernel<CIT, WCO, KS>;
         }
     }
+    if constexpr (PACK_OK) {
+        if (pack) kern = conv_wgrad_rows_ws_kernel<1, WCO, KS, true>;
+    }
     static std::once_flag once;
     std::call_once(once, [&]() {
         // 7x7 (ConvNext stem / tail): the cross-wave reduction buffer alone is 100 KB -> one workgroup per CU
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, CIT, COT, WCO, PF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, KS >= 7 ? kLdsMax : kLdsBudget));
+        if constexpr (PACK_OK)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_ws_kernel<1, WCO, KS, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax));
         if constexpr (ROWS_OK) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_ws_kernel<CIT, WCO, KS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax));

@@ -363,6 +363,24 @@ def test_conv2d_dgrad_wgrad(ops, n, h, w, ci, co, ks):
     close(ops.conv2d_wgrad(x, dz, ks), gw)
 
 
+@pytest.mark.parametrize('n,h,w,ci,co,ks', [(3, 20, 37, 8, 32, 5), (2, 17, 16, 8, 32, 3), (2, 33, 18, 4, 48, 3), (1, 40, 40, 6, 20, 5),
+                                            (2, 9, 70, 5, 64, 3), (4, 16, 16, 8, 24, 5)])
+def test_conv2d_wgrad_packed_taps(ops, n, h, w, ci, co, ks):
+    """Weight gradient of layers with <= 8 input channels and more than 16 outputs (the ConvLSTM2D kernels of the recurrent nets,
+    8 -> 32 gate channels, blocks.py:350-355) on conv_wgrad_rows_ws_kernel<1, WCO, KS, PACK>: rows 8..15 of the MFMA's first
+    operand carry the same channels one pixel to the right, so one MFMA accumulates two taps.  Ragged grids, several tiles per
+    workgroup, channel counts below 8, accumulation, bitwise repeatability."""
+    from tests.parity import kernel_tags
+    x, dz = R(n, h, w, ci), R(n, h, w, co)
+    _, gw = _torch_conv_grads(x, R(ks, ks, ci, co), dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_wgrad(x, dz, ks))
+    assert any(t.startswith('conv_wgrad_rows<') for t in tags), tags
+    close(got, gw)
+    base_w = R(*gw.shape)
+    close(ops.conv2d_wgrad(x, dz, ks, accumulate_into=base_w), gw + base_w)
+    np.testing.assert_array_equal(got, ops.conv2d_wgrad(x, dz, ks))
+
+
 @pytest.mark.parametrize('h,w', [(9, 17), (16, 20)])        # 16x20: dgrad through the streamed-filter kernel
 def test_conv2d_grads_through_d2s_and_accumulate(ops, h, w):
     n, ci, co, r = 2, 48, 192, 2
