@@ -514,19 +514,24 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
                 }
             }
         };
-        size_t hosx, hosy;
-        {
-            const int rr = a.out.d2s > 1 ? a.out.d2s : 1;
-            hosx = (size_t)rr * a.out.ld;
-            hosy = (size_t)rr * (size_t)(a.out.W * rr) * a.out.ld;
-        }
+        size_t hosx, hosy, hasx = 0, hasy = 0, hmsx = 0, hmsy = 0;
+        auto strides_of = [](const TView& v, size_t& sx, size_t& sy) {
+            const int rr = v.d2s > 1 ? v.d2s : 1;
+            sx = (size_t)rr * v.ld;
+            sy = (size_t)rr * (size_t)(v.W * rr) * v.ld;
+        };
+        strides_of(a.out, hosx, hosy);
+        if (f_add) strides_of(a.add, hasx, hasy);
+        if (f_mask) strides_of(a.mask, hmsx, hmsy);
         auto describe = [&](int t, unsigned* d) __attribute__((always_inline)) {
             int n, y0, x0;
             origin(t, n, y0, x0);
+            // (every operand through its OWN pixel strides: the output may live inside a Concatenate's buffer -- pixel pitch 16 --
+            //  while the residual operand or the ReLU mask is a dense 8-channel tensor, and the other way round)
             const size_t pb = (size_t)y0 * hosy + (size_t)x0 * hosx;
             const unsigned long long ob = (unsigned long long)(uintptr_t)a.out.p + ((size_t)n * a.out.nstride + pb) * 4;
-            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (f_add ? ((size_t)n * a.add.nstride + pb) * 4 : 0);
-            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (f_mask ? ((size_t)n * a.mask.nstride + pb) * 4 : 0);
+            const unsigned long long ab = (unsigned long long)(uintptr_t)a.add.p + (f_add ? ((size_t)n * a.add.nstride + (size_t)y0 * hasy + (size_t)x0 * hasx) * 4 : 0);
+            const unsigned long long mb = (unsigned long long)(uintptr_t)a.mask.p + (f_mask ? ((size_t)n * a.mask.nstride + (size_t)y0 * hmsy + (size_t)x0 * hmsx) * 4 : 0);
             const int ymax = min(PTH, a.H - y0), xmax = min(PTW, a.W - x0);
             if (tid == 256) {
                 *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)ob, (unsigned)(ob >> 32), (unsigned)ab, (unsigned)(ab >> 32));
@@ -598,12 +603,30 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         osx = (size_t)r * a.out.ld;
         osy = (size_t)r * (size_t)(a.out.W * r) * a.out.ld;
     }
-    int eo[NR], eoff[NR];
+    // per-lane offsets of the four output rows, for the output and -- through their own strides -- for the residual operand and the
+    // mask; recomputed (a handful of multiplications) only when the tile's border signature changes
+    size_t asx = 0, asy = 0, msx = 0, msy = 0;
+    auto strides_of = [](const TView& v, size_t& sx, size_t& sy) {
+        const int rr = v.d2s > 1 ? v.d2s : 1;
+        sx = (size_t)rr * v.ld;
+        sy = (size_t)rr * (size_t)(v.W * rr) * v.ld;
+    };
+    if (f_add) strides_of(a.add, asx, asy);
+    if (f_mask) strides_of(a.mask, msx, msy);
+    const int co_ch = (int)view_chan_off(a.out, c_ok ? ec : 0) * 4;
+    const int ca_ch = f_add ? (int)view_chan_off(a.add, c_ok ? ec : 0) * 4 : 0;
+    const int cm_ch = f_mask ? (int)view_chan_off(a.mask, c_ok ? ec : 0) * 4 : 0;
+    int eoff[NR], aoff[NR], moff[NR];
+    auto set_offsets = [&](int ymax, int xmax) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        eo[i] = c_ok ? (int)(((wave * NR + i) * osy + (2 * l15 + eh) * osx + view_chan_off(a.out, c_ok ? ec : 0)) * 4) : OOB;
-        eoff[i] = eo[i];
-    }
+        for (int i = 0; i < NR; ++i) {
+            const bool in = c_ok && wave * NR + i < ymax && 2 * l15 + eh < xmax;
+            eoff[i] = in ? (int)(((wave * NR + i) * osy + (2 * l15 + eh) * osx) * 4) + co_ch : OOB;
+            aoff[i] = (f_add && in) ? (int)(((wave * NR + i) * asy + (2 * l15 + eh) * asx) * 4) + ca_ch : OOB;
+            moff[i] = (f_mask && in) ? (int)(((wave * NR + i) * msy + (2 * l15 + eh) * msx) * 4) + cm_ch : OOB;
+        }
+    };
+    set_offsets(PTH, PTW);
     int esig = (PTH << 8) | PTW;
 
     __syncthreads();                                              // S0
@@ -622,9 +645,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         const int sig = (int)sg(d1.z);
         if (sig != esig) {
             esig = sig;
-            const int ymax = sig >> 8, xmax = sig & 0xff;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) eoff[i] = (wave * NR + i < ymax && 2 * l15 + eh < xmax) ? eo[i] : OOB;
+            set_offsets(sig >> 8, sig & 0xff);
         }
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ob), 0, 0x7fffff00, RSRC3);
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)ab), 0, 0x7fffff00, RSRC3);
@@ -633,17 +654,19 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         // exposed once per tile (cfg5: the residual + ReLU form 155 us against 122 us for the plain ReLU form with 1.5 x the bytes).
         // Two operands at once (32 registers) only where the budget of 128 holds them.
         constexpr bool PRE = EPI >= 0;
+        // (all three operands at once do not fit 128 registers beside their offsets: the old value is then requested after the K loop)
+        constexpr bool PRE_OLD = PRE && !((EPI & PAIR_EPI_ADD) && (EPI & PAIR_EPI_MASK) && (EPI & PAIR_EPI_ACC));
         i32x4_t ad[NR], mk[NR], old[NR];
         if (PRE) {
             if (f_add) {
 #pragma unroll
-                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[i], 0, 0);
             }
             if (f_mask) {
 #pragma unroll
-                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, moff[i], 0, 0);
             }
-            if (f_acc) {
+            if (f_acc && PRE_OLD) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
             }
@@ -694,14 +717,18 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
             a.pool[(size_t)(t - G) * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
         }
         f32x4 psum = {0.f, 0.f, 0.f, 0.f};          // a.pool: this lane's share of the tile's channel sums
+        if (PRE && !PRE_OLD && f_acc) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, eoff[i], 0, 0);
+        }
         if (!PRE) {
             if (f_add) {
 #pragma unroll
-                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, eoff[i], 0, 0);
+                for (int i = 0; i < NR; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[i], 0, 0);
             }
             if (f_mask) {
 #pragma unroll
-                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, eoff[i], 0, 0);
+                for (int i = 0; i < NR; ++i) mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, moff[i], 0, 0);
             }
             if (f_acc) {
 #pragma unroll
@@ -1116,14 +1143,21 @@ bool narrow_pair_ws_ok(const ConvParams& p) {
     // 16-byte buffer loads only need dword alignment, what a quad picks up beyond Cin meets zero filter entries, and the
     // descriptor's exact size makes the buffer unit zero-fill at the very end of the view
     static const bool no_ragged = getenv("DL4DS_NO_PAIR_WS_RAGGED") != nullptr;
+    if (getenv("DL4DS_NARROW_DEBUG"))
+        fprintf(stderr, "pair_ws?: N=%d H=%d W=%d Cin=%d (ld %d vec %d d2s %d sc %d) Cout=%d (ld %d vec %d d2s %d) add=%d(ld %d d2s %d) mask=%d(ld %d d2s %d) acc=%d pool=%d\n",
+                p.in.N, p.H, p.W, p.Cin, p.in.ld, p.in.vec, p.in.d2s, p.in.sc != nullptr, p.Cout, p.out.ld, p.out.vec, p.out.d2s, p.add.p != nullptr,
+                p.add.ld, p.add.d2s, p.mask.p != nullptr, p.mask.ld, p.mask.d2s, p.accumulate, p.pool != nullptr);
     if (off || p.in.d2s > 1) return false;
     if ((p.pool || p.in.sc) && getenv("DL4DS_NO_PAIR_WS_FUSED")) return false;      // (A/B: attention pieces through the older kernel)
     if (p.in.sc && (!p.in.vec || (p.Cin & 3))) return false;
     if ((!p.in.vec || (p.Cin & 3)) && no_ragged) return false;
-    if (p.add.p && !same_layout(p.add, p.out)) return false;
-    if (p.mask.p && !same_layout(p.mask, p.out)) return false;
-    const size_t r = p.out.d2s > 1 ? p.out.d2s : 1;
-    if ((size_t)20 * p.out.W * r * r * p.out.ld * 4 >= (1ull << 31) || (size_t)20 * p.W * p.in.ld * 4 >= (1ull << 31)) return false;
+    // the residual operand and the ReLU mask are addressed through their own strides: any plain layout of the output's grid (a
+    // dense tensor beside an output that lives inside a Concatenate's buffer, ...); depth_to_space operands like the output only
+    auto operand_ok = [&](const TView& v) { return same_layout(v, p.out) || (v.d2s <= 1 && p.out.d2s <= 1 && v.vec); };
+    if (p.add.p && !operand_ok(p.add)) return false;
+    if (p.mask.p && !operand_ok(p.mask)) return false;
+    auto span_ok = [](const TView& v) { const size_t r = v.d2s > 1 ? v.d2s : 1; return (size_t)20 * v.W * r * r * v.ld * 4 < (1ull << 31); };
+    if (!span_ok(p.out) || (p.add.p && !span_ok(p.add)) || (p.mask.p && !span_ok(p.mask)) || (size_t)20 * p.W * p.in.ld * 4 >= (1ull << 31)) return false;
     return true;
 }
 
