@@ -249,8 +249,11 @@ struct GapOp : GOp {
         const GTensor& ti = g.tensors[in];
         const int fr = over_time ? ti.nmul : 1;
         const int cnt = (c.b_cnt < 0 ? c.B : c.b_cnt) * ti.nmul / fr;
+        // (a ReLU output whose consumers apply its mask: this store does -- the tensor is dense, pooling never reads an alias)
+        const float* mask = (ti.grad_masked && ti.alias_of < 0) ? ti.data + (size_t)c.b_off * ti.per_sample() : nullptr;
+        DL4DS_REQUIRE(!ti.grad_masked || mask, "gap: masked gradient of an aliased tensor");
         gap_backward(g.stream, g.tensors[out].grad + (size_t)c.b_off * (ti.nmul / fr) * ti.C,
-                     ti.grad + (size_t)c.b_off * ti.per_sample(), cnt, ti.H * ti.W * fr, ti.C, ti.grad_written);
+                     ti.grad + (size_t)c.b_off * ti.per_sample(), cnt, ti.H * ti.W * fr, ti.C, ti.grad_written, mask);
         g.tensors[in].grad_written = true;
     }
 };
@@ -373,7 +376,8 @@ int g_gap(Graph& g, int in, int over_time) {
     const int out = g.add_tensor(1, 1, ti.C, over_time ? 1 : ti.nmul, true, false);
     GapOp* op = push<GapOp>(g);
     op->in = in; op->out = out; op->over_time = over_time != 0;
-    g.tensors[in].n_other++;
+    // a masking consumer (like MaxPooling2D / Concatenate): its backward applies the input's ReLU mask (DL4DS_NO_GAP_MASK=1: as before)
+    if (getenv("DL4DS_NO_GAP_MASK")) g.tensors[in].n_other++; else g.tensors[in].n_masking++;
     op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;

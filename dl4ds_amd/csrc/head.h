@@ -2,7 +2,7 @@
 #include "common.h"
 size_t gap_workspace_bytes(int N, int C);
 void gap_forward(hipStream_t s, const float* x, float* out, int N, int HW, int C, float* ws = nullptr, size_t ws_bytes = 0);
-void gap_backward(hipStream_t s, const float* dy, float* dx, int N, int HW, int C, int accumulate);
+void gap_backward(hipStream_t s, const float* dy, float* dx, int N, int HW, int C, int accumulate, const float* mask = nullptr);   // mask: dx zeroed where mask <= 0
 void dense_forward(hipStream_t s, const float* x, const float* w, const float* b, float* y, int B, int Cin, int F, int act);
 // dy is overwritten with dz = dy*act'(y) for rows [b0, b0+B)
 void dense_backward(hipStream_t s, const float* x, const float* w, const float* y, float* dy, float* dx, int acc_dx,
