@@ -974,6 +974,20 @@ void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
             sp.c.w = w0;
         }
     }
+    if constexpr (KS == 1 && E > 4) {      // (16-channel chunks: a single group-step per tile, the filter ring needs two)
+        // 1x1 layers on the producer / consumer kernel too (round 3): the helper waves keep the next tile in flight while the MFMA
+        // waves work -- 48 -> 48 at 64 x 128^2: 0.137 -> 0.110 ms (2.9 -> 3.7 TB/s).  DL4DS_STREAM_NO_WS1=1 for A/B.
+        static const bool ws1 = getenv("DL4DS_STREAM_NO_WS") == nullptr && getenv("DL4DS_STREAM_NO_WS1") == nullptr;
+        if (ws1 && NT <= 3) {
+            const float* w0 = sp.c.w;
+            bool done = false;
+            if (NT == 1) done = launch_stream_ws<1, E, 1, 4>(s, sp, N);
+            else if (NT == 2) done = launch_stream_ws<1, E, 2, 4>(s, sp, N);
+            else done = launch_stream_ws<1, E, 3, 4>(s, sp, N);
+            if (done) return;
+            sp.c.w = w0;
+        }
+    }
     switch (NT) {
         case 1: launch_stream<KS, E, 1, 4>(s, sp, N); break;
         case 2: launch_stream<KS, E, 2, 4>(s, sp, N); break;

@@ -135,6 +135,27 @@ def test_conv2d_stream_producer_consumer(ops, monkeypatch, sx, n, h, w, ci, co):
 
 
 @pytest.mark.parametrize('sx', ['1', '32'])
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 33, 20, 48, 48), (1, 40, 40, 40, 48), (3, 16, 16, 32, 48), (2, 20, 36, 24, 32), (2, 17, 19, 48, 8),
+                                        (1, 32, 32, 32, 16), (2, 24, 33, 24, 24), (1, 16, 16, 40, 40)])
+def test_conv2d_stream_producer_consumer_1x1(ops, monkeypatch, sx, n, h, w, ci, co):
+    """1x1 layers (TransitionBlock, the projected skips of the residual blocks: blocks.py:208,299) on conv_stream_ws_kernel<1,..>
+    (24- .. 48-channel chunks, one to three cout blocks): forward with fused epilogues, dgrad with accumulate; kernel tag asserted."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_STREAM_FORCE_WS', sx)
+    x, wt, b, add = R(n, h, w, ci), R(1, 1, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert any(t.startswith('conv_stream_ws<1,') for t in tags), tags
+    close(got, ref)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    close(ops.conv2d_dgrad(dz, wt), gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+
+
+@pytest.mark.parametrize('sx', ['1', '32'])
 @pytest.mark.parametrize('n,h,w,ci,co', [(2, 33, 20, 32, 64), (1, 40, 40, 64, 128), (3, 16, 16, 24, 48), (2, 20, 36, 48, 32), (2, 33, 20, 32, 8), (2, 20, 36, 16, 12),
                                         (1, 32, 32, 128, 96), (2, 17, 17, 32, 40), (2, 24, 33, 16, 32), (1, 16, 16, 80, 48)])
 def test_conv2d_stream_producer_consumer_5x5(ops, monkeypatch, sx, n, h, w, ci, co):
