@@ -273,7 +273,10 @@ def main():
     nprof = min(3, args.warmup) if prof_on else 0
     if prof_on and nprof == 0:
         nprof = 2            # --warmup 0: two extra (untimed) steps are needed to pick the kernel to instrument
-    for _ in range(max(args.warmup - nprof, 0)):
+    # every rank runs the SAME number of steps (each step is a sequence of collectives): the ranks that do not profile make up
+    # for rank 0's extra steps of a --warmup 0 run
+    extra_other = (2 if (args.warmup == 0 and not args.no_profile) else 0) if (world > 1 and rank != 0) else 0
+    for _ in range(max(args.warmup - nprof, 0) + extra_other):
         step()
     breakdown, dom, dom_share = None, None, None
     executed_gflop_per_step = mfma_gflop_per_step = direct_gflop_per_step = None
