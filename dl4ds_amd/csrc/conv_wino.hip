@@ -15,8 +15,9 @@ int wino_cu_count() {
 
 // U = G g G^T in the fragment order the workgroups load it in: element ((pc * 4 + xi) * F/4 + f4) * 64 + lane, component j,
 // f = 4 f4 + j = (nu * 4 KQ + ks) * NT + cb (pc = pass * nchunk + chunk, F = 16 KQ NT); nu = 3 negated
+// second form of the kernel (conv_wino2_kernel): slots 1 and 2 hold U1 - U2 and U1 + U2 (see its K loop)
 __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout, int KQ,
-                                                          int NT, int nchunk, int total) {
+                                                          int NT, int nchunk, int total, int form2) {
     const int F = 16 * KQ * NT;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int j = idx & 3, lane = (idx >> 2) & 63;
@@ -38,7 +39,8 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
             float t[3];
 #pragma unroll
             for (int b = 0; b < 3; ++b) t[b] = c0 * p[(0 * 3 + b) * tap] + c1 * p[(1 * 3 + b) * tap] + c2 * p[(2 * 3 + b) * tap];
-            val = nu == 0 ? t[0] : (nu == 1 ? .5f * (t[0] + t[1] + t[2]) : (nu == 2 ? .5f * (t[0] - t[1] + t[2]) : -t[2]));
+            if (form2) val = nu == 0 ? t[0] : (nu == 1 ? t[1] : (nu == 2 ? t[0] + t[2] : -t[2]));
+            else val = nu == 0 ? t[0] : (nu == 1 ? .5f * (t[0] + t[1] + t[2]) : (nu == 2 ? .5f * (t[0] - t[1] + t[2]) : -t[2]));
         }
         u[idx] = val;
     }
@@ -127,7 +129,7 @@ bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const T
     {
         const int total = (int)(per_pass * passes);
         hipLaunchKernelGGL(wino_filter_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, u, in.C, out.C, KQ, NT,
-                           wp.nchunk, total);
+                           wp.nchunk, total, 0);
         HIP_CHECK(hipGetLastError());
     }
     for (int ps_ = 0; ps_ < passes; ++ps_) {

@@ -11,6 +11,9 @@ B = int(os.environ.get('MB_N', 64))
 rng = np.random.default_rng(0)
 CASES = [  # H, Cin, Cout, d2s
     (128, 48, 48, 0), (128, 48, 192, 2), (256, 48, 32, 2), (128, 40, 48, 0), (128, 32, 32, 0), (128, 24, 32, 0)]
+if os.environ.get('MB_CASES'):          # e.g. MB_CASES=1,0: only those rows of CASES
+    CASES = [CASES[int(i)] for i in os.environ['MB_CASES'].split(',')]
+MODES = tuple(os.environ.get('MB_MODES', 'wino,direct').split(','))
 for H, CI, CO, r in CASES:
     x = DeviceArray.from_numpy(rng.standard_normal((B, H, H, CI)).astype(np.float32))
     w = DeviceArray.from_numpy((rng.standard_normal((3, 3, CI, CO)) * 0.1).astype(np.float32))
@@ -19,7 +22,7 @@ for H, CI, CO, r in CASES:
     y = DeviceArray.zeros((B, rr * H, rr * H, CO // (rr * rr)))
     dz = DeviceArray.from_numpy(rng.standard_normal((B, rr * H, rr * H, CO // (rr * rr))).astype(np.float32))
     dx = DeviceArray.zeros((B, H, H, CI))
-    for mode in ('wino', 'direct'):
+    for mode in MODES:
         if mode == 'direct':
             os.environ['DL4DS_NO_WINOGRAD'] = '1'
         else:
@@ -41,13 +44,15 @@ for H, CI, CO, r in CASES:
             print(f'{H:4d}^2 {CI:3d}->{CO:3d} d2s={r} {mode:6s} {what:5s} {tot:8.4f} ms  {direct_tf:6.1f} direct-equivalent TFLOP/s  [{tags}]', flush=True)
 
 # ---- weight gradients
+if os.environ.get('MB_NO_WGRAD'):
+    sys.exit(0)
 print('weight gradients', flush=True)
 for H, CI, CO, r in CASES:
     x = DeviceArray.from_numpy(rng.standard_normal((B, H, H, CI)).astype(np.float32))
     rr = max(r, 1)
     dz = DeviceArray.from_numpy(rng.standard_normal((B, rr * H, rr * H, CO // (rr * rr))).astype(np.float32))
     dw = DeviceArray.zeros((3, 3, CI, CO))
-    for mode in ('wino', 'direct'):
+    for mode in MODES:
         if mode == 'direct':
             os.environ['DL4DS_NO_WINOGRAD'] = '1'
         else:
