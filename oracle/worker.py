@@ -1,6 +1,6 @@
-"""Worker process of tests/parity.py: evaluates the oracle for a subset of the samples of one job.
+"""Worker process of oracle/reference.py: evaluates the oracle for a subset of the samples of one job.
 
-    python tests/oracle_worker.py <job.npz> <worker index> <n workers> <out.npz>
+    python oracle/worker.py <job.npz> <worker index> <n workers> <out.npz>
 
 The job file holds the model kind / configuration (JSON), the weights by name, the inputs and -- for a CGAN step -- the
 discriminator's weights and dropout mask.  Sample i of the batch is handled by worker i % n.  Per sample the worker runs

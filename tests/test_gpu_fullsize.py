@@ -145,7 +145,7 @@ def test_cfg5_generator_full_size_batch_independence_and_gradient():
 
 
 def test_cfg1_full_size_against_the_oracle():
-    """BASELINE configs[0] at its own size (net_pin, residual backbone, 2 channels, 128 x 128, B = 2): forward, MAE loss and
+    """BASELINE configs[0] at its own size (net_pin, residual backbone, 2 channels, 128 x 128, B = 8): forward, MAE loss and
     every gradient -- each tensor at its own scale, tests/parity.py -- against the fp64 torch-CPU oracle."""
     import dl4ds_amd.models as PM
     from dl4ds_amd.training import SupervisedEngine
@@ -154,15 +154,16 @@ def test_cfg1_full_size_against_the_oracle():
     assert model.count_params() == 121341
     w = _randomise_biases(model)
     rng = np.random.default_rng(1001)
-    x = rng.standard_normal((2, 128, 128, 2)).astype(np.float32)
+    x = rng.standard_normal((8, 128, 128, 2)).astype(np.float32)
     out = model([x])
     y = _targets_clear_of_the_kink(out, rng)
-    ref = oracle_reference('supervised', 'net_pin', dict(backbone_block='resnet'), w, x, None, y, loss='mae', workers=2)
+    ref = oracle_reference('supervised', 'net_pin', dict(backbone_block='resnet'), w, x, None, y, loss='mae', workers=8)
     assert np.abs(out - ref['pred']).max() / np.abs(ref['pred']).max() < 1e-3          # north_star tolerance; observed ~1e-6
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     l_hip, g_hip = eng.loss_and_grads([x], y)
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
-    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg1'))
+    # (8 x 128^2 pixels per gradient entry: the fp32 noise floor of the smallest tensors is 1.9 % here, 0.1-0.4 % at cfg2 / 4 / 5)
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg1 full size', full=True), limit=0.03)
 
 
 def test_cfg5_full_size_cgan_step_properties():
@@ -227,14 +228,8 @@ def _no_force_overrides():
 
 
 def _targets_clear_of_the_kink(pred, rng):
-    """Targets for the gradient comparisons: prediction +/- (0.5 ... 1.5), the sign + for 80 % of the pixels.  |pred - y| >= 0.5
-    keeps every MAE residual far from its sign change, and the mostly-coherent sign makes the parameter gradients sums that
-    do NOT cancel (with pure-noise targets every gradient entry is a random walk over the pixels: one ReLU unit on the other
-    side of its threshold then moves it by ~2 / sqrt(#pixels), percent-level, in any single-precision evaluation -- the
-    oracle's own band shows it, tests/parity.py).  The field of signs is still random pixel by pixel, so the upstream gradient
-    entering the last layers varies from pixel to pixel."""
-    s = np.where(rng.random(pred.shape) < 0.8, 1.0, -1.0)
-    return (pred.astype(np.float64) + s * (0.5 + rng.random(pred.shape))).astype(np.float32)
+    from tests.parity import targets_clear_of_the_kink          # (oracle/reference.py: shared with __graft_entry__.smoke())
+    return targets_clear_of_the_kink(pred, rng)
 
 
 def _fwd_close(out, ref, tol=1e-3):
@@ -244,12 +239,23 @@ def _fwd_close(out, ref, tol=1e-3):
     return err
 
 
-def _slack_is_small(report, limit=0.05, allow=()):
-    """The discontinuity band + noise floor the oracle grants (tests/parity.py) must stay a correction to the 1e-3
-    criterion: no tensor -- except the named ``allow`` prefixes, with their reason at the call site -- may be granted more
-    than ``limit`` of its own size."""
-    worst = [(f, k) for f, k in report if not k.startswith(tuple(allow))] if allow else report
-    assert worst[0][0] < limit, f'oracle slack too large, the comparison has lost its teeth: {worst[:6]}'
+SLACK_LIMIT = 0.01         # band + noise floor the oracle may grant a tensor, as a fraction of the tensor's own size
+PLAIN_FRACTION = 0.95      # share of the tensors that must pass on north_star's 1e-3 (+ the ulp floor) ALONE
+
+
+def _slack_is_small(rows, limit=SLACK_LIMIT):
+    """``rows`` = tests.parity.assert_matches_reference's per-tensor breakdown.  Two statements about the evidence itself:
+    (1) at least PLAIN_FRACTION of the tensors pass on tol = 1e-3 + the ulp floor alone, without band or noise
+        (realised in round 4: 56/56 cfg2 either kernel set, 58/58 cfg4, 76/76 + 48/48 cfg5, cfg1 see the artefact);
+    (2) the discontinuity band + noise floor the oracle grants stays a correction: no tensor -- none exempted by name -- gets
+        more than ``limit`` = 1 % of its own size (realised: <= 0.11 % in cfg2 / cfg4, 0.35 % in cfg5's generator; the two
+        small-sample cases pass limit = 3 % at their call sites: cfg1 1.9 %, the CGAN discriminator at B = 4 1.6 %)."""
+    from tests.parity import summarize
+    sm = summarize(rows)
+    assert sm['plain_frac'] >= PLAIN_FRACTION, f'only {sm["plain_ok"]} of {sm["n"]} tensors pass on 1e-3 alone: {sm}'
+    for r in rows:
+        assert r['band'] + r['noise'] < limit, f'oracle slack too large, the comparison has lost its teeth: {r}'
+    return sm
 
 
 _CFG2_REF = {}
@@ -291,7 +297,7 @@ def test_cfg2_full_size_against_the_oracle(monkeypatch, winograd):
     ref = _CFG2_REF['ref']
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
-    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg2'))
+    _slack_is_small(assert_matches_reference(g_hip, ref, what=f'cfg2 full size ({"Winograd" if winograd else "direct"} kernels)', full=True))
 
 
 def _cfg4_model(seed=3):
@@ -327,9 +333,9 @@ def test_cfg4_full_size_against_the_oracle():
     ref = oracle_reference('supervised', 'recnet_postupsampling', CFG4_OCFG, w, x, aux, y, loss='mae', workers=ORACLE_WORKERS)
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
-    # LocalizedConvBlock's variables are per grid point: each gradient entry sums B x T = 64 terms only, so one unit on
-    # either side of a discontinuity is 1/64 of an entry -- the band the oracle grants there is wider than elsewhere
-    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg4'), allow=('LocalizedConvBlock/',))
+    # (LocalizedConvBlock's per-grid-point variables sum only B x T = 64 terms per entry; with targets clear of the MAE kink the
+    #  oracle grants them 3e-4 of their size -- profiles/parity_r04.json -- so they need no exemption from the cap any more)
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg4 full size', full=True))
 
 
 def _cfg5_pair():
@@ -367,7 +373,7 @@ def test_cfg5_generator_full_size_against_the_oracle():
     ref = oracle_reference('supervised', 'unet_pin', CFG5_GCFG, w, lr, st, y, loss='mae', workers=ORACLE_WORKERS)
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
-    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg5 generator'))
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg5 generator full size', full=True))
 
 
 def test_cfg5_full_size_cgan_step_against_the_oracle():
@@ -392,5 +398,6 @@ def test_cfg5_full_size_cgan_step_against_the_oracle():
                            workers=B)
     for i, k in enumerate(('gen_total', 'gen_gan', 'gen_px', 'disc')):
         assert out[i] == pytest.approx(ref['losses'][i], rel=1e-4), k
-    _slack_is_small(assert_matches_reference(gd, ref, 'gradsD', what='cfg5 discriminator'))
-    _slack_is_small(assert_matches_reference(gg, ref, 'gradsG', what='cfg5 generator (adversarial + 100 x MAE)'))
+    # (B = 4: the bias of the merge block is a sum of four samples' terms, noise floor 1.6 % of it)
+    _slack_is_small(assert_matches_reference(gd, ref, 'gradsD', what='cfg5 CGAN step full size: discriminator', full=True), limit=0.03)
+    _slack_is_small(assert_matches_reference(gg, ref, 'gradsG', what='cfg5 CGAN step full size: generator (adversarial + 100 x MAE)', full=True))

@@ -3,7 +3,7 @@ sys.path.insert(0,'/root/repo')
 import numpy as np
 import dl4ds_amd.models as PM
 from oracle import torch_ops as T, models as M, train as TR
-from tests.parity import oracle_reference
+from oracle.reference import oracle_reference
 cfg = dict(backbone_block='resnet', upsampling='spc', scale=4)
 model = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (16, 16), seed=1)
 rng = np.random.default_rng(0)
