@@ -45,6 +45,6 @@ void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, si
     if (n == 0) return;
     ProfScope ps(s, "adam", 0.0, 28.0 * (double)n);
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n / 4 + 1, 256), 2048));
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    DL4DS_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
     HIP_CHECK(hipGetLastError());
 }

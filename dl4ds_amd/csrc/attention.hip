@@ -145,8 +145,8 @@ void chatt_apply(hipStream_t s, const float* a, const float* scale, const float*
     const bool v4 = (RQ & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)out)) & 15) == 0;
     const size_t n = v4 ? RQ / 4 : RQ;
     const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, std::max<size_t>(1, 8192 / (size_t)G)));
-    if (v4) hipLaunchKernelGGL((chatt_apply_kernel<4, BWD>), dim3(bx, (unsigned)G), dim3(256), 0, s, a, scale, dmean, out, (unsigned)n, Q, accumulate);
-    else hipLaunchKernelGGL((chatt_apply_kernel<1, BWD>), dim3(bx, (unsigned)G), dim3(256), 0, s, a, scale, dmean, out, (unsigned)n, Q, accumulate);
+    if (v4) DL4DS_LAUNCH((chatt_apply_kernel<4, BWD>), dim3(bx, (unsigned)G), dim3(256), 0, s, a, scale, dmean, out, (unsigned)n, Q, accumulate);
+    else DL4DS_LAUNCH((chatt_apply_kernel<1, BWD>), dim3(bx, (unsigned)G), dim3(256), 0, s, a, scale, dmean, out, (unsigned)n, Q, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -216,13 +216,13 @@ void colsum(hipStream_t s, const float* a, const float* b, float* partial, float
     const int nb = colsum_blocks(R, TY);
     dim3 grid((unsigned)nb, (unsigned)cdiv(Q, TX), (unsigned)G);
     switch (TX) {
-        case 8: hipLaunchKernelGGL(colsum_kernel<8>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
-        case 16: hipLaunchKernelGGL(colsum_kernel<16>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
-        case 32: hipLaunchKernelGGL(colsum_kernel<32>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
-        default: hipLaunchKernelGGL(colsum_kernel<64>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+        case 8: DL4DS_LAUNCH(colsum_kernel<8>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+        case 16: DL4DS_LAUNCH(colsum_kernel<16>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+        case 32: DL4DS_LAUNCH(colsum_kernel<32>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
+        default: DL4DS_LAUNCH(colsum_kernel<64>, grid, dim3(256), 0, s, a, b, partial, R, Q); break;
     }
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(G * Q, 256)), dim3(256), 0, s, partial, out, nb, Q, G * Q, scale);
+    DL4DS_LAUNCH(colsum_finish_kernel, dim3(cdiv(G * Q, 256)), dim3(256), 0, s, partial, out, nb, Q, G * Q, scale);
     HIP_CHECK(hipGetLastError());
 }
 inline int ew_blocks(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 8192)); }
@@ -245,13 +245,13 @@ void chatt_forward(hipStream_t s, const float* x, float* y, const AttShape& sh, 
     ProfScope ps(s, "chatt_fwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * ((pool_partial ? 0 : 1) + (y ? 2 : 0)));
     if (pool_partial) {
         DL4DS_REQUIRE(sh.P == 1 && sh.C <= 8, "chatt: pooling partials come from the 8-channel pair convolution");
-        hipLaunchKernelGGL(pool_finish_kernel, dim3(cdiv(sh.G, 4)), dim3(256), 0, s, pool_partial, mean, pool_tiles,
+        DL4DS_LAUNCH(pool_finish_kernel, dim3(cdiv(sh.G, 4)), dim3(256), 0, s, pool_partial, mean, pool_tiles,
                            sh.C, sh.G, 1.f / (float)sh.R);
         HIP_CHECK(hipGetLastError());
     } else {
         colsum(s, x, nullptr, workspace, mean, sh.G, sh.R, Q, 1.f / (float)sh.R);
     }
-    hipLaunchKernelGGL(chatt_mlp_fwd_kernel, dim3(cdiv(ninst * sh.C, 256)), dim3(256), 0, s, mean, w1, b1, w2, b2,
+    DL4DS_LAUNCH(chatt_mlp_fwd_kernel, dim3(cdiv(ninst * sh.C, 256)), dim3(256), 0, s, mean, w1, b1, w2, b2,
                        hidden, scale, ninst, sh.C, sh.Cr);
     HIP_CHECK(hipGetLastError());
     if (y == nullptr) return;                  // the consumer reads x through a view carrying `scale` (TView::sc)
@@ -272,12 +272,12 @@ void chatt_backward(hipStream_t s, const float* x, const float* dy, float* dx, i
     if (dmean_out) dmean = dmean_out;           // kept by the caller: the producer reads dX = dY * scale + dmean lazily
     ProfScope ps(s, "chatt_bwd", 0.0, 4.0 * (double)sh.G * sh.R * Q * ((ds_given ? 0 : 2) + (dx ? 2 + (accumulate_dx ? 1 : 0) : 0)));
     if (ds_given == nullptr) colsum(s, dy, x, partial, ds, sh.G, sh.R, Q, 1.f);
-    hipLaunchKernelGGL(chatt_mlp_bwd_inst_kernel, dim3(cdiv(ninst, 256)), dim3(256), 0, s, ds_given ? ds_given : ds, hidden, scale, w1, w2,
+    DL4DS_LAUNCH(chatt_mlp_bwd_inst_kernel, dim3(cdiv(ninst, 256)), dim3(256), 0, s, ds_given ? ds_given : ds, hidden, scale, w1, w2,
                        dpre1, dpre2, dmean, ninst, sh.C, sh.Cr, 1.f / (float)sh.R);
     HIP_CHECK(hipGetLastError());
     if (dw1) {              // (null: input gradient only -- the CGAN generator pass through the discriminator)
         const int nout = 2 * sh.C * sh.Cr + sh.Cr + sh.C;
-        hipLaunchKernelGGL(chatt_mlp_bwd_param_kernel, dim3(cdiv(nout, 4)), dim3(256), 0, s, mean, hidden, dpre1, dpre2, dw1, db1, dw2, db2,
+        DL4DS_LAUNCH(chatt_mlp_bwd_param_kernel, dim3(cdiv(nout, 4)), dim3(256), 0, s, mean, hidden, dpre1, dpre2, dw1, db1, dw2, db2,
                            ninst, sh.C, sh.Cr, accumulate_dw);
         HIP_CHECK(hipGetLastError());
     }

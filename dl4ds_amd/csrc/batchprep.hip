@@ -170,7 +170,7 @@ void launch_taps(hipStream_t s, const TapParams& a, const char* name, double src
     const size_t n = (size_t)a.B * a.T * a.oy_n * a.ox_n * a.CL;
     ProfScope ps(s, name, 0.0, src_bytes + 4.0 * n);
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 16384));
-    hipLaunchKernelGGL(prep_taps_kernel, dim3(blocks), dim3(256), 0, s, a);
+    DL4DS_LAUNCH(prep_taps_kernel, dim3(blocks), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -257,7 +257,7 @@ void batch_prepare_taps(hipStream_t s, const float* hr, const float* pred, const
     const size_t n_hr = (size_t)B * T * psy * psx * C + (S ? (size_t)B * psy * psx * S : 0);
     ProfScope ps(s, "batch_prepare_hr", 0.0, 8.0 * n_hr);
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n_hr, 256), 16384));
-    hipLaunchKernelGGL(prep_hr_kernel, dim3(blocks), dim3(256), 0, s, h);
+    DL4DS_LAUNCH(prep_hr_kernel, dim3(blocks), dim3(256), 0, s, h);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -281,13 +281,13 @@ void batch_prepare(hipStream_t s, const float* hr, const float* pred, const floa
     {
         ProfScope ps(s, "batch_prepare_lr", 0.0, crop_bytes + 4.0 * n_lr);
         const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n_lr, 256), 16384));
-        hipLaunchKernelGGL(prep_lr_kernel, dim3(blocks), dim3(256), 0, s, a);
+        DL4DS_LAUNCH(prep_lr_kernel, dim3(blocks), dim3(256), 0, s, a);
         HIP_CHECK(hipGetLastError());
     }
     {
         ProfScope ps(s, "batch_prepare_hr", 0.0, 8.0 * n_hr);
         const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n_hr, 256), 16384));
-        hipLaunchKernelGGL(prep_hr_kernel, dim3(blocks), dim3(256), 0, s, a);
+        DL4DS_LAUNCH(prep_hr_kernel, dim3(blocks), dim3(256), 0, s, a);
         HIP_CHECK(hipGetLastError());
     }
 }

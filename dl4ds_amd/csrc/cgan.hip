@@ -11,6 +11,7 @@
 #include "graph.h"
 #include "runtime.h"
 #include "dist.h"
+#include "prof.h"
 #include <cmath>
 
 // Pass 2 without a second backward pass (round 3).  D is per-sample independent (no batch statistics), its output is one
@@ -190,7 +191,7 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
             HIP_CHECK(hipMalloc((void**)&t.ratio, (size_t)2 * B * sizeof(float)));
             t.ratio_n = 2 * B;
         }
-        hipLaunchKernelGGL(cgan_ratio_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, p_fake, t.ratio, B);
+        DL4DS_LAUNCH(cgan_ratio_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, s, p_fake, t.ratio, B);
         HIP_CHECK(hipGetLastError());
         BwdCtx cr{2 * B, 0, 2 * B, false, true};
         for (int k = (int)t.ratio_ops.size() - 1; k >= 0; --k) {
@@ -199,7 +200,7 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
             if (!to.grad_written) continue;
             TView gv = D.view(op->out_tid, 2 * B, true);
             const size_t per_img = (size_t)gv.H * gv.W * gv.C, total = per_img * gv.N;
-            hipLaunchKernelGGL(scale_samples_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, gv, t.ratio,
+            DL4DS_LAUNCH(scale_samples_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, gv, t.ratio,
                                per_img, to.nmul, total);
             HIP_CHECK(hipGetLastError());
             op->backward(D, cr);

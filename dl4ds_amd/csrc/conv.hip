@@ -511,7 +511,7 @@ bool try_launch_db(hipStream_t s, ConvParams& p, int N, size_t lds_limit) {
     ProfScope ps(s, "conv_igemm_db<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
                         std::to_string(WM) + "," + std::to_string(WN) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
-    hipLaunchKernelGGL(kern, grid, dim3(NTHR), best_lds, s, p);
+    DL4DS_LAUNCH(kern, grid, dim3(NTHR), best_lds, s, p);
     HIP_CHECK(hipGetLastError());
     return true;
 }
@@ -575,15 +575,15 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
         q.bias = nullptr; q.add.p = nullptr; q.mask.p = nullptr; q.relu = 0; q.accumulate = 0;
         q.kchunks = cps;
         grid.z = (unsigned)S;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN * KSP), lds, s, q);
+        DL4DS_LAUNCH(kern, grid, dim3(64 * WM * WN * KSP), lds, s, q);
         HIP_CHECK(hipGetLastError());
         const size_t total = slab;
-        hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, s, slabs, S,
+        DL4DS_LAUNCH(splitk_combine_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, s, slabs, S,
                            slab, p, N);
         HIP_CHECK(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN * KSP), lds, s, p);
+    DL4DS_LAUNCH(kern, grid, dim3(64 * WM * WN * KSP), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1502,7 +1502,7 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     ProfScope ps(s, std::string(rows ? "conv_wgrad_rows<" : "conv_wgrad<") + std::to_string(KS) + "," + std::to_string(CIT) +
                         "," + std::to_string(COT) + "," + std::to_string(WCO) + ">",
                  2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
-    hipLaunchKernelGGL(kern, grid, dim3(ws ? 512 : 256), lds, s, p);
+    DL4DS_LAUNCH(kern, grid, dim3(ws ? 512 : 256), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1605,7 +1605,7 @@ int dgrad_weights_job_blocks(int KK, int Cin, int Cout) { return cdiv(Cin, 32) *
 void conv2d_dgrad_weights_batched(hipStream_t s, const DgradWeightsJob* jobs_dev, int nj, int blocks) {
     if (nj == 0 || blocks == 0) return;
     ProfScope ps(s, "dgrad_weights_batched", 0.0, 0.0);
-    hipLaunchKernelGGL(dgrad_weights_batched_kernel, dim3(blocks), dim3(256), 0, s, jobs_dev, nj);
+    DL4DS_LAUNCH(dgrad_weights_batched_kernel, dim3(blocks), dim3(256), 0, s, jobs_dev, nj);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1613,11 +1613,11 @@ void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int 
     const size_t total = (size_t)KS * KS * Cin * Cout;
     ProfScope ps(s, "dgrad_weights", 0.0, 8.0 * (double)total);
     if ((size_t)Cin * Cout >= 4096 && Cin >= 16 && Cout >= 16) {
-        hipLaunchKernelGGL(dgrad_weights_tiled_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), KS * KS), dim3(256), 0, s, w, wt, KS * KS,
+        DL4DS_LAUNCH(dgrad_weights_tiled_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), KS * KS), dim3(256), 0, s, w, wt, KS * KS,
                            Cin, Cout);
     } else {
         const int blocks = (int)std::min<size_t>(cdivz(total, 256), 2048);
-        hipLaunchKernelGGL(dgrad_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wt, KS * KS, Cin, Cout);
+        DL4DS_LAUNCH(dgrad_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wt, KS * KS, Cin, Cout);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1667,11 +1667,11 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     // 64 slabs per thread one latency after the other (13 us); 4 elements per block put 64 slabs in flight per block
     if (n < 4096 && nslabs >= 128 && !getenv("DL4DS_REDUCE16")) {
         const int blocks = (int)std::max<size_t>(1, cdivz(n, 4));
-        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
+        DL4DS_LAUNCH(reduce_slabs_kernel<4>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
                            accumulate_db);
     } else {
         const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 16), 8192));
-        hipLaunchKernelGGL(reduce_slabs_kernel<16>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
+        DL4DS_LAUNCH(reduce_slabs_kernel<16>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
                            accumulate_db);
     }
     HIP_CHECK(hipGetLastError());

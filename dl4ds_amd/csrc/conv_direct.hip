@@ -833,11 +833,11 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
                             std::to_string(CI) + "," + std::to_string(CO) + ">";
     ProfScope ps(s, tag, 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * px * (p.Cin + p.Cout));
     if (gen2) {
-        if (wgrad) hipLaunchKernelGGL((conv_direct2_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_direct2_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        if (wgrad) DL4DS_LAUNCH((conv_direct2_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        else DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
     } else {
-        if (wgrad) hipLaunchKernelGGL((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_direct_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        if (wgrad) DL4DS_LAUNCH((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        else DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
     }
     HIP_CHECK(hipGetLastError());
     return blocks;
@@ -961,10 +961,10 @@ bool conv2d_direct_wgrad_attention(hipStream_t s, const TView& x_raw, const TVie
     fill_tiles(p, N);
     dispatch_direct(s, p, true, N * bpi, /*exact_grid=*/true);
     float* perimg = workspace + (size_t)N * bpi * n_el;
-    hipLaunchKernelGGL(att_wgrad_per_image_kernel, dim3(N), dim3(256), n_el * sizeof(float), s, workspace, perimg, w, ds, bpi, n_el,
+    DL4DS_LAUNCH(att_wgrad_per_image_kernel, dim3(N), dim3(256), n_el * sizeof(float), s, workspace, perimg, w, ds, bpi, n_el,
                        nw, KS * KS, x_raw.C, dz.C);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(att_wgrad_combine_kernel, dim3(cdiv(4 * n_el, 256)), dim3(256), 0, s, perimg, scale, dw, db, N, n_el, nw,
+    DL4DS_LAUNCH(att_wgrad_combine_kernel, dim3(cdiv(4 * n_el, 256)), dim3(256), 0, s, perimg, scale, dw, db, N, n_el, nw,
                        x_raw.C, dz.C, accumulate, accumulate_db);
     HIP_CHECK(hipGetLastError());
     return true;

@@ -153,7 +153,7 @@ void launch_narrow(hipStream_t s, ConvParams& p, int N) {
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_narrow<" + std::to_string(CI) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
-    hipLaunchKernelGGL((conv_narrow_kernel<CI>), dim3(blocks), dim3(256), 0, s, p);
+    DL4DS_LAUNCH((conv_narrow_kernel<CI>), dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1124,7 +1124,7 @@ bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
     static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;                     // (A/B)
     p.CK = no_xcd ? 0 : 1;
     auto grid_of = [&](int resident) { const int b = std::min(ntiles, resident); return b >= 8 ? (b & ~7) : b; };
-#define NARROW16_FORM(E_) case E_: hipLaunchKernelGGL((conv_narrow16_ws_kernel<NR, E_>), \
+#define NARROW16_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow16_ws_kernel<NR, E_>), \
         dim3(grid_of(resident_blocks<conv_narrow16_ws_kernel<NR, E_>>(512))), dim3(512), 0, s, p); break;
     switch (epi) {
         NARROW16_FORM(0) NARROW16_FORM(1) NARROW16_FORM(2) NARROW16_FORM(3) NARROW16_FORM(4) NARROW16_FORM(5) NARROW16_FORM(6) NARROW16_FORM(7)
@@ -1181,7 +1181,7 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
         p.CK = no_xcd ? 0 : 1;
         ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                      4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
-#define PAIR_WS_FORM(E_) case E_: hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR, E_>), dim3(blocks), dim3(512), 0, s, p); break;
+#define PAIR_WS_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, E_>), dim3(blocks), dim3(512), 0, s, p); break;
         switch (generic_only ? -1 : epi) {
             PAIR_WS_FORM(0) PAIR_WS_FORM(1) PAIR_WS_FORM(2) PAIR_WS_FORM(3) PAIR_WS_FORM(4) PAIR_WS_FORM(5) PAIR_WS_FORM(6) PAIR_WS_FORM(7)
             PAIR_WS_FORM(8) PAIR_WS_FORM(9) PAIR_WS_FORM(10) PAIR_WS_FORM(11) PAIR_WS_FORM(12) PAIR_WS_FORM(13) PAIR_WS_FORM(14) PAIR_WS_FORM(15)
@@ -1189,7 +1189,7 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
             PAIR_WS_FORM(PAIR_EPI_POOL | PAIR_EPI_RELU)
             PAIR_WS_FORM(PAIR_EPI_AFF) PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_MASK) PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_ACC)
             PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_MASK | PAIR_EPI_ACC) PAIR_WS_FORM(PAIR_EPI_AFF | PAIR_EPI_RELU)
-            default: hipLaunchKernelGGL((conv_narrow_pair_ws_kernel<NR, -1>), dim3(blocks), dim3(512), 0, s, p); break;
+            default: DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, -1>), dim3(blocks), dim3(512), 0, s, p); break;
         }
 #undef PAIR_WS_FORM
         HIP_CHECK(hipGetLastError());
@@ -1210,7 +1210,7 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
     const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_kernel<NR>>(256));
     ProfScope ps(s, "conv_narrow_pair<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
-    hipLaunchKernelGGL((conv_narrow_pair_kernel<NR>), dim3(blocks), dim3(256), 0, s, p);
+    DL4DS_LAUNCH((conv_narrow_pair_kernel<NR>), dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1581,7 +1581,7 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
     const double px = (double)x.N * p.H * p.W;
     ProfScope ps(s, std::string("conv_narrow_wgrad<") + (wide ? "16>" : "8>"), 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * px * (p.Cin + p.Cout));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, p);
+    DL4DS_LAUNCH(kern, dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
     return blocks;
 }

@@ -181,7 +181,7 @@ void launch_point(hipStream_t s, const PointParams& p, size_t lds) {
     const size_t ntiles = (p.npx + PT - 1) / PT;
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / lds));
     const int blocks = (int)std::min<size_t>(ntiles, (size_t)256 * per_cu);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
+    DL4DS_LAUNCH(kern, dim3(blocks), dim3(256), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -815,7 +815,7 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
         const int rows = KS * KS * p.Cin;
         float* wp = pad_scratch(s, (size_t)rows * sp.cw);
         ProfScope pp(s, "pad_filter", 0.0, 4.0 * rows * (p.Cout + sp.cw));
-        hipLaunchKernelGGL(pad_filter_kernel, dim3(std::min(cdiv(rows * sp.cw, 256), 1024)), dim3(256), 0, s, p.w, wp, rows, p.Cout, sp.cw);
+        DL4DS_LAUNCH(pad_filter_kernel, dim3(std::min(cdiv(rows * sp.cw, 256), 1024)), dim3(256), 0, s, p.w, wp, rows, p.Cout, sp.cw);
         HIP_CHECK(hipGetLastError());
         p.w = wp;
     }
@@ -844,7 +844,7 @@ void launch_stream(hipStream_t s, StreamParams& sp, int N) {
         sp.trace = trace_buf;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kStreamThreads), lds, s, sp);
+    DL4DS_LAUNCH(kern, dim3(grid), dim3(kStreamThreads), lds, s, sp);
     HIP_CHECK(hipGetLastError());
 #ifdef STREAM_TRACE
     if (sp.trace) {
@@ -910,7 +910,7 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
             const int rows = KS * KS * p.Cin;
             float* wp = pad_scratch(s, (size_t)rows * sp.cw);
             ProfScope pp(s, "pad_filter", 0.0, 4.0 * rows * (p.Cout + sp.cw));
-            hipLaunchKernelGGL(pad_filter_kernel, dim3(std::min(cdiv(rows * sp.cw, 256), 1024)), dim3(256), 0, s, p.w, wp, rows, p.Cout, sp.cw);
+            DL4DS_LAUNCH(pad_filter_kernel, dim3(std::min(cdiv(rows * sp.cw, 256), 1024)), dim3(256), 0, s, p.w, wp, rows, p.Cout, sp.cw);
             HIP_CHECK(hipGetLastError());
             p.w = wp;
         }
@@ -943,7 +943,7 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
             sp.trace = trace_buf;
         }
 #endif
-        hipLaunchKernelGGL(kern, dim3(8 * SX), dim3(512), GM::LDS_BYTES, s, sp);
+        DL4DS_LAUNCH(kern, dim3(8 * SX), dim3(512), GM::LDS_BYTES, s, sp);
         HIP_CHECK(hipGetLastError());
 #ifdef STREAM_TRACE
         if (sp.trace) {

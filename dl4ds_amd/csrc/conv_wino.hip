@@ -128,7 +128,7 @@ bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const T
     float* const u = wino_scratch(s, per_pass * passes);
     {
         const int total = (int)(per_pass * passes);
-        hipLaunchKernelGGL(wino_filter_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, u, in.C, out.C, KQ, NT,
+        DL4DS_LAUNCH(wino_filter_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, u, in.C, out.C, KQ, NT,
                            wp.nchunk, total, 0);
         HIP_CHECK(hipGetLastError());
     }

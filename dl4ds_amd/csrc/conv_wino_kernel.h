@@ -906,7 +906,7 @@ void launch_one(hipStream_t s, WinoParams& wp, int SX) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_kernel<KQ, NT, EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES));
         });
-        hipLaunchKernelGGL((conv_wino2_kernel<KQ, NT, EPI>), dim3(8 * SX), dim3(256), G2::LDS_BYTES, s, wp);
+        DL4DS_LAUNCH((conv_wino2_kernel<KQ, NT, EPI>), dim3(8 * SX), dim3(256), G2::LDS_BYTES, s, wp);
         HIP_CHECK(hipGetLastError());
 #ifdef WINO_TRACE
         if (wp.trace) {
@@ -936,7 +936,7 @@ void launch_one(hipStream_t s, WinoParams& wp, int SX) {
 #endif
         return;
     }
-    hipLaunchKernelGGL((conv_wino_kernel<KQ, NT, EPI>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
+    DL4DS_LAUNCH((conv_wino_kernel<KQ, NT, EPI>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
     HIP_CHECK(hipGetLastError());
 #ifdef WINO_TRACE
     if (wp.trace) {

@@ -402,7 +402,7 @@ void launch_wgrad(hipStream_t s, WinoWgradParams& wp, int SX) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<KQ, NT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES));
     });
-    hipLaunchKernelGGL((conv_wino_wgrad_kernel<KQ, NT>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
+    DL4DS_LAUNCH((conv_wino_wgrad_kernel<KQ, NT>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -461,10 +461,10 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     }
     ProfScope ps(s, "wino_wgrad_finish", 0.0, 4.0 * (double)per_k * (nslabs + 2));
     const int n4 = (int)(per_k / 4);
-    hipLaunchKernelGGL(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048)), dim3(256), 0, s, slab, sum, n4, nslabs);
+    DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048)), dim3(256), 0, s, slab, sum, n4, nslabs);
     HIP_CHECK(hipGetLastError());
     const int total = npair * KQ * NT * 64;
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, sum, dw, db, x.C, dy.C, KQ, NT,
+    DL4DS_LAUNCH(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, sum, dw, db, x.C, dy.C, KQ, NT,
                        wp.ncin, wp.ncout, accumulate, accumulate_db);
     HIP_CHECK(hipGetLastError());
     return true;

@@ -74,7 +74,7 @@ void convlstm_gates_forward(hipStream_t s, const TView& z, const TView& c_prev, 
                             const TView& out, int relu, int first) {
     const size_t total = (size_t)c.N * c.H * c.W * c.C;
     ProfScope ps(s, "convlstm_gates_fwd", 0.0, 4.0 * (double)total * 8);
-    hipLaunchKernelGGL(gates_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, z, c_prev, c, h, out, relu, first, total);
+    DL4DS_LAUNCH(gates_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, z, c_prev, c, h, out, relu, first, total);
     HIP_CHECK(hipGetLastError());
 }
 void convlstm_gates_backward(hipStream_t s, const TView& z, const TView& c_prev, const TView& c, const TView& out,
@@ -82,7 +82,7 @@ void convlstm_gates_backward(hipStream_t s, const TView& z, const TView& c_prev,
                              int first, int last) {
     const size_t total = (size_t)c.N * c.H * c.W * c.C;
     ProfScope ps(s, "convlstm_gates_bwd", 0.0, 4.0 * (double)total * 15);
-    hipLaunchKernelGGL(gates_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, z, c_prev, c, out, dout, dh_rec, dc_next,
+    DL4DS_LAUNCH(gates_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, z, c_prev, c, out, dout, dh_rec, dc_next,
                        dz, relu, first, last, total);
     HIP_CHECK(hipGetLastError());
 }

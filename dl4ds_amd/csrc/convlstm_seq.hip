@@ -527,7 +527,7 @@ void launch_fwd(hipStream_t s, const SeqParams& p, int grid) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         once = true;
     }
-    hipLaunchKernelGGL((convlstm_seq_fwd_kernel<KS, F, TR>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    DL4DS_LAUNCH((convlstm_seq_fwd_kernel<KS, F, TR>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     HIP_CHECK(hipGetLastError());
 }
 template <int KS, int F, int TR>
@@ -539,7 +539,7 @@ void launch_bwd(hipStream_t s, const SeqParams& p, int grid) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         once = true;
     }
-    hipLaunchKernelGGL((convlstm_seq_bwd_kernel<KS, F, TR>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    DL4DS_LAUNCH((convlstm_seq_bwd_kernel<KS, F, TR>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -562,7 +562,7 @@ void convlstm_gate_interleave_n(hipStream_t s, int njobs, const float* const* sr
         nmax = std::max(nmax, rows[j] * 4 * F);
     }
     if (njobs <= 0 || nmax == 0) return;
-    hipLaunchKernelGGL(gate_interleave_kernel, dim3(std::min(cdiv(nmax, 256), 512), njobs), dim3(256), 0, s, jobs, F, to_interleaved ? 1 : 0);
+    DL4DS_LAUNCH(gate_interleave_kernel, dim3(std::min(cdiv(nmax, 256), 512), njobs), dim3(256), 0, s, jobs, F, to_interleaved ? 1 : 0);
     HIP_CHECK(hipGetLastError());
 }
 void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int rows, int F, bool to_interleaved, bool accumulate) {

@@ -97,7 +97,7 @@ void conv2d_transpose_forward(hipStream_t s, const TView& in, const float* w, in
     DeconvGeom g = make_geom(KS, stride, in.C, out.C);
     Carve c = carve(g, workspace, workspace_bytes);
     const size_t total = (size_t)g.KV * g.KV * g.Cin * stride * stride * g.Cout;
-    hipLaunchKernelGGL(deconv_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, w, c.wp, g);
+    DL4DS_LAUNCH(deconv_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, w, c.wp, g);
     HIP_CHECK(hipGetLastError());
     TView outv = make_view_d2s(out.p, in.N, in.H, in.W, stride * stride * out.C, stride);
     outv.nstride = out.nstride;
@@ -114,7 +114,7 @@ void conv2d_transpose_dgrad(hipStream_t s, const TView& dz, const float* w, int 
     Carve c = carve(g, workspace, workspace_bytes);
     const int CoutP = stride * stride * dz.C;
     const size_t total = (size_t)g.KV * g.KV * g.Cin * CoutP;
-    hipLaunchKernelGGL(deconv_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, w, c.wp, g);
+    DL4DS_LAUNCH(deconv_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, w, c.wp, g);
     HIP_CHECK(hipGetLastError());
     conv2d_dgrad_weights(s, c.wp, c.wpt, g.KV, g.Cin, CoutP);
     TView dzv = make_view_d2s(dz.p, dx.N, dx.H, dx.W, CoutP, stride);
@@ -138,6 +138,6 @@ void conv2d_transpose_wgrad(hipStream_t s, const TView& x, const TView& dz, int 
     dzv.vec = dzv.vec && dz.vec && (dz.ld & 3) == 0;
     conv2d_wgrad(s, x, dzv, g.KV, c.dwp, 0, nullptr, 0, c.rest, c.rest_bytes);
     const size_t total = (size_t)KS * KS * dz.C * x.C;
-    hipLaunchKernelGGL(deconv_unpack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, c.dwp, dw, g, accumulate);
+    DL4DS_LAUNCH(deconv_unpack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, c.dwp, dw, g, accumulate);
     HIP_CHECK(hipGetLastError());
 }

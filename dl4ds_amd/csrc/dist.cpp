@@ -11,6 +11,7 @@
 // The 1/world average is folded into the Adam kernel (adam.hip).
 #include "dist.h"
 #include "runtime.h"
+#include "prof.h"
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <chrono>
@@ -45,7 +46,7 @@ void launch_standin(float* buf, size_t n, hipStream_t cs) {
     static const bool on = std::getenv("DL4DS_DIST_STANDIN") != nullptr;
     if (!on || g_world != 1) return;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 64);      // few workgroups: a collective occupies few CUs
-    hipLaunchKernelGGL(standin_for_rccl_allreduce_kernel, dim3(blocks), dim3(256), 0, cs, buf, n);
+    DL4DS_LAUNCH(standin_for_rccl_allreduce_kernel, dim3(blocks), dim3(256), 0, cs, buf, n);
     HIP_CHECK(hipGetLastError());
 }
 hipEvent_t next_ready_event() {

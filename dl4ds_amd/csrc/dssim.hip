@@ -615,26 +615,26 @@ void dssim_forward_backward(hipStream_t s, const float* y_true, const float* y_p
     static const Gauss gk = make_gauss();
     ProfScope ps(s, "dssim", 0.0, 4.0 * (double)n * 8);
     const int nb = (int)std::min<size_t>(l.nb_mm, cdivz(n, 256));
-    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n, pf, pi);
-    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
+    DL4DS_LAUNCH(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n, pf, pi);
+    DL4DS_LAUNCH(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
     const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
     const int nbf = N * C * txo * tyo;
-    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(nbf), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txo, tyo, gk, st, dmu, da,
+    DL4DS_LAUNCH(ssim_fwd_kernel, dim3(nbf), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txo, tyo, gk, st, dmu, da,
                        db, part);
     float* part2 = reinterpret_cast<float*>(base + l.part2);
-    hipLaunchKernelGGL(compact_partials_kernel<3>, dim3(COMPACT_G), dim3(256), 0, s, part, nbf, part2);
-    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(256), 0, s, part2, COMPACT_G, st);
+    DL4DS_LAUNCH(compact_partials_kernel<3>, dim3(COMPACT_G), dim3(256), 0, s, part, nbf, part2);
+    DL4DS_LAUNCH(sum3_kernel, dim3(1), dim3(256), 0, s, part2, COMPACT_G, st);
     const float inv_m = 1.f / (float)msz;
     const float coef = -0.5f * weight * inv_m;
     int nbb = 0;
     if (dpred) {
         const int txi = cdiv(W, TS), tyi = cdiv(H, TS);
         nbb = N * C * txi * tyi;
-        hipLaunchKernelGGL(ssim_bwd_kernel, dim3(nbb), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txi, tyi, gk, st, dmu, da,
+        DL4DS_LAUNCH(ssim_bwd_kernel, dim3(nbb), dim3(256), 0, s, y_true, y_pred, H, W, C, Ho, Wo, txi, tyi, gk, st, dmu, da,
                            db, coef, dpred, 1, part);
     }
-    if (nbb) hipLaunchKernelGGL(compact_partials_kernel<1>, dim3(COMPACT_G), dim3(256), 0, s, part, nbb, part2);
-    hipLaunchKernelGGL(dssim_finish_kernel, dim3(1), dim3(256), 0, s, part2, nbb ? COMPACT_G : 0, st, weight, inv_m, coef, dpred,
+    if (nbb) DL4DS_LAUNCH(compact_partials_kernel<1>, dim3(COMPACT_G), dim3(256), 0, s, part, nbb, part2);
+    DL4DS_LAUNCH(dssim_finish_kernel, dim3(1), dim3(256), 0, s, part2, nbb ? COMPACT_G : 0, st, weight, inv_m, coef, dpred,
                        loss_out, accumulate_loss);
     HIP_CHECK(hipGetLastError());
 }
@@ -663,8 +663,8 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
     static const Gauss gk = make_gauss();
     ProfScope ps(s, "msdssim", 0.0, 4.0 * (double)n0 * 12);
     const int nb = (int)std::min<size_t>(l.nb_mm, cdivz(n0, 256));
-    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n0, pf, pi);
-    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
+    DL4DS_LAUNCH(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n0, pf, pi);
+    DL4DS_LAUNCH(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
     auto ew = [](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 256), 8192)); };
     const float* xk[MS_SCALES];
     const float* qk[MS_SCALES];
@@ -674,9 +674,9 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
         const size_t n = (size_t)N * l.d.H[k] * l.d.W[k] * C;
         float* xd = imgs + l.img_off[k];
         float* qd = xd + n;
-        hipLaunchKernelGGL(ms_pool_kernel, dim3(ew(n)), dim3(256), 0, s, xk[k - 1], xd, N, l.d.H[k - 1], l.d.W[k - 1], l.d.H[k],
+        DL4DS_LAUNCH(ms_pool_kernel, dim3(ew(n)), dim3(256), 0, s, xk[k - 1], xd, N, l.d.H[k - 1], l.d.W[k - 1], l.d.H[k],
                            l.d.W[k], C, st, k == 1 ? 1 : 0);
-        hipLaunchKernelGGL(ms_pool_kernel, dim3(ew(n)), dim3(256), 0, s, qk[k - 1], qd, N, l.d.H[k - 1], l.d.W[k - 1], l.d.H[k],
+        DL4DS_LAUNCH(ms_pool_kernel, dim3(ew(n)), dim3(256), 0, s, qk[k - 1], qd, N, l.d.H[k - 1], l.d.W[k - 1], l.d.H[k],
                            l.d.W[k], C, st, k == 1 ? 2 : 0);
         xk[k] = xd; qk[k] = qd;
     }
@@ -684,12 +684,12 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
     for (int k = 0; k < MS_SCALES; ++k) {
         const int Ho = l.d.H[k] - KF + 1, Wo = l.d.W[k] - KF + 1;
         const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
-        hipLaunchKernelGGL(ms_ssim_kernel<0>, dim3(NC * txo * tyo), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, l.d.H[k], l.d.W[k],
+        DL4DS_LAUNCH(ms_ssim_kernel<0>, dim3(NC * txo * tyo), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, l.d.H[k], l.d.W[k],
                            C, Ho, Wo, txo, tyo, gk, st, nullptr, nullptr, nullptr, nullptr, nullptr, part);
-        hipLaunchKernelGGL(ms_means_kernel, dim3(NC), dim3(64), 0, s, part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo),
+        DL4DS_LAUNCH(ms_means_kernel, dim3(NC), dim3(64), 0, s, part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo),
                            means + (size_t)k * NC, means + (size_t)(MS_SCALES + k) * NC);
     }
-    hipLaunchKernelGGL(ms_combine_kernel, dim3(1), dim3(256), 0, s, means, means + (size_t)MS_SCALES * NC, NC, weight, gw,
+    DL4DS_LAUNCH(ms_combine_kernel, dim3(1), dim3(256), 0, s, means, means + (size_t)MS_SCALES * NC, NC, weight, gw,
                        gw + (size_t)MS_SCALES * NC, loss_out, accumulate_loss);
     HIP_CHECK(hipGetLastError());
     if (!dpred) return;
@@ -702,25 +702,25 @@ void msdssim_forward_backward(hipStream_t s, const float* y_true, const float* y
         float* da = dmu + msz;
         float* db = da + msz;
         const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
-        hipLaunchKernelGGL(ms_ssim_kernel<1>, dim3(NC * txo * tyo), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, Hk, Wk, C, Ho, Wo,
+        DL4DS_LAUNCH(ms_ssim_kernel<1>, dim3(NC * txo * tyo), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, Hk, Wk, C, Ho, Wo,
                            txo, tyo, gk, st, gw + (size_t)k * NC, gw + (size_t)(MS_SCALES + k) * NC, dmu, da, db,
                            gcp + l.gcp_off[k] * 2);
         gcp_total = std::max(gcp_total, l.gcp_off[k] + (size_t)NC * txo * tyo);
         const int txi = cdiv(Wk, TS), tyi = cdiv(Hk, TS);
         float* gk_img = grads + l.grad_off[k];
-        hipLaunchKernelGGL(ms_bwd_kernel, dim3(NC * txi * tyi), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, Hk, Wk, C, Ho, Wo, txi,
+        DL4DS_LAUNCH(ms_bwd_kernel, dim3(NC * txi * tyi), dim3(256), 0, s, xk[k], qk[k], k == 0 ? 1 : 0, Hk, Wk, C, Ho, Wo, txi,
                            tyi, gk, st, dmu, da, db, gk_img);
         if (k < MS_SCALES - 1) {
             const size_t n = (size_t)N * Hk * Wk * C;
-            hipLaunchKernelGGL(ms_unpool_add_kernel, dim3(ew(n)), dim3(256), 0, s, gk_img, grads + l.grad_off[k + 1], N, Hk, Wk,
+            DL4DS_LAUNCH(ms_unpool_add_kernel, dim3(ew(n)), dim3(256), 0, s, gk_img, grads + l.grad_off[k + 1], N, Hk, Wk,
                                l.d.H[k + 1], l.d.W[k + 1], C);
         }
     }
     const int nba = (int)std::min<size_t>(cdivz(n0, 256), 2048);
-    hipLaunchKernelGGL(ms_apply_kernel, dim3(nba), dim3(256), 0, s, grads + l.grad_off[0], dpred, n0, 1, part);
+    DL4DS_LAUNCH(ms_apply_kernel, dim3(nba), dim3(256), 0, s, grads + l.grad_off[0], dpred, n0, 1, part);
     float* part2 = reinterpret_cast<float*>(base + l.part2);
-    hipLaunchKernelGGL(compact_partials_kernel<2>, dim3(COMPACT_G), dim3(256), 0, s, gcp, (int)gcp_total, part2);
-    hipLaunchKernelGGL(ms_finish_kernel, dim3(1), dim3(256), 0, s, part, nba, part2, COMPACT_G, st, dpred);
+    DL4DS_LAUNCH(compact_partials_kernel<2>, dim3(COMPACT_G), dim3(256), 0, s, gcp, (int)gcp_total, part2);
+    DL4DS_LAUNCH(ms_finish_kernel, dim3(1), dim3(256), 0, s, part, nba, part2, COMPACT_G, st, dpred);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -825,11 +825,11 @@ void image_metrics(hipStream_t s, const float* y_true, const float* y_pred, int 
     static const Gauss gk = make_gauss();
     ProfScope ps(s, "image_metrics", 0.0, 4.0 * (double)n0 * 6);
     const int nb = (int)std::min<size_t>(512, cdivz(n0, 256));
-    hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n0, pf, pi);
-    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
-    hipLaunchKernelGGL(met_pair_partial_kernel, dim3(MET_CHUNKS, N), dim3(256), 0, s, y_true, y_pred, per, partial);
-    hipLaunchKernelGGL(met_pair_finish_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, partial, MET_CHUNKS, N, (double)per, pair3);
-    hipLaunchKernelGGL(met_grid_kernel, dim3((unsigned)std::min<size_t>(cdivz(per, 256), 4096)), dim3(256), 0, s, y_true, y_pred, N,
+    DL4DS_LAUNCH(minmax_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, n0, pf, pi);
+    DL4DS_LAUNCH(minmax_finish_kernel, dim3(1), dim3(256), 0, s, pf, pi, nb, st);
+    DL4DS_LAUNCH(met_pair_partial_kernel, dim3(MET_CHUNKS, N), dim3(256), 0, s, y_true, y_pred, per, partial);
+    DL4DS_LAUNCH(met_pair_finish_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, partial, MET_CHUNKS, N, (double)per, pair3);
+    DL4DS_LAUNCH(met_grid_kernel, dim3((unsigned)std::min<size_t>(cdivz(per, 256), 4096)), dim3(256), 0, s, y_true, y_pred, N,
                        per, grid_out_dev);
     // SSIM per pair = mean over channels of the per-plane mean SSIM (needs an 11x11 window)
     const int Ho = H - KF + 1, Wo = W - KF + 1;
@@ -838,14 +838,14 @@ void image_metrics(hipStream_t s, const float* y_true, const float* y_pred, int 
     if (Ho > 0 && Wo > 0) {
         const int txo = cdiv(Wo, TS), tyo = cdiv(Ho, TS);
         means = tile_part + (size_t)NC * txo * tyo * 2;
-        hipLaunchKernelGGL(ms_ssim_kernel<0>, dim3(NC * txo * tyo), dim3(256), 0, s, y_true, y_pred, 0, H, W, C, Ho, Wo, txo, tyo, gk, st,
+        DL4DS_LAUNCH(ms_ssim_kernel<0>, dim3(NC * txo * tyo), dim3(256), 0, s, y_true, y_pred, 0, H, W, C, Ho, Wo, txo, tyo, gk, st,
                            nullptr, nullptr, nullptr, nullptr, nullptr, tile_part);
-        hipLaunchKernelGGL(ms_means_kernel, dim3(NC), dim3(64), 0, s, tile_part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo), means,
+        DL4DS_LAUNCH(ms_means_kernel, dim3(NC), dim3(64), 0, s, tile_part, txo * tyo, NC, 1.f / ((float)Ho * (float)Wo), means,
                            means + NC);
     }
     HIP_CHECK(hipGetLastError());
     // assemble [N][4] and the range on the device (tiny)
-    hipLaunchKernelGGL(met_assemble_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, pair3, means, N, C, (Ho > 0 && Wo > 0) ? 1 : 0, st, pair_out_dev,
+    DL4DS_LAUNCH(met_assemble_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, pair3, means, N, C, (Ho > 0 && Wo > 0) ? 1 : 0, st, pair_out_dev,
                        range_out_dev);
     HIP_CHECK(hipGetLastError());
 }

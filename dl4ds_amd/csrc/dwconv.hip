@@ -225,8 +225,8 @@ void dwconv_forward(hipStream_t s, const float* x, const float* k, const float* 
     const bool v4 = vec_ok(C, {x, k, bias, y});
     const size_t total = (size_t)N * H * ((W + DW_PW - 1) / DW_PW) * (C / (v4 ? 4 : 1));
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 1 << 20));
-    if (v4) hipLaunchKernelGGL((dwconv_kernel<7, 4>), dim3(blocks), dim3(256), 0, s, x, k, bias, y, N, H, W, C, flip, accumulate);
-    else hipLaunchKernelGGL((dwconv_kernel<7, 1>), dim3(blocks), dim3(256), 0, s, x, k, bias, y, N, H, W, C, flip, accumulate);
+    if (v4) DL4DS_LAUNCH((dwconv_kernel<7, 4>), dim3(blocks), dim3(256), 0, s, x, k, bias, y, N, H, W, C, flip, accumulate);
+    else DL4DS_LAUNCH((dwconv_kernel<7, 1>), dim3(blocks), dim3(256), 0, s, x, k, bias, y, N, H, W, C, flip, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -241,10 +241,10 @@ void dwconv_wgrad(hipStream_t s, const float* x, const float* dy, float* dk, flo
     ProfScope ps(s, "dwconv_wgrad", 2.0 * KS * KS * (double)npix * C, 8.0 * (double)npix * C);
     const bool v4 = vec_ok(C, {x, dy, ws});
     const WgradGeom g = wgrad_geom((size_t)N * H * ((W + DW_PW - 1) / DW_PW), C, v4 ? 4 : 1, KS);
-    if (v4) hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 4>), dim3(g.nchunks, g.groups), dim3(256), 0, s, x, dy, ws, N, H, W, C, g.CPB, g.LANES, g.chunk);
-    else hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 1>), dim3(g.nchunks, g.groups), dim3(256), 0, s, x, dy, ws, N, H, W, C, g.CPB, g.LANES, g.chunk);
+    if (v4) DL4DS_LAUNCH((dwconv_wgrad_kernel<7, 4>), dim3(g.nchunks, g.groups), dim3(256), 0, s, x, dy, ws, N, H, W, C, g.CPB, g.LANES, g.chunk);
+    else DL4DS_LAUNCH((dwconv_wgrad_kernel<7, 1>), dim3(g.nchunks, g.groups), dim3(256), 0, s, x, dy, ws, N, H, W, C, g.CPB, g.LANES, g.chunk);
     HIP_CHECK(hipGetLastError());
     const int n = (KS * KS + 1) * C;
-    hipLaunchKernelGGL(dwconv_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, g.nchunks, KS * KS, C, dk, db, accumulate);
+    DL4DS_LAUNCH(dwconv_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, g.nchunks, KS * KS, C, dk, db, accumulate);
     HIP_CHECK(hipGetLastError());
 }

@@ -480,7 +480,7 @@ void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TVi
     if (!db && y.p && dz.p && plain_contig(dy) && plain_contig(y) && plain_contig(dz) && (total & 3) == 0 &&
         ((((uintptr_t)dy.p) | ((uintptr_t)y.p) | ((uintptr_t)dz.p)) & 15) == 0) {
         ProfScope ps(s, "relu_mask_flat", 0.0, 12.0 * (double)total);
-        hipLaunchKernelGGL(relu_mask_flat4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
+        DL4DS_LAUNCH(relu_mask_flat4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
                            reinterpret_cast<const float4*>(dy.p), reinterpret_cast<const float4*>(y.p),
                            reinterpret_cast<float4*>(dz.p), total / 4);
         HIP_CHECK(hipGetLastError());
@@ -497,14 +497,14 @@ void bias_act_backward(hipStream_t s, const TView& dy, const TView& y, const TVi
     dim3 grid((unsigned)nb, (unsigned)cdiv(dy.C, TX));
     ProfScope ps(s, "bias_act_bwd", 0.0, 4.0 * (double)npix * dy.C * (1 + (y.p ? 1 : 0) + (dz.p ? 1 : 0)));
     switch (TX) {
-        case 8: hipLaunchKernelGGL(bias_act_bwd_kernel<8>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
-        case 16: hipLaunchKernelGGL(bias_act_bwd_kernel<16>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
-        case 32: hipLaunchKernelGGL(bias_act_bwd_kernel<32>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
-        default: hipLaunchKernelGGL(bias_act_bwd_kernel<64>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+        case 8: DL4DS_LAUNCH(bias_act_bwd_kernel<8>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+        case 16: DL4DS_LAUNCH(bias_act_bwd_kernel<16>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+        case 32: DL4DS_LAUNCH(bias_act_bwd_kernel<32>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
+        default: DL4DS_LAUNCH(bias_act_bwd_kernel<64>, grid, dim3(256), 0, s, dy, y, dz, partial, npix); break;
     }
     HIP_CHECK(hipGetLastError());
     if (db) {
-        hipLaunchKernelGGL(reduce_slabs_kernel2, dim3(cdiv(dy.C, 256)), dim3(256), 0, s, partial, db,
+        DL4DS_LAUNCH(reduce_slabs_kernel2, dim3(cdiv(dy.C, 256)), dim3(256), 0, s, partial, db,
                            (size_t)dy.C, nb, accumulate_db);
         HIP_CHECK(hipGetLastError());
     }
@@ -516,7 +516,7 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
     if (total == 0) return;
     ProfScope ps(s, "view_axpy", 0.0, 4.0 * (double)total * (2 + (accumulate ? 1 : 0)));
     if (plain_contig(src) && plain_contig(dst) && (total & 3) == 0 && ((((uintptr_t)src.p) | ((uintptr_t)dst.p)) & 15) == 0) {
-        hipLaunchKernelGGL(flat_axpy4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
+        DL4DS_LAUNCH(flat_axpy4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s,
                            reinterpret_cast<const float4*>(src.p), reinterpret_cast<float4*>(dst.p), alpha, accumulate, total / 4);
     } else if (src.d2s <= 1 && dst.d2s <= 1 && (src.C & 3) == 0 && (src.ld & 3) == 0 && (dst.ld & 3) == 0 &&
                ((((uintptr_t)src.p) | ((uintptr_t)dst.p)) & 15) == 0 && src.nstride == (size_t)src.H * src.W * src.ld &&
@@ -524,7 +524,7 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
         const int c4n = src.C / 4;
         const int blocks = ew_blocks(total / 4);
         const size_t stride = (size_t)blocks * 256;
-        hipLaunchKernelGGL(strided_axpy4_kernel, dim3(blocks), dim3(256), 0, s, src.p, src.ld, dst.p, dst.ld, c4n,
+        DL4DS_LAUNCH(strided_axpy4_kernel, dim3(blocks), dim3(256), 0, s, src.p, src.ld, dst.p, dst.ld, c4n,
                            stride / (size_t)c4n, (int)(stride % (size_t)c4n), alpha, accumulate, total / 4);
     } else if (src.d2s <= 1 && dst.d2s <= 1 && !src.sc && !dst.sc && src.nstride == (size_t)src.H * src.W * src.ld &&
                dst.nstride == (size_t)dst.H * dst.W * dst.ld) {
@@ -536,10 +536,10 @@ void view_axpy(hipStream_t s, const TView& src, const TView& dst, float alpha, i
         const int blocks = ew_blocks(totalv);
         const size_t stride = (size_t)blocks * 256;
         auto kern = v2 ? strided_axpy_small_kernel<2> : strided_axpy_small_kernel<1>;
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, src.p, src.ld, dst.p, dst.ld, cvn, stride / (size_t)cvn,
+        DL4DS_LAUNCH(kern, dim3(blocks), dim3(256), 0, s, src.p, src.ld, dst.p, dst.ld, cvn, stride / (size_t)cvn,
                            (int)(stride % (size_t)cvn), alpha, accumulate, totalv);
     } else {
-        hipLaunchKernelGGL(view_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, dst, alpha, accumulate, total);
+        DL4DS_LAUNCH(view_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, dst, alpha, accumulate, total);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -558,10 +558,10 @@ void view_axpy_masked(hipStream_t s, const TView& src, const TView& mask, const 
         const int c4n = src.C / 4;
         const int blocks = ew_blocks(total / 4);
         const size_t stride = (size_t)blocks * 256;
-        hipLaunchKernelGGL(strided_masked_axpy4_kernel, dim3(blocks), dim3(256), 0, s, src.p, src.ld, mask.p, mask.ld, dst.p,
+        DL4DS_LAUNCH(strided_masked_axpy4_kernel, dim3(blocks), dim3(256), 0, s, src.p, src.ld, mask.p, mask.ld, dst.p,
                            dst.ld, c4n, stride / (size_t)c4n, (int)(stride % (size_t)c4n), accumulate, total / 4);
     } else {
-        hipLaunchKernelGGL(view_masked_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, mask, dst, accumulate, total);
+        DL4DS_LAUNCH(view_masked_axpy_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, src, mask, dst, accumulate, total);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -628,7 +628,7 @@ void concat_split(hipStream_t s, const float* src, int ld, size_t npx, const Con
     const int blocks = ew_blocks(totalv);
     const size_t stride = (size_t)blocks * 256;
     auto kern = even ? concat_split_kernel<2> : concat_split_kernel<1>;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, a, cvn, stride / (size_t)cvn, (int)(stride % (size_t)cvn), totalv);
+    DL4DS_LAUNCH(kern, dim3(blocks), dim3(256), 0, s, a, cvn, stride / (size_t)cvn, (int)(stride % (size_t)cvn), totalv);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -682,7 +682,7 @@ void concat_join(hipStream_t s, float* dst, int ld, size_t npx, const ConcatSlic
     const int blocks = ew_blocks(totalv);
     const size_t stride = (size_t)blocks * 256;
     auto kern = even ? concat_join_kernel<2> : concat_join_kernel<1>;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, a, cvn, stride / (size_t)cvn, (int)(stride % (size_t)cvn), totalv);
+    DL4DS_LAUNCH(kern, dim3(blocks), dim3(256), 0, s, a, cvn, stride / (size_t)cvn, (int)(stride % (size_t)cvn), totalv);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -690,32 +690,32 @@ void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, siz
     if (n == 0) return;
     ProfScope ps(s, "masked_axpy", 0.0, 4.0 * (double)n * (3 + (accumulate ? 1 : 0)));
     if ((n & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dst)) & 15) == 0)
-        hipLaunchKernelGGL(masked_axpy4_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
+        DL4DS_LAUNCH(masked_axpy4_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
                            reinterpret_cast<const float4*>(y), reinterpret_cast<float4*>(dst), n / 4, accumulate);
     else
-        hipLaunchKernelGGL(masked_axpy1_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, y, dst, n, accumulate);
+        DL4DS_LAUNCH(masked_axpy1_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, y, dst, n, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 
 void add_act(hipStream_t s, const float* a, const float* b, float* out, size_t n, int relu) {
     ProfScope ps(s, "add_act", 0.0, 12.0 * (double)n);
-    hipLaunchKernelGGL(add_act_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, out, n, relu);
+    DL4DS_LAUNCH(add_act_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, out, n, relu);
     HIP_CHECK(hipGetLastError());
 }
 void act_forward(hipStream_t s, const float* x, float* y, size_t n, int kind) {
     ProfScope ps(s, "act_fwd", 0.0, 8.0 * (double)n);
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n, kind);
+    DL4DS_LAUNCH(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n, kind);
     HIP_CHECK(hipGetLastError());
 }
 void act_backward(hipStream_t s, const float* x, const float* dy, float* dx, size_t n, int kind, int accumulate) {
     ProfScope ps(s, "act_bwd", 0.0, 12.0 * (double)n);
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, dy, dx, n, kind, accumulate);
+    DL4DS_LAUNCH(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, dy, dx, n, kind, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 void fill(hipStream_t s, float* p, size_t n, float v) {
     if (n == 0) return;
     ProfScope ps(s, "fill", 0.0, 4.0 * (double)n);
-    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, n, v);
+    DL4DS_LAUNCH(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, n, v);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -734,7 +734,7 @@ void maxpool2_forward(hipStream_t s, const TView& x, const TView& y) {
     DL4DS_REQUIRE(y.H == x.H / 2 && y.W == x.W / 2 && y.C == x.C && y.N == x.N, "maxpool2: shapes");
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     ProfScope ps(s, "maxpool2_fwd", 0.0, 4.0 * (double)total * 5);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, total);
+    DL4DS_LAUNCH(maxpool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, total);
     HIP_CHECK(hipGetLastError());
 }
 void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TView& dy, const TView& dx, int accumulate,
@@ -743,21 +743,21 @@ void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TVie
                   "maxpool2 backward with odd sizes needs a pre-zeroed accumulate target");
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     ProfScope ps(s, "maxpool2_bwd", 0.0, 4.0 * (double)total * (2 + 4 + 4 + (accumulate ? 4 : 0)));
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, dy, dx, accumulate, relu_mask, total);
+    DL4DS_LAUNCH(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, dy, dx, accumulate, relu_mask, total);
     HIP_CHECK(hipGetLastError());
 }
 
 void resize_bilinear_forward(hipStream_t s, const TView& x, const TView& y) {
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     ProfScope ps(s, "resize_bilinear_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
-    hipLaunchKernelGGL(resize_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
+    DL4DS_LAUNCH(resize_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
                        (float)x.W / (float)y.W, total);
     HIP_CHECK(hipGetLastError());
 }
 void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate) {
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
     ProfScope ps(s, "resize_bilinear_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
+    DL4DS_LAUNCH(resize_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
                        (float)dx.W / (float)dy.W, accumulate, total);
     HIP_CHECK(hipGetLastError());
 }
@@ -765,14 +765,14 @@ void resize_bilinear_backward(hipStream_t s, const TView& dy, const TView& dx, i
 void resize_nearest_forward(hipStream_t s, const TView& x, const TView& y) {
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     ProfScope ps(s, "resize_nearest_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
-    hipLaunchKernelGGL(resize_nearest_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
+    DL4DS_LAUNCH(resize_nearest_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, (float)x.H / (float)y.H,
                        (float)x.W / (float)y.W, total);
     HIP_CHECK(hipGetLastError());
 }
 void resize_nearest_backward(hipStream_t s, const TView& dy, const TView& dx, int accumulate) {
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
     ProfScope ps(s, "resize_nearest_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
-    hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
+    DL4DS_LAUNCH(resize_nearest_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, (float)dx.H / (float)dy.H,
                        (float)dx.W / (float)dy.W, accumulate, total);
     HIP_CHECK(hipGetLastError());
 }
@@ -781,7 +781,7 @@ void localconv_forward(hipStream_t s, const TView& x, const float* w, const floa
     DL4DS_REQUIRE(x.C <= kLcMax && y.C <= kLcMax, "localconv: at most 8 channels in/out");
     const size_t npix = (size_t)x.N * x.H * x.W;
     ProfScope ps(s, "localconv_fwd", 2.0 * npix * x.C * y.C, 4.0 * ((double)npix * (x.C + y.C) + (double)x.H * x.W * (x.C + 1) * y.C));
-    hipLaunchKernelGGL(localconv_fwd_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, w, b, y, npix);
+    DL4DS_LAUNCH(localconv_fwd_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, w, b, y, npix);
     HIP_CHECK(hipGetLastError());
 }
 void localconv_backward(hipStream_t s, const TView& x, const float* w, const TView& dy, const TView& dx,
@@ -792,9 +792,9 @@ void localconv_backward(hipStream_t s, const TView& x, const float* w, const TVi
                  4.0 * ((double)nhw * x.N * (2 * x.C + dy.C) + 2.0 * (double)nhw * (x.C + 1) * dy.C));
     const dim3 grid((unsigned)cdivz(nhw, 64));
     if (x.C == 2 && dy.C == 2)      // LocalizedConvBlock (blocks.py:312-336): TransitionBlock(2) -> LocallyConnected2D(2)
-        hipLaunchKernelGGL((localconv_bwd_kernel<2, 2>), grid, dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db, accumulate_dw);
+        DL4DS_LAUNCH((localconv_bwd_kernel<2, 2>), grid, dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db, accumulate_dw);
     else
-        hipLaunchKernelGGL((localconv_bwd_kernel<0, 0>), grid, dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db, accumulate_dw);
+        DL4DS_LAUNCH((localconv_bwd_kernel<0, 0>), grid, dim3(256), 0, s, x, w, dy, dx, accumulate_dx, dw, db, accumulate_dw);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -825,7 +825,7 @@ void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int 
     if (total == 0) return;
     ProfScope pp(s, "repeat_time_fwd", 0.0, 4.0 * (double)total * (1 + T));
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(repeat_time_fwd_kernel, dim3(blocks), dim3(256), 0, s, in, out, ps, T, total);
+    DL4DS_LAUNCH(repeat_time_fwd_kernel, dim3(blocks), dim3(256), 0, s, in, out, ps, T, total);
     HIP_CHECK(hipGetLastError());
 }
 // ... straight into a channel slice of a wider buffer (the Concatenate that follows, GTensor::alias_of): out is a view with pixel
@@ -861,9 +861,9 @@ void repeat_time_forward_view(hipStream_t s, const float* in, const TView& out, 
     const size_t totalv = total / V;
     const int blocks = (int)std::min<size_t>((totalv + 255) / 256, 8192);
     const int cvn = out.C / V;
-    if (V == 4) hipLaunchKernelGGL(repeat_time_fwd_view_kernel<4>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
-    else if (V == 2) hipLaunchKernelGGL(repeat_time_fwd_view_kernel<2>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
-    else hipLaunchKernelGGL(repeat_time_fwd_view_kernel<1>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
+    if (V == 4) DL4DS_LAUNCH(repeat_time_fwd_view_kernel<4>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
+    else if (V == 2) DL4DS_LAUNCH(repeat_time_fwd_view_kernel<2>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
+    else DL4DS_LAUNCH(repeat_time_fwd_view_kernel<1>, dim3(blocks), dim3(256), 0, s, in, out.p, cvn, hw, out.C, out.ld, out.nstride, T, totalv);
     HIP_CHECK(hipGetLastError());
 }
 // ... and its gradient read from a channel slice of the Concatenate's gradient (GTensor::galias): same summation order
@@ -885,7 +885,7 @@ void repeat_time_backward_view(hipStream_t s, const TView& dout, float* din, int
     if (total == 0) return;
     ProfScope pp(s, "repeat_time_bwd", 0.0, 4.0 * (double)total * (1 + T + (accumulate ? 1 : 0)));
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(repeat_time_bwd_view_kernel, dim3(blocks), dim3(256), 0, s, dout.p, din, hw, dout.C, dout.ld, dout.nstride, T, total,
+    DL4DS_LAUNCH(repeat_time_bwd_view_kernel, dim3(blocks), dim3(256), 0, s, dout.p, din, hw, dout.C, dout.ld, dout.nstride, T, total,
                        accumulate);
     HIP_CHECK(hipGetLastError());
 }
@@ -894,7 +894,7 @@ void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, i
     if (total == 0) return;
     ProfScope pp(s, "repeat_time_bwd", 0.0, 4.0 * (double)total * (1 + T + (accumulate ? 1 : 0)));
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(repeat_time_bwd_kernel, dim3(blocks), dim3(256), 0, s, dout, din, ps, T, total, accumulate);
+    DL4DS_LAUNCH(repeat_time_bwd_kernel, dim3(blocks), dim3(256), 0, s, dout, din, ps, T, total, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1042,18 +1042,18 @@ void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const i
     if (dense(x) && dense(y) && !x.sc && ky == kx && (ky == 2 || ky == 4) && total / 4 < (1ull << 32) && !getenv("DL4DS_NO_RESIZE_FWDK")) {
         ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
         auto kern = ky == 2 ? resize_table_fwdk_kernel<2> : resize_table_fwdk_kernel<4>;
-        hipLaunchKernelGGL(kern, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x.p, y.p, x.H, x.W, y.H, y.W, y.C, iy, wy, ix, wx, total / 4);
+        DL4DS_LAUNCH(kern, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x.p, y.p, x.H, x.W, y.H, y.W, y.C, iy, wy, ix, wx, total / 4);
         HIP_CHECK(hipGetLastError());
         return;
     }
     if (x.vec && y.vec && x.d2s <= 1 && y.d2s <= 1 && !x.sc && total / 4 < (1ull << 32)) {
         ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
-        hipLaunchKernelGGL(resize_table_fwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x, y, iy, wy, ix, wx, ky, kx, total / 4);
+        DL4DS_LAUNCH(resize_table_fwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x, y, iy, wy, ix, wx, ky, kx, total / 4);
         HIP_CHECK(hipGetLastError());
         return;
     }
     ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
-    hipLaunchKernelGGL(resize_table_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, iy, wy, ix, wx, ky, kx, total);
+    DL4DS_LAUNCH(resize_table_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, iy, wy, ix, wx, ky, kx, total);
     HIP_CHECK(hipGetLastError());
 }
 void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
@@ -1061,12 +1061,12 @@ void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, cons
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
     if (dy.vec && dx.vec && dy.d2s <= 1 && dx.d2s <= 1 && !dy.sc && total / 4 < (1ull << 32)) {
         ProfScope ps(s, "resize_table_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
-        hipLaunchKernelGGL(resize_table_bwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate,
+        DL4DS_LAUNCH(resize_table_bwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate,
                            total / 4);
         HIP_CHECK(hipGetLastError());
         return;
     }
     ProfScope ps(s, "resize_table_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
-    hipLaunchKernelGGL(resize_table_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate, total);
+    DL4DS_LAUNCH(resize_table_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate, total);
     HIP_CHECK(hipGetLastError());
 }

@@ -218,7 +218,7 @@ struct FoldedConvOp : GOp {
         {
             ProfScope ps(g.stream, "fold_weights", 2.0 * (K + 1) * ncol() * Cm, 4.0 * ((double)K * r * r * Cm + (double)K * ncol()));
             const int total = (K + 1) * ncol();
-            hipLaunchKernelGGL(fold_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, g.stream, g.wp(w1),
+            DL4DS_LAUNCH(fold_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, g.stream, g.wp(w1),
                                b1 >= 0 ? g.wp(b1) : nullptr, g.wp(w2), b2 >= 0 ? g.wp(b2) : nullptr, weff, beff, K, r * r, Cm, Co);
             HIP_CHECK(hipGetLastError());
         }
@@ -262,11 +262,11 @@ struct FoldedConvOp : GOp {
             conv2d_wgrad(g.stream, g.view(in, c.B, false, c.b_off, c.b_cnt), dY, KS, dweff, 0, dbeff, 0, g.workspace, g.workspace_bytes);
             ProfScope ps(g.stream, "unfold_weight_grads", 4.0 * K * ncol() * Cm, 4.0 * 3 * (double)K * R2 * Cm);
             const int n1 = (K + 1) * R2 * Cm;
-            hipLaunchKernelGGL(unfold_w1_kernel, dim3((n1 + 255) / 256), dim3(256), 0, g.stream, dweff, dbeff, g.wp(w2), g.gp(w1),
+            DL4DS_LAUNCH(unfold_w1_kernel, dim3((n1 + 255) / 256), dim3(256), 0, g.stream, dweff, dbeff, g.wp(w2), g.gp(w1),
                                b1 >= 0 ? g.gp(b1) : nullptr, K, R2, Cm, Co, (int)g.params[w1].grad_written,
                                b1 >= 0 ? (int)g.params[b1].grad_written : 0);
             const int n2 = Cm * Co + Co;
-            hipLaunchKernelGGL(unfold_w2_kernel, dim3((n2 + 3) / 4), dim3(256), 0, g.stream, dweff, dbeff, g.wp(w1),
+            DL4DS_LAUNCH(unfold_w2_kernel, dim3((n2 + 3) / 4), dim3(256), 0, g.stream, dweff, dbeff, g.wp(w1),
                                b1 >= 0 ? g.wp(b1) : nullptr, g.gp(w2), b2 >= 0 ? g.gp(b2) : nullptr, K, R2, Cm, Co,
                                (int)g.params[w2].grad_written, b2 >= 0 ? (int)g.params[b2].grad_written : 0);
             HIP_CHECK(hipGetLastError());
@@ -339,7 +339,7 @@ struct SliceOp : GOp {
         const GTensor& ti = g.tensors[in];
         const GTensor& to = g.tensors[out];
         const size_t total = to.per_sample() * B;
-        hipLaunchKernelGGL(slice_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, ti.data, to.data, ti.H, ti.W, ti.C,
+        DL4DS_LAUNCH(slice_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, ti.data, to.data, ti.H, ti.W, ti.C,
                            to.H, to.W, oy, ox, step, total);
         HIP_CHECK(hipGetLastError());
     }
@@ -349,7 +349,7 @@ struct SliceOp : GOp {
         const GTensor& to = g.tensors[out];
         const int cnt = c.b_cnt < 0 ? c.B : c.b_cnt;
         const size_t total = ti.per_sample() * cnt;
-        hipLaunchKernelGGL(slice_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream,
+        DL4DS_LAUNCH(slice_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream,
                            to.grad + (size_t)c.b_off * to.per_sample(), ti.grad + (size_t)c.b_off * ti.per_sample(), ti.H, ti.W,
                            ti.C, to.H, to.W, oy, ox, step, total, (int)ti.grad_written);
         HIP_CHECK(hipGetLastError());
@@ -367,7 +367,7 @@ struct PadOp : GOp {
         const GTensor& ti = g.tensors[in];
         const GTensor& to = g.tensors[out];
         const size_t total = to.per_sample() * B;
-        hipLaunchKernelGGL(slice_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, ti.data, to.data, to.H, to.W, to.C, ti.H,
+        DL4DS_LAUNCH(slice_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, ti.data, to.data, to.H, to.W, to.C, ti.H,
                            ti.W, 0, 0, 1, total, 0);
         HIP_CHECK(hipGetLastError());
     }
@@ -379,7 +379,7 @@ struct PadOp : GOp {
         const size_t total = ti.per_sample() * cnt;
         float* dx = ti.grad + (size_t)c.b_off * ti.per_sample();
         const float* dy = to.grad + (size_t)c.b_off * to.per_sample();
-        hipLaunchKernelGGL(slice_acc_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, dy, dx, to.H, to.W, to.C, ti.H, ti.W, total,
+        DL4DS_LAUNCH(slice_acc_kernel, dim3(ew_grid(total)), dim3(256), 0, g.stream, dy, dx, to.H, to.W, to.C, ti.H, ti.W, total,
                            (int)ti.grad_written);
         HIP_CHECK(hipGetLastError());
         g.tensors[in].grad_written = true;

@@ -184,14 +184,14 @@ void gap_forward(hipStream_t s, const float* x, float* out, int N, int HW, int C
     const bool v4 = (C & 3) == 0 && (((uintptr_t)x) & 15) == 0;
     const int CP = v4 ? C / 4 : C;
     if (ws == nullptr || ws_bytes < gap_workspace_bytes(N, C) || CP > 256 || HW < 4096) {
-        hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, C), dim3(256), 0, s, x, out, HW, C);
+        DL4DS_LAUNCH(gap_fwd_kernel, dim3(N, C), dim3(256), 0, s, x, out, HW, C);
         HIP_CHECK(hipGetLastError());
         return;
     }
-    if (v4) hipLaunchKernelGGL(gap_partial_kernel<4>, dim3(GAP_CHUNKS, N), dim3(256), 0, s, x, ws, HW, C);
-    else hipLaunchKernelGGL(gap_partial_kernel<1>, dim3(GAP_CHUNKS, N), dim3(256), 0, s, x, ws, HW, C);
+    if (v4) DL4DS_LAUNCH(gap_partial_kernel<4>, dim3(GAP_CHUNKS, N), dim3(256), 0, s, x, ws, HW, C);
+    else DL4DS_LAUNCH(gap_partial_kernel<1>, dim3(GAP_CHUNKS, N), dim3(256), 0, s, x, ws, HW, C);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(gap_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ws, out, GAP_CHUNKS, C, N * C, 1.f / (float)HW);
+    DL4DS_LAUNCH(gap_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ws, out, GAP_CHUNKS, C, N * C, 1.f / (float)HW);
     HIP_CHECK(hipGetLastError());
 }
 // ... with the ReLU backward of the pooled tensor on the way (mask = that tensor, or null): the residual block in front of the
@@ -229,34 +229,34 @@ void gap_backward(hipStream_t s, const float* dy, float* dx, int N, int HW, int 
     ProfScope ps(s, "gap_bwd", 0.0, 4.0 * (double)total * (1 + (mask ? 1 : 0) + (accumulate ? 1 : 0)));
     const bool v4 = (C & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)mask)) & 15) == 0;
     if (v4)
-        hipLaunchKernelGGL(gap_bwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, dy, reinterpret_cast<float4*>(dx),
+        DL4DS_LAUNCH(gap_bwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, dy, reinterpret_cast<float4*>(dx),
                            reinterpret_cast<const float4*>(mask), HW, C / 4, total / 4, accumulate);
     else if (mask)
-        hipLaunchKernelGGL(gap_bwd_masked_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, mask, HW, C, total, accumulate);
+        DL4DS_LAUNCH(gap_bwd_masked_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, mask, HW, C, total, accumulate);
     else
-        hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, HW, C, total, accumulate);
+        DL4DS_LAUNCH(gap_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, dy, dx, HW, C, total, accumulate);
     HIP_CHECK(hipGetLastError());
 }
 void dense_forward(hipStream_t s, const float* x, const float* w, const float* b, float* y, int B, int Cin, int F, int act) {
-    hipLaunchKernelGGL(dense_fwd_kernel, dim3(cdiv(B * F, 256)), dim3(256), 0, s, x, w, b, y, B, Cin, F, act);
+    DL4DS_LAUNCH(dense_fwd_kernel, dim3(cdiv(B * F, 256)), dim3(256), 0, s, x, w, b, y, B, Cin, F, act);
     HIP_CHECK(hipGetLastError());
 }
 void dense_backward(hipStream_t s, const float* x, const float* w, const float* y, float* dy, float* dx, int acc_dx,
                     float* dw, float* db, int acc_dw, int want_dw, int b0, int B, int Cin, int F, int act) {
-    hipLaunchKernelGGL(dense_bwd_kernel, dim3(1), dim3(256), 0, s, x, w, y, dy, dx, acc_dx, dw, db, acc_dw, want_dw, b0, B,
+    DL4DS_LAUNCH(dense_bwd_kernel, dim3(1), dim3(256), 0, s, x, w, y, dy, dx, acc_dx, dw, db, acc_dw, want_dw, b0, B,
                        Cin, F, act);
     HIP_CHECK(hipGetLastError());
 }
 void dropout_make_mask(hipStream_t s, float* mask, size_t n, float rate, unsigned long long seed, int gaussian) {
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, mask, n, rate, seed, gaussian);
+    DL4DS_LAUNCH(dropout_mask_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, mask, n, rate, seed, gaussian);
     HIP_CHECK(hipGetLastError());
 }
 void dropout_apply_bcast(hipStream_t s, const float* x, const float* mask, float* y, size_t n, float scale, int accumulate, int C,
                          size_t inner) {
-    hipLaunchKernelGGL(dropout_apply_bcast_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, mask, y, n, scale, accumulate, C, inner);
+    DL4DS_LAUNCH(dropout_apply_bcast_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, mask, y, n, scale, accumulate, C, inner);
     HIP_CHECK(hipGetLastError());
 }
 void dropout_apply(hipStream_t s, const float* x, const float* mask, float* y, size_t n, float scale, int accumulate) {
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, mask, y, n, scale, accumulate);
+    DL4DS_LAUNCH(dropout_apply_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, mask, y, n, scale, accumulate);
     HIP_CHECK(hipGetLastError());
 }

@@ -124,10 +124,10 @@ void loss_forward_backward(hipStream_t s, int kind, const float* y_true, const f
     const int nb = loss_blocks(n);
     const float inv_n = 1.f / (float)n;
     ProfScope ps(s, "pixel_loss", 0.0, 12.0 * (double)n);
-    hipLaunchKernelGGL(pixel_loss_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, dpred, n, scale * wa * inv_n,
+    DL4DS_LAUNCH(pixel_loss_kernel, dim3(nb), dim3(256), 0, s, y_true, y_pred, dpred, n, scale * wa * inv_n,
                        scale * ws * inv_n, accumulate, workspace);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(pixel_loss_finish_kernel, dim3(1), dim3(64), 0, s, workspace, nb, scale * wa, scale * ws, inv_n,
+    DL4DS_LAUNCH(pixel_loss_finish_kernel, dim3(1), dim3(64), 0, s, workspace, nb, scale * wa, scale * ws, inv_n,
                        loss_out, 0);
     HIP_CHECK(hipGetLastError());
     if (wd != 0.f) {
@@ -142,6 +142,6 @@ void loss_forward_backward(hipStream_t s, int kind, const float* y_true, const f
 
 void bce_forward_backward(hipStream_t s, const float* p, float label, int n, float scale, float* loss_out, float* dp,
                           int accumulate_loss) {
-    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, s, p, label, n, scale, loss_out, dp, accumulate_loss);
+    DL4DS_LAUNCH(bce_kernel, dim3(1), dim3(256), 0, s, p, label, n, scale, loss_out, dp, accumulate_loss);
     HIP_CHECK(hipGetLastError());
 }

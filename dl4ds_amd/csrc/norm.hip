@@ -420,8 +420,8 @@ void layernorm_forward(hipStream_t s, const float* x, const float* gamma, const 
     const bool v4 = vec_ok(C, {x, gamma, beta, y});
     check_channels(C, v4 ? 4 : 1, "layernorm");
     const int L = ln_lanes(v4 ? C / 4 : C);
-    if (v4) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(ln_blocks(npix, L)), dim3(NORM_THREADS), 0, s, x, gamma, beta, y, npix, C, L, eps, relu);
-    else hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(ln_blocks(npix, L)), dim3(NORM_THREADS), 0, s, x, gamma, beta, y, npix, C, L, eps, relu);
+    if (v4) DL4DS_LAUNCH(ln_fwd_kernel<4>, dim3(ln_blocks(npix, L)), dim3(NORM_THREADS), 0, s, x, gamma, beta, y, npix, C, L, eps, relu);
+    else DL4DS_LAUNCH(ln_fwd_kernel<1>, dim3(ln_blocks(npix, L)), dim3(NORM_THREADS), 0, s, x, gamma, beta, y, npix, C, L, eps, relu);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -435,10 +435,10 @@ void layernorm_backward(hipStream_t s, const float* x, const float* y, const flo
     check_channels(C, v4 ? 4 : 1, "layernorm");
     const int L = ln_lanes(v4 ? C / 4 : C);
     const int nb = ln_blocks(npix, L);
-    if (v4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, dx, acc_dx, ws, npix, C, L, eps, relu);
-    else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, dx, acc_dx, ws, npix, C, L, eps, relu);
+    if (v4) DL4DS_LAUNCH(ln_bwd_kernel<4>, dim3(nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, dx, acc_dx, ws, npix, C, L, eps, relu);
+    else DL4DS_LAUNCH(ln_bwd_kernel<1>, dim3(nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, dx, acc_dx, ws, npix, C, L, eps, relu);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, s, ws, nb, 2 * C, dgamma, dbeta, C, acc_dw);
+    DL4DS_LAUNCH(partial_reduce_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, s, ws, nb, 2 * C, dgamma, dbeta, C, acc_dw);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -455,15 +455,15 @@ void batchnorm_forward(hipStream_t s, const float* x, const float* gamma, const 
     float* partial = ws;
     float* stats = ws + (size_t)NORM_MAX_BLOCKS * 2 * C;
     if (training) {
-        if (v4) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, partial, npix, C, g);
-        else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, partial, npix, C, g);
+        if (v4) DL4DS_LAUNCH(bn_stats_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, partial, npix, C, g);
+        else DL4DS_LAUNCH(bn_stats_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, partial, npix, C, g);
         HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, x, partial, g.nb, npix, C, gamma, beta, mov_mean,
+    DL4DS_LAUNCH(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, x, partial, g.nb, npix, C, gamma, beta, mov_mean,
                        mov_var, eps, momentum, training, stats, saved);
     HIP_CHECK(hipGetLastError());
-    if (v4) hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, stats, y, npix, C, g, relu);
-    else hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, stats, y, npix, C, g, relu);
+    if (v4) DL4DS_LAUNCH(bn_apply_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, stats, y, npix, C, g, relu);
+    else DL4DS_LAUNCH(bn_apply_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, stats, y, npix, C, g, relu);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -479,14 +479,14 @@ void batchnorm_backward(hipStream_t s, const float* x, const float* y, const flo
     const BnGeom g = bn_geom(npix, C, V);
     float* partial = ws;
     float* sums = ws + (size_t)NORM_MAX_BLOCKS * 2 * C;
-    if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, saved, partial, npix, C, g, relu);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, saved, partial, npix, C, g, relu);
+    if (v4) DL4DS_LAUNCH(bn_bwd_reduce_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, saved, partial, npix, C, g, relu);
+    else DL4DS_LAUNCH(bn_bwd_reduce_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, saved, partial, npix, C, g, relu);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.nb, npix, C, sums, dgamma, dbeta, acc_dw);
+    DL4DS_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.nb, npix, C, sums, dgamma, dbeta, acc_dw);
     HIP_CHECK(hipGetLastError());
     if (dx) {
-        if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, saved, sums, dx, acc_dx, npix, C, g, relu);
-        else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, saved, sums, dx, acc_dx, npix, C, g, relu);
+        if (v4) DL4DS_LAUNCH(bn_bwd_apply_kernel<4>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, saved, sums, dx, acc_dx, npix, C, g, relu);
+        else DL4DS_LAUNCH(bn_bwd_apply_kernel<1>, dim3(g.nb), dim3(NORM_THREADS), 0, s, x, y, dy, gamma, saved, sums, dx, acc_dx, npix, C, g, relu);
         HIP_CHECK(hipGetLastError());
     }
 }

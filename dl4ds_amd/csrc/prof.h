@@ -1,7 +1,15 @@
 // Optional per-launch timing with HIP events on the launch stream (off by default; used by bench.py to
 // measure the dominant kernel's duration live and to print a per-kernel breakdown).
+//
+// A tag's time is KERNEL time: every launch made through DL4DS_LAUNCH inside a ProfScope carries its own start / stop events
+// (hipExtLaunchKernelGGL: the dispatch packet's begin and end timestamps), and the tag's figure is the sum over its launches.
+// (Round 3 recorded two events AROUND the scope on the stream: with every launch instrumented the host falls behind the
+// device, and the window of a short kernel then held the host's launch latency -- maxpool2_fwd 0.67 ms per step of cfg5
+// against 0.10 ms in rocprofv3's kernel trace.)  A scope that launches nothing through the macro (memcpys) falls back to
+// the pair of events around it.
 #pragma once
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <string>
 #include <vector>
 
@@ -9,7 +17,8 @@ struct ProfEntry {
     std::string tag;
     double flops, bytes;
     double direct_flops;      // launches that issue fewer multiply-adds than the layer's direct form (Winograd): the direct-form count
-    hipEvent_t e0, e1;
+    hipEvent_t e0, e1;        // around the scope (fallback)
+    std::vector<hipEvent_t> k;      // start, stop of every kernel launched inside the scope
 };
 
 struct Profiler {
@@ -24,12 +33,20 @@ struct Profiler {
 };
 Profiler& prof();
 
+struct ProfScope;
+ProfScope*& prof_current();       // innermost live scope (the library is driven from one host thread per process)
+
 struct ProfScope {
     hipStream_t s;
     int idx = -1;
+    ProfScope* outer = nullptr;
+    bool linked = false;
     ProfScope(hipStream_t stream, const std::string& tag, double flops, double bytes, double direct_flops = 0.0) : s(stream) {
         Profiler& p = prof();
         if (!p.on) return;
+        outer = prof_current();
+        prof_current() = this;
+        linked = true;
         if (!p.filter.empty() && tag.compare(0, p.filter.size(), p.filter) != 0) return;
         ProfEntry e;
         e.tag = tag; e.flops = flops; e.bytes = bytes; e.direct_flops = direct_flops > 0.0 ? direct_flops : flops;
@@ -41,5 +58,26 @@ struct ProfScope {
     }
     ~ProfScope() {
         if (idx >= 0) (void)hipEventRecord(prof().entries[idx].e1, s);
+        if (linked) prof_current() = outer;
     }
 };
+
+// start / stop events for the next kernel launch if it happens inside a timed scope, else (nullptr, nullptr)
+inline bool prof_launch_events(hipEvent_t& a, hipEvent_t& b) {
+    ProfScope* sc = prof().on ? prof_current() : nullptr;
+    if (!sc || sc->idx < 0) { a = b = nullptr; return false; }
+    Profiler& p = prof();
+    a = p.get_event();
+    b = p.get_event();
+    p.entries[sc->idx].k.push_back(a);
+    p.entries[sc->idx].k.push_back(b);
+    return true;
+}
+
+// every kernel launch of the library goes through this: a plain launch unless the profiler wants this launch's own timestamps
+#define DL4DS_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                          \
+    do {                                                                                                               \
+        hipEvent_t pe0_, pe1_;                                                                                         \
+        if (prof_launch_events(pe0_, pe1_)) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, pe0_, pe1_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                      \
+    } while (0)
