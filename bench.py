@@ -207,18 +207,23 @@ def _free_port_pair():
     raise RuntimeError('no free port pair found')
 
 
-def spawn_ranks(n, argv):
-    """One child per GPU (rank i -> LOCAL_RANK i); rank 0's stdout is this process's stdout (the JSON line)."""
-    import dl4ds_amd._lib as L
-    cnt = ctypes.c_int(0)
-    if L.load().dl4ds_device_count(ctypes.byref(cnt)) != 0 or cnt.value < n:
-        raise SystemExit(f'bench.py --gpus {n}: only {cnt.value} HIP device(s) visible')
+def spawn_ranks(n, argv, script=None, device_count=None):
+    """One child per GPU (rank i -> LOCAL_RANK i); rank 0's stdout is this process's stdout (the JSON line).
+    ``script`` / ``device_count``: stand-ins for this file and the library's device count (tests/test_rendezvous.py runs the
+    launcher for N = 8 without a GPU)."""
+    if device_count is None:
+        import dl4ds_amd._lib as L
+        cnt = ctypes.c_int(0)
+        device_count = cnt.value if L.load().dl4ds_device_count(ctypes.byref(cnt)) == 0 else 0
+    if device_count < n:
+        raise SystemExit(f'bench.py --gpus {n}: only {device_count} HIP device(s) visible (one process per GPU: '
+                         f'run with --gpus {max(device_count, 1)} or on a node with {n} GPUs)')
     port = _free_port_pair()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:

@@ -36,6 +36,32 @@ std::mutex g_rt_mu;
 Runtime& rt() { return g_rt; }
 void set_last_error(const std::string& s) { g_last_error = s; }
 
+// ---- sticky device-side error word (runtime.h)
+namespace {
+unsigned* g_err_host = nullptr;       // pinned, mapped
+unsigned* g_err_dev = nullptr;
+}  // namespace
+unsigned* device_error_word() {
+    if (!g_err_dev) {
+        HIP_CHECK(hipHostMalloc((void**)&g_err_host, sizeof(unsigned), hipHostMallocMapped));
+        *g_err_host = 0u;
+        HIP_CHECK(hipHostGetDevicePointer((void**)&g_err_dev, g_err_host, 0));
+    }
+    return g_err_dev;
+}
+void device_error_check(const char* what) {
+    if (!g_err_host) return;
+    const unsigned code = *reinterpret_cast<volatile unsigned*>(g_err_host);
+    if (!code) return;
+    *g_err_host = 0u;                  // reported once; the step that raised it is lost either way
+    std::string msg = std::string(what) + ": a kernel reported a device-side error (code " + std::to_string(code) + ")";
+    if (code & DEV_ERR_CONVLSTM_SEQ_TIMEOUT)
+        msg += ": the persistent ConvLSTM kernel gave up waiting for a neighbouring tile (its workgroups were not all resident, "
+               "e.g. behind kernels of another stream or an RCCL collective held up by a late rank); the activations and "
+               "gradients of that step are INVALID.  DL4DS_NO_CONVLSTM_SEQ=1 runs the recurrence step by step";
+    throw Dl4dsError(msg);
+}
+
 void rt_ensure_init() {
     std::lock_guard<std::mutex> lk(g_rt_mu);
     if (g_rt.inited) return;
@@ -146,6 +172,17 @@ int dl4ds_memset(void* p, int value, size_t bytes) {
 int dl4ds_sync(void) {
     API_BEGIN
     dist_stream_sync(S(), "dl4ds_sync");          // (plain hipStreamSynchronize unless several ranks take part)
+    API_END
+}
+namespace {
+__global__ void raise_device_error_kernel(unsigned* word, unsigned code) {
+    __hip_atomic_fetch_or(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+int dl4ds_debug_raise_device_error(int code) {
+    API_BEGIN
+    hipLaunchKernelGGL(raise_device_error_kernel, dim3(1), dim3(1), 0, S(), device_error_word(), (unsigned)code);
+    HIP_CHECK(hipGetLastError());
     API_END
 }
 int dl4ds_event_timer_start(void) {
@@ -803,7 +840,7 @@ int dl4ds_trainer_evaluate(dl4ds_trainer* tr, const float* const* inputs, int n_
     DL4DS_REQUIRE(loss_host, "evaluate: loss_host is required");
     trainer_evaluate(*tr->t, inputs, n_inputs, y_true, B, is_host != 0);
     HIP_CHECK(hipMemcpyAsync(loss_host, tr->t->d_loss, sizeof(float), hipMemcpyDeviceToHost, S()));
-    dist_stream_sync(S(), "dl4ds_trainer_last_loss");
+    dist_stream_sync(S(), "dl4ds_trainer_evaluate");
     API_END
 }
 int dl4ds_trainer_get_state(dl4ds_trainer* tr, float* m_host, float* v_host, long* step) {

@@ -79,9 +79,8 @@ CganTrainer* cgan_create(Graph* gen, Graph* disc, int px_loss_kind, float lr, fl
     t->D = trainer_create(disc, LOSS_MAE, c);
     t->px_kind = px_loss_kind;
     t->lam = lam;
-    // BatchNormalization inside the discriminator (discriminator.py:38,50,70): the merged [real ; fake] batch keeps the
-    // statistics of the reference's two calls apart
-    for (auto& op : disc->ops) op->set_batch_groups(2);
+    // (BatchNormalization inside the discriminator -- discriminator.py:38,50,70 -- keeps the statistics of the reference's two
+    //  calls apart inside the merged [real ; fake] batch: two statistics groups, switched on for the duration of cgan_step only)
     HIP_CHECK(hipMalloc((void**)&t->d_losses, 8 * sizeof(float)));
     HIP_CHECK(hipMemset(t->d_losses, 0, 8 * sizeof(float)));
     return t;
@@ -151,6 +150,16 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
     }
     // the conditioning branch sees the same array in both halves: evaluated once (Graph::plan_shared; decided per graph, once)
     if (t.shared_plan < 0) t.shared_plan = D.plan_shared({D.inputs[0]}) ? 1 : 0;
+    // (restored on EVERY way out of this function: an exception between here and the end -- API_BEGIN / API_END turns it into a
+    //  status -- must not leave the discriminator graph in shared mode for a later plain forward of the same model)
+    struct SharedGuard {
+        Graph& g;
+        ~SharedGuard() {
+            g.shared_groups = 1;
+            for (auto& op : g.ops) op->set_batch_groups(1);
+        }
+    } shared_guard{D};
+    for (auto& op : D.ops) op->set_batch_groups(2);          // BatchNormalization: [real ; fake] = two statistics groups
     D.shared_groups = t.shared_plan == 1 ? 2 : 1;
     D.forward(2 * B, true);
     GTensor& dout = D.tensors[D.outputs[0]];
@@ -215,7 +224,6 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
         BwdCtx c2{2 * B, 0, 2 * B, false, true};
         D.backward(c2);
     }
-    D.shared_groups = 1;
     // ---- generator backward: lambda * dpx/dgen + dgan/dgen
     G.zero_grad_flags();
     loss_forward_backward(s, t.px_kind, t.hr, go.data, go.grad, B * go.nmul, go.H, go.W, go.C, t.lam, t.d_losses + 1, 0,

@@ -288,6 +288,296 @@ __global__ void __launch_bounds__(256, 1) conv_wino_wgrad_kernel(const WinoWgrad
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form (round 4): BOTH transforms in the registers of the MFMA waves, nothing but the two raw blocks in LDS.
+//
+// The MFMA operands of dU[xi][nu] += V[xi][nu]^T dM[xi][nu] are, in lane (l15, k-slot lq) and k-step s,
+//     A = V [xi][nu][tile(s, lq)][cin  16 i + l15]        B = dM[xi][nu][tile(s, lq)][cout 16 j + l15]
+// i.e. ONE channel of one tile each -- scalars.  A lane therefore reads the raw values of its own (tile, channel) pairs (8 of the
+// input patch: rows ra, rb of wave xi, four columns; 4 of the output gradient's 2 x 2 pixels) as ds_read2_b32 pairs of adjacent
+// columns and transforms them with PACKED instructions on those pairs:
+//     (T0, T1) = a01 + sg b01, (T2, T3) = a23 + sg b23;  (V0, V3) = (T0, T1) - (T2, T3);  (V1, V2) = (T1 + T2, T2 - T1)  [op_sel]
+//     (r0, r1) = y0. + c y1.  (c = 0, 1, -1, 0 for xi = 0..3; xi = 3 reads row 1 as its first row);  dM0 = r0, dM3 = r1,
+//     (dM1, dM2) = (r0 + r1, r0 - r1)  [op_sel]
+// 4 + 2 packed instructions and 4 + 2 LDS reads per (tile, channel) feed 4 x (NT | KQ) MFMAs.  What the first form paid for V
+// and dM -- 32 ds_write_b128 and 48 ds_read2 per thread and tile group, two transform phases with every wave idle on the matrix
+// side, 106 KB of LDS that kept a CU to ONE workgroup -- is gone: 72 KB per workgroup (both raw blocks double-buffered + the
+// DMA offset tables), two workgroups per CU, one barrier per tile group.  The k-slots of a k-step take the tiles tx = 4 (s & 1)
+// + {0, 2, 1, 3}[lq] of tile row s >> 1: tiles two apart sit 16 banks apart at the raw pitch of 4 K + 1 sixteen-byte slots, so
+// the 32-lane halves of every ds_read are conflict-free.  Slab layout, slab sum and the closing transform are unchanged.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KQ, int NT>
+struct Wg2Geom {
+    static constexpr int CK = 16 * KQ, Q4 = 4 * KQ, CO = 16 * NT, NQ = 4 * NT;
+    static constexpr int SPX = Q4 + 1, SPY = NQ + 1;                 // raw pixel pitches in 16-byte slots
+    static constexpr int HW = 18, HH = 6, HPIX = HW * HH, YPIX = 64;
+    static constexpr int NCHX = (HPIX * SPX + 63) / 64, NCHY = (YPIX * SPY + 63) / 64;      // DMA pieces (64 slots each)
+    static constexpr int RAWX = NCHX * 64, RAWY = NCHY * 64;        // slots per buffer
+    static constexpr int SITX = (NCHX + 3) / 4, SITY = (NCHY + 3) / 4;
+    static constexpr int TAB = (SITX + SITY) * 256;                 // ints
+    static constexpr size_t LDS_BYTES = (size_t)(2 * (RAWX + RAWY) * 4 + TAB) * 4;
+    static constexpr int FR = 4 * (4 * KQ * NT) * 64 * 4;
+    static constexpr int ST = FR + CO;
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pk_fma(const f32x2_t b, const f32x2_t s, const f32x2_t c) {      // c + s * b
+    f32x2_t r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(s), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2_t pk_sub(const f32x2_t a, const f32x2_t b) {
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.hi + b.lo, b.lo - a.hi): the middle pair of the column transform from (T0, T1), (T2, T3)
+__device__ __forceinline__ f32x2_t pk_mid(const f32x2_t a, const f32x2_t b) {
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.lo + a.hi, a.lo - a.hi)
+__device__ __forceinline__ f32x2_t pk_sumdiff(const f32x2_t a) {
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+
+template <int KQ, int NT>
+__global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgradParams wp) {
+    typedef Wg2Geom<KQ, NT> GM;
+    constexpr int CK = GM::CK, Q4 = GM::Q4, CO = GM::CO, NQ = GM::NQ, SPX = GM::SPX, SPY = GM::SPY;
+    constexpr int HW = GM::HW, HH = GM::HH, HPIX = GM::HPIX, SITX = GM::SITX, SITY = GM::SITY, NCHX = GM::NCHX, NCHY = GM::NCHY;
+    constexpr int OOB = (int)0xffffff00u;
+    constexpr int RSRC3 = 0x00020000;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const rawx = lds;                                        // two buffers of RAWX slots
+    float* const rawy = lds + 2 * GM::RAWX * 4;                     // two buffers of RAWY slots
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, SX = gridDim.x >> 3;
+    const int npair = wp.ncin * wp.ncout, nsub = SX / npair;
+    const int pc = slot % npair, sub = slot / npair;
+    if (sub >= nsub) return;
+    const int cin0 = (pc / wp.ncout) * CK, n0 = (pc % wp.ncout) * CO;
+    const int tg_lo = xcd * wp.per_xcd, tg_hi = min(wp.ntg, tg_lo + wp.per_xcd);
+    int tg = tg_lo + sub;
+    float* const myslab = wp.slab + ((size_t)(xcd * nsub + sub) * npair + pc) * GM::ST;
+
+    // ---- staging: DMA piece ch = 4 u + wave fills slots [64 ch, 64 ch + 64) of a raw buffer; slot L = (pixel L / SP, quad L % SP).
+    //      Every thread's offsets live in LDS (tab[u][tid]); the packed (y, x) of its slots stay in three registers.
+    size_t isy, isx, ysy, ysx;
+    wino::view_strides(wp.x, isy, isx);
+    wino::view_strides(wp.dy, ysy, ysx);
+    int* const tab = reinterpret_cast<int*>(rawy + 2 * GM::RAWY * 4) + tid;
+    unsigned hyx[(SITX + 3) / 4], hyy[(SITY + 3) / 4];
+    {
+#pragma unroll
+        for (int u = 0; u < (SITX + 3) / 4; ++u) hyx[u] = 0;
+#pragma unroll
+        for (int u = 0; u < (SITY + 3) / 4; ++u) hyy[u] = 0;
+        const int nq = min(NQ, max(0, (wp.Cout - n0) >> 2));
+#pragma unroll
+        for (int u = 0; u < SITX; ++u) {
+            const int L = (4 * u + wave) * 64 + lane;
+            const int p = L / SPX, q = L - p * SPX;
+            const int cq = cin0 + 4 * q;
+            const int hy = p / HW, hx = p - hy * HW;
+            const bool ok = q < Q4 && p < HPIX && cq < wp.Cin;
+            tab[u * 256] = ok ? (int)((hy * isy + hx * isx + view_chan_off(wp.x, cq)) * 4) : OOB;
+            hyx[u >> 2] |= (unsigned)(ok ? (hy | (hx << 3)) : 0) << (8 * (u & 3));
+        }
+#pragma unroll
+        for (int u = 0; u < SITY; ++u) {
+            const int L = (4 * u + wave) * 64 + lane;
+            const int p = L / SPY, q = L - p * SPY;
+            const int py = p >> 4, px = p & 15;
+            const bool ok = q < nq && p < 64;
+            tab[(SITX + u) * 256] = ok ? (int)((py * ysy + px * ysx + view_chan_off(wp.dy, n0 + 4 * q)) * 4) : OOB;
+            hyy[u >> 2] |= (unsigned)(ok ? (py | (px << 3)) : 0) << (8 * (u & 3));
+        }
+    }
+    struct Item { int n, y0, x0; };
+    auto decode = [&](int t) {
+        const int q = fast_div(t, wp.m_tgx);
+        const int bx = t - q * wp.tgx;
+        const int n = fast_div(q, wp.m_tgy);
+        const int by = q - n * wp.tgy;
+        Item it;
+        it.n = n; it.y0 = by * 4; it.x0 = bx * 16;
+        return it;
+    };
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto stage_issue = [&](const Item& it, int buf) __attribute__((always_inline)) {
+        const int ylo = max(0, 1 - it.y0), yhi = min(HH, wp.H + 1 - it.y0);
+        const int xlo = max(0, 1 - it.x0), xhi = min(HW, wp.W + 1 - it.x0);
+        int so[SITX], yo[SITY];
+#pragma unroll
+        for (int u = 0; u < SITX; ++u) so[u] = tab[u * 256];
+#pragma unroll
+        for (int u = 0; u < SITY; ++u) yo[u] = tab[(SITX + u) * 256];
+        if (ylo | xlo | (yhi - HH) | (xhi - HW)) {                  // border tile groups (the empty asm keeps it a branch)
+            asm volatile("" ::: "memory");
+            const int ymax = wp.H - it.y0, xmax = wp.W - it.x0;
+#pragma unroll
+            for (int u = 0; u < SITX; ++u) {
+                unsigned w = hyx[u >> 2];
+                asm volatile("" : "+v"(w));
+                const int b = (int)((w >> (8 * (u & 3))) & 255u);
+                const int hy = b & 7, hx = b >> 3;
+                so[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? so[u] : OOB;
+            }
+#pragma unroll
+            for (int u = 0; u < SITY; ++u) {
+                unsigned w = hyy[u >> 2];
+                asm volatile("" : "+v"(w));
+                const int b = (int)((w >> (8 * (u & 3))) & 255u);
+                yo[u] = ((b & 7) < ymax && (b >> 3) < xmax) ? yo[u] : OOB;
+            }
+        }
+        const long org = (long)((size_t)it.n * wp.x.nstride) + (long)(it.y0 - 1) * (long)isy + (long)(it.x0 - 1) * (long)isx;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(wp.x.p)) + org * 4, 0, 0x7fffff00, RSRC3);
+        const size_t yorg = (size_t)it.n * wp.dy.nstride + it.y0 * ysy + it.x0 * ysx;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(wp.dy.p)) + yorg * 4, 0, 0x7fffff00, RSRC3);
+#if defined(__HIP_DEVICE_COMPILE__)                                   // (the host pass has no LDS address space to cast to)
+        float* const dx = rawx + buf * (GM::RAWX * 4) + wave * 256;
+        float* const dyp = rawy + buf * (GM::RAWY * 4) + wave * 256;
+#pragma unroll
+        for (int u = 0; u < SITX; ++u)
+            if (4 * u + wave < NCHX) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dx + u * 1024), 16, so[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < SITY; ++u)
+            if (4 * u + wave < NCHY) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(dyp + u * 1024), 16, yo[u], 0, 0, 0);
+#else
+        (void)rs; (void)ry; (void)so; (void)yo; (void)buf;
+#endif
+    };
+
+    // ---- the wave's rows of the input patch and of the 2 x 2 gradient block
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg1 = wave == 1 ? 1.f : -1.f;
+    const f32x2_t sg = {sg1, sg1};
+    const int y_first = wave == 3 ? 1 : 0;                          // xi = 3: r = y1.
+    const float cy1 = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);   // r = y(first). + cy y1.
+    const f32x2_t cy = {cy1, cy1};
+    const int txo = (lq >> 1) + 2 * (lq & 1);                       // k-slots 0..3 take tiles tx0 + {0, 2, 1, 3}
+    const int x_lane = (2 * txo * SPX) * 4 + l15;                   // floats, relative to the step's first tile
+    const int y_lane = (2 * txo * SPY) * 4 + l15;
+
+    f32x4 acc[4][KQ][NT];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int i = 0; i < KQ; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[nu][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dbacc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) dbacc[j] = 0.f;
+
+    if (tg < tg_hi) {
+        Item cur = decode(tg);
+        stage_issue(cur, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (;;) {
+            const int ntg = tg + nsub;
+            const bool has_next = ntg < tg_hi;
+            Item nxt = cur;
+            const float* const bx = rawx + buf * (GM::RAWX * 4) + x_lane;
+            const float* const by = rawy + buf * (GM::RAWY * 4) + y_lane;
+            // raw values of k-step s: [i][row a / b][column pair], [j][row][pair]
+            f32x2_t xr[KQ][2][2], yr[NT][2];
+            auto fetch = [&](int s) __attribute__((always_inline)) {
+                const int ty = s >> 1, tx0 = 4 * (s & 1);
+                const float* pa = bx + ((2 * ty + ra) * HW + 2 * tx0) * (SPX * 4);
+                const float* pb = bx + ((2 * ty + rb) * HW + 2 * tx0) * (SPX * 4);
+                const float* py = by + ((2 * ty + y_first) * 16 + 2 * tx0) * (SPY * 4);
+                const float* p1 = by + ((2 * ty + 1) * 16 + 2 * tx0) * (SPY * 4);
+#pragma unroll
+                for (int i = 0; i < KQ; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        xr[i][0][h] = (f32x2_t){pa[16 * i + (2 * h) * (SPX * 4)], pa[16 * i + (2 * h + 1) * (SPX * 4)]};
+                        xr[i][1][h] = (f32x2_t){pb[16 * i + (2 * h) * (SPX * 4)], pb[16 * i + (2 * h + 1) * (SPX * 4)]};
+                    }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    yr[j][0] = (f32x2_t){py[16 * j], py[16 * j + SPY * 4]};
+                    yr[j][1] = (f32x2_t){p1[16 * j], p1[16 * j + SPY * 4]};
+                }
+            };
+            fetch(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                // operands of this k-step
+                float A[4][KQ], B[4][NT];
+#pragma unroll
+                for (int i = 0; i < KQ; ++i) {
+                    const f32x2_t t01 = pk_fma(xr[i][1][0], sg, xr[i][0][0]);
+                    const f32x2_t t23 = pk_fma(xr[i][1][1], sg, xr[i][0][1]);
+                    const f32x2_t v03 = pk_sub(t01, t23);
+                    const f32x2_t v12 = pk_mid(t01, t23);
+                    A[0][i] = v03[0]; A[1][i] = v12[0]; A[2][i] = v12[1]; A[3][i] = v03[1];
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f32x2_t r = pk_fma(yr[j][1], cy, yr[j][0]);
+                    const f32x2_t m12 = pk_sumdiff(r);
+                    B[0][j] = r[0]; B[1][j] = m12[0]; B[2][j] = m12[1]; B[3][j] = r[1];
+                    dbacc[j] += m12[0];                              // (wave 1: the tile's four pixels; the other waves' sums are unused)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s < 3) fetch(s + 1);
+                if (s == 0 && has_next) {
+                    // the next raw blocks: every wave left the buffers they go to before the barrier that ended the last iteration
+                    nxt = decode(ntg);
+                    stage_issue(nxt, buf ^ 1);
+                }
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                    for (int i = 0; i < KQ; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[nu][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[nu][i], B[nu][j], acc[nu][i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the next blocks have landed
+            __syncthreads();
+            if (!has_next) break;
+            cur = nxt;
+            tg = ntg;
+            buf ^= 1;
+        }
+    }
+    // ---- the workgroup's share of dU: lane (column l15 = cout, rows 4 lq + r = cin) -> [wave][nu][cin block][cout block][lane][4]
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int i = 0; i < KQ; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4*>(myslab + ((size_t)((wave * 4 + nu) * KQ + i) * NT + j) * 256 + lane * 4) = acc[nu][i][j];
+    // ---- bias gradient: wave 1's lanes hold, per cout 16 j + l15, the sum over the tiles of their k-slot
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) lds[(j * 4 + lq) * 16 + l15] = dbacc[j];
+    }
+    __syncthreads();
+    if (tid < CO) {
+        const int j = tid >> 4, c = tid & 15;
+        myslab[GM::FR + tid] = (lds[(j * 4 + 0) * 16 + c] + lds[(j * 4 + 1) * 16 + c]) + (lds[(j * 4 + 2) * 16 + c] + lds[(j * 4 + 3) * 16 + c]);
+    }
+}
+
 // out[i] = sum over k of slab[k * n + i], in the order of k (bitwise reproducible); n % 4 == 0
 __global__ void __launch_bounds__(256) wino_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n4, int nslabs) {
     const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
@@ -394,8 +684,26 @@ float* wgrad_scratch(hipStream_t s, size_t floats) {       // grow-only, one buf
     return e.buf;
 }
 
+inline bool wgrad_first_form() {
+    static const bool v = getenv("DL4DS_WINO_WGRAD_V1") != nullptr;
+    return v;
+}
+
+template <int KQ, int NT>
+void launch_wgrad2(hipStream_t s, WinoWgradParams& wp, int SX) {
+    typedef Wg2Geom<KQ, NT> GM;
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad2_kernel<KQ, NT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES));
+    });
+    DL4DS_LAUNCH((conv_wino_wgrad2_kernel<KQ, NT>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
+    HIP_CHECK(hipGetLastError());
+}
+
 template <int KQ, int NT>
 void launch_wgrad(hipStream_t s, WinoWgradParams& wp, int SX) {
+    if (!wgrad_first_form()) { launch_wgrad2<KQ, NT>(s, wp, SX); return; }
     typedef WgGeom<KQ, NT> GM;
     static std::once_flag once;
     std::call_once(once, [&]() {
@@ -435,7 +743,7 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     wp.ntg = (int)ntg;
     wp.per_xcd = cdiv(wp.ntg, 8);
     const int npair = wp.ncin * wp.ncout;
-    const int SXmax = std::max(wgrad_cu_count() / 8, 1);
+    const int SXmax = std::max((wgrad_first_form() ? 1 : 2) * wgrad_cu_count() / 8, 1);          // second form: two workgroups per CU
     if (npair > SXmax) return false;
     int SX = (SXmax / npair) * npair;
     if (force && atoi(force) > 0) SX = std::min(SX, atoi(force) * npair);

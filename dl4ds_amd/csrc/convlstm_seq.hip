@@ -13,15 +13,21 @@
 //     kept interleaved (channel 4 f + gate) in every internal buffer, so the four rows a lane holds are the i, f, g, o
 //     pre-activations of ONE (pixel, filter) and z / dz move as float4;
 //   * steps are ordered by a flag per tile, not by a grid barrier: tile X may start step t once its 3 x 3 tile
-//     neighbourhood has published step t-1 (agent-scope release -> relaxed flag -> relaxed poll by one lane -> ONE
-//     agent-scope acquire -> __syncthreads: MI355X_MICROARCH.md "inter-workgroup visibility" -- per-XCD L2s are not
-//     coherent, a CU's L1 is never refreshed by other CUs' stores).  Tiles of one image are dealt to one XCD (blockIdx % 8)
-//     so that halo exchange stays inside an L2 -- speed only, never correctness.
+//     neighbourhood has published step t-1.  The hand-off is the guide's form R1, WITHOUT fences: the payload is stored
+//     write-through (16-byte sc1 stores), every storing wave drains (s_waitcnt vmcnt(0)), one lane stores the tile's
+//     counter (relaxed, agent scope); the consumer polls the counters (relaxed) and stages the halo with sc1 LOADS that
+//     bypass its CU's L1 (MI355X_MICROARCH.md "inter-workgroup visibility": per-XCD L2s are not coherent, a CU's L1 is
+//     never refreshed by other CUs' stores -- sc1 on both sides is what makes the plain flag sufficient).  Tiles of one
+//     image are dealt to one XCD (blockIdx % 8) so that halo exchange stays inside an L2 -- speed only, never correctness.
 // Every block of the grid must be resident (a tile waits for its neighbours): grid <= CUs (one 256-thread block per CU,
-// LDS-bound), flags zeroed by a memset node ahead of every launch, every spin bounded.
+// LDS-bound; a slice of the CUs is left free while RCCL collectives may run), flags zeroed by a memset node ahead of every
+// launch, every spin bounded -- and a spin that gives up sets the sticky device error word (runtime.h), which every host-side
+// wait checks: the step fails loudly instead of training on stale halos.
 #include "ops.h"
 #include "prof.h"
 #include "head.h"
+#include "runtime.h"
+#include "dist.h"
 #include <algorithm>
 #include <vector>
 
@@ -46,7 +52,7 @@ __device__ __forceinline__ float dhsig(float z) { return (z >= -2.5f && z <= 2.5
 // cleanly.  The gate arithmetic is VALU work squeezed between the MFMA phases of a step: libm's tanhf was ~40 % of it.
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - __fdividef(2.f, __expf(2.f * x) + 1.f); }
 
-constexpr unsigned SPIN_LIMIT = 1u << 22;       // ~seconds: a lost neighbour yields wrong numbers, never a hung GPU
+constexpr unsigned SPIN_LIMIT = 1u << 22;       // ~seconds: a lost neighbour is REPORTED (SeqParams::err), never a hung GPU
 
 // TR = pixel rows per wave: the tile is 16 wide and 4 TR high.  TR = 2 (8 x 16 tiles) doubles the number of tiles: with two
 // tiles per workgroup the hand-off latency of one (drain -> flag -> poll -> stage) passes under the other's arithmetic.
@@ -83,6 +89,7 @@ struct SeqParams {
     float* dZ;             // backward out: (B,T,H,W,4F) interleaved
     float* dc;             // backward scratch: (B,H,W,F) running dL/dc
     unsigned* flags;       // [tiles]: steps completed by each tile (zeroed before the launch)
+    unsigned* err;         // host-visible sticky error word (runtime.h): set when a spin gives up
     int B, T, H, W, tiles_x, tiles_y, ntiles, relu, tr;
     unsigned long long* trace;   // DL4DS_SEQ_TRACE: [block][8] phase times (100 MHz wall clock), null otherwise
 };
@@ -118,6 +125,9 @@ __device__ __forceinline__ void wait_neighbours(const SeqParams& p, int tile, un
             unsigned spins = 0;
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < SPIN_LIMIT)
                 __builtin_amdgcn_s_sleep(1);
+            // gave up: the halo this tile stages next is stale.  Say so where the host looks after every sync (device_error_check):
+            // the step must not pass for a valid one.
+            if (spins >= SPIN_LIMIT) __hip_atomic_fetch_or(p.err, DEV_ERR_CONVLSTM_SEQ_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     __syncthreads();
@@ -547,6 +557,9 @@ void launch_bwd(hipStream_t s, const SeqParams& p, int grid) {
 
 bool convlstm_seq_supported(int KS, int F, int H, int W, int B) {
     if (getenv("DL4DS_NO_CONVLSTM_SEQ")) return false;
+    // weight-gradient kernels on the second compute stream (opt-in, DL4DS_AUX_STREAM=1) may hold CUs for the whole backward pass:
+    // residency of a 256-workgroup launch cannot be promised next to them -> the step-by-step path
+    if (getenv("DL4DS_AUX_STREAM")) return false;
     if (!(KS == 3 || KS == 5) || !(F == 4 || F == 8 || F == 16)) return false;
     if (F == 16 && KS == 5) return false;                  // backward: filter fragments + the dZ halo tile exceed the LDS
     const long tiles = (long)cdiv(H, 16) * cdiv(W, 16) * B;
@@ -590,7 +603,15 @@ static void trace_end(const char* what, const SeqParams& p, int grid, hipStream_
     fprintf(stderr, "%s T=%d tiles=%d grid=%d tr=%d: prefetch %.1f wait %.1f stage %.1f kloop %.1f gates+stores %.1f publish %.1f us (mean per block, whole launch)\n",
             what, p.T, p.ntiles, grid, p.tr, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
 }
-static int seq_grid(const SeqParams& p) { return std::min(p.ntiles, std::max(cu_count(), 8)); }
+// Every workgroup of the launch must be resident at once (one per CU: LDS-bound).  While RCCL collectives of the bucketed
+// backward may be running, a slice of the CUs is left to them, so that their workgroups never have to queue behind -- or hold
+// up -- a workgroup of this kernel (DL4DS_SEQ_RESERVE_CUS overrides the 32).  Co-residency lost anyway (a late peer rank keeps a
+// collective's kernel on the chip for seconds) ends in the error word, not in wrong numbers.
+static int seq_grid(const SeqParams& p) {
+    static const int reserve = [] { const char* e = getenv("DL4DS_SEQ_RESERVE_CUS"); return e ? atoi(e) : 32; }();
+    const int cus = std::max(cu_count() - (dist_active() ? reserve : 0), 8);
+    return std::min(p.ntiles, cus);
+}
 
 // rows per wave.  Backward: 8 x 16 tiles while 16 x 16 tiles would give a workgroup fewer than two of them (see Geom; its
 // step ends with the drain of 32 KB of write-through dZ stores, which the second tile's arithmetic covers).  Forward: 16 x 16
@@ -607,6 +628,7 @@ static SeqParams seq_params(const float* U, float* Z, float* C, float* Hrec, flo
     SeqParams p;
     p.U = U; p.Z = Z; p.C = C; p.Hrec = Hrec; p.out = out; p.dout = dout; p.dZ = dZ; p.dc = dc; p.flags = flags;
     p.B = B; p.T = T; p.H = H; p.W = W; p.relu = relu;
+    p.err = device_error_word();
     p.tr = seq_tr(H, W, B, backward);
     p.trace = nullptr;
     p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 4 * p.tr); p.ntiles = p.tiles_x * p.tiles_y * B;

@@ -127,6 +127,7 @@ void dist_stream_sync(hipStream_t stream, const char* what) {
     static const bool force = std::getenv("DL4DS_FORCE_WATCHDOG") != nullptr;
     if (g_comm == nullptr || (g_world <= 1 && !force)) {
         HIP_CHECK(hipStreamSynchronize(stream));
+        device_error_check(what);
         return;
     }
     static const double limit = [] {
@@ -140,7 +141,7 @@ void dist_stream_sync(hipStream_t stream, const char* what) {
         // hipErrorNotReady is a status, but HIP records it as the thread's sticky "last error": clear it, or the next
         // HIP_CHECK(hipGetLastError()) after a kernel launch would report it
         if (e == hipErrorNotReady) (void)hipGetLastError();
-        if (e == hipSuccess) return;
+        if (e == hipSuccess) { device_error_check(what); return; }
         if (e != hipErrorNotReady) HIP_CHECK(e);
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (waited > 2e-3) {                                   // short waits stay a pure spin

@@ -13,3 +13,10 @@ struct Runtime {
 Runtime& rt();
 void rt_ensure_init();
 void set_last_error(const std::string& s);
+
+// Sticky device-side error word (host-pinned, device-mapped): a persistent kernel that gives up a bounded spin stores a code
+// here instead of continuing silently; every host-side wait (dist_stream_sync) checks it after the stream has drained and
+// throws.  device_error_word(): the DEVICE pointer kernels store through; device_error_check(what): throws if set.
+enum : unsigned { DEV_ERR_CONVLSTM_SEQ_TIMEOUT = 1u };
+unsigned* device_error_word();
+void device_error_check(const char* what);

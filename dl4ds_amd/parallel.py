@@ -10,6 +10,8 @@ on a few floats.  Any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER
 (``torch.distributed.run``, ``bench.py --gpus N``'s own spawner, srun/mpirun wrappers); torch is not involved.
 """
 import ctypes
+import hashlib
+import hmac
 import os
 import socket
 import struct
@@ -67,6 +69,10 @@ def rendezvous_endpoint():
     return host, int(port)
 
 
+def _token_digest():
+    return hashlib.sha256(os.environ.get('DL4DS_RDZV_TOKEN', '').encode()).digest()
+
+
 def _recv_exact(conn, n):
     buf = b''
     while len(buf) < n:
@@ -80,8 +86,10 @@ def _recv_exact(conn, n):
 def exchange_bytes(payload, rank, world, timeout=300.0, endpoint=None):
     """Rank 0 hands `payload` (bytes) to every other rank; returns the payload on all ranks.  Rank 0 returns once all
     world-1 peers have fetched it, so the call also orders the ranks (nobody proceeds before everyone arrived).
-    DL4DS_RDZV_TOKEN (optional, the same on all ranks of a job) is sent with the hello and must match: a per-job secret
-    for hosts where other users can reach MASTER_ADDR, and a guard against two jobs sharing a port by accident."""
+    DL4DS_RDZV_TOKEN (optional, the same on all ranks of a job) must match: a guard against two jobs sharing a port by
+    accident.  What travels is a fixed 32-byte SHA-256 of it (of the empty string when unset), so a rank WITH a token never
+    passes a rank 0 without one or vice versa, prefixes do not match, the hello has one length, and the comparison is
+    constant-time."""
     if world <= 1:
         return payload
     host, port = endpoint or rendezvous_endpoint()
@@ -98,7 +106,7 @@ def exchange_bytes(payload, rank, world, timeout=300.0, endpoint=None):
         srv.listen(world)
         seen = set()
         rejected = []                                 # (peer address, reason): reported if the deadline passes
-        token = os.environ.get('DL4DS_RDZV_TOKEN', '').encode()
+        token = _token_digest()
         try:
             while len(seen) < world - 1:
                 srv.settimeout(max(deadline - time.time(), 0.01))
@@ -112,14 +120,14 @@ def exchange_bytes(payload, rank, world, timeout=300.0, endpoint=None):
                 # connection that dies half-way) must not take rank 0 down: reject it, keep serving, fail at the deadline
                 try:
                     with conn:
-                        conn.settimeout(30.0)
-                        hello = _recv_exact(conn, len(_MAGIC) + 8)
+                        conn.settimeout(5.0)             # (the accept loop is serial: a silent client may hold it this long)
+                        hello = _recv_exact(conn, len(_MAGIC) + 8 + 32)
                         if hello[:len(_MAGIC)] != _MAGIC:
                             continue
-                        r, w = struct.unpack('<ii', hello[len(_MAGIC):])
-                        peer_token = _recv_exact(conn, len(token)) if token else b''
-                        if w != world or not (0 < r < world) or r in seen or peer_token != token:
-                            rejected.append((addr[0], f'says rank {r} of {w}' + ('' if peer_token == token else ', wrong token')))
+                        r, w = struct.unpack('<ii', hello[len(_MAGIC):len(_MAGIC) + 8])
+                        token_ok = hmac.compare_digest(hello[len(_MAGIC) + 8:], token)
+                        if w != world or not (0 < r < world) or r in seen or not token_ok:
+                            rejected.append((addr[0], f'says rank {r} of {w}' + ('' if token_ok else ', wrong token')))
                             conn.sendall(struct.pack('<i', -1))
                             continue
                         conn.sendall(struct.pack('<i', len(payload)) + payload)
@@ -136,7 +144,7 @@ def exchange_bytes(payload, rank, world, timeout=300.0, endpoint=None):
         try:
             with socket.create_connection((host, port), timeout=5.0) as conn:
                 conn.settimeout(max(deadline - time.time(), 1.0))
-                conn.sendall(_MAGIC + struct.pack('<ii', rank, world) + os.environ.get('DL4DS_RDZV_TOKEN', '').encode())
+                conn.sendall(_MAGIC + struct.pack('<ii', rank, world) + _token_digest())
                 n = struct.unpack('<i', _recv_exact(conn, 4))[0]
                 if n < 0:
                     raise RuntimeError('dl4ds_amd.parallel: rank 0 rejected this rank (rank / world / DL4DS_RDZV_TOKEN '

@@ -37,7 +37,13 @@ int dl4ds_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);   /* sy
 int dl4ds_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);   /* synchronous */
 int dl4ds_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);    /* async on the stream */
 int dl4ds_memset(void* p_dev, int value, size_t bytes);
-int dl4ds_sync(void);                             /* hipStreamSynchronize(library stream) */
+int dl4ds_sync(void);                             /* hipStreamSynchronize(library stream); fails if a kernel raised the
+                                                   * sticky device-side error word since the last wait (e.g. the persistent
+                                                   * ConvLSTM kernel gave up waiting for a neighbouring tile: that step is invalid) */
+/* diagnostic: a one-thread kernel on the library stream raises the device-side error word with `code` exactly as a kernel
+ * would; the next host-side wait (dl4ds_sync, a loss read-back ...) must fail once and clear it.  No reference counterpart
+ * (TensorFlow reports device-side failures through its own status plumbing). */
+int dl4ds_debug_raise_device_error(int code);
 int dl4ds_event_timer_start(void);                /* hipEventRecord on the library stream */
 int dl4ds_event_timer_stop(float* ms);            /* record + synchronize + elapsed ms */
 /* per-launch HIP-event timing on the library stream (off by default).  report: JSON

@@ -947,3 +947,17 @@ def test_conv_lstm2d(B, Tn, H, W, C, F, KS, relu):
     dx = np.empty(x.shape, np.float32)
     _lib.check(_lib.lib().dl4ds_memcpy_d2h(dx.ctypes.data, p, dx.nbytes))
     assert_matches_reference(dict(g_hip, x=dx), ref, what=(B, Tn, H, W, C, F, KS, relu))
+
+
+def test_device_side_error_word_fails_the_next_host_wait_once():
+    """ADVICE r3 (convlstm_seq.hip): a persistent kernel that gives up a bounded spin must not let the step pass for a valid one.
+    It raises a sticky, host-visible error word; every host-side wait checks it after the stream has drained.  Here a
+    one-thread kernel raises the same word the ConvLSTM kernel would: dl4ds_sync fails with the explanation, and the wait
+    after that is clean again."""
+    import dl4ds_amd._lib as L
+    lib = L.lib()
+    L.check(lib.dl4ds_sync())
+    L.check(lib.dl4ds_debug_raise_device_error(1))
+    with pytest.raises(L.Dl4dsHipError, match='persistent ConvLSTM kernel gave up'):
+        L.check(lib.dl4ds_sync())
+    L.check(lib.dl4ds_sync())

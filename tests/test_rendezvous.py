@@ -144,12 +144,12 @@ def test_bad_peers_do_not_take_rank_zero_down(monkeypatch):
                 time.sleep(0.02)
         raise AssertionError('rank 0 never listened')
     with connect() as c:                                     # another job's rank: "rank 1 of 4"
-        c.sendall(parallel._MAGIC + struct.pack('<ii', 1, 4))
+        c.sendall(parallel._MAGIC + struct.pack('<ii', 1, 4) + parallel._token_digest())
         assert struct.unpack('<i', parallel._recv_exact(c, 4))[0] == -1
     with connect() as c:                                     # dies half-way through the hello
         c.sendall(parallel._MAGIC[:4])
     with connect() as c:                                     # not this protocol at all
-        c.sendall(b'GET / HTTP/1.0\r\n\r\n' + b' ' * 16)
+        c.sendall(b'GET / HTTP/1.0\r\n\r\n' + b' ' * 48)
     got = parallel.exchange_bytes(b'', 1, 2, timeout=30.0, endpoint=ep)
     t.join(timeout=30)
     assert got == b'I' * 128 and out['root'] == b'I' * 128
@@ -178,10 +178,78 @@ def test_rendezvous_token_must_match(monkeypatch):
         except OSError:
             time.sleep(0.02)
     with c:                                                  # right rank and world, wrong secret: no id for this peer
-        c.sendall(parallel._MAGIC + struct.pack('<ii', 1, 2) + b'job-9999')
+        import hashlib
+        c.sendall(parallel._MAGIC + struct.pack('<ii', 1, 2) + hashlib.sha256(b'job-9999').digest())
         assert struct.unpack('<i', parallel._recv_exact(c, 4))[0] == -1
     t.join(timeout=30)
     assert 'wrong token' in err['root']
+
+
+@pytest.mark.parametrize('root_token,peer_token', [(None, 'job-1'), ('job-1', None), ('job-1', 'job-12'), ('job-12', 'job-1')])
+def test_rendezvous_token_is_symmetric_and_not_a_prefix_match(monkeypatch, root_token, peer_token):
+    """A rank 0 without a token must not accept a peer that sends one (and vice versa), and a token that merely starts
+    with rank 0's does not pass: what is compared is a fixed-size digest, present in every hello."""
+    import hashlib
+    import struct
+    import threading
+    import time
+    from dl4ds_amd import parallel
+    ep = ('127.0.0.1', _free_port())
+    if root_token is None:
+        monkeypatch.delenv('DL4DS_RDZV_TOKEN', raising=False)
+    else:
+        monkeypatch.setenv('DL4DS_RDZV_TOKEN', root_token)
+    err = {}
+
+    def root():
+        try:
+            parallel.exchange_bytes(b'I' * 128, 0, 2, timeout=3.0, endpoint=ep)
+        except TimeoutError as e:
+            err['root'] = str(e)
+    t = threading.Thread(target=root)
+    t.start()
+    for _ in range(200):
+        try:
+            c = socket.create_connection(ep, timeout=2.0)
+            break
+        except OSError:
+            time.sleep(0.02)
+    with c:
+        c.sendall(parallel._MAGIC + struct.pack('<ii', 1, 2) + hashlib.sha256((peer_token or '').encode()).digest())
+        assert struct.unpack('<i', parallel._recv_exact(c, 4))[0] == -1
+    t.join(timeout=30)
+    assert 'wrong token' in err['root']
+
+
+def test_bench_spawns_eight_ranks_with_the_launcher_environment_and_propagates_failure(tmp_path):
+    """bench.spawn_ranks for N = 8 with a stand-in child (no GPU here): every child sees RANK = LOCAL_RANK = i, WORLD_SIZE = 8,
+    one MASTER_ADDR / MASTER_PORT for all, HSA_ENABLE_IPC_MODE_LEGACY=0; a failing rank's code is what the launcher returns
+    and the surviving ranks are stopped instead of waiting in a collective for ever."""
+    import json
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    child = tmp_path / 'child.py'
+    child.write_text(
+        'import json, os, sys, time\n'
+        'r = int(os.environ["RANK"])\n'
+        'keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")\n'
+        'json.dump({k: os.environ.get(k) for k in keys} | {"argv": sys.argv[1:]}, open(os.path.join(sys.argv[1], f"env{r}.json"), "w"))\n'
+        'if len(sys.argv) > 2 and sys.argv[2] == "fail" and r == 5:\n'
+        '    time.sleep(0.3); sys.exit(7)\n'
+        'if len(sys.argv) > 2 and sys.argv[2] == "fail":\n'
+        '    time.sleep(60)\n')
+    assert bench.spawn_ranks(8, [str(tmp_path)], script=str(child), device_count=8) == 0
+    envs = [json.load(open(tmp_path / f'env{r}.json')) for r in range(8)]
+    for r, e in enumerate(envs):
+        assert e['RANK'] == e['LOCAL_RANK'] == str(r) and e['WORLD_SIZE'] == e['LOCAL_WORLD_SIZE'] == '8'
+        assert e['MASTER_ADDR'] == '127.0.0.1' and e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert len({e['MASTER_PORT'] for e in envs}) == 1
+    t0 = time.time()
+    assert bench.spawn_ranks(8, [str(tmp_path), 'fail'], script=str(child), device_count=8) == 7
+    assert time.time() - t0 < 30                              # the other seven were terminated, not waited for
+    with pytest.raises(SystemExit, match='only 4 HIP device'):
+        bench.spawn_ranks(8, [], script=str(child), device_count=4)
 
 
 @pytest.mark.parametrize('value,expect', [(None, False), ('', False), ('0', False), ('false', False), ('No', False), ('off', False),
