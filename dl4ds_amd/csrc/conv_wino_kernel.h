@@ -81,37 +81,45 @@ __device__ __forceinline__ f32x4 sub4(const f32x4 a, const f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-// a + b and c + s * b on float4 as packed instructions (one issue per two floats: what a vector instruction costs beside
-// MFMAs is its issue, WINO_SCALAR_VALU builds the plain forms for comparison)
+// Packed arithmetic the COMPILER schedules (second forms of the kernels).  An inline-asm instruction is opaque to hipcc's hazard
+// recogniser: placed next to MFMAs it may read an accumulator before the MFMA has written it, or overwrite a register an
+// in-flight MFMA still reads (cdna_hip_programming.md section 5.7, item 2; the <2,2> weight-gradient shape failed that way, the
+// <3,3> shape passed by luck of its register allocation).  <2 x float> fma / add select v_pk_fma_f32 / v_pk_add_f32; a
+// subtraction is written as fma(b, -1, a) with an OPAQUE -1 (wino::pk_consts) so that it cannot be turned back into four
+// scalar v_sub_f32, which is what hipcc does with float4 subtractions.  WINO_SCALAR_VALU builds the plain forms for comparison.
+struct PkConsts { f32x2 neg1; };
+__device__ __forceinline__ PkConsts pk_consts() {
+    float m = -1.f;
+    asm volatile("" : "+v"(m));                                      // (no instruction: only hides the value from the optimiser)
+    PkConsts c;
+    c.neg1 = (f32x2){m, m};
+    return c;
+}
+__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 pk_fma(const f32x2 b, const f32x2 s, const f32x2 c) { return __builtin_elementwise_fma(b, s, c); }     // c + s b
+__device__ __forceinline__ f32x2 pk_sub(const PkConsts& k, const f32x2 a, const f32x2 b) { return __builtin_elementwise_fma(b, k.neg1, a); }
+__device__ __forceinline__ f32x2 lo2(const f32x4 a) { return __builtin_shufflevector(a, a, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(const f32x4 a) { return __builtin_shufflevector(a, a, 2, 3); }
+__device__ __forceinline__ f32x4 cat4(const f32x2 l, const f32x2 h) { return __builtin_shufflevector(l, h, 0, 1, 2, 3); }
 __device__ __forceinline__ f32x4 add4(const f32x4 a, const f32x4 b) {
 #ifdef WINO_SCALAR_VALU
     return a + b;
 #else
-    f32x2 lo, hi;
-    const f32x2 alo = __builtin_shufflevector(a, a, 0, 1), ahi = __builtin_shufflevector(a, a, 2, 3);
-    const f32x2 blo = __builtin_shufflevector(b, b, 0, 1), bhi = __builtin_shufflevector(b, b, 2, 3);
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(alo), "v"(blo));
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(ahi), "v"(bhi));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    return cat4(pk_add(lo2(a), lo2(b)), pk_add(hi2(a), hi2(b)));
 #endif
 }
-__device__ __forceinline__ f32x4 subp4(const f32x4 a, const f32x4 b) {
+__device__ __forceinline__ f32x4 subp4(const PkConsts& k, const f32x4 a, const f32x4 b) {
 #ifdef WINO_SCALAR_VALU
     return a - b;
 #else
-    return sub4(a, b);
+    return cat4(pk_sub(k, lo2(a), lo2(b)), pk_sub(k, hi2(a), hi2(b)));
 #endif
 }
 __device__ __forceinline__ f32x4 fma4(const f32x4 b, const f32x2 s, const f32x4 c) {       // c + s * b, s = (s, s)
 #ifdef WINO_SCALAR_VALU
     return c + s[0] * b;
 #else
-    f32x2 lo, hi;
-    const f32x2 clo = __builtin_shufflevector(c, c, 0, 1), chi = __builtin_shufflevector(c, c, 2, 3);
-    const f32x2 blo = __builtin_shufflevector(b, b, 0, 1), bhi = __builtin_shufflevector(b, b, 2, 3);
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(blo), "v"(s), "v"(clo));
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(s), "v"(chi));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    return cat4(pk_fma(lo2(b), s, lo2(c)), pk_fma(hi2(b), s, hi2(c)));
 #endif
 }
 
@@ -398,7 +406,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams wp) 
 #pragma unroll
             for (int cb = 0; cb < NT; ++cb) {
                 R0[cb] += R1[cb] + M[cb];
-                R1[cb] = sub4(R1[cb], M[cb]);
+                R1[cb] = R1[cb] - M[cb];               // (plain: an asm instruction here could read M before the MFMAs wrote it)
             }
             kloop(3, R1);
         }
@@ -624,6 +632,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino2_kernel(const WinoParams wp)
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg1 = wave == 1 ? 1.f : -1.f;
     const f32x2 sg = {sg1, sg1};
+    const PkConsts pkc = pk_consts();
     const int k_ty = (l15 >= 4 && l15 < 12) ? 1 : 0;
     const int k_tx = k_ty ? l15 - 4 : (l15 < 4 ? l15 : l15 - 8);
     const int k_base = ((2 * k_ty * HW + 2 * k_tx) * SP + lq) * 4;                  // floats
@@ -709,10 +718,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino2_kernel(const WinoParams wp)
 #ifdef WINO_NO_A
                 V[0] = Tn[0]; V[1] = Tn[1]; V[2] = Tn[2]; V[3] = Tn[3];
 #else
-                V[0] = subp4(Tn[0], Tn[2]);
+                V[0] = subp4(pkc, Tn[0], Tn[2]);
                 V[1] = add4(Tn[1], Tn[2]);
-                V[2] = subp4(Tn[2], Tn[1]);
-                V[3] = subp4(Tn[1], Tn[3]);
+                V[2] = subp4(pkc, Tn[2], Tn[1]);
+                V[3] = subp4(pkc, Tn[1], Tn[3]);
 #endif
             };
             auto mfmas = [&](int kq, int nu) __attribute__((always_inline)) {
@@ -766,7 +775,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino2_kernel(const WinoParams wp)
 #pragma unroll
             for (int cb = 0; cb < NT; ++cb) {
                 const f32x4 s12 = add4(acc[1][cb], acc[2][cb]);
-                acc[2][cb] = subp4(acc[1][cb], acc[2][cb]);
+                acc[2][cb] = subp4(pkc, acc[1][cb], acc[2][cb]);
                 acc[1][cb] = s12;
             }
             __builtin_amdgcn_sched_barrier(0);

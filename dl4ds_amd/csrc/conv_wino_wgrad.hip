@@ -294,12 +294,14 @@ __global__ void __launch_bounds__(256, 1) conv_wino_wgrad_kernel(const WinoWgrad
 // The MFMA operands of dU[xi][nu] += V[xi][nu]^T dM[xi][nu] are, in lane (l15, k-slot lq) and k-step s,
 //     A = V [xi][nu][tile(s, lq)][cin  16 i + l15]        B = dM[xi][nu][tile(s, lq)][cout 16 j + l15]
 // i.e. ONE channel of one tile each -- scalars.  A lane therefore reads the raw values of its own (tile, channel) pairs (8 of the
-// input patch: rows ra, rb of wave xi, four columns; 4 of the output gradient's 2 x 2 pixels) as ds_read2_b32 pairs of adjacent
-// columns and transforms them with PACKED instructions on those pairs:
-//     (T0, T1) = a01 + sg b01, (T2, T3) = a23 + sg b23;  (V0, V3) = (T0, T1) - (T2, T3);  (V1, V2) = (T1 + T2, T2 - T1)  [op_sel]
-//     (r0, r1) = y0. + c y1.  (c = 0, 1, -1, 0 for xi = 0..3; xi = 3 reads row 1 as its first row);  dM0 = r0, dM3 = r1,
-//     (dM1, dM2) = (r0 + r1, r0 - r1)  [op_sel]
-// 4 + 2 packed instructions and 4 + 2 LDS reads per (tile, channel) feed 4 x (NT | KQ) MFMAs.  What the first form paid for V
+// input patch: rows ra, rb of wave xi, four columns; 4 of the output gradient's 2 x 2 pixels).  Channel blocks are taken TWO AT A
+// TIME -- channels c and c + 16 of a pixel come back from one ds_read2_b32 as a register pair -- and transformed with packed
+// instructions on those pairs (an odd third block with plain ones):
+//     T_c = a_c + sg b_c (c = 0..3);  V0 = T0 - T2, V1 = T1 + T2, V2 = T2 - T1, V3 = T1 - T3
+//     r_c = y_first,c + cy y_1,c (c = 0, 1; cy = 0, 1, -1, 0 for xi = 0..3, xi = 3 reads row 1 as its first row);
+//     dM0 = r0, dM1 = r0 + r1, dM2 = r0 - r1, dM3 = r1
+// all of it arithmetic the compiler schedules (no inline asm beside MFMAs: conv_wino_kernel.h, pk_consts).
+// 8 + 4 packed instructions and 8 + 4 LDS reads per (tile, channel pair) feed 4 x 2 x (NT | KQ) MFMAs.  What the first form paid for V
 // and dM -- 32 ds_write_b128 and 48 ds_read2 per thread and tile group, two transform phases with every wave idle on the matrix
 // side, 106 KB of LDS that kept a CU to ONE workgroup -- is gone: 72 KB per workgroup (both raw blocks double-buffered + the
 // DMA offset tables), two workgroups per CU, one barrier per tile group.  The k-slots of a k-step take the tiles tx = 4 (s & 1)
@@ -322,28 +324,6 @@ struct Wg2Geom {
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t pk_fma(const f32x2_t b, const f32x2_t s, const f32x2_t c) {      // c + s * b
-    f32x2_t r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(s), "v"(c));
-    return r;
-}
-__device__ __forceinline__ f32x2_t pk_sub(const f32x2_t a, const f32x2_t b) {
-    f32x2_t r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// (a.hi + b.lo, b.lo - a.hi): the middle pair of the column transform from (T0, T1), (T2, T3)
-__device__ __forceinline__ f32x2_t pk_mid(const f32x2_t a, const f32x2_t b) {
-    f32x2_t r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// (a.lo + a.hi, a.lo - a.hi)
-__device__ __forceinline__ f32x2_t pk_sumdiff(const f32x2_t a) {
-    f32x2_t r;
-    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a));
-    return r;
-}
 
 template <int KQ, int NT>
 __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgradParams wp) {
@@ -465,6 +445,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
     const int y_first = wave == 3 ? 1 : 0;                          // xi = 3: r = y1.
     const float cy1 = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);   // r = y(first). + cy y1.
     const f32x2_t cy = {cy1, cy1};
+    const wino::PkConsts pkc = wino::pk_consts();
     const int txo = (lq >> 1) + 2 * (lq & 1);                       // k-slots 0..3 take tiles tx0 + {0, 2, 1, 3}
     const int x_lane = (2 * txo * SPX) * 4 + l15;                   // floats, relative to the step's first tile
     const int y_lane = (2 * txo * SPY) * 4 + l15;
@@ -492,8 +473,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
             Item nxt = cur;
             const float* const bx = rawx + buf * (GM::RAWX * 4) + x_lane;
             const float* const by = rawy + buf * (GM::RAWY * 4) + y_lane;
-            // raw values of k-step s: [i][row a / b][column pair], [j][row][pair]
-            f32x2_t xr[KQ][2][2], yr[NT][2];
+            // raw values of k-step s.  Channel blocks in pairs (i, i + 1) = the two halves of a register pair; an odd last block alone.
+            constexpr int KP = KQ / 2, NP = NT / 2;
+            f32x2_t xa[KP ? KP : 1][4], xb[KP ? KP : 1][4], ya[NP ? NP : 1][2], yb[NP ? NP : 1][2];
+            float xa1[4], xb1[4], ya1[2], yb1[2];                    // (KQ, NT odd)
             auto fetch = [&](int s) __attribute__((always_inline)) {
                 const int ty = s >> 1, tx0 = 4 * (s & 1);
                 const float* pa = bx + ((2 * ty + ra) * HW + 2 * tx0) * (SPX * 4);
@@ -501,16 +484,22 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
                 const float* py = by + ((2 * ty + y_first) * 16 + 2 * tx0) * (SPY * 4);
                 const float* p1 = by + ((2 * ty + 1) * 16 + 2 * tx0) * (SPY * 4);
 #pragma unroll
-                for (int i = 0; i < KQ; ++i)
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        xr[i][0][h] = (f32x2_t){pa[16 * i + (2 * h) * (SPX * 4)], pa[16 * i + (2 * h + 1) * (SPX * 4)]};
-                        xr[i][1][h] = (f32x2_t){pb[16 * i + (2 * h) * (SPX * 4)], pb[16 * i + (2 * h + 1) * (SPX * 4)]};
+                    for (int i = 0; i < KP; ++i) {
+                        xa[i][c] = (f32x2_t){pa[32 * i + c * (SPX * 4)], pa[32 * i + 16 + c * (SPX * 4)]};
+                        xb[i][c] = (f32x2_t){pb[32 * i + c * (SPX * 4)], pb[32 * i + 16 + c * (SPX * 4)]};
                     }
+                    if (KQ & 1) { xa1[c] = pa[16 * (KQ - 1) + c * (SPX * 4)]; xb1[c] = pb[16 * (KQ - 1) + c * (SPX * 4)]; }
+                }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    yr[j][0] = (f32x2_t){py[16 * j], py[16 * j + SPY * 4]};
-                    yr[j][1] = (f32x2_t){p1[16 * j], p1[16 * j + SPY * 4]};
+                for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        ya[j][c] = (f32x2_t){py[32 * j + c * (SPY * 4)], py[32 * j + 16 + c * (SPY * 4)]};
+                        yb[j][c] = (f32x2_t){p1[32 * j + c * (SPY * 4)], p1[32 * j + 16 + c * (SPY * 4)]};
+                    }
+                    if (NT & 1) { ya1[c] = py[16 * (NT - 1) + c * (SPY * 4)]; yb1[c] = p1[16 * (NT - 1) + c * (SPY * 4)]; }
                 }
             };
             fetch(0);
@@ -519,19 +508,33 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
                 // operands of this k-step
                 float A[4][KQ], B[4][NT];
 #pragma unroll
-                for (int i = 0; i < KQ; ++i) {
-                    const f32x2_t t01 = pk_fma(xr[i][1][0], sg, xr[i][0][0]);
-                    const f32x2_t t23 = pk_fma(xr[i][1][1], sg, xr[i][0][1]);
-                    const f32x2_t v03 = pk_sub(t01, t23);
-                    const f32x2_t v12 = pk_mid(t01, t23);
-                    A[0][i] = v03[0]; A[1][i] = v12[0]; A[2][i] = v12[1]; A[3][i] = v03[1];
+                for (int i = 0; i < KP; ++i) {
+                    f32x2_t t[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = wino::pk_fma(xb[i][c], sg, xa[i][c]);
+                    const f32x2_t v0 = wino::pk_sub(pkc, t[0], t[2]), v1 = wino::pk_add(t[1], t[2]);
+                    const f32x2_t v2 = wino::pk_sub(pkc, t[2], t[1]), v3 = wino::pk_sub(pkc, t[1], t[3]);
+                    A[0][2 * i] = v0[0]; A[0][2 * i + 1] = v0[1]; A[1][2 * i] = v1[0]; A[1][2 * i + 1] = v1[1];
+                    A[2][2 * i] = v2[0]; A[2][2 * i + 1] = v2[1]; A[3][2 * i] = v3[0]; A[3][2 * i + 1] = v3[1];
+                }
+                if (KQ & 1) {
+                    float t[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = fmaf(xb1[c], sg1, xa1[c]);
+                    A[0][KQ - 1] = t[0] - t[2]; A[1][KQ - 1] = t[1] + t[2]; A[2][KQ - 1] = t[2] - t[1]; A[3][KQ - 1] = t[1] - t[3];
                 }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const f32x2_t r = pk_fma(yr[j][1], cy, yr[j][0]);
-                    const f32x2_t m12 = pk_sumdiff(r);
-                    B[0][j] = r[0]; B[1][j] = m12[0]; B[2][j] = m12[1]; B[3][j] = r[1];
-                    dbacc[j] += m12[0];                              // (wave 1: the tile's four pixels; the other waves' sums are unused)
+                for (int j = 0; j < NP; ++j) {
+                    const f32x2_t r0 = wino::pk_fma(yb[j][0], cy, ya[j][0]), r1 = wino::pk_fma(yb[j][1], cy, ya[j][1]);
+                    const f32x2_t m1 = wino::pk_add(r0, r1), m2 = wino::pk_sub(pkc, r0, r1);
+                    B[0][2 * j] = r0[0]; B[0][2 * j + 1] = r0[1]; B[1][2 * j] = m1[0]; B[1][2 * j + 1] = m1[1];
+                    B[2][2 * j] = m2[0]; B[2][2 * j + 1] = m2[1]; B[3][2 * j] = r1[0]; B[3][2 * j + 1] = r1[1];
+                    dbacc[2 * j] += m1[0]; dbacc[2 * j + 1] += m1[1];          // (wave 1: the tile's four pixels; the other waves' sums are unused)
+                }
+                if (NT & 1) {
+                    const float r0 = fmaf(yb1[0], cy1, ya1[0]), r1 = fmaf(yb1[1], cy1, ya1[1]);
+                    B[0][NT - 1] = r0; B[1][NT - 1] = r0 + r1; B[2][NT - 1] = r0 - r1; B[3][NT - 1] = r1;
+                    dbacc[NT - 1] += r0 + r1;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (s < 3) fetch(s + 1);
@@ -578,9 +581,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
     }
 }
 
-// out[i] = sum over k of slab[k * n + i], in the order of k (bitwise reproducible); n % 4 == 0
-__global__ void __launch_bounds__(256) wino_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n4, int nslabs) {
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
+// out[g][i] = sum over the slabs k of group g (blockIdx.y: slabs [g per, (g + 1) per)) of slab[k * n + i], in the order of k
+// (bitwise reproducible); n % 4 == 0.  The closing transform adds the groups, again in a fixed order: with two workgroups per CU
+// there are 512 slabs, and one thread walking all of them serially was 25 us of latency per weight gradient.
+__global__ void __launch_bounds__(256) wino_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n4, int nslabs_all,
+                                                            int per) {
+    const int k_lo = blockIdx.y * per;
+    const int nslabs = min(per, nslabs_all - k_lo);
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(slab) + (size_t)k_lo * n4;
+    f32x4* o4 = reinterpret_cast<f32x4*>(out) + (size_t)blockIdx.y * n4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
         int k = 0;
@@ -592,7 +601,7 @@ __global__ void __launch_bounds__(256) wino_slab_sum_kernel(const float* __restr
             for (int u = 0; u < 8; ++u) a += v[u];
         }
         for (; k < nslabs; ++k) a += s4[(size_t)k * n4 + i];
-        reinterpret_cast<f32x4*>(out)[i] = a;
+        o4[i] = a;
     }
 }
 
@@ -600,7 +609,7 @@ __global__ void __launch_bounds__(256) wino_slab_sum_kernel(const float* __restr
 // thread = (pair, cin block, cout block, lane): four input channels (rows 4 lq + r) of one output channel
 __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
                                                                 int Cin, int Cout, int KQ, int NT, int ncin, int ncout, int accumulate,
-                                                                int accumulate_db) {
+                                                                int accumulate_db, int ngroups, size_t gstride) {
     const int F = 4 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
     const int per_pair = KQ * NT * 64;
     const int total = ncin * ncout * per_pair;
@@ -618,8 +627,10 @@ __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __r
         for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
-                s[xi][nu] = *reinterpret_cast<const f32x4*>(S + (size_t)pc * ST + ((size_t)((xi * 4 + nu) * KQ + i) * NT + j) * 256 + lane * 4);
-                if ((xi == 3) != (nu == 3)) s[xi][nu] = -s[xi][nu];
+                const float* q = S + (size_t)pc * ST + ((size_t)((xi * 4 + nu) * KQ + i) * NT + j) * 256 + lane * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(q);
+                for (int g = 1; g < ngroups; ++g) v += *reinterpret_cast<const f32x4*>(q + g * gstride);
+                s[xi][nu] = ((xi == 3) != (nu == 3)) ? -v : v;
             }
         // rows: t[a][nu] = sum_xi G[xi][a] s[xi][nu]; G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
         f32x4 t[3][4];
@@ -647,7 +658,9 @@ __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __r
     if (db) {
         for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < Cout; c += gridDim.x * blockDim.x) {
             const int pcq = c / (16 * NT);                          // (cin chunk 0)
-            const float v = S[(size_t)pcq * ST + 4 * F * 256 + (c - pcq * 16 * NT)];
+            const float* q = S + (size_t)pcq * ST + 4 * F * 256 + (c - pcq * 16 * NT);
+            float v = *q;
+            for (int g = 1; g < ngroups; ++g) v += q[g * gstride];
             db[c] = accumulate_db ? db[c] + v : v;
         }
     }
@@ -724,7 +737,9 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     if (x.C < 24 || dy.C < 24) return false;
     // (measured, B = 64 at 128^2 / 256^2: 48 -> 48 0.31 vs 0.39 ms direct, 48 -> 192 1.10 vs 1.28, 40 -> 48 0.30 vs 0.39; chunks of 32
     //  channels on either side do not pay: 48 -> 32 0.90 vs 0.88, 32 -> 32 0.19 vs 0.17)
-    if (!force && (x.C <= 32 || dy.C <= 32)) return false;
+    // (first form, B = 64: chunks of 32 channels on either side did not pay -- 48 -> 32 at 256^2 0.90 vs 0.88 ms direct, 32 -> 32 0.19
+    //  vs 0.17; second form: 0.58 vs 0.84 and 0.127 vs 0.152, so every layer with >= 24 channels on both sides takes it)
+    if (!force && wgrad_first_form() && (x.C <= 32 || dy.C <= 32)) return false;
     auto span = [](const TView& v) { const size_t r = std::max(v.d2s, 1); return (size_t)8 * v.W * r * r * v.ld * 4; };
     if (span(x) >= (1ull << 31) || span(dy) >= (1ull << 31)) return false;
     const int KQ = (cdiv(x.C, 32) * 32 < cdiv(x.C, 48) * 48) ? 2 : 3;
@@ -752,8 +767,10 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     const int F = 4 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
     const int nslabs = 8 * nsub;
     const size_t per_k = (size_t)npair * ST;
-    float* const slab = wgrad_scratch(s, per_k * (nslabs + 1));
-    float* const sum = slab + per_k * nslabs;
+    const int ngroups = std::min(nslabs, 16), per_group = cdiv(nslabs, ngroups);
+    float* const slab = wgrad_scratch(s, per_k * (nslabs + ngroups + 1));
+    float* const part = slab + per_k * nslabs;             // one partial sum per group of slabs,
+    float* const sum = part + per_k * ngroups;             // then their sum (two short launches instead of one long serial walk)
     wp.slab = slab;
     const double px = (double)x.N * x.H * x.W;
     {
@@ -769,11 +786,13 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     }
     ProfScope ps(s, "wino_wgrad_finish", 0.0, 4.0 * (double)per_k * (nslabs + 2));
     const int n4 = (int)(per_k / 4);
-    DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048)), dim3(256), 0, s, slab, sum, n4, nslabs);
+    const int ng = cdiv(nslabs, per_group);
+    DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048), ng), dim3(256), 0, s, slab, part, n4, nslabs, per_group);
+    DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048), 1), dim3(256), 0, s, part, sum, n4, ng, ng);
     HIP_CHECK(hipGetLastError());
     const int total = npair * KQ * NT * 64;
     DL4DS_LAUNCH(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, sum, dw, db, x.C, dy.C, KQ, NT,
-                       wp.ncin, wp.ncout, accumulate, accumulate_db);
+                       wp.ncin, wp.ncout, accumulate, accumulate_db, 1, per_k);
     HIP_CHECK(hipGetLastError());
     return true;
 }

@@ -284,10 +284,11 @@ def test_cfg2_full_size_against_the_oracle(monkeypatch, winograd):
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x], y))
     # the kernels that carry the bench step (profiles/kernel_stats_r03.txt) are the ones that just ran
-    must = ('conv_wino<3,3>', 'conv_wino<3,2>', 'conv_wino<2,3>', 'conv_wino<2,2>', 'conv_wino_wgrad<3,3>') if winograd else \
+    must = ('conv_wino<3,3>', 'conv_wino<3,2>', 'conv_wino<2,3>', 'conv_wino<2,2>', 'conv_wino_wgrad<3,3>', 'conv_wino_wgrad<3,2>',
+            'conv_wino_wgrad<2,2>') if winograd else \
            ('conv_stream_ws<3,6,3,8>', 'conv_stream_ws<3,12,2,4>', 'conv_stream_ws<3,8,3,4>', 'conv_wgrad_rows<3,3,1,4>',
-            'conv_wgrad_rows<3,3,1,1>')
-    for m in must + ('conv_narrow_pair_ws<4>', 'conv_narrow_wgrad<8>', 'conv_wgrad_rows<3,3,1,2>'):
+            'conv_wgrad_rows<3,3,1,1>', 'conv_wgrad_rows<3,3,1,2>')
+    for m in must + ('conv_narrow_pair_ws<4>', 'conv_narrow_wgrad<8>'):
         assert m in tags, (m, sorted(tags))
     assert winograd or not any(t.startswith('conv_wino') for t in tags), sorted(tags)
     if 'ref' not in _CFG2_REF:          # (same weights, inputs and targets in both runs: the oracle is evaluated once)

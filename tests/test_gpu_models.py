@@ -9,7 +9,8 @@ from oracle import np_ops as N
 from oracle import torch_ops as T
 from oracle import models as M
 from oracle import train as TR
-from tests.parity import assert_grads_close, assert_matches_reference, banded_reference, oracle_reference
+from tests.parity import (assert_grads_close, assert_matches_reference, banded_reference, oracle_reference,
+                          targets_clear_of_the_kink)
 
 pytestmark = pytest.mark.gpu
 
@@ -134,7 +135,7 @@ def test_supervised_forward_grads_and_adam_step(kind, cfg, xs, ss, loss):
     assert out.shape == ref.shape
     assert rel(out, ref) < 1e-3
     # loss + grads
-    y = rng.standard_normal(ref.shape).astype(np.float32)
+    y = targets_clear_of_the_kink(ref, rng)          # (gradients that are sums, not random walks: oracle/reference.py)
     PT = M.convert(P, T, requires_grad=True)
     opt = TR.Adam(PT, lr=1e-3)
     lv, grads, _ = TR.supervised_step(kind, ocfg, PT, T.asarray(x.astype(np.float64)),
@@ -201,7 +202,7 @@ def test_headline_model_through_producer_consumer_kernels(monkeypatch):
     inputs = [x] if s is None else [x, s]
     out = model(inputs)
     assert rel(out, ref) < 1e-3
-    y = rng.standard_normal(ref.shape).astype(np.float32)
+    y = targets_clear_of_the_kink(ref, rng)          # (gradients that are sums, not random walks: oracle/reference.py)
     PT = M.convert(P, T, requires_grad=True)
     lv, grads, _ = TR.supervised_step(kind, ocfg, PT, T.asarray(x.astype(np.float64)),
                                       None if s is None else T.asarray(s.astype(np.float64)),
@@ -228,7 +229,7 @@ def test_wide_model_through_the_winograd_kernels(monkeypatch, sx):
     out, tags_f = kernel_tags(lambda: model([x]))
     assert any(t.startswith('conv_wino<') for t in tags_f), sorted(tags_f)
     assert rel(out, ref) < 1e-3
-    y = rng.standard_normal(ref.shape).astype(np.float32)
+    y = targets_clear_of_the_kink(ref, rng)          # (gradients that are sums, not random walks: oracle/reference.py)
     PT = M.convert(P, T, requires_grad=True)
     lv, grads, _ = TR.supervised_step(kind, ocfg, PT, T.asarray(x.astype(np.float64)), None, T.asarray(y.astype(np.float64)),
                                       loss='mae', opt=None)
