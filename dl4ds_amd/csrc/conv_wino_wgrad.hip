@@ -304,9 +304,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_wgrad_kernel(const WinoWgrad
 // 8 + 4 packed instructions and 8 + 4 LDS reads per (tile, channel pair) feed 4 x 2 x (NT | KQ) MFMAs.  What the first form paid for V
 // and dM -- 32 ds_write_b128 and 48 ds_read2 per thread and tile group, two transform phases with every wave idle on the matrix
 // side, 106 KB of LDS that kept a CU to ONE workgroup -- is gone: 72 KB per workgroup (both raw blocks double-buffered + the
-// DMA offset tables), two workgroups per CU, one barrier per tile group.  The k-slots of a k-step take the tiles tx = 4 (s & 1)
-// + {0, 2, 1, 3}[lq] of tile row s >> 1: tiles two apart sit 16 banks apart at the raw pitch of 4 K + 1 sixteen-byte slots, so
-// the 32-lane halves of every ds_read are conflict-free.  Slab layout, slab sum and the closing transform are unchanged.
+// DMA offset tables), two workgroups per CU, one barrier per tile group.  The k-slots of a k-step take the tiles tx = 2 (s & 1)
+// + {0, 4, 1, 5}[lq] of tile row s >> 1: tiles four apart sit 32 banks (mod 64) apart at the raw pitch of 4 K + 1 sixteen-byte
+// slots, so the 32-lane halves of every 8-byte read are conflict-free.  Slab layout and slab sum are unchanged; the closing
+// transform un-permutes the channels of paired blocks.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KQ, int NT>
 struct Wg2Geom {
@@ -446,9 +447,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
     const float cy1 = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);   // r = y(first). + cy y1.
     const f32x2_t cy = {cy1, cy1};
     const wino::PkConsts pkc = wino::pk_consts();
-    const int txo = (lq >> 1) + 2 * (lq & 1);                       // k-slots 0..3 take tiles tx0 + {0, 2, 1, 3}
-    const int x_lane = (2 * txo * SPX) * 4 + l15;                   // floats, relative to the step's first tile
-    const int y_lane = (2 * txo * SPY) * 4 + l15;
+    // k-slots 0..3 take tiles tx0 + {0, 4, 1, 5}: the two k-slots of a 32-lane half read pixels 8 apart = 32 banks (mod 64) apart
+    // at either pitch, which is what an 8-byte read per lane needs.  Channel blocks come in PAIRS: lane m of blocks (2 p, 2 p + 1)
+    // holds channels 32 p + 2 m and 32 p + 2 m + 1 -- adjacent floats, ONE ds_read_b64 = the register pair the packed
+    // instructions work on (the closing transform knows the permutation: wino_wgrad_finish_kernel, `paired`); an odd last block
+    // holds channels 16 (K - 1) + m.
+    const int txo = (lq & 1) * 4 + (lq >> 1);
+    const int x_lane = (2 * txo * SPX) * 4, y_lane = (2 * txo * SPY) * 4;      // floats, relative to the step's first tile
 
     f32x4 acc[4][KQ][NT];
 #pragma unroll
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
             f32x2_t xa[KP ? KP : 1][4], xb[KP ? KP : 1][4], ya[NP ? NP : 1][2], yb[NP ? NP : 1][2];
             float xa1[4], xb1[4], ya1[2], yb1[2];                    // (KQ, NT odd)
             auto fetch = [&](int s) __attribute__((always_inline)) {
-                const int ty = s >> 1, tx0 = 4 * (s & 1);
+                const int ty = s >> 1, tx0 = 2 * (s & 1);
                 const float* pa = bx + ((2 * ty + ra) * HW + 2 * tx0) * (SPX * 4);
                 const float* pb = bx + ((2 * ty + rb) * HW + 2 * tx0) * (SPX * 4);
                 const float* py = by + ((2 * ty + y_first) * 16 + 2 * tx0) * (SPY * 4);
@@ -487,19 +492,19 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
                 for (int c = 0; c < 4; ++c) {
 #pragma unroll
                     for (int i = 0; i < KP; ++i) {
-                        xa[i][c] = (f32x2_t){pa[32 * i + c * (SPX * 4)], pa[32 * i + 16 + c * (SPX * 4)]};
-                        xb[i][c] = (f32x2_t){pb[32 * i + c * (SPX * 4)], pb[32 * i + 16 + c * (SPX * 4)]};
+                        xa[i][c] = *reinterpret_cast<const f32x2_t*>(pa + 32 * i + 2 * l15 + c * (SPX * 4));
+                        xb[i][c] = *reinterpret_cast<const f32x2_t*>(pb + 32 * i + 2 * l15 + c * (SPX * 4));
                     }
-                    if (KQ & 1) { xa1[c] = pa[16 * (KQ - 1) + c * (SPX * 4)]; xb1[c] = pb[16 * (KQ - 1) + c * (SPX * 4)]; }
+                    if (KQ & 1) { xa1[c] = pa[16 * (KQ - 1) + l15 + c * (SPX * 4)]; xb1[c] = pb[16 * (KQ - 1) + l15 + c * (SPX * 4)]; }
                 }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
 #pragma unroll
                     for (int j = 0; j < NP; ++j) {
-                        ya[j][c] = (f32x2_t){py[32 * j + c * (SPY * 4)], py[32 * j + 16 + c * (SPY * 4)]};
-                        yb[j][c] = (f32x2_t){p1[32 * j + c * (SPY * 4)], p1[32 * j + 16 + c * (SPY * 4)]};
+                        ya[j][c] = *reinterpret_cast<const f32x2_t*>(py + 32 * j + 2 * l15 + c * (SPY * 4));
+                        yb[j][c] = *reinterpret_cast<const f32x2_t*>(p1 + 32 * j + 2 * l15 + c * (SPY * 4));
                     }
-                    if (NT & 1) { ya1[c] = py[16 * (NT - 1) + c * (SPY * 4)]; yb1[c] = p1[16 * (NT - 1) + c * (SPY * 4)]; }
+                    if (NT & 1) { ya1[c] = py[16 * (NT - 1) + l15 + c * (SPY * 4)]; yb1[c] = p1[16 * (NT - 1) + l15 + c * (SPY * 4)]; }
                 }
             };
             fetch(0);
@@ -537,19 +542,25 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
                     dbacc[NT - 1] += r0 + r1;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                auto mfmas = [&](int nu) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = 0; i < KQ; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[nu][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[nu][i], B[nu][j], acc[nu][i][j], 0, 0, 0);
+                };
+                mfmas(0);
+                mfmas(1);
+                __builtin_amdgcn_sched_barrier(0);
+                // the next k-step's raw values are requested once half of this step's operands are dead (register budget of <3,3>)
                 if (s < 3) fetch(s + 1);
                 if (s == 0 && has_next) {
                     // the next raw blocks: every wave left the buffers they go to before the barrier that ended the last iteration
                     nxt = decode(ntg);
                     stage_issue(nxt, buf ^ 1);
                 }
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-                    for (int i = 0; i < KQ; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[nu][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[nu][i], B[nu][j], acc[nu][i][j], 0, 0, 0);
+                mfmas(2);
+                mfmas(3);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the next blocks have landed
@@ -577,7 +588,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
     __syncthreads();
     if (tid < CO) {
         const int j = tid >> 4, c = tid & 15;
-        myslab[GM::FR + tid] = (lds[(j * 4 + 0) * 16 + c] + lds[(j * 4 + 1) * 16 + c]) + (lds[(j * 4 + 2) * 16 + c] + lds[(j * 4 + 3) * 16 + c]);
+        const int co = j < 2 * (NT / 2) ? 32 * (j >> 1) + 2 * c + (j & 1) : 16 * j + c;        // (the lane's output channel: paired blocks)
+        myslab[GM::FR + co] = (lds[(j * 4 + 0) * 16 + c] + lds[(j * 4 + 1) * 16 + c]) + (lds[(j * 4 + 2) * 16 + c] + lds[(j * 4 + 3) * 16 + c]);
     }
 }
 
@@ -609,7 +621,7 @@ __global__ void __launch_bounds__(256) wino_slab_sum_kernel(const float* __restr
 // thread = (pair, cin block, cout block, lane): four input channels (rows 4 lq + r) of one output channel
 __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
                                                                 int Cin, int Cout, int KQ, int NT, int ncin, int ncout, int accumulate,
-                                                                int accumulate_db, int ngroups, size_t gstride) {
+                                                                int accumulate_db, int ngroups, size_t gstride, int paired) {
     const int F = 4 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
     const int per_pair = KQ * NT * 64;
     const int total = ncin * ncout * per_pair;
@@ -619,8 +631,11 @@ __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __r
         const int j = r % NT; r /= NT;
         const int i = r % KQ; r /= KQ;
         const int pc = r;
-        const int cin_b = (pc / ncout) * 16 * KQ + 16 * i + 4 * (lane >> 4);
-        const int co = (pc % ncout) * 16 * NT + 16 * j + (lane & 15);
+        // second form of the kernel (`paired`): row m of the blocks (2 p, 2 p + 1) is channel 32 p + 2 m (+ 1), see its fetch
+        const bool pi = paired && i < 2 * (KQ / 2), pj = paired && j < 2 * (NT / 2);
+        const int cin_b = (pc / ncout) * 16 * KQ + (pi ? 32 * (i >> 1) + 8 * (lane >> 4) + (i & 1) : 16 * i + 4 * (lane >> 4));
+        const int cin_st = pi ? 2 : 1;
+        const int co = (pc % ncout) * 16 * NT + (pj ? 32 * (j >> 1) + 2 * (lane & 15) + (j & 1) : 16 * j + (lane & 15));
         if (co >= Cout) continue;
         f32x4 s[4][4];
 #pragma unroll
@@ -647,7 +662,7 @@ __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __r
             for (int b = 0; b < 3; ++b)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int cin = cin_b + rr;
+                    const int cin = cin_b + rr * cin_st;
                     if (cin < Cin) {
                         float* p = dw + ((size_t)((a * 3 + b) * Cin + cin)) * Cout + co;
                         *p = accumulate ? *p + g[b][rr] : g[b][rr];
@@ -792,7 +807,7 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     HIP_CHECK(hipGetLastError());
     const int total = npair * KQ * NT * 64;
     DL4DS_LAUNCH(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, sum, dw, db, x.C, dy.C, KQ, NT,
-                       wp.ncin, wp.ncout, accumulate, accumulate_db, 1, per_k);
+                       wp.ncin, wp.ncout, accumulate, accumulate_db, 1, per_k, wgrad_first_form() ? 0 : 1);
     HIP_CHECK(hipGetLastError());
     return true;
 }
