@@ -1526,6 +1526,14 @@ void dispatch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
 
 }  // namespace
 
+// split-K plumbing shared with conv_gemm.hip: the per-stream slab scratch and the combine + epilogue launch
+float* conv_splitk_scratch(hipStream_t s, size_t floats) { return splitk_scratch(s, floats); }
+void conv_splitk_combine(hipStream_t s, const float* slabs, int S, size_t slab_stride, const ConvParams& p, int N) {
+    const size_t total = (size_t)N * p.H * p.W * p.Cout;
+    DL4DS_LAUNCH(splitk_combine_kernel, dim3((unsigned)std::min<size_t>(cdivz(total, 256), 4096)), dim3(256), 0, s, slabs, S, slab_stride, p, N);
+    HIP_CHECK(hipGetLastError());
+}
+
 // =============================================================================================
 void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
                     const ConvEpilogue& ep) {
@@ -1535,9 +1543,13 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     DL4DS_REQUIRE(!in.sc && !ep.pool, "conv2d: channel-affine input / pooling partials are only implemented by the direct "
                                      "and narrow-pair kernels (the caller must check conv2d_direct_eligible / conv2d_narrow_pair_ok)");
     if (KS == 3 && conv2d_wino_forward(s, in, w, out, ep)) return;  // MFMA-bound 3x3 layers: Winograd F(2x2, 3x3)
+    // small grids, many channels: GEMM over the flattened pixels of the batch -- up to 16 x 16 ahead of the streaming kernels (which
+    // need two tiles per workgroup), up to 32 x 32 for what they decline (measured on cfg5: 106 vs 128-133 TFLOP/s where both apply)
+    if (conv2d_gemm_forward(s, in, w, KS, out, ep, 16 * 16)) return;
     if (KS == 1 && getenv("DL4DS_POINT_FIRST") && conv2d_point_forward(s, in, w, KS, out, ep)) return;     // (experiment)
     if (!getenv("DL4DS_NO_STREAM") && conv2d_stream_forward(s, in, w, KS, out, ep)) return;
     if (conv2d_point_forward(s, in, w, KS, out, ep)) return;      // 1x1 with channel counts that are not multiples of four
+    if (conv2d_gemm_forward(s, in, w, KS, out, ep, 32 * 32)) return;
     ConvParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
     p.w = w; p.bias = ep.bias;

@@ -114,3 +114,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& a, const AccPack
         }
     }
 }
+
+// split-K plumbing of conv.hip, also used by conv_gemm.hip: grow-only slab scratch per stream; out = epilogue(sum of S slabs)
+float* conv_splitk_scratch(hipStream_t s, size_t floats);
+void conv_splitk_combine(hipStream_t s, const float* slabs, int S, size_t slab_stride, const ConvParams& p, int N);

@@ -48,6 +48,8 @@ bool conv2d_direct_wgrad_attention(hipStream_t s, const TView& x_raw, const TVie
 int conv2d_narrow_wgrad_slabs(const TView& x, const TView& dz, int KS);
 int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float* partial, int max_slabs);
 // 3x3, Cin >= 16: filter streamed from L2 into the MFMA operands, no barriers in the K loop (conv_stream.hip)
+// small grids (H W <= max_hw) with many channels as a GEMM over flattened pixels (conv_gemm.hip); false = not eligible
+bool conv2d_gemm_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out, const ConvEpilogue& ep, int max_hw);
 // Winograd F(2x2, 3x3) form of the MFMA-bound 3x3 layers (conv_wino.hip); false = not eligible
 bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep);
 // ... and of their weight gradient (conv_wino_wgrad.hip): dw [3][3][Cin][Cout], db [Cout] or null

@@ -384,6 +384,49 @@ def test_conv2d_dgrad_wgrad(ops, n, h, w, ci, co, ks):
     close(ops.conv2d_wgrad(x, dz, ks), gw)
 
 
+@pytest.mark.parametrize('n,h,w,ci,co,ks', [(4, 8, 8, 128, 256, 5), (16, 8, 8, 256, 132, 3), (2, 16, 16, 64, 128, 3), (5, 7, 9, 80, 68, 3),
+                                            (3, 12, 11, 96, 200, 1), (20, 4, 4, 64, 64, 5)])
+def test_conv2d_gemm_small_grids(ops, n, h, w, ci, co, ks):
+    """conv_gemm_kernel (conv_gemm.hip): small grids with many channels as a GEMM over the flattened pixels of the batch, K split
+    over blockIdx.z, partial slabs combined with the epilogue -- the deep levels of unet_pin (sp_preups.py:262-285) and their
+    transposed convolutions (blocks.py:508-533).  Forward with every fused epilogue, dgrad with accumulation and ReLU mask,
+    ragged pixel counts (M % 128 != 0), cout counts that are not multiples of the 128-wide tile; kernel tag asserted."""
+    from tests.parity import kernel_tags
+    x, wt, b, add = R(n, h, w, ci), R(ks, ks, ci, co) * 0.05, R(co), R(n, h, w, co)
+    xt = torch.tensor(x, dtype=torch.float64)
+    ref = (T.conv2d(xt, torch.tensor(wt, dtype=torch.float64)) + torch.tensor(b, dtype=torch.float64)).numpy()
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert f'conv_gemm<{ks}>' in tags, tags
+    close(got, ref)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt))
+    if co >= 64 and co % 16 == 0:
+        assert f'conv_gemm<{ks}>' in tags, tags
+    close(got, gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+
+
+def test_conv2d_gemm_depth_to_space_both_sides(ops):
+    """... storing through a depth_to_space view (the transposed convolution's forward) and reading the output gradient
+    through one (its dgrad): 64 -> 4 x 64 channels on an 8 x 8 grid."""
+    from tests.parity import kernel_tags
+    n, h, w, ci, co, r = 6, 8, 8, 64, 256, 2
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.05, R(co)
+    ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b, d2s=r))
+    assert 'conv_gemm<3>' in tags, tags
+    close(got, ref)
+    dz = R(n, h * r, w * r, co // (r * r))
+    gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt, d2s=r))
+    assert 'conv_gemm<3>' in tags, tags
+    close(got, gx)
+
+
 @pytest.mark.parametrize('n,h,w,ci,co,ks', [(3, 20, 37, 8, 32, 5), (2, 17, 16, 8, 32, 3), (2, 33, 18, 4, 48, 3), (1, 40, 40, 6, 20, 5),
                                             (2, 9, 70, 5, 64, 3), (4, 16, 16, 8, 24, 5)])
 def test_conv2d_wgrad_packed_taps(ops, n, h, w, ci, co, ks):
