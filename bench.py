@@ -376,7 +376,7 @@ def main():
 
     roofline = None
     if dom is not None:
-        d = report().get(dom)
+        d = report().get(dom)               # (the K timed steps only: the steady-state window below runs un-instrumented)
         L.check(lib.dl4ds_profile_enable(0))
         L.check(lib.dl4ds_profile_filter(b''))
         if d and d['n']:
@@ -400,7 +400,7 @@ def main():
                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                         'traffic_source': traffic_source,
                         'algorithmic_bytes_per_launch': d['bytes'] / d['n'],
-                        'launches': d['n'], 'avg_launch_ms': d['ms'] / d['n'],
+                        'launches': d['n'], 'calls_per_step': d['n'] / args.steps, 'avg_launch_ms': d['ms'] / d['n'],
                         'algorithmic_gflop_per_launch': d['flops'] / d['n'] / 1e9,
                         **({'winograd': True,
                             'note': 'achieved / frac price the multiply-adds this kernel ISSUES (F(2x2,3x3): 4 per output and '

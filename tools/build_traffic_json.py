@@ -20,14 +20,17 @@ for cfg in ('cfg2', 'cfg4', 'cfg5'):
     sfx = '' if cfg == 'cfg2' else '_' + cfg
     line = json.loads(open(os.path.join(root, f'bench_line{sfx}_{tag}.json')).read().strip().splitlines()[-1])
     dom = line['roofline']['kernel']
-    calls_per_step = line['roofline']['launches'] / line['steps']
+    rf = line['roofline']
+    calls_per_step = rf.get('calls_per_step') or rf['launches'] / line['steps']
+    # steps the PMC pass actually ran (bench.py adds a steady-state window of >= 2 s): the loss kernel launches once per step
+    pmc_steps = next((v['launches'] for k, v in t.items() if 'pixel_loss' in k), PMC_STEPS)
     d = {}
     for k, v in t.items():
         if not re.match(r'^[a-z_0-9]+(<[0-9,]*>)?$', k):
             continue
         per_call = v['hbm_bytes_per_launch']
         if k == dom:
-            per_call *= (v['launches'] / PMC_STEPS) / calls_per_step
+            per_call *= (v['launches'] / pmc_steps) / calls_per_step
         d[k] = per_call
     out[cfg] = d
 json.dump(out, open(os.path.join(os.path.dirname(root.rstrip('/')), '..', 'profiles', 'traffic.json') if False else

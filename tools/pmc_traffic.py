@@ -20,7 +20,7 @@ def tag_of(k):
     if not m:
         return k[:60]
     args = m.group(2).replace(' ', '').split(',')
-    name = m.group(1)
+    name = m.group(1).replace('conv_wino2_kernel', 'conv_wino_kernel').replace('conv_wino_wgrad2_kernel', 'conv_wino_wgrad_kernel')   # (round 4: second forms, same tags)
     if name.startswith('conv_narrow_pair_ws') or name.startswith('conv_narrow16_ws'):
         args = args[:1]                      # <NR> (the compiled epilogue form is not part of bench.py's tag)
     name = name.replace('conv_direct2', 'conv_direct')      # both generations of the stencil kernels share bench.py's tag
