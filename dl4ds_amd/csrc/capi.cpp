@@ -582,6 +582,16 @@ int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out)
     *out = g_localconv(g->g, in, w, b, F);
     API_END
 }
+int dl4ds_rec_tail_supported(int CX, int CS, int CO, int* yes) {
+    API_BEGIN
+    *yes = rec_tail_supported(CX, CS, CO) ? 1 : 0;
+    API_END
+}
+int dl4ds_graph_rec_tail(dl4ds_graph* g, int x, int s, int wt, int bt, int wl, int bl, int w, int b, int T, int CO, int* out) {
+    API_BEGIN
+    *out = g_rec_tail(g->g, x, s, wt, bt, wl, bl, w, b, T, CO);
+    API_END
+}
 int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out) {
     API_BEGIN
     *out = g_repeat_time(g->g, in, T);

@@ -179,6 +179,9 @@ int g_pad(Graph& g, int in, int Ho, int Wo);
 int g_dwconv(Graph& g, int in, int w, int b, int KS);
 int g_slice(Graph& g, int in, int oy, int ox, int step, int Ho, int Wo);
 int g_norm(Graph& g, int in, int gamma, int beta, int mov_mean, int mov_var, int batch, float eps, int relu);
+// the recurrent nets' tail [x, repeat(s), LocalizedConvBlock] -> TransitionLast as one op (graph_ops4.hip)
+bool rec_tail_supported(int CX, int CS, int CO);
+int g_rec_tail(Graph& g, int x, int s, int wt, int bt, int wl, int bl, int w, int b, int T, int CO);
 
 // ---- trainer (trainer.hip)
 struct AdamCfg {

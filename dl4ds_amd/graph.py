@@ -195,6 +195,25 @@ class GraphBuilder:
         _lib.check(self._l.dl4ds_graph_localconv(self.h, x.id, w, b, int(filters), ctypes.byref(out)))
         return self._out(out.value, 'locally_connected', name)
 
+    def rec_tail_supported(self, cx, cs, co):
+        yes = ctypes.c_int(0)
+        _lib.check(self._l.dl4ds_rec_tail_supported(int(cx), int(cs), int(co), ctypes.byref(yes)))
+        return bool(yes.value)
+
+    def rec_tail(self, x, s, T, co, lcb_name='LocalizedConvBlock', tl_name='TransitionLast'):
+        """[x, repeat(s, T)] -> LocalizedConvBlock -> Concatenate -> TransitionLast as one op (csrc/graph_ops4.hip); the
+        variables carry the names and shapes of the separate layers (creation order as in models/spt_postups.py: rec_tail)."""
+        c24 = x.C + s.C
+        wt = self.param(lcb_name + '/transition/conv/kernel', (1, 1, c24, 2))
+        bt = self.param(lcb_name + '/transition/conv/bias', (2,), 'zeros')
+        wl = self.param(lcb_name + '/localconv/kernel', (x.H, x.W, 2, 2))
+        bl = self.param(lcb_name + '/localconv/bias', (x.H, x.W, 2), 'zeros')
+        w = self.param(tl_name + '/conv/kernel', (1, 1, c24 + 2, co))
+        b = self.param(tl_name + '/conv/bias', (co,), 'zeros')
+        out = ctypes.c_int()
+        _lib.check(self._l.dl4ds_graph_rec_tail(self.h, x.id, s.id, wt, bt, wl, bl, w, b, int(T), int(co), ctypes.byref(out)))
+        return self._out(out.value, 'rec_tail', tl_name)
+
     def repeat_time(self, x, T, name='repeat_time'):
         out = ctypes.c_int()
         _lib.check(self._l.dl4ds_graph_repeat_time(self.h, x.id, int(T), ctypes.byref(out)))

@@ -26,14 +26,24 @@ def rec_backbone(g, x_in, backbone_block, n_filters, n_blocks, time_window, acti
 def rec_tail(g, x, s_in, n_filters, n_channels_out, time_window, activation, output_activation, attention,
              normalization, dropout_rate, localcon_layer, transition_filters=None):
     """spt_postups.py:133-157 (TransitionLast -> C//2) / spt_preups.py:114-138 (TransitionLast -> n_filters)."""
+    s = None
     if s_in is not None:
         s = conv_block(g, 'ConvBlock_aux', s_in, n_filters, activation=activation, attention=attention)
-        s = g.repeat_time(s, time_window, 'aux_repeat')
-        x = g.concat([x, s], 'aux_concat')
-    if localcon_layer:
-        lws = localized_conv_block(g, 'LocalizedConvBlock', x)
-        x = g.concat([x, lws], 'lcb_concat')
-    x = transition_block(g, 'TransitionLast', x, x.C // 2 if transition_filters is None else transition_filters)
+    co = None
+    if s is not None and localcon_layer:
+        co = (x.C + s.C + 2) // 2 if transition_filters is None else transition_filters
+    if co is not None and g.rec_tail_supported(x.C, s.C, co):
+        # Concatenate([x, repeat(s)]) -> LocalizedConvBlock -> Concatenate -> TransitionLast: one pass per direction, nothing of it
+        # materialised (csrc/graph_ops4.hip; same variables).  DL4DS_NO_REC_TAIL_FUSION=1: the separate layers below.
+        x = g.rec_tail(x, s, time_window, co)
+    else:
+        if s is not None:
+            s = g.repeat_time(s, time_window, 'aux_repeat')
+            x = g.concat([x, s], 'aux_concat')
+        if localcon_layer:
+            lws = localized_conv_block(g, 'LocalizedConvBlock', x)
+            x = g.concat([x, lws], 'lcb_concat')
+        x = transition_block(g, 'TransitionLast', x, x.C // 2 if transition_filters is None else transition_filters)
     x = conv_block(g, 'ConvBlock_att', x, n_filters, activation=None, normalization=normalization, attention=True,
                    dropout_rate=dropout_rate, time_window_5d=time_window)
     return conv_block(g, 'ConvBlock_out', x, n_channels_out, activation=output_activation,

@@ -178,6 +178,15 @@ int dl4ds_graph_resize_bicubic(dl4ds_graph* g, int in, int Ho, int Wo, int* out)
 int dl4ds_graph_resize_method(dl4ds_graph* g, int in, int Ho, int Wo, int method, int* out);
 int dl4ds_graph_localconv(dl4ds_graph* g, int in, int w, int b, int F, int* out);
 int dl4ds_graph_repeat_time(dl4ds_graph* g, int in, int T, int* out);
+/* The recurrent nets' tail as ONE op -- spt_postups.py:133-151 / spt_preups.py:114-132, blocks.py:301-333:
+ *   y = TransitionLast(Concatenate([x24, LocalizedConvBlock(x24)])),  x24 = Concatenate([x, repeat(expand_dims(s, 1), T)])
+ * x: (B,T,H,W,CX), s: (B,H,W,CS) = ConvBlock_aux's output, y: (B,T,H,W,CO), ReLU after both 1x1 convolutions.  Parameters = the
+ * reference layers' own variables: wt / bt = LocalizedConvBlock's TransitionBlock(2) kernel [1,1,CX+CS,2] / bias, wl / bl =
+ * its LocallyConnected2D kernel [H,W,2,2] / bias [H,W,2], w / b = TransitionLast's kernel [1,1,CX+CS+2,CO] / bias.  No
+ * concatenation and no time repeat is materialised (csrc/graph_ops4.hip).  dl4ds_rec_tail_supported says whether the channel
+ * combination is built (and DL4DS_NO_REC_TAIL_FUSION is unset); otherwise the caller builds the separate layers. */
+int dl4ds_rec_tail_supported(int CX, int CS, int CO, int* yes);
+int dl4ds_graph_rec_tail(dl4ds_graph* g, int x, int s, int wt, int bt, int wl, int bl, int w, int b, int T, int CO, int* out);
 int dl4ds_graph_convlstm(dl4ds_graph* g, int in, int wk, int wr, int b, int KS, int F, int T, int relu, int* out);
 int dl4ds_graph_gap(dl4ds_graph* g, int in, int* out);
 /* DepthwiseConv2D(7, 'same') + bias -- blocks.py:143-144 */
