@@ -117,6 +117,85 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
     }
 }
 
+// ---- the same walk with every global access coalesced: a block = 256 consecutive grid points of one sample (HW % 256 == 0);
+// per frame the block's x rows arrive as one contiguous float4 stream into LDS ([pixel][CX + 4]: conflict-free 16-byte row
+// reads), the y rows leave through LDS as one contiguous stream (a 13-float row is 52 bytes: row-per-lane stores touched four
+// 64-byte segments per lane quad and ran at 2.4 TB/s).  The next frame's loads are in flight during the arithmetic.
+template <int CX, int CS, int CO>
+__global__ void __launch_bounds__(256) rec_tail_fwd_staged_kernel(const TailParams a) {
+    constexpr int XQ = CX / 4, XP = CX + 4, NY4 = 256 * CO / 4, YIT = (NY4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float xs[256 * XP];
+    __shared__ __attribute__((aligned(16))) float ys[256 * CO];
+    const int tid = threadIdx.x;
+    const int blocks_per_sample = a.HW / 256;
+    const int bi = blockIdx.x / blocks_per_sample, hw0 = (blockIdx.x - bi * blocks_per_sample) * 256, hw = hw0 + tid;
+    const size_t p = (size_t)bi * a.HW + hw;
+    float sv[CS];
+#pragma unroll
+    for (int q = 0; q < CS; q += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.s + p * CS + q);
+        sv[q] = t[0]; sv[q + 1] = t[1]; sv[q + 2] = t[2]; sv[q + 3] = t[3];
+    }
+    float su[2] = {a.bt[0], a.bt[1]}, sy[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) sy[o] = a.b[o];
+#pragma unroll
+    for (int j = 0; j < CS; ++j) {
+        su[0] = fmaf(sv[j], a.wt[(CX + j) * 2], su[0]);
+        su[1] = fmaf(sv[j], a.wt[(CX + j) * 2 + 1], su[1]);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) sy[o] = fmaf(sv[j], a.w[(CX + j) * CO + o], sy[o]);
+    }
+    const f32x4 wl4 = *reinterpret_cast<const f32x4*>(a.wl + (size_t)hw * 4);
+    const float bl0 = a.bl[(size_t)hw * 2], bl1 = a.bl[(size_t)hw * 2 + 1];
+    f32x4 xin[XQ];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (((size_t)bi * a.T + t) * a.HW + hw0) * CX);
+#pragma unroll
+        for (int k = 0; k < XQ; ++k) xin[k] = src[k * 256 + tid];
+    };
+    fetch(0);
+    for (int t = 0; t < a.T; ++t) {
+        const size_t px0 = ((size_t)bi * a.T + t) * a.HW + hw0;
+#pragma unroll
+        for (int k = 0; k < XQ; ++k) {
+            const int e = k * 256 + tid;
+            *reinterpret_cast<f32x4*>(xs + (e / XQ) * XP + (e % XQ) * 4) = xin[k];
+        }
+        __syncthreads();
+        if (t + 1 < a.T) fetch(t + 1);
+        float xv[CX];
+#pragma unroll
+        for (int q = 0; q < CX; q += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xs + tid * XP + q);
+            xv[q] = v[0]; xv[q + 1] = v[1]; xv[q + 2] = v[2]; xv[q + 3] = v[3];
+        }
+        float u0 = su[0], u1 = su[1];
+#pragma unroll
+        for (int i = 0; i < CX; ++i) { u0 = fmaf(xv[i], a.wt[i * 2], u0); u1 = fmaf(xv[i], a.wt[i * 2 + 1], u1); }
+        u0 = fmaxf(u0, 0.f); u1 = fmaxf(u1, 0.f);
+        const float l0 = fmaf(u1, wl4[2], fmaf(u0, wl4[0], bl0)), l1 = fmaf(u1, wl4[3], fmaf(u0, wl4[1], bl1));
+        float yv[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) yv[o] = fmaf(l1, a.w[(CX + CS + 1) * CO + o], fmaf(l0, a.w[(CX + CS) * CO + o], sy[o]));
+#pragma unroll
+        for (int i = 0; i < CX; ++i)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) yv[o] = fmaf(xv[i], a.w[i * CO + o], yv[o]);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) ys[tid * CO + o] = fmaxf(yv[o], 0.f);
+        *reinterpret_cast<float2*>(a.u + (px0 + tid) * 2) = make_float2(u0, u1);
+        *reinterpret_cast<float2*>(a.lws + (px0 + tid) * 2) = make_float2(l0, l1);
+        __syncthreads();
+        f32x4* dst = reinterpret_cast<f32x4*>(a.y + px0 * CO);
+#pragma unroll
+        for (int k = 0; k < YIT; ++k) {
+            const int e = k * 256 + tid;
+            if (e < NY4) dst[e] = *reinterpret_cast<const f32x4*>(ys + e * 4);
+        }
+    }
+}
+
 struct TailBwdParams {
     const float *x, *s, *u, *y, *dy, *wt, *wl, *w;
     float *dx, *ds, *dz, *dzs, *dwl_part, *dbl_part;      // dz: [B T][HW][CO + 2], dzs: [B][HW][CO + 2] (summed over t)
@@ -211,6 +290,141 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
     *reinterpret_cast<float2*>(a.dbl_part + p * 2) = make_float2(dbl[0], dbl[1]);
 }
 
+// ---- backward, coalesced in the same way: dy, y (and x where its ReLU mask is wanted) arrive as contiguous streams into LDS,
+// dx and dz leave as contiguous streams; dynamic LDS (up to 84 KB: one or two blocks per CU, the next frame's loads in flight)
+template <int CX, int CS, int CO>
+__global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdParams a) {
+    constexpr int CZ = CO + 2, XQ = CX / 4, XP = CX + 4;
+    constexpr int NR4 = 256 * CO / 4, RIT = (NR4 + 255) / 256;       // float4 per block row-stream of a CO-channel tensor
+    constexpr int NZ4 = 256 * CZ / 4, ZIT = (NZ4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const dys = lds;                      // [256][CO]
+    float* const yss = dys + 256 * CO;           // [256][CO]
+    float* const dzs_ = yss + 256 * CO;          // [256][CZ]
+    float* const dxs = dzs_ + 256 * CZ;          // [256][XP]   (dx out)
+    float* const xss = dxs + 256 * XP;           // [256][XP]   (x in, only with mask_x)
+    const int tid = threadIdx.x;
+    const int blocks_per_sample = a.HW / 256;
+    const int bi = blockIdx.x / blocks_per_sample, hw0 = (blockIdx.x - bi * blocks_per_sample) * 256, hw = hw0 + tid;
+    const size_t p = (size_t)bi * a.HW + hw;
+    const f32x4 wl4 = *reinterpret_cast<const f32x4*>(a.wl + (size_t)hw * 4);
+    float zsum[CZ], dsacc[CS], dwl[4] = {0.f, 0.f, 0.f, 0.f}, dbl[2] = {0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < CZ; ++o) zsum[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CS; ++j) dsacc[j] = 0.f;
+    f32x4 rin[2][RIT], xin[XQ];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const size_t px0 = ((size_t)bi * a.T + t) * a.HW + hw0;
+        const f32x4* sdy = reinterpret_cast<const f32x4*>(a.dy + px0 * CO);
+        const f32x4* sy = reinterpret_cast<const f32x4*>(a.y + px0 * CO);
+#pragma unroll
+        for (int k = 0; k < RIT; ++k) {
+            const int e = k * 256 + tid;
+            if (e < NR4) { rin[0][k] = sdy[e]; rin[1][k] = sy[e]; }
+        }
+        if (a.mask_x) {
+            const f32x4* sx = reinterpret_cast<const f32x4*>(a.x + px0 * CX);
+#pragma unroll
+            for (int k = 0; k < XQ; ++k) xin[k] = sx[k * 256 + tid];
+        }
+    };
+    fetch(0);
+    for (int t = 0; t < a.T; ++t) {
+        const size_t px0 = ((size_t)bi * a.T + t) * a.HW + hw0;
+#pragma unroll
+        for (int k = 0; k < RIT; ++k) {
+            const int e = k * 256 + tid;
+            if (e < NR4) {
+                *reinterpret_cast<f32x4*>(dys + e * 4) = rin[0][k];
+                *reinterpret_cast<f32x4*>(yss + e * 4) = rin[1][k];
+            }
+        }
+        if (a.mask_x) {
+#pragma unroll
+            for (int k = 0; k < XQ; ++k) {
+                const int e = k * 256 + tid;
+                *reinterpret_cast<f32x4*>(xss + (e / XQ) * XP + (e % XQ) * 4) = xin[k];
+            }
+        }
+        __syncthreads();
+        if (t + 1 < a.T) fetch(t + 1);
+        float z[CZ];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) z[o] = yss[tid * CO + o] > 0.f ? dys[tid * CO + o] : 0.f;
+        const float2 uv = *reinterpret_cast<const float2*>(a.u + (px0 + tid) * 2);
+        float dl0 = 0.f, dl1 = 0.f;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) { dl0 = fmaf(a.w[(CX + CS) * CO + o], z[o], dl0); dl1 = fmaf(a.w[(CX + CS + 1) * CO + o], z[o], dl1); }
+        dwl[0] = fmaf(uv.x, dl0, dwl[0]); dwl[1] = fmaf(uv.x, dl1, dwl[1]); dwl[2] = fmaf(uv.y, dl0, dwl[2]); dwl[3] = fmaf(uv.y, dl1, dwl[3]);
+        dbl[0] += dl0; dbl[1] += dl1;
+        const float du0 = fmaf(wl4[1], dl1, wl4[0] * dl0), du1 = fmaf(wl4[3], dl1, wl4[2] * dl0);
+        z[CO] = uv.x > 0.f ? du0 : 0.f;
+        z[CO + 1] = uv.y > 0.f ? du1 : 0.f;
+        if (a.want_dx) {
+#pragma unroll
+            for (int q = 0; q < CX; q += 4) {
+                f32x4 d4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = q + r;
+                    float v = fmaf(a.wt[i * 2 + 1], z[CO + 1], a.wt[i * 2] * z[CO]);
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) v = fmaf(a.w[i * CO + o], z[o], v);
+                    if (a.mask_x && !(xss[tid * XP + i] > 0.f)) v = 0.f;
+                    d4[r] = v;
+                }
+                *reinterpret_cast<f32x4*>(dxs + tid * XP + q) = d4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CS; ++j) {
+            float v = fmaf(a.wt[(CX + j) * 2 + 1], z[CO + 1], a.wt[(CX + j) * 2] * z[CO]);
+#pragma unroll
+            for (int o = 0; o < CO; ++o) v = fmaf(a.w[(CX + j) * CO + o], z[o], v);
+            dsacc[j] += v;
+        }
+#pragma unroll
+        for (int o = 0; o < CZ; ++o) { dzs_[tid * CZ + o] = z[o]; zsum[o] += z[o]; }
+        __syncthreads();
+        f32x4* dzo = reinterpret_cast<f32x4*>(a.dz + px0 * CZ);
+#pragma unroll
+        for (int k = 0; k < ZIT; ++k) {
+            const int e = k * 256 + tid;
+            if (e < NZ4) dzo[e] = *reinterpret_cast<const f32x4*>(dzs_ + e * 4);
+        }
+        if (a.want_dx) {
+            f32x4* dxo = reinterpret_cast<f32x4*>(a.dx + px0 * CX);
+#pragma unroll
+            for (int k = 0; k < XQ; ++k) {
+                const int e = k * 256 + tid;
+                f32x4 v = *reinterpret_cast<const f32x4*>(dxs + (e / XQ) * XP + (e % XQ) * 4);
+                if (a.acc_dx) v += dxo[e];
+                dxo[e] = v;
+            }
+        }
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rzs = rsrc_of(a.dzs);
+        store_row<CZ>(rzs, (int)(p * CZ * 4), zsum);
+    }
+    if (a.want_ds) {
+#pragma unroll
+        for (int q = 0; q < CS; q += 4) {
+            f32x4 v = {dsacc[q], dsacc[q + 1], dsacc[q + 2], dsacc[q + 3]};
+            if (a.mask_s) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(a.s + p * CS + q);
+                v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f; v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
+            }
+            f32x4* d = reinterpret_cast<f32x4*>(a.ds + p * CS + q);
+            if (a.acc_ds) v += *d;
+            *d = v;
+        }
+    }
+    *reinterpret_cast<f32x4*>(a.dwl_part + p * 4) = (f32x4){dwl[0], dwl[1], dwl[2], dwl[3]};
+    *reinterpret_cast<float2*>(a.dbl_part + p * 2) = make_float2(dbl[0], dbl[1]);
+}
+
 // the parameter gradients from the pieces: dWl / dbl = sum over the samples of the per-sample partials (fixed order);
 // dW rows = [x-part | s-part | lws-part] columns 0 .. CO-1 of the three 1x1 weight gradients, dWt rows = columns CO, CO+1 of the
 // first two; db / dbt = the first call's bias gradient
@@ -258,12 +472,31 @@ __global__ void __launch_bounds__(256) rec_tail_finish_kernel(const TailFinishPa
 
 template <int CX, int CS, int CO>
 void launch_fwd(hipStream_t s, const TailParams& p) {
+    static const bool no_staged = getenv("DL4DS_REC_TAIL_NO_STAGED") != nullptr;
+    if (p.HW % 256 == 0 && !no_staged) {
+        DL4DS_LAUNCH((rec_tail_fwd_staged_kernel<CX, CS, CO>), dim3((unsigned)((size_t)p.B * p.HW / 256)), dim3(256), 0, s, p);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const size_t n = (size_t)p.B * p.HW;
     DL4DS_LAUNCH((rec_tail_fwd_kernel<CX, CS, CO>), dim3((unsigned)cdivz(n, 256)), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
 template <int CX, int CS, int CO>
 void launch_bwd(hipStream_t s, const TailBwdParams& p) {
+    static const bool no_staged = getenv("DL4DS_REC_TAIL_NO_STAGED") != nullptr;
+    if (p.HW % 256 == 0 && !no_staged) {
+        const size_t lds = (size_t)256 * (2 * CO + (CO + 2) + 2 * (CX + 4)) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rec_tail_bwd_staged_kernel<CX, CS, CO>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        DL4DS_LAUNCH((rec_tail_bwd_staged_kernel<CX, CS, CO>), dim3((unsigned)((size_t)p.B * p.HW / 256)), dim3(256), lds, s, p);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const size_t n = (size_t)p.B * p.HW;
     DL4DS_LAUNCH((rec_tail_bwd_kernel<CX, CS, CO>), dim3((unsigned)cdivz(n, 256)), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
