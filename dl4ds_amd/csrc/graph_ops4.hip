@@ -197,8 +197,9 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_staged_kernel(const TailPara
 }
 
 struct TailBwdParams {
-    const float *x, *s, *u, *y, *dy, *wt, *wl, *w;
+    const float *x, *s, *u, *lws, *y, *dy, *wt, *wl, *w;
     float *dx, *ds, *dz, *dzs, *dwl_part, *dbl_part;      // dz: [B T][HW][CO + 2], dzs: [B][HW][CO + 2] (summed over t)
+    float* wpart;            // staged form: [blocks][2][16][16] partial 1x1 weight gradients (dz is never stored)
     int B, T, HW, acc_dx, acc_ds, want_dx, want_ds;
     int mask_x, mask_s;      // x / s are ReLU outputs whose backward mask their consumers apply (GTensor::grad_masked): zero dx where x <= 0
 };
@@ -290,30 +291,41 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
     *reinterpret_cast<float2*>(a.dbl_part + p * 2) = make_float2(dbl[0], dbl[1]);
 }
 
-// ---- backward, coalesced in the same way: dy, y (and x where its ReLU mask is wanted) arrive as contiguous streams into LDS,
-// dx and dz leave as contiguous streams; dynamic LDS (up to 84 KB: one or two blocks per CU, the next frame's loads in flight)
+// ---- backward, coalesced in the same way: dy, y, x arrive as contiguous streams into LDS, dx leaves as one; u / lws of the
+// next frame are in flight with them.  The 1x1 weight gradients are taken HERE, on the matrix pipe, from what already sits in
+// LDS: per frame a wave multiplies its 64 pixels' rows  [x (CX) | s (CS), lws (2), 1]^T (two 16-row A tiles)  by  dz (CO + 2
+// columns, B tile) with pixels as the k index -- 16 k-steps x 2 v_mfma_f32_16x16x4_f32 -- and keeps the two 16 x 16 sums in
+// eight registers over all T frames.  The row of ones yields the bias gradients, s rides along every frame (same sum as
+// s x sum_t dz).  dz is never written to HBM and x / dz are not read a second time by separate weight-gradient launches
+// (cfg4: three conv_wgrad_rows<1,1,1,1> launches, 0.62 ms per step, gone).  Per block one [2][16][16] partial, summed in a
+// fixed order by rec_tail_wsum_kernel and the finishing kernel.
+constexpr int REC_TAIL_WTILE = 512;
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdParams a) {
-    constexpr int CZ = CO + 2, XQ = CX / 4, XP = CX + 4;
+    constexpr int CZ = CO + 2, XQ = CX / 4, XP = CX + 4, AP = CS + 4;
+    static_assert(CZ <= 16 && CX <= 16 && CS + 3 <= 16 && 4 * REC_TAIL_WTILE <= 256 * CO, "rec_tail: tile shapes");
     constexpr int NR4 = 256 * CO / 4, RIT = (NR4 + 255) / 256;       // float4 per block row-stream of a CO-channel tensor
-    constexpr int NZ4 = 256 * CZ / 4, ZIT = (NZ4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const dys = lds;                      // [256][CO]
-    float* const yss = dys + 256 * CO;           // [256][CO]
-    float* const dzs_ = yss + 256 * CO;          // [256][CZ]
+    float* const dys = lds;                      // [256][CO]   dy masked by y > 0 (at load time)
+    float* const dzs_ = dys + 256 * CO;          // [256][CZ]
     float* const dxs = dzs_ + 256 * CZ;          // [256][XP]   (dx out)
-    float* const xss = dxs + 256 * XP;           // [256][XP]   (x in, only with mask_x)
-    const int tid = threadIdx.x;
+    float* const xss = dxs + 256 * XP;           // [256][XP]   (x in)
+    float* const auxs = xss + 256 * XP;          // [256][AP]   s, lws, 1, 0: the second A tile's rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int blocks_per_sample = a.HW / 256;
     const int bi = blockIdx.x / blocks_per_sample, hw0 = (blockIdx.x - bi * blocks_per_sample) * 256, hw = hw0 + tid;
     const size_t p = (size_t)bi * a.HW + hw;
     const f32x4 wl4 = *reinterpret_cast<const f32x4*>(a.wl + (size_t)hw * 4);
-    float zsum[CZ], dsacc[CS], dwl[4] = {0.f, 0.f, 0.f, 0.f}, dbl[2] = {0.f, 0.f};
-#pragma unroll
-    for (int o = 0; o < CZ; ++o) zsum[o] = 0.f;
+    float dsacc[CS], dwl[4] = {0.f, 0.f, 0.f, 0.f}, dbl[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < CS; ++j) dsacc[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < CS; q += 4) *reinterpret_cast<f32x4*>(auxs + tid * AP + q) = *reinterpret_cast<const f32x4*>(a.s + p * CS + q);
+    auxs[tid * AP + CS + 2] = 1.f;
+    auxs[tid * AP + CS + 3] = 0.f;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 rin[2][RIT], xin[XQ];
+    float2 uvn, lwn;
     auto fetch = [&](int t) __attribute__((always_inline)) {
         const size_t px0 = ((size_t)bi * a.T + t) * a.HW + hw0;
         const f32x4* sdy = reinterpret_cast<const f32x4*>(a.dy + px0 * CO);
@@ -323,11 +335,11 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
             const int e = k * 256 + tid;
             if (e < NR4) { rin[0][k] = sdy[e]; rin[1][k] = sy[e]; }
         }
-        if (a.mask_x) {
-            const f32x4* sx = reinterpret_cast<const f32x4*>(a.x + px0 * CX);
+        const f32x4* sx = reinterpret_cast<const f32x4*>(a.x + px0 * CX);
 #pragma unroll
-            for (int k = 0; k < XQ; ++k) xin[k] = sx[k * 256 + tid];
-        }
+        for (int k = 0; k < XQ; ++k) xin[k] = sx[k * 256 + tid];
+        uvn = *reinterpret_cast<const float2*>(a.u + (px0 + tid) * 2);
+        lwn = *reinterpret_cast<const float2*>(a.lws + (px0 + tid) * 2);
     };
     fetch(0);
     for (int t = 0; t < a.T; ++t) {
@@ -336,23 +348,24 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
         for (int k = 0; k < RIT; ++k) {
             const int e = k * 256 + tid;
             if (e < NR4) {
-                *reinterpret_cast<f32x4*>(dys + e * 4) = rin[0][k];
-                *reinterpret_cast<f32x4*>(yss + e * 4) = rin[1][k];
+                f32x4 d = rin[0][k];
+                const f32x4 y = rin[1][k];
+                d[0] = y[0] > 0.f ? d[0] : 0.f; d[1] = y[1] > 0.f ? d[1] : 0.f; d[2] = y[2] > 0.f ? d[2] : 0.f; d[3] = y[3] > 0.f ? d[3] : 0.f;
+                *reinterpret_cast<f32x4*>(dys + e * 4) = d;
             }
         }
-        if (a.mask_x) {
 #pragma unroll
-            for (int k = 0; k < XQ; ++k) {
-                const int e = k * 256 + tid;
-                *reinterpret_cast<f32x4*>(xss + (e / XQ) * XP + (e % XQ) * 4) = xin[k];
-            }
+        for (int k = 0; k < XQ; ++k) {
+            const int e = k * 256 + tid;
+            *reinterpret_cast<f32x4*>(xss + (e / XQ) * XP + (e % XQ) * 4) = xin[k];
         }
+        const float2 uv = uvn, lw = lwn;
+        *reinterpret_cast<float2*>(auxs + tid * AP + CS) = lw;
         __syncthreads();
         if (t + 1 < a.T) fetch(t + 1);
         float z[CZ];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) z[o] = yss[tid * CO + o] > 0.f ? dys[tid * CO + o] : 0.f;
-        const float2 uv = *reinterpret_cast<const float2*>(a.u + (px0 + tid) * 2);
+        for (int o = 0; o < CO; ++o) z[o] = dys[tid * CO + o];
         float dl0 = 0.f, dl1 = 0.f;
 #pragma unroll
         for (int o = 0; o < CO; ++o) { dl0 = fmaf(a.w[(CX + CS) * CO + o], z[o], dl0); dl1 = fmaf(a.w[(CX + CS + 1) * CO + o], z[o], dl1); }
@@ -361,6 +374,23 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
         const float du0 = fmaf(wl4[1], dl1, wl4[0] * dl0), du1 = fmaf(wl4[3], dl1, wl4[2] * dl0);
         z[CO] = uv.x > 0.f ? du0 : 0.f;
         z[CO + 1] = uv.y > 0.f ? du1 : 0.f;
+#pragma unroll
+        for (int o = 0; o < CZ; ++o) dzs_[tid * CZ + o] = z[o];
+        // the wave's own 64 pixel rows of xss / auxs / dzs_ are complete (written by this wave, or before the barrier): LDS
+        // operations of a wave execute in order
+        {
+            const int cb = l15 < CZ ? l15 : CZ - 1, c1 = l15 < AP ? l15 : AP - 1, c0 = l15 < XP ? l15 : XP - 1;
+#pragma unroll 4
+            for (int ks = 0; ks < 16; ++ks) {
+                const int pix = wave * 64 + 4 * ks + lq;
+                float bv = dzs_[pix * CZ + cb], a0 = xss[pix * XP + c0], a1 = auxs[pix * AP + c1];
+                bv = l15 < CZ ? bv : 0.f;
+                a0 = l15 < CX ? a0 : 0.f;
+                a1 = l15 < CS + 3 ? a1 : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc1, 0, 0, 0);
+            }
+        }
         if (a.want_dx) {
 #pragma unroll
             for (int q = 0; q < CX; q += 4) {
@@ -384,15 +414,7 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
             for (int o = 0; o < CO; ++o) v = fmaf(a.w[(CX + j) * CO + o], z[o], v);
             dsacc[j] += v;
         }
-#pragma unroll
-        for (int o = 0; o < CZ; ++o) { dzs_[tid * CZ + o] = z[o]; zsum[o] += z[o]; }
         __syncthreads();
-        f32x4* dzo = reinterpret_cast<f32x4*>(a.dz + px0 * CZ);
-#pragma unroll
-        for (int k = 0; k < ZIT; ++k) {
-            const int e = k * 256 + tid;
-            if (e < NZ4) dzo[e] = *reinterpret_cast<const f32x4*>(dzs_ + e * 4);
-        }
         if (a.want_dx) {
             f32x4* dxo = reinterpret_cast<f32x4*>(a.dx + px0 * CX);
 #pragma unroll
@@ -404,16 +426,12 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
             }
         }
     }
-    {
-        const __amdgpu_buffer_rsrc_t rzs = rsrc_of(a.dzs);
-        store_row<CZ>(rzs, (int)(p * CZ * 4), zsum);
-    }
     if (a.want_ds) {
 #pragma unroll
         for (int q = 0; q < CS; q += 4) {
             f32x4 v = {dsacc[q], dsacc[q + 1], dsacc[q + 2], dsacc[q + 3]};
             if (a.mask_s) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(a.s + p * CS + q);
+                const f32x4 m = *reinterpret_cast<const f32x4*>(auxs + tid * AP + q);
                 v[0] = m[0] > 0.f ? v[0] : 0.f; v[1] = m[1] > 0.f ? v[1] : 0.f; v[2] = m[2] > 0.f ? v[2] : 0.f; v[3] = m[3] > 0.f ? v[3] : 0.f;
             }
             f32x4* d = reinterpret_cast<f32x4*>(a.ds + p * CS + q);
@@ -423,6 +441,32 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
     }
     *reinterpret_cast<f32x4*>(a.dwl_part + p * 4) = (f32x4){dwl[0], dwl[1], dwl[2], dwl[3]};
     *reinterpret_cast<float2*>(a.dbl_part + p * 2) = make_float2(dbl[0], dbl[1]);
+    // the four waves' tiles -> one partial per block (lane: column l15, rows 4 lq + r)
+    __syncthreads();
+    float* const red = dys;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wave * REC_TAIL_WTILE + (4 * lq + r) * 16 + l15] = acc0[r];
+        red[wave * REC_TAIL_WTILE + 256 + (4 * lq + r) * 16 + l15] = acc1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = h * 256 + tid;
+        a.wpart[(size_t)blockIdx.x * REC_TAIL_WTILE + e] = (red[e] + red[REC_TAIL_WTILE + e]) + (red[2 * REC_TAIL_WTILE + e] + red[3 * REC_TAIL_WTILE + e]);
+    }
+}
+
+// first stage of the fixed-order sum over the blocks' partial tiles: group g adds partials g, g + G, g + 2G, ...
+__global__ void __launch_bounds__(256) rec_tail_wsum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    const int g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
+    float v0 = 0.f, v1 = 0.f;
+    for (int b = g; b < nblk; b += G) {
+        v0 += part[(size_t)b * REC_TAIL_WTILE + tid];
+        v1 += part[(size_t)b * REC_TAIL_WTILE + 256 + tid];
+    }
+    out[(size_t)g * REC_TAIL_WTILE + tid] = v0;
+    out[(size_t)g * REC_TAIL_WTILE + 256 + tid] = v1;
 }
 
 // the parameter gradients from the pieces: dWl / dbl = sum over the samples of the per-sample partials (fixed order);
@@ -430,13 +474,23 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
 // first two; db / dbt = the first call's bias gradient
 struct TailFinishParams {
     const float *dwl_part, *dbl_part, *gx, *gs, *gl, *gb;           // gx [CX][CZ], gs [CS][CZ], gl [2][CZ], gb [CZ]
+    const float* tiles;      // or (staged form): [G][2][16][16] sums of rec_tail_wsum_kernel; tile 0 rows = x, tile 1 rows = s, lws, 1
     float *dwl, *dbl, *dw, *db, *dwt, *dbt;
-    int B, HW, CX, CS, CO, acc;
+    int B, HW, CX, CS, CO, acc, G;
 };
 __global__ void __launch_bounds__(256) rec_tail_finish_kernel(const TailFinishParams a) {
     const int CZ = a.CO + 2;
     const size_t n_l = (size_t)a.HW * 6;
     const size_t n_w = (size_t)(a.CX + a.CS + 2) * a.CO + a.CO + (size_t)(a.CX + a.CS) * 2 + 2;
+    auto tile = [&](int tl, int row, int col) {
+        float v = 0.f;
+        for (int g = 0; g < a.G; ++g) v += a.tiles[(size_t)g * REC_TAIL_WTILE + tl * 256 + row * 16 + col];
+        return v;
+    };
+    auto GX = [&](int row, int col) { return a.tiles ? tile(0, row, col) : a.gx[row * CZ + col]; };
+    auto GS = [&](int row, int col) { return a.tiles ? tile(1, row, col) : a.gs[row * CZ + col]; };
+    auto GL = [&](int row, int col) { return a.tiles ? tile(1, a.CS + row, col) : a.gl[row * CZ + col]; };
+    auto GB = [&](int col) { return a.tiles ? tile(1, a.CS + 2, col) : a.gb[col]; };
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n_l + n_w; e += (size_t)gridDim.x * 256) {
         if (e < n_l) {
             const size_t hw = e / 6;
@@ -454,26 +508,29 @@ __global__ void __launch_bounds__(256) rec_tail_finish_kernel(const TailFinishPa
         const size_t nW = (size_t)(a.CX + a.CS + 2) * a.CO;
         if (r < nW) {
             const int row = (int)(r / a.CO), o = (int)(r - (size_t)row * a.CO);
-            v = row < a.CX ? a.gx[row * CZ + o] : (row < a.CX + a.CS ? a.gs[(row - a.CX) * CZ + o] : a.gl[(row - a.CX - a.CS) * CZ + o]);
+            v = row < a.CX ? GX(row, o) : (row < a.CX + a.CS ? GS(row - a.CX, o) : GL(row - a.CX - a.CS, o));
             d = a.dw + r;
         } else if ((r -= nW) < (size_t)a.CO) {
-            v = a.gb[r]; d = a.db + r;
+            v = GB((int)r); d = a.db + r;
         } else if ((r -= a.CO) < (size_t)(a.CX + a.CS) * 2) {
             const int row = (int)(r >> 1), c = (int)(r & 1);
-            v = row < a.CX ? a.gx[row * CZ + a.CO + c] : a.gs[(row - a.CX) * CZ + a.CO + c];
+            v = row < a.CX ? GX(row, a.CO + c) : GS(row - a.CX, a.CO + c);
             d = a.dwt + r;
         } else {
             r -= (size_t)(a.CX + a.CS) * 2;
-            v = a.gb[a.CO + r]; d = a.dbt + r;
+            v = GB(a.CO + (int)r); d = a.dbt + r;
         }
         *d = a.acc ? *d + v : v;
     }
 }
 
+bool rec_tail_staged(int HW) {
+    static const bool no_staged = getenv("DL4DS_REC_TAIL_NO_STAGED") != nullptr;
+    return HW % 256 == 0 && !no_staged;
+}
 template <int CX, int CS, int CO>
 void launch_fwd(hipStream_t s, const TailParams& p) {
-    static const bool no_staged = getenv("DL4DS_REC_TAIL_NO_STAGED") != nullptr;
-    if (p.HW % 256 == 0 && !no_staged) {
+    if (rec_tail_staged(p.HW)) {
         DL4DS_LAUNCH((rec_tail_fwd_staged_kernel<CX, CS, CO>), dim3((unsigned)((size_t)p.B * p.HW / 256)), dim3(256), 0, s, p);
         HIP_CHECK(hipGetLastError());
         return;
@@ -484,9 +541,8 @@ void launch_fwd(hipStream_t s, const TailParams& p) {
 }
 template <int CX, int CS, int CO>
 void launch_bwd(hipStream_t s, const TailBwdParams& p) {
-    static const bool no_staged = getenv("DL4DS_REC_TAIL_NO_STAGED") != nullptr;
-    if (p.HW % 256 == 0 && !no_staged) {
-        const size_t lds = (size_t)256 * (2 * CO + (CO + 2) + 2 * (CX + 4)) * sizeof(float);
+    if (rec_tail_staged(p.HW)) {
+        const size_t lds = (size_t)256 * (CO + (CO + 2) + 2 * (CX + 4) + (CS + 4)) * sizeof(float);
         static bool attr = false;
         if (!attr) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rec_tail_bwd_staged_kernel<CX, CS, CO>),
@@ -513,18 +569,31 @@ struct RecTailOp : GOp {
     size_t saved_floats_per_sample(Graph& g) override { return 4 * (size_t)T * g.tensors[out].H * g.tensors[out].W; }   // u, lws
     // backward: dz, dzs, the per-sample LocallyConnected partials, the three small weight-gradient results, then the 1x1
     // weight-gradient kernels' own workspace
-    struct Carve { float *dz, *dzs, *pl, *pb, *gx, *gs, *gl, *gb, *rest; size_t rest_bytes; };
+    struct Carve { float *dz, *dzs, *pl, *pb, *gx, *gs, *gl, *gb, *wpart, *wred, *rest; size_t rest_bytes; };
+    static constexpr int WSUM_GROUPS = 64;
     size_t carve_floats(Graph& g, int B) const {
         const size_t HW = (size_t)g.tensors[out].H * g.tensors[out].W, CZ = CO + 2;
         auto up = [](size_t v) { return (v + 3) & ~(size_t)3; };
+        if (rec_tail_staged((int)HW))           // no dz / dzs: the weight gradients come out of the backward kernel as tiles
+            return up((size_t)B * HW * 4) + up((size_t)B * HW * 2) + (size_t)B * (HW / 256) * REC_TAIL_WTILE + (size_t)WSUM_GROUPS * REC_TAIL_WTILE;
         return up(frames(g, B) * HW * CZ) + up((size_t)B * HW * CZ) + up((size_t)B * HW * 4) + up((size_t)B * HW * 2) + up((size_t)CX * CZ) +
                up((size_t)CS * CZ) + up(2 * CZ) + up(CZ);
     }
     Carve carve(Graph& g, int B, float* ws, size_t ws_bytes) const {
         const size_t HW = (size_t)g.tensors[out].H * g.tensors[out].W, CZ = CO + 2;
         auto up = [](size_t v) { return (v + 3) & ~(size_t)3; };
-        Carve c;
+        Carve c = {};
         float* p = ws;
+        if (rec_tail_staged((int)HW)) {
+            c.pl = p; p += up((size_t)B * HW * 4);
+            c.pb = p; p += up((size_t)B * HW * 2);
+            c.wpart = p; p += (size_t)B * (HW / 256) * REC_TAIL_WTILE;
+            c.wred = p; p += (size_t)WSUM_GROUPS * REC_TAIL_WTILE;
+            c.rest = p;
+            DL4DS_REQUIRE((size_t)(p - ws) * sizeof(float) <= ws_bytes, "rec_tail: workspace too small");
+            c.rest_bytes = ws_bytes - (size_t)(p - ws) * sizeof(float);
+            return c;
+        }
         c.dz = p; p += up(frames(g, B) * HW * CZ);
         c.dzs = p; p += up((size_t)B * HW * CZ);
         c.pl = p; p += up((size_t)B * HW * 4);
@@ -578,24 +647,36 @@ struct RecTailOp : GOp {
         p.mask_x = g.tensors[x].grad_masked; p.mask_s = g.tensors[s].grad_masked;
         p.u = saved + f_off * 2;
         const float* lws = saved + 2 * frames(g, c.B) * HW + f_off * 2;
+        p.lws = lws;
+        const bool staged = rec_tail_staged(HW);
         p.y = to.data + f_off * CO; p.dy = to.grad + f_off * CO;
         p.wt = g.wp(wt); p.wl = g.wp(wl); p.w = g.wp(w);
         p.want_dx = wants_grad(g, x, c); p.want_ds = wants_grad(g, s, c);
         p.dx = p.want_dx ? g.tensors[x].grad + f_off * CX : nullptr;
         p.ds = p.want_ds ? g.tensors[s].grad + (size_t)c.b_off * HW * CS : nullptr;
         p.acc_dx = g.tensors[x].grad_written; p.acc_ds = g.tensors[s].grad_written;
-        p.dz = cv.dz; p.dzs = cv.dzs; p.dwl_part = cv.pl; p.dbl_part = cv.pb;
+        p.dz = cv.dz; p.dzs = cv.dzs; p.dwl_part = cv.pl; p.dbl_part = cv.pb; p.wpart = cv.wpart;
         p.B = cnt; p.T = T; p.HW = HW;
         {
             const double px = (double)fr * HW;
-            ProfScope ps(g.stream, "rec_tail_bwd", 2.0 * px * (2 * CO + 8 + (CX + CS) * (CO + 2)),
-                         4.0 * px * (CX * (p.want_dx ? 2 : 1) + 2 * CO + CZ + 2) + 4.0 * cnt * HW * (CZ + CS + 6));
+            // staged: + the weight-gradient products, no dz; x always read
+            ProfScope ps(g.stream, "rec_tail_bwd", 2.0 * px * (2 * CO + 8 + (CX + CS) * (CO + 2) + (staged ? (CX + CS + 3) * CZ : 0)),
+                         staged ? 4.0 * px * (CX * (p.want_dx ? 2 : 1) + 2 * CO + 4) + 4.0 * cnt * HW * (2 * CS + 6)
+                                : 4.0 * px * (CX * (p.want_dx ? 2 : 1) + 2 * CO + CZ + 2) + 4.0 * cnt * HW * (CZ + CS + 6));
 #define X(A_, B_, C_) if (CX == A_ && CS == B_ && CO == C_) launch_bwd<A_, B_, C_>(g.stream, p);
             REC_TAIL_SHAPES(X)
 #undef X
         }
         if (p.want_dx) g.tensors[x].grad_written = true;
         if (p.want_ds) g.tensors[s].grad_written = true;
+        TailFinishParams f = {};
+        if (staged) {
+            const int nblk = cnt * (HW / 256), G = std::min(nblk, (int)WSUM_GROUPS);
+            ProfScope ps(g.stream, "rec_tail_wsum", 0.0, 4.0 * REC_TAIL_WTILE * (nblk + G));
+            DL4DS_LAUNCH(rec_tail_wsum_kernel, dim3(G), dim3(256), 0, g.stream, cv.wpart, nblk, cv.wred);
+            HIP_CHECK(hipGetLastError());
+            f.tiles = cv.wred; f.G = G;
+        } else {
         // the three 1x1 weight gradients against dz (bias gradient = column sums of dz: rides on the first)
         TView xv = make_view(const_cast<float*>(p.x), (int)fr, to.H, to.W, CX), zv = make_view(cv.dz, (int)fr, to.H, to.W, CZ);
         TView sv = make_view(g.tensors[s].data + (size_t)c.b_off * HW * CS, cnt, to.H, to.W, CS), zs = make_view(cv.dzs, cnt, to.H, to.W, CZ);
@@ -603,7 +684,7 @@ struct RecTailOp : GOp {
         conv2d_wgrad(g.stream, xv, zv, 1, cv.gx, 0, cv.gb, 0, cv.rest, cv.rest_bytes);
         conv2d_wgrad(g.stream, sv, zs, 1, cv.gs, 0, nullptr, 0, cv.rest, cv.rest_bytes);
         conv2d_wgrad(g.stream, lv, zv, 1, cv.gl, 0, nullptr, 0, cv.rest, cv.rest_bytes);
-        TailFinishParams f;
+        }
         f.dwl_part = cv.pl; f.dbl_part = cv.pb; f.gx = cv.gx; f.gs = cv.gs; f.gl = cv.gl; f.gb = cv.gb;
         f.dwl = g.gp(wl); f.dbl = g.gp(bl); f.dw = g.gp(w); f.db = g.gp(b); f.dwt = g.gp(wt); f.dbt = g.gp(bt);
         f.B = cnt; f.HW = HW; f.CX = CX; f.CS = CS; f.CO = CO;
