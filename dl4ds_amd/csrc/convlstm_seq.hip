@@ -88,7 +88,8 @@ struct SeqParams {
     const float* dout;     // backward: gradient of out
     float* dZ;             // backward out: (B,T,H,W,4F) interleaved
     float* dc;             // backward scratch: (B,H,W,F) running dL/dc
-    unsigned* flags;       // [tiles]: steps completed by each tile (zeroed before the launch)
+    unsigned* flags;       // [tiles]: epoch + steps completed by each tile (never reset: see seq_epoch)
+    unsigned epoch;        // this launch's base value: everything an earlier launch left in `flags` is below it
     unsigned* err;         // host-visible sticky error word (runtime.h): set when a spin gives up
     int B, T, H, W, tiles_x, tiles_y, ntiles, relu, tr;
     unsigned long long* trace;   // DL4DS_SEQ_TRACE: [block][8] phase times (100 MHz wall clock), null otherwise
@@ -123,7 +124,8 @@ __device__ __forceinline__ void wait_neighbours(const SeqParams& p, int tile, un
         if (threadIdx.x != 4 && yy >= 0 && xx >= 0 && yy < p.tiles_y && xx < p.tiles_x) {
             gu32* f = (gu32*)(p.flags + img * tpi + yy * p.tiles_x + xx);
             unsigned spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < SPIN_LIMIT)
+            const unsigned want = p.epoch + need;                 // (wrap-safe comparison: the counter is a 32-bit running sum)
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 && ++spins < SPIN_LIMIT)
                 __builtin_amdgcn_s_sleep(1);
             // gave up: the halo this tile stages next is stale.  Say so where the host looks after every sync (device_error_check):
             // the step must not pass for a valid one.
@@ -136,7 +138,7 @@ __device__ __forceinline__ void wait_neighbours(const SeqParams& p, int tile, un
 __device__ __forceinline__ void publish(const SeqParams& p, int tile, unsigned done) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains its (sc1) stores
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store((gu32*)(p.flags + tile), done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store((gu32*)(p.flags + tile), p.epoch + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // stage the (TY x TW) halo tile of a frame (pixel pitch CIN floats, zero outside the image) as [y][x][Geom::PITCH], sc1 loads
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_fwd_kernel(const SeqParam
                         const size_t pix = fr + (size_t)y * p.W + xx;
                         const i32x4_t hv = *reinterpret_cast<const i32x4_t*>(xch + pl * F + 4 * cq);
                         if (t + 1 < p.T) __builtin_amdgcn_raw_buffer_store_b128(hv, rh, ((y * p.W + xx) * F + 4 * cq) * 4, 0, AUX_SC1);
+                        if (t == 0) *reinterpret_cast<f32x4_t*>(p.Hrec + pix * F + 4 * cq) = (f32x4_t){0.f, 0.f, 0.f, 0.f};      // h_{-1} = 0
                         *reinterpret_cast<f32x4_t*>(p.C + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (PX + pl) * F + 4 * cq);
                         *reinterpret_cast<f32x4_t*>(p.out + pix * F + 4 * cq) = *reinterpret_cast<const f32x4_t*>(xch + (2 * PX + pl) * F + 4 * cq);
                     }
@@ -623,6 +626,17 @@ static int seq_tr(int H, int W, int B, bool backward) {
     return (backward && t16 < 2l * std::max(cu_count(), 8) && H > 8) ? 2 : 4;
 }
 
+// Flags are never zeroed between launches (two memset nodes per layer and step were 30 dispatches of a cfg4 step): a launch
+// publishes `epoch + steps done` (1 <= steps <= T) and waits for `epoch + needed`; the epoch is a process-wide running sum of
+// T + 1 per launch, so whatever an earlier launch -- of any layer, tiling or direction -- left in a flag word is <= the new
+// epoch and reads as "nothing done yet".  A freshly allocated slab is zeroed (Graph::prepare).
+static unsigned seq_epoch(int T) {
+    static unsigned next = 1;
+    const unsigned e = next;
+    next += (unsigned)T + 1;
+    return e;
+}
+
 static SeqParams seq_params(const float* U, float* Z, float* C, float* Hrec, float* out, const float* dout, float* dZ, float* dc,
                             unsigned* flags, int B, int T, int H, int W, int relu, bool backward) {
     SeqParams p;
@@ -631,6 +645,7 @@ static SeqParams seq_params(const float* U, float* Z, float* C, float* Hrec, flo
     p.err = device_error_word();
     p.tr = seq_tr(H, W, B, backward);
     p.trace = nullptr;
+    p.epoch = seq_epoch(T);
     p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 4 * p.tr); p.ntiles = p.tiles_x * p.tiles_y * B;
     return p;
 }
@@ -640,7 +655,6 @@ size_t convlstm_seq_flag_bytes(int H, int W, int B) { return (size_t)cdiv(H, 8) 
 void convlstm_seq_forward(hipStream_t s, const float* U_il, float* Z_il, float* C, float* Hrec, float* out, unsigned* flags,
                           int B, int T, int H, int W, int KS, int F, int relu) {
     SeqParams p = seq_params(U_il, Z_il, C, Hrec, out, nullptr, nullptr, nullptr, flags, B, T, H, W, relu, false);
-    HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)p.ntiles * sizeof(unsigned), s));
     const double px = (double)B * T * H * W;
     ProfScope ps(s, "convlstm_seq_fwd<" + std::to_string(KS) + "," + std::to_string(F) + ">",
                  2.0 * (double)B * (T - 1) * H * W * KS * KS * F * 4 * F, 4.0 * px * (4 * F * 2 + F * 4));
@@ -656,7 +670,6 @@ void convlstm_seq_backward(hipStream_t s, const float* U_il, const float* Z_il, 
                            float* dZ_il, float* dc, unsigned* flags, int B, int T, int H, int W, int KS, int F, int relu) {
     SeqParams p = seq_params(U_il, const_cast<float*>(Z_il), const_cast<float*>(C), nullptr, const_cast<float*>(out), dout, dZ_il, dc,
                              flags, B, T, H, W, relu, true);
-    HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)p.ntiles * sizeof(unsigned), s));
     const double px = (double)B * T * H * W;
     ProfScope ps(s, "convlstm_seq_bwd<" + std::to_string(KS) + "," + std::to_string(F) + ">",
                  2.0 * (double)B * (T - 1) * H * W * KS * KS * F * 4 * F, 4.0 * px * (4 * F * 2 + F * 6));

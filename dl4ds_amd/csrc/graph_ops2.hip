@@ -110,12 +110,15 @@ struct ConvLSTMOp : GOp {
     Bufs bufs(Graph& g, int B) {
         const size_t n = (size_t)B * T * hw(g);
         Bufs r;
-        r.Z = saved; r.C = r.Z + n * 4 * F; r.H = r.C + n * F; r.dZ = r.H + n * F;
+        // the tile flags come FIRST and at the size of the slab's largest batch: they are never reset (convlstm_seq.hip:
+        // seq_epoch), so no other buffer of any batch size may ever overlay them
+        const size_t flag_floats = ((size_t)(hw(g) / 64 + 64) * g.maxB + 63) & ~(size_t)63;
+        r.flags = reinterpret_cast<unsigned*>(saved);
+        r.Z = saved + (seq ? flag_floats : 0); r.C = r.Z + n * 4 * F; r.H = r.C + n * F; r.dZ = r.H + n * F;
         r.dh = r.dZ + n * 4 * F; r.dc = r.dh + (size_t)B * hw(g) * F;
         r.dKp = r.dc + (size_t)B * hw(g) * F;
         r.dUp = r.dKp + (size_t)KS * KS * cin(g) * 4 * F;
         r.dbp = r.dUp + (size_t)KS * KS * F * 4 * F;
-        r.flags = reinterpret_cast<unsigned*>(r.dbp + 4 * F + 60);
         return r;
     }
     TView frame(Graph& g, float* base, int B, int t, int ch) {      // frame t of every sample of a (B,T,H,W,ch) buffer
@@ -130,9 +133,10 @@ struct ConvLSTMOp : GOp {
         // H holds the RECURRENT INPUT of every step: H[b, t] = h_{t-1}, H[b, 0] = 0 (zero initial state).  Stored that way
         // the recurrent kernel's weight gradient sum_{b,t} wgrad(h_{t-1}, dZ_t) is ONE convolution-wgrad over the B*T frame
         // pairs (H, dZ) -- frame 0 of every sample contributes nothing -- instead of T-1 launches of ~60 us.
-        HIP_CHECK(hipMemset2DAsync(bf.H, (size_t)T * hw(g) * F * sizeof(float), 0, hw(g) * F * sizeof(float), (size_t)B, g.stream));
+        // (the one-launch recurrence writes that zero frame itself)
+        if (!seq) HIP_CHECK(hipMemset2DAsync(bf.H, (size_t)T * hw(g) * F * sizeof(float), 0, hw(g) * F * sizeof(float), (size_t)B, g.stream));
         if (seq) {
-            DL4DS_REQUIRE(convlstm_seq_flag_bytes(ti.H, ti.W, B) <= (hw(g) / 64 + 64) * sizeof(float) * (size_t)B, "convlstm: flag area");
+            DL4DS_REQUIRE(convlstm_seq_flag_bytes(ti.H, ti.W, B) <= (hw(g) / 64 + 64) * sizeof(float) * (size_t)B && B <= g.maxB, "convlstm: flag area");
             float *Kp = g.Wt + wt_kp, *Up = g.Wt + wt_up, *bp = g.Wt + wt_bp;
             {   // kernel, recurrent kernel and bias into the interleaved gate order: one launch
                 const float* src[3] = {g.wp(wk), g.wp(wr), g.wp(b)};

@@ -32,6 +32,12 @@ inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 constexpr int RSRC3 = 0x00020000;
 
+// The filter arrays are read with wave-uniform indices.  Through a generic pointer the compiler may not assume that the stores
+// of the pass leave them alone: it re-read them with VECTOR loads after every store (280 global loads per frame in the backward
+// pass).  Read through the constant address space they are scalar loads, invariant for the launch.
+typedef const float __attribute__((address_space(4))) * cfloat_p;
+__device__ __forceinline__ cfloat_p uniform_ro(const float* p) { return (cfloat_p)p; }
+
 struct TailParams {
     const float *x, *s, *wt, *bt, *wl, *bl, *w, *b;
     float *y, *u, *lws;
@@ -67,6 +73,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
 // indices: scalar loads, used straight as FMA operands.
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
+    const cfloat_p wt_ = uniform_ro(a.wt), bt_ = uniform_ro(a.bt), w_ = uniform_ro(a.w), b_ = uniform_ro(a.b);
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= (size_t)a.B * a.HW) return;
     const int bi = (int)(p / a.HW), hw = (int)(p - (size_t)bi * a.HW);
@@ -76,15 +83,15 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(a.s + p * CS + q);
         sv[q] = t[0]; sv[q + 1] = t[1]; sv[q + 2] = t[2]; sv[q + 3] = t[3];
     }
-    float su[2] = {a.bt[0], a.bt[1]}, sy[CO];
+    float su[2] = {bt_[0], bt_[1]}, sy[CO];
 #pragma unroll
-    for (int o = 0; o < CO; ++o) sy[o] = a.b[o];
+    for (int o = 0; o < CO; ++o) sy[o] = b_[o];
 #pragma unroll
     for (int j = 0; j < CS; ++j) {
-        su[0] = fmaf(sv[j], a.wt[(CX + j) * 2], su[0]);
-        su[1] = fmaf(sv[j], a.wt[(CX + j) * 2 + 1], su[1]);
+        su[0] = fmaf(sv[j], wt_[(CX + j) * 2], su[0]);
+        su[1] = fmaf(sv[j], wt_[(CX + j) * 2 + 1], su[1]);
 #pragma unroll
-        for (int o = 0; o < CO; ++o) sy[o] = fmaf(sv[j], a.w[(CX + j) * CO + o], sy[o]);
+        for (int o = 0; o < CO; ++o) sy[o] = fmaf(sv[j], w_[(CX + j) * CO + o], sy[o]);
     }
     const f32x4 wl4 = *reinterpret_cast<const f32x4*>(a.wl + (size_t)hw * 4);         // Wl[h][w][c][f] -> c * 2 + f
     const float bl0 = a.bl[(size_t)hw * 2], bl1 = a.bl[(size_t)hw * 2 + 1];
@@ -99,16 +106,16 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
         }
         float u0 = su[0], u1 = su[1];
 #pragma unroll
-        for (int i = 0; i < CX; ++i) { u0 = fmaf(xv[i], a.wt[i * 2], u0); u1 = fmaf(xv[i], a.wt[i * 2 + 1], u1); }
+        for (int i = 0; i < CX; ++i) { u0 = fmaf(xv[i], wt_[i * 2], u0); u1 = fmaf(xv[i], wt_[i * 2 + 1], u1); }
         u0 = fmaxf(u0, 0.f); u1 = fmaxf(u1, 0.f);
         const float l0 = fmaf(u1, wl4[2], fmaf(u0, wl4[0], bl0)), l1 = fmaf(u1, wl4[3], fmaf(u0, wl4[1], bl1));
         float yv[CO];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) yv[o] = fmaf(l1, a.w[(CX + CS + 1) * CO + o], fmaf(l0, a.w[(CX + CS) * CO + o], sy[o]));
+        for (int o = 0; o < CO; ++o) yv[o] = fmaf(l1, w_[(CX + CS + 1) * CO + o], fmaf(l0, w_[(CX + CS) * CO + o], sy[o]));
 #pragma unroll
         for (int i = 0; i < CX; ++i)
 #pragma unroll
-            for (int o = 0; o < CO; ++o) yv[o] = fmaf(xv[i], a.w[i * CO + o], yv[o]);
+            for (int o = 0; o < CO; ++o) yv[o] = fmaf(xv[i], w_[i * CO + o], yv[o]);
 #pragma unroll
         for (int o = 0; o < CO; ++o) yv[o] = fmaxf(yv[o], 0.f);
         store_row<CO>(ry, (int)(px * CO * 4), yv);
@@ -123,6 +130,7 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
 // 64-byte segments per lane quad and ran at 2.4 TB/s).  The next frame's loads are in flight during the arithmetic.
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_fwd_staged_kernel(const TailParams a) {
+    const cfloat_p wt_ = uniform_ro(a.wt), bt_ = uniform_ro(a.bt), w_ = uniform_ro(a.w), b_ = uniform_ro(a.b);
     constexpr int XQ = CX / 4, XP = CX + 4, NY4 = 256 * CO / 4, YIT = (NY4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float xs[256 * XP];
     __shared__ __attribute__((aligned(16))) float ys[256 * CO];
@@ -136,15 +144,15 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_staged_kernel(const TailPara
         const f32x4 t = *reinterpret_cast<const f32x4*>(a.s + p * CS + q);
         sv[q] = t[0]; sv[q + 1] = t[1]; sv[q + 2] = t[2]; sv[q + 3] = t[3];
     }
-    float su[2] = {a.bt[0], a.bt[1]}, sy[CO];
+    float su[2] = {bt_[0], bt_[1]}, sy[CO];
 #pragma unroll
-    for (int o = 0; o < CO; ++o) sy[o] = a.b[o];
+    for (int o = 0; o < CO; ++o) sy[o] = b_[o];
 #pragma unroll
     for (int j = 0; j < CS; ++j) {
-        su[0] = fmaf(sv[j], a.wt[(CX + j) * 2], su[0]);
-        su[1] = fmaf(sv[j], a.wt[(CX + j) * 2 + 1], su[1]);
+        su[0] = fmaf(sv[j], wt_[(CX + j) * 2], su[0]);
+        su[1] = fmaf(sv[j], wt_[(CX + j) * 2 + 1], su[1]);
 #pragma unroll
-        for (int o = 0; o < CO; ++o) sy[o] = fmaf(sv[j], a.w[(CX + j) * CO + o], sy[o]);
+        for (int o = 0; o < CO; ++o) sy[o] = fmaf(sv[j], w_[(CX + j) * CO + o], sy[o]);
     }
     const f32x4 wl4 = *reinterpret_cast<const f32x4*>(a.wl + (size_t)hw * 4);
     const float bl0 = a.bl[(size_t)hw * 2], bl1 = a.bl[(size_t)hw * 2 + 1];
@@ -172,16 +180,16 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_staged_kernel(const TailPara
         }
         float u0 = su[0], u1 = su[1];
 #pragma unroll
-        for (int i = 0; i < CX; ++i) { u0 = fmaf(xv[i], a.wt[i * 2], u0); u1 = fmaf(xv[i], a.wt[i * 2 + 1], u1); }
+        for (int i = 0; i < CX; ++i) { u0 = fmaf(xv[i], wt_[i * 2], u0); u1 = fmaf(xv[i], wt_[i * 2 + 1], u1); }
         u0 = fmaxf(u0, 0.f); u1 = fmaxf(u1, 0.f);
         const float l0 = fmaf(u1, wl4[2], fmaf(u0, wl4[0], bl0)), l1 = fmaf(u1, wl4[3], fmaf(u0, wl4[1], bl1));
         float yv[CO];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) yv[o] = fmaf(l1, a.w[(CX + CS + 1) * CO + o], fmaf(l0, a.w[(CX + CS) * CO + o], sy[o]));
+        for (int o = 0; o < CO; ++o) yv[o] = fmaf(l1, w_[(CX + CS + 1) * CO + o], fmaf(l0, w_[(CX + CS) * CO + o], sy[o]));
 #pragma unroll
         for (int i = 0; i < CX; ++i)
 #pragma unroll
-            for (int o = 0; o < CO; ++o) yv[o] = fmaf(xv[i], a.w[i * CO + o], yv[o]);
+            for (int o = 0; o < CO; ++o) yv[o] = fmaf(xv[i], w_[i * CO + o], yv[o]);
 #pragma unroll
         for (int o = 0; o < CO; ++o) ys[tid * CO + o] = fmaxf(yv[o], 0.f);
         *reinterpret_cast<float2*>(a.u + (px0 + tid) * 2) = make_float2(u0, u1);
@@ -206,6 +214,7 @@ struct TailBwdParams {
 
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a) {
+    const cfloat_p wt_ = uniform_ro(a.wt), w_ = uniform_ro(a.w);
     constexpr int CZ = CO + 2;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= (size_t)a.B * a.HW) return;
@@ -231,7 +240,7 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
         const float2 uv = *reinterpret_cast<const float2*>(a.u + px * 2);
         float dl0 = 0.f, dl1 = 0.f;
 #pragma unroll
-        for (int o = 0; o < CO; ++o) { dl0 = fmaf(a.w[(CX + CS) * CO + o], z[o], dl0); dl1 = fmaf(a.w[(CX + CS + 1) * CO + o], z[o], dl1); }
+        for (int o = 0; o < CO; ++o) { dl0 = fmaf(w_[(CX + CS) * CO + o], z[o], dl0); dl1 = fmaf(w_[(CX + CS + 1) * CO + o], z[o], dl1); }
         // lws[f] = sum_c u[c] Wl[c][f] + bl[f]
         dwl[0] = fmaf(uv.x, dl0, dwl[0]); dwl[1] = fmaf(uv.x, dl1, dwl[1]); dwl[2] = fmaf(uv.y, dl0, dwl[2]); dwl[3] = fmaf(uv.y, dl1, dwl[3]);
         dbl[0] += dl0; dbl[1] += dl1;
@@ -249,9 +258,9 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
             }
 #pragma unroll
             for (int i = 0; i < CX; ++i) {
-                float v = fmaf(a.wt[i * 2 + 1], z[CO + 1], a.wt[i * 2] * z[CO]);
+                float v = fmaf(wt_[i * 2 + 1], z[CO + 1], wt_[i * 2] * z[CO]);
 #pragma unroll
-                for (int o = 0; o < CO; ++o) v = fmaf(a.w[i * CO + o], z[o], v);
+                for (int o = 0; o < CO; ++o) v = fmaf(w_[i * CO + o], z[o], v);
                 dxv[i] = (a.mask_x && !(xm[i] > 0.f)) ? 0.f : v;
             }
 #pragma unroll
@@ -264,9 +273,9 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
         }
 #pragma unroll
         for (int j = 0; j < CS; ++j) {
-            float v = fmaf(a.wt[(CX + j) * 2 + 1], z[CO + 1], a.wt[(CX + j) * 2] * z[CO]);
+            float v = fmaf(wt_[(CX + j) * 2 + 1], z[CO + 1], wt_[(CX + j) * 2] * z[CO]);
 #pragma unroll
-            for (int o = 0; o < CO; ++o) v = fmaf(a.w[(CX + j) * CO + o], z[o], v);
+            for (int o = 0; o < CO; ++o) v = fmaf(w_[(CX + j) * CO + o], z[o], v);
             dsacc[j] += v;
         }
         store_row<CZ>(rdz, (int)(px * CZ * 4), z);
@@ -302,6 +311,7 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
 constexpr int REC_TAIL_WTILE = 512;
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdParams a) {
+    const cfloat_p wt_ = uniform_ro(a.wt), w_ = uniform_ro(a.w);
     constexpr int CZ = CO + 2, XQ = CX / 4, XP = CX + 4, AP = CS + 4;
     static_assert(CZ <= 16 && CX <= 16 && CS + 3 <= 16 && 4 * REC_TAIL_WTILE <= 256 * CO, "rec_tail: tile shapes");
     constexpr int NR4 = 256 * CO / 4, RIT = (NR4 + 255) / 256;       // float4 per block row-stream of a CO-channel tensor
@@ -368,7 +378,7 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
         for (int o = 0; o < CO; ++o) z[o] = dys[tid * CO + o];
         float dl0 = 0.f, dl1 = 0.f;
 #pragma unroll
-        for (int o = 0; o < CO; ++o) { dl0 = fmaf(a.w[(CX + CS) * CO + o], z[o], dl0); dl1 = fmaf(a.w[(CX + CS + 1) * CO + o], z[o], dl1); }
+        for (int o = 0; o < CO; ++o) { dl0 = fmaf(w_[(CX + CS) * CO + o], z[o], dl0); dl1 = fmaf(w_[(CX + CS + 1) * CO + o], z[o], dl1); }
         dwl[0] = fmaf(uv.x, dl0, dwl[0]); dwl[1] = fmaf(uv.x, dl1, dwl[1]); dwl[2] = fmaf(uv.y, dl0, dwl[2]); dwl[3] = fmaf(uv.y, dl1, dwl[3]);
         dbl[0] += dl0; dbl[1] += dl1;
         const float du0 = fmaf(wl4[1], dl1, wl4[0] * dl0), du1 = fmaf(wl4[3], dl1, wl4[2] * dl0);
@@ -398,9 +408,9 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = q + r;
-                    float v = fmaf(a.wt[i * 2 + 1], z[CO + 1], a.wt[i * 2] * z[CO]);
+                    float v = fmaf(wt_[i * 2 + 1], z[CO + 1], wt_[i * 2] * z[CO]);
 #pragma unroll
-                    for (int o = 0; o < CO; ++o) v = fmaf(a.w[i * CO + o], z[o], v);
+                    for (int o = 0; o < CO; ++o) v = fmaf(w_[i * CO + o], z[o], v);
                     if (a.mask_x && !(xss[tid * XP + i] > 0.f)) v = 0.f;
                     d4[r] = v;
                 }
@@ -409,9 +419,9 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
         }
 #pragma unroll
         for (int j = 0; j < CS; ++j) {
-            float v = fmaf(a.wt[(CX + j) * 2 + 1], z[CO + 1], a.wt[(CX + j) * 2] * z[CO]);
+            float v = fmaf(wt_[(CX + j) * 2 + 1], z[CO + 1], wt_[(CX + j) * 2] * z[CO]);
 #pragma unroll
-            for (int o = 0; o < CO; ++o) v = fmaf(a.w[(CX + j) * CO + o], z[o], v);
+            for (int o = 0; o < CO; ++o) v = fmaf(w_[(CX + j) * CO + o], z[o], v);
             dsacc[j] += v;
         }
         __syncthreads();
