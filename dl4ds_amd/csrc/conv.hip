@@ -510,7 +510,7 @@ bool try_launch_db(hipStream_t s, ConvParams& p, int N, size_t lds_limit) {
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_igemm_db<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
                         std::to_string(WM) + "," + std::to_string(WN) + ">",
-                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + (double)KS * KS * p.Cin * p.Cout));
     DL4DS_LAUNCH(kern, grid, dim3(NTHR), best_lds, s, p);
     HIP_CHECK(hipGetLastError());
     return true;
@@ -563,7 +563,7 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
     if (!no_splitk && blocks < 256 && nchunks >= 2) S = (int)std::min<long>(nchunks, std::max<long>(2, sk_target / blocks));
     ProfScope ps(s, "conv_igemm<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
                         std::to_string(WM) + "," + std::to_string(WN) + (S > 1 ? ",splitk>" : ">"),
-                 2.0 * px * KK * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KK * p.Cin * p.Cout));
+                 2.0 * px * KK * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + (double)KK * p.Cin * p.Cout));
     p.kchunks = 0; p.nimg = N;
     if (S > 1) {
         const int cps = cdiv(nchunks, S);
@@ -1501,7 +1501,7 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     const double px = (double)p.x.N * p.H * p.W;
     ProfScope ps(s, std::string(rows ? "conv_wgrad_rows<" : "conv_wgrad<") + std::to_string(KS) + "," + std::to_string(CIT) +
                         "," + std::to_string(COT) + "," + std::to_string(WCO) + ">",
-                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
+                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + (double)KS * KS * p.Cin * p.Cout));
     DL4DS_LAUNCH(kern, grid, dim3(ws ? 512 : 256), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }

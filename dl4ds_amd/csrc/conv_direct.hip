@@ -831,7 +831,9 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
     const double px = (double)p.in.N * p.H * p.W;
     const std::string tag = std::string(wgrad ? "conv_direct_wgrad<" : "conv_direct<") + std::to_string(KS) + "," +
                             std::to_string(CI) + "," + std::to_string(CO) + ">";
-    ProfScope ps(s, tag, 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * px * (p.Cin + p.Cout));
+    // (forward / dgrad: the epilogue's operands -- residual, ReLU mask, old value -- are part of the layer's traffic)
+    ProfScope ps(s, tag, 2.0 * px * KS * KS * p.Cin * p.Cout,
+                 4.0 * px * (p.Cin + p.Cout * (wgrad ? 1 : 1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))));
     if (gen2) {
         if (wgrad) DL4DS_LAUNCH((conv_direct2_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
         else DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);

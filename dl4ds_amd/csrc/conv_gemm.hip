@@ -213,7 +213,7 @@ bool conv2d_gemm_forward(hipStream_t s, const TView& in, const float* w, int KS,
     });
     const double px = (double)M;
     ProfScope ps(s, "conv_gemm<" + std::to_string(KS) + ">", 2.0 * px * KS * KS * in.C * out.C,
-                 4.0 * (px * (in.C + out.C) + (double)KS * KS * in.C * out.C));
+                 4.0 * (px * (in.C + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))) + (double)KS * KS * in.C * out.C));
     DL4DS_LAUNCH(conv_gemm_kernel, dim3(gm, gn, S), dim3(256), LDS_FLOATS * sizeof(float), s, p);
     HIP_CHECK(hipGetLastError());
     ConvParams c;

@@ -152,7 +152,7 @@ void launch_narrow(hipStream_t s, ConvParams& p, int N) {
     const int blocks = std::min(ntiles, resident_blocks<conv_narrow_kernel<CI>>(256));
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_narrow<" + std::to_string(CI) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
-                 4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+                 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
     DL4DS_LAUNCH((conv_narrow_kernel<CI>), dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
@@ -1120,7 +1120,7 @@ bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
                                          (p.accumulate ? PAIR_EPI_ACC : 0));
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_narrow16_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
-                 4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+                 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
     static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;                     // (A/B)
     p.CK = no_xcd ? 0 : 1;
     auto grid_of = [&](int resident) { const int b = std::min(ntiles, resident); return b >= 8 ? (b & ~7) : b; };
@@ -1180,7 +1180,7 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
         if (blocks >= 8) blocks &= ~7;
         p.CK = no_xcd ? 0 : 1;
         ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
-                     4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+                     4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
 #define PAIR_WS_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, E_>), dim3(blocks), dim3(512), 0, s, p); break;
         switch (generic_only ? -1 : epi) {
             PAIR_WS_FORM(0) PAIR_WS_FORM(1) PAIR_WS_FORM(2) PAIR_WS_FORM(3) PAIR_WS_FORM(4) PAIR_WS_FORM(5) PAIR_WS_FORM(6) PAIR_WS_FORM(7)
@@ -1209,7 +1209,7 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
     }
     const int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_kernel<NR>>(256));
     ProfScope ps(s, "conv_narrow_pair<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
-                 4.0 * (px * (p.Cin + p.Cout) + 9.0 * p.Cin * p.Cout));
+                 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
     DL4DS_LAUNCH((conv_narrow_pair_kernel<NR>), dim3(blocks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }

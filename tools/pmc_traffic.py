@@ -16,6 +16,10 @@ def collect(root, counter):
 fetch = collect(sys.argv[1], 'FETCH_SIZE')
 write = collect(sys.argv[2], 'WRITE_SIZE')
 def tag_of(k):
+    if 'rec_tail_fwd' in k:
+        return 'rec_tail_fwd'                # plain and LDS-staged form share bench.py's tag
+    if 'rec_tail_bwd' in k:
+        return 'rec_tail_bwd'
     m = re.search(r'(conv\w+)<([^>]*)>', k)
     if not m:
         return k[:60]
