@@ -1501,7 +1501,7 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     const double px = (double)p.x.N * p.H * p.W;
     ProfScope ps(s, std::string(rows ? "conv_wgrad_rows<" : "conv_wgrad<") + std::to_string(KS) + "," + std::to_string(CIT) +
                         "," + std::to_string(COT) + "," + std::to_string(WCO) + ">",
-                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + (double)KS * KS * p.Cin * p.Cout));
+                 2.0 * px * KS * KS * p.Cin * p.Cout, 4.0 * (px * (p.Cin + p.Cout) + (double)KS * KS * p.Cin * p.Cout));
     DL4DS_LAUNCH(kern, grid, dim3(ws ? 512 : 256), lds, s, p);
     HIP_CHECK(hipGetLastError());
 }
