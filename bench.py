@@ -413,6 +413,15 @@ def main():
                            if dom.startswith('conv_wino') else {}),
                         'share_of_step_time': dom_share,
                         'measured': 'HIP events around every launch of this kernel inside the timed region'}
+            # the roof that binds: a narrow-channel layer's algorithmic bytes / 8 TB/s can be the larger fraction
+            gbps = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+            if gbps / PEAK_HBM_GBPS > roofline['frac']:
+                roofline['mfma_roof'] = {'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS}
+                roofline.update({'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                                 'frac': gbps / PEAK_HBM_GBPS})
+            else:
+                roofline['hbm_roof'] = {'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS}
 
     # ---- a second, longer window: the driver's K steps may be a fraction of a second (cfg2: 20 x 14 ms), during which the
     #      clock is still settling; `value` stays the K-step figure the contract asks for, `steady_state` reports both
