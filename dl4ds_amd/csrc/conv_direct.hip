@@ -176,8 +176,19 @@ struct TileStager {
     }
 };
 
-template <int KS, int CI, int CO>
-__global__ void __launch_bounds__(256) conv_direct_kernel(const DirectParams a) {
+template <int KS, int CI, int CO, bool PLAIN>
+__global__ void __launch_bounds__(256) conv_direct_kernel(const DirectParams a_) {
+    // PLAIN: bias (+ ReLU) only, plain input view, output without depth_to_space.  The KK * CI * CO filter values live in scalar
+    // registers; with the residual / mask / accumulate views and the input's channel affine live across the tile loop as well the
+    // kernels spill scalar registers into vector lanes (v_readlane before the FMAs that use them); nulled at compile time the
+    // 1 -> 1 layer has none left (0.117 -> 0.069 ms for two launches at 64 x 512^2).  The 72-value filters of 8 -> 1 / 1 -> 8 still
+    // spill ~40; reading them with just-in-time scalar loads (constant address space, pointer made opaque per tile) and four
+    // blocks per CU were measured: no change -- those two wait on HBM, not on issue slots.
+    DirectParams a = a_;
+    if constexpr (PLAIN) {
+        a.add.p = nullptr; a.mask.p = nullptr; a.accumulate = 0; a.in.sc = nullptr; a.in.sh = nullptr;
+        a.out.d2s = 1; a.in.d2s = 1;
+    }
     constexpr int HWD = DTX + KS - 1, HHT = DTY + KS - 1, HPIX = HWD * HHT;
     constexpr int VEC = CI < 4 ? CI : 4, NPL = CI / VEC;
     constexpr int KK = KS * KS, NWT = KK * CI * CO;
@@ -507,8 +518,19 @@ __device__ __forceinline__ Walk2 walk2(const DirectParams& a) {
     return w;
 }
 
-template <int KS, int CI, int CO>
-__global__ void __launch_bounds__(256) conv_direct2_kernel(const DirectParams a) {
+template <int KS, int CI, int CO, bool PLAIN>
+__global__ void __launch_bounds__(256) conv_direct2_kernel(const DirectParams a_) {
+    // PLAIN: bias (+ ReLU) only, plain input view, output without depth_to_space.  The KK * CI * CO filter values live in scalar
+    // registers; with the residual / mask / accumulate views and the input's channel affine live across the tile loop as well the
+    // kernels spill scalar registers into vector lanes (v_readlane before the FMAs that use them); nulled at compile time the
+    // 1 -> 1 layer has none left (0.117 -> 0.069 ms for two launches at 64 x 512^2).  The 72-value filters of 8 -> 1 / 1 -> 8 still
+    // spill ~40; reading them with just-in-time scalar loads (constant address space, pointer made opaque per tile) and four
+    // blocks per CU were measured: no change -- those two wait on HBM, not on issue slots.
+    DirectParams a = a_;
+    if constexpr (PLAIN) {
+        a.add.p = nullptr; a.mask.p = nullptr; a.accumulate = 0; a.in.sc = nullptr; a.in.sh = nullptr;
+        a.out.d2s = 1; a.in.d2s = 1;
+    }
     typedef Stager2<CI> ST;
     constexpr int HWD = ST::HWD, HPIX = ST::HPIX, VEC = ST::VEC, NPL = ST::NPL;
     constexpr int KK = KS * KS, NWT = KK * CI * CO;
@@ -820,11 +842,13 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
         static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;
         p.xcd = no_xcd ? 0 : 1;
     }
+    static const bool no_plain = getenv("DL4DS_DIRECT_NO_PLAIN") != nullptr;      // (A/B)
+    const bool plain = !wgrad && !no_plain && !p.add.p && !p.mask.p && !p.accumulate && !p.in.sc && p.out.d2s <= 1 && p.in.d2s <= 1;
     // persistent kernels: one residency round (blocks do equal work); exact_grid: per-image slabs need exactly that many blocks
     int blocks = max_blocks;
     if (!exact_grid) {
-        const int resident = gen2 ? (wgrad ? resident_blocks<conv_direct2_wgrad_kernel<KS, CI, CO>>(256) : resident_blocks<conv_direct2_kernel<KS, CI, CO>>(256))
-                                  : (wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256) : resident_blocks<conv_direct_kernel<KS, CI, CO>>(256));
+        const int resident = gen2 ? (wgrad ? resident_blocks<conv_direct2_wgrad_kernel<KS, CI, CO>>(256) : (plain ? resident_blocks<conv_direct2_kernel<KS, CI, CO, true>>(256) : resident_blocks<conv_direct2_kernel<KS, CI, CO, false>>(256)))
+                                  : (wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256) : (plain ? resident_blocks<conv_direct_kernel<KS, CI, CO, true>>(256) : resident_blocks<conv_direct_kernel<KS, CI, CO, false>>(256)));
         blocks = std::max(1, std::min(std::min(max_blocks, resident), p.ntiles));
         if (gen2 && blocks >= 8) blocks &= ~7;
     }
@@ -836,10 +860,12 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
                  4.0 * px * (p.Cin + p.Cout * (wgrad ? 1 : 1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))));
     if (gen2) {
         if (wgrad) DL4DS_LAUNCH((conv_direct2_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
-        else DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        else if (plain) DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO, true>), dim3(blocks), dim3(256), 0, s, p);
+        else DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO, false>), dim3(blocks), dim3(256), 0, s, p);
     } else {
         if (wgrad) DL4DS_LAUNCH((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
-        else DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
+        else if (plain) DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO, true>), dim3(blocks), dim3(256), 0, s, p);
+        else DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO, false>), dim3(blocks), dim3(256), 0, s, p);
     }
     HIP_CHECK(hipGetLastError());
     return blocks;
