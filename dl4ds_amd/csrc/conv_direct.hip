@@ -176,7 +176,7 @@ struct TileStager {
     }
 };
 
-template <int KS, int CI, int CO, bool PLAIN>
+template <int KS, int CI, int CO, int PLAIN>
 __global__ void __launch_bounds__(256) conv_direct_kernel(const DirectParams a_) {
     // PLAIN: bias (+ ReLU) only, plain input view, output without depth_to_space.  The KK * CI * CO filter values live in scalar
     // registers; with the residual / mask / accumulate views and the input's channel affine live across the tile loop as well the
@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const DirectParams a_)
     // blocks per CU were measured: no change -- those two wait on HBM, not on issue slots.
     DirectParams a = a_;
     if constexpr (PLAIN) {
-        a.add.p = nullptr; a.mask.p = nullptr; a.accumulate = 0; a.in.sc = nullptr; a.in.sh = nullptr;
+        a.add.p = nullptr; a.mask.p = nullptr; a.accumulate = 0;
+        if constexpr (PLAIN == 1) { a.in.sc = nullptr; a.in.sh = nullptr; }      // (2: the input view keeps its channel affine)
         a.out.d2s = 1; a.in.d2s = 1;
     }
     constexpr int HWD = DTX + KS - 1, HHT = DTY + KS - 1, HPIX = HWD * HHT;
@@ -420,6 +421,7 @@ struct Stager2 {
     int soff[ITERS], hyx[ITERS], sig;
     int r[ITERS][VEC];
     unsigned inside;                     // (channel affine: which elements of `r` lie inside the image)
+    float4 aff_s, aff_h;                 // (channel affine of the requested tile's image, this thread's channel quad)
     __device__ __forceinline__ int rel(const TView& v, int hy, int hx, int pl) const {
         return (int)((((size_t)hy * v.W + hx) * v.ld + pl * 4) * 4);
     }
@@ -468,13 +470,18 @@ struct Stager2 {
                 r[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, soff[u], 0, 0);
             }
         }
+        // the view's channel affine for this tile's image travels with the tile: requested here, behind the tile's loads (vector
+        // memory returns in order), it is there when put() needs it.  Requested in put() every tile waited a full memory round
+        // trip for it (8 -> 1 behind ChannelAttention2D: 0.164 ms in the step against 0.116 ms for the same layer without affine)
+        if constexpr (VEC == 4) {
+            if (v.sc) view_affine4(v, n, (tid % NPL) * 4, aff_s, aff_h);
+        }
     }
     // the requested halo -> LDS planes [pl][halo pixel][VEC]; the channel affine of the view (image n_of_tile) on the way
     __device__ __forceinline__ void put(const TView& v, int n_of_tile, int tid, float* __restrict__ tile) {
         if constexpr (VEC == 4) {
             if (v.sc) {
-                float4 s4, h4;
-                view_affine4(v, n_of_tile, (tid % NPL) * 4, s4, h4);
+                const float4 s4 = aff_s, h4 = aff_h;      // (requested by issue(), right behind the tile's loads)
 #pragma unroll
                 for (int u = 0; u < ITERS; ++u) {
                     if ((inside >> u) & 1u) {
@@ -518,7 +525,7 @@ __device__ __forceinline__ Walk2 walk2(const DirectParams& a) {
     return w;
 }
 
-template <int KS, int CI, int CO, bool PLAIN>
+template <int KS, int CI, int CO, int PLAIN>
 __global__ void __launch_bounds__(256) conv_direct2_kernel(const DirectParams a_) {
     // PLAIN: bias (+ ReLU) only, plain input view, output without depth_to_space.  The KK * CI * CO filter values live in scalar
     // registers; with the residual / mask / accumulate views and the input's channel affine live across the tile loop as well the
@@ -528,7 +535,8 @@ __global__ void __launch_bounds__(256) conv_direct2_kernel(const DirectParams a_
     // blocks per CU were measured: no change -- those two wait on HBM, not on issue slots.
     DirectParams a = a_;
     if constexpr (PLAIN) {
-        a.add.p = nullptr; a.mask.p = nullptr; a.accumulate = 0; a.in.sc = nullptr; a.in.sh = nullptr;
+        a.add.p = nullptr; a.mask.p = nullptr; a.accumulate = 0;
+        if constexpr (PLAIN == 1) { a.in.sc = nullptr; a.in.sh = nullptr; }      // (2: the input view keeps its channel affine)
         a.out.d2s = 1; a.in.d2s = 1;
     }
     typedef Stager2<CI> ST;
@@ -614,12 +622,13 @@ __global__ void __launch_bounds__(256) conv_direct2_kernel(const DirectParams a_
             for (int co = 0; co < CO; ++co) acc[i][co] = 0.f;
 #pragma unroll
         for (int rr = 0; rr < KS + 1; ++rr) {
+            const int row_off = (2 * ty + rr) * HWD + tx;
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {
                     float v[VEC];
-                    const float* src = tile + ((size_t)pl * HPIX + (2 * ty + rr) * HWD + tx + dx) * VEC;
+                    const float* src = tile + ((size_t)pl * HPIX + row_off + dx) * VEC;
                     if (VEC == 4) {
                         const float4 t4 = *reinterpret_cast<const float4*>(src);
                         v[0] = t4.x; v[1] = t4.y; v[2 % VEC] = t4.z; v[3 % VEC] = t4.w;
@@ -834,7 +843,11 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
     DirectParams p = p0;
     // forward with more than two outputs per pixel stays on the first generation (1 -> 8 at 64 x 512^2: 0.196 ms there, 0.229 here:
     // 142 registers against 45 and the layer is bound by its stores); every weight gradient measured is faster here
-    const bool gen2 = direct2_ok(p, CI) && (wgrad || CO <= 2);
+    static const bool no_plain = getenv("DL4DS_DIRECT_NO_PLAIN") != nullptr;      // (A/B)
+    const int plain = (!wgrad && !no_plain && !p.add.p && !p.mask.p && !p.accumulate && p.out.d2s <= 1 && p.in.d2s <= 1) ? (p.in.sc ? 2 : 1) : 0;
+    static const bool no_wide2 = getenv("DL4DS_DIRECT2_NO_WIDE") != nullptr;      // (A/B)
+    // ... but in the PLAIN form (no epilogue operands to hold) the second generation wins there too: 1 -> 8 0.218 -> 0.171 ms
+    const bool gen2 = direct2_ok(p, CI) && (wgrad || CO <= 2 || (plain == 1 && !no_wide2));
     if (gen2) {
         p.tiles_y = cdiv(p.H, D2Y);
         p.ntiles = p.tiles_x * p.tiles_y * p.in.N;
@@ -842,13 +855,11 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
         static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;
         p.xcd = no_xcd ? 0 : 1;
     }
-    static const bool no_plain = getenv("DL4DS_DIRECT_NO_PLAIN") != nullptr;      // (A/B)
-    const bool plain = !wgrad && !no_plain && !p.add.p && !p.mask.p && !p.accumulate && !p.in.sc && p.out.d2s <= 1 && p.in.d2s <= 1;
     // persistent kernels: one residency round (blocks do equal work); exact_grid: per-image slabs need exactly that many blocks
     int blocks = max_blocks;
     if (!exact_grid) {
-        const int resident = gen2 ? (wgrad ? resident_blocks<conv_direct2_wgrad_kernel<KS, CI, CO>>(256) : (plain ? resident_blocks<conv_direct2_kernel<KS, CI, CO, true>>(256) : resident_blocks<conv_direct2_kernel<KS, CI, CO, false>>(256)))
-                                  : (wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256) : (plain ? resident_blocks<conv_direct_kernel<KS, CI, CO, true>>(256) : resident_blocks<conv_direct_kernel<KS, CI, CO, false>>(256)));
+        const int resident = gen2 ? (wgrad ? resident_blocks<conv_direct2_wgrad_kernel<KS, CI, CO>>(256) : (plain == 2 ? resident_blocks<conv_direct2_kernel<KS, CI, CO, 2>>(256) : plain ? resident_blocks<conv_direct2_kernel<KS, CI, CO, 1>>(256) : resident_blocks<conv_direct2_kernel<KS, CI, CO, 0>>(256)))
+                                  : (wgrad ? resident_blocks<conv_direct_wgrad_kernel<KS, CI, CO>>(256) : (plain == 2 ? resident_blocks<conv_direct_kernel<KS, CI, CO, 2>>(256) : plain ? resident_blocks<conv_direct_kernel<KS, CI, CO, 1>>(256) : resident_blocks<conv_direct_kernel<KS, CI, CO, 0>>(256)));
         blocks = std::max(1, std::min(std::min(max_blocks, resident), p.ntiles));
         if (gen2 && blocks >= 8) blocks &= ~7;
     }
@@ -860,12 +871,14 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
                  4.0 * px * (p.Cin + p.Cout * (wgrad ? 1 : 1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))));
     if (gen2) {
         if (wgrad) DL4DS_LAUNCH((conv_direct2_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
-        else if (plain) DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO, true>), dim3(blocks), dim3(256), 0, s, p);
-        else DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO, false>), dim3(blocks), dim3(256), 0, s, p);
+        else if (plain == 2) DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO, 2>), dim3(blocks), dim3(256), 0, s, p);
+        else if (plain) DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO, 1>), dim3(blocks), dim3(256), 0, s, p);
+        else DL4DS_LAUNCH((conv_direct2_kernel<KS, CI, CO, 0>), dim3(blocks), dim3(256), 0, s, p);
     } else {
         if (wgrad) DL4DS_LAUNCH((conv_direct_wgrad_kernel<KS, CI, CO>), dim3(blocks), dim3(256), 0, s, p);
-        else if (plain) DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO, true>), dim3(blocks), dim3(256), 0, s, p);
-        else DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO, false>), dim3(blocks), dim3(256), 0, s, p);
+        else if (plain == 2) DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO, 2>), dim3(blocks), dim3(256), 0, s, p);
+        else if (plain) DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO, 1>), dim3(blocks), dim3(256), 0, s, p);
+        else DL4DS_LAUNCH((conv_direct_kernel<KS, CI, CO, 0>), dim3(blocks), dim3(256), 0, s, p);
     }
     HIP_CHECK(hipGetLastError());
     return blocks;
