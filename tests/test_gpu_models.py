@@ -288,6 +288,82 @@ def test_folded_upsampling_tail_equals_unfolded(monkeypatch, ups, scale, n_aux):
         assert np.abs(w1[k] - w2[k]).max() < 0.1 * 3e-3, k
 
 
+REC_TAIL_CASES = [
+    # builder, its arguments, the LR / HR grid.  HR grids of 16 x 16 = 256 points take the LDS-staged kernels (weight gradients
+    # on the matrix pipe inside the backward pass), 12 x 10 the plain ones (dz materialised, three 1x1 weight-gradient calls)
+    ('recnet_postupsampling', dict(backbone_block='densenet', upsampling='rc', scale=2, n_blocks=1), (8, 8)),      # cfg4's shape
+    ('recnet_postupsampling', dict(backbone_block='densenet', upsampling='rc', scale=2, n_blocks=1), (6, 5)),
+    ('recnet_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=2, n_blocks=1), (8, 8)),
+    ('recnet_postupsampling', dict(backbone_block='convnet', upsampling='rc', scale=2, n_blocks=1), (6, 5)),
+    ('recnet_pin', dict(backbone_block='densenet', n_blocks=1), (16, 16)),
+    ('recnet_pin', dict(backbone_block='densenet', n_blocks=1), (12, 10)),
+    ('recnet_pin', dict(backbone_block='convnet', n_blocks=1), (16, 16)),
+    ('recnet_pin', dict(backbone_block='resnet', n_blocks=1), (12, 10)),
+]
+
+
+@pytest.mark.parametrize('kind,kw,grid', REC_TAIL_CASES)
+def test_recurrent_tail_as_one_op_equals_the_separate_layers(monkeypatch, kind, kw, grid):
+    """[x, repeat(ConvBlock_aux(s)), LocalizedConvBlock(..)] -> TransitionLast as ONE op per direction (csrc/graph_ops4.hip,
+    RecTailOp: spt_postups.py:133-151 / spt_preups.py:114-132) against the same model built with DL4DS_NO_REC_TAIL_FUSION=1
+    (repeat_time, two Concatenates, 1x1 conv, LocallyConnected2D, 1x1 conv): same variables; forward output, loss, every
+    gradient and the weights after three Adam steps agree to fp32 rounding.  Covers every channel combination that is built
+    (REC_TAIL_SHAPES) in both kernel forms, and two batch sizes on one graph (the ConvLSTM tile flags are never reset)."""
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import SupervisedEngine
+    T_, B = 3, 2
+    h, w = grid
+    if kind == 'recnet_postupsampling':
+        cfg = dict(n_channels=2, n_aux_channels=2, lr_size=(h, w), time_window=T_, n_filters=8, attention=True,
+                   localcon_layer=True, seed=7, **kw)
+        H, W = h * kw['scale'], w * kw['scale']
+        build = PM.recnet_postupsampling
+        xs = (B, T_, h, w, 2)
+    else:
+        cfg = dict(n_channels=2, n_aux_channels=2, hr_size=(h, w), time_window=T_, n_filters=8, localcon_layer=True, seed=7, **kw)
+        H, W = h, w
+        build = PM.recnet_pin
+        xs = (B, T_, h, w, 2)
+    monkeypatch.delenv('DL4DS_NO_REC_TAIL_FUSION', raising=False)
+    fused = build(**cfg)
+    monkeypatch.setenv('DL4DS_NO_REC_TAIL_FUSION', '1')
+    plain = build(**cfg)
+    monkeypatch.delenv('DL4DS_NO_REC_TAIL_FUSION')
+    assert any(k == 'rec_tail' for k, _, _ in fused.graph.layers), [k for k, _, _ in fused.graph.layers]
+    assert not any(k == 'rec_tail' for k, _, _ in plain.graph.layers)
+    rng = np.random.default_rng(11)
+    wts = plain.get_weights()
+    assert sorted(wts) == sorted(fused.get_weights())
+    for k in wts:
+        if k.endswith('bias'):
+            wts[k] = (rng.standard_normal(wts[k].shape) * 0.1).astype(np.float32)
+    plain.set_weights(wts); fused.set_weights(wts)
+    x = rng.standard_normal(xs).astype(np.float32)
+    s = rng.standard_normal((B, H, W, 2)).astype(np.float32)
+    y = rng.standard_normal((B, T_, H, W, 1)).astype(np.float32)
+    assert rel(fused([x, s]), plain([x, s])) < 2e-5
+    e1, e2 = SupervisedEngine(fused, loss='mse', learning_rate=1e-3), SupervisedEngine(plain, loss='mse', learning_rate=1e-3)
+    l1, g1 = e1.loss_and_grads([x, s], y)
+    l2, g2 = e2.loss_and_grads([x, s], y)
+    assert l1 == pytest.approx(l2, rel=1e-5)
+    assert_grads_close(g1, g2, tol=1e-4, what='rec_tail vs separate layers')
+    # a smaller batch on the same graph, then the first one again: identical results (nothing stale in the op's buffers)
+    l1h, g1h = e1.loss_and_grads([x[:1], s[:1]], y[:1])
+    l2h, g2h = e2.loss_and_grads([x[:1], s[:1]], y[:1])
+    assert l1h == pytest.approx(l2h, rel=1e-5)
+    assert_grads_close(g1h, g2h, tol=1e-4, what='rec_tail vs separate layers, B = 1')
+    l1b, g1b = e1.loss_and_grads([x, s], y)
+    assert l1b == l1
+    for k in g1:
+        assert np.array_equal(g1[k], g1b[k]), k
+    for _ in range(3):
+        a, b = e1.step([x, s], y), e2.step([x, s], y)
+        assert a == pytest.approx(b, rel=1e-4)
+    w1, w2 = fused.get_weights(), plain.get_weights()
+    for k in w1:
+        assert np.abs(w1[k] - w2[k]).max() < 0.1 * 3e-3, k
+
+
 def test_cfg2_parameter_count_and_name():
     import dl4ds_amd.models as PM
     m = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (16, 16))
