@@ -38,6 +38,10 @@ constexpr int RSRC3 = 0x00020000;
 typedef const float __attribute__((address_space(4))) * cfloat_p;
 __device__ __forceinline__ cfloat_p uniform_ro(const float* p) { return (cfloat_p)p; }
 
+// (inside the frame loop: the filter pointer made opaque per frame, so that the scalar loads stay next to their uses instead of
+//  being hoisted out of the loop and spilled -- 200+ scalar registers parked in vector lanes, a v_readlane per use)
+#define REC_TAIL_OPAQUE(p_) asm volatile("" : "+s"(p_))
+
 struct TailParams {
     const float *x, *s, *wt, *bt, *wl, *bl, *w, *b;
     float *y, *u, *lws;
@@ -73,7 +77,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
 // indices: scalar loads, used straight as FMA operands.
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
-    const cfloat_p wt_ = uniform_ro(a.wt), bt_ = uniform_ro(a.bt), w_ = uniform_ro(a.w), b_ = uniform_ro(a.b);
+    cfloat_p wt_ = uniform_ro(a.wt), bt_ = uniform_ro(a.bt), w_ = uniform_ro(a.w), b_ = uniform_ro(a.b);
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= (size_t)a.B * a.HW) return;
     const int bi = (int)(p / a.HW), hw = (int)(p - (size_t)bi * a.HW);
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
 // 64-byte segments per lane quad and ran at 2.4 TB/s).  The next frame's loads are in flight during the arithmetic.
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_fwd_staged_kernel(const TailParams a) {
-    const cfloat_p wt_ = uniform_ro(a.wt), bt_ = uniform_ro(a.bt), w_ = uniform_ro(a.w), b_ = uniform_ro(a.b);
+    cfloat_p wt_ = uniform_ro(a.wt), bt_ = uniform_ro(a.bt), w_ = uniform_ro(a.w), b_ = uniform_ro(a.b);
     constexpr int XQ = CX / 4, XP = CX + 4, NY4 = 256 * CO / 4, YIT = (NY4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float xs[256 * XP];
     __shared__ __attribute__((aligned(16))) float ys[256 * CO];
@@ -172,6 +176,7 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_staged_kernel(const TailPara
         }
         __syncthreads();
         if (t + 1 < a.T) fetch(t + 1);
+        REC_TAIL_OPAQUE(wt_); REC_TAIL_OPAQUE(w_);
         float xv[CX];
 #pragma unroll
         for (int q = 0; q < CX; q += 4) {
@@ -214,7 +219,7 @@ struct TailBwdParams {
 
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a) {
-    const cfloat_p wt_ = uniform_ro(a.wt), w_ = uniform_ro(a.w);
+    cfloat_p wt_ = uniform_ro(a.wt), w_ = uniform_ro(a.w);
     constexpr int CZ = CO + 2;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= (size_t)a.B * a.HW) return;
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
 constexpr int REC_TAIL_WTILE = 512;
 template <int CX, int CS, int CO>
 __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdParams a) {
-    const cfloat_p wt_ = uniform_ro(a.wt), w_ = uniform_ro(a.w);
+    cfloat_p wt_ = uniform_ro(a.wt), w_ = uniform_ro(a.w);
     constexpr int CZ = CO + 2, XQ = CX / 4, XP = CX + 4, AP = CS + 4;
     static_assert(CZ <= 16 && CX <= 16 && CS + 3 <= 16 && 4 * REC_TAIL_WTILE <= 256 * CO, "rec_tail: tile shapes");
     constexpr int NR4 = 256 * CO / 4, RIT = (NR4 + 255) / 256;       // float4 per block row-stream of a CO-channel tensor
@@ -373,6 +378,7 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_staged_kernel(const TailBwdP
         *reinterpret_cast<float2*>(auxs + tid * AP + CS) = lw;
         __syncthreads();
         if (t + 1 < a.T) fetch(t + 1);
+        REC_TAIL_OPAQUE(wt_); REC_TAIL_OPAQUE(w_);
         float z[CZ];
 #pragma unroll
         for (int o = 0; o < CO; ++o) z[o] = dys[tid * CO + o];
