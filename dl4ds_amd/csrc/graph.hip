@@ -898,6 +898,7 @@ struct ResizeOp : GOp {
     int method = 0, ky = 4, kx = 4;             // 0 bilinear 1 nearest 2 bicubic 3 lanczos3 4 lanczos5 5 gaussian 6 mitchellcubic
     // table-driven: forward tables [out][k] and their transpose as CSR over the input index, on the device
     int *d_iy = nullptr, *d_ix = nullptr, *d_py = nullptr, *d_oy = nullptr, *d_px = nullptr, *d_ox = nullptr;
+    int max_back_x = 0;          // most output columns any input column feeds (the backward gather's row length)
     float *d_wy = nullptr, *d_wx = nullptr, *d_vy = nullptr, *d_vx = nullptr;
     ResizeOp() { kind = "resize"; }
     ~ResizeOp() override {
@@ -912,7 +913,7 @@ struct ResizeOp : GOp {
         if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
         return d;
     }
-    int axis(int in_size, int out_size, int*& d_i, float*& d_w, int*& d_p, int*& d_o, float*& d_v) const {
+    int axis(int in_size, int out_size, int*& d_i, float*& d_w, int*& d_p, int*& d_o, float*& d_v, int& max_back) const {
         std::vector<int> idx;
         std::vector<float> w;
         int K = 4;
@@ -929,14 +930,17 @@ struct ResizeOp : GOp {
         for (int i = 0; i < in_size; ++i) {
             for (auto& pr : cols[i]) { oo.push_back(pr.first); vv.push_back(pr.second); }
             ptr[i + 1] = (int)oo.size();
+            max_back = std::max(max_back, (int)cols[i].size());
         }
         d_i = upload(idx); d_w = upload(w); d_p = upload(ptr); d_o = upload(oo); d_v = upload(vv);
         return K;
     }
     void on_finalize(Graph& g) override {
         if (!bicubic) return;
-        ky = axis(g.tensors[in].H, g.tensors[out].H, d_iy, d_wy, d_py, d_oy, d_vy);
-        kx = axis(g.tensors[in].W, g.tensors[out].W, d_ix, d_wx, d_px, d_ox, d_vx);
+        int my = 0;
+        max_back_x = 0;
+        ky = axis(g.tensors[in].H, g.tensors[out].H, d_iy, d_wy, d_py, d_oy, d_vy, my);
+        kx = axis(g.tensors[in].W, g.tensors[out].W, d_ix, d_wx, d_px, d_ox, d_vx, max_back_x);
     }
     void forward(Graph& g, int B, bool) override {
         if (bicubic) resize_table_forward(g.stream, g.view(in, B, false), g.view(out, B, false), d_iy, d_wy, d_ix, d_wx, ky, kx);
@@ -947,7 +951,7 @@ struct ResizeOp : GOp {
         if (!g.tensors[out].grad_written || !wants_grad(g, in, c)) return;
         if (bicubic)
             resize_table_backward(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt), g.view(in, c.B, true, c.b_off, c.b_cnt), d_py, d_oy,
-                                  d_vy, d_px, d_ox, d_vx, g.tensors[in].grad_written);
+                                  d_vy, d_px, d_ox, d_vx, g.tensors[in].grad_written, max_back_x);
         else
             (nearest ? resize_nearest_backward : resize_bilinear_backward)(g.stream, g.view(out, c.B, true, c.b_off, c.b_cnt),
                                      g.view(in, c.B, true, c.b_off, c.b_cnt), g.tensors[in].grad_written);

@@ -193,4 +193,4 @@ void repeat_time_backward_view(hipStream_t s, const TView& dout, float* din, int
 void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const int* iy, const float* wy, const int* ix, const float* wx,
                           int ky, int kx);   // [out][k] taps per axis
 void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, const int* py, const int* oy, const float* vy,
-                           const int* px, const int* ox, const float* vx, int accumulate);
+                           const int* px, const int* ox, const float* vx, int accumulate, int max_taps_x = 0);
