@@ -975,35 +975,41 @@ __global__ void resize_table_fwd4_kernel(TView x, TView y, const int* __restrict
 template <int K>
 __global__ void resize_table_fwdk_kernel(const float* __restrict__ xp, float* __restrict__ yp, int Hi, int Wi, int Ho, int Wo, int C,
                                          const int* __restrict__ iy, const float* __restrict__ wy, const int* __restrict__ ix,
-                                         const float* __restrict__ wx, size_t total4) {
-    const int C4 = C >> 2;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
-        const unsigned e32 = (unsigned)e;
-        unsigned r = e32 / (unsigned)C4;
-        const int c = (int)(e32 - r * (unsigned)C4) * 4;
-        const unsigned r1 = r / (unsigned)Wo;
-        const int xo = (int)(r - r1 * (unsigned)Wo);
-        const int n = (int)(r1 / (unsigned)Ho);
-        const int yo = (int)(r1 - (unsigned)n * (unsigned)Ho);
-        int sy[K], sx[K];
-        float fy[K], fx[K];
+                                         const float* __restrict__ wx, int rows, unsigned m_c4) {
+    // a block takes whole output rows: image, output row and the row taps are wave-uniform (scalar), a thread only splits its
+    // position in the row into (column, channel quad) -- the flat form spent three run-time integer divisions per float4 and was
+    // bound by them (0.20 ms for cfg4's 537 MB output, 2.8 TB/s)
+    const int C4 = C >> 2, per_row = Wo * C4;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / Ho, yo = row - n * Ho;
+        int sy[K];
+        float fy[K];
 #pragma unroll
-        for (int a = 0; a < K; ++a) { sy[a] = iy[yo * K + a]; fy[a] = wy[yo * K + a]; sx[a] = ix[xo * K + a]; fx[a] = wx[xo * K + a]; }
-        const float* img = xp + (size_t)n * Hi * Wi * C + c;
-        float4 v[K][K];
+        for (int a = 0; a < K; ++a) { sy[a] = iy[yo * K + a]; fy[a] = wy[yo * K + a]; }
+        const float* img = xp + (size_t)n * Hi * Wi * C;
+        float* out = yp + (size_t)row * per_row * 4;
+        for (int e = threadIdx.x; e < per_row; e += blockDim.x) {
+            const int xo = fast_div(e, m_c4);
+            const int c = (e - xo * C4) * 4;
+            int sx[K];
+            float fx[K];
 #pragma unroll
-        for (int a = 0; a < K; ++a)
+            for (int b = 0; b < K; ++b) { sx[b] = ix[xo * K + b]; fx[b] = wx[xo * K + b]; }
+            float4 v[K][K];
 #pragma unroll
-            for (int b = 0; b < K; ++b) v[a][b] = *reinterpret_cast<const float4*>(img + ((size_t)sy[a] * Wi + sx[b]) * C);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int a = 0; a < K; ++a)
 #pragma unroll
-        for (int a = 0; a < K; ++a) {                  // (the generic kernel's order of operations)
-            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int b = 0; b < K; ++b) v[a][b] = *reinterpret_cast<const float4*>(img + ((size_t)sy[a] * Wi + sx[b]) * C + c);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int b = 0; b < K; ++b) { row.x += fx[b] * v[a][b].x; row.y += fx[b] * v[a][b].y; row.z += fx[b] * v[a][b].z; row.w += fx[b] * v[a][b].w; }
-            acc.x += fy[a] * row.x; acc.y += fy[a] * row.y; acc.z += fy[a] * row.z; acc.w += fy[a] * row.w;
+            for (int a = 0; a < K; ++a) {                  // (the generic kernel's order of operations)
+                float4 rowv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < K; ++b) { rowv.x += fx[b] * v[a][b].x; rowv.y += fx[b] * v[a][b].y; rowv.z += fx[b] * v[a][b].z; rowv.w += fx[b] * v[a][b].w; }
+                acc.x += fy[a] * rowv.x; acc.y += fy[a] * rowv.y; acc.z += fy[a] * rowv.z; acc.w += fy[a] * rowv.w;
+            }
+            *reinterpret_cast<float4*>(out + (size_t)e * 4) = acc;
         }
-        *reinterpret_cast<float4*>(yp + e * 4) = acc;
     }
 }
 __global__ void resize_table_bwd4_kernel(TView dy, TView dx, const int* __restrict__ py, const int* __restrict__ oy,
@@ -1084,10 +1090,14 @@ void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const i
                           int ky, int kx) {
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     auto dense = [](const TView& v) { return v.d2s <= 1 && v.ld == v.C && v.nstride == (size_t)v.H * v.W * v.C && v.vec; };
-    if (dense(x) && dense(y) && !x.sc && ky == kx && (ky == 2 || ky == 4) && total / 4 < (1ull << 32) && !getenv("DL4DS_NO_RESIZE_FWDK")) {
+    const size_t rows = (size_t)y.N * y.H, per_row4 = (size_t)y.W * (y.C >> 2);
+    if (dense(x) && dense(y) && !x.sc && ky == kx && (ky == 2 || ky == 4) && rows < (1ull << 31) && per_row4 < (1u << 20) && (y.C >> 2) <= 4096 &&
+        !getenv("DL4DS_NO_RESIZE_FWDK")) {
         ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
         auto kern = ky == 2 ? resize_table_fwdk_kernel<2> : resize_table_fwdk_kernel<4>;
-        DL4DS_LAUNCH(kern, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x.p, y.p, x.H, x.W, y.H, y.W, y.C, iy, wy, ix, wx, total / 4);
+        const int threads = per_row4 >= 256 ? 256 : 64;
+        DL4DS_LAUNCH(kern, dim3((unsigned)std::min<size_t>(rows, 65536)), dim3(threads), 0, s, x.p, y.p, x.H, x.W, y.H, y.W, y.C, iy, wy, ix, wx,
+                     (int)rows, div_magic(y.C >> 2));
         HIP_CHECK(hipGetLastError());
         return;
     }
