@@ -45,6 +45,7 @@ int cu_count() {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 using gu32 = __attribute__((address_space(1))) unsigned;
+using gu64 = __attribute__((address_space(1))) unsigned long long;
 
 __device__ __forceinline__ float hsig(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float dhsig(float z) { return (z >= -2.5f && z <= 2.5f) ? 0.2f : 0.f; }
@@ -88,8 +89,8 @@ struct SeqParams {
     const float* dout;     // backward: gradient of out
     float* dZ;             // backward out: (B,T,H,W,4F) interleaved
     float* dc;             // backward scratch: (B,H,W,F) running dL/dc
-    unsigned* flags;       // [tiles]: epoch + steps completed by each tile (never reset: see seq_epoch)
-    unsigned epoch;        // this launch's base value: everything an earlier launch left in `flags` is below it
+    unsigned* flags;       // [tiles] 64-bit words: epoch + steps completed by each tile (never reset: see seq_epoch)
+    unsigned long long epoch;        // this launch's base value: everything an earlier launch left in `flags` is below it
     unsigned* err;         // host-visible sticky error word (runtime.h): set when a spin gives up
     int B, T, H, W, tiles_x, tiles_y, ntiles, relu, tr;
     unsigned long long* trace;   // DL4DS_SEQ_TRACE: [block][8] phase times (100 MHz wall clock), null otherwise
@@ -122,10 +123,10 @@ __device__ __forceinline__ void wait_neighbours(const SeqParams& p, int tile, un
         const int ty = loc / p.tiles_x, tx = loc - ty * p.tiles_x;
         const int yy = ty + (int)threadIdx.x / 3 - 1, xx = tx + (int)threadIdx.x % 3 - 1;
         if (threadIdx.x != 4 && yy >= 0 && xx >= 0 && yy < p.tiles_y && xx < p.tiles_x) {
-            gu32* f = (gu32*)(p.flags + img * tpi + yy * p.tiles_x + xx);
+            gu64* f = (gu64*)p.flags + (img * tpi + yy * p.tiles_x + xx);
             unsigned spins = 0;
-            const unsigned want = p.epoch + need;                 // (wrap-safe comparison: the counter is a 32-bit running sum)
-            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 && ++spins < SPIN_LIMIT)
+            const unsigned long long want = p.epoch + need;       // (64-bit running sum: never wraps, a zeroed slab reads as "nothing done")
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < SPIN_LIMIT)
                 __builtin_amdgcn_s_sleep(1);
             // gave up: the halo this tile stages next is stale.  Say so where the host looks after every sync (device_error_check):
             // the step must not pass for a valid one.
@@ -138,7 +139,7 @@ __device__ __forceinline__ void wait_neighbours(const SeqParams& p, int tile, un
 __device__ __forceinline__ void publish(const SeqParams& p, int tile, unsigned done) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains its (sc1) stores
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store((gu32*)(p.flags + tile), p.epoch + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store((gu64*)p.flags + tile, p.epoch + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // stage the (TY x TW) halo tile of a frame (pixel pitch CIN floats, zero outside the image) as [y][x][Geom::PITCH], sc1 loads
@@ -628,12 +629,13 @@ static int seq_tr(int H, int W, int B, bool backward) {
 
 // Flags are never zeroed between launches (two memset nodes per layer and step were 30 dispatches of a cfg4 step): a launch
 // publishes `epoch + steps done` (1 <= steps <= T) and waits for `epoch + needed`; the epoch is a process-wide running sum of
-// T + 1 per launch, so whatever an earlier launch -- of any layer, tiling or direction -- left in a flag word is <= the new
+// T + 1 per launch (64 bits: a 32-bit sum would pass 2^31 after a day and a half of cfg4 steps, and a freshly zeroed slab
+// would then compare as ahead), so whatever an earlier launch -- of any layer, tiling or direction -- left in a flag word is <= the new
 // epoch and reads as "nothing done yet".  A freshly allocated slab is zeroed (Graph::prepare).
-static unsigned seq_epoch(int T) {
-    static unsigned next = 1;
-    const unsigned e = next;
-    next += (unsigned)T + 1;
+static unsigned long long seq_epoch(int T) {
+    static unsigned long long next = 1;
+    const unsigned long long e = next;
+    next += (unsigned long long)T + 1;
     return e;
 }
 
@@ -650,7 +652,7 @@ static SeqParams seq_params(const float* U, float* Z, float* C, float* Hrec, flo
     return p;
 }
 
-size_t convlstm_seq_flag_bytes(int H, int W, int B) { return (size_t)cdiv(H, 8) * cdiv(W, 16) * B * sizeof(unsigned); }
+size_t convlstm_seq_flag_bytes(int H, int W, int B) { return (size_t)cdiv(H, 8) * cdiv(W, 16) * B * sizeof(unsigned long long); }
 
 void convlstm_seq_forward(hipStream_t s, const float* U_il, float* Z_il, float* C, float* Hrec, float* out, unsigned* flags,
                           int B, int T, int H, int W, int KS, int F, int relu) {

@@ -92,8 +92,10 @@ struct ConvLSTMOp : GOp {
         g.add_wt_job(g.params[wr].offset, false, wt_r, KS * KS, F, 4 * F);
     }
     size_t hw(Graph& g) { return (size_t)g.tensors[in].H * g.tensors[in].W; }
+    // floats per sample reserved for the recurrence's tile flags (64-bit words, one per 8 x 16 tile of the finest tiling)
+    size_t flag_quota(Graph& g) { return 2 * (size_t)cdiv(g.tensors[in].H, 8) * cdiv(g.tensors[in].W, 16) + 64; }
     size_t scratch_floats(Graph& g) {       // dK', dU', db' (interleaved weight gradients) + the tile flags of one launch
-        return (size_t)KS * KS * (cin(g) + F) * 4 * F + 4 * F + 64 + hw(g) / 64 + 64;
+        return (size_t)KS * KS * (cin(g) + F) * 4 * F + 4 * F + 64 + flag_quota(g);
     }
     size_t saved_floats_per_sample(Graph& g) override {
         return (size_t)T * hw(g) * (4 * F + F + F + 4 * F) + 2 * hw(g) * F + (seq ? scratch_floats(g) : 0);
@@ -112,7 +114,7 @@ struct ConvLSTMOp : GOp {
         Bufs r;
         // the tile flags come FIRST and at the size of the slab's largest batch: they are never reset (convlstm_seq.hip:
         // seq_epoch), so no other buffer of any batch size may ever overlay them
-        const size_t flag_floats = ((size_t)(hw(g) / 64 + 64) * g.maxB + 63) & ~(size_t)63;
+        const size_t flag_floats = (flag_quota(g) * g.maxB + 63) & ~(size_t)63;
         r.flags = reinterpret_cast<unsigned*>(saved);
         r.Z = saved + (seq ? flag_floats : 0); r.C = r.Z + n * 4 * F; r.H = r.C + n * F; r.dZ = r.H + n * F;
         r.dh = r.dZ + n * 4 * F; r.dc = r.dh + (size_t)B * hw(g) * F;
@@ -136,7 +138,7 @@ struct ConvLSTMOp : GOp {
         // (the one-launch recurrence writes that zero frame itself)
         if (!seq) HIP_CHECK(hipMemset2DAsync(bf.H, (size_t)T * hw(g) * F * sizeof(float), 0, hw(g) * F * sizeof(float), (size_t)B, g.stream));
         if (seq) {
-            DL4DS_REQUIRE(convlstm_seq_flag_bytes(ti.H, ti.W, B) <= (hw(g) / 64 + 64) * sizeof(float) * (size_t)B && B <= g.maxB, "convlstm: flag area");
+            DL4DS_REQUIRE(convlstm_seq_flag_bytes(ti.H, ti.W, B) <= flag_quota(g) * sizeof(float) * (size_t)B && B <= g.maxB, "convlstm: flag area");
             float *Kp = g.Wt + wt_kp, *Up = g.Wt + wt_up, *bp = g.Wt + wt_bp;
             {   // kernel, recurrent kernel and bias into the interleaved gate order: one launch
                 const float* src[3] = {g.wp(wk), g.wp(wr), g.wp(b)};
