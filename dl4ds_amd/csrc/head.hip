@@ -68,7 +68,15 @@ __global__ void gap_finish_kernel(const float* __restrict__ partial, float* __re
     if (e >= total) return;
     const int n = e / C, c = e - n * C;
     double a = 0.0;
-    for (int k = 0; k < nchunks; ++k) a += (double)partial[((size_t)n * nchunks + k) * C + c];
+    int k = 0;
+    for (; k + 8 <= nchunks; k += 8) {          // (eight loads in flight, added in the order of k)
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = partial[((size_t)n * nchunks + k + u) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (double)t[u];
+    }
+    for (; k < nchunks; ++k) a += (double)partial[((size_t)n * nchunks + k) * C + c];
     out[e] = (float)(a * (double)inv);
 }
 
