@@ -239,17 +239,18 @@ def _fwd_close(out, ref, tol=1e-3):
     return err
 
 
-SLACK_LIMIT = 0.01         # band + noise floor the oracle may grant a tensor, as a fraction of the tensor's own size
+SLACK_LIMIT = 0.01         # largest band + noise floor the oracle may GRANT any entry of a tensor, as a fraction of the tensor's own size
 PLAIN_FRACTION = 0.95      # share of the tensors that must pass on north_star's 1e-3 (+ the ulp floor) ALONE
 
 
 def _slack_is_small(rows, limit=SLACK_LIMIT):
-    """``rows`` = tests.parity.assert_matches_reference's per-tensor breakdown.  Two statements about the evidence itself:
-    (1) at least PLAIN_FRACTION of the tensors pass on tol = 1e-3 + the ulp floor alone, without band or noise
+    """``rows`` = tests.parity.assert_matches_reference's per-tensor breakdown (which has already asserted the per-element
+    criterion and the element-level caps every comparison is held to: tests/parity.py).  At the BASELINE sizes two more
+    statements hold and are asserted:
+    (1) at least PLAIN_FRACTION of the TENSORS pass with every entry on tol = 1e-3 + the ulp floor alone
         (realised in round 4: 56/56 cfg2 either kernel set, 58/58 cfg4, 76/76 + 48/48 cfg5, cfg1 see the artefact);
-    (2) the discontinuity band + noise floor the oracle grants stays a correction: no tensor -- none exempted by name -- gets
-        more than ``limit`` = 1 % of its own size (realised: <= 0.11 % in cfg2 / cfg4, 0.35 % in cfg5's generator; the two
-        small-sample cases pass limit = 3 % at their call sites: cfg1 1.9 %, the CGAN discriminator at B = 4 1.6 %)."""
+    (2) the largest allowance the oracle grants ANY entry stays a correction: no tensor -- none exempted by name -- holds an entry
+        with more than ``limit`` = 1 % of the tensor's size (the two small-sample cases pass limit = 3 % at their call sites)."""
     from tests.parity import summarize
     sm = summarize(rows)
     assert sm['plain_frac'] >= PLAIN_FRACTION, f'only {sm["plain_ok"]} of {sm["n"]} tensors pass on 1e-3 alone: {sm}'

@@ -263,3 +263,71 @@ def test_resize_scale_translate_known_properties():
     for m in radius:
         np.testing.assert_allclose(T.resize_scale_translate(torch.tensor(x), 15, 8, m).numpy(),
                                    N.resize_scale_translate(x, 15, 8, m), atol=1e-12)
+
+
+# ---- third-party-PUBLISHED known answers: the numeric examples of the public TensorFlow / Keras API documentation -------------
+# The reference's arithmetic is TensorFlow's, which cannot run here (tests/golden/README.md).  The docstrings of the TF / Keras
+# functions the reference calls carry worked examples; those printed values are the only numbers available in this container
+# that were produced by TensorFlow itself and not by this repository's author.  Each is checked on BOTH oracle backends.
+def _both(fn_name, *args, **kw):
+    a = getattr(N, fn_name)(*[np.asarray(v, np.float64) if isinstance(v, (list, np.ndarray)) else v for v in args], **kw)
+    b = getattr(T, fn_name)(*[T.asarray(np.asarray(v, np.float64)) if isinstance(v, (list, np.ndarray)) else v for v in args], **kw)
+    return np.asarray(a, np.float64), np.asarray(T.to_numpy(b), np.float64)
+
+
+def test_tf_doc_hard_sigmoid():
+    """tf.keras.activations.hard_sigmoid doc (TF 2.x): hard_sigmoid([-3, -1, 0, 1, 3]) = [0, 0.3, 0.5, 0.7, 1] -- the 0.2 x + 0.5
+    form ConvLSTM2D's recurrent_activation default uses (blocks.py:350-355), NOT Keras-3's x / 6 + 0.5."""
+    for out in _both('hard_sigmoid', [-3.0, -1.0, 0.0, 1.0, 3.0]):
+        np.testing.assert_allclose(out, [0.0, 0.3, 0.5, 0.7, 1.0], atol=1e-12)
+
+
+def test_tf_doc_activations():
+    """tf.keras.activations.{gelu, tanh, sigmoid, relu} doc examples on x = [-3, -1, 0, 1, 3] (gelu: the exact erf form, the
+    approximate=False default; the tanh approximation would print -0.00363752 ... 2.9963627)."""
+    x = [-3.0, -1.0, 0.0, 1.0, 3.0]
+    want = dict(gelu=[-0.00404951, -0.15865529, 0.0, 0.8413447, 2.9959507], tanh=[-0.9950547, -0.7615942, 0.0, 0.7615942, 0.9950547],
+                relu=[0.0, 0.0, 0.0, 1.0, 3.0])
+    for k, w in want.items():
+        for out in _both('activation', x, k):
+            np.testing.assert_allclose(out, w, rtol=2e-6, atol=3e-7, err_msg=k)      # (the doc's values are fp32 prints: gelu(-3) carries
+            # the cancellation of 1 + erf(-2.12) in single precision, 1.8e-7 absolute)
+    assert abs(want['gelu'][0] - (-0.00363752)) > 1e-4            # the doc's two forms are distinguishable at this tolerance
+    for out in _both('activation', [-20.0, -1.0, 0.0, 1.0, 20.0], 'sigmoid'):      # tf.keras.activations.sigmoid doc
+        np.testing.assert_allclose(out, [2.0611535e-09, 2.6894143e-01, 5.0e-01, 7.3105860e-01, 1.0], rtol=2e-6)
+
+
+def test_tf_doc_depth_to_space():
+    """tf.nn.depth_to_space doc, block_size 2, NHWC: the three worked examples (1x1x4 -> 2x2x1, 1x1x12 -> 2x2x3, 2x2x4 -> 4x4x1)."""
+    for out in _both('depth_to_space', [[[[1, 2, 3, 4]]]], 2):
+        np.testing.assert_array_equal(out, [[[[1], [2]], [[3], [4]]]])
+    for out in _both('depth_to_space', [[[[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]]]], 2):
+        np.testing.assert_array_equal(out, [[[[1, 2, 3], [4, 5, 6]], [[7, 8, 9], [10, 11, 12]]]])
+    x = [[[[1, 2, 3, 4], [5, 6, 7, 8]], [[9, 10, 11, 12], [13, 14, 15, 16]]]]
+    want = [[[[1], [2], [5], [6]], [[3], [4], [7], [8]], [[9], [10], [13], [14]], [[11], [12], [15], [16]]]]
+    for out in _both('depth_to_space', x, 2):
+        np.testing.assert_array_equal(out, want)
+
+
+def test_tf_doc_losses():
+    """tf.keras.losses doc examples: BinaryCrossentropy()([[0, 1], [0, 0]], [[0.6, 0.4], [0.4, 0.6]]) = 0.815;
+    MeanAbsoluteError()([[0, 1], [0, 0]], [[1, 1], [1, 0]]) = 0.5; MeanSquaredError() on the same = 0.5."""
+    yt, yp = [[0.0, 1.0], [0.0, 0.0]], [[0.6, 0.4], [0.4, 0.6]]
+    for out in _both('bce', yt, yp):
+        assert float(out) == pytest.approx(0.815, abs=5e-4)
+    for fn in ('mae', 'mse'):
+        for out in _both(fn, yt, [[1.0, 1.0], [1.0, 0.0]]):
+            assert float(out) == pytest.approx(0.5, abs=1e-12), fn
+
+
+def test_tf_doc_layer_normalization_and_max_pooling():
+    """tf.keras.layers.LayerNormalization(axis=1) doc: rows of arange(10).reshape(5, 2) * 10 -> [-1, 1] each (to the eps = 1e-3
+    inside the square root: 5 / sqrt(25 + 1e-3)); tf.keras.layers.MaxPooling2D(2, strides=2, 'valid') doc:
+    [[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]] -> [[6, 8]] (floor(3 / 2) = 1 row: the odd last row is dropped)."""
+    data = (np.arange(10).reshape(5, 2) * 10.0).reshape(5, 1, 1, 2)
+    for out in _both('layer_norm', data, np.ones(2), np.zeros(2)):
+        np.testing.assert_allclose(out.reshape(5, 2), np.tile([-1.0, 1.0], (5, 1)), atol=3e-5)
+        np.testing.assert_allclose(out.reshape(5, 2)[:, 1], 5.0 / np.sqrt(25.0 + 1e-3), rtol=1e-12)
+    x = np.asarray([[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]], np.float64).reshape(1, 3, 4, 1)
+    for out in _both('max_pool2', x):
+        np.testing.assert_array_equal(out.reshape(1, 2), [[6.0, 8.0]])
