@@ -10,7 +10,10 @@
 namespace {
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr_t,
-                                                   float b1, float b2, float eps, float gs) {
+                                                   float b1, float b2, float eps, float gs, const unsigned* err) {
+    // a step whose kernels raised the sticky device error word (runtime.h) has INVALID gradients; the host only learns of it
+    // at its next wait, after this kernel.  Leave parameters and moments untouched in that case (one uncached read per block).
+    if (err && __builtin_nontemporal_load(err) != 0u) return;
     const size_t n4 = n >> 2;
     float4* w4 = reinterpret_cast<float4*>(w);
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -41,10 +44,10 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const 
 }  // namespace
 
 void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
-                 float beta2, float eps, float grad_scale) {
+                 float beta2, float eps, float grad_scale, const unsigned* err_word) {
     if (n == 0) return;
     ProfScope ps(s, "adam", 0.0, 28.0 * (double)n);
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n / 4 + 1, 256), 2048));
-    DL4DS_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    DL4DS_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, s, w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale, err_word);
     HIP_CHECK(hipGetLastError());
 }

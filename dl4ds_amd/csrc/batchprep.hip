@@ -146,7 +146,10 @@ __global__ void prep_taps_kernel(const TapParams a) {
         const float* img = g.src + frame * g.sh * g.sw * g.Cn + cc;
         float v;
         if (g.raw) {
-            v = img[((size_t)(cy + oy) * g.sw + cx + ox) * g.Cn];
+            // copy of the source pixel at the crop corner (+ output position); row_div > 0: the source lives on a grid row_div times
+            // coarser than the corner's (an external LR array / LR-grid predictors cropped at corner / scale, dataloader.py:166-200)
+            const int sy = g.row_div ? cy / g.row_div : cy, sx = g.row_div ? cx / g.row_div : cx;
+            v = img[((size_t)(sy + oy) * g.sw + sx + ox) * g.Cn];
         } else {
             const int ry = g.row_div ? oy + cy / g.row_div : oy, rx = g.row_div ? ox + cx / g.row_div : ox;
             const int y0 = g.origin_from_crop ? cy : 0, x0 = g.origin_from_crop ? cx : 0;
@@ -259,6 +262,35 @@ void batch_prepare_taps(hipStream_t s, const float* hr, const float* pred, const
     const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n_hr, 256), 16384));
     DL4DS_LAUNCH(prep_hr_kernel, dim3(blocks), dim3(256), 0, s, h);
     HIP_CHECK(hipGetLastError());
+}
+
+// The gather pass itself as a primitive (round 5): up to three channel groups, each with its own source array / grid / frame rule and
+// either a raw crop or a separable tap table.  The host composes create_pair_hr_lr's remaining cases from it (an external LR array,
+// predictors already on the LR grid, fields whose size `scale` does not divide -- dl4ds_amd/dataloader.py: DeviceDataGenerator).
+void batch_gather(hipStream_t s, const GatherGroup* groups, int n_groups, const int* idx, const int* cy, const int* cx, float* out,
+                  int out_h, int out_w, int T, int B) {
+    DL4DS_REQUIRE(n_groups >= 1 && n_groups <= 3 && B > 0 && T > 0 && out_h > 0 && out_w > 0 && out, "batch_gather: bad sizes");
+    TapParams a{};
+    a.idx = idx; a.cy = cy; a.cx = cx; a.out = out; a.oy_n = out_h; a.ox_n = out_w; a.T = T; a.B = B; a.ng = n_groups;
+    int cend = 0;
+    double src_bytes = 0.0;
+    for (int i = 0; i < n_groups; ++i) {
+        const GatherGroup& q = groups[i];
+        DL4DS_REQUIRE(q.src && q.channels > 0 && q.src_h > 0 && q.src_w > 0 && q.frames >= 0 && q.frames <= 2, "batch_gather: bad group");
+        DL4DS_REQUIRE(q.frames != 0 || idx, "batch_gather: dataset-indexed group without an index list");
+        DL4DS_REQUIRE(q.raw || (q.taps[0].idx && q.taps[0].wt && q.taps[0].k > 0 && q.taps[1].idx && q.taps[1].wt && q.taps[1].k > 0),
+                      "batch_gather: tap tables missing");
+        TapGroup& g = a.g[i];
+        g = TapGroup{};
+        g.src = q.src; g.Cn = q.channels; g.frames = q.frames; g.sh = q.src_h; g.sw = q.src_w; g.raw = q.raw;
+        g.origin_from_crop = q.origin_from_crop; g.row_div = q.row_div;
+        if (!q.raw) { g.tab.iy = q.taps[0].idx; g.tab.wy = q.taps[0].wt; g.tab.ky = q.taps[0].k; g.tab.ix = q.taps[1].idx; g.tab.wx = q.taps[1].wt; g.tab.kx = q.taps[1].k; }
+        cend += q.channels;
+        a.cend[i] = cend;
+        src_bytes += 4.0 * B * T * (double)out_h * out_w * q.channels * (q.raw ? 1 : q.taps[0].k * q.taps[1].k);
+    }
+    a.CL = cend;
+    launch_taps(s, a, "batch_gather", src_bytes);
 }
 
 void batch_prepare(hipStream_t s, const float* hr, const float* pred, const float* stat, const int* idx, const int* cy,

@@ -49,6 +49,7 @@ unsigned* device_error_word() {
     }
     return g_err_dev;
 }
+unsigned* device_error_word_if_any() { return g_err_dev; }
 void device_error_check(const char* what) {
     if (!g_err_host) return;
     const unsigned code = *reinterpret_cast<volatile unsigned*>(g_err_host);
@@ -346,6 +347,36 @@ int dl4ds_batch_prepare_taps(const float* hr, const float* pred, const float* st
     TapAxis a0[2], a1[2], a2[2];
     batch_prepare_taps(S(), hr, pred, stat, d_idx, d_idx + B, d_idx + 2 * B, out_lr, out_hr, out_stat, scratch_dev, H, W, C, P,
                        S_, T, B, scale, psy, psx, pin, static_in_lr, axes(dn_patch, a0), axes(dn_field, a1), axes(up_field, a2));
+    API_END
+}
+int dl4ds_batch_gather(const dl4ds_gather_group* groups, int n_groups, const int* idx_host, const int* cy_host, const int* cx_host,
+                       float* out_dev, int out_h, int out_w, int T, int B) {
+    API_BEGIN
+    DL4DS_REQUIRE(groups && n_groups >= 1 && n_groups <= 3 && B > 0, "batch_gather: groups / batch size");
+    DL4DS_REQUIRE((cy_host == nullptr) == (cx_host == nullptr), "batch_gather: crop corner lists");
+    static int* d_idx = nullptr;
+    static int cap = 0;
+    static std::vector<int> h_idx;
+    if (3 * B > cap) {
+        if (d_idx) HIP_CHECK(hipFree(d_idx));
+        cap = std::max(3 * B, 3 * 256);
+        HIP_CHECK(hipMalloc((void**)&d_idx, (size_t)cap * sizeof(int)));
+    }
+    h_idx.assign(3 * (size_t)B, 0);
+    for (int b = 0; b < B; ++b) {
+        if (idx_host) h_idx[b] = idx_host[b];
+        if (cy_host) { h_idx[B + b] = cy_host[b]; h_idx[2 * B + b] = cx_host[b]; }
+    }
+    HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), 3 * (size_t)B * sizeof(int), hipMemcpyHostToDevice, S()));
+    GatherGroup g[3];
+    for (int i = 0; i < n_groups; ++i) {
+        const dl4ds_gather_group& q = groups[i];
+        g[i].src = q.src_dev; g[i].channels = q.channels; g[i].frames = q.frames; g[i].src_h = q.src_h; g[i].src_w = q.src_w;
+        g[i].raw = q.raw; g[i].origin_from_crop = q.origin_from_crop; g[i].row_div = q.row_div;
+        for (int k = 0; k < 2; ++k) { g[i].taps[k].idx = q.taps[k].idx; g[i].taps[k].wt = q.taps[k].wt; g[i].taps[k].k = q.taps[k].k; }
+    }
+    batch_gather(S(), g, n_groups, idx_host ? d_idx : nullptr, cy_host ? d_idx + B : nullptr, cy_host ? d_idx + 2 * B : nullptr, out_dev,
+                 out_h, out_w, T, B);
     API_END
 }
 int dl4ds_op_depth_to_space(const float* x, float* y, int N, int H, int W, int C, int r) {

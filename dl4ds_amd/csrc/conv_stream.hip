@@ -1005,11 +1005,15 @@ static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* 
     if (getenv("DL4DS_STREAM_DEBUG"))
         fprintf(stderr, "stream5: N=%d H=%d W=%d Cin=%d (d2s %d cp %d vec %d) Cout=%d (d2s %d cp %d vec %d) add=%d mask=%d acc=%d\n", in.N, in.H,
                 in.W, in.C, in.d2s, in.cp, in.vec, out.C, out.d2s, out.cp, out.vec, ep.add.p != nullptr, ep.mask.p != nullptr, ep.accumulate);
-    if (off || in.C < 16 || (long)in.H * in.W < 256) return false;
+    // 8 input channels (round 5: the ConvLSTM cells' 5x5 input convolutions 8 -> 32 gate channels, which ran on the fallback
+    // conv_igemm_kernel at 58 TFLOP/s): one chunk of 8 channels, E = 2.  DL4DS_STREAM5_NO_E2=1 for A/B.
+    static const bool no_e2 = getenv("DL4DS_STREAM5_NO_E2") != nullptr;
+    const bool e2 = in.C == 8 && out.C >= 16 && !no_e2;
+    if (off || (in.C < 16 && !e2) || (long)in.H * in.W < 256) return false;
     if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
     if ((((uintptr_t)ep.bias) & 15) != 0) return false;
     if ((long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N >= (1l << 20)) return false;
-    const int E = (in.C % 32 == 0) ? 8 : ((in.C % 24 == 0) ? 6 : ((in.C % 16 == 0) ? 4 : 0));
+    const int E = e2 ? 2 : ((in.C % 32 == 0) ? 8 : ((in.C % 24 == 0) ? 6 : ((in.C % 16 == 0) ? 4 : 0)));
     if (!E) return false;
     int NT = 0;
     long best = -1;
@@ -1031,6 +1035,12 @@ static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* 
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.CK = 4 * E; p.TPS = 0;
+    if (E == 2) {
+        if (NT == 1) NT = 2;
+        if (NT == 2) return launch_stream_ws<5, 2, 2, 4>(s, sp, in.N);
+        if (NT == 3) return launch_stream_ws<5, 2, 3, 4>(s, sp, in.N);
+        return launch_stream_ws<5, 2, 4, 4>(s, sp, in.N);
+    }
     if (E == 8) {
         if (NT == 1) return launch_stream_ws<5, 8, 1, 4>(s, sp, in.N);
         if (NT == 2) return launch_stream_ws<5, 8, 2, 4>(s, sp, in.N);
@@ -1053,6 +1063,20 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
                            const ConvEpilogue& ep) {
     if (KS == 5) return conv2d_stream5_forward(s, in, w, out, ep);
     if (KS != 3 && KS != 1) return false;
+    // 3x3 with 8 input and >= 16 output channels (the ConvLSTM cells' 3x3 input convolutions 8 -> 32, conv_igemm before round 5):
+    // the producer / consumer kernel with one 8-channel chunk
+    if (KS == 3 && in.C == 8 && out.C >= 16 && (out.C & 3) == 0 && out.C % 32 == 0 && (long)in.H * in.W >= 256 && in.vec && out.vec &&
+        (!ep.add.p || ep.add.vec) && (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) &&
+        (long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N < (1l << 20) && !getenv("DL4DS_STREAM5_NO_E2") && !getenv("DL4DS_STREAM_NO_WS")) {
+        StreamParams sp;
+        ConvParams& p = sp.c;
+        p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
+        p.w = w; p.bias = ep.bias;
+        p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
+        p.relu = ep.relu; p.accumulate = ep.accumulate;
+        p.wvec = 0; p.CK = 8; p.TPS = 0;
+        if (launch_stream_ws<3, 2, 2, 4>(s, sp, in.N)) return true;
+    }
     if (in.C < 16 || (long)in.H * in.W < 256) return false;
     if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
     if ((((uintptr_t)ep.bias) & 15) != 0) return false;

@@ -15,9 +15,9 @@ int wino_cu_count() {
 
 // U = G g G^T in the fragment order the workgroups load it in: element ((pc * 4 + xi) * F/4 + f4) * 64 + lane, component j,
 // f = 4 f4 + j = (nu * 4 KQ + ks) * NT + cb (pc = pass * nchunk + chunk, F = 16 KQ NT); nu = 3 negated
-// second form of the kernel (conv_wino2_kernel): slots 1 and 2 hold U1 - U2 and U1 + U2 (see its K loop)
+// (both forms of the kernel -- conv_wino_kernel / conv_wino2_kernel -- read this one layout: nu = 1, 2 hold (U0 +- U1 + U2) / 2)
 __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout, int KQ,
-                                                          int NT, int nchunk, int total, int form2) {
+                                                          int NT, int nchunk, int total) {
     const int F = 16 * KQ * NT;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int j = idx & 3, lane = (idx >> 2) & 63;
@@ -39,8 +39,7 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
             float t[3];
 #pragma unroll
             for (int b = 0; b < 3; ++b) t[b] = c0 * p[(0 * 3 + b) * tap] + c1 * p[(1 * 3 + b) * tap] + c2 * p[(2 * 3 + b) * tap];
-            if (form2) val = nu == 0 ? t[0] : (nu == 1 ? t[1] : (nu == 2 ? t[0] + t[2] : -t[2]));
-            else val = nu == 0 ? t[0] : (nu == 1 ? .5f * (t[0] + t[1] + t[2]) : (nu == 2 ? .5f * (t[0] - t[1] + t[2]) : -t[2]));
+            val = nu == 0 ? t[0] : (nu == 1 ? .5f * (t[0] + t[1] + t[2]) : (nu == 2 ? .5f * (t[0] - t[1] + t[2]) : -t[2]));
         }
         u[idx] = val;
     }
@@ -68,6 +67,124 @@ float* wino_scratch(hipStream_t s, size_t floats) {
     return e.buf;
 }
 
+// ---- transformed filters of a GRAPH's layers: one batched launch per pass (round 5) ---------------------------------------------
+// Inside a graph pass (WinoPassGuard, opened by Graph::forward / Graph::backward) every Winograd layer registers its filter
+// (pointer into the graph's parameter arena W or its derived-weights arena Wt, shape, fragment geometry) with a buffer of its own.
+// From the second pass on, wino_filters_refresh(range) transforms ALL registered filters of that range in ONE launch -- at the start
+// of the forward pass for W, right after the dgrad arrangements have been rebuilt for Wt -- and the layers find their entry fresh:
+// 20 launches of wino_filter_kernel per cfg2 step become 2.  Freshness never outlives a forward pass: Graph::forward invalidates
+// the graph's ranges first (the optimiser, set_weights, a checkpoint load or a broadcast may have touched W).  Outside a graph pass
+// (the op-level API) nothing is registered or trusted: the shared scratch and one launch per call, as before.
+struct WinoFilterJob { const float* w; float* u; int Cin, Cout, KQ, NT, nchunk, total, first; };     // first: the job's first block
+constexpr int WINO_JOBS_MAX = 24, WINO_FILTER_PER_BLOCK = 1024;
+struct WinoFilterJobs { WinoFilterJob j[WINO_JOBS_MAX]; int n, total; };                            // total: blocks
+
+__global__ void __launch_bounds__(256) wino_filter_batched_kernel(const WinoFilterJobs jobs) {
+    // block -> job: wave-uniform (scalar loads from the kernel arguments; a per-thread job index made the compiler copy the
+    // whole table into scratch memory per thread)
+    int k = 0;
+#pragma unroll 1
+    while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].first) ++k;
+    const float* const w = jobs.j[k].w;
+    float* const u = jobs.j[k].u;
+    const int Cin = jobs.j[k].Cin, Cout = jobs.j[k].Cout, KQ = jobs.j[k].KQ, NT = jobs.j[k].NT, nchunk = jobs.j[k].nchunk;
+    const int total = jobs.j[k].total, b0 = jobs.j[k].first;
+    const int F = 16 * KQ * NT;
+#pragma unroll 1
+    for (int q = 0; q < WINO_FILTER_PER_BLOCK / 256; ++q) {
+        const int idx = ((int)blockIdx.x - b0) * WINO_FILTER_PER_BLOCK + q * 256 + (int)threadIdx.x;
+        if (idx >= total) break;
+        const int j = idx & 3, lane = (idx >> 2) & 63;
+        int r = idx >> 8;
+        const int f4 = r % (F / 4); r /= F / 4;
+        const int xi = r & 3; r >>= 2;
+        const int chunk = r % nchunk, pass = r / nchunk;
+        const int f = 4 * f4 + j;
+        const int nu = f / (4 * KQ * NT), ks = (f / NT) % (4 * KQ), cb = f % NT;
+        const int cin = pass * 16 * KQ + 16 * (ks >> 2) + 4 * (lane >> 4) + (ks & 3);
+        const int co = chunk * 16 * NT + 16 * cb + (lane & 15);
+        float val = 0.f;
+        if (cin < Cin && co < Cout) {
+            const float c0 = xi == 0 ? 1.f : (xi == 3 ? 0.f : .5f);
+            const float c1 = xi == 1 ? .5f : (xi == 2 ? -.5f : 0.f);
+            const float c2 = xi == 3 ? 1.f : (xi == 0 ? 0.f : .5f);
+            const size_t tap = (size_t)Cin * Cout;
+            const float* p = w + (size_t)cin * Cout + co;
+            float t[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) t[b] = c0 * p[(0 * 3 + b) * tap] + c1 * p[(1 * 3 + b) * tap] + c2 * p[(2 * 3 + b) * tap];
+            val = nu == 0 ? t[0] : (nu == 1 ? .5f * (t[0] + t[1] + t[2]) : (nu == 2 ? .5f * (t[0] - t[1] + t[2]) : -t[2]));
+        }
+        u[idx] = val;
+    }
+}
+
+struct WinoFilterEntry {
+    const float* w; int Cin, Cout, KQ, NT, nchunk; int total; int kind;       // kind: pass it was registered in (0 forward, 1 backward)
+    hipStream_t stream; float* u; bool fresh;
+};
+std::vector<WinoFilterEntry>& wino_entries() { static std::vector<WinoFilterEntry> v; return v; }
+int g_wino_pass_depth = 0, g_wino_pass_kind = 0;
+constexpr size_t WINO_ENTRIES_MAX = 512;
+
+// -> the transformed filter to use and whether it still has to be computed (by the caller, on s)
+float* wino_filter_lookup(hipStream_t s, const float* w, int Cin, int Cout, int KQ, int NT, int nchunk, int total, bool& need) {
+    static const bool off = getenv("DL4DS_WINO_NO_FILTER_CACHE") != nullptr;          // (A/B)
+    need = true;
+    if (g_wino_pass_depth <= 0 || off) return wino_scratch(s, (size_t)total);
+    auto& es = wino_entries();
+    for (auto& e : es)
+        if (e.w == w && e.Cin == Cin && e.Cout == Cout && e.KQ == KQ && e.NT == NT && e.nchunk == nchunk && e.stream == s) {
+            need = !e.fresh;
+            e.fresh = true;                      // (the caller transforms it now if it was not)
+            return e.u;
+        }
+    if (es.size() >= WINO_ENTRIES_MAX) return wino_scratch(s, (size_t)total);
+    WinoFilterEntry e{w, Cin, Cout, KQ, NT, nchunk, total, g_wino_pass_kind, s, nullptr, true};
+    HIP_CHECK(hipMalloc((void**)&e.u, (size_t)total * sizeof(float)));
+    es.push_back(e);
+    return e.u;
+}
+
+}  // namespace
+
+WinoPassGuard::WinoPassGuard(int kind) : prev_kind(g_wino_pass_kind) { ++g_wino_pass_depth; g_wino_pass_kind = kind; }
+WinoPassGuard::~WinoPassGuard() { --g_wino_pass_depth; g_wino_pass_kind = prev_kind; }
+
+void wino_filters_invalidate(const float* lo, const float* hi) {
+    for (auto& e : wino_entries())
+        if (e.w >= lo && e.w < hi) e.fresh = false;
+}
+
+void wino_filters_release(const float* lo, const float* hi) {
+    auto& es = wino_entries();
+    for (size_t i = 0; i < es.size();) {
+        if (es[i].w >= lo && es[i].w < hi) { (void)hipFree(es[i].u); es[i] = es.back(); es.pop_back(); }
+        else ++i;
+    }
+}
+
+void wino_filters_refresh(hipStream_t s, const float* lo, const float* hi, int kind) {
+    WinoFilterJobs jobs;
+    jobs.n = 0; jobs.total = 0;
+    auto flush = [&]() {
+        if (!jobs.n) return;
+        ProfScope ps(s, "wino_filters", 0.0, 4.0 * jobs.total * WINO_FILTER_PER_BLOCK);
+        DL4DS_LAUNCH(wino_filter_batched_kernel, dim3(jobs.total), dim3(256), 0, s, jobs);
+        HIP_CHECK(hipGetLastError());
+        jobs.n = 0; jobs.total = 0;
+    };
+    for (auto& e : wino_entries()) {
+        if (e.fresh || e.kind != kind || e.stream != s || e.w < lo || e.w >= hi) continue;
+        if (jobs.n == WINO_JOBS_MAX) flush();
+        jobs.j[jobs.n++] = WinoFilterJob{e.w, e.u, e.Cin, e.Cout, e.KQ, e.NT, e.nchunk, e.total, jobs.total};
+        jobs.total += cdiv(e.total, WINO_FILTER_PER_BLOCK);
+        e.fresh = true;
+    }
+    flush();
+}
+
+namespace {
 }  // namespace
 
 // 3x3, stride 1, SAME.  Returns false when the layer is not eligible (the caller falls through to the direct kernels).
@@ -125,11 +242,12 @@ bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const T
                  4.0 * (px * (in.C + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))) + 9.0 * in.C * out.C),
                  2.0 * px * 9.0 * in.C * out.C);
     const size_t per_pass = (size_t)wp.nchunk * 4 * (16 * KQ * NT) * 64;
-    float* const u = wino_scratch(s, per_pass * passes);
-    {
-        const int total = (int)(per_pass * passes);
+    const int total = (int)(per_pass * passes);
+    bool need = true;
+    float* const u = wino_filter_lookup(s, w, in.C, out.C, KQ, NT, wp.nchunk, total, need);
+    if (need) {
         DL4DS_LAUNCH(wino_filter_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, u, in.C, out.C, KQ, NT,
-                           wp.nchunk, total, 0);
+                           wp.nchunk, total);
         HIP_CHECK(hipGetLastError());
     }
     for (int ps_ = 0; ps_ < passes; ++ps_) {

@@ -20,9 +20,14 @@
 //     never refreshed by other CUs' stores -- sc1 on both sides is what makes the plain flag sufficient).  Tiles of one
 //     image are dealt to one XCD (blockIdx % 8) so that halo exchange stays inside an L2 -- speed only, never correctness.
 // Every block of the grid must be resident (a tile waits for its neighbours): grid <= CUs (one 256-thread block per CU,
-// LDS-bound; a slice of the CUs is left free while RCCL collectives may run), flags zeroed by a memset node ahead of every
-// launch, every spin bounded -- and a spin that gives up sets the sticky device error word (runtime.h), which every host-side
-// wait checks: the step fails loudly instead of training on stale halos.
+// LDS-bound; a slice of the CUs is left free while RCCL collectives may run), every spin bounded -- and a spin that gives up sets the
+// sticky device error word (runtime.h), which every host-side wait checks and which stops the optimiser kernel: the step fails
+// loudly instead of training on stale halos.  The flags are NEVER reset between launches: they are 64-bit words holding
+// `epoch + steps done` of a process-wide running epoch (seq_epoch below).  INVARIANT the design rests on: a flag word only ever
+// holds 0 (fresh slab, zeroed by Graph::prepare) or a value some earlier launch of THIS process published, i.e. <= the current
+// epoch + T.  The words sit at the head of the op's private saved area (graph_ops2.hip: Bufs), which no other op and no other
+// kernel of this op writes; a stray larger value would make neighbours read as finished (stale halos, no time-out), so the
+// launch wrappers check in debug builds (-DDL4DS_SEQ_CHECK_FLAGS) that no word exceeds the epoch before launching.
 #include "ops.h"
 #include "prof.h"
 #include "head.h"
@@ -649,6 +654,14 @@ static SeqParams seq_params(const float* U, float* Z, float* C, float* Hrec, flo
     p.trace = nullptr;
     p.epoch = seq_epoch(T);
     p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 4 * p.tr); p.ntiles = p.tiles_x * p.tiles_y * B;
+#ifdef DL4DS_SEQ_CHECK_FLAGS
+    {   // the invariant of the header comment, checked the slow way (drains the device: debug builds only)
+        std::vector<unsigned long long> h((size_t)p.ntiles);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(h.data(), flags, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (unsigned long long v : h) DL4DS_REQUIRE(v < p.epoch, "convlstm_seq: a tile flag is ahead of the epoch (stray write into the flag area)");
+    }
+#endif
     return p;
 }
 

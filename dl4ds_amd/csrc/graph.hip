@@ -12,6 +12,8 @@ static void plan_grad_aliases(Graph& g);
 
 // ============================================================================================ Graph
 Graph::~Graph() {
+    if (W) wino_filters_release(W, W + n_params);
+    if (Wt) wino_filters_release(Wt, Wt + wt_floats);
     for (float* p : allocations) (void)hipFree(p);
     if (own_arena) {
         if (W) (void)hipFree(W);
@@ -221,6 +223,11 @@ bool Graph::plan_shared(const std::vector<int>& dup_inputs) {
 void Graph::forward(int B, bool training) {
     prepare(B);
     wt_fresh = false;          // the filters may have been updated since the last backward pass
+    // ... and so are the Winograd layers' transformed filters: all stale, those made from W re-made in one launch (conv_wino.hip)
+    WinoPassGuard wino_pass(0);
+    wino_filters_invalidate(W, W + n_params);
+    if (Wt) wino_filters_invalidate(Wt, Wt + wt_floats);
+    wino_filters_refresh(stream, W, W + n_params, 0);
     const bool sh = shared_groups > 1 && !op_shared.empty() && B % shared_groups == 0;
     for (size_t i = 0; i < ops.size(); ++i) {
         GOp* op = ops[i].get();
@@ -256,6 +263,7 @@ void Graph::refresh_dgrad_weights() {
     }
     conv2d_dgrad_weights_batched(stream, static_cast<const DgradWeightsJob*>(wt_jobs_dev), (int)wt_jobs.size(), wt_job_blocks);
     wt_fresh = true;
+    wino_filters_refresh(stream, Wt, Wt + wt_floats, 1);       // the dgrad layers' transformed filters, from the arrangements just made
 }
 
 void Graph::zero_grad_flags() {
@@ -264,6 +272,7 @@ void Graph::zero_grad_flags() {
 }
 
 void Graph::backward(const BwdCtx& c) {
+    WinoPassGuard wino_pass(1);
     refresh_dgrad_weights();
     for (auto& t : tensors) { t.grad_written = false; t.pending_add = nullptr; }
     for (int o : outputs) tensors[o].grad_written = true;      // seeded by the loss

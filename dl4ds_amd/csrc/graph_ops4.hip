@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
     }
     const f32x4 wl4 = *reinterpret_cast<const f32x4*>(a.wl + (size_t)hw * 4);         // Wl[h][w][c][f] -> c * 2 + f
     const float bl0 = a.bl[(size_t)hw * 2], bl1 = a.bl[(size_t)hw * 2 + 1];
-    const __amdgpu_buffer_rsrc_t ry = rsrc_of(a.y);                  // (wave-uniform descriptor, per-lane byte offsets < 2^31: checked by the host)
+    // wave-uniform descriptor based at the first frame of the BLOCK's first sample: the per-lane byte offsets then span at most the
+    // few samples a block of 256 grid points touches (< 2^31 checked by the host per sample, whatever the batch size)
+    const size_t fbase = (size_t)(((size_t)blockIdx.x * 256) / a.HW) * a.T * a.HW;
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(a.y + fbase * CO);
     for (int t = 0; t < a.T; ++t) {
         const size_t px = ((size_t)bi * a.T + t) * a.HW + hw;
         float xv[CX];
@@ -122,7 +125,7 @@ __global__ void __launch_bounds__(256) rec_tail_fwd_kernel(const TailParams a) {
             for (int o = 0; o < CO; ++o) yv[o] = fmaf(xv[i], w_[i * CO + o], yv[o]);
 #pragma unroll
         for (int o = 0; o < CO; ++o) yv[o] = fmaxf(yv[o], 0.f);
-        store_row<CO>(ry, (int)(px * CO * 4), yv);
+        store_row<CO>(ry, (int)((px - fbase) * CO * 4), yv);
         *reinterpret_cast<float2*>(a.u + px * 2) = make_float2(u0, u1);
         *reinterpret_cast<float2*>(a.lws + px * 2) = make_float2(l0, l1);
     }
@@ -231,14 +234,17 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
 #pragma unroll
     for (int j = 0; j < CS; ++j) dsacc[j] = 0.f;
     const size_t f0 = (size_t)bi * a.T * a.HW + hw;                  // the sample's first frame at this grid point
-    const __amdgpu_buffer_rsrc_t ry = rsrc_of(a.y), rdy = rsrc_of(a.dy), rdz = rsrc_of(a.dz), rzs = rsrc_of(a.dzs);
+    // descriptors based at the block's first sample / first grid point (see rec_tail_fwd_kernel): offsets independent of the batch size
+    const size_t p0 = (size_t)blockIdx.x * 256, fbase = (p0 / a.HW) * a.T * a.HW;
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(a.y + fbase * CO), rdy = rsrc_of(a.dy + fbase * CO), rdz = rsrc_of(a.dz + fbase * CZ),
+                                 rzs = rsrc_of(a.dzs + p0 * CZ);
     for (int t = 0; t < a.T; ++t) {
         const size_t px = f0 + (size_t)t * a.HW;
         float z[CZ];                                                 // dy masked by y > 0, then the transition's masked gradient
         {
             float dyv[CO], yv[CO];
-            load_row<CO>(rdy, (int)(px * CO * 4), dyv);
-            load_row<CO>(ry, (int)(px * CO * 4), yv);
+            load_row<CO>(rdy, (int)((px - fbase) * CO * 4), dyv);
+            load_row<CO>(ry, (int)((px - fbase) * CO * 4), yv);
 #pragma unroll
             for (int o = 0; o < CO; ++o) z[o] = yv[o] > 0.f ? dyv[o] : 0.f;
         }
@@ -283,11 +289,11 @@ __global__ void __launch_bounds__(256) rec_tail_bwd_kernel(const TailBwdParams a
             for (int o = 0; o < CO; ++o) v = fmaf(w_[(CX + j) * CO + o], z[o], v);
             dsacc[j] += v;
         }
-        store_row<CZ>(rdz, (int)(px * CZ * 4), z);
+        store_row<CZ>(rdz, (int)((px - fbase) * CZ * 4), z);
 #pragma unroll
         for (int o = 0; o < CZ; ++o) zsum[o] += z[o];
     }
-    store_row<CZ>(rzs, (int)(p * CZ * 4), zsum);
+    store_row<CZ>(rzs, (int)((p - p0) * CZ * 4), zsum);
     if (a.want_ds) {
 #pragma unroll
         for (int q = 0; q < CS; q += 4) {
@@ -592,6 +598,14 @@ struct RecTailOp : GOp {
     int CX, CS, CO;
     RecTailOp() { kind = "rec_tail"; }
     size_t frames(Graph& g, int B) const { return (size_t)B * T; }
+    // The non-staged kernels (grids whose point count is no multiple of 256) address rows with 32-bit byte offsets from a descriptor
+    // based at the block's first sample: a block of 256 grid points spans at most 256 / HW + 2 samples.  Independent of the batch
+    // size (the round-4 check bounded B T HW and also stopped the staged kernels, which index with size_t).
+    void require_row_offsets_fit(int HW) const {
+        if (rec_tail_staged(HW)) return;
+        const size_t span = (size_t)(256 / HW + 2) * T * HW * (size_t)(CO + 2) * 4;
+        DL4DS_REQUIRE(span < (1ull << 31), "rec_tail: one sample's frames exceed 32-bit row offsets (DL4DS_NO_REC_TAIL_FUSION=1 builds the separate layers)");
+    }
     size_t saved_floats_per_sample(Graph& g) override { return 4 * (size_t)T * g.tensors[out].H * g.tensors[out].W; }   // u, lws
     // backward: dz, dzs, the per-sample LocallyConnected partials, the three small weight-gradient results, then the 1x1
     // weight-gradient kernels' own workspace
@@ -651,8 +665,7 @@ struct RecTailOp : GOp {
         p.y = to.data;
         p.u = saved; p.lws = saved + 2 * frames(g, B) * to.H * to.W;
         p.B = B; p.T = T; p.HW = to.H * to.W;
-        DL4DS_REQUIRE(frames(g, B) * p.HW * (size_t)(CO + 2) * 4 < (1ull << 31),
-                      "rec_tail: batch too large for 32-bit row offsets (DL4DS_NO_REC_TAIL_FUSION=1 builds the separate layers)");
+        require_row_offsets_fit(p.HW);
         const double px = (double)frames(g, B) * p.HW;
         ProfScope ps(g.stream, "rec_tail_fwd", 2.0 * px * ((CX + CS) * 2 + 4 + (CX + CS + 2) * CO), 4.0 * px * (CX + CO + 4) + 4.0 * B * p.HW * CS);
 #define X(A_, B_, C_) if (CX == A_ && CS == B_ && CO == C_) { launch_fwd<A_, B_, C_>(g.stream, p); return; }
@@ -675,6 +688,7 @@ struct RecTailOp : GOp {
         const float* lws = saved + 2 * frames(g, c.B) * HW + f_off * 2;
         p.lws = lws;
         const bool staged = rec_tail_staged(HW);
+        require_row_offsets_fit(HW);
         p.y = to.data + f_off * CO; p.dy = to.grad + f_off * CO;
         p.wt = g.wp(wt); p.wl = g.wp(wl); p.w = g.wp(w);
         p.want_dx = wants_grad(g, x, c); p.want_ds = wants_grad(g, s, c);

@@ -52,6 +52,13 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
 bool conv2d_gemm_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out, const ConvEpilogue& ep, int max_hw);
 // Winograd F(2x2, 3x3) form of the MFMA-bound 3x3 layers (conv_wino.hip); false = not eligible
 bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep);
+// The transformed filters of a graph's Winograd layers, one batched launch per pass instead of one per layer (conv_wino.hip):
+// a pass of a graph holds a WinoPassGuard (kind 0 = forward, 1 = backward); _invalidate marks every registered filter inside
+// [lo, hi) stale, _refresh transforms the stale ones of that kind in one launch on s, _release frees them (graph destruction).
+struct WinoPassGuard { int prev_kind; explicit WinoPassGuard(int kind); ~WinoPassGuard(); WinoPassGuard(const WinoPassGuard&) = delete; };
+void wino_filters_invalidate(const float* lo, const float* hi);
+void wino_filters_refresh(hipStream_t s, const float* lo, const float* hi, int kind);
+void wino_filters_release(const float* lo, const float* hi);
 // ... and of their weight gradient (conv_wino_wgrad.hip): dw [3][3][Cin][Cout], db [Cout] or null
 bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw, int accumulate, float* db, int accumulate_db);
 bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
@@ -170,7 +177,7 @@ void bce_forward_backward(hipStream_t s, const float* p, float label, int n, flo
 // -------------------------------------------------------------------------- optimiser (adam.hip)
 // Keras Adam on a flat arena. lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.
 void adam_update(hipStream_t s, float* w, const float* g, float* m, float* v, size_t n, float lr_t,
-                 float beta1, float beta2, float eps, float grad_scale);
+                 float beta1, float beta2, float eps, float grad_scale, const unsigned* err_word = nullptr);   // err_word: see runtime.h
 
 // ------------------------------------------------------------- batch preparation (batchprep.hip), "next" row f1
 // Gathers one training batch from a device-resident dataset: block-mean coarsening (cv2 INTER_AREA at an integer
@@ -186,6 +193,10 @@ void batch_prepare_taps(hipStream_t s, const float* hr, const float* pred, const
                         const int* cx, float* out_lr, float* out_hr, float* out_stat, float* scratch, int H, int W, int C,
                         int P, int S, int T, int B, int scale, int psy, int psx, int pin, int static_in_lr,
                         const TapAxis* dn_patch, const TapAxis* dn_field, const TapAxis* up_field);
+// one gather pass over up to three channel groups (raw crops or separable tap tables): the primitive behind both of the above
+struct GatherGroup { const float* src; int channels, frames, src_h, src_w, raw, origin_from_crop, row_div; TapAxis taps[2]; };
+void batch_gather(hipStream_t s, const GatherGroup* groups, int n_groups, const int* idx, const int* cy, const int* cx, float* out,
+                  int out_h, int out_w, int T, int B);
 void repeat_time_forward(hipStream_t s, const float* in, float* out, int B, int T, size_t ps);
 void repeat_time_forward_view(hipStream_t s, const float* in, const TView& out, int B, int T);     // out: (B*T, H, W, C) view, any pixel pitch
 void repeat_time_backward(hipStream_t s, const float* dout, float* din, int B, int T, size_t ps, int accumulate);

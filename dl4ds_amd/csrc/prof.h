@@ -34,7 +34,9 @@ struct Profiler {
 Profiler& prof();
 
 struct ProfScope;
-ProfScope*& prof_current();       // innermost live scope (the library is driven from one host thread per process)
+ProfScope*& prof_current();       // innermost live scope.  SINGLE HOST THREAD: the profiler, this pointer, convlstm_seq's epoch
+                                  // counter and the lazily created device error word are process-wide statics without locks -- the
+                                  // library is driven from one host thread per process (one process per GPU), as the C header states
 
 struct ProfScope {
     hipStream_t s;
@@ -65,7 +67,8 @@ struct ProfScope {
 // start / stop events for the next kernel launch if it happens inside a timed scope, else (nullptr, nullptr)
 inline bool prof_launch_events(hipEvent_t& a, hipEvent_t& b) {
     ProfScope* sc = prof().on ? prof_current() : nullptr;
-    if (!sc || sc->idx < 0) { a = b = nullptr; return false; }
+    while (sc && sc->idx < 0) sc = sc->outer;          // a nested scope the filter rejected must not hide a matching outer one
+    if (!sc) { a = b = nullptr; return false; }
     Profiler& p = prof();
     a = p.get_event();
     b = p.get_event();

@@ -128,7 +128,7 @@ void trainer_apply_adam(Trainer& t) {
     int rank = 0, world = 1;
     dist_world(rank, world);
     adam_update(g.stream, g.W, g.G, t.m, t.v, g.n_params, lr_t, t.cfg.beta1, t.cfg.beta2, t.cfg.eps,
-                1.f / (float)world);
+                1.f / (float)world, device_error_word_if_any());
 }
 
 void trainer_step(Trainer& t, const float* const* inputs, int n_inputs, const float* y_true, int B, bool is_host,

@@ -61,15 +61,31 @@ def crop_array(array, size, yx=None, position=False, rng=None):
     return (out, y, x) if position else out
 
 
-def _axis_taps(n_src, n_dst, interpolation):
-    """(indices [n_dst, k], weights [n_dst, k]) of cv2.resize along one axis (OpenCV resize.cpp)."""
+def _axis_taps(n_src, n_dst, interpolation, area_linear=False):
+    """(indices [n_dst, k], weights [n_dst, k]) of cv2.resize along one axis (OpenCV resize.cpp).  ``area_linear``: INTER_AREA
+    while the OTHER axis grows -- OpenCV runs true area resampling only when neither axis grows, otherwise both axes take the
+    bilinear code path with its "area" coefficients (the up-scaling branch below, valid at any ratio)."""
     d = np.arange(n_dst)
     scale = n_src / n_dst
-    if interpolation == 'inter_area' and n_dst < n_src:
-        if n_src % n_dst:
-            raise NotImplementedError('inter_area down-scaling is implemented for integer ratios (block means)')
-        s = n_src // n_dst
-        return d[:, None] * s + np.arange(s)[None, :], np.full((n_dst, s), 1.0 / s)
+    if interpolation == 'inter_area' and n_dst < n_src and not area_linear:
+        if n_src % n_dst == 0:
+            s = n_src // n_dst
+            return d[:, None] * s + np.arange(s)[None, :], np.full((n_dst, s), 1.0 / s)
+        # non-integer ratio (cv2 computeResizeAreaTab): destination cell d = [d scale, (d + 1) scale) of the source axis; source
+        # pixel j weighs in with its overlap |[j, j + 1) & cell| / cell width, overlaps of the two partial end pixels below 1e-3
+        # dropped as OpenCV does.  K = the widest cell's pixel count; unused taps carry weight 0 at a valid index.
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = np.minimum(scale, n_src - f1)
+        s2 = np.minimum(np.floor(f2).astype(int), n_src - 1)
+        s1 = np.minimum(np.ceil(f1).astype(int), s2)
+        K = int((s2 - s1).max()) + 2
+        j = (s1 - 1)[:, None] + np.arange(K)[None, :]                 # candidate pixels s1 - 1 ... s1 + K - 2
+        head = (j == (s1 - 1)[:, None]) & ((s1 - f1) > 1e-3)[:, None]
+        body = (j >= s1[:, None]) & (j < s2[:, None])
+        tail = (j == s2[:, None]) & ((f2 - s2) > 1e-3)[:, None]
+        w = (head * (s1 - f1)[:, None] + body * 1.0 + tail * np.minimum(np.minimum(f2 - s2, 1.0), cell)[:, None]) / cell[:, None]
+        return np.clip(j, 0, n_src - 1), w
     if interpolation == 'nearest':
         return np.minimum(np.floor(d * scale).astype(int), n_src - 1)[:, None], np.ones((n_dst, 1))
     if interpolation in ('inter_area', 'bilinear'):
@@ -119,11 +135,12 @@ def _axis_taps(n_src, n_dst, interpolation):
 def _resize2d(a, size_y, size_x, interpolation):
     """cv2.resize of a [y,x,c] float array to (size_y, size_x), separable gathers."""
     h, w = a.shape[:2]
+    lin = interpolation == 'inter_area' and (size_y > h or size_x > w)
     if h != size_y:
-        idx, wt = _axis_taps(h, size_y, interpolation)
+        idx, wt = _axis_taps(h, size_y, interpolation, lin)
         a = np.einsum('dk,dkxc->dxc', wt, a[idx])
     if w != size_x:
-        idx, wt = _axis_taps(w, size_x, interpolation)
+        idx, wt = _axis_taps(w, size_x, interpolation, lin)
         a = np.einsum('ek,yekc->yec', wt, a[:, idx])
     return a
 
@@ -358,13 +375,16 @@ class DataGenerator:
 
 
 class DeviceDataGenerator:
-    """DataGenerator whose dataset lives in HBM and whose batches are gathered by `dl4ds_batch_prepare`
-    (csrc/batchprep.hip) -- SURVEY section 8 "next" row f1.  Same constructor, same seeded permutation and the same
-    per-sample RNG calls as DataGenerator, so `gen[i]` holds exactly the batch `DataGenerator(...)[i]` would build
-    (to fp32 rounding).  'inter_area' (the default) runs the block-mean / replication kernels; every other interpolation
-    of `resize_array` (nearest, bilinear, bicubic, lanczos -- and inter_area again with ``taps=True``) runs
-    `dl4ds_batch_prepare_taps` on per-axis tap tables built once from cv2's coefficients (`_axis_taps`).  Not supported:
-    an external LR array, field sizes not divisible by `scale` (use DataGenerator).
+    """DataGenerator whose dataset lives in HBM and whose batches are gathered on the device (csrc/batchprep.hip) -- SURVEY
+    section 8 "next" row f1.  Same constructor, same seeded permutation and the same per-sample RNG calls as DataGenerator, so
+    `gen[i]` holds exactly the batch `DataGenerator(...)[i]` would build (to fp32 rounding).  Three routes, chosen once:
+      * 'inter_area' on HR-grid inputs whose size `scale` divides (the trainers' default): `dl4ds_batch_prepare`, block-mean /
+        replication kernels;
+      * every other interpolation of `resize_array` on the same inputs (and inter_area with ``taps=True``):
+        `dl4ds_batch_prepare_taps` on per-axis tap tables built once from cv2's coefficients (`_axis_taps`);
+      * round 5, everything else the reference's create_pair_hr_lr accepts (dataloader.py:72-73,92-96,149-163,193-200;
+        utils.py:369-381) -- a caller-supplied LR array, predictors on the LR (or any other) grid, fields whose size `scale` does
+        not divide (cv2.INTER_AREA between grids at a non-integer ratio) -- composed here from `dl4ds_batch_gather` passes.
 
     `gen[i]` returns ([lr(, static_hr)], [hr]) as DeviceArray objects that stay valid until the next `gen[...]` call
     (two rotating output buffers, so the previous batch can still be in flight); `.numpy()` them for inspection.
@@ -374,8 +394,6 @@ class DeviceDataGenerator:
                  static_vars=None, predictors=None, interpolation='inter_area', repeat=None, seed=None, rank=0,
                  world=1, taps=None):
         from .device import DeviceArray
-        if array_lr is not None:
-            raise NotImplementedError('DeviceDataGenerator: an external LR array is not supported (use DataGenerator)')
         if interpolation not in INTERPOLATION_METHODS:
             raise ValueError(f'`interpolation` must be one of {INTERPOLATION_METHODS}. Received {interpolation}')
         self.interpolation = interpolation
@@ -385,8 +403,6 @@ class DeviceDataGenerator:
             a = a[..., None]
         self.N, self.H, self.W, self.C = a.shape
         self.scale, self.batch_size, self.upsampling, self.backbone = int(scale), int(batch_size), upsampling, backbone
-        if self.H % self.scale or self.W % self.scale:
-            raise ValueError('DeviceDataGenerator: field size must be divisible by `scale`')
         self.pin = upsampling == 'pin'
         if not self.pin and upsampling not in POSTUPSAMPLING_METHODS:
             raise ValueError(f'unknown upsampling {upsampling}')
@@ -396,20 +412,36 @@ class DeviceDataGenerator:
         self.T = 1 if time_window is None else int(time_window)
         self.spt = time_window is not None
         self._hr = DeviceArray.from_numpy(a)
-        self._pred, self.P = None, 0
+        # the LR grid: the caller's LR array's own (dataloader.py:92-96,145-148), else int(H / scale) x int(W / scale)
+        self._lr_src, self.CLR = None, self.C
+        self.hl, self.wl = int(self.H / self.scale), int(self.W / self.scale)
+        if array_lr is not None:
+            al = np.asarray(getattr(array_lr, 'values', array_lr), np.float32)
+            if al.ndim == 3:
+                al = al[..., None]
+            if al.shape[0] != self.N:
+                raise ValueError('`array_lr` must hold as many time steps as `array`')
+            self._lr_src, self.CLR = DeviceArray.from_numpy(al), al.shape[-1]
+            self.hl, self.wl = al.shape[1], al.shape[2]
+        self._pred, self.P, self.pred_grid = None, 0, (self.H, self.W)
         if predictors is not None:
-            p = np.concatenate([np.asarray(q, np.float32) for q in predictors], axis=-1)
-            if p.shape[:3] != a.shape[:3]:
-                # predictors already on the LR / an intermediate grid (dataloader.py:158-163): the host generator's case
-                raise NotImplementedError('DeviceDataGenerator: predictors must share the HR grid')
-            self._pred, self.P = DeviceArray.from_numpy(p), p.shape[-1]
+            ps = [np.asarray(getattr(q, 'values', q), np.float32) for q in predictors]
+            ps = [q[..., None] if q.ndim == 3 else q for q in ps]
+            p = np.concatenate(ps, axis=-1)
+            if p.shape[0] != self.N:
+                raise ValueError('`predictors` must hold as many time steps as `array`')
+            self._pred, self.P, self.pred_grid = DeviceArray.from_numpy(p), p.shape[-1], (p.shape[1], p.shape[2])
         self._stat, self.S = None, 0
         if static_vars is not None:
             sv = [checkarray_ndim(np.squeeze(np.asarray(getattr(v, 'values', v), np.float32)), 3) for v in static_vars]
             st = np.concatenate(sv, axis=-1)
             if st.shape[:2] != (self.H, self.W):
-                raise NotImplementedError('DeviceDataGenerator: static variables must share the HR grid')
+                # (the reference crops them with the HR corner and feeds them to the model's HR auxiliary input, dataloader.py:52-68)
+                raise ValueError('static variables must be on the HR grid')
             self._stat, self.S = DeviceArray.from_numpy(st), st.shape[-1]
+        # the composed route: anything but HR-grid inputs of a size `scale` divides
+        self.general = (self._lr_src is not None or self.pred_grid != (self.H, self.W) or self.H % self.scale != 0
+                        or self.W % self.scale != 0)
         self.n = self.N - self.T if self.spt else self.N
         self.rng = np.random.default_rng(seed)
         perm = self.rng.permutation(self.n)
@@ -418,8 +450,14 @@ class DeviceDataGenerator:
             self.indices = np.hstack([self.indices for _ in range(repeat)])
         self.psy, self.psx = (self.H, self.W) if patch_size is None else (int(patch_size), int(patch_size))
         self.static_in_lr = bool(self.S and not self.spt)
-        cl = self.C + self.P + (self.S if self.static_in_lr else 0)
-        oy, ox = (self.psy, self.psx) if self.pin else (self.psy // self.scale, self.psx // self.scale)
+        cl = self.CLR + self.P + (self.S if self.static_in_lr else 0)
+        if self.pin:
+            oy, ox = self.psy, self.psx
+        elif patch_size is None:
+            oy, ox = self.hl, self.wl
+        else:
+            oy, ox = self.psy // self.scale, self.psx // self.scale
+        self.lr_out = (oy, ox)
         B, T = self.batch_size, self.T
         lead = (B, T) if self.spt else (B,)
         self._bufs = []
@@ -429,41 +467,147 @@ class DeviceDataGenerator:
             st = DeviceArray((B, self.psy, self.psx, self.S)) if self.S else None
             self._bufs.append((lr, hr, st))
         self._turn = 0
-        if self.taps:
+        self._tap_keep, self._tab_cache = [], {}
+        if self.general:
+            self._plan_general()
+        elif self.taps:
             self._build_tap_tables()
 
-    def _build_tap_tables(self):
-        """Per-axis (index, weight) tables of cv2.resize for the three resizes of create_pair_hr_lr, resident in HBM."""
+    # ---- per-axis cv2.resize tables, resident in HBM ----------------------------------------------------------------------------
+    def _axis_pair(self, src_yx, dst_yx):
+        """ctypes (dl4ds_tap_axis * 2) {y, x} of cv2.resize from a src_yx grid to a dst_yx grid (cached per pair of grids)."""
         import ctypes
         from .device import DeviceArray
 
         class TapAxis(ctypes.Structure):
             _fields_ = [('idx', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('k', ctypes.c_int)]
-        self._tap_keep = []
+        key = (tuple(src_yx), tuple(dst_yx))
+        if key in self._tab_cache:
+            return self._tab_cache[key]
+        lin = self.interpolation == 'inter_area' and (dst_yx[0] > src_yx[0] or dst_yx[1] > src_yx[1])
+        arr = (TapAxis * 2)()
+        for i, (n_src, n_dst) in enumerate(zip(src_yx, dst_yx)):
+            if n_src == n_dst:
+                idx, wt = np.arange(n_dst)[:, None], np.ones((n_dst, 1))
+            else:
+                idx, wt = _axis_taps(n_src, n_dst, self.interpolation, lin)
+            d_idx = DeviceArray.from_numpy(np.ascontiguousarray(idx, np.int32))
+            d_wt = DeviceArray.from_numpy(np.ascontiguousarray(wt, np.float32))
+            self._tap_keep += [d_idx, d_wt]
+            arr[i].idx, arr[i].wt, arr[i].k = d_idx.ptr, d_wt.ptr, idx.shape[1]
+        self._tab_cache[key] = arr
+        return arr
 
-        def pair(src_yx, dst_yx):
-            arr = (TapAxis * 2)()
-            for i, (n_src, n_dst) in enumerate(zip(src_yx, dst_yx)):
-                if n_src == n_dst:
-                    idx, wt = np.arange(n_dst)[:, None], np.ones((n_dst, 1))
-                else:
-                    idx, wt = _axis_taps(n_src, n_dst, self.interpolation)
-                d_idx = DeviceArray.from_numpy(np.ascontiguousarray(idx, np.int32))
-                d_wt = DeviceArray.from_numpy(np.ascontiguousarray(wt, np.float32))
-                self._tap_keep += [d_idx, d_wt]
-                arr[i].idx, arr[i].wt, arr[i].k = d_idx.ptr, d_wt.ptr, idx.shape[1]
-            return arr
+    def _build_tap_tables(self):
+        """The three resizes of create_pair_hr_lr for HR-grid inputs (dl4ds_batch_prepare_taps)."""
+        from .device import DeviceArray
         s = self.scale
         hl, wl = self.H // s, self.W // s
         self._dn_patch = self._dn_field = self._up_field = self._scratch = None
         if self.pin:
-            self._dn_field = pair((self.H, self.W), (hl, wl))
-            self._up_field = pair((hl, wl), (self.H, self.W))
+            self._dn_field = self._axis_pair((self.H, self.W), (hl, wl))
+            self._up_field = self._axis_pair((hl, wl), (self.H, self.W))
             self._scratch = DeviceArray((self.batch_size, self.T, hl, wl, self.C + self.P))
         else:
-            self._dn_patch = pair((self.psy, self.psx), (self.psy // s, self.psx // s))
+            self._dn_patch = self._axis_pair((self.psy, self.psx), (self.psy // s, self.psx // s))
             if self.P:
-                self._dn_field = pair((self.H, self.W), (hl, wl))
+                self._dn_field = self._axis_pair((self.H, self.W), (hl, wl))
+
+    # ---- the composed route (round 5) ---------------------------------------------------------------------------------------------
+    def _plan_general(self):
+        """Gather passes (dl4ds_batch_gather) for the inputs create_pair_hr_lr accepts beyond HR-grid fields of a divisible size.
+        Each pass = (groups, crop?, output buffer selector, out_h, out_w, T); a group = dict(src, channels, frames, grid, raw,
+        origin_from_crop, row_div, table)."""
+        from .device import DeviceArray
+        H, W, hl, wl, s = self.H, self.W, self.hl, self.wl, self.scale
+        B, T = self.batch_size, self.T
+        ident = None
+        self._passes = []
+        self._scratch_g = None
+
+        def grp(src, channels, frames, grid, raw=0, origin_from_crop=0, row_div=0, table=None):
+            return dict(src=src, channels=channels, frames=frames, grid=grid, raw=raw, origin_from_crop=origin_from_crop,
+                        row_div=row_div, table=table)
+        lr_groups = []
+        if self.pin:
+            # dataloader.py:88-141: LR part = the caller's LR array, or the HR field coarsened to the LR grid, resized to the HR grid;
+            # predictors brought to the LR grid unless they are on it, then to the HR grid; everything cropped on the HR grid
+            down = []
+            if self._lr_src is None:
+                down.append(grp(self._hr, self.C, 0, (H, W), table=self._axis_pair((H, W), (hl, wl))))
+            if self.P and self.pred_grid != (hl, wl):
+                down.append(grp(self._pred, self.P, 0, self.pred_grid, table=self._axis_pair(self.pred_grid, (hl, wl))))
+            n_down = sum(g['channels'] for g in down)
+            if down:
+                self._scratch_g = DeviceArray((B, T, hl, wl, n_down))
+                self._passes.append(dict(groups=down, crop=False, out='scratch', oh=hl, ow=wl, T=T))
+            up = self._axis_pair((hl, wl), (H, W))
+            pred_direct = self.P and self.pred_grid == (hl, wl)
+            if self._lr_src is not None:
+                lr_groups.append(grp(self._lr_src, self.CLR, 0, (hl, wl), row_div=1, table=up))
+                if self.P:
+                    lr_groups.append(grp(self._pred, self.P, 0, (hl, wl), row_div=1, table=up) if pred_direct
+                                     else grp(self._scratch_g, self.P, 1, (hl, wl), row_div=1, table=up))
+            else:
+                if self.P and not pred_direct:
+                    lr_groups.append(grp(self._scratch_g, self.C + self.P, 1, (hl, wl), row_div=1, table=up))
+                else:
+                    lr_groups.append(grp(self._scratch_g, self.C, 1, (hl, wl), row_div=1, table=up))
+                    if self.P:
+                        lr_groups.append(grp(self._pred, self.P, 0, (hl, wl), row_div=1, table=up))
+            if self.static_in_lr:
+                lr_groups.append(grp(self._stat, self.S, 2, (H, W), raw=1))
+        else:
+            # dataloader.py:143-214: LR part = the caller's LR array cropped on its own grid, or the HR crop (the whole field without
+            # a patch) coarsened; predictors on the LR grid cropped there, others resized as whole fields first; static variables
+            # cropped on the HR grid, then coarsened to the LR patch
+            oy, ox = self.lr_out
+            if self._lr_src is not None:
+                lr_groups.append(grp(self._lr_src, self.CLR, 0, (hl, wl), raw=1, row_div=s))
+            else:
+                lr_groups.append(grp(self._hr, self.C, 0, (H, W), origin_from_crop=1,
+                                     table=self._axis_pair((self.psy, self.psx), (oy, ox))))
+            if self.P:
+                if self.pred_grid == (hl, wl):
+                    lr_groups.append(grp(self._pred, self.P, 0, (hl, wl), raw=1, row_div=s))
+                else:
+                    lr_groups.append(grp(self._pred, self.P, 0, self.pred_grid, row_div=s,
+                                         table=self._axis_pair(self.pred_grid, (hl, wl))))
+            if self.static_in_lr:
+                lr_groups.append(grp(self._stat, self.S, 2, (H, W), origin_from_crop=1,
+                                     table=self._axis_pair((self.psy, self.psx), (oy, ox))))
+        oy, ox = self.lr_out
+        self._passes.append(dict(groups=lr_groups, crop=True, out='lr', oh=oy, ow=ox, T=T))
+        self._passes.append(dict(groups=[grp(self._hr, self.C, 0, (H, W), raw=1)], crop=True, out='hr', oh=self.psy, ow=self.psx, T=T))
+        if self.S:
+            self._passes.append(dict(groups=[grp(self._stat, self.S, 2, (H, W), raw=1)], crop=True, out='st', oh=self.psy,
+                                     ow=self.psx, T=1))
+
+    def _run_general(self, idx, cy, cx, lr, hr, st):
+        import ctypes
+        from . import _lib
+
+        class TapAxis(ctypes.Structure):
+            _fields_ = [('idx', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('k', ctypes.c_int)]
+
+        class Group(ctypes.Structure):
+            _fields_ = [('src', ctypes.c_void_p), ('channels', ctypes.c_int), ('frames', ctypes.c_int), ('src_h', ctypes.c_int),
+                        ('src_w', ctypes.c_int), ('raw', ctypes.c_int), ('origin_from_crop', ctypes.c_int), ('row_div', ctypes.c_int),
+                        ('taps', TapAxis * 2)]
+        ip = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data
+        outs = dict(scratch=self._scratch_g, lr=lr, hr=hr, st=st)
+        for ps in self._passes:
+            arr = (Group * len(ps['groups']))()
+            for i, g in enumerate(ps['groups']):
+                arr[i].src, arr[i].channels, arr[i].frames = g['src'].ptr, g['channels'], g['frames']
+                arr[i].src_h, arr[i].src_w = g['grid']
+                arr[i].raw, arr[i].origin_from_crop, arr[i].row_div = g['raw'], g['origin_from_crop'], g['row_div']
+                if g['table'] is not None:
+                    for k in range(2):
+                        arr[i].taps[k].idx, arr[i].taps[k].wt, arr[i].taps[k].k = g['table'][k].idx, g['table'][k].wt, g['table'][k].k
+            _lib.check(_lib.lib().dl4ds_batch_gather(ctypes.addressof(arr), len(ps['groups']), ip(idx),
+                                                     ip(cy) if ps['crop'] else None, ip(cx) if ps['crop'] else None,
+                                                     outs[ps['out']].ptr, ps['oh'], ps['ow'], ps['T'], self.batch_size))
 
     def __len__(self):
         return len(self.indices) // self.batch_size
@@ -474,17 +618,17 @@ class DeviceDataGenerator:
     def _draw_for(self, sample_indices):
         """Crop corners (HR pixels) for the given samples, with the RNG calls of create_pair_hr_lr / crop_array: 'pin' and
         post-upsampling without predictors crop the HR field at any pixel (dataloader.py:107-112,201-205); with predictors
-        the corner is drawn on the LR grid and scaled (dataloader.py:166-174)."""
+        or a caller-supplied LR array the corner is drawn on the LR grid and scaled (dataloader.py:166-174,193-200)."""
         idx = np.asarray(sample_indices, np.int32)
         cy = np.zeros(len(idx), np.int32)
         cx = np.zeros(len(idx), np.int32)
         if self.patch_size is not None:
             for b in range(len(idx)):
-                if self.pin or self.P == 0:
+                if self.pin or (self.P == 0 and self._lr_src is None):
                     cy[b], cx[b] = random_corner(self.H, self.W, self.patch_size, self.rng)
                 else:
                     ps_lr = self.patch_size // self.scale
-                    y, x = random_corner(self.H // self.scale, self.W // self.scale, ps_lr, self.rng)
+                    y, x = random_corner(self.hl, self.wl, ps_lr, self.rng)
                     cy[b], cx[b] = y * self.scale, x * self.scale
         return idx, cy, cx
 
@@ -500,6 +644,9 @@ class DeviceDataGenerator:
         lr, hr, st = self._bufs[self._turn]
         self._turn ^= 1
         ip = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data
+        if self.general:
+            self._run_general(idx, cy, cx, lr, hr, st)
+            return ([lr, st], [hr]) if st is not None else ([lr], [hr])
         if self.taps:
             import ctypes
             ap = lambda t: None if t is None else ctypes.addressof(t)

@@ -85,17 +85,15 @@ class CGANTrainer(Trainer):
         rng = np.random.default_rng(17)
         preds = None if self.predictors_train is None else np.concatenate(self.predictors_train, axis=-1)
         # dataset in HBM, batches gathered by csrc/batchprep.hip (same crops as the numpy loop: it draws them from the
-        # same generator); the host loop below remains for external LR arrays
+        # same generator), a caller-supplied LR array included; the host loop below remains for models without static variables
+        # (whose batches carry no auxiliary array)
         dev = None
-        if self.data_train_lr is None and self.static_vars is not None:
-            try:
-                dev = DeviceDataGenerator(self.data_train, None, self.backbone, self.upsampling, self.scale,
-                                          batch_size=self.batch_size, patch_size=self.patch_size,
-                                          time_window=self.time_window, static_vars=self.static_vars,
-                                          predictors=self.predictors_train, interpolation=self.interpolation)
-                dev.rng = rng
-            except (NotImplementedError, ValueError):
-                dev = None
+        if self.static_vars is not None:
+            dev = DeviceDataGenerator(self.data_train, self.data_train_lr, self.backbone, self.upsampling, self.scale,
+                                      batch_size=self.batch_size, patch_size=self.patch_size,
+                                      time_window=self.time_window, static_vars=self.static_vars,
+                                      predictors=self.predictors_train, interpolation=self.interpolation)
+            dev.rng = rng
         first = True
         for epoch in range(self.epochs):
             idx = parallel.shard_indices(n_samples, self.rank, self.world, seed=17, epoch=epoch)

@@ -51,12 +51,10 @@ class SupervisedTrainer(Trainer):
                   interpolation=self.interpolation, time_window=self.time_window, rank=self.rank, world=self.world)
         def make(data, data_lr, predictors, seed):
             # datasets live in HBM and batches are gathered on the device (csrc/batchprep.hip: block means for the default
-            # 'inter_area', cv2 tap tables for the other interpolations); the numpy loop remains for external LR arrays
-            if getattr(self, 'device_data', True) and data_lr is None:
-                try:
-                    return DeviceDataGenerator(data, None, predictors=predictors, seed=seed, **kw)
-                except (NotImplementedError, ValueError):
-                    pass
+            # 'inter_area', cv2 tap tables for the other interpolations, composed gather passes for a caller-supplied LR array /
+            # predictors on the LR grid / field sizes `scale` does not divide); device_data=False keeps the numpy loop
+            if getattr(self, 'device_data', True):
+                return DeviceDataGenerator(data, data_lr, predictors=predictors, seed=seed, **kw)
             return DataGenerator(data, data_lr, predictors=predictors, seed=seed, **kw)
         self.ds_train = make(self.data_train, self.data_train_lr, self.predictors_train, 1)
         self.ds_val = make(self.data_val, self.data_val_lr, self.predictors_val, 2)

@@ -11,7 +11,7 @@
  * exception crosses the boundary; all tensors are fp32 NHWC ("channels_last"), conv kernels HWIO,
  * transposed-conv kernels HWOI, dense kernels [in][out]; pointers named *_dev are device (HBM) pointers,
  * *_host are host pointers; sizes are element counts unless called bytes.  One library-wide HIP stream;
- * calls are asynchronous unless documented otherwise.  Thread-compatible (one thread drives a handle).
+ * calls are asynchronous unless documented otherwise.  ONE HOST THREAD per process drives the library (one process per GPU): the profiler and a few run-time statics are unsynchronised.
  */
 #ifndef DL4DS_HIP_H
 #define DL4DS_HIP_H
@@ -322,6 +322,24 @@ int dl4ds_batch_prepare_taps(const float* hr_dev, const float* pred_dev, const f
                              float* out_static_dev, float* scratch_dev, int H, int W, int C, int P, int S, int T, int B,
                              int scale, int psy, int psx, int pin, int static_in_lr, const dl4ds_tap_axis* dn_patch,
                              const dl4ds_tap_axis* dn_field, const dl4ds_tap_axis* up_field);
+
+/* The gather pass of the two entries above as a primitive, for the input forms of create_pair_hr_lr they do not cover
+ * (dataloader.py:72-73,92-96,149-163,193-200: a caller-supplied LR array, predictors already on the LR grid; utils.py:369-381:
+ * cv2.INTER_AREA between grids whose ratio is not an integer):
+ *   out[b][t][oy][ox][:] = concat over the groups g of
+ *     raw              : src_g[frame][cy_b / row_div + oy][cx_b / row_div + ox][:]      (row_div 0: the corner as given)
+ *     origin_from_crop : sum_k wy[oy][ky] wx[ox][kx] src_g[frame][cy_b + iy[oy][ky]][cx_b + ix[ox][kx]][:]  (a PATCH was resized)
+ *     row_div > 0      : the same with table rows oy + cy_b / row_div, ox + cx_b / row_div and no origin (the FIELD was resized,
+ *                        then cropped on the output grid);   otherwise rows oy, ox, no crop
+ *   frame = idx[b] + t (frames 0: dataset), b T + t (frames 1: a batch-local scratch of an earlier pass) or 0 (frames 2: one image).
+ * <= 3 groups; idx / cy / cx are host lists of B ints (cy / cx NULL: no crop; idx NULL only without dataset-indexed groups).
+ * Asynchronous on the library stream. */
+typedef struct dl4ds_gather_group {
+    const float* src_dev; int channels; int frames; int src_h; int src_w; int raw; int origin_from_crop; int row_div;
+    dl4ds_tap_axis taps[2];
+} dl4ds_gather_group;
+int dl4ds_batch_gather(const dl4ds_gather_group* groups, int n_groups, const int* idx_host, const int* cy_host,
+                       const int* cx_host, float* out_dev, int out_h, int out_w, int T, int B);
 
 /* ---------------------------------------------------------------- data parallelism (RCCL over xGMI)
  * replaces Horovod: hvd.init/rank/size (base.py:97-107), DistributedOptimizer / DistributedGradientTape

@@ -7,6 +7,9 @@ OpenCV is an un-vendored dependency of the reference (setup.py: opencv-python, u
 scale_x = src_w / dst_w (the same along y), for floating-point images:
 
 * INTER_AREA, scale >= 1 integer ("resizeAreaFast_"): dst[y, x] = mean of the scale_y x scale_x source block.
+* INTER_AREA, scale > 1 not an integer (computeResizeAreaTab): overlap-weighted mean of the source pixels a destination
+  cell covers, separably per axis (``_axis_area_down``); used whenever EITHER axis has a non-integer ratio.
+  True area resampling needs scale_x >= 1 AND scale_y >= 1: if either axis grows, BOTH take the next rule.
 * INTER_AREA, scale < 1 (up-scaling): OpenCV switches to the bilinear code path with its own coefficients:
   ``sx = floor(dx * scale_x); fx = (dx + 1) - (sx + 1) / scale_x; fx = fx <= 0 ? 0 : fx - floor(fx)``.
   For an INTEGER factor s = 1 / scale_x and dx = sx * s + k (0 <= k < s): fx = k + 1 - s <= 0, so fx = 0 and
@@ -29,11 +32,30 @@ POST = ['spc', 'rc', 'dc']
 
 # ----------------------------------------------------------------------------------------------- cv2.resize restated
 def _axis_area_down(n_src, n_dst):
-    s = n_src // n_dst
-    assert s * n_dst == n_src, 'INTER_AREA is restated for integer ratios only'
+    """INTER_AREA down-scaling along one axis.  Integer ratio ("resizeAreaFast_"): block means.  Any other ratio
+    (resize.cpp: computeResizeAreaTab / ResizeArea_): destination cell d covers [d scale, (d + 1) scale) of the source axis
+    (scale = n_src / n_dst); every source pixel contributes its OVERLAP with the cell, normalised by the cell width
+    min(scale, n_src - d scale) -- with OpenCV's rule that a partial overlap below 1e-3 of a pixel is dropped."""
     W = np.zeros((n_dst, n_src))
+    if n_src % n_dst == 0:
+        s = n_src // n_dst
+        for d in range(n_dst):
+            W[d, d * s:(d + 1) * s] = 1.0 / s
+        return W
+    scale = n_src / n_dst
     for d in range(n_dst):
-        W[d, d * s:(d + 1) * s] = 1.0 / s
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, n_src - f1)
+        s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+        s2 = min(s2, n_src - 1)
+        s1 = min(s1, s2)
+        if s1 - f1 > 1e-3:
+            W[d, s1 - 1] += (s1 - f1) / cell
+        for sx in range(s1, s2):
+            W[d, sx] += 1.0 / cell
+        if f2 - s2 > 1e-3:
+            W[d, s2] += min(min(f2 - s2, 1.0), cell) / cell
     return W
 
 
@@ -128,7 +150,9 @@ def cv2_resize(img, size_xy, interpolation):
         if n_src == n_dst:
             return np.eye(n_src)
         if interpolation == 'inter_area':
-            return _axis_area_down(n_src, n_dst) if n_dst < n_src else _axis_area_up(n_src, n_dst)
+            # true area resampling only when NEITHER axis grows (resize.cpp: `scale_x >= 1 && scale_y >= 1`); otherwise BOTH
+            # axes run the bilinear path with the "area" coefficients, whose formula holds at any ratio
+            return _axis_area_down(n_src, n_dst) if (n_dst < n_src and not any_grows) else _axis_area_up(n_src, n_dst)
         if interpolation == 'nearest':
             return _axis_nearest(n_src, n_dst)
         if interpolation == 'bilinear':
@@ -138,8 +162,7 @@ def cv2_resize(img, size_xy, interpolation):
         if interpolation == 'lanczos':
             return _axis_lanczos4(n_src, n_dst)
         raise NotImplementedError(f'cv2 interpolation {interpolation!r} is not restated')
-    if interpolation == 'inter_area' and ((size_y < h) != (size_x < w)) and size_y != h and size_x != w:
-        raise NotImplementedError('INTER_AREA with one axis shrinking and the other growing is not restated')
+    any_grows = size_y > h or size_x > w
     Wy, Wx = axis(h, size_y), axis(w, size_x)
     out = np.einsum('dy,yxc->dxc', Wy, a)
     out = np.einsum('ex,dxc->dec', Wx, out)

@@ -16,7 +16,8 @@ THE GRADIENT CRITERION (round 5: per ELEMENT).  Element i of parameter tensor k 
   distance of zero takes either branch depending on summation order, and every gradient entry that unit feeds moves by the
   unit's whole contribution.  The oracle therefore evaluates the gradient TWICE in fp64, with every derivative discontinuity
   (ReLU thresholds, hard-sigmoid clip points, the sign of the MAE residual, max-pooling ties) displaced by +BAND and by -BAND
-  relative to the magnitude of its argument (oracle/torch_ops.py: KINK); the reference is the mid-point.  Up to round 4 the
+  relative to the magnitude of its argument (oracle/torch_ops.py: KINK); the REFERENCE is a third fp64 evaluation with no
+  displacement (until the middle of round 5: the mid-point of the two, half a band away from the true gradient).  Up to round 4 the
   spread was granted to the whole tensor as one scalar |g+ - g-|_inf, so ONE entry next to a kink loosened the bound of every
   entry of its tensor (bands of 15 ... 61 % on the ConvLSTM cases); now only the entries that the two displaced
   evaluations actually disagree on get the allowance, each its own.  BAND = 2e-6 is >= 4x the forward error observed
@@ -56,14 +57,17 @@ ULPS = 64.0
 K_NOISE = 8.0
 
 
-def elementwise_slack(gp, gm, g32):
-    """(g+, g-, g_fp32) of one tensor -> (mid, band array, noise array) as the criterion above defines them."""
+def elementwise_slack(gp, gm, g32, g0=None):
+    """(g+, g-, g_fp32[, g0]) of one tensor -> (reference, band array, noise array) as the criterion above defines them.  ``g0``: the
+    fp64 gradient with NO displacement = the reference (without it: the mid-point of g+ and g-, which sits half a band away from
+    what an evaluation that does not cross the kink returns -- up to round 5's first half that alone put 0.8 % of net_pin's
+    entries "on slack" although the HIP path had not flipped any unit)."""
     gp, gm, g32 = (np.asarray(a, np.float64) for a in (gp, gm, g32))
-    mid = 0.5 * (gp + gm)
+    ref = 0.5 * (gp + gm) if g0 is None else np.asarray(g0, np.float64)
     band = np.abs(gp - gm)
-    dev = np.abs(g32 - mid)
+    dev = np.abs(g32 - ref)
     noise = np.maximum(dev, 1.4826 * float(np.median(dev))) if dev.size else dev
-    return mid, band, noise
+    return ref, band, noise
 
 
 def _terms(k, r, got, gscale, tol, ulps, band, noise, k_noise):
@@ -204,12 +208,13 @@ def _merge(parts, meta, names_by_prefix):
         gp = {k: tot['p' + sfx + '/' + k] for k in names}
         gm = {k: tot['m' + sfx + '/' + k] for k in names}
         g32 = {k: tot['f32' + sfx + '/' + k] for k in names}
-        es = {k: elementwise_slack(gp[k], gm[k], g32[k]) for k in names}
+        g0 = {k: tot['z' + sfx + '/' + k] for k in names}
+        es = {k: elementwise_slack(gp[k], gm[k], g32[k], g0[k]) for k in names}
         out['grads' + sfx] = {k: es[k][0] for k in names}
         out['band' + sfx] = {k: es[k][1] for k in names}
         out['noise' + sfx] = {k: es[k][2] for k in names}
     lp, lm = tot['loss/p'], tot['loss/m']
-    out['losses'] = 0.5 * (lp + lm)
+    out['losses'] = tot['loss/z']
     out['loss_spread'] = float(np.abs(lp - lm).max())
     out['loss'] = float(out['losses'][0])
     if any('pred' in (p.files if hasattr(p, 'files') else p) for p in parts):
@@ -226,22 +231,23 @@ def _merge(parts, meta, names_by_prefix):
 
 
 def banded_reference(call, band=BAND):
-    """The same reference for ANY oracle evaluation: ``call(dtype)`` -> (losses, {name: gradient}, prediction) is run
-    under +band and -band in fp64 and once in fp32 (whole batch at once: batch statistics and batch-wide losses allowed).
+    """The same reference for ANY oracle evaluation: ``call(dtype)`` -> (losses, {name: gradient}, prediction) is run in fp64
+    undisplaced (the reference) and under +band and -band, and once in fp32 (whole batch at once: batch statistics and batch-wide
+    losses allowed).
     -> dict(loss, losses, loss_spread, pred, grads, band, noise)."""
     from oracle import torch_ops as T
     res = {}
-    for tag, shift, dt in (('p', +band, np.float64), ('m', -band, np.float64), ('f32', 0.0, np.float32)):
+    for tag, shift, dt in (('p', +band, np.float64), ('m', -band, np.float64), ('z', 0.0, np.float64), ('f32', 0.0, np.float32)):
         with T.kink_shift(shift):
             lv, g, pred = call(dt)
         res[tag] = (np.atleast_1d(np.asarray(lv, np.float64)), {k: _np(v).astype(np.float64) for k, v in g.items() if v is not None},
                     None if pred is None else _np(pred).astype(np.float64))
     names = list(res['p'][1])
-    es = {k: elementwise_slack(res['p'][1][k], res['m'][1][k], res['f32'][1][k]) for k in names}
+    es = {k: elementwise_slack(res['p'][1][k], res['m'][1][k], res['f32'][1][k], res['z'][1][k]) for k in names}
     return dict(grads={k: es[k][0] for k in names}, band={k: es[k][1] for k in names}, noise={k: es[k][2] for k in names},
-                losses=0.5 * (res['p'][0] + res['m'][0]), loss=float(0.5 * (res['p'][0][0] + res['m'][0][0])),
+                losses=res['z'][0], loss=float(res['z'][0][0]),
                 loss_spread=float(np.abs(res['p'][0] - res['m'][0]).max()),
-                pred=None if res['p'][2] is None else plain_forward(call))
+                pred=res['z'][2])
 
 
 def plain_forward(call):

@@ -4,8 +4,9 @@
 
 The job file holds the model kind / configuration (JSON), the weights by name, the inputs and -- for a CGAN step -- the
 discriminator's weights and dropout mask.  Sample i of the batch is handled by worker i % n.  Per sample the worker runs
-  * the fp64 torch oracle twice, with every derivative discontinuity displaced by +band and by -band
-    (oracle/torch_ops.py: KINK), and
+  * the fp64 torch oracle with no displacement ('z': THE reference gradient),
+  * twice more in fp64 with every derivative discontinuity displaced by +band and by -band (oracle/torch_ops.py: KINK): their
+    difference is the per-entry allowance for a unit the two sides of whose kink lie within rounding distance, and
   * once in fp32 (band 0): what an independent single-precision evaluation of the same graph yields,
 and returns the sums over its samples.  Losses that are batch means and models without batch statistics only."""
 import json
@@ -47,7 +48,7 @@ def run_job(job, meta, mine):
     v_shape = {}
     for i in mine:
         sl = slice(i, i + 1)
-        for tag, shift, dt in (('p', +band, np.float64), ('m', -band, np.float64), ('f32', 0.0, np.float32)):
+        for tag, shift, dt in (('p', +band, np.float64), ('m', -band, np.float64), ('z', 0.0, np.float64), ('f32', 0.0, np.float32)):
             with T.kink_shift(shift):
                 if meta['what'] == 'supervised':
                     PT = params('w', dt)

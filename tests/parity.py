@@ -28,6 +28,32 @@ CAP_OVERRIDES = {
 REPORT_ONLY = os.environ.get('DL4DS_PARITY_REPORT_ONLY', '') == '1'       # collect the artefact without asserting the caps (tuning runs)
 
 
+# ---- inputs on which the reference is well defined --------------------------------------------------------------------------
+# The gradient of these networks is discontinuous wherever a ReLU / hard-sigmoid / max-pool / |.| argument sits on its kink, and on
+# the small grids of the model tests (a few hundred pixels per gradient sum) one such unit moves whole filters by percents.  The
+# oracle itself says whether a set of inputs has such a unit: its two displaced evaluations then disagree (band_i > 0).  Tests
+# that can draw their inputs freely take the FIRST seed of a fixed list for which the oracle grants no entry more than
+# QUIET_LIMIT of its tensor's size -- a selection made from the oracle alone, before any result of the HIP path is looked at --
+# and are then held to the caps like every other comparison (with nothing granted, every entry has to pass on 1e-3 itself).
+QUIET_LIMIT = 5e-4
+QUIET_SEEDS = 12
+
+
+def is_quiet(ref, limit=QUIET_LIMIT):
+    return all(slack_report(ref, key)[0][0] < limit for key in ('grads', 'gradsG', 'gradsD') if key in ref)
+
+
+def first_quiet(attempt, first_seed, n=QUIET_SEEDS, ref_of=lambda out: out[-1]):
+    """``attempt(seed)`` -> tuple whose last item is the oracle's reference (see ``ref_of``).  Returns attempt's result for the
+    first of the seeds first_seed, first_seed + 1, ... whose reference is quiet; the last attempt's if none is."""
+    out = None
+    for seed in range(first_seed, first_seed + n):
+        out = attempt(seed)
+        if is_quiet(ref_of(out)):
+            break
+    return out
+
+
 def record(what, rows, full=False):
     """Summary of a comparison (and, for the BASELINE-size ones, every tensor's row) for the session's parity artefact."""
     entry = summarize(rows)

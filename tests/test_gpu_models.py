@@ -9,7 +9,7 @@ from oracle import np_ops as N
 from oracle import torch_ops as T
 from oracle import models as M
 from oracle import train as TR
-from tests.parity import (assert_grads_close, assert_matches_reference, banded_reference, oracle_reference,
+from tests.parity import (BAND, assert_grads_close, assert_matches_reference, banded_reference, first_quiet, oracle_reference,
                           targets_clear_of_the_kink)
 
 pytestmark = pytest.mark.gpu
@@ -99,11 +99,15 @@ SUP_CASES = [
 
 
 def tie_free_inputs(kind, P, ocfg, xs, ss, first_seed=5):
-    """Seeded inputs for which no ReLU input of the fp64 oracle lies within 3e-7 (relative, ~ fp32 rounding of a K-term sum) of zero.  Such a value
-    (seen: |pre| = 5e-8 at scale 0.7 for seed 5 on net_pin) takes either branch depending on fp32 summation order, so
-    the comparison would test the tie and not the kernels.  Returns (rng, x, s, oracle forward)."""
+    """Seeded inputs for which no ReLU input of the fp64 oracle lies within 1.25 BAND = 2.5e-6 (relative to the largest one of its
+    layer: the oracle's own normalisation of the displacement, oracle/torch_ops.py) of zero.  Such a value (seen: |pre| = 5e-8 at
+    scale 0.7 for seed 5 on net_pin) takes either branch depending on fp32 summation order, so the comparison would test the tie
+    and not the kernels; with none inside the band the oracle's two displaced evaluations agree and NOTHING is granted to any
+    entry (round 4 searched at 3e-7 only: units between that and the band left 0.8 % of net_pin's entries on slack).
+    Returns (rng, x, s, oracle forward)."""
     orig = N.relu
-    for seed in range(first_seed, first_seed + 20):
+    best = None
+    for seed in range(first_seed, first_seed + 12):
         rng = np.random.default_rng(seed)
         x = rng.standard_normal(xs).astype(np.float32)
         s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
@@ -118,9 +122,19 @@ def tie_free_inputs(kind, P, ocfg, xs, ss, first_seed=5):
             ref = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), **ocfg)
         finally:
             N.relu = orig
-        if not margins or min(margins) > 3e-7:
-            return rng, x, s, ref
-    raise AssertionError('no tie-free seed found')
+        m = min(margins) if margins else 1.0
+        if best is None or m > best[0]:
+            best = (m, seed, x, s, ref)
+        if m > 1.25 * BAND:
+            break
+    # (models with ~10^6 ReLU units have no seed without a unit inside the band: the seed whose closest unit is farthest is
+    #  taken, and the few entries that unit feeds are what the per-element band is for -- the caps of tests/parity.py apply)
+    _, seed, x, s, ref = best
+    rng = np.random.default_rng(seed)
+    rng.standard_normal(xs)
+    if ss is not None:
+        rng.standard_normal(ss)
+    return rng, x, s, ref
 
 
 @pytest.mark.parametrize('kind,cfg,xs,ss', SUP_CASES)
@@ -417,24 +431,28 @@ def test_cgan_step_matches_oracle():
         PG[k] = v.astype(np.float64)
     for k, v in disc.get_weights().items():
         PD[k] = v.astype(np.float64)
-    lr = rng.random((B, H, H, 3)).astype(np.float32)
-    st = rng.random((B, H, H, 1)).astype(np.float32)
-    hr = rng.random((B, H, H, 1)).astype(np.float32)
-    mask = (rng.random((2 * B, 8)) > 0.4).astype(np.float32)
+    g0, d0 = gen.get_weights(), disc.get_weights()
+
+    def draw(seed):
+        r = np.random.default_rng(seed)
+        lr = r.random((B, H, H, 3)).astype(np.float32)
+        st = r.random((B, H, H, 1)).astype(np.float32)
+        hr = r.random((B, H, H, 1)).astype(np.float32)
+        mask = (r.random((2 * B, 8)) > 0.4).astype(np.float32)
+        return lr, st, hr, mask, _cgan_banded('unet_pin', gcfg, g0, dcfg, d0, lr, hr, st, mask)
+    lr, st, hr, mask, bref = first_quiet(draw, 90)           # (inputs on which the oracle's reference is well defined)
     PGt, PDt = M.convert(PG, T, requires_grad=True), M.convert(PD, T, requires_grad=True)
     optG, optD = TR.Adam(PGt, lr=2e-4, beta1=0.5), TR.Adam(PDt, lr=2e-4, beta1=0.5)
     t64 = lambda a: T.asarray(a.astype(np.float64))
     ref = TR.cgan_step('unet_pin', gcfg, PGt, dcfg, PDt, t64(lr), t64(hr), t64(st),
                        dropout_masks=(t64(mask[:B]), t64(mask[B:])), optG=optG, optD=optD)
     eng = CGANEngine(gen, disc, loss='mae', learning_rate=2e-4, beta_1=0.5)
-    g0, d0 = gen.get_weights(), disc.get_weights()
     out = eng.step([lr, st], hr, dropout_keep=mask)
     assert out[0] == pytest.approx(ref['gen_total'], rel=1e-4)
     assert out[1] == pytest.approx(ref['gen_gan'], rel=1e-4)
     assert out[2] == pytest.approx(ref['gen_px'], rel=1e-4)
     assert out[3] == pytest.approx(ref['disc'], rel=1e-4)
     gg, gd = gen.get_gradients(), disc.get_gradients()
-    bref = _cgan_banded('unet_pin', gcfg, g0, dcfg, d0, lr, hr, st, mask)
     assert_matches_reference({'G:' + k: v for k, v in gg.items()} | {'D:' + k: v for k, v in gd.items()}, bref, what='cgan')
     # first Adam step = -lr * sign(g) (to eps): compare against the oracle's updated weights
     for m, P0, Pt in ((gen, g0, PGt), (disc, d0, PDt)):
@@ -543,14 +561,20 @@ def test_cgan_step_discriminator_variants(gkind, gcfg, dcfg, lr_hw, scale, tw):
         PG[k] = v.astype(np.float64)
     for k, v in disc.get_weights().items():
         PD[k] = v.astype(np.float64)
-    lr = rng.random((B,) + lead + (h, w, n_ch)).astype(np.float32)
-    st = rng.random((B, H, W, 1)).astype(np.float32)
-    hr = rng.random((B,) + lead + (H, W, 1)).astype(np.float32)
     nf_merge = 2 * dcfg['n_filters']
-    mask = (rng.random((2 * B, nf_merge)) > 0.4).astype(np.float32)
+    ocfg = dict(dcfg, lr_size=(h, w))
+    g0, d0 = gen.get_weights(), disc.get_weights()
+
+    def draw(seed):
+        r = np.random.default_rng(seed)
+        lr = r.random((B,) + lead + (h, w, n_ch)).astype(np.float32)
+        st = r.random((B, H, W, 1)).astype(np.float32)
+        hr = r.random((B,) + lead + (H, W, 1)).astype(np.float32)
+        mask = (r.random((2 * B, nf_merge)) > 0.4).astype(np.float32)
+        return lr, st, hr, mask, _cgan_banded(gkind, gcfg, g0, ocfg, d0, lr, hr, st, mask)
+    lr, st, hr, mask, bref = first_quiet(draw, 90)           # (inputs on which the oracle's reference is well defined)
     PGt, PDt = M.convert(PG, T, requires_grad=True), M.convert(PD, T, requires_grad=True)
     t64 = lambda a: T.asarray(a.astype(np.float64))
-    ocfg = dict(dcfg, lr_size=(h, w))
     ref = TR.cgan_step(gkind, gcfg, PGt, ocfg, PDt, t64(lr), t64(hr), t64(st),
                        dropout_masks=(t64(mask[:B]), t64(mask[B:])))
     assert set(PD.keys()) == set(ref['gradsD'].keys())
@@ -559,7 +583,6 @@ def test_cgan_step_discriminator_variants(gkind, gcfg, dcfg, lr_hw, scale, tw):
     for i, k in enumerate(('gen_total', 'gen_gan', 'gen_px', 'disc')):
         assert out[i] == pytest.approx(ref[k], rel=1e-4), k
     gg, gd = gen.get_gradients(), disc.get_gradients()
-    bref = _cgan_banded(gkind, gcfg, gen.get_weights(), ocfg, disc.get_weights(), lr, hr, st, mask)
     assert_matches_reference({'G:' + k: v for k, v in gg.items()} | {'D:' + k: v for k, v in gd.items()}, bref,
                              what=(gkind, dcfg))
     if dcfg.get('normalization') == 'bn':
@@ -631,24 +654,28 @@ def test_normalization_and_dropout_variants(kind, cfg, var, xs, ss):
     device), BatchNormalization moving averages after the step, and the inference-mode forward afterwards."""
     from dl4ds_amd.training import SupervisedEngine
     model, P, ocfg = build_pair(kind, cfg, xs, ss, ctx_kw=var)
-    rng = np.random.default_rng(21)
-    x = rng.standard_normal(xs).astype(np.float32)
-    s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
-    inputs = [x] if s is None else [x, s]
     B = xs[0]
-    # the oracle declares how many noise arrays it consumes and their shapes
-    probe = M.Ctx(training=True, **var)
-    ref_shape = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), ctx=probe,
-                               **ocfg).shape
     g = model.graph
-    y = rng.standard_normal(ref_shape).astype(np.float32)
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     w_before = model.get_weights()
-    l_hip, g_hip = eng.loss_and_grads(inputs, y)
-    n_drop = g.dropout_count()
-    assert n_drop == len(probe.noise_shapes)
-    noises = [g.dropout_mask(i, B).reshape(shp) for i, shp in enumerate(probe.noise_shapes)]
     rate = var.get('dropout_rate', 0)
+
+    def attempt(seed):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal(xs).astype(np.float32)
+        s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
+        inputs = [x] if s is None else [x, s]
+        probe = M.Ctx(training=True, **var)        # the oracle declares how many noise arrays it consumes and their shapes
+        ref_shape = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), ctx=probe,
+                                   **ocfg).shape
+        y = rng.standard_normal(ref_shape).astype(np.float32)
+        model.set_weights(w_before)                          # (an earlier attempt has moved the BatchNormalization averages)
+        l_hip, g_hip = eng.loss_and_grads(inputs, y)
+        assert g.dropout_count() == len(probe.noise_shapes)
+        noises = [g.dropout_mask(i, B).reshape(shp) for i, shp in enumerate(probe.noise_shapes)]
+        return x, s, inputs, y, l_hip, g_hip, noises, probe, _banded_pass(kind, ocfg, P, x, s, y, 'mae', var, noises)
+    # inputs (and the device's own dropout draw) for which the oracle's reference is well defined: tests/parity.first_quiet
+    x, s, inputs, y, l_hip, g_hip, noises, probe, bref = first_quiet(attempt, 21)
     for nz in noises:                                        # the noise has the statistics the layer promises
         if set(np.unique(nz)) <= {0.0, 1.0}:                 # keep mask (ConvBlock_att always uses plain Dropout)
             if nz.size > 2000:
@@ -659,7 +686,7 @@ def test_normalization_and_dropout_variants(kind, cfg, var, xs, ss):
                 assert abs(nz.mean() - 1) < 0.05 and abs(nz.std() - np.sqrt(rate / (1 - rate))) < 0.05
     lv, grads, pred, ctx = _oracle_pass(kind, ocfg, P, x, s, y, 'mae', var, noises)
     assert l_hip == pytest.approx(lv, rel=1e-4)
-    assert_matches_reference(g_hip, _banded_pass(kind, ocfg, P, x, s, y, 'mae', var, noises), what=(kind, var))
+    assert_matches_reference(g_hip, bref, what=(kind, var))
     w_after = model.get_weights()
     for k in w_after:
         if k.endswith(('moving_mean', 'moving_variance')):
@@ -766,22 +793,26 @@ def test_random_builder_combinations(i):
     kind, cfg, var, xs, ss = _random_combo(i) if i < 28 else _random_rec_combo(i - 28)
     var = {k: v for k, v in var.items() if v not in (None, 0)}
     model, P, ocfg = build_pair(kind, cfg, xs, ss, ctx_kw=var or None)
-    rng = np.random.default_rng(77 + i)
-    x = rng.standard_normal(xs).astype(np.float32)
-    s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
-    inputs = [x] if s is None else [x, s]
-    probe = M.Ctx(training=True, **var)
-    ref_shape = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), ctx=probe,
-                               **ocfg).shape
-    y = rng.standard_normal(ref_shape).astype(np.float32)
     eng = SupervisedEngine(model, loss='mse', learning_rate=1e-3)
-    l_hip, g_hip = eng.loss_and_grads(inputs, y)
     g = model.graph
-    assert g.dropout_count() == len(probe.noise_shapes)
-    noises = [g.dropout_mask(k, xs[0]).reshape(shp) for k, shp in enumerate(probe.noise_shapes)]
+
+    def attempt(seed):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal(xs).astype(np.float32)
+        s = None if ss is None else rng.standard_normal(ss).astype(np.float32)
+        inputs = [x] if s is None else [x, s]
+        probe = M.Ctx(training=True, **var)
+        ref_shape = M.MODELS[kind](N, P, x.astype(np.float64), None if s is None else s.astype(np.float64), ctx=probe,
+                                   **ocfg).shape
+        y = rng.standard_normal(ref_shape).astype(np.float32)
+        l_hip, g_hip = eng.loss_and_grads(inputs, y)
+        assert g.dropout_count() == len(probe.noise_shapes)
+        noises = [g.dropout_mask(k, xs[0]).reshape(shp) for k, shp in enumerate(probe.noise_shapes)]
+        return x, s, y, l_hip, g_hip, noises, _banded_pass(kind, ocfg, P, x, s, y, 'mse', var, noises)
+    x, s, y, l_hip, g_hip, noises, bref = first_quiet(attempt, 77 + 100 * i)
     lv, grads, pred, ctx = _oracle_pass(kind, ocfg, P, x, s, y, 'mse', var, noises)
     assert l_hip == pytest.approx(lv, rel=2e-4), (kind, cfg, var)
-    assert_matches_reference(g_hip, _banded_pass(kind, ocfg, P, x, s, y, 'mse', var, noises), what=(kind, cfg, var))
+    assert_matches_reference(g_hip, bref, what=(kind, cfg, var))
 
 
 def _fusion_report(model, B):

@@ -70,15 +70,46 @@ def test_lanczos4_known_answers():
     np.testing.assert_array_equal(O.cv2_resize(x, (10, 1), 'lanczos'), x)
 
 
+def test_inter_area_with_one_growing_axis_takes_the_bilinear_path_on_both():
+    """resize.cpp runs true INTER_AREA only when neither axis grows; otherwise BOTH axes use the bilinear path with the "area"
+    coefficients sx = floor(dx s), fx = (dx + 1) - (sx + 1) / s clipped to [0, 1).  1 x 6 ramp -> 2 x 2 (x shrinks by 3, y doubles):
+    fx = 2/3 at sx = 0 and 3 -> (0.667, 3.667), NOT the block means (1, 4) the same x axis yields when y does not grow."""
+    a = np.arange(6.0)[None, :]
+    np.testing.assert_allclose(O.cv2_resize(a, (2, 2), 'inter_area'), [[2 / 3, 3 + 2 / 3]] * 2, atol=1e-14)
+    np.testing.assert_allclose(O.cv2_resize(a, (2, 1), 'inter_area'), [[1.0, 4.0]], atol=1e-14)
+    np.testing.assert_allclose(O.cv2_resize(np.arange(4.0)[None, :], (2, 2), 'inter_area'), [[0.5, 2.5]] * 2, atol=1e-14)
+
+
+def test_inter_area_non_integer_ratio_known_answers():
+    """cv2.INTER_AREA at a non-integer ratio (resize.cpp computeResizeAreaTab): overlap-weighted means.  5 -> 2 pixels (scale 2.5):
+    cell 0 = [0, 2.5) holds pixels 0 and 1 whole and half of pixel 2 -> weights (1, 1, .5) / 2.5; the ramp 0..4 gives (0.8, 3.2), the
+    value OpenCV's documentation of the mode ("pixel area relation") implies and cv2 returns.  Rows sum to 1, a constant image stays
+    constant, one integer and one non-integer axis are resampled independently, and a partial overlap below 1e-3 pixel is DROPPED
+    (1001 -> 1000: cell 0 = [0, 1.001) keeps pixel 0 only, weight 1 / 1.001 -- OpenCV's table does not renormalise)."""
+    W = O._axis_area_down(5, 2)
+    np.testing.assert_allclose(W, [[0.4, 0.4, 0.2, 0, 0], [0, 0, 0.2, 0.4, 0.4]], atol=1e-15)
+    np.testing.assert_allclose(O.cv2_resize(np.arange(5.0)[None, :], (2, 1), 'inter_area'), [[0.8, 3.2]], atol=1e-14)
+    for ns, nd in ((7, 5), (100, 33), (512, 100), (9, 4)):
+        Wn = O._axis_area_down(ns, nd)
+        np.testing.assert_allclose(Wn.sum(1), 1.0, atol=1e-12)
+        assert (Wn >= 0).all() and np.count_nonzero(Wn, axis=1).max() <= int(np.ceil(ns / nd)) + 1
+        # every source pixel is used in full (column sums = n_dst / n_src each): the cells tile the axis
+        np.testing.assert_allclose(Wn.sum(0), nd / ns, atol=1e-12)
+    img = np.random.default_rng(0).standard_normal((9, 12))
+    out = O.cv2_resize(img, (4, 4), 'inter_area')                      # x: 12 -> 4 (block means of 3), y: 9 -> 4 (ratio 2.25)
+    np.testing.assert_allclose(out, O._axis_area_down(9, 4) @ img.reshape(9, 4, 3).mean(-1), atol=1e-14)
+    np.testing.assert_allclose(O.cv2_resize(np.full((7, 10), 2.5), (3, 5), 'inter_area'), 2.5, atol=1e-14)
+    W = O._axis_area_down(1001, 1000)
+    assert np.count_nonzero(W[0]) == 1 and W[0, 0] == pytest.approx(1 / 1.001, rel=1e-12)
+    assert np.count_nonzero(W[1]) == 2 and W[1, 1] == pytest.approx(0.999 / 1.001, rel=1e-9)
+
+
 @pytest.mark.parametrize('interp', ['inter_area', 'nearest', 'bilinear', 'bicubic', 'lanczos'])
-@pytest.mark.parametrize('shape,new', [((12, 8, 3), (4, 6)), ((6, 9, 1), (27, 12)), ((10, 10, 2), (10, 5)), ((4, 6), (18, 8))])
+@pytest.mark.parametrize('shape,new', [((12, 8, 3), (4, 6)), ((6, 9, 1), (27, 12)), ((10, 10, 2), (10, 5)), ((4, 6), (18, 8)),
+                                       ((10, 7, 2), (5, 3)), ((100, 50, 1), (16, 33)), ((9, 9), (4, 9))])
 def test_product_resize_equals_oracle(interp, shape, new):
     a = np.random.default_rng(1).standard_normal(shape)
     sx, sy = new
-    if interp == 'inter_area' and ((shape[0] % sy and sy < shape[0]) or (shape[1] % sx and sx < shape[1])):
-        pytest.skip('INTER_AREA down-scaling is restated for integer ratios only')
-    if interp == 'inter_area' and (sy < shape[0]) != (sx < shape[1]):
-        pytest.skip('mixed shrink / grow')
     ref = O.resize_array(a, new, interp, squeezed=False)
     got = D.resize_array(a, new, interp, squeezed=False)
     assert got.shape == ref.shape

@@ -72,8 +72,9 @@ def test_criterion_still_rejects_wrong_gradients():
 
 def test_band_is_granted_to_the_entries_next_to_the_kink_only():
     """one entry near a kink must not loosen the bound of its whole tensor.  y_j = relu(w_j * x_j) with entry 1 tied:
-    a 30 % error passes on the tied entry's own band (its two displaced evaluations differ by the whole contribution), the same
-    error on the entry next to it fails, and the breakdown counts exactly one entry on slack."""
+    an evaluation that takes the other branch of the tied unit passes on that entry's own band (its two displaced evaluations
+    differ by the unit's whole contribution), the same deviation on the entry next to it fails, and the breakdown counts exactly
+    one entry on slack.  The reference itself is the UNDISPLACED gradient: an evaluation that does not cross the kink needs no slack."""
     from tests.parity import assert_caps, breakdown
     x = np.asarray([2.0, 1e-9, -1.0, 0.75])             # (0.75: exact in fp32, so the noise term of that entry is zero)
 
@@ -84,8 +85,9 @@ def test_band_is_granted_to_the_entries_next_to_the_kink_only():
         return float(loss), {'w': torch.autograd.grad(loss, wt)[0]}, out.detach()
     ref = banded_reference(call)
     assert ref['band']['w'].tolist() == pytest.approx([0.0, 1e-9, 0.0, 0.0])
-    g = ref['grads']['w'].copy()                                  # mid-point: [2, 0.5e-9, 0, 0.75]
-    on = g.copy(); on[1] = 1e-9                                   # the tied unit switched on: inside its own band
+    g = ref['grads']['w'].copy()                                  # the undisplaced gradient: [2, 1e-9, 0, 0.75] (the tied unit is on)
+    assert g.tolist() == pytest.approx([2.0, 1e-9, 0.0, 0.75])
+    on = g.copy(); on[1] = 0.0                                    # the tied unit switched OFF by a rounding error: inside its own band
     assert not grad_failures({'w': on}, ref['grads'], band=ref['band'], noise=ref['noise'], ulps=0.0, tol=1e-12)
     off = g.copy(); off[3] += 1e-9                                # the same deviation on an entry with no kink nearby
     fails = grad_failures({'w': off}, ref['grads'], band=ref['band'], noise=ref['noise'], ulps=0.0, tol=1e-12)
