@@ -799,7 +799,12 @@ constexpr int narrow16_wps(int epi) {
     return (epi >= 0 && ((epi & 1) + ((epi >> 2) & 1) + ((epi >> 3) & 1)) <= 2) ? 4 : 2;
 #endif
 }
-template <int NR, int EPI>      // EPI: compiled epilogue form (PAIR_EPI_* bits) or -1 = run-time, as in conv_narrow_pair_ws_kernel
+// C8 (round 5): the form for <= 8 INPUT channels (8 -> 13: the dgrad of ConvBlock_att's first layer in the recurrent nets).  With the
+// 16-channel K layout half of every MFMA's k-slots met zero pixels (36 MFMAs per output row for 9 x 8 channels of work).  Here k-slots
+// 0, 1 carry the two channel quads of tap 2j and k-slots 2, 3 those of tap 2j + 1: the nine taps take FIVE groups of four MFMAs
+// per output row (the tenth half-group has a zero filter), each lane reading the pixel of ITS tap (one ds_read_b128 per group at a
+// per-lane offset); pixels are staged 8 floats apart (two 16-byte slots: conflict-free by the same rule as the pitch of 24).
+template <int NR, int EPI, bool C8 = false>      // EPI: compiled epilogue form (PAIR_EPI_* bits) or -1 = run-time, as in conv_narrow_pair_ws_kernel
 __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kernel(const ConvParams a) {
     const bool f_add = EPI < 0 ? a.add.p != nullptr : (EPI & PAIR_EPI_ADD) != 0;
     const bool f_relu = EPI < 0 ? a.relu != 0 : (EPI & PAIR_EPI_RELU) != 0;
@@ -814,8 +819,9 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
     // floats per staged pixel: 6 x 16 bytes.  ds_read_b128 is serviced in four non-contiguous 16-lane groups that mix eight
     // pixels of one k-slot with the other eight of the next (MI355X_MICROARCH.md, LDS): with the k-slots one 16-byte slot apart
     // the 16 lanes cover all 64 banks iff the pitch is 2 (mod 4) slots; the odd pitch (20 floats) lost 0.46 of the LDS cycles
-    constexpr int P = NARROW16_PITCH;
-    constexpr int TOTAL = HPIX * 4, ITERS = (TOTAL + 255) / 256;
+    constexpr int P = C8 ? 8 : NARROW16_PITCH;
+    constexpr int QPP = C8 ? 2 : 4;                               // channel quads staged per pixel
+    constexpr int TOTAL = HPIX * QPP, ITERS = (TOTAL + 255) / 256;
     constexpr int TILE = HPIX * P;
     constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
@@ -846,9 +852,10 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
 #ifdef PAIR_WS_LOADER_PRIO
         __builtin_amdgcn_s_setprio(PAIR_WS_LOADER_PRIO);
 #endif
-        // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 2) + 64 u, channel quad htid & 3)
+        // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 2) + 64 u, channel quad htid & 3)   [C8: htid >> 1, + 128 u, htid & 1]
         const int htid = tid & 255;
-        const int c4 = htid & 3, p0 = htid >> 2;
+        constexpr int PSTEP = 256 / QPP;
+        const int c4 = htid & (QPP - 1), p0 = htid / QPP;
         const size_t isx = a.in.ld, isy = (size_t)a.W * a.in.ld;
         // channel counts / pixel pitches that are not multiples of four (the 13-channel layer behind TransitionLast 26 -> 13,
         // 16-channel slices of a 26-channel concatenation): the 16-byte buffer loads only need dword alignment, what a quad
@@ -858,7 +865,7 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
         int rel[ITERS], soff[ITERS], hyx[ITERS];
 #pragma unroll
         for (int u = 0; u < ITERS; ++u) {
-            const int pix = p0 + 64 * u;
+            const int pix = p0 + PSTEP * u;
             const int hy = pix / TWH, hx = pix - hy * TWH;
             const bool live = pix < HPIX && c4 * 4 < a.Cin;
             hyx[u] = pix < HPIX ? ((hy << 8) | hx) : 0x7f7f;
@@ -893,7 +900,7 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
             float* d0 = tile + p0 * P + c4 * 4;
 #pragma unroll
             for (int u = 0; u < ITERS; ++u)
-                if (u + 1 < ITERS || (hyx[u] >> 8) < THH) *reinterpret_cast<i32x4_t*>(d0 + u * (64 * P)) = src[u];
+                if (u + 1 < ITERS || (hyx[u] >> 8) < THH) *reinterpret_cast<i32x4_t*>(d0 + u * (PSTEP * P)) = src[u];
         };
         size_t hosx, hosy;
         {
@@ -940,17 +947,36 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
     // ---- MFMA waves: filter fragment (tap, e) = W[tap][cin = 4 lq + e][cout = l15]
     const int wave = wave8 & 3;
     const int l15 = lane & 15, lq = lane >> 4;
-    float wr[9][4];
+    constexpr int NWR = C8 ? 5 : 9;
+    float wr[NWR][4];
+    int toff[C8 ? 5 : 1];                                         // C8: float offset of this lane's tap of pair j inside the halo tile
+    if constexpr (C8) {
+        const int hi = lq >> 1, cq = lq & 1;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int j = 0; j < 5; ++j) {
+            const int tap = 2 * j + hi;
+            toff[j] = tap < 9 ? ((tap / 3) * TWH + (tap % 3)) * P : 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ci = 4 * lq + e;
-            const bool ok = ci < a.Cin && l15 < a.Cout;
-            const float v = a.w[((size_t)t * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? l15 : 0)];
-            wr[t][e] = ok ? v : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const int ci = 4 * cq + e;
+                const bool ok = tap < 9 && ci < a.Cin && l15 < a.Cout;
+                const float v = a.w[((size_t)(ok ? tap : 0) * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? l15 : 0)];
+                wr[j][e] = ok ? v : 0.f;
+            }
         }
-    const int rd_off = ((wave * NR) * TWH + l15) * P + 4 * lq;
+    } else {
+        toff[0] = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = 4 * lq + e;
+                const bool ok = ci < a.Cin && l15 < a.Cout;
+                const float v = a.w[((size_t)t * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? l15 : 0)];
+                wr[t][e] = ok ? v : 0.f;
+            }
+    }
+    const int rd_off = ((wave * NR) * TWH + l15) * P + 4 * (C8 ? (lq & 1) : lq);
     // lane (pixel column l15, k-slot lq) ends with rows 4 lq + r = couts 4 lq .. 4 lq + 3 of its pixel
     const int ec = 4 * lq;
     const bool c_ok = ec < a.Cout;
@@ -1009,6 +1035,27 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
             }
         }
         f32x4 acc[NR];
+        if constexpr (C8) {
+            f32x4 pw[2][5];                                       // pixel fragments of the five tap pairs, ONE output row ahead
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pw[0][j] = *reinterpret_cast<const f32x4*>(rd + toff[j]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (r + 1 < NR) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) pw[(r + 1) & 1][j] = *reinterpret_cast<const f32x4*>(rd + (r + 1) * TWH * P + toff[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const f32x4 v = pw[r & 1][j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][e], v[e], (j == 0 && e == 0) ? bias_c : acc[r], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         f32x4 pv[2][3];                                           // pixel fragments, ONE halo row ahead of the MFMAs that use them
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) pv[0][dx] = *reinterpret_cast<const f32x4*>(rd + dx * P);
@@ -1035,6 +1082,7 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         __syncthreads();                                          // X
         if (!PRE) {
@@ -1124,6 +1172,21 @@ bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
     static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;                     // (A/B)
     p.CK = no_xcd ? 0 : 1;
     auto grid_of = [&](int resident) { const int b = std::min(ntiles, resident); return b >= 8 ? (b & ~7) : b; };
+    // <= 8 input channels: the five-group form (round 5), compiled for the epilogue forms such layers have -- plain, ReLU, ReLU mask,
+    // accumulate and their pairs; the others take the run-time form of it.  DL4DS_NARROW16_NO_C8=1 for A/B.
+    static const bool no_c8 = getenv("DL4DS_NARROW16_NO_C8") != nullptr;
+    if (p.Cin <= 8 && !no_c8) {
+#define NARROW16_C8_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow16_ws_kernel<NR, E_, true>), \
+        dim3(grid_of(resident_blocks<conv_narrow16_ws_kernel<NR, E_, true>>(512))), dim3(512), 0, s, p); break;
+        switch (epi) {
+            NARROW16_C8_FORM(0) NARROW16_C8_FORM(2) NARROW16_C8_FORM(4) NARROW16_C8_FORM(6) NARROW16_C8_FORM(8) NARROW16_C8_FORM(12)
+            default: DL4DS_LAUNCH((conv_narrow16_ws_kernel<NR, -1, true>), dim3(grid_of(resident_blocks<conv_narrow16_ws_kernel<NR, -1, true>>(512))),
+                                  dim3(512), 0, s, p); break;
+        }
+#undef NARROW16_C8_FORM
+        HIP_CHECK(hipGetLastError());
+        return true;
+    }
 #define NARROW16_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow16_ws_kernel<NR, E_>), \
         dim3(grid_of(resident_blocks<conv_narrow16_ws_kernel<NR, E_>>(512))), dim3(512), 0, s, p); break;
     switch (epi) {

@@ -805,15 +805,13 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048), ng), dim3(256), 0, s, slab, part, n4, nslabs, per_group);
     HIP_CHECK(hipGetLastError());
     const int total = npair * KQ * NT * 64;
-    // round 5: the closing transform adds the <= 16 group sums itself, in the order of the groups (independent loads at known
-    // addresses) -- the separate launch that did it was one of 65 tiny launches of a cfg2 step.  DL4DS_WINO_WGRAD_TWO_SUMS=1 for A/B.
-    static const bool two_sums = getenv("DL4DS_WINO_WGRAD_TWO_SUMS") != nullptr;
-    if (two_sums) {
-        DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048), 1), dim3(256), 0, s, part, sum, n4, ng, ng);
-        HIP_CHECK(hipGetLastError());
-    }
-    DL4DS_LAUNCH(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, two_sums ? sum : part, dw, db, x.C, dy.C,
-                       KQ, NT, wp.ncin, wp.ncout, accumulate, accumulate_db, two_sums ? 1 : ng, per_k, wgrad_first_form() ? 0 : 1);
+    // (round 5, measured and dropped: the closing transform adding the <= 16 group sums itself -- ngroups = ng on `part` -- instead of
+    //  this second short launch: wino_wgrad_finish 0.20 -> 0.78 ms per cfg2 step, 5 020 -> 4 790 samples/s; its 16 x 16 strided
+    //  float4 loads per thread are far slower than the coalesced sum)
+    DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048), 1), dim3(256), 0, s, part, sum, n4, ng, ng);
+    HIP_CHECK(hipGetLastError());
+    DL4DS_LAUNCH(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, sum, dw, db, x.C, dy.C, KQ, NT,
+                       wp.ncin, wp.ncout, accumulate, accumulate_db, 1, per_k, wgrad_first_form() ? 0 : 1);
     HIP_CHECK(hipGetLastError());
     return true;
 }

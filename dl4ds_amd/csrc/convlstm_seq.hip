@@ -71,7 +71,16 @@ struct Geom {
     static constexpr int CIN = BWD ? 4 * F : F;             // channels of the staged tensor (dZ' : h)
     static constexpr int NQ = CIN / 4;                      // ... in quads
     static constexpr int RT = BWD ? 1 : F / 4;              // MFMA row tiles: 4F gate rows forward, F (<= 16) rows backward
-    static constexpr int KSTEPS = KS * KS * NQ;
+    // PAIR (round 5, backward with F = 8 and two pixel rows per wave): the 8 filters fill half of the MFMA's 16 rows; rows 8 .. 15
+    // take the SAME filters for the pixel ONE ROW BELOW, i.e. the filter displaced by one tap row -- K runs over (KS + 1) x KS
+    // taps, and one accumulator holds both pixel rows of the wave: 30 tap steps instead of 2 x 25 at 5 x 5, 12 instead of 18 at 3 x 3
+#ifdef DL4DS_SEQ_NO_PAIR
+    static constexpr bool PAIR = false;
+#else
+    static constexpr bool PAIR = BWD && F == 8 && TR == 2;
+#endif
+    static constexpr int NTY = PAIR ? KS + 1 : KS;          // tap rows of the K loop
+    static constexpr int KSTEPS = NTY * KS * NQ;
     static constexpr int W_FLOATS = KSTEPS * RT * 64;
     static constexpr int E = CIN / 4;                       // channels per MFMA k-slot and tap (see seq_chan)
     // floats per staged pixel.  ds_read_b128 is serviced in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, ...:
@@ -225,12 +234,12 @@ __device__ __forceinline__ void lds_pix(const float* p, float (&d)[E]) {
     }
 }
 
-template <int KS, int CIN, int RT, int TR, int TW>
+template <int KS, int CIN, int RT, int TR, int TW, int NTY = KS, int WROWS = TR>     // NTY tap rows; the wave's first pixel row is WROWS * wave
 __device__ __forceinline__ void seq_kloop(const float* wA, const float* tile, int lane, int wave, int n16, int q,
                                           f32x4_t (&acc)[RT][TR]) {
     constexpr int E = CIN / 4, P = CIN >= 16 ? CIN + 8 : CIN + 4;
     // k-slot q reads channels seq_chan(q, e): quads 4 q .. 4 q + 3 of every 16-channel group (one 16-byte slot per k-slot)
-    const float* bbase = tile + ((size_t)(TR * wave) * TW + n16) * P + (E >= 4 ? 4 : E) * q;
+    const float* bbase = tile + ((size_t)(WROWS * wave) * TW + n16) * P + (E >= 4 ? 4 : E) * q;
     // filter fragments: [tap][row tile][E / 4][lane][4] (E >= 4: every 16-byte read has the lanes side by side), else [tap][row tile][lane][E]
     const float* abase = wA + (size_t)lane * (E >= 4 ? 4 : E);
     float afA[RT][E], bfA[TR][E], afB[RT][E], bfB[TR][E];
@@ -260,13 +269,12 @@ __device__ __forceinline__ void seq_kloop(const float* wA, const float* tile, in
 #pragma unroll
                 for (int a = 0; a < RT; ++a) acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][e], bf[r][e], acc[a][r], 0, 0, 0);
     };
-    constexpr int NT = KS * KS;                  // odd: (NT - 1) / 2 pairs of taps, then the last tap -- no conditional inside the loop
-    static_assert(NT % 2 == 1, "tap count must be odd");
+    constexpr int NT = NTY * KS;                 // pairs of taps, then the last one (odd) or two (even) -- no conditional inside the loop
     int ky = 0, kx = 0;
     auto next = [&]() __attribute__((always_inline)) { if (++kx == KS) { kx = 0; ++ky; } };
     load(0, 0, 0, afA, bfA);
 #pragma unroll 1
-    for (int tap = 0; tap < NT - 1; tap += 2) {
+    for (int tap = 0; tap + 2 < NT; tap += 2) {
         next();
         load(tap + 1, ky, kx, afB, bfB);
         mma(afA, bfA);
@@ -274,7 +282,14 @@ __device__ __forceinline__ void seq_kloop(const float* wA, const float* tile, in
         load(tap + 2, ky, kx, afA, bfA);
         mma(afB, bfB);
     }
-    mma(afA, bfA);
+    if constexpr (NT % 2 == 0) {
+        next();
+        load(NT - 1, ky, kx, afB, bfB);
+        mma(afA, bfA);
+        mma(afB, bfB);
+    } else {
+        mma(afA, bfA);
+    }
 }
 
 // ================================================================================================ forward
@@ -412,8 +427,17 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParam
         int tap, a_, l, e;
         seq_wpos(E, 1, i, tap, a_, l, e);
         const int ci = l & 15, cc = seq_chan(E, l >> 4, e);
-        const int ftap = KS * KS - 1 - tap;                              // flipped tap
-        wA[i] = (ci < F) ? p.U[((size_t)ftap * F + ci) * C4 + cc] : 0.f;
+        if constexpr (G::PAIR) {
+            // row ci = (half, filter): half 0 = the wave's upper pixel row with tap row ky', half 1 = the row below, whose tap row
+            // ky' is tap row ky' - 1 of the filter
+            const int kyp = tap / KS, kx = tap - kyp * KS, half = ci >> 3, ky = kyp - half;
+            const bool ok = ky >= 0 && ky < KS;
+            const int ftap = KS * KS - 1 - ((ok ? ky : 0) * KS + kx);    // flipped tap
+            wA[i] = ok ? p.U[((size_t)ftap * F + (ci & 7)) * C4 + cc] : 0.f;
+        } else {
+            const int ftap = KS * KS - 1 - tap;                          // flipped tap
+            wA[i] = (ci < F) ? p.U[((size_t)ftap * F + ci) * C4 + cc] : 0.f;
+        }
     }
     __syncthreads();
     const int grid = gridDim.x;
@@ -430,9 +454,10 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParam
             const int y0 = ty * (4 * TR), x0 = tx * 16;
             const size_t fr = ((size_t)img * p.T + t) * hw;
             const int x = x0 + n16;
-            f32x4_t acc[1][TR];
+            constexpr int NACC = G::PAIR ? 1 : TR;                       // PAIR: one accumulator tile holds both pixel rows
+            f32x4_t acc[1][NACC];
 #pragma unroll
-            for (int r = 0; r < TR; ++r) acc[0][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < NACC; ++r) acc[0][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             // everything the gate arithmetic reads is requested right AFTER the halo has been staged, so that it arrives under
             // the K loop (vector memory returns in order: requested before the staging loads it would delay them).  The gate
             // work is spread over ALL lanes: lane (pixel n16, q) takes filters FPL q .. FPL q + FPL - 1 (FPL = F / 4), although
@@ -466,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParam
                 __syncthreads();
                 SEQ_MARK(2);
                 request();
-                seq_kloop<KS, C4, 1, TR, TW>(wA, tile, lane, wave, n16, q, acc);
+                seq_kloop<KS, C4, 1, NACC, TW, G::NTY, TR>(wA, tile, lane, wave, n16, q, acc);
             } else {
                 request();
             }
@@ -479,8 +504,14 @@ __global__ __launch_bounds__(256, 1) void convlstm_seq_bwd_kernel(const SeqParam
                 const int y = y0 + TR * wave + r;
                 // the recurrent part of dh for this lane's filters sits in lane src_lane, accumulator rows j0 .. j0 + FPL - 1
                 float rec[4];
+                if constexpr (G::PAIR) {
+                    // (rows 4 q' .. 4 q' + 3 of the one accumulator: q' = 0, 1 the upper pixel row's filters, q' = 2, 3 the lower one's)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rec[j] = (FPL == 4) ? acc[0][r][j] : __shfl(acc[0][r][j], src_lane, 64);
+                    for (int j = 0; j < 4; ++j) rec[j] = __shfl(acc[0][0][j], src_lane + 32 * r, 64);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rec[j] = (FPL == 4) ? acc[0][r][j] : __shfl(acc[0][r][j], src_lane, 64);
+                }
                 if (y < p.H && x < p.W) {
                     const size_t sp = ((size_t)img * hw + (size_t)y * p.W + x) * F + FPL * q;      // per-sample state (dc)
                     float dcout[FPL];

@@ -234,3 +234,72 @@ def test_watchdog_polling_path_on_a_one_rank_communicator():
         print('WATCHDOG-OK')
     ''', env={'DL4DS_FORCE_WATCHDOG': '1'})
     assert r.returncode == 0 and 'WATCHDOG-OK' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_bucket_plans_of_the_benchmark_models_are_the_plan_of_survey_8e():
+    """SURVEY section 8e as an invariant (VERDICT r4 #7): the gradient arena goes out in buckets ordered by backward completion.
+    cfg2 (0.82 MB): at least two buckets, and the one holding the arena's head -- the parameters the backward pass reaches last, i.e.
+    the collective nothing is left to hide -- is at most 256 KB.  cfg5's generator (54.3 MB): about a dozen buckets of a few MB,
+    the first one final while most of the backward pass is still to run; its discriminator (65 KB) is one small bucket.  The plan
+    depends on the parameter arena only, so the models are built on small grids."""
+    import bench
+    import dl4ds_amd.models as PM
+    m2 = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (16, 16), seed=7)
+    p2 = bench.bucket_plan(m2)
+    assert m2.count_params() == 204405 and sum(p2['bytes']) == 4 * 204405
+    assert p2['buckets'] >= 2
+    ready = p2['final_after_backward_of_op']
+    assert all(a >= b for a, b in zip(ready, ready[1:])), ready              # launch order = backward order (op indices fall)
+    assert p2['bytes'][-1] <= 256 * 1024 and ready[-1] == min(ready)         # the arena's head closes the step with a small message
+    gen = PM.unet_pin('unet', 5, 1, hr_size=(64, 64), n_filters=8, n_blocks=6, decoder_upsampling='dc', seed=7)
+    pg = bench.bucket_plan(gen)
+    assert gen.count_params() == 13566325 and sum(pg['bytes']) == 4 * 13566325
+    assert 8 <= pg['buckets'] <= 16, pg
+    assert max(pg['bytes']) <= 24 * 2 ** 20                                   # (Dec1's 21.2 MB deconvolution kernel is one tensor)
+    big = [b for b in pg['bytes'] if b >= 2 ** 20]
+    assert len(big) >= 6 and 2.5e6 <= float(np.median(big)) <= 8e6, pg['bytes']
+    ready = pg['final_after_backward_of_op']
+    assert all(a >= b for a, b in zip(ready, ready[1:])), ready
+    assert ready[0] > 0.5 * pg['forward_ops']                                 # the first collective starts in the first half of the backward pass
+    disc = PM.residual_discriminator(5, 'pin', False, 8, (8, 8), n_filters=8, hr_size=(64, 64), seed=8)
+    pd = bench.bucket_plan(disc)
+    assert sum(pd['bytes']) == 4 * disc.count_params() <= 80 * 1024 and pd['buckets'] <= 2
+
+
+def test_persistent_convlstm_beside_collective_standins_does_not_time_out():
+    """The persistent ConvLSTM recurrence needs all of its workgroups co-resident while kernels of the communication stream hold
+    CUs (ADVICE r3; csrc/convlstm_seq.hip reserves CUs when a communicator exists).  No second rank is reachable from one GPU, so the
+    collectives are played by DL4DS_DIST_STANDIN=1's stand-in kernels: every bucket launch of a 1-rank communicator is followed on
+    the communication stream by a kernel that reads and rewrites the bucket, concurrent with the rest of the backward pass.  Five
+    steps of a recurrent net: no spin gives up (the sticky device error word would fail a host wait), and losses and weights equal
+    the local run bit for bit."""
+    r = _run('''
+        import sys, numpy as np
+        sys.path.insert(0, %(root)r)
+        import dl4ds_amd.models as PM
+        from dl4ds_amd.training import SupervisedEngine
+        from dl4ds_amd import parallel, _lib
+        rng = np.random.default_rng(0)
+        B, T, h, s = 4, 4, 32, 2
+        x = rng.standard_normal((B, T, h, h, 1)).astype(np.float32)
+        aux = rng.standard_normal((B, h * s, h * s, 1)).astype(np.float32)
+        y = rng.standard_normal((B, T, h * s, h * s, 1)).astype(np.float32)
+        def run(dist):
+            m = PM.recnet_postupsampling('densenet', 'rc', s, 1, 1, (h, h), time_window=T, attention=True, localcon_layer=True,
+                                         n_blocks=2, seed=7)
+            e = SupervisedEngine(m, loss='mae', learning_rate=1e-3)
+            if dist:
+                parallel.broadcast_trainer(e)
+            losses = [e.step([x, aux], y) for _ in range(5)]
+            _lib.check(_lib.lib().dl4ds_sync())          # (a spin that gave up raises the sticky error word here)
+            return losses, m.get_weights()
+        l0, w0 = run(False)
+        parallel.init_with_id(0, 1, parallel.unique_id())
+        l1, w1 = run(True)
+        parallel.finalize()
+        assert l0 == l1, (l0, l1)
+        for k in w0:
+            np.testing.assert_array_equal(w0[k], w1[k], err_msg=k)
+        print('SEQ-STANDIN-OK')
+    ''', env={'DL4DS_DIST_STANDIN': '1'})
+    assert 'SEQ-STANDIN-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

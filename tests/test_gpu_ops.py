@@ -445,6 +445,30 @@ def test_conv2d_wgrad_packed_taps(ops, n, h, w, ci, co, ks):
     np.testing.assert_array_equal(got, ops.conv2d_wgrad(x, dz, ks))
 
 
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 20, 33, 8, 13), (3, 64, 48, 8, 16), (1, 17, 16, 4, 15), (2, 33, 70, 5, 9), (1, 128, 128, 8, 13)])
+def test_conv2d_narrow16_eight_input_channels(ops, n, h, w, ci, co):
+    """Round 5: <= 8 input channels with 9 .. 16 outputs (8 -> 13: the dgrad of ConvBlock_att's first layer in the recurrent nets,
+    spt_postups.py:152-157) on conv_narrow16_ws_kernel<NR, EPI, C8 = true> -- k-slots 0, 1 carry the channel quads of tap 2j, k-slots
+    2, 3 those of tap 2j + 1: five MFMA groups per output row instead of nine.  Forward with bias / ReLU / residual, dgrad (the
+    transposed layer ci <- co runs the 16-channel form) with and without accumulation, ragged grids and channel counts."""
+    from tests.parity import kernel_tags
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    if ci % 4 == 0:                                  # (ragged input channel counts through the op-level API take the fallback kernel)
+        assert any(t.startswith('conv_narrow16_ws<') for t in tags), tags
+    close(got, ref)
+    close(ops.conv2d(x, wt, b, relu=True), np.maximum(ref, 0))
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    # as a dgrad: dz with ci' = co channels -> dx with co' = ci ... and the other way round (8 gradient channels -> 13)
+    wt2 = R(3, 3, co, ci) * 0.2
+    dz = R(n, h, w, ci)
+    gx, _ = _torch_conv_grads(R(n, h, w, co), wt2, dz)
+    close(ops.conv2d_dgrad(dz, wt2), gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt2, accumulate_into=base_x), gx + base_x)
+
+
 @pytest.mark.parametrize('sx', ['1', '32'])
 @pytest.mark.parametrize('n,h,w,co,ks', [(3, 20, 37, 32, 5), (2, 64, 64, 32, 5), (2, 17, 33, 32, 3), (4, 64, 64, 32, 3), (1, 40, 24, 64, 5),
                                          (2, 16, 16, 48, 5)])

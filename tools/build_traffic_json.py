@@ -10,7 +10,21 @@ statistics of the same command give launches per step for the tag's kernels, the
 import json, os, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'prof_' + tag) if len(sys.argv) < 3 else sys.argv[2]
-out = {'_round': tag, '_unit': 'HBM bytes per call of the tagged layer kernel(s): (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction'}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import subprocess
+from bench import csrc_sha
+try:
+    commit = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True,
+                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip()
+    dirty = bool(subprocess.run(['git', 'status', '--porcelain', 'dl4ds_amd/csrc', 'include'], capture_output=True, text=True,
+                                cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip())
+except Exception:
+    commit, dirty = None, None
+# the fingerprint of the kernel sources the PMC passes ran on: the collection script writes it next to the counters
+# (gpurun_out/prof_<tag>/csrc_sha.txt); bench.py reports `traffic` only when its own build has the same one
+shaf = os.path.join(root, 'csrc_sha.txt')
+sha = open(shaf).read().strip() if os.path.exists(shaf) else csrc_sha()
+out = {'_round': tag, '_csrc_sha': sha, '_commit': (commit or '?') + ('+uncommitted kernel changes' if dirty else ''), '_unit': 'HBM bytes per call of the tagged layer kernel(s): (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction'}
 PMC_STEPS = 5
 for cfg in ('cfg2', 'cfg4', 'cfg5'):
     f = os.path.join(root, f'pmc_traffic_{cfg}_{tag}.json')
