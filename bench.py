@@ -128,22 +128,34 @@ def cpu_baseline_worker(path):
         t0 = time.perf_counter()
         TR.supervised_step('net_postupsampling', cfg, P, xt, None, yt, loss='mae', opt=opt)
         return time.perf_counter() - t0
+    # thread counts inside the socket: the graph's 8-channel 512^2 layers stop scaling well before 64 cores (measured on the GPU box,
+    # round 5: 4.7 samples/s with all 64 cores of a socket at B = 64, ~10 with 16-32 threads) -- the best count is reported with the sweep
     t_all = time.perf_counter()
-    times = [step()]                                       # warm-up (first touch of every activation buffer)
-    while len(times) < 3 and (time.perf_counter() - t_all) + times[-1] < budget_s:
-        times.append(step())
-    dt = min(times[1:]) if len(times) > 1 else times[0]
-    print(json.dumps({'value': b / dt, 'unit': 'HR samples/s', 'cores': threads, 'cores_total': ncpu, 'kind': 'port',
-                      'step_seconds': [round(t, 3) for t in times],
+    sweep, best = {}, None
+    for n in sorted({min(threads, t) for t in (16, 32, threads)}):
+        if best is not None and time.perf_counter() - t_all > budget_s:
+            sweep[str(n)] = 'skipped (time budget)'
+            continue
+        torch.set_num_threads(n)
+        times = [step()]                                   # warm-up (first touch of every activation buffer)
+        while len(times) < 3 and (time.perf_counter() - t_all) + times[-1] < budget_s:
+            times.append(step())
+        dt = min(times[1:]) if len(times) > 1 else times[0]
+        sweep[str(n)] = round(b / dt, 2)
+        if best is None or dt < best[1]:
+            best = (n, dt, times)
+    n, dt, times = best
+    print(json.dumps({'value': b / dt, 'unit': 'HR samples/s', 'cores': n, 'cores_total': ncpu, 'kind': 'port',
+                      'socket_cores': threads, 'sweep_samples_per_s_by_threads': sweep, 'step_seconds': [round(t, 3) for t in times],
                       'sample': f'oracle torch-CPU (oneDNN) fp32 train step (fwd+MAE+bwd+Adam) of the same graph and weights, B={b} at '
-                                f'128->512, {threads} threads pinned to the {threads} physical cores of ONE socket '
-                                f'(os.sched_setaffinity; the host has {ncpu} hardware threads), best of {max(len(times) - 1, 1)} '
-                                f'step(s) after a warm-up step, {budget_s:.0f} s budget'}), flush=True)
+                                f'128->512, process pinned to the {threads} physical cores of ONE socket (os.sched_setaffinity; the host '
+                                f'has {ncpu} hardware threads), thread counts 16 / 32 / {threads} swept, {n} threads fastest: best of '
+                                f'{max(len(times) - 1, 1)} step(s) after a warm-up step, {budget_s:.0f} s budget'}), flush=True)
 
 
-def cpu_baseline(weights, budget_s=30.0, batch=64):
+def cpu_baseline(weights, budget_s=30.0, batch=16):
     """The oracle (torch-CPU restatement of the identical graph, fp32, oneDNN convolutions) timed on a bounded sample of the same
-    workload -- the bench batch (B = 64 at 128 -> 512), one socket's physical cores, in a CHILD process so that the affinity mask
+    workload -- B = 16 at 128 -> 512 (the metric is samples/s; B = 64 was slower per sample), one socket's physical cores, in a CHILD process so that the affinity mask
     is in place before torch's thread pool exists and nothing of it leaks into this process.  A reported baseline, never a target
     (cores stated -- `cores`, `cores_total`)."""
     import tempfile

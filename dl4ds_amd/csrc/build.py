@@ -12,11 +12,15 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-OUT = os.path.join(PKG, 'libdl4ds_hip.so')
-OBJ = os.path.join(HERE, '_build')
+# DL4DS_BUILD_EXPERIMENTS=1: the library with the measured-and-dropped variants' and the diagnostics' run-time switches compiled in
+# (common.h: exp_env) -> dl4ds_amd/libdl4ds_hip_exp.so, objects in _build_exp/; load it with DL4DS_HIP_LIB for A/B runs.  The product
+# library (the default, what __graft_entry__.build() makes and the tests / bench load) has them compiled out.
+EXPERIMENTS = os.environ.get('DL4DS_BUILD_EXPERIMENTS', '') == '1'
+OUT = os.path.join(PKG, 'libdl4ds_hip_exp.so' if EXPERIMENTS else 'libdl4ds_hip.so')
+OBJ = os.path.join(HERE, '_build_exp' if EXPERIMENTS else '_build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-I/opt/rocm/include', '-x', 'hip']
+         '-I/opt/rocm/include', '-x', 'hip'] + (['-DDL4DS_EXPERIMENTS'] if EXPERIMENTS else [])
 
 
 def sources():

@@ -180,7 +180,7 @@ void cgan_step(CganTrainer& t, const float* const* gen_inputs, int n_gen_inputs,
     bce_forward_backward(s, p_fake, 1.f, B, 1.f, t.d_losses + 0, dout.grad + B, 0);
     if (t.ratio_plan < 0) {
         // eligible: no normalisation ops (BatchNormalization couples the samples of a group), every reader of the HR input known
-        bool ok = getenv("DL4DS_NO_CGAN_RATIO") == nullptr;
+        bool ok = test_env("DL4DS_NO_CGAN_RATIO") == nullptr;
         t.ratio_ops.clear();
         for (size_t i = 0; i < D.ops.size() && ok; ++i) {
             GOp* op = D.ops[i].get();

@@ -6,6 +6,32 @@
 #include <stdio.h>
 #include <string>
 #include <stdexcept>
+#include <cstdlib>
+
+// ---- run-time switches (README "Environment switches") ------------------------------------------------------------------------
+// The PRODUCT reads eight variables by name through getenv: DL4DS_NO_WINOGRAD, DL4DS_NO_WINOGRAD_WGRAD, DL4DS_NO_REC_TAIL_FUSION,
+// DL4DS_NO_CONVLSTM_SEQ (kernel families / graph transformations with an A/B test and a documented fall-back), DL4DS_AUX_STREAM,
+// DL4DS_ALLOW_UNSYNCED, DL4DS_COLLECTIVE_TIMEOUT_S, DL4DS_SEQ_RESERVE_CUS (multi-process behaviour).
+// test_env: hooks of the test-suite -- force a kernel onto grids it would not pick, play a collective, switch one graph transformation
+//   off for an A/B comparison -- honoured only while DL4DS_TEST_HOOKS=1 (tests/conftest.py sets it; a production process never does).
+// exp_env: switches of measured-and-dropped variants and of diagnostics.  They exist in -DDL4DS_EXPERIMENTS builds only
+//   (DL4DS_BUILD_EXPERIMENTS=1 python dl4ds_amd/csrc/build.py -> dl4ds_amd/libdl4ds_hip_exp.so, loaded through DL4DS_HIP_LIB); in the
+//   product library the call is the constant nullptr and the variant's branch is dead code.
+#ifdef DL4DS_EXPERIMENTS
+inline const char* exp_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
+inline const char* test_env(const char* name) {
+    static const bool hooks = [] { const char* e = std::getenv("DL4DS_TEST_HOOKS"); return e && e[0] == '1'; }();
+#ifdef DL4DS_EXPERIMENTS
+    (void)hooks;
+    return std::getenv(name);
+#else
+    return hooks ? std::getenv(name) : nullptr;
+#endif
+}
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

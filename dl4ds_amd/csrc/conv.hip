@@ -555,11 +555,11 @@ void launch_fwd(hipStream_t s, ConvParams& p, int N) {
     // Deep U-Net levels (256 -> 256 at 8x8, the 9x9 transposed convolutions as 5x5 convolutions with 1024 couts): a few
     // dozen blocks each walking thousands of k-steps.  Split the channel chunks over blockIdx.z into plain slabs and let
     // a small kernel sum them and apply the epilogue (fixed order: deterministic).
-    static const bool no_splitk = getenv("DL4DS_NO_SPLITK") != nullptr;
+    static const bool no_splitk = exp_env("DL4DS_NO_SPLITK") != nullptr;
     const long blocks = (long)grid.x * grid.y;
     const int nchunks = cdiv(p.Cin, CK);
     int S = 1;
-    static const long sk_target = getenv("DL4DS_SPLITK_TARGET") ? atol(getenv("DL4DS_SPLITK_TARGET")) : 768;
+    static const long sk_target = exp_env("DL4DS_SPLITK_TARGET") ? atol(exp_env("DL4DS_SPLITK_TARGET")) : 768;
     if (!no_splitk && blocks < 256 && nchunks >= 2) S = (int)std::min<long>(nchunks, std::max<long>(2, sk_target / blocks));
     ProfScope ps(s, "conv_igemm<" + std::to_string(KS) + "," + std::to_string(MT) + "," + std::to_string(NT) + "," +
                         std::to_string(WM) + "," + std::to_string(WN) + (S > 1 ? ",splitk>" : ">"),
@@ -607,7 +607,7 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
         // ... unless the reduction is long enough for split-K (launch_fwd) to supply the blocks: a wide cout tile reads 0.5 LDS
         // fragments per MFMA where the 16-cout tile reads 1.25, and the slabs of these layers are a few MB
         const long kparts = std::max(1, cdiv(p.Cin, 64));
-        const bool wide_splitk = kparts >= 2 && blocks_for(best) * kparts >= (getenv("DL4DS_WIDE_SPLITK_MIN") ? atol(getenv("DL4DS_WIDE_SPLITK_MIN")) : 128) && !getenv("DL4DS_NO_WIDE_SPLITK");
+        const bool wide_splitk = kparts >= 2 && blocks_for(best) * kparts >= (exp_env("DL4DS_WIDE_SPLITK_MIN") ? atol(exp_env("DL4DS_WIDE_SPLITK_MIN")) : 128) && !exp_env("DL4DS_NO_WIDE_SPLITK");
         if (blocks_for(best) < 256 && !wide_splitk) {
             int pick = best;
             for (int bn : bns) {
@@ -639,7 +639,7 @@ void dispatch_fwd(hipStream_t s, ConvParams& p, int N) {
         case 48:  launch_fwd<KS, 4, 3, 4, 1>(s, p, N); break;   // 16x16 x 48
         case 32:  launch_fwd<KS, 4, 2, 4, 1>(s, p, N); break;   // 16x16 x 32 (a second wave set measured no better here)
         default:                                                // 16x16 x 16; under-filled multi-tap launches: 2 waves/SIMD
-            if (KS > 1 && (long)cdiv(p.W, 16) * cdiv(p.H, 16) * N * cdiv(p.Cout, 16) <= (getenv("DL4DS_KSP_MAX") ? atol(getenv("DL4DS_KSP_MAX")) : 256) && !getenv("DL4DS_NO_KSP"))
+            if (KS > 1 && (long)cdiv(p.W, 16) * cdiv(p.H, 16) * N * cdiv(p.Cout, 16) <= (exp_env("DL4DS_KSP_MAX") ? atol(exp_env("DL4DS_KSP_MAX")) : 256) && !exp_env("DL4DS_NO_KSP"))
                 launch_fwd<KS, 4, 1, 4, 1, 2>(s, p, N);       // (four wave sets measured no better than two)
             else
                 launch_fwd<KS, 4, 1, 4, 1>(s, p, N);
@@ -1413,7 +1413,7 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     // its channels (the next pixel's first channels) lands in rows / columns of the MFMA tile that are never written out
     // (ci >= Cin, co >= Cout) -- 13-, 26- and 2-channel layers (densenet transitions, LocalizedConvBlock) used to fall back to
     // the scalar-staged kernel at 1.5 TB/s
-    auto ws_ok = [](const TView& v) { return v.vec || (v.d2s <= 1 && !getenv("DL4DS_NO_WGRAD_WS_UNALIGNED")); };
+    auto ws_ok = [](const TView& v) { return v.vec || (v.d2s <= 1 && !exp_env("DL4DS_NO_WGRAD_WS_UNALIGNED")); };
     p.tiles_x = cdiv(x.W, 16);
     p.tiles_y = cdiv(x.H, 8);
     p.ntiles = p.tiles_x * p.tiles_y * x.N;
@@ -1429,7 +1429,7 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     else if (dz.C <= 32 && p.WCO == 4) p.WCO = 2;
     // 1x1 layers are HBM-bound: every cout block re-reads the x tile, so the fewest blocks win there (padded MFMAs are free)
     if (KS == 1) p.WCO = (dz.C <= 16) ? 1 : (dz.C <= 32 ? 2 : 4);
-    if (const char* e = getenv("DL4DS_WGRAD_WCO")) p.WCO = atoi(e);      // (experiments)
+    if (const char* e = exp_env("DL4DS_WGRAD_WCO")) p.WCO = atoi(e);      // (experiments)
     p.WK = 4 / p.WCO;
     const int cob = cdiv(dz.C, 16 * p.WCO), cib = cdiv(x.C, 16 * p.CIT);
     // every block does the same amount of work, so the grid should be exactly one residency round:
@@ -1437,8 +1437,8 @@ WgradPlan plan_wgrad(const TView& x, const TView& dz, int KS) {
     // (the producer/consumer rows kernel runs ONE 8-wave workgroup per CU)
     // (1x1 layers are HBM streaming: the same producer / consumer kernel with one tap)
     // (<= 16 x <= 16 channels used to keep the register-prefetch kernel: 373 us vs 196 us for 16 -> 16 at 16 x 512^2)
-    p.ws = (KS == 3 || (KS == 1 && !getenv("DL4DS_NO_WGRAD_WS1")) || (KS == 5 && !getenv("DL4DS_NO_WGRAD_WS5"))) && (!(p.CIT == 1 && p.WCO == 1) || !getenv("DL4DS_NO_WGRAD_WS11")) && ws_ok(x) && ws_ok(dz) &&
-           p.ntiles < (1 << 20) && !getenv("DL4DS_NO_WGRAD_ROWS") && !getenv("DL4DS_NO_WGRAD_WS");
+    p.ws = (KS == 3 || (KS == 1 && !exp_env("DL4DS_NO_WGRAD_WS1")) || (KS == 5 && !exp_env("DL4DS_NO_WGRAD_WS5"))) && (!(p.CIT == 1 && p.WCO == 1) || !exp_env("DL4DS_NO_WGRAD_WS11")) && ws_ok(x) && ws_ok(dz) &&
+           p.ntiles < (1 << 20) && !exp_env("DL4DS_NO_WGRAD_ROWS") && !exp_env("DL4DS_NO_WGRAD_WS");
     int target = std::max(1, (p.ws ? 256 : 512) / (cob * cib));
     const size_t slab = (size_t)KS * KS * x.C * dz.C + dz.C;
     const size_t cap = std::max<size_t>(1, ((size_t)192 << 20) / (slab * sizeof(float)));
@@ -1457,7 +1457,7 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
     constexpr int WK = 4 / WCO;
     constexpr size_t red_bytes = (size_t)(WK / 2) * WCO * (KS * KS * CIT * COT * 4 + COT) * 64 * sizeof(float);
     // 3x3 layers beyond the small-channel prefetch variants: row-walking kernel (MFMA bound instead of LDS-read bound)
-    static const bool no_rows = getenv("DL4DS_NO_WGRAD_ROWS") != nullptr;
+    static const bool no_rows = exp_env("DL4DS_NO_WGRAD_ROWS") != nullptr;
     // (KS == 1, KS == 5 and the small-channel variants: only the producer / consumer form; 5x5 plans always have CIT == 1)
     constexpr bool ROWS_OK = (KS == 3 || KS == 1 || (KS == 5 && CIT == 1)) && COT == 1;
     const bool rows = ROWS_OK && !no_rows && ((KS == 3 && !PF) || pl.ws);
@@ -1466,7 +1466,7 @@ void launch_wgrad(hipStream_t s, WgradParams& p, const WgradPlan& pl) {
                             : std::max((size_t)(PF ? 2 : 1) * (HPIX * PX + 128 * PZ) * sizeof(float), red_bytes);
     void (*kern)(const WgradParams) = conv_wgrad_kernel<KS, CIT, COT, WCO, PF>;
     // <= 8 input channels on the producer / consumer kernel: two taps per MFMA (see the kernel's PACK comment); DL4DS_NO_WGRAD_PACK=1 for A/B
-    static const bool no_pack = getenv("DL4DS_NO_WGRAD_PACK") != nullptr;
+    static const bool no_pack = exp_env("DL4DS_NO_WGRAD_PACK") != nullptr;
     constexpr bool PACK_OK = ROWS_OK && CIT == 1 && (KS == 3 || KS == 5);
     const bool pack = PACK_OK && ws && p.Cin <= 8 && !no_pack;
     if constexpr (ROWS_OK) {
@@ -1539,15 +1539,15 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
                     const ConvEpilogue& ep) {
     DL4DS_REQUIRE(in.N == out.N && in.H == out.H && in.W == out.W, "conv2d: stride-1 SAME shapes differ");
     if (conv2d_direct_forward(s, in, w, KS, out, ep)) return;      // a handful of channels: HBM-bound stencil
-    if (!getenv("DL4DS_NO_NARROW") && conv2d_narrow_forward(s, in, w, KS, out, ep)) return;
+    if (!exp_env("DL4DS_NO_NARROW") && conv2d_narrow_forward(s, in, w, KS, out, ep)) return;
     DL4DS_REQUIRE(!in.sc && !ep.pool, "conv2d: channel-affine input / pooling partials are only implemented by the direct "
                                      "and narrow-pair kernels (the caller must check conv2d_direct_eligible / conv2d_narrow_pair_ok)");
     if (KS == 3 && conv2d_wino_forward(s, in, w, out, ep)) return;  // MFMA-bound 3x3 layers: Winograd F(2x2, 3x3)
     // small grids, many channels: GEMM over the flattened pixels of the batch -- up to 16 x 16 ahead of the streaming kernels (which
     // need two tiles per workgroup), up to 32 x 32 for what they decline (measured on cfg5: 106 vs 128-133 TFLOP/s where both apply)
     if (conv2d_gemm_forward(s, in, w, KS, out, ep, 16 * 16)) return;
-    if (KS == 1 && getenv("DL4DS_POINT_FIRST") && conv2d_point_forward(s, in, w, KS, out, ep)) return;     // (experiment)
-    if (!getenv("DL4DS_NO_STREAM") && conv2d_stream_forward(s, in, w, KS, out, ep)) return;
+    if (KS == 1 && exp_env("DL4DS_POINT_FIRST") && conv2d_point_forward(s, in, w, KS, out, ep)) return;     // (experiment)
+    if (!exp_env("DL4DS_NO_STREAM") && conv2d_stream_forward(s, in, w, KS, out, ep)) return;
     if (conv2d_point_forward(s, in, w, KS, out, ep)) return;      // 1x1 with channel counts that are not multiples of four
     if (conv2d_gemm_forward(s, in, w, KS, out, ep, 32 * 32)) return;
     ConvParams p;
@@ -1651,7 +1651,7 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     const size_t nw = (size_t)KS * KS * x.C * dz.C;
     const size_t n = nw + dz.C;
     const int direct_slabs = conv2d_direct_wgrad_slabs(x, dz, KS);
-    const int narrow_slabs = (direct_slabs || getenv("DL4DS_NO_NARROW")) ? 0 : conv2d_narrow_wgrad_slabs(x, dz, KS);
+    const int narrow_slabs = (direct_slabs || exp_env("DL4DS_NO_NARROW")) ? 0 : conv2d_narrow_wgrad_slabs(x, dz, KS);
     DL4DS_REQUIRE(direct_slabs || ((!x.sc) && (narrow_slabs || !dz.sc)),
                   "wgrad: channel-affine operands are only implemented by the direct (x) and narrow (dz) kernels");
     int nslabs = direct_slabs ? direct_slabs : (narrow_slabs ? narrow_slabs : pl.S);
@@ -1677,7 +1677,7 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     ProfScope ps(s, "wgrad_reduce_slabs", 0.0, 4.0 * (double)n * (nslabs + 1));
     // small filters (a 3x3 8 -> 8 layer has 584 values in up to 1024 slabs): 16 elements per block would leave 37 blocks walking
     // 64 slabs per thread one latency after the other (13 us); 4 elements per block put 64 slabs in flight per block
-    if (n < 4096 && nslabs >= 128 && !getenv("DL4DS_REDUCE16")) {
+    if (n < 4096 && nslabs >= 128 && !exp_env("DL4DS_REDUCE16")) {
         const int blocks = (int)std::max<size_t>(1, cdivz(n, 4));
         DL4DS_LAUNCH(reduce_slabs_kernel<4>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
                            accumulate_db);

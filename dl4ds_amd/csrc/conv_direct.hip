@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(256) conv_direct2_wgrad_kernel(const DirectPar
 
 // the second generation takes plain inputs whose channels its loads cover exactly
 bool direct2_ok(const DirectParams& p, int ci) {
-    static const bool off = getenv("DL4DS_NO_DIRECT2") != nullptr;
+    static const bool off = exp_env("DL4DS_NO_DIRECT2") != nullptr;
     if (off || p.in.d2s > 1) return false;
     if ((((uintptr_t)p.in.p) & 3) != 0) return false;
     if (ci >= 4 ? (!p.in.vec || (p.Cin & 3) != 0) : (p.Cin != ci)) return false;
@@ -843,16 +843,16 @@ int launch_direct(hipStream_t s, const DirectParams& p0, bool wgrad, int max_blo
     DirectParams p = p0;
     // forward with more than two outputs per pixel stays on the first generation (1 -> 8 at 64 x 512^2: 0.196 ms there, 0.229 here:
     // 142 registers against 45 and the layer is bound by its stores); every weight gradient measured is faster here
-    static const bool no_plain = getenv("DL4DS_DIRECT_NO_PLAIN") != nullptr;      // (A/B)
+    static const bool no_plain = exp_env("DL4DS_DIRECT_NO_PLAIN") != nullptr;      // (A/B)
     const int plain = (!wgrad && !no_plain && !p.add.p && !p.mask.p && !p.accumulate && p.out.d2s <= 1 && p.in.d2s <= 1) ? (p.in.sc ? 2 : 1) : 0;
-    static const bool no_wide2 = getenv("DL4DS_DIRECT2_NO_WIDE") != nullptr;      // (A/B)
+    static const bool no_wide2 = exp_env("DL4DS_DIRECT2_NO_WIDE") != nullptr;      // (A/B)
     // ... but in the PLAIN form (no epilogue operands to hold) the second generation wins there too: 1 -> 8 0.218 -> 0.171 ms
     const bool gen2 = direct2_ok(p, CI) && (wgrad || CO <= 2 || (plain == 1 && !no_wide2));
     if (gen2) {
         p.tiles_y = cdiv(p.H, D2Y);
         p.ntiles = p.tiles_x * p.tiles_y * p.in.N;
         p.m_ty = div_magic(p.tiles_y);
-        static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;
+        static const bool no_xcd = exp_env("DL4DS_NO_XCD_WALK") != nullptr;
         p.xcd = no_xcd ? 0 : 1;
     }
     // persistent kernels: one residency round (blocks do equal work); exact_grid: per-image slabs need exactly that many blocks

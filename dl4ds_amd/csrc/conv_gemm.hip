@@ -179,7 +179,7 @@ int gemm_cu_count() {
 
 // false = not eligible (the caller goes on to the tile kernels)
 bool conv2d_gemm_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out, const ConvEpilogue& ep, int max_hw) {
-    static const bool off = getenv("DL4DS_NO_GEMM") != nullptr;
+    static const bool off = exp_env("DL4DS_NO_GEMM") != nullptr;
     if (off) return false;
     if (!(KS == 1 || KS == 3 || KS == 5)) return false;
     if (in.sc || ep.pool) return false;

@@ -1123,14 +1123,14 @@ __global__ void __launch_bounds__(512, narrow16_wps(EPI)) conv_narrow16_ws_kerne
 }
 
 bool narrow16_ws_ok(const ConvParams& p) {
-    static const bool off = getenv("DL4DS_NO_NARROW16_WS") != nullptr;
+    static const bool off = exp_env("DL4DS_NO_NARROW16_WS") != nullptr;
     auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
-    static const bool no_ragged = getenv("DL4DS_NO_NARROW16_WS_RAGGED") != nullptr;      // (A/B)
+    static const bool no_ragged = exp_env("DL4DS_NO_NARROW16_WS_RAGGED") != nullptr;      // (A/B)
     if (off || p.pool || p.in.sc || p.in.d2s > 1) return false;
     // <= 8 input channels with 9..16 outputs (8 -> 13: the dgrad of ConvBlock_att's first layer in the recurrent nets) come here too
     // since the epilogue forms are compiled in: conv_narrow_kernel<8> issues half the MFMAs but 0.53 ms at 128 x 256^2 against
     // 0.35 here (first half of round 3, run-time epilogue: 0.54 there, 0.59 here).  DL4DS_NARROW16_NO_SMALL_CIN=1 for A/B.
-    static const bool no_small_cin = getenv("DL4DS_NARROW16_NO_SMALL_CIN") != nullptr;
+    static const bool no_small_cin = exp_env("DL4DS_NARROW16_NO_SMALL_CIN") != nullptr;
     if (p.Cin <= 8 && no_small_cin) return false;
     if ((!p.in.vec || (p.Cin & 3)) && no_ragged) return false;
     if ((((uintptr_t)p.in.p) & 3) != 0) return false;
@@ -1149,7 +1149,7 @@ bool narrow16_ws_ok(const ConvParams& p) {
 template <int NR>
 bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
     if (!narrow16_ws_ok(p)) {
-        if (getenv("DL4DS_NARROW_DEBUG"))
+        if (exp_env("DL4DS_NARROW_DEBUG"))
             fprintf(stderr, "narrow16_ws declined: N=%d H=%d W=%d Cin=%d (ld %d vec %d d2s %d sc %d) Cout=%d (ld %d vec %d d2s %d) add=%d(ld %d vec %d) mask=%d(ld %d vec %d) "
                             "acc=%d pool=%d bias&15=%d\n", N, p.H, p.W, p.Cin, p.in.ld, p.in.vec, p.in.d2s, p.in.sc != nullptr, p.Cout, p.out.ld, p.out.vec,
                     p.out.d2s, p.add.p != nullptr, p.add.ld, p.add.vec, p.mask.p != nullptr, p.mask.ld, p.mask.vec, p.accumulate, p.pool != nullptr,
@@ -1163,18 +1163,18 @@ bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
     const long nt = (long)p.tiles_x * p.tiles_y * N;
     if (nt == 0 || nt >= (1l << 20)) return false;
     const int ntiles = (int)nt;
-    static const bool generic_only = getenv("DL4DS_NARROW16_WS_GENERIC") != nullptr;      // (A/B)
+    static const bool generic_only = exp_env("DL4DS_NARROW16_WS_GENERIC") != nullptr;      // (A/B)
     const int epi = generic_only ? -1 : ((p.add.p ? PAIR_EPI_ADD : 0) | (p.relu ? PAIR_EPI_RELU : 0) | (p.mask.p ? PAIR_EPI_MASK : 0) |
                                          (p.accumulate ? PAIR_EPI_ACC : 0));
     const double px = (double)N * p.H * p.W;
     ProfScope ps(s, "conv_narrow16_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                  4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
-    static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;                     // (A/B)
+    static const bool no_xcd = exp_env("DL4DS_NO_XCD_WALK") != nullptr;                     // (A/B)
     p.CK = no_xcd ? 0 : 1;
     auto grid_of = [&](int resident) { const int b = std::min(ntiles, resident); return b >= 8 ? (b & ~7) : b; };
     // <= 8 input channels: the five-group form (round 5), compiled for the epilogue forms such layers have -- plain, ReLU, ReLU mask,
     // accumulate and their pairs; the others take the run-time form of it.  DL4DS_NARROW16_NO_C8=1 for A/B.
-    static const bool no_c8 = getenv("DL4DS_NARROW16_NO_C8") != nullptr;
+    static const bool no_c8 = exp_env("DL4DS_NARROW16_NO_C8") != nullptr;
     if (p.Cin <= 8 && !no_c8) {
 #define NARROW16_C8_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow16_ws_kernel<NR, E_, true>), \
         dim3(grid_of(resident_blocks<conv_narrow16_ws_kernel<NR, E_, true>>(512))), dim3(512), 0, s, p); break;
@@ -1200,18 +1200,18 @@ bool launch_narrow16_ws(hipStream_t s, ConvParams& p, int N) {
 }
 
 bool narrow_pair_ws_ok(const ConvParams& p) {
-    static const bool off = getenv("DL4DS_NO_PAIR_WS") != nullptr;
+    static const bool off = exp_env("DL4DS_NO_PAIR_WS") != nullptr;
     auto same_layout = [](const TView& u, const TView& v) { return u.ld == v.ld && u.d2s == v.d2s && u.W == v.W && u.cp == v.cp; };
     // inputs whose channel count / pixel pitch is not a multiple of four (the discriminator's 5-channel first layer): the loaders'
     // 16-byte buffer loads only need dword alignment, what a quad picks up beyond Cin meets zero filter entries, and the
     // descriptor's exact size makes the buffer unit zero-fill at the very end of the view
-    static const bool no_ragged = getenv("DL4DS_NO_PAIR_WS_RAGGED") != nullptr;
-    if (getenv("DL4DS_NARROW_DEBUG"))
+    static const bool no_ragged = exp_env("DL4DS_NO_PAIR_WS_RAGGED") != nullptr;
+    if (exp_env("DL4DS_NARROW_DEBUG"))
         fprintf(stderr, "pair_ws?: N=%d H=%d W=%d Cin=%d (ld %d vec %d d2s %d sc %d) Cout=%d (ld %d vec %d d2s %d) add=%d(ld %d d2s %d) mask=%d(ld %d d2s %d) acc=%d pool=%d\n",
                 p.in.N, p.H, p.W, p.Cin, p.in.ld, p.in.vec, p.in.d2s, p.in.sc != nullptr, p.Cout, p.out.ld, p.out.vec, p.out.d2s, p.add.p != nullptr,
                 p.add.ld, p.add.d2s, p.mask.p != nullptr, p.mask.ld, p.mask.d2s, p.accumulate, p.pool != nullptr);
     if (off || p.in.d2s > 1) return false;
-    if ((p.pool || p.in.sc) && getenv("DL4DS_NO_PAIR_WS_FUSED")) return false;      // (A/B: attention pieces through the older kernel)
+    if ((p.pool || p.in.sc) && exp_env("DL4DS_NO_PAIR_WS_FUSED")) return false;      // (A/B: attention pieces through the older kernel)
     if (p.in.sc && (!p.in.vec || (p.Cin & 3))) return false;
     if ((!p.in.vec || (p.Cin & 3)) && no_ragged) return false;
     // the residual operand and the ReLU mask are addressed through their own strides: any plain layout of the output's grid (a
@@ -1235,11 +1235,11 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
     const double px = (double)N * p.H * p.W;
     if (narrow_pair_ws_ok(p)) {
         // the epilogue forms the models use are compiled in (see the kernel's comment); anything else takes the run-time form
-        static const bool generic_only = getenv("DL4DS_PAIR_WS_GENERIC") != nullptr;      // (A/B)
+        static const bool generic_only = exp_env("DL4DS_PAIR_WS_GENERIC") != nullptr;      // (A/B)
         const int epi = (p.add.p ? PAIR_EPI_ADD : 0) | (p.relu ? PAIR_EPI_RELU : 0) | (p.mask.p ? PAIR_EPI_MASK : 0) |
                         (p.accumulate ? PAIR_EPI_ACC : 0) | (p.pool ? PAIR_EPI_POOL : 0) | (p.in.sc ? PAIR_EPI_AFF : 0);
         int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_ws_kernel<NR, -1>>(512));
-        static const bool no_xcd = getenv("DL4DS_NO_XCD_WALK") != nullptr;                 // (A/B)
+        static const bool no_xcd = exp_env("DL4DS_NO_XCD_WALK") != nullptr;                 // (A/B)
         if (blocks >= 8) blocks &= ~7;
         p.CK = no_xcd ? 0 : 1;
         ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
@@ -1653,7 +1653,7 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
 // the only variant that also takes inputs whose channel count is not a multiple of 4.  Also the only narrow variant that
 // reads a view with a channel affine (float4-loadable inputs only) and emits the pooling partial sums.
 bool conv2d_narrow_pair_ok(const TView& in, const TView& out, int KS, const ConvEpilogue& ep) {
-    if (KS != 3 || in.d2s > 1 || getenv("DL4DS_NO_PAIR") || getenv("DL4DS_NO_NARROW")) return false;
+    if (KS != 3 || in.d2s > 1 || exp_env("DL4DS_NO_PAIR") || exp_env("DL4DS_NO_NARROW")) return false;
     if ((long)cdiv(in.W, NTW) * cdiv(in.H, NTH) * in.N >= (1l << 20)) return false;    // fast_div range
     return in.C <= 8 && out.C <= 8 && (out.C & 3) == 0 && out.vec && (!ep.add.p || ep.add.vec) &&
            (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) && (!in.sc || (in.vec && (in.C & 3) == 0));
@@ -1666,7 +1666,7 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
     const bool pair_ok = conv2d_narrow_pair_ok(in, out, KS, ep);
     // 9..16 input channels that are not a multiple of four (the 13-channel ConvBlock behind TransitionLast 26 -> 13): the halo
     // staging's float4 loads only need dword alignment; channels beyond Cin are masked when the tile is written to LDS
-    const bool unaligned_ok = in.C > 8 && in.d2s <= 1 && !in.sc && !ep.pool && !getenv("DL4DS_NO_NARROW_UNALIGNED");
+    const bool unaligned_ok = in.C > 8 && in.d2s <= 1 && !in.sc && !ep.pool && !exp_env("DL4DS_NO_NARROW_UNALIGNED");
     if (!in.vec && !pair_ok && !unaligned_ok) return false;
     if ((long)cdiv(in.W, NTW) * cdiv(in.H, NTH) * in.N >= (1l << 20)) return false;    // fast_div range
     DL4DS_REQUIRE(pair_ok || (!in.sc && !ep.pool), "conv_narrow: channel-affine input / pooling partials need the pair kernel");

@@ -201,8 +201,8 @@ void dispatch_nt(hipStream_t s, const PointParams& p, size_t lds) {
 // 1x1, <= 64 -> <= 64 channels, at least one side not a multiple of four, plain contiguous views.  Returns false when the
 // layer is not eligible (the caller goes on to the general kernels).
 bool conv2d_point_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out, const ConvEpilogue& ep) {
-    if (KS != 1 || getenv("DL4DS_NO_POINT")) return false;
-    static const bool take_aligned = getenv("DL4DS_POINT_FIRST") != nullptr;      // (experiment: aligned 1x1 layers here instead of conv_stream<1,..>)
+    if (KS != 1 || exp_env("DL4DS_NO_POINT")) return false;
+    static const bool take_aligned = exp_env("DL4DS_POINT_FIRST") != nullptr;      // (experiment: aligned 1x1 layers here instead of conv_stream<1,..>)
     if ((!take_aligned && (in.C & 3) == 0 && (out.C & 3) == 0) || in.C > 64 || out.C > 64 || ep.pool) return false;
     // the input may be a channel slice of a wider buffer (pixel pitch ld > C: a Concatenate's buffer): whole pixels of the wide
     // buffer are staged, the channels outside the slice meet zero filter entries

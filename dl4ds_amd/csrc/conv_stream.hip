@@ -898,11 +898,11 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
         sp.nblk = cdiv(p.Cout, 16 * NT);
         sp.m_nblk = div_magic(sp.nblk);
         sp.per_xcd = cdiv(sp.ntiles, 8);
-        const char* force = getenv("DL4DS_STREAM_FORCE_WS");       // (tests: "<workgroups per XCD>", small grids too)
+        const char* force = test_env("DL4DS_STREAM_FORCE_WS");       // (tests: "<workgroups per XCD>", small grids too)
         const int SX = force ? std::max(atoi(force), 1) : std::max(cu_count() / 8, 1);
         // at least one item per workgroup (two until round 3: "nothing to overlap" -- but the LDS-staged kernel these layers fell back to
         // is slower still: cfg5 568 -> 580 samples/s with 1, 581 with 0.5, 575 with 0.25; DL4DS_STREAM_MIN_ITEMS=<f> for A/B)
-        static const double min_items = getenv("DL4DS_STREAM_MIN_ITEMS") ? atof(getenv("DL4DS_STREAM_MIN_ITEMS")) : 1.0;
+        static const double min_items = exp_env("DL4DS_STREAM_MIN_ITEMS") ? atof(exp_env("DL4DS_STREAM_MIN_ITEMS")) : 1.0;
         if (!force && (double)sp.per_xcd * sp.nblk < min_items * SX) return false;
         sp.cw = p.Cout;
         if (p.Cout % NT) {
@@ -962,8 +962,8 @@ bool launch_stream_ws(hipStream_t s, StreamParams& sp, int N) {
 template <int KS, int E>
 void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
     if constexpr (KS == 3 && E >= 6) {
-        static const bool use_ws = getenv("DL4DS_STREAM_NO_WS") == nullptr;
-        if (use_ws && (NT >= 2 || (NT == 1 && E == 8 && !getenv("DL4DS_STREAM_NO_WS_NT1")))) {
+        static const bool use_ws = exp_env("DL4DS_STREAM_NO_WS") == nullptr;
+        if (use_ws && (NT >= 2 || (NT == 1 && E == 8 && !exp_env("DL4DS_STREAM_NO_WS_NT1")))) {
             const float* w0 = sp.c.w;
             bool done = false;
             if (NT == 1) { if constexpr (E == 8) done = launch_stream_ws<3, 8, 1, 4>(s, sp, N); }
@@ -977,7 +977,7 @@ void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
     if constexpr (KS == 1 && E > 4) {      // (16-channel chunks: a single group-step per tile, the filter ring needs two)
         // 1x1 layers on the producer / consumer kernel too (round 3): the helper waves keep the next tile in flight while the MFMA
         // waves work -- 48 -> 48 at 64 x 128^2: 0.137 -> 0.110 ms (2.9 -> 3.7 TB/s).  DL4DS_STREAM_NO_WS1=1 for A/B.
-        static const bool ws1 = getenv("DL4DS_STREAM_NO_WS") == nullptr && getenv("DL4DS_STREAM_NO_WS1") == nullptr;
+        static const bool ws1 = exp_env("DL4DS_STREAM_NO_WS") == nullptr && exp_env("DL4DS_STREAM_NO_WS1") == nullptr;
         if (ws1 && NT <= 3) {
             const float* w0 = sp.c.w;
             bool done = false;
@@ -1001,13 +1001,13 @@ void dispatch_nt(hipStream_t s, StreamParams& sp, int N, int NT) {
 // 5x5 layers (the 9x9 stride-2 transposed convolutions of DeconvolutionBlock as 5x5 convolutions + depth_to_space, deconv.hip):
 // only the producer / consumer kernel, 24- or 32-channel chunks
 static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep) {
-    static const bool off = getenv("DL4DS_STREAM_NO_WS") != nullptr || getenv("DL4DS_STREAM_NO_WS5") != nullptr;
-    if (getenv("DL4DS_STREAM_DEBUG"))
+    static const bool off = exp_env("DL4DS_STREAM_NO_WS") != nullptr || exp_env("DL4DS_STREAM_NO_WS5") != nullptr;
+    if (exp_env("DL4DS_STREAM_DEBUG"))
         fprintf(stderr, "stream5: N=%d H=%d W=%d Cin=%d (d2s %d cp %d vec %d) Cout=%d (d2s %d cp %d vec %d) add=%d mask=%d acc=%d\n", in.N, in.H,
                 in.W, in.C, in.d2s, in.cp, in.vec, out.C, out.d2s, out.cp, out.vec, ep.add.p != nullptr, ep.mask.p != nullptr, ep.accumulate);
     // 8 input channels (round 5: the ConvLSTM cells' 5x5 input convolutions 8 -> 32 gate channels, which ran on the fallback
     // conv_igemm_kernel at 58 TFLOP/s): one chunk of 8 channels, E = 2.  DL4DS_STREAM5_NO_E2=1 for A/B.
-    static const bool no_e2 = getenv("DL4DS_STREAM5_NO_E2") != nullptr;
+    static const bool no_e2 = exp_env("DL4DS_STREAM5_NO_E2") != nullptr;
     const bool e2 = in.C == 8 && out.C >= 16 && !no_e2;
     if (off || (in.C < 16 && !e2) || (long)in.H * in.W < 256) return false;
     if (!in.vec || !out.vec || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
@@ -1019,7 +1019,7 @@ static bool conv2d_stream5_forward(hipStream_t s, const TView& in, const float* 
     long best = -1;
     // (<= 16 outputs -- the dgrad of a ConvLSTM's 5x5 input kernel, 32 gate channels -> 8: one 16-cout block instead of two,
     //  half the MFMAs; DL4DS_STREAM5_NO_NT1=1 for A/B)
-    const int nt_lo = (out.C <= 16 && !getenv("DL4DS_STREAM5_NO_NT1")) ? 1 : 2;
+    const int nt_lo = (out.C <= 16 && !exp_env("DL4DS_STREAM5_NO_NT1")) ? 1 : 2;
     for (int pass = 0; pass < 2 && !NT; ++pass)
         for (int nt = nt_lo; nt <= 4; ++nt) {
             // through a depth_to_space store an n-block should not straddle a group (cp channels each); where every choice
@@ -1067,7 +1067,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     // the producer / consumer kernel with one 8-channel chunk
     if (KS == 3 && in.C == 8 && out.C >= 16 && (out.C & 3) == 0 && out.C % 32 == 0 && (long)in.H * in.W >= 256 && in.vec && out.vec &&
         (!ep.add.p || ep.add.vec) && (!ep.mask.p || ep.mask.vec) && ((((uintptr_t)ep.bias) & 15) == 0) &&
-        (long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N < (1l << 20) && !getenv("DL4DS_STREAM5_NO_E2") && !getenv("DL4DS_STREAM_NO_WS")) {
+        (long)cdiv(in.W, 16) * cdiv(in.H, 16) * in.N < (1l << 20) && !exp_env("DL4DS_STREAM5_NO_E2") && !exp_env("DL4DS_STREAM_NO_WS")) {
         StreamParams sp;
         ConvParams& p = sp.c;
         p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask;
@@ -1084,7 +1084,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     // cout tiling: NT accumulator tiles per wave, lanes own NT consecutive couts -> needs Cout % NT == 0
     int NT = 0;
     long best = -1;
-    static const bool no_ragged = getenv("DL4DS_STREAM_NO_RAGGED") != nullptr;      // (A/B measurements)
+    static const bool no_ragged = exp_env("DL4DS_STREAM_NO_RAGGED") != nullptr;      // (A/B measurements)
     for (int nt = 1; nt <= 4; ++nt) {
         if ((out.C % nt) && (no_ragged || out.C < 16)) continue;     // Cout % nt != 0: runs on a zero-padded filter copy
         const long padded = (long)cdiv(out.C, 16 * nt) * 16 * nt;
@@ -1112,7 +1112,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     // chunk width of 16 or 24 channels that does not pad K more than the wide chunk would
     bool tall = false;
     int NT8 = 0, E8 = 0;
-    if (KS == 3 && !getenv("DL4DS_STREAM_NO_TALL")) {
+    if (KS == 3 && !exp_env("DL4DS_STREAM_NO_TALL")) {
         long bp = -1;
         for (int nt = 1; nt <= 3; ++nt) {
             if ((out.C % nt) && (no_ragged || out.C < 16)) continue;
@@ -1125,10 +1125,10 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
             if (bk < 0 || padded < bk || (padded == bk && e > E8)) { bk = padded; E8 = e; }
         }
         const long ntiles8 = (long)cdiv(in.W, 16) * cdiv(in.H, 32) * in.N;
-        const bool big = ntiles8 * cdiv(out.C, 16 * NT8) >= 1024 || getenv("DL4DS_STREAM_FORCE_TALL") != nullptr ||
-                         getenv("DL4DS_STREAM_FORCE_WS") != nullptr;   // (tests)
+        const bool big = ntiles8 * cdiv(out.C, 16 * NT8) >= 1024 || test_env("DL4DS_STREAM_FORCE_TALL") != nullptr ||
+                         test_env("DL4DS_STREAM_FORCE_WS") != nullptr;   // (tests)
         tall = NT8 == 3 && E8 == 6 && bp <= best && bk <= bestk && big;     // (NT 2 / 16-channel chunks measured slower)
-        if (getenv("DL4DS_STREAM_TALL_ANY")) tall = NT8 >= 2 && bp <= best && bk <= bestk && big;     // (experiments)
+        if (exp_env("DL4DS_STREAM_TALL_ANY")) tall = NT8 >= 2 && bp <= best && bk <= bestk && big;     // (experiments)
     }
     StreamParams sp;
     ConvParams& p = sp.c;
@@ -1137,7 +1137,7 @@ bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int K
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;
     p.relu = ep.relu; p.accumulate = ep.accumulate;
     p.wvec = 0; p.CK = 4 * E; p.TPS = 0;
-    static const bool use_ws = getenv("DL4DS_STREAM_NO_WS") == nullptr;
+    static const bool use_ws = exp_env("DL4DS_STREAM_NO_WS") == nullptr;
     if (tall && use_ws && E8 == 6 && NT8 == 3) {
         p.CK = 24;
         if (launch_stream_ws<3, 6, 3, 8>(s, sp, in.N)) return true;

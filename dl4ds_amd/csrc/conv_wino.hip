@@ -129,7 +129,7 @@ constexpr size_t WINO_ENTRIES_MAX = 512;
 
 // -> the transformed filter to use and whether it still has to be computed (by the caller, on s)
 float* wino_filter_lookup(hipStream_t s, const float* w, int Cin, int Cout, int KQ, int NT, int nchunk, int total, bool& need) {
-    static const bool off = getenv("DL4DS_WINO_NO_FILTER_CACHE") != nullptr;          // (A/B)
+    static const bool off = exp_env("DL4DS_WINO_NO_FILTER_CACHE") != nullptr;          // (A/B)
     need = true;
     if (g_wino_pass_depth <= 0 || off) return wino_scratch(s, (size_t)total);
     auto& es = wino_entries();
@@ -190,7 +190,7 @@ namespace {
 // 3x3, stride 1, SAME.  Returns false when the layer is not eligible (the caller falls through to the direct kernels).
 bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep) {
     const bool off = getenv("DL4DS_NO_WINOGRAD") != nullptr;
-    const char* force = getenv("DL4DS_WINO_FORCE");          // (tests: small grids too; "<k>" = k workgroups per XCD and cout chunk)
+    const char* force = test_env("DL4DS_WINO_FORCE");          // (tests: small grids too; "<k>" = k workgroups per XCD and cout chunk)
     if (off) return false;
     if (in.sc || ep.pool) return false;
     if (!in.vec || !out.vec || (in.C & 3) || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;

@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino2_kernel(const WinoParams wp)
 }
 
 inline bool wino_first_form() {
-    static const bool v = getenv("DL4DS_WINO_V1") != nullptr;
+    static const bool v = exp_env("DL4DS_WINO_V1") != nullptr;
     return v;
 }
 

@@ -713,7 +713,7 @@ float* wgrad_scratch(hipStream_t s, size_t floats) {       // grow-only, one buf
 }
 
 inline bool wgrad_first_form() {
-    static const bool v = getenv("DL4DS_WINO_WGRAD_V1") != nullptr;
+    static const bool v = exp_env("DL4DS_WINO_WGRAD_V1") != nullptr;
     return v;
 }
 
@@ -747,7 +747,7 @@ void launch_wgrad(hipStream_t s, WinoWgradParams& wp, int SX) {
 // 3x3, stride 1, SAME: dw = [3][3][Cin][Cout], db = [Cout] or null.  false = not eligible (the caller runs the direct kernels).
 bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw, int accumulate, float* db, int accumulate_db) {
     if (getenv("DL4DS_NO_WINOGRAD") || getenv("DL4DS_NO_WINOGRAD_WGRAD")) return false;
-    const char* force = getenv("DL4DS_WINO_FORCE");
+    const char* force = test_env("DL4DS_WINO_FORCE");
     if (x.sc || dy.sc || !x.vec || !dy.vec || (x.C & 3) || (dy.C & 3)) return false;
     if (x.C < 24 || dy.C < 24) return false;
     // (measured, B = 64 at 128^2 / 256^2: 48 -> 48 0.31 vs 0.39 ms direct, 48 -> 192 1.10 vs 1.28, 40 -> 48 0.30 vs 0.39; chunks of 32

@@ -625,7 +625,7 @@ void convlstm_gate_interleave(hipStream_t s, const float* src, float* dst, int r
 
 // DL4DS_SEQ_TRACE=1 (development): per-phase times of every launch on stderr (synchronises)
 static unsigned long long* trace_begin(SeqParams& p, int grid, hipStream_t s) {
-    static const bool on = getenv("DL4DS_SEQ_TRACE") != nullptr;
+    static const bool on = exp_env("DL4DS_SEQ_TRACE") != nullptr;
     if (!on) return nullptr;
     static unsigned long long* buf = nullptr;
     if (!buf) HIP_CHECK(hipMalloc((void**)&buf, 4096 * 8 * sizeof(unsigned long long)));
@@ -658,7 +658,7 @@ static int seq_grid(const SeqParams& p) {
 // (its hand-off is 8 KB and the smaller tiles' extra halo costs more than it hides).  Measured at 16 x 8 x 64^2, F = 8:
 // backward 5x5 184 -> 173 us, 3x3 123 -> 109 us per launch with two 8 x 16 tiles; forward 87 / 62 us with 16 x 16, 95 / 68 with 8 x 16.
 static int seq_tr(int H, int W, int B, bool backward) {
-    if (const char* e = getenv("DL4DS_CONVLSTM_SEQ_TR")) return atoi(e) == 2 ? 2 : 4;
+    if (const char* e = exp_env("DL4DS_CONVLSTM_SEQ_TR")) return atoi(e) == 2 ? 2 : 4;
     const long t16 = (long)cdiv(H, 16) * cdiv(W, 16) * B;
     return (backward && t16 < 2l * std::max(cu_count(), 8) && H > 8) ? 2 : 4;
 }

@@ -43,7 +43,7 @@ __global__ void standin_for_rccl_allreduce_kernel(float* buf, size_t n) {
     }
 }
 void launch_standin(float* buf, size_t n, hipStream_t cs) {
-    static const bool on = std::getenv("DL4DS_DIST_STANDIN") != nullptr;
+    static const bool on = test_env("DL4DS_DIST_STANDIN") != nullptr;
     if (!on || g_world != 1) return;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 64);      // few workgroups: a collective occupies few CUs
     DL4DS_LAUNCH(standin_for_rccl_allreduce_kernel, dim3(blocks), dim3(256), 0, cs, buf, n);
@@ -124,14 +124,14 @@ void dist_allreduce_bucket_async(float* buf, size_t n, hipStream_t stream, hipSt
 // give up after DL4DS_COLLECTIVE_TIMEOUT_S (default 1800 s) with a message that names the call.
 void dist_stream_sync(hipStream_t stream, const char* what) {
     // (DL4DS_FORCE_WATCHDOG=1: take the polling path with a 1-rank communicator too -- the only way to exercise it on one GPU)
-    static const bool force = std::getenv("DL4DS_FORCE_WATCHDOG") != nullptr;
+    static const bool force = test_env("DL4DS_FORCE_WATCHDOG") != nullptr;
     if (g_comm == nullptr || (g_world <= 1 && !force)) {
         HIP_CHECK(hipStreamSynchronize(stream));
         device_error_check(what);
         return;
     }
     static const double limit = [] {
-        const char* e = std::getenv("DL4DS_COLLECTIVE_TIMEOUT_S");
+        const char* e = getenv("DL4DS_COLLECTIVE_TIMEOUT_S");
         const double v = e ? std::atof(e) : 0.0;
         return v > 0.0 ? v : 1800.0;
     }();
@@ -172,7 +172,7 @@ void dist_broadcast(float* buf, size_t n, int root, hipStream_t stream) {
 
 int dist_expected_world() {
     // (same reading as dl4ds_amd.parallel.allow_unsynced: unset, empty, "0", "false", "no", "off" mean NO)
-    const char* allow = std::getenv("DL4DS_ALLOW_UNSYNCED");
+    const char* allow = getenv("DL4DS_ALLOW_UNSYNCED");
     if (allow && allow[0] && std::strcmp(allow, "0") != 0 && strcasecmp(allow, "false") != 0 && strcasecmp(allow, "no") != 0 &&
         strcasecmp(allow, "off") != 0)
         return 1;

@@ -789,7 +789,7 @@ void maxpool2_forward(hipStream_t s, const TView& x, const TView& y) {
     DL4DS_REQUIRE(y.H == x.H / 2 && y.W == x.W / 2 && y.C == x.C && y.N == x.N, "maxpool2: shapes");
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     ProfScope ps(s, "maxpool2_fwd", 0.0, 4.0 * (double)total * 5);
-    static const bool no_quad = getenv("DL4DS_NO_POOL_QUAD") != nullptr;      // (A/B)
+    static const bool no_quad = exp_env("DL4DS_NO_POOL_QUAD") != nullptr;      // (A/B)
     if (!no_quad && pool_quad_ok(x) && pool_quad_ok(y)) {
         DL4DS_LAUNCH(maxpool2_fwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x, y, total / 4);
         HIP_CHECK(hipGetLastError());
@@ -804,7 +804,7 @@ void maxpool2_backward(hipStream_t s, const TView& x, const TView& y, const TVie
                   "maxpool2 backward with odd sizes needs a pre-zeroed accumulate target");
     const size_t total = (size_t)y.N * y.H * y.W * y.C;
     ProfScope ps(s, "maxpool2_bwd", 0.0, 4.0 * (double)total * (2 + 4 + 4 + (accumulate ? 4 : 0)));
-    static const bool no_quad = getenv("DL4DS_NO_POOL_QUAD") != nullptr;      // (A/B)
+    static const bool no_quad = exp_env("DL4DS_NO_POOL_QUAD") != nullptr;      // (A/B)
     if (!no_quad && pool_quad_ok(x) && pool_quad_ok(y) && pool_quad_ok(dy) && pool_quad_ok(dx)) {
         DL4DS_LAUNCH(maxpool2_bwd4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, s, x, y, dy, dx, accumulate, relu_mask, total / 4);
         HIP_CHECK(hipGetLastError());
@@ -1159,7 +1159,7 @@ void resize_table_forward(hipStream_t s, const TView& x, const TView& y, const i
     auto dense = [](const TView& v) { return v.d2s <= 1 && v.ld == v.C && v.nstride == (size_t)v.H * v.W * v.C && v.vec; };
     const size_t rows = (size_t)y.N * y.H, per_row4 = (size_t)y.W * (y.C >> 2);
     if (dense(x) && dense(y) && !x.sc && ky == kx && (ky == 2 || ky == 4) && rows < (1ull << 31) && per_row4 < (1u << 20) && (y.C >> 2) <= 4096 &&
-        !getenv("DL4DS_NO_RESIZE_FWDK")) {
+        !exp_env("DL4DS_NO_RESIZE_FWDK")) {
         ProfScope ps(s, "resize_table_fwd", 0.0, 4.0 * ((double)total + (double)x.N * x.H * x.W * x.C));
         auto kern = ky == 2 ? resize_table_fwdk_kernel<2> : resize_table_fwdk_kernel<4>;
         const int threads = per_row4 >= 256 ? 256 : 64;
@@ -1183,7 +1183,7 @@ void resize_table_backward(hipStream_t s, const TView& dy, const TView& dx, cons
     const size_t total = (size_t)dx.N * dx.H * dx.W * dx.C;
     if (dy.vec && dx.vec && dy.d2s <= 1 && dx.d2s <= 1 && !dy.sc && total / 4 < (1ull << 32)) {
         ProfScope ps(s, "resize_table_bwd", 0.0, 4.0 * ((double)total * (accumulate ? 2 : 1) + (double)dy.N * dy.H * dy.W * dy.C));
-        static const bool no_u = getenv("DL4DS_NO_RESIZE_BWDU") != nullptr;      // (A/B)
+        static const bool no_u = exp_env("DL4DS_NO_RESIZE_BWDU") != nullptr;      // (A/B)
         if (max_taps_x > 0 && max_taps_x <= 8 && !no_u) {
             auto kern = max_taps_x <= 4 ? resize_table_bwd4u_kernel<4> : resize_table_bwd4u_kernel<8>;
             DL4DS_LAUNCH(kern, dim3(ew_blocks(total / 4)), dim3(256), 0, s, dy, dx, py, oy, vy, px, ox, vx, accumulate, total / 4);

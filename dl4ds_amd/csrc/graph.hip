@@ -178,7 +178,7 @@ bool Graph::plan_shared(const std::vector<int>& dup_inputs) {
     op_shared.assign(ops.size(), 0);
     t_boundary.assign(tensors.size(), 0);
     auto fail = [&]() { op_shared.clear(); t_boundary.clear(); return false; };
-    if (getenv("DL4DS_NO_SHARED_BRANCH")) return fail();
+    if (test_env("DL4DS_NO_SHARED_BRANCH")) return fail();
     std::vector<char> tdup(tensors.size(), 0);
     for (int t : dup_inputs) {
         if (tensors.at(t).requires_grad) return fail();
@@ -322,7 +322,7 @@ inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
     const GTensor& t = g.tensors[tid];
     // (a pass without parameter gradients -- the generator's adversarial gradient through the discriminator -- only needs the
     //  tensors that depend on an input that takes a gradient: the conditioning branch of the discriminator is skipped)
-    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || getenv("DL4DS_NO_BWD_PRUNE") != nullptr);
+    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || exp_env("DL4DS_NO_BWD_PRUNE") != nullptr);
 }
 
 // ChannelAttention2D between two convolutions (ConvBlock(attention=True) followed by another conv: blocks.py:87-103,
@@ -381,7 +381,7 @@ struct ConvOp : GOp {
     void on_finalize(Graph& g) override {
         // y = act(conv(x) + r): dL/dr = dZ.  When this add is r's only consumer (the 1x1-projected skip of a residual
         // block) r's gradient buffer can simply be dZ's -- nothing writes it again before r's producer has read it
-        if (add >= 0 && d2s <= 1 && !getenv("DL4DS_NO_GRAD_SHARE")) {
+        if (add >= 0 && d2s <= 1 && !exp_env("DL4DS_NO_GRAD_SHARE")) {
             const GTensor& r = g.tensors[add];
             bool is_output = false;
             for (int o : g.outputs) is_output |= (o == add);
@@ -391,7 +391,7 @@ struct ConvOp : GOp {
         // ... and where it cannot be shared, the copy of dZ into r's gradient can apply r's own ReLU mask (r = ReLU output of a
         // Conv2D: the input of a residual block that also feeds the block's first convolution), which lets r's producer drop
         // its separate ReLU-backward pass as it does when all consumers are convolutions
-        if (add >= 0 && !add_grad_shared && !getenv("DL4DS_NO_MASK_FUSION")) {
+        if (add >= 0 && !add_grad_shared && !exp_env("DL4DS_NO_MASK_FUSION")) {
             GTensor& r = g.tensors[add];
             bool is_output = false;
             for (int o : g.outputs) is_output |= (o == add);
@@ -405,7 +405,7 @@ struct ConvOp : GOp {
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
         t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_add_in + t.n_masking) >= 1 && t.n_other == 0 &&
-                        !getenv("DL4DS_NO_MASK_FUSION");
+                        !exp_env("DL4DS_NO_MASK_FUSION");
     }
     TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
         const GTensor& ti = g.tensors[in];
@@ -444,7 +444,7 @@ struct ConvOp : GOp {
             // leave dZ where it is; that convolution's dgrad store adds it (ConvOp::backward below), no copy
             const bool defer = !add_grad_shared && !ra.grad_written && ra.n_conv_in == 1 && ra.n_add_in == 0 && ra.n_masking == 0 &&
                                ra.n_other == 1 && ra.n_fused_add == 1 && d2s <= 1 && !dY.sc && defer_ok(g, add) &&
-                               !getenv("DL4DS_NO_DEFERRED_ADD");
+                               !exp_env("DL4DS_NO_DEFERRED_ADD");
             if (defer) {
                 ra.pending_add = dY.p;
             } else if (!add_grad_shared) {
@@ -468,7 +468,7 @@ struct ConvOp : GOp {
             // dW, db AND the attention's d(loss)/d(scale) (conv2d_direct_wgrad_attention), on the main stream
             bool done = false;
             if (att_before && att_before->fuse_scale && c.b_off == 0 && (c.b_cnt < 0 || c.b_cnt == c.B) &&
-                !getenv("DL4DS_NO_DS_FUSION")) {
+                !exp_env("DL4DS_NO_DS_FUSION")) {
                 done = conv2d_direct_wgrad_attention(g.stream, g.view(att_before->att_in, c.B, false), dY, KS, att_before->scale,
                                                      g.wp(w), g.gp(w), g.params[w].grad_written, need_db ? g.gp(b) : nullptr,
                                                      need_db ? (int)g.params[b].grad_written : 0, att_before->ds, g.workspace,
@@ -557,7 +557,7 @@ struct ChAttOp : GOp {
     // which pieces can be handed to the neighbours: needs the real views (alignment), so decided once the buffers exist
     void on_prepare(Graph& g) override {
         fz.fuse_pool = fz.fuse_scale = fz.fuse_dx = false;
-        if (T5 > 0 || getenv("DL4DS_NO_TAIL_FUSION")) return;
+        if (T5 > 0 || test_env("DL4DS_NO_TAIL_FUSION")) return;
         const int B = g.maxB;
         float *mean, *hidden, *scale, *dmean, *pool;
         ptrs(g, B, mean, hidden, scale, dmean, pool, &fz.ds);
@@ -612,7 +612,7 @@ struct ChAttOp : GOp {
         return std::string("{\"op\":\"chatt\",\"in\":") + std::to_string(in) + ",\"pool_from_producer\":" +
                (fz.fuse_pool ? "true" : "false") + ",\"scale_in_consumer_load\":" + (fz.fuse_scale ? "true" : "false") +
                ",\"dx_in_producer_backward\":" + (fz.fuse_dx ? "true" : "false") + ",\"dscale_from_consumer_wgrad\":" +
-               (fz.fuse_scale && !getenv("DL4DS_NO_DS_FUSION") ? "true" : "false") + "}";
+               (fz.fuse_scale && !exp_env("DL4DS_NO_DS_FUSION") ? "true" : "false") + "}";
     }
     bool partial_batch_ok() const override { return false; }
     void backward(Graph& g, const BwdCtx& c) override {
@@ -656,7 +656,7 @@ struct ConcatOp : GOp {
             const TView wide = g.view(out, B, false);
             ConcatSlice sl[4];
             int n = 0, off = 0;
-            bool ok = wide.d2s <= 1 && wide.ld == wide.C && wide.nstride == (size_t)wide.H * wide.W * wide.C && !getenv("DL4DS_NO_CONCAT_JOIN");
+            bool ok = wide.d2s <= 1 && wide.ld == wide.C && wide.nstride == (size_t)wide.H * wide.W * wide.C && !exp_env("DL4DS_NO_CONCAT_JOIN");
             for (size_t k = 0; k < ins.size() && ok; ++k) {
                 const GTensor& ti = g.tensors[ins[k]];
                 if (ti.alias_parent != out) {
@@ -684,7 +684,7 @@ struct ConcatOp : GOp {
             const bool wide_plain = wide.d2s <= 1 && wide.ld == wide.C && wide.nstride == (size_t)wide.H * wide.W * wide.C;
             ConcatSlice sl[4];
             int n = 0, off = 0;
-            bool ok = wide_plain && !getenv("DL4DS_NO_CONCAT_SPLIT");
+            bool ok = wide_plain && !exp_env("DL4DS_NO_CONCAT_SPLIT");
             for (size_t k = 0; k < ins.size() && ok; ++k) {
                 const GTensor& ti = g.tensors[ins[k]];
                 if (wants_grad(g, ins[k], c) && !ti.galias) {
@@ -1140,7 +1140,7 @@ int g_resize(Graph& g, int in, int Ho, int Wo, int nearest) {
     ResizeOp* op = push<ResizeOp>(g);
     DL4DS_REQUIRE(nearest >= 0 && nearest <= 6, "resize: unknown method");
     op->in = in; op->out = out; op->method = nearest; op->nearest = nearest == 1;
-    op->bicubic = nearest >= 2 || (nearest == 0 && !getenv("DL4DS_RESIZE_BILINEAR_DIRECT"));     // table-driven
+    op->bicubic = nearest >= 2 || (nearest == 0 && !exp_env("DL4DS_RESIZE_BILINEAR_DIRECT"));     // table-driven
     g.tensors[in].n_other++;
     op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
@@ -1181,7 +1181,7 @@ int g_repeat_time(Graph& g, int in, int T) {
 // not a model input / output.  DenseBlock chains resolve to ONE buffer:
 // x_{k+1} = concat(x_k, f(x_k)) makes x_k a channel prefix of x_{k+1}.  DL4DS_NO_CONCAT_ALIAS=1 keeps the copies (A/B, tests).
 static void plan_concat_aliases(Graph& g) {
-    if (getenv("DL4DS_NO_CONCAT_ALIAS")) return;
+    if (test_env("DL4DS_NO_CONCAT_ALIAS")) return;
     const int nt = (int)g.tensors.size();
     std::vector<int> conv_readers(nt, 0), producer_ok(nt, 0);
     for (auto& up : g.ops) {
@@ -1194,7 +1194,7 @@ static void plan_concat_aliases(Graph& g) {
             // Conv2DTranspose stores through a depth_to_space view; LocalizedConvBlock and the time repeat store through plain
             // views of any channel count / offset (2 = no alignment rule: cfg4's 16 + 8 + 2-channel concatenation)
             const bool any_align = std::string(up->kind) == "localconv" || std::string(up->kind) == "repeat_time";
-            producer_ok[up->alias_output()] = (any_align && !getenv("DL4DS_NO_SLICE_WRITERS")) ? 2 : (any_align ? 0 : 1);
+            producer_ok[up->alias_output()] = (any_align && !exp_env("DL4DS_NO_SLICE_WRITERS")) ? 2 : (any_align ? 0 : 1);
         }
     }
     auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
@@ -1207,7 +1207,7 @@ static void plan_concat_aliases(Graph& g) {
         // and every producer that stores into it writes partial sectors (cfg4: the 16-channel convolution 519 instead of 302 us,
         // the 8-channel time repeat 394 instead of 69, LocalizedConvBlock 319 instead of 72).  Such a concatenation keeps its own
         // buffer and is written in one pass (concat_join); its inputs may still be concatenations with aligned pixels.
-        const bool pitch_ok = (g.tensors[k->out].C & 7) == 0 || getenv("DL4DS_ALIAS_ANY_PITCH") != nullptr;
+        const bool pitch_ok = (g.tensors[k->out].C & 7) == 0 || exp_env("DL4DS_ALIAS_ANY_PITCH") != nullptr;
         for (int t : k->ins) {
             GTensor& ti = g.tensors[t];
             const bool ok = pitch_ok && producer_ok[t] && !ti.is_input && !is_output(t) && ti.alias_of < 0 && ti.n_add_in == 0 &&
@@ -1240,7 +1240,7 @@ static void plan_concat_aliases(Graph& g) {
 // The U-Net decoder levels (PadConcat of the transposed convolution's output and the encoder skip) qualify.
 // DL4DS_NO_GRAD_ALIAS=1 keeps the copies (A/B, tests).
 static void plan_grad_aliases(Graph& g) {
-    if (getenv("DL4DS_NO_GRAD_ALIAS") || getenv("DL4DS_NO_CONCAT_ALIAS")) return;
+    if (test_env("DL4DS_NO_GRAD_ALIAS") || test_env("DL4DS_NO_CONCAT_ALIAS")) return;
     auto is_output = [&](int t) { for (int o : g.outputs) if (o == t) return true; return false; };
     const int nops = (int)g.ops.size();
     for (int ik = 0; ik < nops; ++ik) {
@@ -1270,7 +1270,7 @@ static void plan_grad_aliases(Graph& g) {
                 if (reads(g.ops[j].get(), t)) ok = false;
         if (!ok) continue;
         if (any_masked) {
-            const bool r_maskable = (tr.n_conv_in + tr.n_add_in + tr.n_masking) >= 1 && tr.n_other == 0 && !getenv("DL4DS_NO_MASK_FUSION");
+            const bool r_maskable = (tr.n_conv_in + tr.n_add_in + tr.n_masking) >= 1 && tr.n_other == 0 && !exp_env("DL4DS_NO_MASK_FUSION");
             if (!all_relu || !r_maskable) continue;
             tr.grad_masked = true;
             tr.relu_out = true;                      // (every channel of R is a ReLU output)

@@ -9,7 +9,7 @@ namespace {
 
 inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
     const GTensor& t = g.tensors[tid];
-    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || getenv("DL4DS_NO_BWD_PRUNE") != nullptr);
+    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || exp_env("DL4DS_NO_BWD_PRUNE") != nullptr);
 }
 template <class T>
 T* push(Graph& g) {
@@ -37,7 +37,7 @@ struct ConvTOp : GOp {
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
         t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_add_in + t.n_masking) >= 1 && t.n_other == 0 &&
-                        !getenv("DL4DS_NO_MASK_FUSION");
+                        !exp_env("DL4DS_NO_MASK_FUSION");
     }
     void forward(Graph& g, int B, bool) override {
         conv2d_transpose_forward(g.stream, g.view(in, B, false), g.wp(w), KS, stride, g.view(out, B, false), relu,
@@ -383,7 +383,7 @@ int g_gap(Graph& g, int in, int over_time) {
     GapOp* op = push<GapOp>(g);
     op->in = in; op->out = out; op->over_time = over_time != 0;
     // a masking consumer (like MaxPooling2D / Concatenate): its backward applies the input's ReLU mask (DL4DS_NO_GAP_MASK=1: as before)
-    if (getenv("DL4DS_NO_GAP_MASK")) g.tensors[in].n_other++; else g.tensors[in].n_masking++;
+    if (exp_env("DL4DS_NO_GAP_MASK")) g.tensors[in].n_other++; else g.tensors[in].n_masking++;
     op->out_tid = out; op->in_tids = {in};
     g.tensors[out].dep_grad_input = g.tensors[in].dep_grad_input;
     return out;

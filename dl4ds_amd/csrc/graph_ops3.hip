@@ -9,7 +9,7 @@ namespace {
 
 inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
     const GTensor& t = g.tensors[tid];
-    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || getenv("DL4DS_NO_BWD_PRUNE") != nullptr);
+    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || exp_env("DL4DS_NO_BWD_PRUNE") != nullptr);
 }
 
 // ============================================================================================ LayerNorm / BatchNorm
@@ -191,7 +191,7 @@ struct FoldedConvOp : GOp {
         bool is_output = false;
         for (int o : g.outputs) is_output |= (o == out);
         t.grad_masked = relu && !is_output && (t.n_conv_in + t.n_masking) >= 1 && t.n_add_in == 0 && t.n_other == 0 &&
-                        !getenv("DL4DS_NO_MASK_FUSION");
+                        !exp_env("DL4DS_NO_MASK_FUSION");
     }
     TView out_view(Graph& g, bool grad, int B, int bo, int bc) {
         const GTensor& ti = g.tensors[in];

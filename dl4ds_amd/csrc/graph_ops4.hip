@@ -26,7 +26,7 @@ namespace {
 
 inline bool wants_grad(const Graph& g, int tid, const BwdCtx& c) {
     const GTensor& t = g.tensors[tid];
-    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || getenv("DL4DS_NO_BWD_PRUNE") != nullptr);
+    return t.requires_grad && (!t.is_input || c.input_grads) && (c.param_grads || t.dep_grad_input || exp_env("DL4DS_NO_BWD_PRUNE") != nullptr);
 }
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) rec_tail_finish_kernel(const TailFinishPa
 }
 
 bool rec_tail_staged(int HW) {
-    static const bool no_staged = getenv("DL4DS_REC_TAIL_NO_STAGED") != nullptr;
+    static const bool no_staged = exp_env("DL4DS_REC_TAIL_NO_STAGED") != nullptr;
     return HW % 256 == 0 && !no_staged;
 }
 template <int CX, int CS, int CO>

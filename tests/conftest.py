@@ -7,6 +7,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the library honours its test hooks (force a kernel onto a small grid, play a collective, switch one graph transformation off for an
+# A/B comparison: csrc/common.h test_env) only under this switch; child processes of the tests inherit it
+os.environ.setdefault('DL4DS_TEST_HOOKS', '1')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')
 

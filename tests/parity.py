@@ -36,7 +36,7 @@ REPORT_ONLY = os.environ.get('DL4DS_PARITY_REPORT_ONLY', '') == '1'       # coll
 # QUIET_LIMIT of its tensor's size -- a selection made from the oracle alone, before any result of the HIP path is looked at --
 # and are then held to the caps like every other comparison (with nothing granted, every entry has to pass on 1e-3 itself).
 QUIET_LIMIT = 5e-4
-QUIET_SEEDS = 12
+QUIET_SEEDS = 8
 
 
 def is_quiet(ref, limit=QUIET_LIMIT):

@@ -6,6 +6,8 @@ import pytest
 
 import dl4ds_amd._lib as L
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_header_parses_and_library_exports_every_symbol():
     protos = L.parse_header()
@@ -31,3 +33,23 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_product_run_time_switches_stay_few_and_documented():
+    """experiment scaffolding must not be product surface.  The library sources read at most ten DL4DS_*
+    variables through getenv (all of them in README's table); test hooks go through test_env (honoured only under DL4DS_TEST_HOOKS=1)
+    and are listed in README; everything else goes through exp_env, which is the constant nullptr outside -DDL4DS_EXPERIMENTS builds."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, 'dl4ds_amd', 'csrc')
+    src = ''.join(open(f).read() for f in sorted(glob.glob(csrc + '/*.hip') + glob.glob(csrc + '/*.cpp') + glob.glob(csrc + '/*.h')))
+    readme = open(os.path.join(ROOT, 'README.md')).read()
+    product = set(re.findall(r'(?<![_a-z])getenv\("(DL4DS_[A-Z0-9_]+)"\)', src)) - {'DL4DS_TEST_HOOKS'}
+    hooks = set(re.findall(r'test_env\("(DL4DS_[A-Z0-9_]+)"\)', src))
+    exps = set(re.findall(r'exp_env\("(DL4DS_[A-Z0-9_]+)"\)', src))
+    assert 0 < len(product) <= 10, sorted(product)
+    for name in sorted(product | hooks):
+        assert '`' + name in readme, f'{name} is read by the product library but not documented in README.md'
+    assert not (product & exps) and not (hooks & exps) and not (product & hooks)
+    common = open(os.path.join(csrc, 'common.h')).read()
+    assert 'inline const char* exp_env(const char*) { return nullptr; }' in common

@@ -1,16 +1,17 @@
 #!/bin/bash
-# Run on the GPU box: rocprofv3 kernel-trace stats of bench.py + separate PMC passes (FETCH_SIZE, WRITE_SIZE).
-# Usage: tools/rocprof_round.sh r01   -> writes summaries under gpurun_out/prof_<tag>/
-TAG=${1:-r01}
+# GPU box: a round's evidence in one call:  tools/rocprof_round.sh r05
+#   tools/rocprof_all.sh <tag> (kernel stats + FETCH_SIZE / WRITE_SIZE passes for three configs + the default bench line), the
+#   fingerprint of the kernel sources the counters ran on (bench.py: csrc_sha -> profiles/traffic.json), SQ counters per config
+#   (three separate --pmc passes each, no tracing flags), the derived MFMA-busy tables, a DL4DS_FORCE_DIST=1 line (1-rank RCCL path).
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-unfolded"
-rocprofv3 --kernel-trace --stats -d /tmp/prof_stats --output-format csv -- $CMD > $OUT/bench_under_rocprof.log 2>&1
-python $R/tools/rocprof_stats_summary.py /tmp/prof_stats > $OUT/kernel_stats_$TAG.txt
-rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch --output-format csv -- $CMD > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_write --output-format csv -- $CMD > /dev/null 2>&1
-python $R/tools/pmc_traffic.py /tmp/prof_fetch /tmp/prof_write > $OUT/pmc_traffic_$TAG.json
-grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_$TAG.json
-ls -la $OUT
+mkdir -p $R/gpurun_out/prof_$TAG
+python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.csrc_sha())" > $R/gpurun_out/prof_$TAG/csrc_sha.txt
+bash $R/tools/rocprof_all.sh $TAG > /dev/null 2>&1
+for CFG in cfg2 cfg5 cfg4; do
+  bash $R/tools/pmc_sq.sh --config $CFG
+  cp $R/gpurun_out/pmc_sq.txt $R/gpurun_out/prof_$TAG/pmc_sq_${CFG}_$TAG.txt
+  python $R/tools/pmc_derived.py $R/gpurun_out/pmc_sq.txt > $R/gpurun_out/prof_$TAG/pmc_mfma_${CFG}_$TAG.txt
+done
+( cd $R && DL4DS_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > gpurun_out/prof_$TAG/bench_force_dist_$TAG.json 2>/dev/null )
+ls $R/gpurun_out/prof_$TAG
