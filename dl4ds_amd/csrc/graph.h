@@ -27,11 +27,13 @@ struct GTensor {
     int n_masking = 0;         // ... as an input of a Concatenate / MaxPooling2D (their backward applies the mask, too)
     int n_concat_in = 0;       // ... of which Concatenates
     int n_fused_add = 0;       // ... (counted in n_other) as the residual operand fused into a Conv2D's epilogue
+    bool two_add_inplace = false;   // feeds ONE Conv2D and TWO fused adds, planned copy-free (ConvOp::on_prepare, round 5)
     int n_pool_in = 0, n_convt_in = 0;   // ... (counted in n_masking) as the input of a MaxPooling2D / Conv2DTranspose
     bool relu_out = false;     // written by a layer whose fused activation is ReLU
     // residual-block input during a backward pass: the gradient arriving through the block's fused add (the add's dZ) that
     // the block's first convolution will fold into its dgrad store instead of a copy + an accumulating store (null: none)
     const float* pending_add = nullptr;
+    TView pending_view{};      // the pending operand with ITS layout (it may be a channel slice of a Concatenate's gradient: pitch != C)
     // Concatenate without the forward copy: the activation lives INSIDE the concatenation's buffer (channel offset
     // alias_coff of tensor alias_of, pixel pitch alias_ld = that buffer's channel count); decided at finalize for tensors
     // written by a Conv2D / Concatenate and read only by Conv2Ds and ONE Concatenate.  Gradients stay dense.

@@ -377,6 +377,39 @@ struct ConvOp : GOp {
     }
     void on_prepare(Graph& g) override {
         if (add_grad_shared) g.tensors[add].grad = g.tensors[out].grad;
+        plan_two_adds(g);
+        if (add_grad_inplace) g.tensors[add].grad = g.tensors[out].grad;
+    }
+    // r feeds ONE convolution C and TWO fused adds A1 < A2 (a residual branch's input that is also its long skip: the
+    // discriminator's branches, cfg5).  Until round 5: dZ(A2) was COPIED into r's gradient, dZ(A1) accumulated onto it, C's dgrad
+    // accumulated again -- five passes over an 8 x 512^2 x 32 tensor beside the dgrad.  Now r's gradient buffer IS dZ(A1)'s (this op =
+    // A1 decides, like add_grad_shared), dZ(A2) stays where it is as the pending operand of C's dgrad store (ConvOp::backward: dx =
+    // dgrad + dZ(A2) + old value): no pass at all.  Needs C before A1 in op order (its backward comes last), equal shapes, no ReLU mask
+    // on r's gradient, and no second stream (A1's weight gradient reads the buffer C's dgrad overwrites).
+    bool add_grad_inplace = false;
+    void plan_two_adds(Graph& g) {
+        add_grad_inplace = false;
+        if (add < 0 || add_grad_shared || d2s > 1 || g.aux_stream || att_before || att_after || test_env("DL4DS_NO_TWO_ADD_INPLACE")) return;
+        GTensor& r = g.tensors[add];
+        for (int o : g.outputs) if (o == add) return;
+        if (r.is_input || !r.requires_grad || r.grad_masked || r.galias || r.alias_of >= 0 || r.n_conv_in != 1 || r.n_add_in != 0 ||
+            r.n_masking != 0 || r.n_other != 2 || r.n_fused_add != 2 || r.per_sample() != g.tensors[out].per_sample())
+            return;
+        int me = -1, other = -1, consumer = -1;
+        for (int i = 0; i < (int)g.ops.size(); ++i) {
+            ConvOp* c = dynamic_cast<ConvOp*>(g.ops[i].get());
+            if (!c) continue;
+            if (c == this) me = i;
+            else if (c->add == add) other = i;
+            if (c->in == add) { if (c->att_before || c->att_after) return; consumer = i; }
+        }
+        if (me < 0 || other < 0 || consumer < 0) return;
+        ConvOp* oc = static_cast<ConvOp*>(g.ops[other].get());
+        if (oc->d2s > 1 || oc->add_grad_shared || oc->att_before || oc->att_after || g.tensors[oc->out].per_sample() != r.per_sample()) return;
+        if (g.tensors[out].galias || g.tensors[out].alias_of >= 0) return;
+        if (!(consumer < me && me < other)) return;        // this op is A1; A2 = `other` defers through r.two_add_inplace
+        add_grad_inplace = true;
+        r.two_add_inplace = true;
     }
     void on_finalize(Graph& g) override {
         // y = act(conv(x) + r): dL/dr = dZ.  When this add is r's only consumer (the 1x1-projected skip of a residual
@@ -442,11 +475,22 @@ struct ConvOp : GOp {
             GTensor& ra = g.tensors[add];
             // r feeds exactly this add and ONE convolution (a residual block's input) and nothing has written its gradient yet:
             // leave dZ where it is; that convolution's dgrad store adds it (ConvOp::backward below), no copy
-            const bool defer = !add_grad_shared && !ra.grad_written && ra.n_conv_in == 1 && ra.n_add_in == 0 && ra.n_masking == 0 &&
-                               ra.n_other == 1 && ra.n_fused_add == 1 && d2s <= 1 && !dY.sc && defer_ok(g, add) &&
-                               !exp_env("DL4DS_NO_DEFERRED_ADD");
+            bool defer = !add_grad_shared && !ra.grad_written && ra.n_conv_in == 1 && ra.n_add_in == 0 && ra.n_masking == 0 &&
+                         ra.n_other == 1 && ra.n_fused_add == 1 && d2s <= 1 && !dY.sc && defer_ok(g, add) &&
+                         !exp_env("DL4DS_NO_DEFERRED_ADD");
+            // two fused adds planned copy-free (plan_two_adds): the LATER one (its backward runs first) leaves dZ as the pending
+            // operand of the consuming convolution's dgrad store; the earlier one's dZ already is r's gradient buffer
+            const bool inplace_here = add_grad_inplace && ra.two_add_inplace && !dY.sc;
+            if (ra.two_add_inplace && !add_grad_inplace && !ra.grad_written && !ra.pending_add && d2s <= 1 && !dY.sc) defer = true;
+            if (exp_env("DL4DS_ADD_DEBUG"))
+                fprintf(stderr, "conv add grad: op out=%d add=%d defer=%d shared=%d written=%d n_conv_in=%d n_add_in=%d n_masking=%d n_other=%d n_fused_add=%d d2s=%d masked=%d C=%d H=%d B=%d\n",
+                        out, add, (int)defer, (int)add_grad_shared, (int)ra.grad_written, ra.n_conv_in, ra.n_add_in, ra.n_masking, ra.n_other,
+                        ra.n_fused_add, d2s, (int)ra.grad_masked, ra.C, ra.H, c.B);
             if (defer) {
                 ra.pending_add = dY.p;
+                ra.pending_view = dY;
+            } else if (inplace_here) {
+                DL4DS_REQUIRE(!ra.grad_written && dY.p == g.view(add, c.B, true, c.b_off, c.b_cnt).p, "two-add plan: the shared gradient buffer is not dZ");
             } else if (!add_grad_shared) {
                 if (g.tensors[add].grad_masked)
                     view_axpy_masked(g.stream, dY, g.view(add, c.B, false, c.b_off, c.b_cnt), g.view(add, c.B, true, c.b_off, c.b_cnt),
@@ -490,9 +534,7 @@ struct ConvOp : GOp {
             if (g.tensors[in].grad_masked) ep.mask = g.view(in, c.B, false, c.b_off, c.b_cnt);
             if (g.tensors[in].pending_add) {
                 // the gradient that reached this tensor through the residual add of its block: dx = dgrad + dZ_add (then masked)
-                TView pv = g.view(in, c.B, true, c.b_off, c.b_cnt);
-                pv.p = const_cast<float*>(g.tensors[in].pending_add);
-                ep.add = pv;
+                ep.add = g.tensors[in].pending_view;       // (its own pixel pitch: dZ may live inside a Concatenate's gradient buffer)
                 g.tensors[in].pending_add = nullptr;
             }
             conv2d_forward(g.stream, dY, wt, KS, g.view(in, c.B, true, c.b_off, c.b_cnt), ep);
@@ -738,6 +780,9 @@ struct AddOp : GOp {
         }
         for (int t : {a, b}) {
             if (!wants_grad(g, t, c)) continue;
+            if (exp_env("DL4DS_ADD_DEBUG"))
+                fprintf(stderr, "add op grad: out=%d operand=%d masked=%d written=%d C=%d H=%d B=%d\n", out, t, (int)g.tensors[t].grad_masked,
+                        (int)g.tensors[t].grad_written, g.tensors[t].C, g.tensors[t].H, c.B);
             if (g.tensors[t].grad_masked) {
                 // the operand is a ReLU output whose mask its consumers apply: fold it into this copy
                 const size_t ps = g.tensors[t].per_sample();

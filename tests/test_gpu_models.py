@@ -461,14 +461,17 @@ def test_cgan_step_matches_oracle():
             assert np.abs((w[k] - P0[k]) - (Pt[k].detach().numpy() - P0[k])).max() < 0.2 * 2e-4 + 1e-7, k
 
 
-@pytest.mark.parametrize('switch', ['DL4DS_NO_SHARED_BRANCH', 'DL4DS_NO_CGAN_RATIO'])
+@pytest.mark.parametrize('switch', ['DL4DS_NO_SHARED_BRANCH', 'DL4DS_NO_CGAN_RATIO', 'DL4DS_NO_TWO_ADD_INPLACE'])
 def test_cgan_shared_conditioning_branch_equals_two_evaluations(monkeypatch, switch):
     """The discriminator sees [real ; fake] with the SAME conditioning array in both halves; its conditioning branch is evaluated
     once (Graph::plan_shared, csrc/graph.hip), the hand-over tensor copied to the second half and its gradient halves summed
     before the branch's backward.  Against the same step with the branch evaluated on both halves (DL4DS_NO_SHARED_BRANCH=1:
     what the reference's two discriminator calls do, cgan.py:598-599): losses and every gradient of both models.
     DL4DS_NO_CGAN_RATIO: the generator's adversarial gradient by per-sample rescaling of the discriminator-loss pass
-    (csrc/cgan.hip, cgan_ratio_kernel) against the second backward pass through the discriminator it replaces."""
+    (csrc/cgan.hip, cgan_ratio_kernel) against the second backward pass through the discriminator it replaces.
+    DL4DS_NO_TWO_ADD_INPLACE (round 5): a branch input that feeds one convolution and two fused adds gets its gradient without a copy
+    (ConvOp::plan_two_adds: its buffer is the first add's dZ, the second add's dZ rides on the convolution's dgrad store) against the
+    copy + accumulate passes it replaces."""
     import dl4ds_amd.models as PM
     from dl4ds_amd.training import CGANEngine
     B, H = 3, 24
@@ -496,8 +499,8 @@ def test_cgan_shared_conditioning_branch_equals_two_evaluations(monkeypatch, swi
             scale = max(np.abs(y[k]).max(), 1e-12)
             assert np.abs(x[k] - y[k]).max() <= 2e-5 * scale + 1e-9, (name, k)
     # the branch's weight gradients are sums over a different association of the two halves: close, not identical
-    changed = d0 if switch == 'DL4DS_NO_SHARED_BRANCH' else g0
-    other = d1 if switch == 'DL4DS_NO_SHARED_BRANCH' else g1
+    changed = g0 if switch == 'DL4DS_NO_CGAN_RATIO' else d0
+    other = g1 if switch == 'DL4DS_NO_CGAN_RATIO' else d1
     assert any(not np.array_equal(changed[k], other[k]) for k in changed)     # (the switch did select another evaluation)
 
 
