@@ -40,6 +40,50 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ a
     }
 }
 
+// the same with four consecutive columns per thread (16-byte loads; round 5: the scalar form moved 2.6 TB/s on cfg4's 5-D attention,
+// 268 MB in 103 us): block = 64 column quads x 4 row phases, 16 rows per thread in flight as two batches of eight
+__global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial,
+                                                      int R, int Q) {
+    constexpr int TX = 64, TY = 4;
+    __shared__ float4 red[TY][TX];
+    const int tx = threadIdx.x % TX, tyi = threadIdx.x / TX;
+    const int q = (blockIdx.y * TX + tx) * 4;
+    const int g = blockIdx.z;
+    const float* ap = a + (size_t)g * R * Q;
+    const float* bp = b ? b + (size_t)g * R * Q : nullptr;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Q) {
+        const int step = gridDim.x * TY;
+        int r = blockIdx.x * TY + tyi;
+        for (; r + 7 * step < R; r += 8 * step) {
+            float4 v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(ap + (size_t)(r + u * step) * Q + q);
+            if (bp) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(bp + (size_t)(r + u * step) * Q + q);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u].x *= w[u].x; v[u].y *= w[u].y; v[u].z *= w[u].z; v[u].w *= w[u].w; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+        }
+        for (; r < R; r += step) {
+            float4 v = *reinterpret_cast<const float4*>(ap + (size_t)r * Q + q);
+            if (bp) { const float4 w = *reinterpret_cast<const float4*>(bp + (size_t)r * Q + q); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+    }
+    red[tyi][tx] = sum;
+    __syncthreads();
+    if (tyi == 0 && q < Q) {
+        float4 s = red[0][tx];
+#pragma unroll
+        for (int k = 1; k < TY; ++k) { s.x += red[k][tx].x; s.y += red[k][tx].y; s.z += red[k][tx].z; s.w += red[k][tx].w; }
+        *reinterpret_cast<float4*>(partial + ((size_t)g * gridDim.x + blockIdx.x) * Q + q) = s;
+    }
+}
+
 // out[g*Q+q] = scale * sum_k partial[(g*nb+k)*Q+q]
 __global__ void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int nb, int Q,
                                      int GQ, float scale) {
@@ -213,6 +257,17 @@ int colsum_blocks(int R, int TY) { return std::max(1, std::min(cdiv(R, TY * 8), 
 
 void colsum(hipStream_t s, const float* a, const float* b, float* partial, float* out, int G, int R, int Q, float scale) {
     const int TX = pick_tx(Q), TY = 256 / TX;
+    // wide instances (5-D attention: Q = W C) with 16-byte-aligned rows: the float4 form
+    if (Q >= 256 && (Q & 3) == 0 && ((uintptr_t)a & 15) == 0 && (!b || ((uintptr_t)b & 15) == 0) && ((uintptr_t)partial & 15) == 0 &&
+        !exp_env("DL4DS_NO_COLSUM4")) {
+        const int nb4 = std::max(1, std::min(cdiv(R, 4 * 8), 256));
+        dim3 grid4((unsigned)nb4, (unsigned)cdiv(Q, 256), (unsigned)G);
+        DL4DS_LAUNCH(colsum4_kernel, grid4, dim3(256), 0, s, a, b, partial, R, Q);
+        HIP_CHECK(hipGetLastError());
+        DL4DS_LAUNCH(colsum_finish_kernel, dim3(cdiv(G * Q, 256)), dim3(256), 0, s, partial, out, nb4, Q, G * Q, scale);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int nb = colsum_blocks(R, TY);
     dim3 grid((unsigned)nb, (unsigned)cdiv(Q, TX), (unsigned)G);
     switch (TX) {
