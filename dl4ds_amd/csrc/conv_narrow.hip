@@ -378,7 +378,11 @@ __device__ unsigned long long pair_ws_trace[4096 * 8];      // diagnostics build
 // generic epilogue's ~45 vector instructions per row were as long as the K loop itself (PAIR_WS_TRACE: K loop 150 us,
 // epilogue 133 us per workgroup at 64 x 512^2).
 enum : int { PAIR_EPI_ADD = 1, PAIR_EPI_RELU = 2, PAIR_EPI_MASK = 4, PAIR_EPI_ACC = 8, PAIR_EPI_POOL = 16, PAIR_EPI_AFF = 32 };
-template <int NR, int EPI>
+// C16 (round 5): the same kernel for 9 .. 16 INPUT channels and <= 8 outputs (13 -> 8: ConvBlock_att's first layer in the recurrent nets;
+// 16 -> 8: the U-Net decoder's first 512^2 layer) -- conv_narrow16_ws left rows 8 .. 15 of every MFMA idle there (36 MFMAs per 16
+// pixels).  k-slot lq carries channels 4 lq .. 4 lq + 3 (one ds_read_b128 per tap column), four MFMAs per tap position: 48 per 32 pixels.
+// Pixels are staged 20 floats apart: the pair columns are then 10 sixteen-byte slots apart = 2 (mod 4), the conflict-free pitch.
+template <int NR, int EPI, bool C16 = false>
 __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvParams a) {      // (4 waves per SIMD = two workgroups per CU)
     const bool f_add = EPI < 0 ? a.add.p != nullptr : (EPI & PAIR_EPI_ADD) != 0;
     const bool f_relu = EPI < 0 ? a.relu != 0 : (EPI & PAIR_EPI_RELU) != 0;
@@ -389,8 +393,11 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int PTW = 32, PTH = 4 * NR;
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
-    constexpr int P = 10;
-    constexpr int TOTAL = HPIX * 2, ITERS = (TOTAL + 255) / 256;
+    constexpr int P = C16 ? 20 : 10;
+    constexpr int QPP = C16 ? 4 : 2;                              // channel quads staged per pixel
+    constexpr int CPK = C16 ? 4 : 2;                              // channels per k-slot
+    constexpr int PSTEP = 256 / QPP;                              // halo pixels a pass of the 256 loader threads covers
+    constexpr int TOTAL = HPIX * QPP, ITERS = (TOTAL + 255) / 256;
     constexpr int TILE = HPIX * P;
     constexpr int OOB = (int)0xffffff00u, RSRC3 = 0x00020000;
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
@@ -438,14 +445,14 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
 #endif
         // ---- loaders: element e = htid + 256 u = (halo pixel (htid >> 1) + 128 u, channel quad htid & 1)
         const int htid = tid & 255;
-        const int c4 = htid & 1, p0 = htid >> 1;
+        const int c4 = htid & (QPP - 1), p0 = htid / QPP;
         const size_t isx = a.in.ld, isy = (size_t)a.W * a.in.ld;
         const bool ragged = (a.Cin & 3) != 0 || (a.in.ld & 3) != 0;     // quads may reach beyond the end of the view
         const long in_total = (long)((size_t)(a.in.N - 1) * a.in.nstride + (size_t)a.H * a.W * a.in.ld);
         int rel[ITERS], soff[ITERS], hyx[ITERS];
 #pragma unroll
         for (int u = 0; u < ITERS; ++u) {
-            const int pix = p0 + 128 * u;
+            const int pix = p0 + PSTEP * u;
             const int hy = pix / TWH, hx = pix - hy * TWH;
             const bool live = pix < HPIX && c4 * 4 < a.Cin;
             hyx[u] = pix < HPIX ? ((hy << 8) | hx) : 0x7f7f;
@@ -508,7 +515,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
                         const float4 f = affine4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])), s4, h4);
                         v = (i32x4_t){__float_as_int(f.x), __float_as_int(f.y), __float_as_int(f.z), __float_as_int(f.w)};
                     }
-                    int2* d = reinterpret_cast<int2*>(d0 + u * (128 * P));
+                    int2* d = reinterpret_cast<int2*>(d0 + u * (PSTEP * P));
                     d[0] = make_int2(v[0], v[1]);
                     d[1] = make_int2(v[2], v[3]);
                 }
@@ -576,7 +583,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
     // ---- MFMA waves
     const int wave = wave8 & 3;
     const int l15 = lane & 15, lq = lane >> 4;
-    float wr[3][4][2];
+    float wr[3][4][CPK];
     {
         const int h = l15 >> 3, co = l15 & 7;
 #pragma unroll
@@ -584,14 +591,14 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
 #pragma unroll
             for (int ux = 0; ux < 4; ++ux)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int kx = ux - h, ci = 2 * lq + e;
+                for (int e = 0; e < CPK; ++e) {
+                    const int kx = ux - h, ci = CPK * lq + e;
                     const bool ok = kx >= 0 && kx <= 2 && ci < a.Cin && co < a.Cout;
                     const float v = a.w[((size_t)(dy * 3 + (ok ? kx : 0)) * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? co : 0)];
                     wr[dy][ux][e] = ok ? v : 0.f;
                 }
     }
-    const int rd_off = ((wave * NR) * TWH + 2 * l15) * P + 2 * lq;
+    const int rd_off = ((wave * NR) * TWH + 2 * l15) * P + CPK * lq;
     // lane (pair column l15, k-slot lq) holds rows 4*lq + r = (h = lq >> 1, couts 4*(lq & 1) + r)
     const int eh = lq >> 1, ec = 4 * (lq & 1);
     const bool c_ok = ec < a.Cout;
@@ -675,33 +682,41 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
         // pixel fragments ONE halo row ahead of the MFMAs that use them: without it every pair of rows waited for its eight LDS
         // reads (ablation: no loads / no stores change nothing, no MFMAs -> 26 us of 79; the K loop itself ran at 65 %).  Two rows
         // ahead costs 16 more registers and with them the second workgroup per CU (78 -> 87 us).
-        float2 pv[2][4];
+        float pv[2][4][CPK];
+        auto fetch = [&](float (&dst)[CPK], const float* src) __attribute__((always_inline)) {
+            if constexpr (C16) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            } else {
+                const float2 v = *reinterpret_cast<const float2*>(src);
+                dst[0] = v.x; dst[1] = v.y;
+            }
+        };
 #if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 1
         for (int i_ = 0; i_ < NR; ++i_) acc[i_] = bias_c;
         for (int rho = 0; rho < 0; ++rho) {
 #else
 #pragma unroll
-        for (int ux = 0; ux < 4; ++ux) pv[0][ux] = *reinterpret_cast<const float2*>(rd + ux * P);
+        for (int ux = 0; ux < 4; ++ux) fetch(pv[0][ux], rd + ux * P);
 #pragma unroll
         for (int rho = 0; rho < NR + 2; ++rho) {
 #endif
             if (rho + 1 < NR + 2) {
 #pragma unroll
-                for (int ux = 0; ux < 4; ++ux) pv[(rho + 1) & 1][ux] = *reinterpret_cast<const float2*>(rd + ((rho + 1) * TWH + ux) * P);
+                for (int ux = 0; ux < 4; ++ux) fetch(pv[(rho + 1) & 1][ux], rd + ((rho + 1) * TWH + ux) * P);
             }
             __builtin_amdgcn_sched_barrier(0);
             // (consecutive MFMAs go to different accumulators wherever a halo row feeds more than one output row)
 #pragma unroll
             for (int ux = 0; ux < 4; ++ux) {
-                const float2 v = pv[rho & 1][ux];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < CPK; ++e) {
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int r = rho - dy;
                         if (r >= 0 && r < NR) {
                             const bool first = dy == 0 && ux == 0 && e == 0;    // this row's first MFMA: C = bias
-                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][e], e ? v.y : v.x, first ? bias_c : acc[r], 0, 0, 0);
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[dy][ux][e], pv[rho & 1][ux][e], first ? bias_c : acc[r], 0, 0, 0);
                         }
                     }
                 }
@@ -1277,6 +1292,38 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
     HIP_CHECK(hipGetLastError());
 }
 
+// 9 .. 16 input channels, <= 8 outputs: the two-pixels-per-column kernel with 16-channel k-slots (round 5).  Two tile rows per wave so
+// that two workgroups (2 x 27 KB of halo tiles each) share a CU; epilogue forms of the layers that come here compiled in.
+bool launch_narrow_pair16(hipStream_t s, ConvParams& p, int N) {
+    constexpr int NR = 2;
+    static const bool off = exp_env("DL4DS_NO_PAIR16") != nullptr;                    // (A/B)
+    if (off || p.pool || p.in.sc || p.Cin <= 8 || p.Cin > 16 || p.Cout > 8 || (p.Cout & 3) || !narrow_pair_ws_ok(p)) return false;
+    if (!p.out.vec || (p.add.p && !p.add.vec) || (p.mask.p && !p.mask.vec) || ((((uintptr_t)p.bias) & 15) != 0)) return false;
+    if ((((uintptr_t)p.in.p) & 3) != 0) return false;
+    p.tiles_x = cdiv(p.W, 32);
+    p.tiles_y = cdiv(p.H, 4 * NR);
+    p.m_txy[0] = div_magic(p.tiles_x);
+    p.m_txy[1] = div_magic(p.tiles_y);
+    const long nt = (long)p.tiles_x * p.tiles_y * N;
+    if (nt == 0 || nt >= (1l << 20)) return false;
+    const int ntiles = (int)nt;
+    const int epi = (p.add.p ? PAIR_EPI_ADD : 0) | (p.relu ? PAIR_EPI_RELU : 0) | (p.mask.p ? PAIR_EPI_MASK : 0) | (p.accumulate ? PAIR_EPI_ACC : 0);
+    int blocks = std::min(ntiles, resident_blocks<conv_narrow_pair_ws_kernel<NR, -1, true>>(512));
+    if (blocks >= 8) blocks &= ~7;
+    p.CK = 1;
+    const double px = (double)N * p.H * p.W;
+    ProfScope ps(s, "conv_narrow_pair16_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
+                 4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
+#define PAIR16_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, E_, true>), dim3(blocks), dim3(512), 0, s, p); break;
+    switch (epi) {
+        PAIR16_FORM(0) PAIR16_FORM(1) PAIR16_FORM(2) PAIR16_FORM(3) PAIR16_FORM(4) PAIR16_FORM(8) PAIR16_FORM(12)
+        default: DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, -1, true>), dim3(blocks), dim3(512), 0, s, p); break;
+    }
+#undef PAIR16_FORM
+    HIP_CHECK(hipGetLastError());
+    return true;
+}
+
 // --------------------------------------------------------------------------------------------
 // Weight gradient for Cin <= 8: dW[tap][ci][co] = sum_p x[p + tap][ci] * dz[p][co].
 // GEMM view per MFMA: rows = cout (first operand, dz), columns = (tap-of-a-pair, cin) (second operand, x), K = 4
@@ -1681,6 +1728,7 @@ bool conv2d_narrow_forward(hipStream_t s, const TView& in, const float* w, int K
         launch_narrow_pair<NARROW_PAIR_ROWS>(s, p, in.N);
         return true;
     }
+    if (in.C > 8 && out.C <= 8 && launch_narrow_pair16(s, p, in.N)) return true;
     {
         const bool done = launch_narrow16_ws<4>(s, p, in.N);
         if (!done) { if (in.C <= 8) launch_narrow<8>(s, p, in.N); else launch_narrow<16>(s, p, in.N); }

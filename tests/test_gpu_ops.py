@@ -445,6 +445,34 @@ def test_conv2d_wgrad_packed_taps(ops, n, h, w, ci, co, ks):
     np.testing.assert_array_equal(got, ops.conv2d_wgrad(x, dz, ks))
 
 
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 20, 33, 13, 8), (3, 64, 48, 16, 8), (1, 17, 70, 12, 4), (2, 33, 16, 9, 8), (1, 128, 128, 13, 8),
+                                         (2, 7, 5, 16, 8)])
+def test_conv2d_pair_kernel_sixteen_input_channels(ops, n, h, w, ci, co):
+    """Round 5: 9 .. 16 input channels with <= 8 outputs (13 -> 8: ConvBlock_att's first layer in the recurrent nets,
+    spt_postups.py:152-157; 16 -> 8: the U-Net decoder's first 512^2 layer, sp_preups.py:262-285) on
+    conv_narrow_pair_ws_kernel<2, EPI, C16 = true> -- two pixels per MFMA column, 16-channel k-slots: 48 MFMAs per 32 pixels instead of
+    conv_narrow16_ws's 72 with half of their rows idle.  Forward with bias / ReLU / residual, as a dgrad with and without accumulation;
+    ragged grids, channel counts and pixel pitches (13 channels: 16-byte loads at dword alignment)."""
+    from tests.parity import kernel_tags
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert any(t.startswith('conv_narrow_pair16_ws<') for t in tags), tags
+    close(got, ref)
+    close(ops.conv2d(x, wt, b, relu=True), np.maximum(ref, 0))
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    # as the dgrad of a co -> ci layer (dz has ci channels, dx co): plain and accumulating
+    wt2 = R(3, 3, co, ci) * 0.2
+    dz = R(n, h, w, ci)
+    gx, _ = _torch_conv_grads(R(n, h, w, co), wt2, dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt2))
+    assert any(t.startswith('conv_narrow_pair16_ws<') for t in tags), tags
+    close(got, gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt2, accumulate_into=base_x), gx + base_x)
+
+
 @pytest.mark.parametrize('n,h,w,ci,co', [(2, 20, 33, 8, 13), (3, 64, 48, 8, 16), (1, 17, 16, 4, 15), (2, 33, 70, 5, 9), (1, 128, 128, 8, 13)])
 def test_conv2d_narrow16_eight_input_channels(ops, n, h, w, ci, co):
     """Round 5: <= 8 input channels with 9 .. 16 outputs (8 -> 13: the dgrad of ConvBlock_att's first layer in the recurrent nets,
