@@ -382,8 +382,16 @@ enum : int { PAIR_EPI_ADD = 1, PAIR_EPI_RELU = 2, PAIR_EPI_MASK = 4, PAIR_EPI_AC
 // 16 -> 8: the U-Net decoder's first 512^2 layer) -- conv_narrow16_ws left rows 8 .. 15 of every MFMA idle there (36 MFMAs per 16
 // pixels).  k-slot lq carries channels 4 lq .. 4 lq + 3 (one ds_read_b128 per tap column), four MFMAs per tap position: 48 per 32 pixels.
 // Pixels are staged 20 floats apart: the pair columns are then 10 sixteen-byte slots apart = 2 (mod 4), the conflict-free pitch.
-template <int NR, int EPI, bool C16 = false>
+// SPLIT (experiments builds only): the K loop on the 16-bit matrix pipe.  The loaders split every staged value
+// into bf16 parts (hi = bf16(x), lo = bf16(x - hi), lo2 = bf16(x - hi - lo): three 16-byte planes of eight channels per pixel), the
+// filter is split the same way in registers, and ONE v_mfma_f32_16x16x32_bf16 covers the four tap columns x eight channels of a halo row
+// for one term: SPLIT = 3 issues (hi,lo) (lo,hi) (hi,hi), SPLIT = 6 adds (lo,lo) (hi,lo2) (lo2,hi) -- fp32 accumulation, the C layout of the
+// fp32 MFMA, so everything outside the K loop is unchanged.  Not part of the product: it exists to MEASURE what the form buys in a kernel.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <int NR, int EPI, bool C16 = false, int SPLIT = 0>
 __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvParams a) {      // (4 waves per SIMD = two workgroups per CU)
+    static_assert(SPLIT == 0 || !C16, "the split form is built for <= 8 input channels");
     const bool f_add = EPI < 0 ? a.add.p != nullptr : (EPI & PAIR_EPI_ADD) != 0;
     const bool f_relu = EPI < 0 ? a.relu != 0 : (EPI & PAIR_EPI_RELU) != 0;
     const bool f_mask = EPI < 0 ? a.mask.p != nullptr : (EPI & PAIR_EPI_MASK) != 0;
@@ -393,7 +401,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int PTW = 32, PTH = 4 * NR;
     constexpr int TWH = PTW + 2, THH = PTH + 2, HPIX = TWH * THH;
-    constexpr int P = C16 ? 20 : 10;
+    constexpr int P = SPLIT ? 12 : (C16 ? 20 : 10);              // floats per staged pixel (SPLIT: three 16-byte bf16 planes)
     constexpr int QPP = C16 ? 4 : 2;                              // channel quads staged per pixel
     constexpr int CPK = C16 ? 4 : 2;                              // channels per k-slot
     constexpr int PSTEP = 256 / QPP;                              // halo pixels a pass of the 256 loader threads covers
@@ -515,9 +523,26 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
                         const float4 f = affine4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])), s4, h4);
                         v = (i32x4_t){__float_as_int(f.x), __float_as_int(f.y), __float_as_int(f.z), __float_as_int(f.w)};
                     }
+                    if constexpr (SPLIT != 0) {
+                        // this thread's channel quad c4 of the pixel: 8 bytes at offset 8 c4 of each plane
+                        bf16x4_t hi, lo, lo2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x = __int_as_float(v[q]);
+                            hi[q] = (__bf16)x;
+                            const float r1 = x - (float)hi[q];
+                            lo[q] = (__bf16)r1;
+                            lo2[q] = (__bf16)(r1 - (float)lo[q]);
+                        }
+                        char* dp = reinterpret_cast<char*>(tile) + (size_t)(p0 + u * PSTEP) * 48 + c4 * 8;
+                        *reinterpret_cast<bf16x4_t*>(dp) = hi;
+                        *reinterpret_cast<bf16x4_t*>(dp + 16) = lo;
+                        *reinterpret_cast<bf16x4_t*>(dp + 32) = lo2;
+                    } else {
                     int2* d = reinterpret_cast<int2*>(d0 + u * (PSTEP * P));
                     d[0] = make_int2(v[0], v[1]);
                     d[1] = make_int2(v[2], v[3]);
+                    }
                 }
             }
         };
@@ -583,8 +608,24 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
     // ---- MFMA waves
     const int wave = wave8 & 3;
     const int l15 = lane & 15, lq = lane >> 4;
+    bf16x8_t ws[SPLIT ? 3 : 1][3];                                // SPLIT: [dy][plane], row (h, co) x k-group ux = lq: channels 0 .. 7
+    if constexpr (SPLIT != 0) {
+        const int h = l15 >> 3, co = l15 & 7, kx = lq - h;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                const bool ok = kx >= 0 && kx <= 2 && ci < a.Cin && co < a.Cout;
+                const float xv = a.w[((size_t)(dy * 3 + (ok ? kx : 0)) * a.Cin + (ok ? ci : 0)) * a.Cout + (ok ? co : 0)];
+                const float x = ok ? xv : 0.f;
+                ws[dy][0][ci] = (__bf16)x;
+                const float r1 = x - (float)ws[dy][0][ci];
+                ws[dy][1][ci] = (__bf16)r1;
+                ws[dy][2][ci] = (__bf16)(r1 - (float)ws[dy][1][ci]);
+            }
+    }
     float wr[3][4][CPK];
-    {
+    if constexpr (SPLIT == 0) {
         const int h = l15 >> 3, co = l15 & 7;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -692,6 +733,37 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
                 dst[0] = v.x; dst[1] = v.y;
             }
         };
+        if constexpr (SPLIT != 0) {
+            // lane (pair column l15, k-group lq = tap column ux): the eight channels of halo pixel 2 l15 + lq, one 16-byte read per plane
+            constexpr int NPL = SPLIT >= 6 ? 3 : 2;
+            const char* rb = reinterpret_cast<const char*>(lds + (k & 1) * TILE) + (size_t)((wave * NR) * TWH + 2 * l15 + lq) * 48;
+            bf16x8_t pb[2][NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) pb[0][pl] = *reinterpret_cast<const bf16x8_t*>(rb + pl * 16);
+#pragma unroll
+            for (int rho = 0; rho < NR + 2; ++rho) {
+                if (rho + 1 < NR + 2) {
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) pb[(rho + 1) & 1][pl] = *reinterpret_cast<const bf16x8_t*>(rb + (size_t)(rho + 1) * TWH * 48 + pl * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // terms (filter plane, pixel plane), small ones first; consecutive MFMAs go to different accumulators
+                constexpr int NT_ = SPLIT >= 6 ? 6 : 3;
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int tm = 6 - NT_; tm < 6; ++tm) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = rho - dy;
+                        if (r >= 0 && r < NR) {
+                            const bool first = dy == 0 && tm == 6 - NT_;        // this row's first MFMA: C = bias
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[dy][TA[tm]], pb[rho & 1][TB[tm]], first ? bias_c : acc[r], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #if defined(PAIR_WS_ABL) && PAIR_WS_ABL == 1
         for (int i_ = 0; i_ < NR; ++i_) acc[i_] = bias_c;
         for (int rho = 0; rho < 0; ++rho) {
@@ -722,6 +794,7 @@ __global__ void __launch_bounds__(512, 4) conv_narrow_pair_ws_kernel(const ConvP
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         PT_TOC(0);
         __syncthreads();                                          // X
@@ -1259,6 +1332,18 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
         p.CK = no_xcd ? 0 : 1;
         ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                      4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
+#ifdef DL4DS_EXPERIMENTS
+        // DL4DS_PAIR_SPLIT=3|6: the K loop as split-bf16 MFMAs (measurement only, see the kernel's comment); plain / ReLU / mask forms
+        static const int split = exp_env("DL4DS_PAIR_SPLIT") ? atoi(exp_env("DL4DS_PAIR_SPLIT")) : 0;
+        if ((split == 3 || split == 6) && !p.pool && !p.in.sc && (epi == 0 || epi == 2 || epi == 4)) {
+#define PAIR_SPLIT_FORM(E_, S_) DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, E_, false, S_>), dim3(blocks), dim3(512), 0, s, p)
+            if (split == 3) { if (epi == 0) PAIR_SPLIT_FORM(0, 3); else if (epi == 2) PAIR_SPLIT_FORM(2, 3); else PAIR_SPLIT_FORM(4, 3); }
+            else { if (epi == 0) PAIR_SPLIT_FORM(0, 6); else if (epi == 2) PAIR_SPLIT_FORM(2, 6); else PAIR_SPLIT_FORM(4, 6); }
+#undef PAIR_SPLIT_FORM
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+#endif
 #define PAIR_WS_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, E_>), dim3(blocks), dim3(512), 0, s, p); break;
         switch (generic_only ? -1 : epi) {
             PAIR_WS_FORM(0) PAIR_WS_FORM(1) PAIR_WS_FORM(2) PAIR_WS_FORM(3) PAIR_WS_FORM(4) PAIR_WS_FORM(5) PAIR_WS_FORM(6) PAIR_WS_FORM(7)
