@@ -1332,6 +1332,7 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
         p.CK = no_xcd ? 0 : 1;
         ProfScope ps(s, "conv_narrow_pair_ws<" + std::to_string(NR) + ">", 2.0 * px * 9 * p.Cin * p.Cout,
                      4.0 * (px * (p.Cin + p.Cout * (1 + (p.add.p ? 1 : 0) + (p.mask.p ? 1 : 0) + (p.accumulate ? 1 : 0))) + 9.0 * p.Cin * p.Cout));
+        bool split_done = false;
 #ifdef DL4DS_EXPERIMENTS
         // DL4DS_PAIR_SPLIT=3|6: the K loop as split-bf16 MFMAs (measurement only, see the kernel's comment); plain / ReLU / mask forms
         static const int split = exp_env("DL4DS_PAIR_SPLIT") ? atoi(exp_env("DL4DS_PAIR_SPLIT")) : 0;
@@ -1340,12 +1341,11 @@ void launch_narrow_pair(hipStream_t s, ConvParams& p, int N) {
             if (split == 3) { if (epi == 0) PAIR_SPLIT_FORM(0, 3); else if (epi == 2) PAIR_SPLIT_FORM(2, 3); else PAIR_SPLIT_FORM(4, 3); }
             else { if (epi == 0) PAIR_SPLIT_FORM(0, 6); else if (epi == 2) PAIR_SPLIT_FORM(2, 6); else PAIR_SPLIT_FORM(4, 6); }
 #undef PAIR_SPLIT_FORM
-            HIP_CHECK(hipGetLastError());
-            return;
+            split_done = true;
         }
 #endif
 #define PAIR_WS_FORM(E_) case E_: DL4DS_LAUNCH((conv_narrow_pair_ws_kernel<NR, E_>), dim3(blocks), dim3(512), 0, s, p); break;
-        switch (generic_only ? -1 : epi) {
+        if (!split_done) switch (generic_only ? -1 : epi) {
             PAIR_WS_FORM(0) PAIR_WS_FORM(1) PAIR_WS_FORM(2) PAIR_WS_FORM(3) PAIR_WS_FORM(4) PAIR_WS_FORM(5) PAIR_WS_FORM(6) PAIR_WS_FORM(7)
             PAIR_WS_FORM(8) PAIR_WS_FORM(9) PAIR_WS_FORM(10) PAIR_WS_FORM(11) PAIR_WS_FORM(12) PAIR_WS_FORM(13) PAIR_WS_FORM(14) PAIR_WS_FORM(15)
             PAIR_WS_FORM(PAIR_EPI_POOL)
