@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for CFG in cfg2 cfg4 cfg5; do
   SFX=_$CFG; [ $CFG == cfg2 ] && SFX=""
-  CMD="python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-unfolded --no-b16"
+  CMD="python $R/bench.py --config $CFG --steps 10 --warmup 5 --no-cpu-baseline --no-unfolded --no-b16"
   rm -rf /tmp/ps_$CFG /tmp/pf_$CFG /tmp/pw_$CFG
   rocprofv3 --kernel-trace --stats -d /tmp/ps_$CFG --output-format csv -- $CMD > $OUT/bench_under_rocprof$SFX.log 2>&1
   python $R/tools/rocprof_stats_summary.py /tmp/ps_$CFG > $OUT/kernel_stats${SFX}_$TAG.txt

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline"
+CMD="python $R/bench.py --config $CFG --steps 10 --warmup 5 --no-cpu-baseline --no-unfolded --no-b16"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats_$CFG --output-format csv -- $CMD > $OUT/bench_under_rocprof_$CFG.log 2>&1
 python $R/tools/rocprof_stats_summary.py /tmp/prof_stats_$CFG > $OUT/kernel_stats_${CFG}_$TAG.txt
 grep '^{"metric"' $OUT/bench_under_rocprof_$CFG.log | tail -1 > $OUT/bench_line_${CFG}_$TAG.json
