@@ -87,6 +87,20 @@ __global__ void __launch_bounds__(256) masked_axpy4_kernel(const float4* __restr
         dst[e] = g;
     }
 }
+// both operands of an Add in one pass: da (+)= dy * [ya > 0], db (+)= dy * [yb > 0]  (dy is read once: five tensor passes instead of six)
+__global__ void __launch_bounds__(256) masked_axpy4_pair_kernel(const float4* __restrict__ dy, const float4* __restrict__ ya, float4* __restrict__ da,
+                                                                const float4* __restrict__ yb, float4* __restrict__ db, size_t n4, int acc_a, int acc_b) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        const float4 g = dy[e], ma = ya[e], mb = yb[e];
+        float4 ga, gb;
+        ga.x = ma.x > 0.f ? g.x : 0.f; ga.y = ma.y > 0.f ? g.y : 0.f; ga.z = ma.z > 0.f ? g.z : 0.f; ga.w = ma.w > 0.f ? g.w : 0.f;
+        gb.x = mb.x > 0.f ? g.x : 0.f; gb.y = mb.y > 0.f ? g.y : 0.f; gb.z = mb.z > 0.f ? g.z : 0.f; gb.w = mb.w > 0.f ? g.w : 0.f;
+        if (acc_a) { const float4 o = da[e]; ga.x += o.x; ga.y += o.y; ga.z += o.z; ga.w += o.w; }
+        if (acc_b) { const float4 o = db[e]; gb.x += o.x; gb.y += o.y; gb.z += o.z; gb.w += o.w; }
+        da[e] = ga;
+        db[e] = gb;
+    }
+}
 __global__ void masked_axpy1_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dst, size_t n,
                                     int accumulate) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -684,6 +698,16 @@ void concat_join(hipStream_t s, float* dst, int ld, size_t npx, const ConcatSlic
     auto kern = even ? concat_join_kernel<2> : concat_join_kernel<1>;
     DL4DS_LAUNCH(kern, dim3(blocks), dim3(256), 0, s, a, cvn, stride / (size_t)cvn, (int)(stride % (size_t)cvn), totalv);
     HIP_CHECK(hipGetLastError());
+}
+
+bool masked_axpy_pair(hipStream_t s, const float* dy, const float* ya, float* da, int acc_a, const float* yb, float* db, int acc_b, size_t n) {
+    if (n == 0 || (n & 3) || ((((uintptr_t)dy) | ((uintptr_t)ya) | ((uintptr_t)da) | ((uintptr_t)yb) | ((uintptr_t)db)) & 15) || da == db) return false;
+    ProfScope ps(s, "masked_axpy", 0.0, 4.0 * (double)n * (5 + (acc_a ? 1 : 0) + (acc_b ? 1 : 0)));
+    DL4DS_LAUNCH(masked_axpy4_pair_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
+                 reinterpret_cast<const float4*>(ya), reinterpret_cast<float4*>(da), reinterpret_cast<const float4*>(yb), reinterpret_cast<float4*>(db),
+                 n / 4, acc_a, acc_b);
+    HIP_CHECK(hipGetLastError());
+    return true;
 }
 
 void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate) {

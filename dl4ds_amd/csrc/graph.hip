@@ -778,6 +778,19 @@ struct AddOp : GOp {
             bias_act_backward(g.stream, dY, g.view(out, c.B, false, c.b_off, c.b_cnt), dY, nullptr, 0, g.workspace,
                               g.workspace_bytes);
         }
+        if (a != b && wants_grad(g, a, c) && wants_grad(g, b, c) && g.tensors[a].grad_masked && g.tensors[b].grad_masked &&
+            !exp_env("DL4DS_NO_MASKED_PAIR")) {
+            // both operands are ReLU outputs whose masks ride on this copy: one pass that reads dY once (cfg2's long skip)
+            const size_t ps = g.tensors[a].per_sample();
+            const size_t off = (size_t)c.b_off * ps, n = (size_t)(c.b_cnt < 0 ? c.B : c.b_cnt) * ps;
+            if (g.tensors[b].per_sample() == ps &&
+                masked_axpy_pair(g.stream, g.tensors[out].grad + off, g.tensors[a].data + off, g.tensors[a].grad + off, g.tensors[a].grad_written,
+                                 g.tensors[b].data + off, g.tensors[b].grad + off, g.tensors[b].grad_written, n)) {
+                g.tensors[a].grad_written = true;
+                g.tensors[b].grad_written = true;
+                return;
+            }
+        }
         for (int t : {a, b}) {
             if (!wants_grad(g, t, c)) continue;
             if (exp_env("DL4DS_ADD_DEBUG"))

@@ -94,6 +94,8 @@ void concat_split(hipStream_t s, const float* src, int ld, size_t npx, const Con
 void concat_join(hipStream_t s, float* dst, int ld, size_t npx, const ConcatSlice* slices, int n);
 // dst (+)= dy * [y > 0]  (flat, contiguous)
 void masked_axpy(hipStream_t s, const float* dy, const float* y, float* dst, size_t n, int accumulate);
+// ... for both operands of an Add at once (false: not applicable, call masked_axpy twice)
+bool masked_axpy_pair(hipStream_t s, const float* dy, const float* ya, float* da, int acc_a, const float* yb, float* db, int acc_b, size_t n);
 // out = act(a + b)
 void add_act(hipStream_t s, const float* a, const float* b, float* out, size_t n, int relu);
 // in-place / out-of-place activation forward y = f(x) and backward dx (+)= dy * f'(x)
