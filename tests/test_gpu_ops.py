@@ -260,6 +260,59 @@ def test_conv2d_winograd_depth_to_space(ops, monkeypatch, ci, co):
     close(got, gx)
 
 
+F44_CASES = [
+    # F(4x4, 3x3): cout chunks of 32, passes of 48 / 32 input channels; ragged grids (sizes that are not multiples of the 16 x 16 tile group, of the
+    # 4 x 4 tile), several images, several chunks, several passes; couts that are not whole chunks (forced)
+    (2, 40, 33, 48, 32), (3, 64, 48, 48, 64), (2, 33, 40, 32, 32), (1, 48, 32, 40, 64), (2, 20, 50, 24, 32), (1, 35, 21, 48, 96),
+    (1, 17, 19, 24, 32), (5, 32, 16, 32, 64), (2, 32, 32, 48, 48), (1, 16, 16, 28, 36), (1, 33, 17, 192, 32), (2, 17, 33, 96, 96), (1, 16, 17, 64, 40),
+]
+
+
+@pytest.mark.parametrize('sx', ['all', '1'])
+@pytest.mark.parametrize('n,h,w,ci,co', F44_CASES)
+def test_conv2d_winograd_f44(ops, monkeypatch, sx, n, h, w, ci, co):
+    """conv_wino4_kernel (Winograd F(4x4, 3x3), conv_wino4_kernel.h): forward with fused epilogues, dgrad with accumulate, on grids
+    the dispatcher would not pick it for (DL4DS_WINO_FORCE as above).  Same 2e-4 bar as the direct kernels (the transform's own
+    error is 5e-6)."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_WINO_FORCE', sx)
+    monkeypatch.setenv('DL4DS_WINO_F44', 'force')
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert any(t.startswith('conv_wino4<') for t in tags), tags
+    close(got, ref)
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt))
+    assert any(t.startswith('conv_wino') for t in tags), tags
+    close(got, gx)
+    base_x = R(*gx.shape)
+    close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+
+
+@pytest.mark.parametrize('ci,co', [(48, 128), (48, 32), (24, 32), (32, 128)])
+def test_conv2d_winograd_f44_depth_to_space(ops, monkeypatch, ci, co):
+    """... through depth_to_space views on the output (forward) and the input (dgrad): 48 -> 4 x 8 is the composed upsampling tail of
+    the headline model."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_WINO_FORCE', '1')
+    monkeypatch.setenv('DL4DS_WINO_F44', 'force')
+    n, h, w, r = 2, 34, 20, 2
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b, d2s=r))
+    assert any(t.startswith('conv_wino4<') for t in tags), tags
+    close(got, ref)
+    dz = R(n, h * r, w * r, co // (r * r))
+    gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt, d2s=r))
+    assert any(t.startswith('conv_wino') for t in tags), tags
+    close(got, gx)
+
+
 @pytest.mark.parametrize('sx', ['all', '1'])
 @pytest.mark.parametrize('n,h,w,ci,co', WINO_CASES)
 def test_conv2d_winograd_wgrad(ops, monkeypatch, sx, n, h, w, ci, co):

@@ -27,6 +27,10 @@ for H, CI, CO, r in CASES:
             os.environ['DL4DS_NO_WINOGRAD'] = '1'
         else:
             os.environ.pop('DL4DS_NO_WINOGRAD', None)
+        if mode.startswith('f44'):          # F(4x4, 3x3) where it is built (run with DL4DS_TEST_HOOKS=1); 'f44force': also ragged cout chunks
+            os.environ['DL4DS_WINO_F44'] = 'force' if mode == 'f44force' else '1'
+        else:
+            os.environ.pop('DL4DS_WINO_F44', None)
         for what in ('fwd', 'dgrad'):
             L.check(lib.dl4ds_profile_enable(1))
             for _ in range(reps):
