@@ -85,6 +85,16 @@ __device__ __forceinline__ void transform3(const Recipe& rc, const f32x4 R0, con
     o0 = fma4v(R0, rc.s0, fma4v(R1, rc.s1, mul4v(R4, rc.s4)));
 }
 
+// workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding vector-memory operation (vmcnt(0)) -- here
+// the DMA pieces just requested for the NEXT tile group, whose whole latency it would expose
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int KQ, int NT, int EPI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) conv_wino4_kernel(const WinoParams wp) {
     typedef Geom<KQ, NT> GM;
@@ -228,9 +238,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 
     __syncthreads();                                                // ctab
+#ifdef WINO_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = clock64();
+#endif
     Item cur = decode(tg);
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) stage_issue(cur, kq);
+    const bool s_full = 4 * (SIT - 1) + wave < NCHP;               // this wave requests SIT pieces per chunk (else SIT - 1)
+    bool first_it = true;
+    WT(0);
     for (;;) {
         const int ntg = tg + nsub;
         const bool has_next = ntg < tg_hi;
@@ -245,10 +261,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int cb = 0; cb < NT; ++cb) acc[x][n][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of chunk kq (and everything older) have landed
-            __syncthreads();                                        // ... everybody's; and every wave has left chunk kq - 1
+            // this wave's pieces of chunk kq have landed: everything but the requests made after it may still be in flight (its
+            // vector-memory operations complete in order) -- the last chunk's request is followed by the 8 stores of phase C, the
+            // others by a later chunk's S pieces and those stores; the first tile group's three requests are simply all awaited
+            if (first_it) wait_vm<0>();
+            else if (kq == KQ - 1) wait_vm<8>();
+            else if (s_full) wait_vm<GM::SIT + 8>();
+            else wait_vm<GM::SIT - 1 + 8>();
+            lds_barrier();                                        // ... everybody's; and every wave has left chunk kq - 1
+            WT(1);
             // the buffer of chunk kq - 1 is free: the next tile group's chunk kq - 1 goes there (chunk 2 waits for the products)
             if (kq >= 1 && kq - 1 < GM::NBUF && has_next) stage_issue(nxt, kq - 1);
+            WT(2);
             const float* const rb = chunk_buf(kq);
             f32x4 T[3][5];
 #pragma unroll
@@ -271,7 +295,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                             acc[x][n][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[x][n][4 * kq + s4][cb], V[n][s4], acc[x][n][cb], 0, 0, 0);
             }
         }
-        __syncthreads();                                            // every wave has left the last chunk (its buffer may be the products')
+        WT(3);
+        lds_barrier();                                            // every wave has left the last chunk (its buffer may be the products')
         if (has_next && KQ - 1 < GM::NBUF) stage_issue(nxt, KQ - 1);
         // ---- the products of position (xi, nu), tile l15, couts 16 cb + 4 lq ..
 #pragma unroll
@@ -285,7 +310,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int cb = 0; cb < NT; ++cb) *reinterpret_cast<f32x4*>(pw + 16 * cb) = acc[x][n][cb];
             }
         }
-        __syncthreads();                                            // products complete
+        lds_barrier();                                            // products complete
+        WT(4);
         // ---- C: Y = A^T M A for (tile, quad, two columns), epilogue, store
         {
             const size_t pb_ = cur.y0 * osy + cur.x0 * osx;
@@ -337,11 +363,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 RA[xi] = fma4v(mx, w0v, fma4v(t, k1v, s));
                 RB[xi] = fma4v(mx, w1v, fma4v(ee, k2v, d));
             }
+            WT(5);
             if (KQ - 1 >= GM::NBUF && has_next) {
                 // chunk 2 of the next tile group goes where the products were: every thread has read them
-                __syncthreads();
+                lds_barrier();
                 stage_issue(nxt, KQ - 1);
             }
+            WT(6);
             f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (want_bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + min(n0 + 4 * quad, bias_max));
             const f32x2 two = {2.f, 2.f}, four = {4.f, 4.f}, eight = {8.f, 8.f};
@@ -371,10 +399,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
             }
         }
+        WT(7);
+#ifdef WINO_TRACE
+        tr[0] += 1ull << 48;
+#endif
         if (!has_next) break;
         cur = nxt;
         tg = ntg;
+        first_it = false;
     }
+#ifdef WINO_TRACE
+    if (wp.trace && lane == 0)
+        for (int q = 0; q < 8; ++q) wp.trace[((size_t)blockIdx.x * 4 + wave) * 8 + q] = tr[q];
+#endif
 }
 
 template <int KQ, int NT, int EPI>
@@ -385,8 +422,44 @@ void launch_one(hipStream_t s, WinoParams& wp, int SX) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<KQ, NT, EPI>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES));
     });
+#ifdef WINO_TRACE
+    static unsigned long long* trace_buf = nullptr;
+    static int trace_n = 0;
+    wp.trace = nullptr;
+    if (trace_n < 3) {
+        if (!trace_buf) HIP_CHECK(hipMalloc((void**)&trace_buf, (size_t)1024 * 32 * 8));
+        HIP_CHECK(hipMemsetAsync(trace_buf, 0, (size_t)1024 * 32 * 8, s));
+        wp.trace = trace_buf;
+    }
+#endif
     DL4DS_LAUNCH((conv_wino4_kernel<KQ, NT, EPI>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
     HIP_CHECK(hipGetLastError());
+#ifdef WINO_TRACE
+    if (wp.trace) {
+        ++trace_n;
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)8 * SX * 32);
+        HIP_CHECK(hipMemcpy(h.data(), trace_buf, h.size() * 8, hipMemcpyDeviceToHost));
+        static const char* nm[8] = {"prologue", "wait+bar", "issue", "transform+mfma", "barK+issue+writeP+bar", "C-read+transform", "bar+issue2", "store"};
+        for (int wv = 0; wv < 4; wv += 3) {
+            double sum[8] = {0}, its = 0;
+            int nwg = 0;
+            for (int b = 0; b < 8 * SX; ++b) {
+                const unsigned long long* t = &h[((size_t)b * 4 + wv) * 8];
+                const double it = (double)(t[0] >> 48);
+                if (it == 0) continue;
+                ++nwg; its += it;
+                for (int q = 0; q < 8; ++q) sum[q] += (double)(q == 0 ? (t[0] & ((1ull << 48) - 1)) : t[q]);
+            }
+            if (!nwg) continue;
+            fprintf(stderr, "wino4<%d,%d,%d> wave %d: %d workgroups, %.1f iterations each; cycles: prologue %.0f | per iteration", KQ, NT, EPI, wv,
+                    nwg, its / nwg, sum[0] / nwg);
+            double tot = 0;
+            for (int q = 1; q < 8; ++q) { fprintf(stderr, " %s %.0f", nm[q], sum[q] / its); tot += sum[q] / its; }
+            fprintf(stderr, " = %.0f\n", tot);
+        }
+    }
+#endif
 }
 
 template <int KQ, int NT>
