@@ -371,6 +371,15 @@ int dl4ds_batch_gather(const dl4ds_gather_group* groups, int n_groups, const int
     GatherGroup g[3];
     for (int i = 0; i < n_groups; ++i) {
         const dl4ds_gather_group& q = groups[i];
+        DL4DS_REQUIRE(q.src_dev && q.channels > 0 && q.src_h > 0 && q.src_w > 0 && q.row_div >= 0, "batch_gather: group");
+        // the kernel does not clamp: every crop has to stay inside its source (raw groups: the corner + the output extent; a patch that
+        // was resized: the corner inside the field -- its tap indices are the caller's table, relative to the corner)
+        for (int b = 0; b < B && (q.raw || q.origin_from_crop); ++b) {
+            const int cy = cy_host ? cy_host[b] : 0, cx = cx_host ? cx_host[b] : 0;
+            const int sy = q.row_div ? cy / q.row_div : cy, sx = q.row_div ? cx / q.row_div : cx;
+            DL4DS_REQUIRE(cy >= 0 && cx >= 0 && sy < q.src_h && sx < q.src_w, "batch_gather: crop corner outside the source");
+            if (q.raw) DL4DS_REQUIRE(sy + out_h <= q.src_h && sx + out_w <= q.src_w, "batch_gather: crop leaves the source");
+        }
         g[i].src = q.src_dev; g[i].channels = q.channels; g[i].frames = q.frames; g[i].src_h = q.src_h; g[i].src_w = q.src_w;
         g[i].raw = q.raw; g[i].origin_from_crop = q.origin_from_crop; g[i].row_div = q.row_div;
         for (int k = 0; k < 2; ++k) { g[i].taps[k].idx = q.taps[k].idx; g[i].taps[k].wt = q.taps[k].wt; g[i].taps[k].k = q.taps[k].k; }
@@ -514,7 +523,7 @@ int dl4ds_op_adam(float* w, const float* g, float* m, float* v, size_t n, int t,
     API_BEGIN
     const float lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) /
                                (1.0 - std::pow((double)beta1, (double)t)));
-    adam_update(S(), w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    adam_update(S(), w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale, device_error_word_if_any());       // (skips the update once the sticky word is set)
     API_END
 }
 

@@ -244,9 +244,7 @@ namespace {
 // cout chunks of 32 (NT = 2) with 48 or 32 input channels per pass.  Same contract as conv2d_wino_forward below, which tries this first.
 static bool conv2d_wino4_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep, int KQ, int cpass,
                                  const char* force) {
-    static const bool off = getenv("DL4DS_NO_F44") != nullptr;
     const char* f44 = test_env("DL4DS_WINO_F44");                 // (tests: "force" = also couts that are not whole chunks of 32)
-    if (off) return false;
     const bool forced = f44 && f44[0] == 'f';
     if (!forced && (out.C % 32) != 0) return false;
     if (!forced && in.C % cpass != 0 && in.C > cpass) return false;

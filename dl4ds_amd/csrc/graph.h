@@ -73,6 +73,7 @@ struct GOp {
     int out_tid = -1;
     virtual void on_finalize(Graph& g) {}
     virtual void on_prepare(Graph& g) {}      // after (re)allocation of the activation / gradient buffers
+    virtual void on_resolve_aliases(Graph& g) {}   // after every op's on_prepare, in reverse op order: gradient buffers shared along chains
     virtual bool partial_batch_ok() const { return true; }   // backward over a sample sub-range (BwdCtx::b_off / b_cnt)
     // ops with batch statistics: the forward batch is `groups` independent sub-batches (CGAN: [real ; fake] = the reference's
     // two discriminator calls), each normalised by its own statistics, moving averages updated group after group

@@ -155,7 +155,12 @@ void Graph::prepare(int B) {
     HIP_CHECK(hipMalloc((void**)&workspace, ws));
     if (aux_stream) HIP_CHECK(hipMalloc((void**)&aux_workspace, ws));
     maxB = B;
+    for (auto& t : tensors) t.two_add_inplace = false;           // (re-planned below: ConvOp::plan_two_adds)
     for (auto& op : ops) op->on_prepare(*this);
+    // gradient buffers shared between a fused add's output and its residual operand: resolved once more in REVERSE op order, so that a
+    // chain (this op's output is a later op's shared / in-place residual, which re-pointed its gradient after this op had planned)
+    // ends on the final buffer instead of a stale alias
+    for (auto it = ops.rbegin(); it != ops.rend(); ++it) (*it)->on_resolve_aliases(*this);
 }
 
 TView Graph::view(int tid, int B, bool grad, int b_off, int b_cnt) const {
@@ -380,6 +385,9 @@ struct ConvOp : GOp {
         plan_two_adds(g);
         if (add_grad_inplace) g.tensors[add].grad = g.tensors[out].grad;
     }
+    void on_resolve_aliases(Graph& g) override {
+        if (add >= 0 && (add_grad_shared || add_grad_inplace)) g.tensors[add].grad = g.tensors[out].grad;
+    }
     // r feeds ONE convolution C and TWO fused adds A1 < A2 (a residual branch's input that is also its long skip: the
     // discriminator's branches, cfg5).  Until round 5: dZ(A2) was COPIED into r's gradient, dZ(A1) accumulated onto it, C's dgrad
     // accumulated again -- five passes over an 8 x 512^2 x 32 tensor beside the dgrad.  Now r's gradient buffer IS dZ(A1)'s (this op =
@@ -481,7 +489,8 @@ struct ConvOp : GOp {
             // two fused adds planned copy-free (plan_two_adds): the LATER one (its backward runs first) leaves dZ as the pending
             // operand of the consuming convolution's dgrad store; the earlier one's dZ already is r's gradient buffer
             const bool inplace_here = add_grad_inplace && ra.two_add_inplace && !dY.sc;
-            if (ra.two_add_inplace && !add_grad_inplace && !ra.grad_written && !ra.pending_add && d2s <= 1 && !dY.sc) defer = true;
+            if (ra.two_add_inplace && !add_grad_inplace && !ra.grad_written && !ra.pending_add && d2s <= 1 && !dY.sc && defer_ok(g, add))
+                defer = true;
             if (exp_env("DL4DS_ADD_DEBUG"))
                 fprintf(stderr, "conv add grad: op out=%d add=%d defer=%d shared=%d written=%d n_conv_in=%d n_add_in=%d n_masking=%d n_other=%d n_fused_add=%d d2s=%d masked=%d C=%d H=%d B=%d\n",
                         out, add, (int)defer, (int)add_grad_shared, (int)ra.grad_written, ra.n_conv_in, ra.n_add_in, ra.n_masking, ra.n_other,
@@ -489,9 +498,10 @@ struct ConvOp : GOp {
             if (defer) {
                 ra.pending_add = dY.p;
                 ra.pending_view = dY;
-            } else if (inplace_here) {
-                DL4DS_REQUIRE(!ra.grad_written && dY.p == g.view(add, c.B, true, c.b_off, c.b_cnt).p, "two-add plan: the shared gradient buffer is not dZ");
-            } else if (!add_grad_shared) {
+            } else if (inplace_here && !ra.grad_written && dY.p == g.view(add, c.B, true, c.b_off, c.b_cnt).p) {
+                // (r's gradient buffer IS this dZ: nothing to do)
+            } else if (!add_grad_shared || inplace_here) {
+                // (also the fall-back of a two-add plan whose buffers did not end up shared: the copying path is always right)
                 if (g.tensors[add].grad_masked)
                     view_axpy_masked(g.stream, dY, g.view(add, c.B, false, c.b_off, c.b_cnt), g.view(add, c.B, true, c.b_off, c.b_cnt),
                                      g.tensors[add].grad_written);

@@ -118,6 +118,10 @@ static float current_lr(const Trainer& t) {
     return ((double)t.step <= t.cfg.boundary) ? t.cfg.lr0 : t.cfg.lr1;
 }
 
+// The sticky device error word (runtime.h) ENDS the process's training: the optimiser kernel leaves parameters and moments untouched
+// once it is set, every later host-side wait throws, and nothing clears it -- a caller that catches the exception and goes on would
+// only advance the step counter here (and, in a multi-rank job, diverge from ranks that did not raise).  SupervisedEngine / CGANEngine
+// do not catch it; the C header says the same (dl4ds_last_error: "device error word set").
 void trainer_apply_adam(Trainer& t) {
     Graph& g = *t.g;
     const float lr = current_lr(t);

@@ -439,6 +439,21 @@ class DeviceDataGenerator:
                 # (the reference crops them with the HR corner and feeds them to the model's HR auxiliary input, dataloader.py:52-68)
                 raise ValueError('static variables must be on the HR grid')
             self._stat, self.S = DeviceArray.from_numpy(st), st.shape[-1]
+        # every crop stays inside its source (the device gathers do not clamp; the reference's numpy slices would hand back short
+        # arrays and fail on shapes later): the patch inside the HR field, its LR counterpart inside the LR grid, and -- where the
+        # corner is drawn on the LR grid and scaled (dataloader.py:166-174,193-200) -- the LR grid times `scale` inside the HR field
+        if patch_size is not None:
+            ps = int(patch_size)
+            if ps < 1 or ps > self.H or ps > self.W:
+                raise ValueError(f'`patch_size` {ps} does not fit the {self.H} x {self.W} HR field')
+            if not self.pin:
+                if ps // self.scale < 1 or ps // self.scale > min(self.hl, self.wl):
+                    raise ValueError(f'the LR patch ({ps // self.scale}) does not fit the {self.hl} x {self.wl} LR grid')
+                if (self._lr_src is not None or self.P) and (self.hl * self.scale > self.H or self.wl * self.scale > self.W):
+                    raise ValueError(f'the LR grid {self.hl} x {self.wl} times scale {self.scale} exceeds the {self.H} x {self.W} HR field: '
+                                     'crop corners drawn on the LR grid would leave it')
+        if self.hl < 1 or self.wl < 1:
+            raise ValueError('the LR grid is empty')
         # the composed route: anything but HR-grid inputs of a size `scale` divides
         self.general = (self._lr_src is not None or self.pred_grid != (self.H, self.W) or self.H % self.scale != 0
                         or self.W % self.scale != 0)

@@ -228,3 +228,37 @@ def test_trainer_takes_the_device_generator_for_an_external_lr_array():
     for ds in (tr.ds_train, tr.ds_val, tr.ds_test):
         assert isinstance(ds, DeviceDataGenerator) and ds.general
     assert tr.model.count_params() > 0
+
+
+def test_crops_that_would_leave_their_source_are_refused():
+    """the device gathers do not clamp.  A caller-supplied LR array whose grid times `scale` exceeds the HR field, a patch
+    larger than the field or its LR counterpart larger than the LR grid raise at construction (the reference's numpy path fails on
+    shapes); dl4ds_batch_gather itself refuses a corner whose crop leaves the source."""
+    import ctypes
+    from dl4ds_amd import _lib
+    from dl4ds_amd.dataloader import DeviceDataGenerator
+    from dl4ds_amd.device import DeviceArray
+    hr = _fields(6, 128, 128, 1, 1)
+    with pytest.raises(ValueError, match='exceeds'):
+        DeviceDataGenerator(hr, _fields(6, 33, 32, 1, 2), backbone='resnet', upsampling='spc', scale=4, batch_size=2, patch_size=32)
+    with pytest.raises(ValueError, match='does not fit'):
+        DeviceDataGenerator(hr, None, backbone='resnet', upsampling='spc', scale=4, batch_size=2, patch_size=256)
+    with pytest.raises(ValueError, match='LR patch'):
+        DeviceDataGenerator(hr, _fields(6, 4, 4, 1, 2), backbone='resnet', upsampling='spc', scale=4, batch_size=2, patch_size=32)
+    DeviceDataGenerator(hr, _fields(6, 32, 32, 1, 2), backbone='resnet', upsampling='spc', scale=4, batch_size=2, patch_size=32)     # fits
+
+    class TapAxis(ctypes.Structure):
+        _fields_ = [('idx', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('k', ctypes.c_int)]
+
+    class Group(ctypes.Structure):
+        _fields_ = [('src', ctypes.c_void_p), ('channels', ctypes.c_int), ('frames', ctypes.c_int), ('src_h', ctypes.c_int),
+                    ('src_w', ctypes.c_int), ('raw', ctypes.c_int), ('origin_from_crop', ctypes.c_int), ('row_div', ctypes.c_int),
+                    ('taps', TapAxis * 2)]
+    src, out = DeviceArray.from_numpy(hr), DeviceArray((2, 1, 32, 32, 1))
+    g = (Group * 1)()
+    g[0].src, g[0].channels, g[0].frames, g[0].src_h, g[0].src_w, g[0].raw = src.ptr, 1, 0, 128, 128, 1
+    ip = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data
+    idx, ok, bad = np.array([0, 1], np.int32), np.array([96, 0], np.int32), np.array([97, 0], np.int32)
+    assert _lib.lib().dl4ds_batch_gather(ctypes.addressof(g), 1, ip(idx), ip(ok), ip(ok), out.ptr, 32, 32, 1, 2) == 0
+    assert _lib.lib().dl4ds_batch_gather(ctypes.addressof(g), 1, ip(idx), ip(bad), ip(ok), out.ptr, 32, 32, 1, 2) != 0
+    assert b'leaves the source' in _lib.lib().dl4ds_last_error()
