@@ -65,6 +65,25 @@ def synthetic_batch(seed, batch, hr=512, scale=4):
     return block_mean(y, scale).astype(np.float32), y.astype(np.float32)
 
 
+def synthetic_batch_cfg4(seed, batch, T=8, h=64, s=4):
+    """cfg4: T box-blurred HR frames per sample, LR = their block means, one HR auxiliary field -> (x, aux, y)."""
+    rng = np.random.default_rng(seed)
+    y = np.stack([box_blur_fields(rng, (batch, h * s, h * s)) for _ in range(T)], axis=1)          # (B,T,256,256,1)
+    x = np.stack([block_mean(y[:, t], s) for t in range(T)], axis=1)
+    aux = box_blur_fields(rng, (batch, h * s, h * s))
+    return x.astype(np.float32), aux.astype(np.float32), y.astype(np.float32)
+
+
+def synthetic_batch_cfg5(seed, batch, H=512):
+    """cfg5 ('pin'): five 64^2 fields (block means of box-blurred 512^2 ones) re-expanded x 8, one HR static field, the HR target."""
+    rng = np.random.default_rng(seed)
+    y = box_blur_fields(rng, (batch, H, H))
+    f = box_blur_fields(rng, (batch, H, H), channels=5)
+    x = np.repeat(np.repeat(block_mean(f, 8), 8, axis=1), 8, axis=2)
+    aux = box_blur_fields(rng, (batch, H, H))
+    return x.astype(np.float32), aux.astype(np.float32), y.astype(np.float32)
+
+
 def csrc_sha():
     """Fingerprint of the kernel sources this run's library was built from (dl4ds_amd/csrc/*.{hip,cpp,h} + the C header), 16 hex
     digits.  profiles/traffic.json carries the fingerprint of the tree its PMC passes ran on: counters collected before a kernel
@@ -215,11 +234,8 @@ def make_workload(name, B, rank, world):
         model = PM.recnet_postupsampling('densenet', 'rc', s, 1, 1, (h, h), time_window=T, attention=True,
                                          localcon_layer=True, seed=7)
         eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3 * world)
-        rng = np.random.default_rng(1004 + rank)
-        y = np.stack([box_blur_fields(rng, (B, h * s, h * s)) for _ in range(T)], axis=1)          # (B,T,256,256,1)
-        x = np.stack([block_mean(y[:, t], s) for t in range(T)], axis=1)
-        aux = box_blur_fields(rng, (B, h * s, h * s))
-        dx, da, dy = (DeviceArray.from_numpy(a.astype(np.float32)) for a in (x, aux, y))
+        x, aux, y = synthetic_batch_cfg4(1004 + rank, B, T, h, s)
+        dx, da, dy = (DeviceArray.from_numpy(a) for a in (x, aux, y))
         return dict(step=lambda: eng.step_device([dx.ptr, da.ptr], dy.ptr, B), engine=eng, model=model, keep=(dx, da, dy),
                     metric='HR samples/s (train step), spatio-temporal dense + attention + LCB, resize-conv 4x, T=8, 64->256',
                     describe=f'configs[3]: recnet_postupsampling(densenet, rc, scale=4, lr 64x64, T=8, attention, LCB, 1 aux; '
@@ -230,18 +246,93 @@ def make_workload(name, B, rank, world):
         gen = PM.unet_pin('unet', 5, 1, hr_size=(H, H), n_filters=8, n_blocks=6, decoder_upsampling='dc', seed=7)
         disc = PM.residual_discriminator(5, 'pin', False, 8, (H // 8, H // 8), n_filters=8, hr_size=(H, H), seed=8)
         eng = CGANEngine(gen, disc, loss='mae', learning_rate=(2e-4, 2e-4))
-        rng = np.random.default_rng(1005 + rank)
-        y = box_blur_fields(rng, (B, H, H))
-        f = box_blur_fields(rng, (B, H, H), channels=5)
-        x = np.repeat(np.repeat(block_mean(f, 8), 8, axis=1), 8, axis=2)            # 64^2 fields re-expanded ('pin')
-        aux = box_blur_fields(rng, (B, H, H))
-        dx, da, dy = (DeviceArray.from_numpy(a.astype(np.float32)) for a in (x, aux, y))
+        x, aux, y = synthetic_batch_cfg5(1005 + rank, B, H)
+        dx, da, dy = (DeviceArray.from_numpy(a) for a in (x, aux, y))
         return dict(step=lambda: eng.step_device([dx.ptr, da.ptr], dy.ptr, B), engine=eng, model=gen, keep=(dx, da, dy),
                     metric='HR samples/s (CGAN train step), U-Net(deconv) generator + residual discriminator, 8x 64->512',
                     describe=f'configs[4]: unet_pin(unet, dc, 5+1 channels, hr 512x512; G {gen.count_params()} + '
                              f'D {disc.count_params()} params), CGAN step (MAE x100 + BCE), 2 x Adam(2e-4, beta1 0.5)',
                     loss=lambda: None)
     raise SystemExit(f'unknown --config {name}')
+
+
+# ------------------------------------------------------------------------------------------------ predict line
+def predict_line(args):
+    """`python bench.py --predict`: forward-only HR samples/s of configs[1] (north_star: the Predictor API, inference.py:109-255) --
+    `value` with the LR batch and the HR output resident in HBM (dl4ds_graph_forward), `host_arrays` the same through Model.predict
+    with numpy arrays in and out (one PCIe copy each way per batch), the dominant kernel with its roofline and the forward pass's
+    distance from its own roofline; one JSON line (kept as profiles/bench_predict_rNN.json)."""
+    import dl4ds_amd._lib as L
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.device import DeviceArray
+    lib = L.lib()
+    B = args.batch or 64
+    model = PM.net_postupsampling('resnet', 'spc', 4, 1, 0, (128, 128), seed=7)
+    x_host, _ = synthetic_batch(1002, B)
+    x = DeviceArray.from_numpy(x_host)
+    y = DeviceArray.zeros((B, 512, 512, 1))
+    ptrs = (ctypes.c_void_p * 1)(x.ptr)
+    fwd = lambda: L.check(lib.dl4ds_graph_forward(model.graph.h, ptrs, 1, B, 0, 0, y.ptr))
+    for _ in range(max(args.warmup, 3)):
+        fwd()
+    L.check(lib.dl4ds_profile_filter(b''))
+    L.check(lib.dl4ds_profile_enable(1))
+    nprof = 3
+    for _ in range(nprof):
+        fwd()
+    buf = ctypes.create_string_buffer(1 << 17)
+    L.check(lib.dl4ds_profile_report(buf, len(buf)))
+    rep = json.loads(buf.value.decode())
+    L.check(lib.dl4ds_profile_enable(0))
+    L.check(lib.dl4ds_sync())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd()
+    L.check(lib.dl4ds_sync())
+    dt = (time.perf_counter() - t0) / args.steps
+    n2 = int(np.ceil(MIN_STEADY_S / dt))
+    t0 = time.perf_counter()
+    for _ in range(n2):
+        fwd()
+    L.check(lib.dl4ds_sync())
+    dt2 = (time.perf_counter() - t0) / n2
+    # through the reference's call: numpy in, numpy out (4 batches per call, batch_size = B)
+    xs = np.concatenate([x_host] * 4, axis=0)
+    model.predict(xs[:B], batch_size=B)
+    t0 = time.perf_counter()
+    reps_h = 3
+    for _ in range(reps_h):
+        out_h = model.predict(xs, batch_size=B)
+    dth = (time.perf_counter() - t0) / (reps_h * 4)
+    assert out_h.shape == (4 * B, 512, 512, 1)
+    dom = max((k for k in rep if rep[k]['flops'] > 0), key=lambda k: rep[k]['ms'])
+    d = rep[dom]
+    wino = dom.startswith('conv_wino')
+    achieved = (d.get('direct_flops', d['flops']) / WINOGRAD_SAVING if wino else d['flops']) / (d['ms'] * 1e-3) / 1e12
+    tot = sum(v['ms'] for v in rep.values())
+    top = {k: {'ms_per_batch': round(v['ms'] / nprof, 4), 'launches': v['n'] / nprof,
+               'tflops_issued': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['flops'] else None,
+               'gbps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1)}
+           for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms'])[:8]}
+    out = {'metric': 'HR samples/s (predict: forward only) at 4x 128->512 residual SR', 'value': B / dt, 'unit': 'HR samples/s',
+           'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 3), 'ms_per_step': 1e3 * dt, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'configs[1] forward only: net_postupsampling(resnet, spc, scale=4, lr 128x128 -> hr 512x512, 204405 params), '
+                                  'dl4ds_graph_forward with the LR batch and the HR output resident in HBM', 'per_gpu_batch': B},
+           'steady_state': {'steps': n2, 'ms_per_step': 1e3 * dt2, 'value': B / dt2},
+           'host_arrays': {'value': B / dth, 'ms_per_batch': 1e3 * dth, 'unit': 'HR samples/s',
+                           'note': 'Model.predict(numpy (4 B, 128, 128, 1), batch_size=B) -> numpy (4 B, 512, 512, 1): one host-to-device '
+                                   'copy of the LR batch and one device-to-host copy of the HR fields (67 MB) per batch, pageable memory'},
+           'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'winograd': wino,
+                        'avg_launch_ms': d['ms'] / d['n'], 'launches_per_batch': d['n'] / nprof, 'share_of_forward_time': d['ms'] / tot,
+                        'algorithmic_bytes_per_launch': d['bytes'] / d['n'],
+                        'measured': 'HIP events around every launch of three profiled forward passes right before the timed ones'},
+           'step_roofline': step_roofline(rep, nprof, 1e3 * dt),
+           'executed_gflop_per_sample': sum(v['flops'] for v in rep.values()) / nprof / 1e9 / B,
+           'direct_form_gflop_per_sample': sum(v.get('direct_flops', v['flops']) for v in rep.values()) / nprof / 1e9 / B,
+           'kernels': top, 'cpu_baseline': None}
+    print(json.dumps(out), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -318,6 +409,7 @@ def main():
                     help='per-GPU batch (weak scaling); default 64 for cfg2 (the reference default, '
                          'training/supervised.py:49) and 16 for cfg4 / cfg5 (training/cgan.py:48)')
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5'])
+    ap.add_argument('--predict', action='store_true', help='the forward-only line of configs[1] (Predictor API) instead of the train step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-unfolded', action='store_true', help='skip the 5-step comparison run of the unfolded graph')
@@ -327,6 +419,8 @@ def main():
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.cpu_baseline_worker)
 
+    if args.predict:
+        return predict_line(args)
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))

@@ -129,7 +129,9 @@ def slack_report(ref, key='grads'):
 def breakdown(got, ref, key='grads', tol=1e-3, ulps=ULPS, k_noise=K_NOISE):
     """Per tensor: the error and every term of its bound, all relative to the tensor's OWN largest entry (tensors below 1e-3 of
     the model's largest gradient are measured against that level, as in slack_report).
-    -> [dict(name, size, err, tol, ulp, band, noise, plain_ok, ok, n_slack, n_bad, slack_used)]:
+    -> [dict(name, size, err, tol, ulp, n_ulp, band, noise, plain_ok, ok, n_slack, n_bad, slack_used)]:
+       ``n_ulp``    entries whose error exceeds tol x the tensor's own largest entry and that pass on the ulp floor (64 eps32 x the
+                    model's largest gradient entry) -- small tensors of a model whose other gradients are much larger;
        ``err``      largest entry error; ``band`` / ``noise``: the largest allowance any entry of the tensor was GRANTED;
        ``plain_ok`` every entry passes on tol + ulp floor alone;
        ``n_slack``  entries that pass only through their own band / noise term (``slack_used``: the largest amount by which such an
@@ -148,7 +150,11 @@ def breakdown(got, ref, key='grads', tol=1e-3, ulps=ULPS, k_noise=K_NOISE):
         over_plain = err - plain
         needs = over_plain > 0
         bad = ~(err <= plain + slack)
+        # (entries beyond 1e-3 of the tensor's own largest entry that pass on the ulp floor of the model's largest gradient: counted, so
+        #  that "passes on 1e-3" and "passes on 1e-3 + 64 ulp of the gradient scale" are two statements -- VERDICT r5 next #5)
+        on_ulp = (err > tol * own) & ~needs
         rows.append(dict(name=k, size=int(r.size), err=float(err.max()) / scale, tol=tol * own / scale, ulp=ulps * EPS32 * gscale / scale,
+                         n_ulp=int(np.count_nonzero(on_ulp)),
                          band=float(np.max(ref['band' + sfx][k])) / scale, noise=k_noise * float(np.max(ref['noise' + sfx][k])) / scale,
                          plain_ok=bool(not needs.any()), ok=bool(not bad.any()), n_slack=int(np.count_nonzero(needs & ~bad)),
                          n_bad=int(np.count_nonzero(bad)), slack_used=float(over_plain[needs & ~bad].max() / scale) if (needs & ~bad).any() else 0.0))

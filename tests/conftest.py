@@ -35,7 +35,7 @@ def pytest_collection_modifyitems(config, items):
 
 def pytest_sessionfinish(session, exitstatus):
     """The parity artefact: every oracle comparison of this session, per tensor for the BASELINE-size ones (tests/parity.py).
-    Written under gpurun_out/ (scratch that travels back from the GPU box); the copy that is judged is profiles/parity_r05.json."""
+    Written under gpurun_out/ (scratch that travels back from the GPU box); the copy that is judged is profiles/parity_r06.json."""
     try:
         from tests import parity
     except Exception:
@@ -45,7 +45,7 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
-    path = os.path.join(out, 'parity_r05.json')
+    path = os.path.join(out, 'parity_r06.json')
     old = {}
     if os.path.exists(path):          # (several pytest invocations of one GPU call add to the same file)
         try:

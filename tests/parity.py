@@ -4,7 +4,7 @@ The oracle's reference for a train step and the per-tensor gradient criterion li
 __graft_entry__.smoke() can use them without importing tests/); this module re-exports them and adds what needs the
 library: ``kernel_tags`` = the set of kernel tags the library launched while a callable ran (dl4ds_profile_*), so a test
 can assert that the kernels it means to check are the ones that were dispatched, and ``record`` = the collector behind
-profiles/parity_r05.json.
+profiles/parity_r06.json.
 """
 import ctypes
 import json
@@ -60,7 +60,7 @@ def record(what, rows, full=False):
     if full:
         entry['tensors'] = [{k: (round(v, 9) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
     else:                                   # the tensors that drew on their allowance are always listed
-        entry['tensors_on_slack'] = [{k: (round(v, 9) if isinstance(v, float) else v) for k, v in r.items()} for r in rows if r['n_slack']]
+        entry['tensors_on_slack'] = [{k: (round(v, 9) if isinstance(v, float) else v) for k, v in r.items()} for r in rows if r['n_slack'] or r.get('n_ulp', 0)]
     PARITY_LOG[str(what)] = entry
 
 
@@ -101,6 +101,7 @@ def summarize(rows):
     wf = max(rows, key=lambda r: r['n_slack'] / r['size'])
     ne, ns = sum(r['size'] for r in rows), sum(r['n_slack'] + r['n_bad'] for r in rows)
     return dict(n=n, plain_ok=ok, plain_frac=ok / max(n, 1), elements=ne, elements_on_slack=ns, element_plain_frac=1.0 - ns / max(ne, 1),
+                elements_on_ulp_floor=sum(r.get('n_ulp', 0) for r in rows), tensors_on_ulp_floor=sum(1 for r in rows if r.get('n_ulp', 0)),
                 worst_slack=ws['band'] + ws['noise'], worst_slack_name=ws['name'], worst_slack_used=max(r['slack_used'] for r in rows),
                 worst_err=we['err'], worst_err_name=we['name'],
                 worst_tensor_slack_frac=wf['n_slack'] / wf['size'], worst_tensor_slack_name=wf['name'], worst_tensor_slack_entries=wf['n_slack'])

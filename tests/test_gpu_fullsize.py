@@ -367,6 +367,33 @@ def test_cfg4_full_size_against_the_oracle():
     _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg4 full size', full=True))
 
 
+def test_cfg4_on_the_bench_workload_itself_against_the_oracle():
+    """`bench.py --config cfg4` times box-blurred U[0, 1) frames, their block means, a blurred auxiliary field and
+    the zero biases the builders start from (bench.synthetic_batch_cfg4(1004, B), model seed 7) -- that step, with nothing steered away
+    from a discontinuity (ReLU, hard-sigmoid and MAE kinks get their per-entry allowance from the oracle), against the fp64 oracle.
+    B = 4: the oracle's cost."""
+    import bench
+    from dl4ds_amd.training import SupervisedEngine
+    from tests.parity import assert_matches_reference, kernel_tags, oracle_reference
+    _no_force_overrides()
+    B = 4
+    model = _cfg4_model(seed=7)
+    w = model.get_weights()
+    # (zero biases, except the ConvLSTM cells' unit forget bias: Keras' default, blocks.py:350-355)
+    assert all(set(np.unique(v)) <= {0.0, 1.0} for k, v in w.items() if k.endswith('bias'))
+    x, aux, y = bench.synthetic_batch_cfg4(1004, B)
+    out = model([x, aux])
+    eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
+    (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x, aux], y))
+    for must in ('convlstm_seq_fwd<5,8>', 'convlstm_seq_bwd<5,8>', 'convlstm_seq_bwd<3,8>'):
+        assert must in tags, (must, sorted(tags))
+    ref = oracle_reference('supervised', 'recnet_postupsampling', CFG4_OCFG, w, x, aux, y, loss='mae', workers=ORACLE_WORKERS)
+    _fwd_close(out, ref['pred'])
+    assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg4 on the bench workload (box-blurred frames, zero biases, B = 4)', full=True),
+                    limit=0.03)
+
+
 def _cfg5_pair():
     import dl4ds_amd.models as PM
     H = 512
@@ -403,6 +430,32 @@ def test_cfg5_generator_full_size_against_the_oracle():
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
     _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg5 generator full size', full=True))
+
+
+def test_cfg5_generator_on_the_bench_workload_itself_against_the_oracle():
+    """the generator of `bench.py --config cfg5` on the bench's own arrays (bench.synthetic_batch_cfg5(1005, B): five
+    64^2 block-mean fields re-expanded x 8, a blurred static field, the blurred HR target) and its own zero-bias weights (seed 7), as
+    a supervised MAE step against the fp64 oracle; nothing steered.  B = 4."""
+    import bench
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import SupervisedEngine
+    from tests.parity import assert_matches_reference, kernel_tags, oracle_reference
+    _no_force_overrides()
+    B = 4
+    gen = PM.unet_pin('unet', 5, 1, hr_size=(512, 512), n_filters=8, n_blocks=6, decoder_upsampling='dc', seed=7)
+    w = gen.get_weights()
+    assert all(np.abs(v).max() == 0.0 for k, v in w.items() if k.endswith('bias'))
+    x, aux, y = bench.synthetic_batch_cfg5(1005, B)
+    out = gen([x, aux])
+    eng = SupervisedEngine(gen, loss='mae', learning_rate=1e-3)
+    (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x, aux], y))
+    for must in ('conv_narrow_pair_ws<4>', 'conv_narrow16_ws<4>', 'conv_narrow_wgrad<8>'):
+        assert must in tags, (must, sorted(tags))
+    ref = oracle_reference('supervised', 'unet_pin', CFG5_GCFG, w, x, aux, y, loss='mae', workers=ORACLE_WORKERS)
+    _fwd_close(out, ref['pred'])
+    assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg5 generator on the bench workload (re-expanded block means, zero biases, B = 4)',
+                                             full=True), limit=0.03)
 
 
 def test_cfg5_full_size_cgan_step_against_the_oracle():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build a variant of libdl4ds_hip.so with one source recompiled under extra -D flags:
-#   tools/variant_build.sh <name> <source.hip> -DFOO=1 ...   -> gpurun_variants/libdl4ds_<name>.so
-# Run with DL4DS_HIP_LIB=gpurun_variants/libdl4ds_<name>.so.  (gpurun_variants/ travels to the GPU box; it is git-ignored.)
+#   tools/variant_build.sh <name> <source.hip> -DFOO=1 ...   -> dl4ds_amd/libdl4ds_hip_<name>.so
+# Run with DL4DS_HIP_LIB=.../dl4ds_amd/libdl4ds_hip_<name>.so (*.so is git-ignored and travels to the GPU box; gpurun_variants/ holds only the objects).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; SRC=$2; shift 2
@@ -14,5 +14,5 @@ for f in $R/dl4ds_amd/csrc/*.hip $R/dl4ds_amd/csrc/*.cpp; do
   OBJS="$OBJS $R/dl4ds_amd/csrc/_build/$b.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/opt/rocm/include -x hip "$@" -c $R/dl4ds_amd/csrc/$SRC -o $R/gpurun_variants/obj_$NAME/$SRC.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/gpurun_variants/libdl4ds_$NAME.so $OBJS $R/gpurun_variants/obj_$NAME/$SRC.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
-echo built gpurun_variants/libdl4ds_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/dl4ds_amd/libdl4ds_hip_$NAME.so $OBJS $R/gpurun_variants/obj_$NAME/$SRC.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo built dl4ds_amd/libdl4ds_hip_$NAME.so
