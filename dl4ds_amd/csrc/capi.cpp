@@ -160,6 +160,17 @@ int dl4ds_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     HIP_CHECK(hipStreamSynchronize(S()));
     API_END
 }
+int dl4ds_host_register(void* p, size_t bytes) {
+    API_BEGIN
+    DL4DS_REQUIRE(p && bytes, "host_register: empty range");
+    HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    API_END
+}
+int dl4ds_host_unregister(void* p) {
+    API_BEGIN
+    HIP_CHECK(hipHostUnregister(p));
+    API_END
+}
 int dl4ds_memcpy_d2d(void* dst, const void* src, size_t bytes) {
     API_BEGIN
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S()));

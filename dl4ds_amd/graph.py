@@ -471,10 +471,21 @@ class Model:
         if grid != tuple(self.input_shapes[0][-3:-1]):
             return self.resized(grid).predict(inputs, batch_size=batch_size, verbose=verbose)
         n = first.shape[0]
-        outs = []
-        for i in range(0, n, batch_size):
-            outs.append(self([a[i:i + batch_size] for a in inputs], training=False))
-        return np.concatenate(outs, axis=0)
+        inputs = [np.ascontiguousarray(a, np.float32) for a in inputs]
+        # one result array, page-locked while the batches land in it: no per-batch allocation, no concatenation, device-to-host copies
+        # at the link's rate (a pageable 67 MB batch of 512^2 fields took 18 ms of the 22 ms per batch)
+        out = np.empty((n,) + self.output_shape, np.float32)
+        lib = self.graph._l
+        pinned = n > 0 and out.nbytes >= (1 << 22) and lib.dl4ds_host_register(out.ctypes.data, out.nbytes) == 0
+        try:
+            for i in range(0, n, batch_size):
+                part, b = self._prep_inputs([a[i:i + batch_size] for a in inputs])
+                ptrs = (ctypes.c_void_p * len(part))(*[a.ctypes.data for a in part])
+                _lib.check(lib.dl4ds_graph_forward(self.graph.h, ptrs, len(part), b, 0, 1, out[i:i + b].ctypes.data))
+        finally:
+            if pinned:
+                lib.dl4ds_host_unregister(out.ctypes.data)
+        return out
 
     def resized(self, grid):
         """The same architecture planned for inputs of spatial size ``grid`` (size of the FIRST input: the LR grid of a

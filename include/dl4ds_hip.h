@@ -36,6 +36,12 @@ int dl4ds_free(void* p_dev);
 int dl4ds_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);   /* synchronous */
 int dl4ds_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);   /* synchronous */
 int dl4ds_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);    /* async on the stream */
+/* Page-lock a host buffer the caller owns for the duration of a run of host <-> device copies (hipHostRegister / hipHostUnregister):
+ * copies to / from it then go at the link's rate instead of through the runtime's staging of pageable memory.  Used by
+ * Model.predict for the array it returns (inference.py:238-249 hands numpy arrays in and out).  register returns non-zero when the
+ * range cannot be pinned (the caller simply goes on with pageable copies). */
+int dl4ds_host_register(void* p_host, size_t bytes);
+int dl4ds_host_unregister(void* p_host);
 int dl4ds_memset(void* p_dev, int value, size_t bytes);
 int dl4ds_sync(void);                             /* hipStreamSynchronize(library stream); fails if a kernel raised the
                                                    * sticky device-side error word since the last wait (e.g. the persistent

@@ -483,3 +483,53 @@ def test_cfg5_full_size_cgan_step_against_the_oracle():
     # (B = 4: the bias of the merge block is a sum of four samples' terms, noise floor 1.6 % of it)
     _slack_is_small(assert_matches_reference(gd, ref, 'gradsD', what='cfg5 CGAN step full size: discriminator', full=True), limit=0.03)
     _slack_is_small(assert_matches_reference(gg, ref, 'gradsG', what='cfg5 CGAN step full size: generator (adversarial + 100 x MAE)', full=True))
+
+
+def test_cfg2_after_training_steps_on_the_bench_workload_against_the_oracle():
+    """The state `bench.py` actually times is not the initial one: after 25 Adam steps on the bench batch the biases are no longer zero,
+    the residuals have shrunk and the ReLU patterns have moved.  The gradients AT THAT STATE (weights read back from the device) against
+    the fp64 oracle, nothing steered; B = 16."""
+    import bench
+    from dl4ds_amd.training import SupervisedEngine
+    from tests.parity import assert_matches_reference, oracle_reference
+    _no_force_overrides()
+    B = 16
+    model = _cfg2(seed=7)
+    x, y = bench.synthetic_batch(1002, B)
+    eng = SupervisedEngine(model, loss='mae', learning_rate=(1e-3, 1e-4), lr_decay_after=1e5)
+    losses = [eng.step([x], y) for _ in range(25)]
+    assert losses[-1] < 0.5 * losses[0], losses                          # (it trains: 0.50 -> below 0.1 on the blurred fields)
+    w = model.get_weights()
+    assert any(np.abs(v).max() > 0.0 for k, v in w.items() if k.endswith('bias'))
+    out = model([x])
+    l_hip, g_hip = eng.loss_and_grads([x], y)
+    ref = oracle_reference('supervised', 'net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4), w, x, None, y,
+                           loss='mae', workers=ORACLE_WORKERS)
+    _fwd_close(out, ref['pred'])
+    assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
+    _slack_is_small(assert_matches_reference(g_hip, ref, what='cfg2 on the bench workload after 25 Adam steps (B = 16)', full=True), limit=0.05)
+
+
+def test_cfg5_cgan_step_on_the_bench_workload_itself_against_the_oracle():
+    """The CGAN step `bench.py --config cfg5` times -- its arrays (bench.synthetic_batch_cfg5), its zero-bias weights (generator seed 7,
+    discriminator seed 8), an injected dropout mask -- against the fp64 restatement of train_step (cgan.py:575-639); nothing steered.
+    B = 2: the oracle's cost."""
+    import bench
+    import dl4ds_amd.models as PM
+    from dl4ds_amd.training import CGANEngine
+    from tests.parity import assert_matches_reference, oracle_reference
+    _no_force_overrides()
+    B, H = 2, 512
+    gen = PM.unet_pin('unet', 5, 1, hr_size=(H, H), n_filters=8, n_blocks=6, decoder_upsampling='dc', seed=7)
+    disc = PM.residual_discriminator(5, 'pin', False, 8, (H // 8, H // 8), n_filters=8, hr_size=(H, H), seed=8)
+    gw, dw = gen.get_weights(), disc.get_weights()
+    x, aux, y = bench.synthetic_batch_cfg5(1005, B)
+    mask = (np.random.default_rng(5).random((2 * B, 16)) > 0.4).astype(np.float32)
+    eng = CGANEngine(gen, disc, loss='mae', learning_rate=2e-4, beta_1=0.5)
+    out = eng.step([x, aux], y, dropout_keep=mask, apply_update=False)
+    gg, gd = gen.get_gradients(), disc.get_gradients()
+    ref = oracle_reference('cgan', 'unet_pin', CFG5_GCFG, gw, x, aux, y, loss='mae', dcfg=CFG5_DCFG, dweights=dw, mask=mask, workers=B)
+    for i, k in enumerate(('gen_total', 'gen_gan', 'gen_px', 'disc')):
+        assert out[i] == pytest.approx(ref['losses'][i], rel=1e-4), k
+    _slack_is_small(assert_matches_reference(gd, ref, 'gradsD', what='cfg5 CGAN step on the bench workload: discriminator (B = 2)', full=True), limit=0.05)
+    _slack_is_small(assert_matches_reference(gg, ref, 'gradsG', what='cfg5 CGAN step on the bench workload: generator (B = 2)', full=True), limit=0.05)
