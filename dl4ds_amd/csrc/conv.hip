@@ -1371,10 +1371,12 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_rows_ws_kernel(const WgradP
 // out0[e] (+)= sum_k partial[k*n + e] for e < n0 ; out1[e-n0] likewise for e >= n0.
 // One block reduces 16 consecutive elements: thread = (slab sub-index 0..15, element 0..15) -> 64-byte row
 // segments per slab, 16 slabs in flight per block, fixed summation order (deterministic).
+// rowlen > 0: out0 is a channel SLICE of a wider filter -- element e of a slab lands at (e / rowlen) * dstride + doff + e % rowlen
+// (the 9..16-input-channel weight gradients computed as two 8-channel slices: rowlen = Cs * Cout per tap, dstride = C * Cout).
 template <int EL>      // elements per block: 16 (64-byte row segments per slab, 16 slabs in flight) or 4 (small filters: 64 slabs in flight)
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out0,
                                                            float* __restrict__ out1, size_t n0, size_t n, int S,
-                                                           int acc0, int acc1) {
+                                                           int acc0, int acc1, int rowlen, int dstride, int doff) {
     constexpr int SL = 256 / EL;
     __shared__ float red[SL][EL + 1];
     const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
@@ -1397,8 +1399,10 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < SL; ++k) t += red[k][el];
-            if (e < n0) out0[e] = acc0 ? out0[e] + t : t;
-            else if (out1) out1[e - n0] = acc1 ? out1[e - n0] + t : t;
+            if (e < n0) {
+                const size_t d = rowlen ? (e / (size_t)rowlen) * (size_t)dstride + doff + e % (size_t)rowlen : e;
+                out0[d] = acc0 ? out0[d] + t : t;
+            } else if (out1) out1[e - n0] = acc1 ? out1[e - n0] + t : t;
         }
         __syncthreads();
     }
@@ -1634,12 +1638,30 @@ void conv2d_dgrad_weights(hipStream_t s, const float* w, float* wt, int KS, int 
     HIP_CHECK(hipGetLastError());
 }
 
+// 9 .. 16 input channels with <= 8 outputs (13 -> 8: ConvBlock_att's first layer in the recurrent nets; 16 -> 8 U-Net decoder
+// layers): the general kernel runs these with the eight output channels on half of the MFMA's rows (nine MFMAs per pixel quad);
+// conv_narrow_wgrad_kernel<8> on the channel slices [0, 8) and [8, C) takes 2 x 3 (rows 8-15 carry the pixel below).  The slices are
+// plain views of the same pixels (pitch = the tensor's); the slab sums scatter into the [9][C][Cout] gradient.
+static TView channel_slice(const TView& x, int c0, int c1) {
+    TView v = x;
+    v.p = x.p + c0; v.C = c1 - c0; v.cp = v.C;
+    v.vec = ((v.C & 3) == 0) && ((x.ld & 3) == 0) && ((((uintptr_t)v.p) & 15) == 0);
+    return v;
+}
+static int narrow_wgrad_split_slabs(const TView& x, const TView& dz, int KS) {
+    static const bool off = exp_env("DL4DS_NO_WGRAD_SPLIT") != nullptr;                 // (A/B)
+    if (off || KS != 3 || x.C <= 8 || x.C > 16 || dz.C > 8 || x.sc || x.d2s > 1 || dz.d2s > 1 || !dz.vec) return 0;
+    if (conv2d_direct_wgrad_slabs(x, dz, KS) || exp_env("DL4DS_NO_NARROW")) return 0;
+    return conv2d_narrow_wgrad_slabs(channel_slice(x, 0, 8), dz, KS);
+}
+
 size_t conv2d_wgrad_workspace_bytes(const TView& x, const TView& dz, int KS) {
     const size_t slab = ((size_t)KS * KS * x.C * dz.C + dz.C) * sizeof(float);
     if (const int ds = conv2d_direct_wgrad_slabs(x, dz, KS)) return (size_t)ds * slab;
     // (the narrow path can be switched off for A/B runs: size for whichever of the two plans needs more)
     const size_t general = (size_t)plan_wgrad(x, dz, KS).S * slab;
     if (const int ns = conv2d_narrow_wgrad_slabs(x, dz, KS)) return std::max((size_t)ns * slab, general);
+    if (const int ns = narrow_wgrad_split_slabs(x, dz, KS)) return std::max((size_t)2 * ns * slab, general);     // (two slices, each < slab)
     return general;
 }
 
@@ -1647,6 +1669,27 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
                   int accumulate_db, float* workspace, size_t workspace_bytes) {
     DL4DS_REQUIRE(x.N == dz.N && x.H == dz.H && x.W == dz.W, "wgrad: shapes differ");
     if (KS == 3 && conv2d_wino_wgrad(s, x, dz, dw, accumulate, db, accumulate_db)) return;     // MFMA-bound 3x3 layers: Winograd
+    if (const int ns = narrow_wgrad_split_slabs(x, dz, KS)) {
+        float* ws = workspace;
+        for (int c0 = 0; c0 < x.C; c0 += 8) {
+            const TView xs = channel_slice(x, c0, std::min(c0 + 8, x.C));
+            const size_t nws = (size_t)9 * xs.C * dz.C, ns_n = nws + dz.C;
+            DL4DS_REQUIRE((size_t)(ws - workspace) * sizeof(float) + (size_t)ns * ns_n * sizeof(float) <= workspace_bytes, "wgrad: workspace too small");
+            const int got = conv2d_narrow_wgrad(s, xs, dz, KS, ws, ns);
+            ProfScope ps(s, "wgrad_reduce_slabs", 0.0, 4.0 * (double)ns_n * (got + 1));
+            float* dbs = c0 == 0 ? db : nullptr;                                           // (every slice sums the same dz)
+            if (got >= 128) {
+                DL4DS_LAUNCH(reduce_slabs_kernel<4>, dim3((int)cdivz(ns_n, 4)), dim3(256), 0, s, ws, dw, dbs, nws, ns_n, got, accumulate,
+                             accumulate_db, xs.C * dz.C, x.C * dz.C, c0 * dz.C);
+            } else {
+                DL4DS_LAUNCH(reduce_slabs_kernel<16>, dim3((int)cdivz(ns_n, 16)), dim3(256), 0, s, ws, dw, dbs, nws, ns_n, got, accumulate,
+                             accumulate_db, xs.C * dz.C, x.C * dz.C, c0 * dz.C);
+            }
+            HIP_CHECK(hipGetLastError());
+            ws += (size_t)ns * ns_n;
+        }
+        return;
+    }
     WgradPlan pl = plan_wgrad(x, dz, KS);
     const size_t nw = (size_t)KS * KS * x.C * dz.C;
     const size_t n = nw + dz.C;
@@ -1680,11 +1723,11 @@ void conv2d_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, float*
     if (n < 4096 && nslabs >= 128 && !exp_env("DL4DS_REDUCE16")) {
         const int blocks = (int)std::max<size_t>(1, cdivz(n, 4));
         DL4DS_LAUNCH(reduce_slabs_kernel<4>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
-                           accumulate_db);
+                           accumulate_db, 0, 0, 0);
     } else {
         const int blocks = (int)std::max<size_t>(1, std::min<size_t>(cdivz(n, 16), 8192));
         DL4DS_LAUNCH(reduce_slabs_kernel<16>, dim3(blocks), dim3(256), 0, s, workspace, dw, db, nw, n, nslabs, accumulate,
-                           accumulate_db);
+                           accumulate_db, 0, 0, 0);
     }
     HIP_CHECK(hipGetLastError());
 }

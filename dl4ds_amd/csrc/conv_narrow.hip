@@ -1767,11 +1767,16 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
     p.m_tx = div_magic(p.tiles_x);
     p.m_ty = div_magic(p.tiles_y);
     const bool wide = dz.C > 8;
+    // The 16-byte buffer loads of the staging code only need dword alignment: a plain view whose channel count or pixel pitch is
+    // not a multiple of four (channel slices of a 13-channel tensor) takes the same path -- what the last quad of a pixel picks up
+    // beyond its channels (the next pixel's first values) sits in MFMA columns ci >= Cin, which are never written out.
+    static const bool no_unaligned = exp_env("DL4DS_NO_NARROW_WGRAD_UNALIGNED") != nullptr;
+    const bool xv = x.vec || (x.d2s <= 1 && !no_unaligned);
     void (*kern)(const NarrowWgradParams) =
-        wide ? (x.vec ? conv_narrow_wgrad_kernel<16, true> : conv_narrow_wgrad_kernel<16, false>)
-             : (x.vec ? conv_narrow_wgrad_kernel<8, true> : conv_narrow_wgrad_kernel<8, false>);
-    const int resident = wide ? (x.vec ? resident_blocks<conv_narrow_wgrad_kernel<16, true>>(256) : resident_blocks<conv_narrow_wgrad_kernel<16, false>>(256))
-                              : (x.vec ? resident_blocks<conv_narrow_wgrad_kernel<8, true>>(256) : resident_blocks<conv_narrow_wgrad_kernel<8, false>>(256));
+        wide ? (xv ? conv_narrow_wgrad_kernel<16, true> : conv_narrow_wgrad_kernel<16, false>)
+             : (xv ? conv_narrow_wgrad_kernel<8, true> : conv_narrow_wgrad_kernel<8, false>);
+    const int resident = wide ? (xv ? resident_blocks<conv_narrow_wgrad_kernel<16, true>>(256) : resident_blocks<conv_narrow_wgrad_kernel<16, false>>(256))
+                              : (xv ? resident_blocks<conv_narrow_wgrad_kernel<8, true>>(256) : resident_blocks<conv_narrow_wgrad_kernel<8, false>>(256));
     const int blocks = std::max(1, std::min(std::min(max_slabs, p.ntiles), resident));
     const double px = (double)x.N * p.H * p.W;
     ProfScope ps(s, std::string("conv_narrow_wgrad<") + (wide ? "16>" : "8>"), 2.0 * px * 9 * p.Cin * p.Cout,

@@ -778,7 +778,10 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     int SX = (SXmax / npair) * npair;
     if (force && atoi(force) > 0) SX = std::min(SX, atoi(force) * npair);
     const int nsub = SX / npair;
-    if (!force && (long)wp.per_xcd < 16l * nsub) return false;                // fewer than 16 tile groups per workgroup: the slabs dominate
+    // fewer than 8 tile groups per workgroup: the slabs dominate.  (Round 6, cfg2 at per-GPU batch 16 = 8 groups per workgroup: the
+    // former limit of 16 sent the five 48-channel layers to the direct kernels -- weight-gradient family 1.46 -> 1.35 ms per step of 16,
+    // 3 845 -> 3 950 samples/s; one workgroup per CU with 16 groups each is slower (3 640), and so is a limit of 4 for the 32-channel shapes)
+    if (!force && (long)wp.per_xcd < 8l * nsub) return false;
     const int F = 4 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
     const int nslabs = 8 * nsub;
     const size_t per_k = (size_t)npair * ST;

@@ -526,6 +526,25 @@ def test_conv2d_pair_kernel_sixteen_input_channels(ops, n, h, w, ci, co):
     close(ops.conv2d_dgrad(dz, wt2, accumulate_into=base_x), gx + base_x)
 
 
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 20, 33, 13, 8), (3, 64, 48, 16, 8), (1, 17, 70, 12, 4), (2, 33, 16, 9, 8), (1, 128, 128, 13, 8),
+                                         (2, 7, 5, 16, 8), (2, 40, 36, 10, 4), (64, 64, 64, 13, 8)])
+def test_conv2d_wgrad_channel_slices(ops, n, h, w, ci, co):
+    """Round 6: the 3x3 weight gradient of 9 .. 16 input channels with <= 8 outputs (13 -> 8: ConvBlock_att's first layer in the
+    recurrent nets, spt_postups.py:152-157; 16 -> 8 U-Net decoder layers, sp_preups.py:262-285) as two launches of
+    conv_narrow_wgrad_kernel<8> on the channel slices [0, 8) and [8, C) -- plain views of the same pixels at the tensor's pitch
+    (13 floats: 16-byte loads at dword alignment) -- whose slab sums scatter into the [9][C][Cout] gradient (the bias gradient
+    comes from the first slice: covered by the recurrent-net model tests).  Ragged grids / channel counts, accumulation into dW and db, bitwise repeatability."""
+    from tests.parity import kernel_tags
+    x, dz = R(n, h, w, ci), R(n, h, w, co)
+    _, gw = _torch_conv_grads(x, R(3, 3, ci, co), dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_wgrad(x, dz, 3))
+    assert tags.get('conv_narrow_wgrad<8>') == 2 and not any(t.startswith('conv_wgrad_rows<') for t in tags), tags
+    close(got, gw)
+    base_w = R(*gw.shape)
+    close(ops.conv2d_wgrad(x, dz, 3, accumulate_into=base_w), gw + base_w)
+    np.testing.assert_array_equal(got, ops.conv2d_wgrad(x, dz, 3))
+
+
 @pytest.mark.parametrize('n,h,w,ci,co', [(2, 20, 33, 8, 13), (3, 64, 48, 8, 16), (1, 17, 16, 4, 15), (2, 33, 70, 5, 9), (1, 128, 128, 8, 13)])
 def test_conv2d_narrow16_eight_input_channels(ops, n, h, w, ci, co):
     """Round 5: <= 8 input channels with 9 .. 16 outputs (8 -> 13: the dgrad of ConvBlock_att's first layer in the recurrent nets,
