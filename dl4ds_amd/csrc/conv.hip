@@ -1546,6 +1546,7 @@ void conv2d_forward(hipStream_t s, const TView& in, const float* w, int KS, cons
     if (!exp_env("DL4DS_NO_NARROW") && conv2d_narrow_forward(s, in, w, KS, out, ep)) return;
     DL4DS_REQUIRE(!in.sc && !ep.pool, "conv2d: channel-affine input / pooling partials are only implemented by the direct "
                                      "and narrow-pair kernels (the caller must check conv2d_direct_eligible / conv2d_narrow_pair_ok)");
+    if (KS == 3 && conv2d_split_forward(s, in, w, out, ep)) return; // 40 / 48-channel 3x3 layers: fp32 products as six bf16 MFMA terms
     if (KS == 3 && conv2d_wino_forward(s, in, w, out, ep)) return;  // MFMA-bound 3x3 layers: Winograd F(2x2, 3x3)
     // small grids, many channels: GEMM over the flattened pixels of the batch -- up to 16 x 16 ahead of the streaming kernels (which
     // need two tiles per workgroup), up to 32 x 32 for what they decline (measured on cfg5: 106 vs 128-133 TFLOP/s where both apply)

@@ -52,6 +52,8 @@ int conv2d_narrow_wgrad(hipStream_t s, const TView& x, const TView& dz, int KS, 
 bool conv2d_gemm_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out, const ConvEpilogue& ep, int max_hw);
 // Winograd F(2x2, 3x3) form of the MFMA-bound 3x3 layers (conv_wino.hip); false = not eligible
 bool conv2d_wino_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep);
+// the 40 / 48-channel 3x3 layers with their fp32 products as six bf16 MFMA terms (conv_split.hip); false = not eligible / DL4DS_NO_SPLIT
+bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep);
 // The transformed filters of a graph's Winograd layers, one batched launch per pass instead of one per layer (conv_wino.hip):
 // a pass of a graph holds a WinoPassGuard (kind 0 = forward, 1 = backward); _invalidate marks every registered filter inside
 // [lo, hi) stale, _refresh transforms the stale ones of that kind in one launch on s, _release frees them (graph destruction).

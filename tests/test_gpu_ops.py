@@ -260,6 +260,72 @@ def test_conv2d_winograd_depth_to_space(ops, monkeypatch, ci, co):
     close(got, gx)
 
 
+SPLIT_CASES = [
+    # 33 .. 48 input channels (or passes of 48), output channels in chunks of 48; ragged grids (widths that are not multiples of the
+    # 32-pixel strip, heights that are not multiples of the 32-row segment), several images / chunks / passes
+    (2, 40, 33, 48, 48), (3, 64, 48, 48, 192), (1, 48, 32, 40, 40), (1, 35, 21, 48, 96), (2, 32, 32, 48, 40), (1, 70, 100, 40, 48),
+    (1, 33, 17, 192, 48), (2, 17, 33, 96, 96), (1, 20, 20, 144, 40), (1, 5, 3, 48, 48), (4, 130, 64, 48, 48),
+]
+
+
+@pytest.mark.parametrize('sx', ['all', '1'])
+@pytest.mark.parametrize('n,h,w,ci,co', SPLIT_CASES)
+def test_conv2d_split_bf16(ops, monkeypatch, sx, n, h, w, ci, co):
+    """Round 6: conv_split_kernel (conv_split.hip) -- the 40 / 48-channel 3x3 layers with every fp32 product as six bf16 MFMA terms
+    (operands split exactly into three bf16 parts, fp32 accumulation): forward with the fused epilogues, dgrad with accumulation, at
+    the SAME 2e-4 bar as the fp32-pipe kernels and with a measured error of the fp32 MFMA's own size (asserted below against the
+    Winograd / direct result of the same call); DL4DS_SPLIT_FORCE makes it take grids it would leave to them ('1': one workgroup per
+    output-channel chunk, i.e. many strips per workgroup); DL4DS_NO_SPLIT is the product's A/B switch."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_SPLIT_FORCE', sx)
+    x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert 'conv_split<3,3>' in tags, tags
+    close(got, ref)
+    e_split = np.abs(got - ref).max() / np.abs(ref).max()
+    close(ops.conv2d(x, wt, b, add=add, relu=True), np.maximum(ref + add, 0))
+    close(ops.conv2d(x, wt, None, add=add), ref - b + add)
+    mask = R(n, h, w, co)
+    base = R(n, h, w, co)
+    close(ops.conv2d_epilogue(x, wt, b, add=add, mask=mask, relu=True), np.where(mask > 0, np.maximum(ref + add, 0), 0))
+    if ci <= 48:
+        close(ops.conv2d_epilogue(x, wt, b, mask=mask, accumulate_into=base), base + np.where(mask > 0, ref, 0))
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    if co > 32 and (co <= 48 or co % 48 == 0) and ci > 32:
+        got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt))
+        assert 'conv_split<3,3>' in tags, tags
+        close(got, gx)
+        if co <= 48:
+            base_x = R(*gx.shape)
+            close(ops.conv2d_dgrad(dz, wt, accumulate_into=base_x), gx + base_x)
+    monkeypatch.setenv('DL4DS_NO_SPLIT', '1')
+    got32, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert 'conv_split<3,3>' not in tags, tags
+    e_f32 = np.abs(got32 - ref).max() / np.abs(ref).max()
+    assert e_split < 2e-6 and e_split < 4 * e_f32 + 2e-7, (e_split, e_f32)        # fp32 arithmetic to rounding, not a narrower type
+
+
+@pytest.mark.parametrize('ci,co', [(48, 192), (48, 96), (40, 192)])
+def test_conv2d_split_bf16_depth_to_space(ops, monkeypatch, ci, co):
+    """... through depth_to_space views on the output (forward: SubpixelConvolution's conv2x, blocks.py:414-454) and on the input
+    (its dgrad: four passes over 192 gradient channels)."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_SPLIT_FORCE', '1')
+    n, h, w, r = 2, 34, 20, 2
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    ref = N.depth_to_space(N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)), r)
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b, d2s=r))
+    assert 'conv_split<3,3>' in tags, tags
+    close(got, ref)
+    dz = R(n, h * r, w * r, co // (r * r))
+    gx, _ = _torch_conv_grads(x, wt, dz, d2s=r)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt, d2s=r))
+    assert 'conv_split<3,3>' in tags, tags
+    close(got, gx)
+
+
 F44_CASES = [
     # F(4x4, 3x3): cout chunks of 32, passes of 48 / 32 input channels; ragged grids (sizes that are not multiples of the 16 x 16 tile group, of the
     # 4 x 4 tile), several images, several chunks, several passes; couts that are not whole chunks (forced)
