@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E spec (about 6.3 TB/s is achievable)
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (only the opt-in conv_split kernel runs there)
 ACHIEVABLE_HBM_GBPS = 6300.0           # MI355X_MICROARCH.md: measured float4 copy, the bandwidth term of the step-level bound
 WINOGRAD_SAVING = 2.25                 # F(2x2,3x3): 16 multiplies per 2x2 tile and (cin, cout) pair instead of 36
 MIN_STEADY_S = 2.0                     # the second timing window (`steady_state`) runs at least this long
@@ -578,6 +579,13 @@ def main():
                            if wino else {}),
                         'share_of_step_time': dom_share,
                         'measured': 'HIP events around every launch of this kernel inside the timed region'}
+            if dom.startswith('conv_split'):
+                # fp32 products as six bf16 MFMA terms: both roofs -- the fp32 MFMA's (what the layer would be priced at) and the pipe it
+                # runs on (dense bf16 peak / 12 bf16 multiply-adds per fp32 multiply-add with two parts per k-slot)
+                roofline['arith'] = 'fp32 products as 6 bf16 MFMA terms, fp32 accumulate'
+                roofline['bf16_pipe_roof'] = {'achieved': achieved, 'peak': PEAK_BF16_MFMA_TFLOPS / 6.0, 'unit': 'TFLOP/s of fp32 products',
+                                              'frac': achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                                              'note': 'v_mfma_f32_16x16x32_bf16 dense peak 2 500 TFLOP/s; six bf16 products per fp32 product'}
             # the roof that binds: a narrow-channel layer's algorithmic bytes / 8 TB/s can be the larger fraction
             gbps = d['bytes'] / (d['ms'] * 1e-3) / 1e9
             if gbps / PEAK_HBM_GBPS > roofline['frac']:
@@ -613,6 +621,7 @@ def main():
         slots[rank] = 1e3 * dt_own / args.steps
         per_rank = parallel.allreduce_host(slots, 'sum')
 
+    split_on = bool(os.environ.get('DL4DS_SPLIT')) and not os.environ.get('DL4DS_NO_SPLIT')
     if rank == 0:
         value = world * B * args.steps / dt
         ms_step = 1e3 * dt / args.steps
@@ -636,6 +645,9 @@ def main():
             'direct_form_gflop_per_sample': (direct_gflop_per_step / B) if direct_gflop_per_step else None,
             'conv_folding': not bool(os.environ.get('DL4DS_NO_FOLD')),
             'winograd': winograd,
+            # what the matrix pipes multiply (a six-term split counts as f32 only if it says so and prints both roofs)
+            'arith': ('fp32 products as 6 bf16 MFMA terms, fp32 accumulate (conv_split<3,3>: the 40/48-channel 3x3 layers; opt-in, DL4DS_SPLIT=1); '
+                      'every other layer v_mfma_f32_16x16x4_f32' if split_on else 'fp32 MFMA (v_mfma_f32_16x16x4_f32) / fp32 VALU, fp32 accumulate'),
             'roofline': roofline,
             'hbm_kernels': hbm_kernels,
             'cpu_baseline': None,
