@@ -44,7 +44,10 @@ constexpr int SPX = 32;                 // output pixels per strip row
 constexpr int HPX = SPX + 2;            // staged pixels per row
 constexpr int PIXB = 288;               // bytes per staged pixel: three parts x 48 channels x 2
 constexpr int ROWB = HPX * PIXB;        // 9792
-constexpr int REDF = 5 * SPX * 48;      // floats of one row's partial sums: [slot: the tile's four matrix waves, its helper wave][pixel][48 output channels]
+constexpr int RPIX = 52;                // floats per pixel of the partial sums: 48 + 4 -- a 16-byte store is serviced in groups of eight consecutive lanes
+                                        // (eight pixels here): at 48 floats apart they hit the same banks four at a time (SQ_LDS_BANK_CONFLICT 0.41 of
+                                        // the LDS cycles), at 52 the eight quads cover the 32 banks once
+constexpr int REDF = 5 * SPX * RPIX;    // floats of one row's partial sums: [slot: the tile's four matrix waves, its helper wave][pixel][RPIX]
 constexpr int NMW = 12, NHW = 4;        // matrix waves, helper waves
 constexpr int NTHREADS = 64 * (NMW + NHW);
 constexpr size_t LDS_BYTES = 3 * ROWB + 2 * REDF * sizeof(float) + 48 * sizeof(float);
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_split_kernel(const SplitParams 
     const int boff3 = n16 * PIXB + (kq >> 1) * 192 + (kq & 1) * 16;
     const int ct = split_tile(wave);                                        // (helper wave 3: no unit)
     const int rslot = wave < NMW ? (wave & 3) : 4;                          // this wave's place among the tile's partial sums
-    const int rdoff = (rslot * SPX + n16) * 48 + (ct < 3 ? ct : 0) * 16 + kq * 4;
+    const int rdoff = (rslot * SPX + n16) * RPIX + (ct < 3 ? ct : 0) * 16 + kq * 4;
     SPLIT_TRACE_DECL;
     if (tid < 48) lbias[tid] = (p.bias && p.final_pass && chunk * 48 + tid < p.Cout) ? p.bias[chunk * 48 + tid] : 0.f;     // (visible after the first barrier)
 
@@ -234,12 +237,12 @@ __global__ void __launch_bounds__(NTHREADS) conv_split_kernel(const SplitParams 
             // output row yo from the five per-wave partial sums of every channel tile in red[buf]
             auto finish = [&](int yo, int buf) __attribute__((always_inline)) {
                 const int eoff = (yo >= y_lo && yo < y_hi && ooff != OOB) ? 0 : OOB;
-                const float* r0 = red + buf * REDF + epx * 48 + eq * 4;
+                const float* r0 = red + buf * REDF + epx * RPIX + eq * 4;
                 const float4 a0 = *reinterpret_cast<const float4*>(r0);
-                const float4 a1 = *reinterpret_cast<const float4*>(r0 + SPX * 48);
-                const float4 a2 = *reinterpret_cast<const float4*>(r0 + 2 * SPX * 48);
-                const float4 a3 = *reinterpret_cast<const float4*>(r0 + 3 * SPX * 48);
-                const float4 a4 = *reinterpret_cast<const float4*>(r0 + 4 * SPX * 48);
+                const float4 a1 = *reinterpret_cast<const float4*>(r0 + SPX * RPIX);
+                const float4 a2 = *reinterpret_cast<const float4*>(r0 + 2 * SPX * RPIX);
+                const float4 a3 = *reinterpret_cast<const float4*>(r0 + 3 * SPX * RPIX);
+                const float4 a4 = *reinterpret_cast<const float4*>(r0 + 4 * SPX * RPIX);
                 float4 v = make_float4(((a0.x + a1.x) + (a2.x + a3.x)) + a4.x, ((a0.y + a1.y) + (a2.y + a3.y)) + a4.y,
                                        ((a0.z + a1.z) + (a2.z + a3.z)) + a4.z, ((a0.w + a1.w) + (a2.w + a3.w)) + a4.w);
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f), r = o, mk = o;
@@ -300,7 +303,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_split_kernel(const SplitParams 
                 float* rd = red + (y & 1) * REDF + rdoff;
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
-                    *reinterpret_cast<f32x4*>(rd + pt * 16 * 48) = O[pt];
+                    *reinterpret_cast<f32x4*>(rd + pt * 16 * RPIX) = O[pt];
                     O[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 SPLIT_STAMP(1);
@@ -416,7 +419,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_split_kernel(const SplitParams 
                 float* rd = red + (y & 1) * REDF + rdoff;
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
-                    *reinterpret_cast<f32x4*>(rd + pt * 16 * 48) = O[pt];
+                    *reinterpret_cast<f32x4*>(rd + pt * 16 * RPIX) = O[pt];
                     O[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -490,8 +493,8 @@ float* frag_scratch(size_t floats) {
 }  // namespace
 
 bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep) {
-    // Measured (round 6, profiles/conv_split_r06.txt): on a par with the Winograd F(2x2,3x3) kernels on the fp32 pipe (0.215 vs 0.222 ms for
-    // 48 -> 48 at 64 x 128^2, 3.4 vs 3.3 ms over the ten layers of a cfg2 step) -- not ahead, so it is OPT-IN: DL4DS_SPLIT=1 (the bench line
+    // Measured (round 6, profiles/conv_split_r06.txt): on a par with the Winograd F(2x2,3x3) kernels on the fp32 pipe (0.205 vs 0.21-0.23 ms for
+    // 48 -> 48 at 64 x 128^2, 3.27 vs 3.34 ms over the ten layers of a cfg2 step, 5 036 vs 5 053 samples/s for the whole step) -- not ahead, so it is OPT-IN: DL4DS_SPLIT=1 (the bench line
     // then says so in "arith"); DL4DS_NO_SPLIT wins over it.
     const char* force = test_env("DL4DS_SPLIT_FORCE");           // (tests: small grids too; "<k>": k workgroups per output-channel chunk)
     if (getenv("DL4DS_NO_SPLIT") || !(getenv("DL4DS_SPLIT") || force)) return false;
