@@ -409,6 +409,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_split_kernel(const SplitParams 
             if (hunit) {                              // (first: the matrix pipe is what the row waits for)
                 const unsigned char* rb = rowbuf + K * ROWB;
                 bf16x8 bA[3];
+                __builtin_amdgcn_s_setprio(3);                  // (the youngest wave of its SIMD: without this its two MFMA groups wait behind the matrix waves' -- ten calls 3.27 -> 3.19 ms)
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -416,6 +417,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_split_kernel(const SplitParams 
                     split_mma9(A, bA, N[pt], M[pt], O[pt]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
                 float* rd = red + (y & 1) * REDF + rdoff;
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
@@ -493,8 +495,8 @@ float* frag_scratch(size_t floats) {
 }  // namespace
 
 bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep) {
-    // Measured (round 6, profiles/conv_split_r06.txt): on a par with the Winograd F(2x2,3x3) kernels on the fp32 pipe (0.205 vs 0.21-0.23 ms for
-    // 48 -> 48 at 64 x 128^2, 3.27 vs 3.34 ms over the ten layers of a cfg2 step, 5 036 vs 5 053 samples/s for the whole step) -- not ahead, so it is OPT-IN: DL4DS_SPLIT=1 (the bench line
+    // Measured (round 6, profiles/conv_split_r06.txt): on a par with the Winograd F(2x2,3x3) kernels on the fp32 pipe (0.199 vs 0.21-0.23 ms for
+    // 48 -> 48 at 64 x 128^2, 3.19 vs 3.34 ms over the ten layers of a cfg2 step, 5 050 vs 5 060 samples/s for the whole step) -- not ahead, so it is OPT-IN: DL4DS_SPLIT=1 (the bench line
     // then says so in "arith"); DL4DS_NO_SPLIT wins over it.
     const char* force = test_env("DL4DS_SPLIT_FORCE");           // (tests: small grids too; "<k>": k workgroups per output-channel chunk)
     if (getenv("DL4DS_NO_SPLIT") || !(getenv("DL4DS_SPLIT") || force)) return false;
