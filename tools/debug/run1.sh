@@ -1,12 +1,9 @@
 mkdir -p gpurun_out/r1
-export DL4DS_SPLIT=1
-cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}
-rm -rf /tmp/ps_split
-rocprofv3 --kernel-trace --stats -d /tmp/ps_split --output-format csv -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-unfolded --no-b16 > $R/gpurun_out/r1/bench_under_rocprof_split.log 2>&1
-python $R/tools/rocprof_stats_summary.py /tmp/ps_split > $R/gpurun_out/r1/kernel_stats_split_r06.txt
-cd $R
-bash tools/pmc_sq.sh
-cp gpurun_out/pmc_sq.txt gpurun_out/r1/pmc_sq_split_r06.txt
-python tools/pmc_derived.py gpurun_out/pmc_sq.txt > gpurun_out/r1/pmc_mfma_split_r06.txt
-head -12 gpurun_out/r1/kernel_stats_split_r06.txt | cut -c1-130
+python bench.py > gpurun_out/r1/default.json 2> gpurun_out/r1/default.err
+python - <<'EOF'
+import json
+d=json.loads(open('gpurun_out/r1/default.json').read().strip().splitlines()[-1])
+print(round(d['value'],1), d['gpu_over_cpu'], d['roofline']['traffic'])
+c=d['cpu_baseline']; print({k:c[k] for k in c if k not in ('sample',)})
+print(c['sample'])
+EOF
