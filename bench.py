@@ -324,6 +324,17 @@ def cpu_baseline(weights, budget_s=30.0, batch=16):
     return out
 
 
+def arith_text():
+    """What the matrix pipes multiply (a six-term split counts as f32 only if the line says so and prints both roofs)."""
+    if os.environ.get('DL4DS_NO_SPLIT'):
+        return 'fp32 MFMA (v_mfma_f32_16x16x4_f32) / fp32 VALU, fp32 accumulate (DL4DS_NO_SPLIT=1)'
+    which = ('every eligible 40/48-channel shape: DL4DS_SPLIT=1' if os.environ.get('DL4DS_SPLIT') else
+             'default dispatch: one pass of <= 48 input channels, <= 48 output channels, grids of >= 2 strips per CU')
+    return ('fp32 products as 6 bf16 MFMA terms, fp32 accumulate, on the 3x3 layers tagged conv_split<3,3> (' + which + '; same error as the '
+            'fp32 MFMA, profiles/conv_split_r06.txt; DL4DS_NO_SPLIT=1 is the A/B switch); every other layer fp32 MFMA '
+            '(v_mfma_f32_16x16x4_f32) / fp32 VALU, fp32 accumulate')
+
+
 def step_roofline(rep, nprof, ms_step):
     """How far the whole STEP is from its own roofline.  Every profiled launch class k (a kernel tag = one shape class) is priced
     at the larger of its matrix time and its memory time, lower_bound = sum_k max(flops_k / 157.3 TFLOP/s, bytes_k / 6.3 TB/s):
@@ -453,7 +464,7 @@ def predict_line(args):
            for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms'])[:8]}
     out = {'metric': 'HR samples/s (predict: forward only) at 4x 128->512 residual SR', 'value': B / dt, 'unit': 'HR samples/s',
            'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 3), 'ms_per_step': 1e3 * dt, 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'arith': arith_text(),
            'config': {'workload': 'configs[1] forward only: net_postupsampling(resnet, spc, scale=4, lr 128x128 -> hr 512x512, 204405 params), '
                                   'dl4ds_graph_forward with the LR batch and the HR output resident in HBM', 'per_gpu_batch': B},
            'steady_state': {'steps': n2, 'ms_per_step': 1e3 * dt2, 'value': B / dt2},
@@ -760,7 +771,7 @@ def main():
         slots[rank] = 1e3 * dt_own / args.steps
         per_rank = parallel.allreduce_host(slots, 'sum')
 
-    split_on = bool(os.environ.get('DL4DS_SPLIT')) and not os.environ.get('DL4DS_NO_SPLIT')
+    split_on = not os.environ.get('DL4DS_NO_SPLIT')          # (the default dispatch: conv_split for the single-pass <= 48 x <= 48 channel 3x3 layers)
     if rank == 0:
         value = world * B * args.steps / dt
         ms_step = 1e3 * dt / args.steps
@@ -785,8 +796,7 @@ def main():
             'conv_folding': not bool(os.environ.get('DL4DS_NO_FOLD')),
             'winograd': winograd,
             # what the matrix pipes multiply (a six-term split counts as f32 only if it says so and prints both roofs)
-            'arith': ('fp32 products as 6 bf16 MFMA terms, fp32 accumulate (conv_split<3,3>: the 40/48-channel 3x3 layers; opt-in, DL4DS_SPLIT=1); '
-                      'every other layer v_mfma_f32_16x16x4_f32' if split_on else 'fp32 MFMA (v_mfma_f32_16x16x4_f32) / fp32 VALU, fp32 accumulate'),
+            'arith': arith_text(),
             'roofline': roofline,
             'hbm_kernels': hbm_kernels,
             'cpu_baseline': None,

@@ -1,4 +1,5 @@
-// 3x3 convolution (stride 1, SAME) of the 40 / 48-channel layers with its fp32 PRODUCTS on the 16-bit matrix pipe of gfx950 (round 6).
+// 3x3 convolution (stride 1, SAME) of the 40 / 48-channel layers with its fp32 PRODUCTS on the 16-bit matrix pipe of gfx950 (round 6;
+// the product path of the single-pass <= 48 x <= 48 channel layers, see conv2d_split_forward).
 // dl4ds/models/blocks.py:210-230, 401-454 (ResidualBlock / the sub-pixel block's convolutions) -- forward, and the data gradient as the
 // same convolution with the flipped / transposed filter.
 //
@@ -495,11 +496,14 @@ float* frag_scratch(size_t floats) {
 }  // namespace
 
 bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep) {
-    // Measured (round 6, profiles/conv_split_r06.txt): on a par with the Winograd F(2x2,3x3) kernels on the fp32 pipe (0.199 vs 0.21-0.23 ms for
-    // 48 -> 48 at 64 x 128^2, 3.19 vs 3.34 ms over the ten layers of a cfg2 step, 5 050 vs 5 060 samples/s for the whole step) -- not ahead, so it is OPT-IN: DL4DS_SPLIT=1 (the bench line
-    // then says so in "arith"); DL4DS_NO_SPLIT wins over it.
+    // Measured (round 6, profiles/conv_split_r06.txt): 10 % faster than the Winograd F(2x2,3x3) kernels on the fp32 pipe for the layers with
+    // ONE pass of <= 48 input channels and <= 48 output channels (0.199 vs 0.21-0.23 ms at 64 x 128^2), slower for 48 -> 192 / 192 -> 48
+    // (0.76 / 0.83 vs 0.74 / 0.84).  So: ON by default for the former (cfg2: eight of the ten <3,3> layers, 5 075 -> 5 175 samples/s in
+    // three alternating runs), the latter only with DL4DS_SPLIT=1 (all eligible shapes: an experiment switch); DL4DS_NO_SPLIT=1 turns the
+    // kernel off altogether -- the A/B switch of the product, and what `arith` in the bench line reports against.
     const char* force = test_env("DL4DS_SPLIT_FORCE");           // (tests: small grids too; "<k>": k workgroups per output-channel chunk)
-    if (getenv("DL4DS_NO_SPLIT") || !(getenv("DL4DS_SPLIT") || force)) return false;
+    if (getenv("DL4DS_NO_SPLIT")) return false;
+    const bool every_shape = getenv("DL4DS_SPLIT") != nullptr || force != nullptr;
     if (in.sc || ep.pool) return false;
     if (!in.vec || !out.vec || (in.C & 3) || (out.C & 3) || (ep.add.p && !ep.add.vec) || (ep.mask.p && !ep.mask.vec)) return false;
     if ((((uintptr_t)ep.bias) & 15) != 0) return false;
@@ -507,8 +511,13 @@ bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const 
     if (in.C <= 32 || (in.C > 48 && in.C % 48 != 0)) return false;
     if (out.C <= 32 || cdiv(out.C, 32) * 32 < cdiv(out.C, 48) * 48) return false;
     const int passes = cdiv(in.C, 48);
+    if (!every_shape && (passes > 1 || out.C > 48)) return false;
     if (passes > 1 && ep.accumulate) return false;
     if (ep.add.p && (ep.add.C != out.C)) return false;
+    // (the kernel addresses an image with 32-bit byte offsets from the image's base)
+    auto span = [](const TView& v) { const size_t r = std::max(v.d2s, 1); return (size_t)(v.H + 2) * v.W * r * r * v.ld * 4; };
+    if (span(in) >= (1ull << 31) || span(out) >= (1ull << 31) || (ep.add.p && span(ep.add) >= (1ull << 31)) ||
+        (ep.mask.p && span(ep.mask) >= (1ull << 31))) return false;
     SplitParams p;
     p.in = in; p.out = out; p.add = ep.add; p.mask = ep.mask; p.bias = ep.bias;
     p.Cin = in.C; p.Cout = out.C; p.H = in.H; p.W = in.W;

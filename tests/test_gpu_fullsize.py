@@ -267,19 +267,21 @@ def test_cfg2_full_size_against_the_oracle(monkeypatch, winograd):
     """BASELINE configs[1] (the headline: resnet + sub-pixel x4, 128 -> 512) at B = 32 -- the smallest batch at which every
     producer / consumer kernel of the B = 64 bench step is dispatched (asserted) -- against the fp64 oracle: forward, MAE
     loss, every gradient per tensor; once with the Winograd form of the MFMA-bound 3x3 layers (what the bench runs) and once
-    with the direct kernels (DL4DS_NO_WINOGRAD=1).  Round 6, 'split': the same comparison, UNCHANGED, with the opt-in six-term bf16 kernel
-    (DL4DS_SPLIT=1) on the ten <3,3> layers -- the condition VERDICT r5 set for calling that arithmetic fp32.  sp_postups.py:95-217."""
+    with the direct kernels (DL4DS_NO_WINOGRAD=1), both with DL4DS_NO_SPLIT=1.  Round 6, 'split': the same comparison, UNCHANGED, in the
+    product's DEFAULT dispatch -- the eight single-pass <= 48-channel <3,3> layers on the six-term bf16 kernel (conv_split), 48 -> 192 and
+    192 -> 48 on the Winograd kernel -- the condition VERDICT r5 set for calling that arithmetic fp32.  sp_postups.py:95-217."""
     from dl4ds_amd.training import SupervisedEngine
     from tests.parity import assert_matches_reference, kernel_tags, oracle_reference
     _no_force_overrides()
     split = winograd == 'split'
     monkeypatch.delenv('DL4DS_SPLIT', raising=False)
+    monkeypatch.delenv('DL4DS_NO_SPLIT', raising=False)
     if winograd:
         monkeypatch.delenv('DL4DS_NO_WINOGRAD', raising=False)
     else:
         monkeypatch.setenv('DL4DS_NO_WINOGRAD', '1')
-    if split:
-        monkeypatch.setenv('DL4DS_SPLIT', '1')
+    if not split:
+        monkeypatch.setenv('DL4DS_NO_SPLIT', '1')          # (True / False: the fp32-pipe kernels alone; 'split': the product's default dispatch)
     B = 32
     model = _cfg2(seed=11)
     w = _randomise_biases(model)
@@ -290,14 +292,16 @@ def test_cfg2_full_size_against_the_oracle(monkeypatch, winograd):
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x], y))
     # the kernels that carry the bench step (profiles/kernel_stats_r03.txt) are the ones that just ran
-    must = ('conv_split<3,3>' if split else 'conv_wino<3,3>', 'conv_wino<3,2>', 'conv_wino<2,3>', 'conv_wino<2,2>', 'conv_wino_wgrad<3,3>', 'conv_wino_wgrad<3,2>',
+    must = ('conv_wino<3,3>', 'conv_wino<3,2>', 'conv_wino<2,3>', 'conv_wino<2,2>', 'conv_wino_wgrad<3,3>', 'conv_wino_wgrad<3,2>',
             'conv_wino_wgrad<2,2>') if winograd else \
            ('conv_stream_ws<3,6,3,8>', 'conv_stream_ws<3,12,2,4>', 'conv_stream_ws<3,8,3,4>', 'conv_wgrad_rows<3,3,1,4>',
             'conv_wgrad_rows<3,3,1,1>', 'conv_wgrad_rows<3,3,1,2>')
     for m in must + ('conv_narrow_pair_ws<4>', 'conv_narrow_wgrad<8>'):
         assert m in tags, (m, sorted(tags))
     assert winograd or not any(t.startswith('conv_wino') for t in tags), sorted(tags)
-    assert not split or 'conv_wino<3,3>' not in tags, sorted(tags)
+    assert ('conv_split<3,3>' in tags) == split, sorted(tags)
+    if split:
+        assert tags['conv_split<3,3>'] == 8 and tags['conv_wino<3,3>'] == 2, (tags['conv_split<3,3>'], tags['conv_wino<3,3>'])
     if 'ref' not in _CFG2_REF:          # (same weights, inputs and targets in both runs: the oracle is evaluated once)
         _CFG2_REF['y'] = y
         _CFG2_REF['ref'] = oracle_reference('supervised', 'net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4),
@@ -305,7 +309,7 @@ def test_cfg2_full_size_against_the_oracle(monkeypatch, winograd):
     ref = _CFG2_REF['ref']
     _fwd_close(out, ref['pred'])
     assert l_hip == pytest.approx(ref['loss'], rel=1e-4)
-    _slack_is_small(assert_matches_reference(g_hip, ref, what=f'cfg2 full size ({"six-term bf16 + Winograd" if split else "Winograd" if winograd else "direct"} kernels)', full=True))
+    _slack_is_small(assert_matches_reference(g_hip, ref, what=f'cfg2 full size ({"default dispatch: six-term bf16 + Winograd" if split else "Winograd" if winograd else "direct"} kernels)', full=True))
 
 
 def test_cfg2_on_the_bench_workload_itself_against_the_oracle():

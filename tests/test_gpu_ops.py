@@ -274,8 +274,9 @@ def test_conv2d_split_bf16(ops, monkeypatch, sx, n, h, w, ci, co):
     """Round 6: conv_split_kernel (conv_split.hip) -- the 40 / 48-channel 3x3 layers with every fp32 product as six bf16 MFMA terms
     (operands split exactly into three bf16 parts, fp32 accumulation): forward with the fused epilogues, dgrad with accumulation, at
     the SAME 2e-4 bar as the fp32-pipe kernels and with a measured error of the fp32 MFMA's own size (asserted below against the
-    Winograd / direct result of the same call); DL4DS_SPLIT_FORCE makes it take grids it would leave to them ('1': one workgroup per
-    output-channel chunk, i.e. many strips per workgroup); DL4DS_NO_SPLIT is the product's A/B switch."""
+    Winograd / direct result of the same call); DL4DS_SPLIT_FORCE makes it take grids and shapes it would leave to them ('1': one
+    workgroup per output-channel chunk, i.e. many strips per workgroup; by default it takes the single-pass <= 48 x <= 48 channel layers
+    of large grids); DL4DS_NO_SPLIT is the product's A/B switch."""
     from tests.parity import kernel_tags
     monkeypatch.setenv('DL4DS_SPLIT_FORCE', sx)
     x, wt, b, add = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co), R(n, h, w, co)

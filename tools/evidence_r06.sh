@@ -12,11 +12,13 @@ if [ "${1:-1}" == "1" ]; then
   bash tools/rocprof_round.sh r06 > $O/round.log 2>&1
   python bench.py --predict > $O/bench_predict_r06.json 2> $O/bench_predict_r06.err
   DL4DS_SPLIT=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > $O/bench_split_r06.json 2> $O/bench_split_r06.err
+  DL4DS_NO_SPLIT=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > $O/bench_nosplit_r06.json 2> $O/bench_nosplit_r06.err
 else
   O=gpurun_out/prof_r06b; mkdir -p $O
   ( python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 ; tail -3 $O/gpu_tests.log )
   python bench.py > $O/bench_default_r06.json 2> $O/bench_default_r06.err
   DL4DS_SPLIT=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > $O/bench_split_r06.json 2> $O/bench_split_r06.err
+  DL4DS_NO_SPLIT=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > $O/bench_nosplit_r06.json 2> $O/bench_nosplit_r06.err
   for c in cfg2 cfg4 cfg5; do bash tools/step_gaps.sh $c > /dev/null 2>&1; done
 fi
 ls $O
