@@ -38,6 +38,11 @@ for cfg in ('cfg2', 'cfg4', 'cfg5'):
     calls_per_step = rf.get('calls_per_step') or rf['launches'] / line['steps']
     # steps the PMC pass actually ran (bench.py adds a steady-state window of >= 2 s): the loss kernel launches once per step
     pmc_steps = next((v['launches'] for k, v in t.items() if 'pixel_loss' in k), PMC_STEPS)
+    # (files written by an older tools/pmc_traffic.py carry the split kernel's epilogue forms apart: one bench tag, weighted by launches)
+    forms = {k: v for k, v in t.items() if k.startswith('conv_split<') and k != 'conv_split<3,3>'}
+    if forms:
+        n = sum(v['launches'] for v in forms.values())
+        t['conv_split<3,3>'] = {'launches': n, 'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in forms.values()) / n}
     d = {}
     for k, v in t.items():
         if not re.match(r'^[a-z_0-9]+(<[0-9,]*>)?$', k):

@@ -20,6 +20,8 @@ def tag_of(k):
         return 'rec_tail_fwd'                # plain and LDS-staged form share bench.py's tag
     if 'rec_tail_bwd' in k:
         return 'rec_tail_bwd'
+    if 'conv_split_kernel' in k:
+        return 'conv_split<3,3>'             # (the compiled epilogue-operand form is not part of bench.py's tag)
     m = re.search(r'(conv\w+)<([^>]*)>', k)
     if not m:
         return k[:60]
