@@ -699,7 +699,10 @@ def main():
                     # (another shape) are not this kernel's traffic -- no entry, no number; and counters collected on OTHER
                     # kernel sources than this build's are not this kernel's either -- fingerprint mismatch, no number
                     here = csrc_sha()
-                    if tj.get('_csrc_sha') != here:
+                    if os.environ.get('DL4DS_NO_SPLIT') or os.environ.get('DL4DS_SPLIT'):
+                        # the counters were collected in the default dispatch: with it switched the same tag covers other layers
+                        traffic_source = 'profiles/traffic.json holds the default dispatch; this run has DL4DS_NO_SPLIT / DL4DS_SPLIT set: not reported'
+                    elif tj.get('_csrc_sha') != here:
                         traffic_source = (f'profiles/traffic.json was collected on kernel sources {tj.get("_csrc_sha")} (commit '
                                           f'{tj.get("_commit")}), this build is {here}: stale, not reported')
                     else:
