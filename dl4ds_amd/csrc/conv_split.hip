@@ -480,17 +480,26 @@ int cu_count() {
     return n;
 }
 
-// fragments of the filters seen so far (keyed by the filter pointer: parameters live in one arena and keep their place; the
-// fragments are rebuilt on every call in this first form -- one short launch)
-float* frag_scratch(size_t floats) {
-    static float* buf = nullptr;
-    static size_t cap = 0;
-    if (floats > cap) {
-        if (buf) HIP_CHECK(hipFree(buf));
-        HIP_CHECK(hipMalloc((void**)&buf, floats * sizeof(float)));
-        cap = floats;
+// The filter fragments of a call live in a scratch buffer of the call's STREAM (one per stream, like the Winograd kernels' scratch: two
+// streams may each have a convolution in flight; on one stream the fragment kernel and the convolution that reads it are ordered).  They are
+// rebuilt on every call -- one short launch.
+float* frag_scratch(hipStream_t s, size_t floats) {
+    struct Slot { hipStream_t s; float* buf; size_t cap; };
+    static std::vector<Slot> slots;
+    for (auto& e : slots) {
+        if (e.s != s) continue;
+        if (e.cap < floats) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipFree(e.buf));
+            HIP_CHECK(hipMalloc((void**)&e.buf, floats * sizeof(float)));
+            e.cap = floats;
+        }
+        return e.buf;
     }
-    return buf;
+    Slot e{s, nullptr, std::max<size_t>(floats, 1 << 18)};
+    HIP_CHECK(hipMalloc((void**)&e.buf, e.cap * sizeof(float)));
+    slots.push_back(e);
+    return e.buf;
 }
 
 }  // namespace
@@ -534,7 +543,7 @@ bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const 
     ProfScope ps(s, std::string("conv_split<3,3>") + (test_env("DL4DS_SPLIT_TAG_FORMS") ? std::string("f") + std::to_string((ep.accumulate ? 4 : 0) | (ep.add.p ? 2 : 0) | (ep.mask.p ? 1 : 0)) + "c" + std::to_string(in.C) + "_" + std::to_string(out.C) : std::string()), fl,
                  4.0 * (px * (in.C + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))) + 9.0 * in.C * out.C), fl);
     const int per_pass = p.nchunk * (NMW + NHW) * 12 * 64;                  // uint4 entries
-    u32x4* frag = reinterpret_cast<u32x4*>(frag_scratch((size_t)per_pass * passes * 4));
+    u32x4* frag = reinterpret_cast<u32x4*>(frag_scratch(s, (size_t)per_pass * passes * 4));
     int grid = std::min((int)std::min<long>(items, cu_count()), cu_count()) * 1;
     grid = std::max(1, grid / p.nchunk) * p.nchunk;
     if (grid > cu_count()) grid = (cu_count() / p.nchunk) * p.nchunk;
