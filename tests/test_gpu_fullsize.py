@@ -543,3 +543,32 @@ def test_cfg5_cgan_step_on_the_bench_workload_itself_against_the_oracle():
         assert out[i] == pytest.approx(ref['losses'][i], rel=1e-4), k
     _slack_is_small(assert_matches_reference(gd, ref, 'gradsD', what='cfg5 CGAN step on the bench workload: discriminator (B = 2)', full=True), limit=0.05)
     _slack_is_small(assert_matches_reference(gg, ref, 'gradsG', what='cfg5 CGAN step on the bench workload: generator (B = 2)', full=True), limit=0.05)
+
+
+def test_cfg2_default_dispatch_and_fp32_pipe_follow_one_loss_trajectory(monkeypatch):
+    """Round 6: the product's default dispatch puts the eight single-pass <= 48-channel 3x3 layers of the bench step (B = 64) on
+    conv_split_kernel (fp32 products as six bf16 MFMA terms); DL4DS_NO_SPLIT=1 keeps them on the fp32 pipe.  Twelve Adam steps on the
+    bench batch from the same initial weights, once each way: the two loss curves agree to 2e-5 of their value (what two fp32
+    summation orders differ by), and the kernel tags show that the two runs really took the two paths."""
+    import bench
+    from dl4ds_amd.training import SupervisedEngine
+    from tests.parity import kernel_tags
+    _no_force_overrides()
+    B = 64
+    x, y = bench.synthetic_batch(1002, B)
+    curves, tags = {}, {}
+    for name in ('default', 'fp32 pipe'):
+        monkeypatch.delenv('DL4DS_SPLIT', raising=False)
+        if name == 'default':
+            monkeypatch.delenv('DL4DS_NO_SPLIT', raising=False)
+        else:
+            monkeypatch.setenv('DL4DS_NO_SPLIT', '1')
+        model = _cfg2(seed=7)
+        eng = SupervisedEngine(model, loss='mae', learning_rate=(1e-3, 1e-4), lr_decay_after=1e5)
+        first, tags[name] = kernel_tags(lambda: eng.step([x], y))
+        curves[name] = [first] + [eng.step([x], y) for _ in range(11)]
+        del eng, model
+    assert tags['default'].get('conv_split<3,3>') == 8 and 'conv_split<3,3>' not in tags['fp32 pipe'], (tags['default'], tags['fp32 pipe'])
+    a, b = np.asarray(curves['default']), np.asarray(curves['fp32 pipe'])
+    assert a[-1] < 0.7 * a[0], a
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), (a, b)
