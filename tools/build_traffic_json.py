@@ -43,12 +43,22 @@ for cfg in ('cfg2', 'cfg4', 'cfg5'):
     if forms:
         n = sum(v['launches'] for v in forms.values())
         t['conv_split<3,3>'] = {'launches': n, 'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in forms.values()) / n}
+    # calls per step of EVERY tag from the library profiler's breakdown of the same command (profiles/bench_breakdown[_cfg]_<tag>.json,
+    # DL4DS_BENCH_BREAKDOWN=1), where there is one: a tag's traffic is per CALL of the layer whichever tag a run finds dominant (round 6:
+    # cfg2's two leading tags, conv_wino<3,3> and conv_split<3,3>, are within 3 % of each other and take turns)
+    bfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', f'bench_breakdown{sfx}_{tag}.json')
+    calls = {}
+    if os.path.exists(bfile):
+        bl = json.loads(open(bfile).read().strip().splitlines()[-1])
+        calls = {k: v['launches_per_step'] for k, v in (bl.get('breakdown') or {}).items()}
     d = {}
     for k, v in t.items():
         if not re.match(r'^[a-z_0-9]+(<[0-9,]*>)?$', k):
             continue
         per_call = v['hbm_bytes_per_launch']
-        if k == dom:
+        if k in calls and calls[k] > 0:
+            per_call *= (v['launches'] / pmc_steps) / calls[k]
+        elif k == dom:
             per_call *= (v['launches'] / pmc_steps) / calls_per_step
         d[k] = per_call
     out[cfg] = d
