@@ -340,7 +340,7 @@ def arith_text():
     if os.environ.get('DL4DS_NO_SPLIT'):
         return 'fp32 MFMA (v_mfma_f32_16x16x4_f32) / fp32 VALU, fp32 accumulate (DL4DS_NO_SPLIT=1)'
     which = ('every eligible 40/48-channel shape: DL4DS_SPLIT=1' if os.environ.get('DL4DS_SPLIT') else
-             'default dispatch: one pass of <= 48 input channels, <= 48 output channels, grids of >= 2 strips per CU')
+             'default dispatch: one pass of <= 48 input channels, <= 48 output channels, grids of >= 1 strip segment per CU')
     return ('fp32 products as 6 bf16 MFMA terms, fp32 accumulate, on the 3x3 layers tagged conv_split<3,3> (' + which + '; same error as the '
             'fp32 MFMA, profiles/conv_split_r06.txt; DL4DS_NO_SPLIT=1 is the A/B switch); every other layer fp32 MFMA '
             '(v_mfma_f32_16x16x4_f32) / fp32 VALU, fp32 accumulate')

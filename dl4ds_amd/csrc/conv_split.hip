@@ -535,7 +535,9 @@ bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const 
     p.R = in.H <= 32 ? in.H : 32;
     p.nsy = cdiv(in.H, p.R);
     const long items = (long)p.nsx * p.nsy * in.N;
-    if (items >= (1l << 24) || (!force && items * p.nchunk < 2l * cu_count())) return false;      // too few strips to fill the chip: Winograd / direct kernels
+    // fewer strips than CUs: the Winograd / direct kernels.  (One strip segment per workgroup is enough: cfg2 at per-GPU batch 16 = 256 segments
+    // gains 5 % on the step, 3 950 -> 4 160 samples/s; the first form asked for two per CU.)
+    if (items >= (1l << 24) || (!force && items * p.nchunk < (long)cu_count())) return false;
     p.nitems = (int)items;
     p.relu = ep.relu;
     const double px = (double)in.N * in.H * in.W;
