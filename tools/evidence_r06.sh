@@ -15,7 +15,8 @@ if [ "${1:-1}" == "1" ]; then
   DL4DS_NO_SPLIT=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > $O/bench_nosplit_r06.json 2> $O/bench_nosplit_r06.err
 else
   O=gpurun_out/prof_r06b; mkdir -p $O
-  ( python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 ; tail -3 $O/gpu_tests.log )
+  # (SKIP_TESTS=1: call 1 has already run the GPU suite on these kernel sources)
+  [ -n "$SKIP_TESTS" ] || ( python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 ; tail -3 $O/gpu_tests.log )
   python bench.py > $O/bench_default_r06.json 2> $O/bench_default_r06.err
   DL4DS_SPLIT=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > $O/bench_split_r06.json 2> $O/bench_split_r06.err
   DL4DS_NO_SPLIT=1 python bench.py --no-cpu-baseline --no-unfolded --no-b16 > $O/bench_nosplit_r06.json 2> $O/bench_nosplit_r06.err
