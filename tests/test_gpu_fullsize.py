@@ -312,11 +312,11 @@ def test_cfg2_full_size_against_the_oracle(monkeypatch, winograd):
     _slack_is_small(assert_matches_reference(g_hip, ref, what=f'cfg2 full size ({"default dispatch: six-term bf16 + Winograd" if split else "Winograd" if winograd else "direct"} kernels)', full=True))
 
 
-@pytest.mark.parametrize('B', [8, 16])
+@pytest.mark.parametrize('B', [4, 8, 16])
 def test_cfg2_on_the_bench_workload_itself_against_the_oracle(B):
-    """(B = 16, round 6: the smallest batch at which the product's DEFAULT dispatch puts the eight single-pass <= 48-channel 3x3 layers on
-    conv_split_kernel -- asserted; B = 8 runs them on the fp32 pipe -- so that the six-term bf16 arithmetic is also compared on data nobody
-    steered.)
+    """(Round 6: from B = 8 on the product's DEFAULT dispatch puts the eight single-pass <= 48-channel 3x3 layers on conv_split_kernel --
+    asserted: 16-row strips at B = 8, 32-row strips at B = 16 -- and B = 4 runs them on the fp32 pipe, so that both arithmetics are compared
+    on data nobody steered.)
     VERDICT r4 weak #3: the comparisons above feed N(0, 1) inputs and targets placed clear of the MAE kink; `bench.py` times something
     else -- box-blurred U[0, 1) fields, LR = their 4 x 4 block means, the HR fields themselves as targets, glorot kernels with the ZERO
     biases the builders start from.  The same step on exactly that data and those weights (bench.synthetic_batch(1002, B), seed 7; B = 16:
@@ -334,7 +334,7 @@ def test_cfg2_on_the_bench_workload_itself_against_the_oracle(B):
     eng = SupervisedEngine(model, loss='mae', learning_rate=1e-3)
     (l_hip, g_hip), tags = kernel_tags(lambda: eng.loss_and_grads([x], y))
     assert any(t.startswith('conv_wino<3,3>') for t in tags) and 'conv_narrow_pair_ws<4>' in tags, sorted(tags)
-    assert (tags.get('conv_split<3,3>') == 8) == (B >= 16), sorted(tags)
+    assert (tags.get('conv_split<3,3>') == 8) == (B >= 8), sorted(tags)
     ref = oracle_reference('supervised', 'net_postupsampling', dict(backbone_block='resnet', upsampling='spc', scale=4), w, x, None, y,
                            loss='mae', workers=ORACLE_WORKERS)
     _fwd_close(out, ref['pred'])

@@ -308,6 +308,29 @@ def test_conv2d_split_bf16(ops, monkeypatch, sx, n, h, w, ci, co):
     assert e_split < 2e-6 and e_split < 4 * e_f32 + 2e-7, (e_split, e_f32)        # fp32 arithmetic to rounding, not a narrower type
 
 
+@pytest.mark.parametrize('rows', ['32', '16', '5'])
+@pytest.mark.parametrize('n,h,w,ci,co', [(2, 40, 33, 48, 48), (1, 70, 100, 40, 48), (1, 33, 17, 192, 48)])
+def test_conv2d_split_bf16_strip_rows(ops, monkeypatch, rows, n, h, w, ci, co):
+    """The strip height is a dispatch decision (32 rows; 16 when 32-row strips would leave CUs without one: cfg2 at per-GPU batch 8),
+    not arithmetic: every height gives the SAME bits (each output pixel is one fixed-order sum over its 9 x cin products), ragged last strips
+    included.  DL4DS_SPLIT_R is the test hook that pins the height (the small grids of the op tests would all take 16 otherwise)."""
+    from tests.parity import kernel_tags
+    monkeypatch.setenv('DL4DS_SPLIT_FORCE', 'all')
+    x, wt, b = R(n, h, w, ci), R(3, 3, ci, co) * 0.2, R(co)
+    ref = N.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    base = ops.conv2d(x, wt, b)
+    monkeypatch.setenv('DL4DS_SPLIT_R', rows)
+    got, tags = kernel_tags(lambda: ops.conv2d(x, wt, b))
+    assert 'conv_split<3,3>' in tags, tags
+    close(got, ref)
+    assert np.array_equal(got, base)
+    dz = R(n, h, w, co)
+    gx, _ = _torch_conv_grads(x, wt, dz)
+    got, tags = kernel_tags(lambda: ops.conv2d_dgrad(dz, wt))
+    assert 'conv_split<3,3>' in tags, tags
+    close(got, gx)
+
+
 @pytest.mark.parametrize('ci,co', [(48, 192), (48, 96), (40, 192)])
 def test_conv2d_split_bf16_depth_to_space(ops, monkeypatch, ci, co):
     """... through depth_to_space views on the output (forward: SubpixelConvolution's conv2x, blocks.py:414-454) and on the input
