@@ -38,7 +38,7 @@ struct WgGeom {
     static constexpr int HW = 18, HH = 6, HPIX = HW * HH, YPIX = 64;
     static constexpr int RAWX = HPIX * CK, RAWY = YPIX * CO, V = 256 * VP, M = 256 * MP;      // floats
     static constexpr size_t LDS_BYTES = (size_t)(RAWX + RAWY + V + M) * 4;
-    static constexpr int FR = 4 * (4 * KQ * NT) * 64 * 4;                 // accumulator floats per workgroup
+    static constexpr int FR = 4 * (3 * KQ * NT) * 64 * 4;                 // slab floats per workgroup: 4 rows xi x 3 columns b (see the epilogue)
     static constexpr int ST = FR + CO;                                    // slab stride
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -269,14 +269,20 @@ __global__ void __launch_bounds__(256, 1) conv_wino_wgrad_kernel(const WinoWgrad
             tg = ntg;
         }
     }
-    // ---- the workgroup's share of dU: lane (column l15 = cout, rows 4 lq + r = cin) -> [wave][nu][cin block][cout block][lane][4]
+    // ---- the workgroup's share of dU: lane (column l15 = cout, rows 4 lq + r = cin) -> [wave][b][cin block][cout block][lane][4].
+    // The COLUMN half of G^T . G is applied here, in the wave's registers (round 6): 12 planes leave instead of 16 -- a quarter of the slab bytes
+    // (512 slabs of 147 KB per 48 x 48 weight gradient, written here and read by the first slab sum).  u[b] = sum over nu of G[nu][b] s(nu) dU[xi][nu]
+    // with s(3) = -1 (the rows of A stored positive, see the header); the row half and row 3's sign are the closing kernel's.
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
+    for (int i = 0; i < KQ; ++i)
 #pragma unroll
-        for (int i = 0; i < KQ; ++i)
+        for (int j = 0; j < NT; ++j) {
+            const f32x4 h = .5f * (acc[1][i][j] + acc[2][i][j]);
+            const f32x4 u[3] = {acc[0][i][j] + h, .5f * (acc[1][i][j] - acc[2][i][j]), h - acc[3][i][j]};
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                *reinterpret_cast<f32x4*>(myslab + ((size_t)((wave * 4 + nu) * KQ + i) * NT + j) * 256 + lane * 4) = acc[nu][i][j];
+            for (int b = 0; b < 3; ++b)
+                *reinterpret_cast<f32x4*>(myslab + ((size_t)((wave * 3 + b) * KQ + i) * NT + j) * 256 + lane * 4) = u[b];
+        }
     // ---- bias gradient: the (tile, cout quad) threads' sums, added over the 16 tiles
     if (m_on) *reinterpret_cast<f32x4*>(lds + tid * 4) = dbacc;
     __syncthreads();
@@ -319,7 +325,7 @@ struct Wg2Geom {
     static constexpr int SITX = (NCHX + 3) / 4, SITY = (NCHY + 3) / 4;
     static constexpr int TAB = (SITX + SITY) * 256;                 // ints
     static constexpr size_t LDS_BYTES = (size_t)(2 * (RAWX + RAWY) * 4 + TAB) * 4;
-    static constexpr int FR = 4 * (4 * KQ * NT) * 64 * 4;
+    static constexpr int FR = 4 * (3 * KQ * NT) * 64 * 4;
     static constexpr int ST = FR + CO;
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
@@ -571,14 +577,20 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
             buf ^= 1;
         }
     }
-    // ---- the workgroup's share of dU: lane (column l15 = cout, rows 4 lq + r = cin) -> [wave][nu][cin block][cout block][lane][4]
+    // ---- the workgroup's share of dU: lane (column l15 = cout, rows 4 lq + r = cin) -> [wave][b][cin block][cout block][lane][4].
+    // The COLUMN half of G^T . G is applied here, in the wave's registers (round 6): 12 planes leave instead of 16 -- a quarter of the slab bytes
+    // (512 slabs of 147 KB per 48 x 48 weight gradient, written here and read by the first slab sum).  u[b] = sum over nu of G[nu][b] s(nu) dU[xi][nu]
+    // with s(3) = -1 (the rows of A stored positive, see the header); the row half and row 3's sign are the closing kernel's.
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
+    for (int i = 0; i < KQ; ++i)
 #pragma unroll
-        for (int i = 0; i < KQ; ++i)
+        for (int j = 0; j < NT; ++j) {
+            const f32x4 h = .5f * (acc[1][i][j] + acc[2][i][j]);
+            const f32x4 u[3] = {acc[0][i][j] + h, .5f * (acc[1][i][j] - acc[2][i][j]), h - acc[3][i][j]};
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                *reinterpret_cast<f32x4*>(myslab + ((size_t)((wave * 4 + nu) * KQ + i) * NT + j) * 256 + lane * 4) = acc[nu][i][j];
+            for (int b = 0; b < 3; ++b)
+                *reinterpret_cast<f32x4*>(myslab + ((size_t)((wave * 3 + b) * KQ + i) * NT + j) * 256 + lane * 4) = u[b];
+        }
     // ---- bias gradient: wave 1's lanes hold, per cout 16 j + l15, the sum over the tiles of their k-slot
     __syncthreads();
     if (wave == 1) {
@@ -617,12 +629,12 @@ __global__ void __launch_bounds__(256) wino_slab_sum_kernel(const float* __restr
     }
 }
 
-// dW[a][b][cin][cout] (+)= sum over xi, nu of G[xi][a] G[nu][b] sigma(xi) sigma(nu) S[xi][nu][cin][cout], sigma(3) = -1;
+// dW[a][b][cin][cout] (+)= sum over xi of G[xi][a] sigma(xi) S[xi][b][cin][cout], sigma(3) = -1 (S: the slabs' sum, columns transformed);
 // thread = (pair, cin block, cout block, lane): four input channels (rows 4 lq + r) of one output channel
 __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
                                                                 int Cin, int Cout, int KQ, int NT, int ncin, int ncout, int accumulate,
                                                                 int accumulate_db, int ngroups, size_t gstride, int paired) {
-    const int F = 4 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
+    const int F = 3 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
     const int per_pair = KQ * NT * 64;
     const int total = ncin * ncout * per_pair;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -637,35 +649,29 @@ __global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float* __r
         const int cin_st = pi ? 2 : 1;
         const int co = (pc % ncout) * 16 * NT + (pj ? 32 * (j >> 1) + 2 * (lane & 15) + (j & 1) : 16 * j + (lane & 15));
         if (co >= Cout) continue;
-        f32x4 s[4][4];
+        // the slabs hold u[xi][b] (columns already transformed by the weight-gradient kernel); rows: sigma(3) = -1, then G^T
+        f32x4 u[4][3];
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                const float* q = S + (size_t)pc * ST + ((size_t)((xi * 4 + nu) * KQ + i) * NT + j) * 256 + lane * 4;
+            for (int b = 0; b < 3; ++b) {
+                const float* q = S + (size_t)pc * ST + ((size_t)((xi * 3 + b) * KQ + i) * NT + j) * 256 + lane * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(q);
                 for (int g = 1; g < ngroups; ++g) v += *reinterpret_cast<const f32x4*>(q + g * gstride);
-                s[xi][nu] = ((xi == 3) != (nu == 3)) ? -v : v;
+                u[xi][b] = xi == 3 ? -v : v;
             }
-        // rows: t[a][nu] = sum_xi G[xi][a] s[xi][nu]; G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-        f32x4 t[3][4];
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            t[0][nu] = s[0][nu] + .5f * (s[1][nu] + s[2][nu]);
-            t[1][nu] = .5f * (s[1][nu] - s[2][nu]);
-            t[2][nu] = s[3][nu] + .5f * (s[1][nu] + s[2][nu]);
-        }
+        for (int b = 0; b < 3; ++b) {
+            const f32x4 h = .5f * (u[1][b] + u[2][b]);
+            const f32x4 g[3] = {u[0][b] + h, .5f * (u[1][b] - u[2][b]), u[3][b] + h};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const f32x4 g[3] = {t[a][0] + .5f * (t[a][1] + t[a][2]), .5f * (t[a][1] - t[a][2]), t[a][3] + .5f * (t[a][1] + t[a][2])};
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int cin = cin_b + rr * cin_st;
                     if (cin < Cin) {
                         float* p = dw + ((size_t)((a * 3 + b) * Cin + cin)) * Cout + co;
-                        *p = accumulate ? *p + g[b][rr] : g[b][rr];
+                        *p = accumulate ? *p + g[a][rr] : g[a][rr];
                     }
                 }
         }
@@ -782,7 +788,7 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     // former limit of 16 sent the five 48-channel layers to the direct kernels -- weight-gradient family 1.46 -> 1.35 ms per step of 16,
     // 3 845 -> 3 950 samples/s; one workgroup per CU with 16 groups each is slower (3 640), and so is a limit of 4 for the 32-channel shapes)
     if (!force && (long)wp.per_xcd < 8l * nsub) return false;
-    const int F = 4 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
+    const int F = 3 * KQ * NT, ST = 4 * F * 256 + 16 * NT;
     const int nslabs = 8 * nsub;
     const size_t per_k = (size_t)npair * ST;
     const int ngroups = std::min(nslabs, 16), per_group = cdiv(nslabs, ngroups);
@@ -811,6 +817,10 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     // (round 5, measured and dropped: the closing transform adding the <= 16 group sums itself -- ngroups = ng on `part` -- instead of
     //  this second short launch: wino_wgrad_finish 0.20 -> 0.78 ms per cfg2 step, 5 020 -> 4 790 samples/s; its 16 x 16 strided
     //  float4 loads per thread are far slower than the coalesced sum)
+    // (round 6, measured and dropped: the same with a closing kernel built for it -- one 1024-thread workgroup per (pair, cin block, cout block),
+    //  thread (position, lane) adding the 16 group sums of its float4 coalesced, LDS handing a lane's 16 positions to the transform threads:
+    //  same bits, one launch less, and 0.1 % SLOWER at B = 64, 0.3-0.7 % at B = 16 in three alternating runs -- 9 workgroups take as long as the two
+    //  short launches; the 20 us per weight gradient are the first sum's 75 MB)
     DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048), 1), dim3(256), 0, s, part, sum, n4, ng, ng);
     HIP_CHECK(hipGetLastError());
     DL4DS_LAUNCH(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, sum, dw, db, x.C, dy.C, KQ, NT,
