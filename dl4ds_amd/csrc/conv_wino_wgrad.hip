@@ -4,17 +4,14 @@
 // the 36 of the direct form (conv_wgrad_rows_ws_kernel runs those at 0.7-0.85 of the fp32 MFMA peak; blocks.py:49-61, 210-230,
 // 414-416 in backward).  The shape mirrors conv_wino_kernel (conv_wino_kernel.h) with the roles turned round: what stays in
 // registers is the ACCUMULATOR dU[xi][nu][cin][cout] -- wave xi of a persistent workgroup owns row xi for one (chunk of 16 KQ
-// input channels, chunk of 16 NT output channels) pair, 16 KQ NT registers -- and both MFMA operands come from LDS:
-//   A   V  = B^T d B     from the raw 18 x 6 input halo (buffer_load ... lds), thread = (tile, cin quad)      [as forward]
-//   A'  dM = A dY A^T    from the raw 16 x 4 block of the output gradient, thread = (tile, cout quad); the two negative rows
-//       of A are stored positive (signs applied once, by the closing transform); the same threads sum dM[1][1] = the tile's
-//       four pixels = the bias gradient                                                              -- barrier --
-//   B   wave xi: dU[xi][nu] += V[xi][nu]^T dM[xi][nu] over the 16 tiles: rows = cin, columns = cout, K = tiles (k-slot q owns
-//       tiles 4 q .. 4 q + 3); operands are [tile][channel] arrays with a tile pitch of 4 mod 8 floats, read two k-steps at a
-//       time (ds_read2_b32, conflict-free); 4 nu x 4 k-steps x KQ NT MFMAs                           -- barrier --
-// One workgroup per CU (140 KB of LDS, 4 waves).  Every workgroup leaves its dU in a slab; wino_slab_sum_kernel adds the slabs
-// of each (cin chunk, cout chunk) pair in a fixed order (bitwise reproducible) and wino_wgrad_finish_kernel applies G^T . G
-// and the signs, and writes / accumulates dW and db.  DL4DS_NO_WINOGRAD=1 or DL4DS_NO_WINOGRAD_WGRAD=1: direct kernels.
+// input channels, chunk of 16 NT output channels) pair, 16 KQ NT registers.  The kernel (conv_wino_wgrad2_kernel, below) forms both
+// MFMA operands -- V = B^T d B from the raw 18 x 6 input halo, dM = A dY A^T from the raw 16 x 4 block of the output gradient, the
+// two negative rows of A stored positive -- in the registers of the MFMA waves; the raw blocks are all LDS holds (72 KB, two workgroups
+// per CU).  (The round-3 form that staged V and dM through LDS -- 106 KB, one workgroup per CU, two transform phases with the matrix
+// side idle -- was an experiments-only alternative since round 4 and is gone: git history, DESIGN_HISTORY.md.)
+// Every workgroup leaves its share in a slab -- the column half of G^T . G already applied, 12 planes -- wino_slab_sum_kernel adds the
+// slabs of each (cin chunk, cout chunk) pair in a fixed order (bitwise reproducible) and wino_wgrad_finish_kernel applies the row half
+// and the remaining sign, and writes / accumulates dW and db.  DL4DS_NO_WINOGRAD=1 or DL4DS_NO_WINOGRAD_WGRAD=1: direct kernels.
 #include "conv_wino_kernel.h"
 
 namespace {
@@ -24,275 +21,12 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 struct WinoWgradParams {
     TView x, dy;
-    float* slab;            // [workgroup k][pair][FR + CO]: dU in fragment order, then the bias-gradient partials
+    float* slab;            // [workgroup k][pair][FR + CO]: u[xi][b] in fragment order (12 planes), then the bias-gradient partials
     int Cin, Cout, H, W;
     int ncin, ncout;        // chunks of 16 KQ input / 16 NT output channels
     int ntg, per_xcd, tgx, tgy;
     unsigned m_tgx, m_tgy;
 };
-
-template <int KQ, int NT>
-struct WgGeom {
-    static constexpr int CK = 16 * KQ, Q4 = 4 * KQ, CO = 16 * NT, NQ = 4 * NT;
-    static constexpr int VP = CK + 4, MP = CO + 4;      // tile pitches: 4 mod 8 floats (k-slots 4 tiles apart land 16 banks apart)
-    static constexpr int HW = 18, HH = 6, HPIX = HW * HH, YPIX = 64;
-    static constexpr int RAWX = HPIX * CK, RAWY = YPIX * CO, V = 256 * VP, M = 256 * MP;      // floats
-    static constexpr size_t LDS_BYTES = (size_t)(RAWX + RAWY + V + M) * 4;
-    static constexpr int FR = 4 * (3 * KQ * NT) * 64 * 4;                 // slab floats per workgroup: 4 rows xi x 3 columns b (see the epilogue)
-    static constexpr int ST = FR + CO;                                    // slab stride
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-};
-
-template <int KQ, int NT>
-__global__ void __launch_bounds__(256, 1) conv_wino_wgrad_kernel(const WinoWgradParams wp) {
-    typedef WgGeom<KQ, NT> GM;
-    constexpr int CK = GM::CK, Q4 = GM::Q4, CO = GM::CO, NQ = GM::NQ, VP = GM::VP, MP = GM::MP;
-    constexpr int HW = GM::HW, HH = GM::HH, HPIX = GM::HPIX;
-    constexpr int OOB = (int)0xffffff00u;
-    constexpr int RSRC3 = 0x00020000;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const rawx = lds;
-    float* const rawy = lds + GM::RAWX;
-    float* const Vb = rawy + GM::RAWY;
-    float* const Mb = Vb + GM::V;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, SX = gridDim.x >> 3;
-    const int npair = wp.ncin * wp.ncout, nsub = SX / npair;
-    const int pc = slot % npair, sub = slot / npair;
-    if (sub >= nsub) return;
-    const int cin0 = (pc / wp.ncout) * CK, n0 = (pc % wp.ncout) * CO;
-    const int tg_lo = xcd * wp.per_xcd, tg_hi = min(wp.ntg, tg_lo + wp.per_xcd);
-    int tg = tg_lo + sub;
-    float* const myslab = wp.slab + ((size_t)(xcd * nsub + sub) * npair + pc) * GM::ST;
-
-    // ---- staging of the input halo: thread = (channel quad, pixel p0 + PPASS u), straight into LDS
-    constexpr int PPASS = 256 / Q4, SIT = (HPIX + PPASS - 1) / PPASS;
-    const int squad = tid % Q4, sp0 = tid / Q4;
-    const bool st_active = sp0 < PPASS;
-    size_t isy, isx;
-    wino::view_strides(wp.x, isy, isx);
-    const int cq = cin0 + 4 * squad;
-    const bool q_ok = st_active && cq < wp.Cin;
-    const size_t in_c = q_ok ? view_chan_off(wp.x, cq) : 0;
-    int soff[SIT];
-#pragma unroll
-    for (int u = 0; u < SIT; ++u) {
-        const int hp = sp0 + PPASS * u;
-        const int hy = hp / HW, hx = hp - hy * HW;
-        soff[u] = (q_ok && hp < HPIX) ? (int)((hy * isy + hx * isx + in_c) * 4) : OOB;
-    }
-    const bool st_last = st_active && sp0 + PPASS * (SIT - 1) < HPIX;
-    // ---- staging of the output gradient: element e = tid + 256 u = (pixel e / NQ of the 16 x 4 block, cout quad e % NQ)
-    constexpr int YIT = NQ / 4;
-    size_t ysy, ysx;
-    wino::view_strides(wp.dy, ysy, ysx);
-    const int nq = min(NQ, max(0, (wp.Cout - n0) >> 2));
-    int yoff[YIT];
-#pragma unroll
-    for (int u = 0; u < YIT; ++u) {
-        const int e = tid + 256 * u;
-        const int pix = e / NQ, quad = e - pix * NQ;
-        yoff[u] = quad < nq ? (int)(((pix >> 4) * ysy + (pix & 15) * ysx + view_chan_off(wp.dy, n0 + 4 * quad)) * 4) : OOB;
-    }
-    struct Item { int n, y0, x0; };
-    auto decode = [&](int t) {
-        const int q = fast_div(t, wp.m_tgx);
-        const int bx = t - q * wp.tgx;
-        const int n = fast_div(q, wp.m_tgy);
-        const int by = q - n * wp.tgy;
-        Item it;
-        it.n = n; it.y0 = by * 4; it.x0 = bx * 16;
-        return it;
-    };
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int st_wave = __builtin_amdgcn_readfirstlane(wave) * 256;            // floats
-    auto stage_issue = [&](const Item& it) __attribute__((always_inline)) {
-        const int ylo = max(0, 1 - it.y0), yhi = min(HH, wp.H + 1 - it.y0);
-        const int xlo = max(0, 1 - it.x0), xhi = min(HW, wp.W + 1 - it.x0);
-        int so[SIT], yo[YIT];
-#pragma unroll
-        for (int u = 0; u < SIT; ++u) so[u] = soff[u];
-#pragma unroll
-        for (int u = 0; u < YIT; ++u) yo[u] = yoff[u];
-        if (ylo | xlo | (yhi - HH) | (xhi - HW)) {                  // border tile groups (the empty asm keeps it a branch)
-            asm volatile("" ::: "memory");
-            const int ymax = wp.H - it.y0, xmax = wp.W - it.x0;
-#pragma unroll
-            for (int u = 0; u < SIT; ++u) {
-                const int hp = sp0 + PPASS * u;
-                const int hy = hp / HW, hx = hp - hy * HW;
-                so[u] = (hy >= ylo && hy < yhi && hx >= xlo && hx < xhi) ? soff[u] : OOB;
-            }
-#pragma unroll
-            for (int u = 0; u < YIT; ++u) {
-                const int pix = (tid + 256 * u) / NQ;
-                yo[u] = ((pix >> 4) < ymax && (pix & 15) < xmax) ? yoff[u] : OOB;
-            }
-        }
-        const long org = (long)((size_t)it.n * wp.x.nstride) + (long)(it.y0 - 1) * (long)isy + (long)(it.x0 - 1) * (long)isx;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(wp.x.p)) + org * 4, 0, 0x7fffff00, RSRC3);
-        const size_t yorg = (size_t)it.n * wp.dy.nstride + it.y0 * ysy + it.x0 * ysx;
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(wp.dy.p)) + yorg * 4, 0, 0x7fffff00, RSRC3);
-#if defined(__HIP_DEVICE_COMPILE__)                                   // (the host pass has no LDS address space to cast to)
-#pragma unroll
-        for (int u = 0; u < SIT; ++u)
-            if (u + 1 < SIT ? st_active : st_last)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(rawx + st_wave + u * (PPASS * Q4 * 4)), 16, so[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < YIT; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(rawy + st_wave + u * 1024), 16, yo[u], 0, 0, 0);
-#else
-        (void)rs; (void)ry; (void)st_wave; (void)st_last; (void)so; (void)yo;
-#endif
-    };
-    auto stage_landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-    // ---- phase A: thread = (tile, cin quad); phase A': thread = (tile, cout quad)
-    const bool a_on = tid < 16 * Q4;
-    const int a_t = tid / Q4, a_q = tid - a_t * Q4;
-    const int a_rd = (((a_t >> 3) * 2) * HW + (a_t & 7) * 2) * CK + 4 * a_q;
-    const int a_wr = a_t * VP + 4 * a_q;
-    const bool m_on = tid < 16 * NQ;
-    const int m_t = tid / NQ, m_q = tid - m_t * NQ;
-    const int m_rd = (((m_t >> 3) * 2) * 16 + (m_t & 7) * 2) * CO + 4 * m_q;
-    const int m_wr = m_t * MP + 4 * m_q;
-
-    f32x4 acc[4][KQ][NT];
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-        for (int i = 0; i < KQ; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[nu][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 dbacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const float* const va = Vb + ((wave * 4) * 16 + 4 * lq) * VP + l15;
-    const float* const mb = Mb + ((wave * 4) * 16 + 4 * lq) * MP + l15;
-    if (tg < tg_hi) {
-        Item cur = decode(tg);
-        stage_issue(cur);
-        stage_landed();
-        __syncthreads();
-        for (;;) {
-            // ---- A: V = B^T d B
-            if (a_on) {
-                const float* rp = rawx + a_rd;
-                float* vp = Vb + a_wr;
-                auto emit = [&](int xi, const f32x4 (&T)[4]) __attribute__((always_inline)) {
-                    float* dst = vp + (xi * 4 * 16) * VP;
-                    *reinterpret_cast<f32x4*>(dst) = sub4(T[0], T[2]);
-                    *reinterpret_cast<f32x4*>(dst + 16 * VP) = T[1] + T[2];
-                    *reinterpret_cast<f32x4*>(dst + 32 * VP) = sub4(T[2], T[1]);
-                    *reinterpret_cast<f32x4*>(dst + 48 * VP) = sub4(T[1], T[3]);
-                };
-                f32x4 d1[4], d2[4], T[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d1[c] = *reinterpret_cast<const f32x4*>(rp + (1 * HW + c) * CK);
-                    d2[c] = *reinterpret_cast<const f32x4*>(rp + (2 * HW + c) * CK);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) T[c] = d1[c] + d2[c];
-                emit(1, T);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) T[c] = sub4(d2[c], d1[c]);
-                emit(2, T);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) T[c] = sub4(*reinterpret_cast<const f32x4*>(rp + c * CK), d2[c]);
-                emit(0, T);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) T[c] = sub4(d1[c], *reinterpret_cast<const f32x4*>(rp + (3 * HW + c) * CK));
-                emit(3, T);
-            }
-            // ---- A': dM' = |A| dY |A|^T with rows (y0, y0 + y1, y0 - y1, y1): the signs of row / column 3 are applied at the end
-            if (m_on) {
-                const float* rp = rawy + m_rd;
-                const f32x4 y00 = *reinterpret_cast<const f32x4*>(rp), y01 = *reinterpret_cast<const f32x4*>(rp + CO);
-                const f32x4 y10 = *reinterpret_cast<const f32x4*>(rp + 16 * CO), y11 = *reinterpret_cast<const f32x4*>(rp + 17 * CO);
-                const f32x4 r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {sub4(y00, y10), sub4(y01, y11)}, {y10, y11}};
-                float* mp = Mb + m_wr;
-#pragma unroll
-                for (int xi = 0; xi < 4; ++xi) {
-                    float* dst = mp + (xi * 4 * 16) * MP;
-                    const f32x4 s = r[xi][0] + r[xi][1];
-                    *reinterpret_cast<f32x4*>(dst) = r[xi][0];
-                    *reinterpret_cast<f32x4*>(dst + 16 * MP) = s;
-                    *reinterpret_cast<f32x4*>(dst + 32 * MP) = sub4(r[xi][0], r[xi][1]);
-                    *reinterpret_cast<f32x4*>(dst + 48 * MP) = r[xi][1];
-                    if (xi == 1) dbacc += s;
-                }
-            }
-            __syncthreads();                                        // V, dM complete; raw blocks consumed
-            const int ntg = tg + nsub;
-            const bool has_next = ntg < tg_hi;
-            Item nxt = cur;
-            if (has_next) {
-                nxt = decode(ntg);
-                stage_issue(nxt);
-            }
-            // ---- B: dU[xi][nu][cin][cout] += sum over tiles V[xi][nu][tile][cin] dM[xi][nu][tile][cout]
-            {
-                // (operands of nu + 1 are requested before the MFMAs of nu: one wave per SIMD, nobody else hides the LDS latency)
-                float av[2][KQ][4], bv[2][NT][4];
-                auto fetch = [&](int nu, int sl) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int i = 0; i < KQ; ++i)
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) av[sl][i][s4] = va[nu * 16 * VP + s4 * VP + 16 * i];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) bv[sl][j][s4] = mb[nu * 16 * MP + s4 * MP + 16 * j];
-                };
-                fetch(0, 0);
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) {
-                    if (nu < 3) fetch(nu + 1, (nu + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                        for (int i = 0; i < KQ; ++i)
-#pragma unroll
-                            for (int j = 0; j < NT; ++j)
-                                acc[nu][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nu & 1][i][s4], bv[nu & 1][j][s4], acc[nu][i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            stage_landed();
-            __syncthreads();                                        // V, dM consumed; next raw blocks staged
-            if (!has_next) break;
-            cur = nxt;
-            tg = ntg;
-        }
-    }
-    // ---- the workgroup's share of dU: lane (column l15 = cout, rows 4 lq + r = cin) -> [wave][b][cin block][cout block][lane][4].
-    // The COLUMN half of G^T . G is applied here, in the wave's registers (round 6): 12 planes leave instead of 16 -- a quarter of the slab bytes
-    // (512 slabs of 147 KB per 48 x 48 weight gradient, written here and read by the first slab sum).  u[b] = sum over nu of G[nu][b] s(nu) dU[xi][nu]
-    // with s(3) = -1 (the rows of A stored positive, see the header); the row half and row 3's sign are the closing kernel's.
-#pragma unroll
-    for (int i = 0; i < KQ; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const f32x4 h = .5f * (acc[1][i][j] + acc[2][i][j]);
-            const f32x4 u[3] = {acc[0][i][j] + h, .5f * (acc[1][i][j] - acc[2][i][j]), h - acc[3][i][j]};
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
-                *reinterpret_cast<f32x4*>(myslab + ((size_t)((wave * 3 + b) * KQ + i) * NT + j) * 256 + lane * 4) = u[b];
-        }
-    // ---- bias gradient: the (tile, cout quad) threads' sums, added over the 16 tiles
-    if (m_on) *reinterpret_cast<f32x4*>(lds + tid * 4) = dbacc;
-    __syncthreads();
-    if (tid < CO) {
-        float sdb = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) sdb += lds[(t * NQ + (tid >> 2)) * 4 + (tid & 3)];
-        myslab[GM::FR + tid] = sdb;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Second form (round 4): BOTH transforms in the registers of the MFMA waves, nothing but the two raw blocks in LDS.
@@ -581,6 +315,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_wgrad2_kernel(const WinoWgra
     // The COLUMN half of G^T . G is applied here, in the wave's registers (round 6): 12 planes leave instead of 16 -- a quarter of the slab bytes
     // (512 slabs of 147 KB per 48 x 48 weight gradient, written here and read by the first slab sum).  u[b] = sum over nu of G[nu][b] s(nu) dU[xi][nu]
     // with s(3) = -1 (the rows of A stored positive, see the header); the row half and row 3's sign are the closing kernel's.
+    // (Measured and dropped: the row half here too -- the waves exchanging u[b] through LDS, one b at a time, 9 planes of dW[a][b] leaving:
+    //  wino_wgrad_finish 0.175 -> 0.162 ms per cfg2 step, this kernel's launches + 0.010-0.015 ms for their three barrier pairs: nothing.)
 #pragma unroll
     for (int i = 0; i < KQ; ++i)
 #pragma unroll
@@ -718,11 +454,6 @@ float* wgrad_scratch(hipStream_t s, size_t floats) {       // grow-only, one buf
     return e.buf;
 }
 
-inline bool wgrad_first_form() {
-    static const bool v = exp_env("DL4DS_WINO_WGRAD_V1") != nullptr;
-    return v;
-}
-
 template <int KQ, int NT>
 void launch_wgrad2(hipStream_t s, WinoWgradParams& wp, int SX) {
     typedef Wg2Geom<KQ, NT> GM;
@@ -732,19 +463,6 @@ void launch_wgrad2(hipStream_t s, WinoWgradParams& wp, int SX) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES));
     });
     DL4DS_LAUNCH((conv_wino_wgrad2_kernel<KQ, NT>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
-    HIP_CHECK(hipGetLastError());
-}
-
-template <int KQ, int NT>
-void launch_wgrad(hipStream_t s, WinoWgradParams& wp, int SX) {
-    if (!wgrad_first_form()) { launch_wgrad2<KQ, NT>(s, wp, SX); return; }
-    typedef WgGeom<KQ, NT> GM;
-    static std::once_flag once;
-    std::call_once(once, [&]() {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<KQ, NT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES));
-    });
-    DL4DS_LAUNCH((conv_wino_wgrad_kernel<KQ, NT>), dim3(8 * SX), dim3(256), GM::LDS_BYTES, s, wp);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -760,7 +478,6 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     //  channels on either side do not pay: 48 -> 32 0.90 vs 0.88, 32 -> 32 0.19 vs 0.17)
     // (first form, B = 64: chunks of 32 channels on either side did not pay -- 48 -> 32 at 256^2 0.90 vs 0.88 ms direct, 32 -> 32 0.19
     //  vs 0.17; second form: 0.58 vs 0.84 and 0.127 vs 0.152, so every layer with >= 24 channels on both sides takes it)
-    if (!force && wgrad_first_form() && (x.C <= 32 || dy.C <= 32)) return false;
     auto span = [](const TView& v) { const size_t r = std::max(v.d2s, 1); return (size_t)8 * v.W * r * r * v.ld * 4; };
     if (span(x) >= (1ull << 31) || span(dy) >= (1ull << 31)) return false;
     const int KQ = (cdiv(x.C, 32) * 32 < cdiv(x.C, 48) * 48) ? 2 : 3;
@@ -779,7 +496,7 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     wp.ntg = (int)ntg;
     wp.per_xcd = cdiv(wp.ntg, 8);
     const int npair = wp.ncin * wp.ncout;
-    const int SXmax = std::max((wgrad_first_form() ? 1 : 2) * wgrad_cu_count() / 8, 1);          // second form: two workgroups per CU
+    const int SXmax = std::max(2 * wgrad_cu_count() / 8, 1);          // two workgroups per CU
     if (npair > SXmax) return false;
     int SX = (SXmax / npair) * npair;
     if (force && atoi(force) > 0) SX = std::min(SX, atoi(force) * npair);
@@ -803,9 +520,9 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
         ProfScope ps(s, "conv_wino_wgrad<" + std::to_string(KQ) + "," + std::to_string(NT) + ">", issued,
                      4.0 * (px * (x.C + dy.C) + 9.0 * x.C * dy.C), 2.0 * px * 9.0 * x.C * dy.C);
         if (KQ == 2) {
-            if (NT == 2) launch_wgrad<2, 2>(s, wp, SX); else launch_wgrad<2, 3>(s, wp, SX);
+            if (NT == 2) launch_wgrad2<2, 2>(s, wp, SX); else launch_wgrad2<2, 3>(s, wp, SX);
         } else {
-            if (NT == 2) launch_wgrad<3, 2>(s, wp, SX); else launch_wgrad<3, 3>(s, wp, SX);
+            if (NT == 2) launch_wgrad2<3, 2>(s, wp, SX); else launch_wgrad2<3, 3>(s, wp, SX);
         }
     }
     ProfScope ps(s, "wino_wgrad_finish", 0.0, 4.0 * (double)per_k * (nslabs + 2));
@@ -824,7 +541,7 @@ bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw
     DL4DS_LAUNCH(wino_slab_sum_kernel, dim3(std::min(cdiv(n4, 256), 2048), 1), dim3(256), 0, s, part, sum, n4, ng, ng);
     HIP_CHECK(hipGetLastError());
     DL4DS_LAUNCH(wino_wgrad_finish_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, sum, dw, db, x.C, dy.C, KQ, NT,
-                       wp.ncin, wp.ncout, accumulate, accumulate_db, 1, per_k, wgrad_first_form() ? 0 : 1);
+                       wp.ncin, wp.ncout, accumulate, accumulate_db, 1, per_k, 1);
     HIP_CHECK(hipGetLastError());
     return true;
 }
