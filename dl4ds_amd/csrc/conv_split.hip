@@ -79,10 +79,7 @@ __host__ __device__ inline int split_tile(int w) { return w < NMW ? w >> 2 : w -
 
 // filter -> per-lane fragments.  One thread per (chunk, wave (matrix and helper), i, ky, form, lane): eight bf16 values = part P(form, kq) of
 // w[ky][kx][cin0 + 16 c + 8 (kq & 1) + j][48 chunk + 16 ct + lane % 16], j = 0..7, kq = lane / 16, (kx, c) = the wave's i-th unit.
-__global__ void __launch_bounds__(256) split_filter_kernel(const float* __restrict__ w, u32x4* __restrict__ frag, int CinTot, int cin0,
-                                                           int Cout, int nchunk, int total) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+__device__ __forceinline__ u32x4 split_filter_entry(const float* __restrict__ w, int CinTot, int cin0, int Cout, int e) {
     int i = e;
     const int lane = i & 63; i >>= 6;
     const int form = i % 2; i /= 2;
@@ -107,7 +104,30 @@ __global__ void __launch_bounds__(256) split_filter_kernel(const float* __restri
     }
     u32x4 o;
     __builtin_memcpy(&o, &v, 16);
-    frag[e] = o;
+    return o;
+}
+
+__global__ void __launch_bounds__(256) split_filter_kernel(const float* __restrict__ w, u32x4* __restrict__ frag, int CinTot, int cin0,
+                                                           int Cout, int nchunk, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    (void)nchunk;
+    frag[e] = split_filter_entry(w, CinTot, cin0, Cout, e);
+}
+
+// The fragments of ALL the layers a graph pass will run on this kernel, in one launch (the Winograd layers' scheme, conv_wino.hip: "transformed
+// filters of a GRAPH's layers"): 8 launches of split_filter_kernel per cfg2 step become 2.  Job = (filter, its passes of 48 input channels).
+struct SplitFilterJob { const float* w; u32x4* frag; int Cin, Cout, per_pass, total, first; };      // total: entries of all passes; first: the job's first block
+constexpr int SPLIT_JOBS_MAX = 24;
+struct SplitFilterJobs { SplitFilterJob j[SPLIT_JOBS_MAX]; int n, total; };                        // total: blocks
+__global__ void __launch_bounds__(256) split_filter_batched_kernel(const SplitFilterJobs jobs) {
+    int k = 0;                                                       // block -> job: wave-uniform (scalar loads from the kernel arguments)
+#pragma unroll 1
+    while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].first) ++k;
+    const int e_all = ((int)blockIdx.x - jobs.j[k].first) * 256 + (int)threadIdx.x;
+    if (e_all >= jobs.j[k].total) return;
+    const int per_pass = jobs.j[k].per_pass, pass = e_all / per_pass;
+    jobs.j[k].frag[e_all] = split_filter_entry(jobs.j[k].w, jobs.j[k].Cin, pass * 48, jobs.j[k].Cout, e_all - pass * per_pass);
 }
 
 // x = h + m + l exactly to 2^-24 |x|: h, m the upper halves of x and of the (exact) residual, l the residual's residual -- truncating
@@ -502,7 +522,65 @@ float* frag_scratch(hipStream_t s, size_t floats) {
     return e.buf;
 }
 
+// Inside a graph pass a layer's fragments have a buffer of their own and are rebuilt by ONE launch per pass for all registered layers
+// (split_filters_refresh, called where the Winograd filters are refreshed); freshness never outlives a forward pass.  Outside a pass (the
+// op-level API) nothing is registered or trusted: the stream's scratch and one launch per call.
+struct SplitFilterEntry { const float* w; int Cin, Cout, per_pass, passes, kind; hipStream_t stream; u32x4* frag; bool fresh; };
+std::vector<SplitFilterEntry>& split_entries() { static std::vector<SplitFilterEntry> v; return v; }
+constexpr size_t SPLIT_ENTRIES_MAX = 512;
+
+u32x4* split_filter_lookup(hipStream_t s, const float* w, int Cin, int Cout, int per_pass, int passes, bool& need) {
+    need = true;
+    int kind = 0;
+    if (!wino_pass_active(kind)) return reinterpret_cast<u32x4*>(frag_scratch(s, (size_t)per_pass * passes * 4));
+    auto& es = split_entries();
+    for (auto& e : es)
+        if (e.w == w && e.Cin == Cin && e.Cout == Cout && e.per_pass == per_pass && e.passes == passes && e.stream == s) {
+            need = !e.fresh;
+            e.fresh = true;                      // (the caller builds them now if they were not)
+            return e.frag;
+        }
+    if (es.size() >= SPLIT_ENTRIES_MAX) return reinterpret_cast<u32x4*>(frag_scratch(s, (size_t)per_pass * passes * 4));
+    SplitFilterEntry e{w, Cin, Cout, per_pass, passes, kind, s, nullptr, true};
+    HIP_CHECK(hipMalloc((void**)&e.frag, (size_t)per_pass * passes * sizeof(u32x4)));
+    es.push_back(e);
+    return e.frag;
+}
+
 }  // namespace
+
+void split_filters_invalidate(const float* lo, const float* hi) {
+    for (auto& e : split_entries())
+        if (e.w >= lo && e.w < hi) e.fresh = false;
+}
+
+void split_filters_release(const float* lo, const float* hi) {
+    auto& es = split_entries();
+    for (size_t i = 0; i < es.size();) {
+        if (es[i].w >= lo && es[i].w < hi) { (void)hipFree(es[i].frag); es[i] = es.back(); es.pop_back(); }
+        else ++i;
+    }
+}
+
+void split_filters_refresh(hipStream_t s, const float* lo, const float* hi, int kind) {
+    SplitFilterJobs jobs;
+    jobs.n = 0; jobs.total = 0;
+    auto flush = [&]() {
+        if (!jobs.n) return;
+        ProfScope ps(s, "split_filters", 0.0, 16.0 * jobs.total * 256);
+        DL4DS_LAUNCH(split_filter_batched_kernel, dim3(jobs.total), dim3(256), 0, s, jobs);
+        HIP_CHECK(hipGetLastError());
+        jobs.n = 0; jobs.total = 0;
+    };
+    for (auto& e : split_entries()) {
+        if (e.fresh || e.kind != kind || e.stream != s || e.w < lo || e.w >= hi) continue;
+        if (jobs.n == SPLIT_JOBS_MAX) flush();
+        jobs.j[jobs.n++] = SplitFilterJob{e.w, e.frag, e.Cin, e.Cout, e.per_pass, e.per_pass * e.passes, jobs.total};
+        jobs.total += cdiv(e.per_pass * e.passes, 256);
+        e.fresh = true;
+    }
+    flush();
+}
 
 bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const TView& out, const ConvEpilogue& ep) {
     // Measured (round 6, profiles/conv_split_r06.txt): 10 % faster than the Winograd F(2x2,3x3) kernels on the fp32 pipe for the layers with
@@ -549,7 +627,8 @@ bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const 
     ProfScope ps(s, std::string("conv_split<3,3>") + (test_env("DL4DS_SPLIT_TAG_FORMS") ? std::string("f") + std::to_string((ep.accumulate ? 4 : 0) | (ep.add.p ? 2 : 0) | (ep.mask.p ? 1 : 0)) + "c" + std::to_string(in.C) + "_" + std::to_string(out.C) : std::string()), fl,
                  4.0 * (px * (in.C + out.C * (1 + (ep.add.p ? 1 : 0) + (ep.mask.p ? 1 : 0) + (ep.accumulate ? 1 : 0))) + 9.0 * in.C * out.C), fl);
     const int per_pass = p.nchunk * (NMW + NHW) * 12 * 64;                  // uint4 entries
-    u32x4* frag = reinterpret_cast<u32x4*>(frag_scratch(s, (size_t)per_pass * passes * 4));
+    bool need_frag = true;
+    u32x4* frag = split_filter_lookup(s, w, in.C, out.C, per_pass, passes, need_frag);
     int grid = std::min((int)std::min<long>(items, cu_count()), cu_count()) * 1;
     grid = std::max(1, grid / p.nchunk) * p.nchunk;
     if (grid > cu_count()) grid = (cu_count() / p.nchunk) * p.nchunk;
@@ -565,9 +644,11 @@ bool conv2d_split_forward(hipStream_t s, const TView& in, const float* w, const 
     for (int ps_ = 0; ps_ < passes; ++ps_) {
         p.cin0 = ps_ * 48;
         p.frag = frag + (size_t)per_pass * ps_;
-        DL4DS_LAUNCH(split_filter_kernel, dim3(cdiv(per_pass, 256)), dim3(256), 0, s, w, const_cast<u32x4*>(p.frag), in.C, p.cin0, out.C, p.nchunk,
-                     per_pass);
-        HIP_CHECK(hipGetLastError());
+        if (need_frag) {
+            DL4DS_LAUNCH(split_filter_kernel, dim3(cdiv(per_pass, 256)), dim3(256), 0, s, w, const_cast<u32x4*>(p.frag), in.C, p.cin0, out.C, p.nchunk,
+                         per_pass);
+            HIP_CHECK(hipGetLastError());
+        }
         p.final_pass = ps_ == passes - 1;
         p.old = (ps_ > 0) ? 1 : (ep.accumulate ? 2 : 0);
         if (!p.final_pass) { p.add.p = nullptr; p.mask.p = nullptr; } else { p.add = ep.add; p.mask = ep.mask; }

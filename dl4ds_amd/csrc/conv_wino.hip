@@ -204,12 +204,16 @@ float* wino_filter_lookup(hipStream_t s, const float* w, int Cin, int Cout, int 
 WinoPassGuard::WinoPassGuard(int kind) : prev_kind(g_wino_pass_kind) { ++g_wino_pass_depth; g_wino_pass_kind = kind; }
 WinoPassGuard::~WinoPassGuard() { --g_wino_pass_depth; g_wino_pass_kind = prev_kind; }
 
+bool wino_pass_active(int& kind) { kind = g_wino_pass_kind; return g_wino_pass_depth > 0; }
+
 void wino_filters_invalidate(const float* lo, const float* hi) {
     for (auto& e : wino_entries())
         if (e.w >= lo && e.w < hi) e.fresh = false;
+    split_filters_invalidate(lo, hi);                      // (conv_split.hip: the six-term kernel's filter fragments follow the same life cycle)
 }
 
 void wino_filters_release(const float* lo, const float* hi) {
+    split_filters_release(lo, hi);
     auto& es = wino_entries();
     for (size_t i = 0; i < es.size();) {
         if (es[i].w >= lo && es[i].w < hi) { (void)hipFree(es[i].u); es[i] = es.back(); es.pop_back(); }
@@ -235,6 +239,7 @@ void wino_filters_refresh(hipStream_t s, const float* lo, const float* hi, int k
         e.fresh = true;
     }
     flush();
+    split_filters_refresh(s, lo, hi, kind);
 }
 
 namespace {

@@ -61,6 +61,11 @@ struct WinoPassGuard { int prev_kind; explicit WinoPassGuard(int kind); ~WinoPas
 void wino_filters_invalidate(const float* lo, const float* hi);
 void wino_filters_refresh(hipStream_t s, const float* lo, const float* hi, int kind);
 void wino_filters_release(const float* lo, const float* hi);
+bool wino_pass_active(int& kind);                              // inside a graph pass? (kind: 0 forward, 1 backward)
+// conv_split.hip: the same three for the six-term kernel's filter fragments (called by the wino_filters_* functions)
+void split_filters_invalidate(const float* lo, const float* hi);
+void split_filters_refresh(hipStream_t s, const float* lo, const float* hi, int kind);
+void split_filters_release(const float* lo, const float* hi);
 // ... and of their weight gradient (conv_wino_wgrad.hip): dw [3][3][Cin][Cout], db [Cout] or null
 bool conv2d_wino_wgrad(hipStream_t s, const TView& x, const TView& dy, float* dw, int accumulate, float* db, int accumulate_db);
 bool conv2d_stream_forward(hipStream_t s, const TView& in, const float* w, int KS, const TView& out,
