@@ -576,3 +576,26 @@ def test_cfg2_default_dispatch_and_fp32_pipe_follow_one_loss_trajectory(monkeypa
     a, b = np.asarray(curves['default']), np.asarray(curves['fp32 pipe'])
     assert a[-1] < 0.7 * a[0], a
     assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), (a, b)
+
+def test_split_filter_fragments_follow_the_weights():
+    """conv_split_kernel's filter fragments (the weights as bf16 triples in MFMA fragment order) are built by one launch per pass for all the
+    layers of a graph ('split_filters', from the second pass on; conv_split.hip) and must never outlive the weights they were made from:
+    after set_weights a model gives the bits a fresh model with those weights gives.  cfg2 at B = 8: the eight single-pass <= 48-channel
+    layers on the six-term kernel (16-row strips), 4 of them in the forward pass."""
+    from tests.parity import kernel_tags
+    _no_force_overrides()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((8, 128, 128, 1)).astype(np.float32)
+    a = _cfg2(seed=21)
+    y0, t0 = kernel_tags(lambda: a([x]))
+    assert t0.get('conv_split<3,3>') == 4 and 'split_filters' not in t0, sorted(t0)          # first pass: every layer builds its own
+    y1, t1 = kernel_tags(lambda: a([x]))
+    assert t1.get('conv_split<3,3>') == 4 and t1.get('split_filters') == 1, sorted(t1)        # then one launch for all of them
+    assert np.array_equal(y0, y1)
+    w2 = {k: (v * np.float32(0.75) + np.float32(0.01)).astype(np.float32) for k, v in a.get_weights().items()}
+    a.set_weights(w2)
+    y2 = a([x])
+    b = _cfg2(seed=33)
+    b.set_weights(w2)
+    assert np.array_equal(y2, b([x]))
+    assert not np.array_equal(y2, y1)
