@@ -1,3 +1,4 @@
+# GPU box: cfg2 at per-GPU batch 8 / 16 / 64 with conv_split strips of 8 / 16 / 32 rows (DL4DS_SPLIT_R, a test hook) -> gpurun_out/rs/ (round 6: 16 rows only where 32 leave CUs idle)
 mkdir -p gpurun_out/rs
 export DL4DS_TEST_HOOKS=1
 for B in 8 16 64; do for R in 8 16 32; do
