@@ -218,3 +218,37 @@ def test_season_channels():
     for k, i in enumerate(gen.indices[:3]):
         want = D.SEASONS.index(D.get_season(stamps[i]))
         assert aux[k, 0, 0, 1 + want] == 1 and aux[k, ..., 1:].sum() == 16 * 24
+
+
+@pytest.mark.parametrize('mode,tmode', [('bilinear', 'bilinear'), ('bicubic', 'bicubic'), ('nearest', 'nearest')])
+@pytest.mark.parametrize('src,dst', [((8, 12), (16, 24)), ((8, 12), (20, 30)), ((9, 7), (31, 17)), ((16, 24), (8, 12)), ((15, 10), (6, 7)),
+                                     ((5, 5), (5, 9))])
+def test_resize_restatement_against_an_independent_implementation(mode, tmode, src, dst):
+    """cv2 itself is not installable here (oracle/dataprep.py is pinned by OpenCV's published formulas above).  A second, independent
+    implementation of the same three samplers IS in the image: torch.nn.functional.interpolate with align_corners=False and no
+    anti-aliasing uses OpenCV's half-pixel centres (dx + 0.5) * scale - 0.5, index clamping at the borders (BORDER_REPLICATE), A = -0.75
+    for the cubic and floor(dx * scale) for nearest -- written by other people from the same definitions.  Up- and down-scaling, integer
+    and non-integer factors, one axis growing while the other shrinks (utils.py:369-381 calls cv2.resize with exactly these modes)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(src[0] * 100 + dst[1])
+    a = rng.standard_normal(src + (3,))
+    got = O.cv2_resize(a, (dst[1], dst[0]), mode)                       # (size_x, size_y)
+    t = torch.from_numpy(a).permute(2, 0, 1)[None]
+    kw = {} if tmode == 'nearest' else {'align_corners': False}
+    ref = F.interpolate(t, size=dst, mode=tmode, **kw)[0].permute(1, 2, 0).numpy()
+    assert got.shape == ref.shape == dst + (3,)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_inter_area_integer_shrink_against_average_pooling():
+    """INTER_AREA at integer ratios = non-overlapping block means = torch's avg_pool2d (the LR fields of every configuration in
+    BASELINE.json are made this way: dataloader.py:60-75 with the default interpolation)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    for (h, w), (sy, sx) in (((32, 48), (4, 4)), ((30, 20), (5, 2)), ((16, 16), (8, 8))):
+        a = rng.standard_normal((h, w, 2))
+        got = O.cv2_resize(a, (w // sx, h // sy), 'inter_area')
+        ref = F.avg_pool2d(torch.from_numpy(a).permute(2, 0, 1)[None], (sy, sx))[0].permute(1, 2, 0).numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13)
